@@ -1,0 +1,328 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE.
+
+Runs only in the build container (it needs /root/reference); the GPU box never
+sees the reference -- it gets the small ``.npz`` fixtures written here, which
+hold inputs' recipe (seeds) and the reference's outputs.  Nothing from the
+reference's source text is stored.
+
+How the reference is made importable:
+  shim 1  ``GPT2LMHeadModel.from_pretrained`` needs the HF hub -> patched to
+          build ``GPT2LMHeadModel(GPT2Config.from_json_file(config/model_config.json))``
+          in eval mode (what from_pretrained returns), eager attention.
+  shim 2  ``./vocab/token_id2emb_dict.pkl`` is not in the repo -> a synthetic
+          ``{id: list[2048]}`` is pickled into a scratch cwd.
+  patch   S != 5: the hard-coded 5-step Gaussian priors
+          (src/model.py:116-120) are replaced attribute-wise by S-step ones.
+
+Weights/batches come from ``mmtg_amd.synth`` (numpy default_rng, seeds recorded
+in each fixture) so every consumer regenerates them bit-identically.
+
+Usage:  python tools/make_golden.py [--out tests/golden] [--skip-full]
+"""
+import argparse
+import json
+import os
+import pickle
+import sys
+import tempfile
+
+os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+os.environ.setdefault("HF_HUB_OFFLINE", "1")
+sys.dont_write_bytecode = True
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+REF_SRC = "/root/reference/src"
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+from scipy import stats  # noqa: E402
+
+from mmtg_amd import synth  # noqa: E402
+from mmtg_amd.configs import make_model_cfgs, gpt2_config  # noqa: E402
+
+
+class StubTokenizer:
+    """The four special-token lookups generate.py performs (ids per
+    src/vocab/vocab.txt: [#START#]=1 [#EOS#]=2 [UNK]=100 [SEP]=102)."""
+    _ids = {"[#START#]": 1, "[#EOS#]": 2, "[UNK]": 100, "[SEP]": 102, "[PAD]": 0}
+
+    def convert_tokens_to_ids(self, tok):
+        return self._ids[tok]
+
+
+def import_reference(scratch, gpt2_cfg, table):
+    """chdir into a scratch dir holding config/ and vocab/, import the modules."""
+    os.makedirs(os.path.join(scratch, "config"), exist_ok=True)
+    os.makedirs(os.path.join(scratch, "vocab"), exist_ok=True)
+    with open(os.path.join(scratch, "config", "model_config.json"), "w") as f:
+        json.dump(gpt2_cfg, f)
+    with open(os.path.join(scratch, "vocab", "token_id2emb_dict.pkl"), "wb") as f:
+        pickle.dump({i: table[i].tolist() for i in range(table.shape[0])}, f)
+    os.chdir(scratch)
+    if REF_SRC not in sys.path:
+        sys.path.insert(0, REF_SRC)
+    import transformers
+    from transformers import GPT2Config, GPT2LMHeadModel
+
+    def _offline_from_pretrained(cls, name, *a, **k):
+        cfg = GPT2Config.from_json_file("config/model_config.json")
+        cfg._attn_implementation = "eager"
+        m = GPT2LMHeadModel(cfg)
+        m.eval()
+        return m
+
+    GPT2LMHeadModel.from_pretrained = classmethod(_offline_from_pretrained)
+    import model as ref_model
+    import loss as ref_loss
+    import generate as ref_generate
+    return ref_model, ref_loss, ref_generate
+
+
+def build_reference(ref_model, mcfg, dcfg_ref, weights, V):
+    m = ref_model.MMTG(mcfg, dcfg_ref, V, train_flag=False)
+    S = mcfg["seq_len"]
+    if S != 5:
+        for layer in (m.img_inner_atten_layer, m.text_inner_atten_layer):
+            pri = []
+            for i in range(S):
+                v = stats.norm.pdf(np.arange(0, S, 1), i, 1)
+                pri.append(torch.tensor([x / sum(v) for x in v], dtype=torch.float32))
+            layer.normal_dists = pri
+    sd = m.state_dict()
+    new = {}
+    for k, v in sd.items():
+        if k in weights:
+            assert tuple(v.shape) == weights[k].shape, (k, v.shape, weights[k].shape)
+            new[k] = torch.from_numpy(weights[k].copy())
+        else:
+            new[k] = v  # non-parameter buffers (attn.bias on old transformers)
+    missing = [k for k in weights if k not in sd]
+    assert not missing, missing
+    m.load_state_dict(new)
+    m.eval()
+    return m
+
+
+def to_torch(batch):
+    out = {}
+    for k, v in batch.items():
+        t = torch.from_numpy(np.asarray(v))
+        # MyDataset hands float64 embeddings (np.asarray of python lists); the
+        # model casts with .float() (src/model.py:371-373)
+        out[k] = t.double() if t.dtype == torch.float32 else t
+    return out
+
+
+def sample_vec(a, n=32):
+    a = np.asarray(a, np.float32).reshape(-1)
+    idx = np.unique(np.concatenate([np.arange(min(n, a.size)),
+                                    np.linspace(0, a.size - 1, n).astype(np.int64)]))
+    return idx.astype(np.int64), a[idx]
+
+
+def adamw_hf_step(params, lr, step, state, betas=(0.9, 0.999), eps=1e-6, wd=0.0):
+    """transformers.AdamW semantics (the optimizer train.py:137 builds):
+    bias-corrected step size, eps added to sqrt(v) BEFORE bias correction is
+    folded in, decoupled weight decay (0 here)."""
+    b1, b2 = betas
+    for p in params:
+        if p.grad is None:
+            continue
+        g = p.grad
+        st = state.setdefault(id(p), {"m": torch.zeros_like(p), "v": torch.zeros_like(p)})
+        st["m"].mul_(b1).add_(g, alpha=1 - b1)
+        st["v"].mul_(b2).addcmul_(g, g, value=1 - b2)
+        denom = st["v"].sqrt().add_(eps)
+        step_size = lr * (1 - b2 ** step) ** 0.5 / (1 - b1 ** step)
+        p.data.addcdiv_(st["m"], denom, value=-step_size)
+        if wd > 0:
+            p.data.add_(p.data, alpha=-lr * wd)
+
+
+def case_model(name, out_dir, S, n_layer, V, B, seed, full_logits=True,
+               with_grads=True, with_decode=True):
+    mcfg = make_model_cfgs(seq_len=S)
+    gcfg = gpt2_config(n_layer=n_layer, vocab_size=V, n_positions=256 if n_layer <= 2 else 1024,
+                       embd_pdrop=0.0, attn_pdrop=0.0, resid_pdrop=0.0)
+    table = synth.make_token_table(V, seed=seed + 1)
+    scratch = tempfile.mkdtemp(prefix="mmtg_golden_")
+    ref_model, ref_loss, ref_generate = import_reference(scratch, gcfg, table)
+    dcfg_ref = ref_model.data_config()
+    dcfg_ref.max_seq_length = 2 * S * (dcfg_ref.max_sent_length + 2)
+    weights = synth.make_weights(mcfg, gcfg, seed=seed)
+    model = build_reference(ref_model, mcfg, dcfg_ref, weights, V)
+    model.train_flag = True  # take the training branch of GPT2_Decoder.forward
+    batch_np = synth.make_batch(B, mcfg, dcfg_ref, V, seed=seed + 2)
+    batch = to_torch(batch_np)
+
+    fx = {"meta": json.dumps({
+        "S": S, "n_layer": n_layer, "V": V, "B": B, "weight_seed": seed,
+        "table_seed": seed + 1, "batch_seed": seed + 2,
+        "torch": torch.__version__, "gpt2_cfg": gcfg, "ratings": batch_np["rating"].tolist(),
+        "source": "reference src/model.py + src/loss.py executed on CPU fp32"})}
+
+    # ---- intermediates via forward hooks ---------------------------------
+    grabbed = {}
+
+    def hook(key):
+        def fn(mod, inp, out):
+            o = out[0] if isinstance(out, tuple) else out
+            grabbed[key] = o.detach().clone()
+            if isinstance(out, tuple) and key.endswith("inner"):
+                grabbed[key + "_kl"] = out[1].detach().clone()
+        return fn
+
+    hs = [model.encoder.register_forward_hook(
+              lambda m, i, o: grabbed.update(enc_topic=o[0].detach().clone(),
+                                             enc_image=o[1].detach().clone(),
+                                             enc_text=o[2].detach().clone())),
+          model.ln_layer1.register_forward_hook(hook("ln_topic")),
+          model.ln_layer2.register_forward_hook(hook("ln_image")),
+          model.ln_layer3.register_forward_hook(hook("ln_text")),
+          model.img_inner_atten_layer.register_forward_hook(hook("img_inner")),
+          model.text_inner_atten_layer.register_forward_hook(hook("text_inner")),
+          model.mm_atten_layer.register_forward_hook(hook("mm_out")),
+          model.decoder.projector_layer2.register_forward_hook(hook("proj_out")),
+          model.decoder.gpt2.transformer.ln_f.register_forward_hook(hook("ln_f"))]
+    for li, blk in enumerate(model.decoder.gpt2.transformer.h):
+        hs.append(blk.register_forward_hook(hook(f"block{li}")))
+
+    for p in model.parameters():
+        p.grad = None
+    lm_loss, kl, logits = model.forward(batch)
+    for h in hs:
+        h.remove()
+
+    tstride = 7
+    for k, v in grabbed.items():
+        a = v.numpy().astype(np.float32)
+        if a.ndim == 3 and a.shape[1] > 64:  # [B,T,D] decoder tensors: strided tokens
+            a = a[:, ::tstride]
+        fx["int_" + k] = a
+    fx["tstride"] = np.int64(tstride)
+    fx["lm_loss"] = np.float32(lm_loss.item())
+    fx["kl"] = np.float32(kl.item())
+    lg = logits.detach().numpy().astype(np.float32)
+    if full_logits:
+        fx["logits"] = lg
+    else:
+        rng = np.random.default_rng(seed + 3)
+        n = 256
+        bi = rng.integers(0, B, n)
+        ti = rng.integers(0, lg.shape[1], n)
+        vi = rng.integers(0, V, n)
+        fx["logit_idx"] = np.stack([bi, ti, vi], 1).astype(np.int64)
+        fx["logit_val"] = lg[bi, ti, vi]
+        fx["logit_top5"] = np.argsort(-lg, axis=-1)[:, :, :5].astype(np.int32)
+        fx["logit_top5_val"] = np.take_along_axis(lg, fx["logit_top5"].astype(np.int64), -1)
+        fx["logit_lse"] = torch.logsumexp(logits.detach(), -1).numpy().astype(np.float32)
+
+    # ---- MyLoss per curriculum stage (src/loss.py:45-74) ------------------
+    crit = ref_loss.MyLoss(dcfg_ref, mcfg)
+    ratings = batch["rating"]
+    for stage in (1, 2, 3):
+        fx[f"myloss_stage{stage}"] = np.float32(
+            crit(logits.detach(), batch["targets"], ratings, stage).item())
+
+    # ---- gradients + one optimizer step (train.py:188-197 semantics) ------
+    if with_grads:
+        alpha, stage, lr = 0.2, 2, 1e-3
+        loss = crit(logits, batch["targets"], ratings, stage)
+        total = loss.mean() + alpha * kl.mean()
+        total.backward()
+        fx["train_total_loss"] = np.float32(total.item())
+        named = [(k, p) for k, p in model.named_parameters()]
+        gn = torch.nn.utils.clip_grad_norm_([p for _, p in named], 1.0)
+        fx["grad_total_norm"] = np.float32(gn.item())  # pre-clip global norm
+        fx["grad_keys"] = np.array([k for k, _ in named])
+        for k, p in named:
+            g = p.grad.detach().numpy()
+            idx, val = sample_vec(g)
+            fx["gidx_" + k] = idx
+            fx["gval_" + k] = val           # values AFTER clipping (what AdamW sees)
+            fx["gnorm_" + k] = np.float32(np.linalg.norm(g.astype(np.float64)))
+        state = {}
+        adamw_hf_step([p for _, p in named], lr, 1, state)
+        for k, p in named:
+            idx, val = sample_vec(p.detach().numpy())
+            fx["pval_" + k] = val
+        fx["train_hparams"] = json.dumps({"alpha": alpha, "stage": stage, "lr": lr,
+                                          "clip": 1.0, "eps": 1e-6, "wd": 0.0})
+        # restore weights for the decode case
+        model.load_state_dict({**model.state_dict(),
+                               **{k: torch.from_numpy(weights[k].copy()) for k in weights}})
+
+    # ---- greedy decode through sample_sequence (generate.py:97-145) -------
+    if with_decode:
+        model.train_flag = False
+        rec = []
+        orig_forward = model.forward
+
+        def rec_forward(inputs):
+            out = orig_forward(inputs)
+            rec.append(out[2][0, -1, :].detach().clone().numpy())
+            return out
+
+        model.forward = rec_forward
+        keys = [k for k in batch_np if k != "rating"]
+        for length in (30, 220 if S == 5 else 2 * S * 22):
+            for row in (0, 1):
+                rec.clear()
+                start = {k: np.asarray(batch_np[k][row]) for k in keys}
+                start["targets"] = np.asarray([1])
+                ids = ref_generate.sample_sequence(
+                    model, start, length, StubTokenizer(), temperature=1.1,
+                    top_k=1, top_p=0.0, repitition_penalty=1.5, device="cpu")
+                fx[f"greedy_len{length}_row{row}"] = np.asarray(ids, np.int64)
+                fx[f"greedy_len{length}_row{row}_rawlogits"] = np.stack(rec).astype(np.float32)
+        model.forward = orig_forward
+        fx["decode_params"] = json.dumps({"temperature": 1.1, "top_k": 1, "top_p": 0.0,
+                                          "repitition_penalty": 1.5})
+
+    path = os.path.join(out_dir, name + ".npz")
+    np.savez_compressed(path, **fx)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+    return ref_generate
+
+
+def case_filtering(out_dir, ref_generate):
+    """KATs for top_k_top_p_filtering (generate.py:64-94)."""
+    rng = np.random.default_rng(7)
+    fx = {}
+    cases = [(0, 0.0), (1, 0.0), (5, 0.0), (10, 0.7), (0, 0.9), (30, 0.3), (200, 0.0)]
+    logits = rng.standard_normal((len(cases), 97)).astype(np.float32) * 3
+    logits[2, 10] = logits[2, 11]  # a tie inside the top-k boundary region
+    fx["in"] = logits.copy()
+    fx["top_k"] = np.array([c[0] for c in cases])
+    fx["top_p"] = np.array([c[1] for c in cases], np.float32)
+    outs = []
+    for i, (k, p) in enumerate(cases):
+        o = ref_generate.top_k_top_p_filtering(torch.from_numpy(logits[i].copy()), top_k=k, top_p=p)
+        outs.append(o.numpy())
+    fx["out"] = np.stack(outs)
+    path = os.path.join(out_dir, "filtering.npz")
+    np.savez_compressed(path, **fx)
+    print("wrote", path)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
+    ap.add_argument("--skip-full", action="store_true")
+    args = ap.parse_args()
+    out_dir = os.path.abspath(args.out)
+    os.makedirs(out_dir, exist_ok=True)
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    gen = case_model("tiny_s5", out_dir, S=5, n_layer=2, V=160, B=3, seed=100)
+    case_filtering(out_dir, gen)
+    case_model("tiny_s2", out_dir, S=2, n_layer=2, V=160, B=4, seed=200, with_decode=False)
+    if not args.skip_full:
+        case_model("full_12l", out_dir, S=5, n_layer=12, V=13317, B=2, seed=300,
+                   full_logits=False, with_grads=False, with_decode=False)
+
+
+if __name__ == "__main__":
+    main()
