@@ -1,0 +1,193 @@
+/* libmmtg_hip.so -- C ABI of the MI355X (gfx950) kernels behind MMTG's
+ * training + generation hot path.
+ *
+ * The reference (Aman-4-Real/MMTG) has no native layer: every operator on the
+ * path is a stock PyTorch call inside src/model.py / src/loss.py /
+ * src/generate.py.  Each entry point below therefore cites the reference
+ * *operator call site(s)* it replaces (file:line into /root/reference/src).
+ *
+ * Conventions
+ *   - plain pointers + sizes only; all pointers are DEVICE pointers unless
+ *     stated; the caller owns every buffer (nothing is allocated, freed or
+ *     retained across calls);
+ *   - `dtype` selects the storage type of activations / weight copies:
+ *     MMTG_F32 (exact fp32 MFMA, the parity-gate mode) or MMTG_BF16 (bf16
+ *     storage, fp32 accumulate).  Statistics, losses, gradients of parameters
+ *     and optimizer state are always fp32;
+ *   - `stream` is a hipStream_t; every call is asynchronous and stream-ordered,
+ *     performs no host synchronisation and is hipGraph-capturable;
+ *   - return 0 on success, a negative MMTG_ERR_* otherwise; the message is
+ *     available (thread-local) from mmtg_last_error().  Nothing throws/exits.
+ */
+#ifndef MMTG_HIP_H
+#define MMTG_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMTG_ABI_VERSION 1
+
+enum { MMTG_OK = 0, MMTG_ERR_BAD_ARG = -1, MMTG_ERR_HIP = -2, MMTG_ERR_UNSUPPORTED = -3 };
+enum { MMTG_F32 = 0, MMTG_BF16 = 1 };
+
+/* GEMM epilogues */
+enum {
+    MMTG_EPI_NONE = 0,   /* C = acc + bias                                    */
+    MMTG_EPI_GELU = 1,   /* aux2 = acc + bias ; C = gelu_new(aux2)            */
+    MMTG_EPI_TANH = 2,   /* C = tanh(acc + bias)                              */
+    MMTG_EPI_RESID = 3,  /* C = dropout(acc + bias) + aux                     */
+    MMTG_EPI_DGELU = 4,  /* C = acc * gelu_new'(aux)                          */
+    MMTG_EPI_DTANH = 5,  /* C = acc * (1 - aux^2)                             */
+    MMTG_EPI_ATOMIC = 6  /* C(f32) += alpha * acc  (atomics; split-K allowed) */
+};
+#define MMTG_GEMM_NO_TR 1 /* flags: gather K-strided bf16 fragments without ds_read_b64_tr_b16 */
+
+/* profiling categories (mmtg_prof_*) */
+enum {
+    MMTG_PROF_GEMM_BF16 = 0, MMTG_PROF_GEMM_F32, MMTG_PROF_ATTN_FWD, MMTG_PROF_ATTN_BWD,
+    MMTG_PROF_LAYERNORM, MMTG_PROF_EMBED, MMTG_PROF_LOSS, MMTG_PROF_OPTIM, MMTG_PROF_ENCODER,
+    MMTG_PROF_DECODE, MMTG_PROF_MISC, MMTG_PROF_NCAT
+};
+
+int mmtg_abi_version(void);
+const char* mmtg_last_error(void);
+
+/* Live per-kernel timing with HIP events recorded on the launch stream.
+ * enable(1) starts bracketing every launch; read() synchronises the recorded
+ * events and returns, per category, launches / total ms / algorithmic flops /
+ * algorithmic bytes (arrays of MMTG_PROF_NCAT), then clears the log. */
+int mmtg_prof_enable(int on);
+int mmtg_prof_read(int* launches, double* ms, double* flops, double* bytes);
+
+/* ---------------------------------------------------------------- GEMM
+ * C[M,N] = epi(opA[M,K] * opB[K,N]).  transA=0: A[m*lda+k]; 1: A[k*lda+m].
+ * transB=0: B[k*ldb+n]; 1: B[n*ldb+k] (an nn.Linear weight [out,in]).
+ * Replaces every nn.Linear / Conv1D / lm_head product on the path:
+ * model.py:77 (topic_fc), :78-79 (GRU projections), :134-136 (alpha QKV),
+ * :199 (out_linear), :279-281 (projector), and the c_attn / c_proj / c_fc /
+ * lm_head products inside GPT2LMHeadModel (call sites model.py:282-288,
+ * 320-326), plus their autograd backward products (train.py:193).           */
+int mmtg_gemm(int dtype, int transA, int transB, int M, int N, int K,
+              const void* A, long lda, const void* B, long ldb, void* C, long ldc,
+              const float* bias, int epi, const void* aux, long ldaux, void* aux2,
+              int out_f32, float alpha, int splits, unsigned drop_thresh, unsigned drop_seed,
+              int flags, void* stream);
+
+/* column sums: out[n] += sum_m X[m,n]  (bias gradients), X of `dtype`, out f32 */
+int mmtg_colsum(int dtype, const void* X, long ldx, int M, int N, float* out, void* stream);
+
+/* ---------------------------------------------------------------- LayerNorm
+ * torch.nn.LayerNorm (model.py:380-382) and GPT-2's ln_1/ln_2/ln_f.          */
+int mmtg_layernorm_fwd(int dtype, const void* x, void* y, const float* gamma, const float* beta,
+                       float* mean, float* rstd, int rows, int cols, float eps, void* stream);
+/* dx = LN'(dy) (+ dres if non-null); dgamma/dbeta accumulated (+=) in fp32   */
+int mmtg_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma,
+                       const float* mean, const float* rstd, const void* dres, void* dx,
+                       float* dgamma, float* dbeta, int rows, int cols, void* stream);
+
+/* ---------------------------------------------------------------- causal self-attention
+ * GPT2Attention._attn: softmax(QK^T/sqrt(dh) + causal + key padding) V with
+ * attention dropout, heads merged (call sites model.py:282-288, 320-326).
+ * qkv: [B*T, 3*D] rows = tokens, columns q|k|v with head h at h*dh (dh = 64);
+ * keep: [B,T] int32 key mask (1 = attend); out: [B*T, D]; lse: [B,nH,T] f32.  */
+int mmtg_attn_fwd(int dtype, const void* qkv, const int* keep, void* out, float* lse,
+                  int B, int T, int nH, int dh, unsigned drop_thresh, unsigned drop_seed, void* stream);
+/* delta: [B,nH,T] f32 scratch; dq32: [B*T, D] f32 scratch (zeroed by the call);
+ * dqkv: [B*T, 3*D] output.                                                    */
+int mmtg_attn_bwd(int dtype, const void* qkv, const int* keep, const void* out, const void* dout,
+                  const float* lse, float* delta, float* dq32, void* dqkv,
+                  int B, int T, int nH, int dh, unsigned drop_thresh, unsigned drop_seed, void* stream);
+
+/* ---------------------------------------------------------------- conditioning front end
+ * WenLan lookup + experience add (model.py:254-268):
+ *   x[b,t] = E[topic_ids[b,t]]                           t <  P
+ *   x[b,P+p] = E[targets[b,p]] + (p/two_sents < S ? c[b,p/two_sents] : 0)
+ * table [V,E], c [B,S,E], x [B,P+L,E] of `dtype`; ids int64.                  */
+int mmtg_embed_condition(int dtype, const void* table, const long long* topic_ids,
+                         const long long* targets, const void* c, void* x,
+                         int B, int P, int L, int S, int E, int two_sents, int V, void* stream);
+/* out[b,k,:] = sum_{p in segment k} g[b,P+p,:]   (backward of the add), out of `dtype` */
+int mmtg_segment_sum(int dtype, const void* g, void* out, int B, int P, int L, int S, int H,
+                     int two_sents, void* stream);
+/* GPT-2 input embedding: h[m,:] = dropout(g[m,:] + wpe[m % T,:] + wte[type_ids[m],:])
+ * (GPT2Model.forward via model.py:282-288).  In place on g allowed.           */
+int mmtg_embed_add(int dtype, const void* g, const void* wpe, const void* wte, const long long* type_ids,
+                   void* h, int M, int T, int D, unsigned drop_thresh, unsigned drop_seed, void* stream);
+/* backward: dwpe[t,:] += sum_b dh[b,t,:]; dwte[type,:] += sum dh; (dh masked in place if dropout) */
+int mmtg_embed_add_bwd(int dtype, void* dh, const long long* type_ids, float* dwpe, float* dwte,
+                       int M, int T, int D, int ntypes, unsigned drop_thresh, unsigned drop_seed, void* stream);
+/* elementwise dropout mask application (backward of a fused-epilogue dropout) */
+int mmtg_dropout_apply(int dtype, const void* x, void* y, long n, int N, unsigned drop_thresh,
+                       unsigned drop_seed, void* stream);
+
+/* ---------------------------------------------------------------- LM head loss (loss.py:45-74 + GPT-2's internal CE)
+ * logits: f32 [M, ldl] (columns >= V ignored).  labels per row t are
+ * cat(topic_ids, targets)[b, t+1] (label_zero != 0: all labels 0, the
+ * inference branch's dummy labels, model.py:314).
+ * Outputs (all f32): nll[M] (0 on each sample's last row), lse[M],
+ * sample_ce[B], coef[B] = d loss / d CE_b / n_tok / batch_denominator,
+ * scalars[0] = MyLoss (sum_b l_b / batch_den), scalars[1] = GPT-2 LM loss.    */
+int mmtg_loss_fwd(const float* logits, long ldl, int V, const long long* topic_ids,
+                  const long long* targets, const long long* ratings, int stage, int label_zero,
+                  int B, int P, int L, float batch_den, float* nll, float* lse, float* sample_ce,
+                  float* coef, float* scalars, void* stream);
+/* dlogits[m,v] = rc[m] * (softmax(logits[m])_v - [v == label]),
+ * rc[m] = gscale * coef[b] on MyLoss rows (P <= t <= T-2) + lm_coef on GPT-2 LM-loss rows
+ * (t <= T-2; pass d lm_loss / B / (T-1), 0 when the LM loss is unused as in train.py:188);
+ * 0 on each sample's last row and on pad columns; dlogits of `dtype`, ld = ldd. */
+int mmtg_loss_bwd(int dtype, const float* logits, long ldl, int V, const long long* topic_ids,
+                  const long long* targets, const float* lse, const float* coef, float gscale, float lm_coef,
+                  int B, int P, int L, void* dlogits, long ldd, int Vpad, void* stream);
+
+/* ---------------------------------------------------------------- encoder / fuser pieces
+ * GRU cell (nn.GRU math, model.py:78-79): gi,gh [B,3H] pre-activations (r|z|n),
+ * h_prev [B,H] -> h [B,H]; saves r,z,n,ghn (each [B,H]) in `save` [4,B,H] f32. */
+int mmtg_gru_cell_fwd(int dtype, const void* gi, const void* gh, const void* h_prev, void* h,
+                      float* save, int B, int H, void* stream);
+/* dh: total gradient wrt h_t (f32 [B,H]); outputs dgi,dgh [B,3H] of `dtype`,
+ * dh_prev (f32 [B,H]) = dh * z (caller adds dgh * W_hh).                       */
+int mmtg_gru_cell_bwd(int dtype, const float* dh, const float* save, const void* h_prev,
+                      void* dgi, void* dgh, float* dh_prev, int B, int H, void* stream);
+/* alpha attention (model.py:138-161): qkv [B*S, 3H] -> ctx [B*S, H], probs [B,heads,S,S] f32,
+ * kl += mean_i KLDiv_batchmean(log P[:,:,i,:], prior_i); prior [S,S] f32.       */
+int mmtg_alpha_attn_fwd(int dtype, const void* qkv, const float* prior, void* ctx, float* probs,
+                        float* kl, int B, int S, int H, int heads, void* stream);
+int mmtg_alpha_attn_bwd(int dtype, const void* qkv, const float* prior, const float* probs,
+                        const void* dctx, float dkl, void* dqkv, int B, int S, int H, int heads,
+                        void* stream);
+/* beta attention / multi-modal fuser (model.py:191-198): topic [B,H], img/txt [B*S,H] (row b*S+i)
+ * att_w [S,H] f32, att_b [S] f32 -> o [B*S,H], a [B,S,3] f32.                   */
+int mmtg_beta_fuse_fwd(int dtype, const void* topic, const void* img, const void* txt,
+                       const float* att_w, const float* att_b, void* o, float* a,
+                       int B, int S, int H, void* stream);
+int mmtg_beta_fuse_bwd(int dtype, const void* topic, const void* img, const void* txt,
+                       const float* att_w, const float* a, const void* d_o,
+                       float* dtopic, void* dimg, void* dtxt, float* datt_w, float* datt_b,
+                       int B, int S, int H, void* stream);
+
+/* ---------------------------------------------------------------- optimizer (train.py:194-197)
+ * sumsq: *out += sum x^2 (global grad-norm partial).                          */
+int mmtg_sumsq(const float* x, long n, float* out, void* stream);
+/* clip (coef = min(1, max_norm / (sqrt(*normsq) + 1e-6))) + transformers.AdamW
+ * (bias-corrected, eps outside the sqrt, decoupled wd) + optional bf16 copy.  */
+int mmtg_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, long n,
+               float lr, float beta1, float beta2, float eps, float wd, int step,
+               const float* normsq, float max_norm, float grad_scale, void* stream);
+int mmtg_cast_f32_to(int dtype, const float* src, void* dst, long n, void* stream);
+/* dst[r, 0:cols] = cast(src[r, 0:cols]); dst[r, cols:ldd] = 0 */
+int mmtg_cast_pad_rows(int dtype, const float* src, long lds_, void* dst, long ldd, int rows, int cols, void* stream);
+int mmtg_cast_to_f32(int dtype, const void* src, float* dst, long n, void* stream);
+int mmtg_axpy_f32(float* y, const float* x, float a, long n, void* stream);
+
+/* ---------------------------------------------------------------- generation (generate.py:127-141)
+ * per row: repetition penalty per occurrence (ids 0 and 102 skipped), /temperature,
+ * ban {1,2,100,102}, sticky PAD, arg-max (lowest index on ties) -> next[B].     */
+int mmtg_logits_process_argmax(const float* logits, long ldl, int V, const long long* generated,
+                               long ldg, const int* gen_len, float temperature, float rep_penalty,
+                               long long* next, int B, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMTG_HIP_H */

@@ -1,0 +1,87 @@
+// Error reporting, ABI version and the live per-kernel event profiler.
+#include <stdarg.h>
+
+#include <vector>
+
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void mmtg_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int mmtg_check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        mmtg_set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+        return MMTG_ERR_HIP;
+    }
+    return MMTG_OK;
+}
+
+extern "C" int mmtg_abi_version(void) { return MMTG_ABI_VERSION; }
+extern "C" const char* mmtg_last_error(void) { return g_err; }
+
+// ---------------------------------------------------------------- profiler
+// When enabled every launcher brackets its kernel(s) with two hipEvents on the
+// launch stream.  Events are pooled and only synchronised in mmtg_prof_read(),
+// so the timed region itself stays free of host syncs.
+namespace {
+struct Rec { int cat; hipEvent_t a, b; double flops, bytes; };
+bool g_prof_on = false;
+std::vector<Rec> g_recs;
+std::vector<hipEvent_t> g_pool;
+hipEvent_t g_open[MMTG_PROF_NCAT];
+
+hipEvent_t get_event() {
+    if (!g_pool.empty()) {
+        hipEvent_t e = g_pool.back();
+        g_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+}  // namespace
+
+void mmtg_prof_begin(int cat, hipStream_t s) {
+    if (!g_prof_on) return;
+    hipEvent_t e = get_event();
+    (void)hipEventRecord(e, s);
+    g_open[cat] = e;
+}
+void mmtg_prof_end(int cat, hipStream_t s, double flops, double bytes) {
+    if (!g_prof_on) return;
+    hipEvent_t e = get_event();
+    (void)hipEventRecord(e, s);
+    g_recs.push_back(Rec{cat, g_open[cat], e, flops, bytes});
+}
+
+extern "C" int mmtg_prof_enable(int on) {
+    g_prof_on = on != 0;
+    return MMTG_OK;
+}
+
+extern "C" int mmtg_prof_read(int* launches, double* ms, double* flops, double* bytes) {
+    for (int i = 0; i < MMTG_PROF_NCAT; ++i) {
+        launches[i] = 0; ms[i] = 0; flops[i] = 0; bytes[i] = 0;
+    }
+    for (auto& r : g_recs) {
+        (void)hipEventSynchronize(r.b);
+        float t = 0.f;
+        (void)hipEventElapsedTime(&t, r.a, r.b);
+        launches[r.cat] += 1;
+        ms[r.cat] += t;
+        flops[r.cat] += r.flops;
+        bytes[r.cat] += r.bytes;
+        g_pool.push_back(r.a);
+        g_pool.push_back(r.b);
+    }
+    g_recs.clear();
+    return MMTG_OK;
+}

@@ -1,0 +1,303 @@
+// Multi-channel experience encoder pieces that are not plain GEMMs:
+// the GRU cell (gates), the inner-modal "alpha" attention with its Gaussian
+// prior KL term, and the multi-modal "beta" fuser (3-way softmax blend).
+// Shapes are tiny (B x 5 steps x 512): these kernels are launch/latency bound;
+// they keep everything in registers / wave shuffles and never touch LDS tiles.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------ GRU cell
+// nn.GRU math (reference src/model.py:78-79):
+//   r = s(gi_r + gh_r)  z = s(gi_z + gh_z)  n = tanh(gi_n + r * gh_n)  h = (1-z) n + z h_prev
+template <typename T>
+__global__ __launch_bounds__(256) void gru_cell_fwd_kernel(const T* __restrict__ gi, long ld_gi, const T* __restrict__ gh,
+        const T* __restrict__ h_prev, long ld_hp, T* __restrict__ h, long ld_h, float* __restrict__ save, int B, int H) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)B * H) return;
+    const int b = (int)(i / H), j = (int)(i % H);
+    const long o = (long)b * 3 * H + j, oi = (long)b * ld_gi + j;
+    const float r = sigmoid_f((float)gi[oi] + (float)gh[o]);
+    const float z = sigmoid_f((float)gi[oi + H] + (float)gh[o + H]);
+    const float ghn = (float)gh[o + 2 * H];
+    const float n = tanhf((float)gi[oi + 2 * H] + r * ghn);
+    const float hp = h_prev ? (float)h_prev[(long)b * ld_hp + j] : 0.f;
+    h[(long)b * ld_h + j] = (T)((1.f - z) * n + z * hp);
+    const long BH = (long)B * H;
+    save[i] = r; save[BH + i] = z; save[2 * BH + i] = n; save[3 * BH + i] = ghn;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gru_cell_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ save,
+        const T* __restrict__ h_prev, long ld_hp, T* __restrict__ dgi, long ld_dgi, T* __restrict__ dgh,
+        float* __restrict__ dh_prev, int B, int H) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)B * H) return;
+    const int b = (int)(i / H), j = (int)(i % H);
+    const long BH = (long)B * H;
+    const float r = save[i], z = save[BH + i], n = save[2 * BH + i], ghn = save[3 * BH + i];
+    const float hp = h_prev ? (float)h_prev[(long)b * ld_hp + j] : 0.f;
+    const float d = dh[i];
+    const float dz = d * (hp - n);
+    const float dn = d * (1.f - z);
+    const float da = dn * (1.f - n * n);
+    const float dr = da * ghn;
+    const float dr_pre = dr * r * (1.f - r);
+    const float dz_pre = dz * z * (1.f - z);
+    const long o = (long)b * 3 * H + j, oi = (long)b * ld_dgi + j;
+    dgi[oi] = (T)dr_pre; dgi[oi + H] = (T)dz_pre; dgi[oi + 2 * H] = (T)da;
+    dgh[o] = (T)dr_pre; dgh[o + H] = (T)dz_pre; dgh[o + 2 * H] = (T)(da * r);
+    dh_prev[i] = d * z;
+}
+
+// ------------------------------------------------------------------ alpha attention
+// One wave per (b, head): S <= 8 steps, dh = H/heads <= 256.  Lane owns dh/64
+// consecutive channels; QK^T dot products by wave reduction.
+constexpr int AS_MAX = 8;
+
+template <typename T>
+__global__ __launch_bounds__(64) void alpha_fwd_kernel(const T* __restrict__ qkv, const float* __restrict__ prior,
+        T* __restrict__ ctx, float* __restrict__ probs, float* __restrict__ kl, int B, int S, int H, int heads) {
+    const int b = blockIdx.x / heads, hd = blockIdx.x % heads;
+    const int dh = H / heads, lane = threadIdx.x;
+    const float scale = rsqrtf((float)dh);
+    float sc[AS_MAX][AS_MAX];
+    for (int i = 0; i < S; ++i)
+        for (int j = 0; j < S; ++j) {
+            float a = 0.f;
+            for (int c = lane; c < dh; c += 64) {
+                const float q = (float)qkv[((long)b * S + i) * 3 * H + hd * dh + c];
+                const float k = (float)qkv[((long)b * S + j) * 3 * H + H + hd * dh + c];
+                a += q * k;
+            }
+            sc[i][j] = wave_sum(a) * scale;
+        }
+    float klacc = 0.f;
+    for (int i = 0; i < S; ++i) {
+        float mx = sc[i][0];
+        for (int j = 1; j < S; ++j) mx = fmaxf(mx, sc[i][j]);
+        float sm = 0.f;
+        for (int j = 0; j < S; ++j) { sc[i][j] = expf(sc[i][j] - mx); sm += sc[i][j]; }
+        const float inv = 1.f / sm;
+        for (int j = 0; j < S; ++j) {
+            sc[i][j] *= inv;
+            const float q = prior[i * S + j];
+            klacc += q * (logf(q) - logf(sc[i][j]));
+        }
+    }
+    if (lane == 0) {
+        for (int i = 0; i < S; ++i)
+            for (int j = 0; j < S; ++j) probs[(((long)b * heads + hd) * S + i) * S + j] = sc[i][j];
+        atomicAdd(kl, klacc / ((float)B * S));
+    }
+    for (int c = lane; c < dh; c += 64) {
+        float vv[AS_MAX];
+        for (int j = 0; j < S; ++j) vv[j] = (float)qkv[((long)b * S + j) * 3 * H + 2 * H + hd * dh + c];
+        for (int i = 0; i < S; ++i) {
+            float a = 0.f;
+            for (int j = 0; j < S; ++j) a += sc[i][j] * vv[j];
+            ctx[((long)b * S + i) * H + hd * dh + c] = (T)a;
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void alpha_bwd_kernel(const T* __restrict__ qkv, const float* __restrict__ prior,
+        const float* __restrict__ probs, const T* __restrict__ dctx, float dkl, T* __restrict__ dqkv,
+        int B, int S, int H, int heads) {
+    const int b = blockIdx.x / heads, hd = blockIdx.x % heads;
+    const int dh = H / heads, lane = threadIdx.x;
+    const float scale = rsqrtf((float)dh);
+    float P[AS_MAX][AS_MAX], dS[AS_MAX][AS_MAX];
+    for (int i = 0; i < S; ++i)
+        for (int j = 0; j < S; ++j) P[i][j] = probs[(((long)b * heads + hd) * S + i) * S + j];
+    // dP[i][j] = dctx[i] . V[j]  - dkl * prior[i][j] / (P[i][j] * B * S)
+    for (int i = 0; i < S; ++i)
+        for (int j = 0; j < S; ++j) {
+            float a = 0.f;
+            for (int c = lane; c < dh; c += 64)
+                a += (float)dctx[((long)b * S + i) * H + hd * dh + c] * (float)qkv[((long)b * S + j) * 3 * H + 2 * H + hd * dh + c];
+            dS[i][j] = wave_sum(a) - dkl * prior[i * S + j] / (P[i][j] * (float)B * S);
+        }
+    for (int i = 0; i < S; ++i) {
+        float dot = 0.f;
+        for (int j = 0; j < S; ++j) dot += P[i][j] * dS[i][j];
+        for (int j = 0; j < S; ++j) dS[i][j] = P[i][j] * (dS[i][j] - dot) * scale;
+    }
+    for (int c = lane; c < dh; c += 64) {
+        float q[AS_MAX], k[AS_MAX], dc[AS_MAX];
+        for (int j = 0; j < S; ++j) {
+            q[j] = (float)qkv[((long)b * S + j) * 3 * H + hd * dh + c];
+            k[j] = (float)qkv[((long)b * S + j) * 3 * H + H + hd * dh + c];
+            dc[j] = (float)dctx[((long)b * S + j) * H + hd * dh + c];
+        }
+        for (int i = 0; i < S; ++i) {
+            float dq = 0.f, dk = 0.f, dv = 0.f;
+            for (int j = 0; j < S; ++j) {
+                dq += dS[i][j] * k[j];
+                dk += dS[j][i] * q[j];
+                dv += P[j][i] * dc[j];
+            }
+            const long o = ((long)b * S + i) * 3 * H + hd * dh + c;
+            dqkv[o] = (T)dq; dqkv[o + H] = (T)dk; dqkv[o + 2 * H] = (T)dv;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ beta fuser
+// One wave per (b, i): scores of {topic, img_i, txt_i} with step i's own weight row,
+// softmax over the 3, blend.  H <= 1024 (lane keeps H/64 channels).
+constexpr int BF_MAXC = 16;
+
+template <typename T>
+__global__ __launch_bounds__(64) void beta_fwd_kernel(const T* __restrict__ topic, const T* __restrict__ img,
+        const T* __restrict__ txt, const float* __restrict__ att_w, const float* __restrict__ att_b,
+        T* __restrict__ o, float* __restrict__ a_out, int B, int S, int H) {
+    const int b = blockIdx.x / S, i = blockIdx.x % S, lane = threadIdx.x;
+    const long r = (long)b * S + i;
+    float tv[BF_MAXC], iv[BF_MAXC], xv[BF_MAXC];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    int n = 0;
+    for (int c = lane; c < H; c += 64, ++n) {
+        const float w = att_w[i * H + c];
+        tv[n] = (float)topic[(long)b * H + c];
+        iv[n] = (float)img[r * H + c];
+        xv[n] = (float)txt[r * H + c];
+        s0 += w * tv[n]; s1 += w * iv[n]; s2 += w * xv[n];
+    }
+    const float bb = att_b[i];
+    s0 = wave_sum(s0) + bb; s1 = wave_sum(s1) + bb; s2 = wave_sum(s2) + bb;
+    const float mx = fmaxf(s0, fmaxf(s1, s2));
+    float e0 = expf(s0 - mx), e1 = expf(s1 - mx), e2 = expf(s2 - mx);
+    const float inv = 1.f / (e0 + e1 + e2);
+    e0 *= inv; e1 *= inv; e2 *= inv;
+    n = 0;
+    for (int c = lane; c < H; c += 64, ++n) o[r * H + c] = (T)(e0 * tv[n] + e1 * iv[n] + e2 * xv[n]);
+    if (lane == 0) { a_out[r * 3] = e0; a_out[r * 3 + 1] = e1; a_out[r * 3 + 2] = e2; }
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void beta_bwd_kernel(const T* __restrict__ topic, const T* __restrict__ img,
+        const T* __restrict__ txt, const float* __restrict__ att_w, const float* __restrict__ a_in,
+        const T* __restrict__ d_o, float* __restrict__ dtopic, T* __restrict__ dimg, T* __restrict__ dtxt,
+        float* __restrict__ datt_w, float* __restrict__ datt_b, int B, int S, int H) {
+    const int b = blockIdx.x / S, i = blockIdx.x % S, lane = threadIdx.x;
+    const long r = (long)b * S + i;
+    const float a0 = a_in[r * 3], a1 = a_in[r * 3 + 1], a2 = a_in[r * 3 + 2];
+    float tv[BF_MAXC], iv[BF_MAXC], xv[BF_MAXC], dv[BF_MAXC];
+    float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+    int n = 0;
+    for (int c = lane; c < H; c += 64, ++n) {
+        tv[n] = (float)topic[(long)b * H + c];
+        iv[n] = (float)img[r * H + c];
+        xv[n] = (float)txt[r * H + c];
+        dv[n] = (float)d_o[r * H + c];
+        d0 += dv[n] * tv[n]; d1 += dv[n] * iv[n]; d2 += dv[n] * xv[n];
+    }
+    d0 = wave_sum(d0); d1 = wave_sum(d1); d2 = wave_sum(d2);
+    const float dot = a0 * d0 + a1 * d1 + a2 * d2;
+    const float ds0 = a0 * (d0 - dot), ds1 = a1 * (d1 - dot), ds2 = a2 * (d2 - dot);
+    n = 0;
+    for (int c = lane; c < H; c += 64, ++n) {
+        const float w = att_w[i * H + c];
+        atomicAdd(dtopic + (long)b * H + c, a0 * dv[n] + ds0 * w);
+        dimg[r * H + c] = (T)(a1 * dv[n] + ds1 * w);
+        dtxt[r * H + c] = (T)(a2 * dv[n] + ds2 * w);
+        atomicAdd(datt_w + i * H + c, ds0 * tv[n] + ds1 * iv[n] + ds2 * xv[n]);
+    }
+    if (lane == 0) atomicAdd(datt_b + i, ds0 + ds1 + ds2);
+}
+
+}  // namespace
+
+#define DISPATCH(dtype, KERN)                                              \
+    if ((dtype) == MMTG_F32) { KERN(float); }                               \
+    else if ((dtype) == MMTG_BF16) { KERN(bf16); }                          \
+    else MMTG_FAIL(MMTG_ERR_BAD_ARG, "bad dtype %d", (dtype));
+
+extern "C" int mmtg_gru_cell_fwd(int dtype, const void* gi, long ld_gi, const void* gh, const void* h_prev, long ld_hp,
+                                 void* h, long ld_h, float* save, int B, int H, void* stream) {
+    MMTG_REQUIRE(gi && gh && h && save && B > 0 && H > 0, "gru_cell_fwd: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(MMTG_PROF_ENCODER, s, 20.0 * B * H, 30.0 * B * H);
+    dim3 grid(cdiv((long)B * H, 256)), block(256);
+#define K_(T) hipLaunchKernelGGL(gru_cell_fwd_kernel<T>, grid, block, 0, s, (const T*)gi, ld_gi, (const T*)gh, (const T*)h_prev, ld_hp, (T*)h, ld_h, save, B, H)
+    DISPATCH(dtype, K_)
+#undef K_
+    MMTG_LAUNCH_CHECK("gru_cell_fwd");
+    return MMTG_OK;
+}
+
+extern "C" int mmtg_gru_cell_bwd(int dtype, const float* dh, const float* save, const void* h_prev, long ld_hp,
+                                 void* dgi, long ld_dgi, void* dgh, float* dh_prev, int B, int H, void* stream) {
+    MMTG_REQUIRE(dh && save && dgi && dgh && dh_prev && B > 0 && H > 0, "gru_cell_bwd: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(MMTG_PROF_ENCODER, s, 20.0 * B * H, 40.0 * B * H);
+    dim3 grid(cdiv((long)B * H, 256)), block(256);
+#define K_(T) hipLaunchKernelGGL(gru_cell_bwd_kernel<T>, grid, block, 0, s, dh, save, (const T*)h_prev, ld_hp, (T*)dgi, ld_dgi, (T*)dgh, dh_prev, B, H)
+    DISPATCH(dtype, K_)
+#undef K_
+    MMTG_LAUNCH_CHECK("gru_cell_bwd");
+    return MMTG_OK;
+}
+
+extern "C" int mmtg_alpha_attn_fwd(int dtype, const void* qkv, const float* prior, void* ctx, float* probs,
+                                   float* kl, int B, int S, int H, int heads, void* stream) {
+    MMTG_REQUIRE(qkv && prior && ctx && probs && kl, "alpha_attn_fwd: null pointer");
+    MMTG_REQUIRE(B > 0 && S > 0 && S <= AS_MAX && heads > 0 && H % heads == 0, "alpha_attn_fwd: S=%d must be <= %d, H %% heads == 0", S, AS_MAX);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(MMTG_PROF_ENCODER, s, 4.0 * B * S * S * H, 8.0 * B * S * H);
+    dim3 grid(B * heads), block(64);
+#define K_(T) hipLaunchKernelGGL(alpha_fwd_kernel<T>, grid, block, 0, s, (const T*)qkv, prior, (T*)ctx, probs, kl, B, S, H, heads)
+    DISPATCH(dtype, K_)
+#undef K_
+    MMTG_LAUNCH_CHECK("alpha_attn_fwd");
+    return MMTG_OK;
+}
+
+extern "C" int mmtg_alpha_attn_bwd(int dtype, const void* qkv, const float* prior, const float* probs,
+                                   const void* dctx, float dkl, void* dqkv, int B, int S, int H, int heads, void* stream) {
+    MMTG_REQUIRE(qkv && prior && probs && dctx && dqkv, "alpha_attn_bwd: null pointer");
+    MMTG_REQUIRE(B > 0 && S > 0 && S <= AS_MAX && heads > 0 && H % heads == 0, "alpha_attn_bwd: bad sizes");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(MMTG_PROF_ENCODER, s, 8.0 * B * S * S * H, 16.0 * B * S * H);
+    dim3 grid(B * heads), block(64);
+#define K_(T) hipLaunchKernelGGL(alpha_bwd_kernel<T>, grid, block, 0, s, (const T*)qkv, prior, probs, (const T*)dctx, dkl, (T*)dqkv, B, S, H, heads)
+    DISPATCH(dtype, K_)
+#undef K_
+    MMTG_LAUNCH_CHECK("alpha_attn_bwd");
+    return MMTG_OK;
+}
+
+extern "C" int mmtg_beta_fuse_fwd(int dtype, const void* topic, const void* img, const void* txt,
+                                  const float* att_w, const float* att_b, void* o, float* a,
+                                  int B, int S, int H, void* stream) {
+    MMTG_REQUIRE(topic && img && txt && att_w && att_b && o && a, "beta_fuse_fwd: null pointer");
+    MMTG_REQUIRE(B > 0 && S > 0 && H > 0 && H <= 64 * BF_MAXC, "beta_fuse_fwd: H=%d too large", H);
+    hipStream_t s = (hipStream_t)stream;
+    const double esz = dtype == MMTG_F32 ? 4 : 2;
+    ProfScope prof(MMTG_PROF_ENCODER, s, 12.0 * B * S * H, esz * (3.0 * B * S * H + B * H));
+    dim3 grid(B * S), block(64);
+#define K_(T) hipLaunchKernelGGL(beta_fwd_kernel<T>, grid, block, 0, s, (const T*)topic, (const T*)img, (const T*)txt, att_w, att_b, (T*)o, a, B, S, H)
+    DISPATCH(dtype, K_)
+#undef K_
+    MMTG_LAUNCH_CHECK("beta_fuse_fwd");
+    return MMTG_OK;
+}
+
+extern "C" int mmtg_beta_fuse_bwd(int dtype, const void* topic, const void* img, const void* txt,
+                                  const float* att_w, const float* a, const void* d_o,
+                                  float* dtopic, void* dimg, void* dtxt, float* datt_w, float* datt_b,
+                                  int B, int S, int H, void* stream) {
+    MMTG_REQUIRE(topic && img && txt && att_w && a && d_o && dtopic && dimg && dtxt && datt_w && datt_b, "beta_fuse_bwd: null pointer");
+    MMTG_REQUIRE(B > 0 && S > 0 && H > 0 && H <= 64 * BF_MAXC, "beta_fuse_bwd: H=%d too large", H);
+    hipStream_t s = (hipStream_t)stream;
+    const double esz = dtype == MMTG_F32 ? 4 : 2;
+    ProfScope prof(MMTG_PROF_ENCODER, s, 24.0 * B * S * H, esz * 6.0 * B * S * H);
+    dim3 grid(B * S), block(64);
+#define K_(T) hipLaunchKernelGGL(beta_bwd_kernel<T>, grid, block, 0, s, (const T*)topic, (const T*)img, (const T*)txt, att_w, a, (const T*)d_o, dtopic, (T*)dimg, (T*)dtxt, datt_w, datt_b, B, S, H)
+    DISPATCH(dtype, K_)
+#undef K_
+    MMTG_LAUNCH_CHECK("beta_fuse_bwd");
+    return MMTG_OK;
+}

@@ -1,0 +1,171 @@
+// LM-head loss: row log-sum-exp + label gather, the rating-conditioned
+// sequence loss of the reference (src/loss.py:45-74) with GPT-2's internal
+// shifted CE (labels= at src/model.py:286), and the analytic d(loss)/d(logits).
+// HBM-bound over the [M, V] fp32 logits (one read forward, one read backward).
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ long long label_of(const long long* topic_ids, const long long* targets,
+                                              int b, int t1, int P, int L, int label_zero) {
+    // label of row t is cat(topic_ids, targets)[b, t+1]; t1 = t + 1
+    if (label_zero) return 0;
+    return t1 < P ? topic_ids[(long)b * P + t1] : targets[(long)b * L + (t1 - P)];
+}
+
+__device__ __forceinline__ float block_max(float v, float* sh) {
+    v = wave_max(v);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    v = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+    __syncthreads();
+    return v;
+}
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    v = sh[0] + sh[1] + sh[2] + sh[3];
+    __syncthreads();
+    return v;
+}
+
+// one block per row: lse[m], nll[m] = lse - logit[label]
+__global__ __launch_bounds__(256) void row_lse_kernel(const float* __restrict__ logits, long ldl, int V,
+        const long long* __restrict__ topic_ids, const long long* __restrict__ targets, int label_zero,
+        int P, int L, float* __restrict__ nll, float* __restrict__ lse) {
+    __shared__ float sh[4];
+    const int Tt = P + L;
+    const long m = blockIdx.x;
+    const int b = (int)(m / Tt), t = (int)(m % Tt);
+    const float* row = logits + m * ldl;
+    float mx = -INFINITY;
+    const int V4 = V & ~3;
+    for (int v = threadIdx.x * 4; v < V4; v += 1024) {
+        f32x4 x = *reinterpret_cast<const f32x4*>(row + v);
+        mx = fmaxf(fmaxf(mx, fmaxf(x[0], x[1])), fmaxf(x[2], x[3]));
+    }
+    for (int v = V4 + threadIdx.x; v < V; v += 256) mx = fmaxf(mx, row[v]);
+    mx = block_max(mx, sh);
+    float sm = 0.f;
+    for (int v = threadIdx.x * 4; v < V4; v += 1024) {
+        f32x4 x = *reinterpret_cast<const f32x4*>(row + v);
+        sm += expf(x[0] - mx) + expf(x[1] - mx) + expf(x[2] - mx) + expf(x[3] - mx);
+    }
+    for (int v = V4 + threadIdx.x; v < V; v += 256) sm += expf(row[v] - mx);
+    sm = block_sum(sm, sh);
+    if (threadIdx.x == 0) {
+        const float l = mx + logf(sm);
+        lse[m] = l;
+        float n = 0.f;
+        if (t + 1 < Tt) {
+            long long lab = label_of(topic_ids, targets, b, t + 1, P, L, label_zero);
+            if (lab < 0) lab = 0;
+            if (lab >= V) lab = V - 1;
+            n = l - row[lab];
+        }
+        nll[m] = n;
+    }
+}
+
+// single block: per-sample CE, rating-conditioned loss, coefficients, both scalars
+__global__ __launch_bounds__(256) void sample_loss_kernel(const float* __restrict__ nll,
+        const long long* __restrict__ ratings, int stage, int B, int P, int L, float batch_den,
+        float* __restrict__ sample_ce, float* __restrict__ coef, float* __restrict__ scalars) {
+    __shared__ float sh[4];
+    const int Tt = P + L;
+    const int ntok = Tt - 1 - P;  // rows P .. T-2  (loss.py:62-63)
+    float my = 0.f, lm = 0.f;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        float ce = 0.f, all = 0.f;
+        for (int t = 0; t < Tt - 1; ++t) {
+            const float n = nll[(long)b * Tt + t];
+            all += n;
+            if (t >= P) ce += n;
+        }
+        ce /= ntok;
+        lm += all;
+        float lb = 0.f, cf = 0.f;
+        if (ratings) {
+            const float y = ratings[b] > (stage == 1 ? 4 : 3) ? 1.f : 0.f;
+            const float p = 1.0f / expf(ce);
+            const float near0 = 1e-10f;
+            lb = -y * logf(p + near0) - (1.f - y) * logf(1.f - p + near0);
+            // d l / d ce = -p * (-y/(p+e) + (1-y)/(1-p+e))
+            cf = -p * (-y / (p + near0) + (1.f - y) / (1.f - p + near0));
+        }
+        sample_ce[b] = ce;
+        coef[b] = cf / (ntok * batch_den);
+        my += lb;
+    }
+    my = block_sum(my, sh);
+    lm = block_sum(lm, sh);
+    if (threadIdx.x == 0) {
+        scalars[0] = my / batch_den;
+        scalars[1] = lm / ((float)B * (Tt - 1));
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__ logits, long ldl, int V,
+        const long long* __restrict__ topic_ids, const long long* __restrict__ targets,
+        const float* __restrict__ lse, const float* __restrict__ coef, float gscale, float lm_coef, int P, int L,
+        T* __restrict__ dlogits, long ldd, int Vpad) {
+    const int Tt = P + L;
+    const long m = blockIdx.x;
+    const int b = (int)(m / Tt), t = (int)(m % Tt);
+    T* drow = dlogits + m * ldd;
+    const bool active = t + 1 < Tt && (t >= P || lm_coef != 0.f);
+    if (!active) {
+        for (int v = threadIdx.x; v < Vpad; v += 256) drow[v] = (T)0.f;
+        return;
+    }
+    const float* row = logits + m * ldl;
+    const float l = lse[m], cf = (t >= P ? coef[b] * gscale : 0.f) + lm_coef;
+    long long lab = label_of(topic_ids, targets, b, t + 1, P, L, 0);
+    if (lab < 0) lab = 0;
+    if (lab >= V) lab = V - 1;
+    for (int v = threadIdx.x; v < Vpad; v += 256) {
+        float d = 0.f;
+        if (v < V) d = cf * (expf(row[v] - l) - (v == (int)lab ? 1.f : 0.f));
+        drow[v] = (T)d;
+    }
+}
+
+}  // namespace
+
+extern "C" int mmtg_loss_fwd(const float* logits, long ldl, int V, const long long* topic_ids,
+                             const long long* targets, const long long* ratings, int stage, int label_zero,
+                             int B, int P, int L, float batch_den, float* nll, float* lse, float* sample_ce,
+                             float* coef, float* scalars, void* stream) {
+    MMTG_REQUIRE(B > 0 && L > 1 && P >= 0 && V > 0 && ldl >= V && ldl % 4 == 0, "loss_fwd: bad sizes (V=%d ldl=%ld)", V, ldl);
+    MMTG_REQUIRE(logits && targets && nll && lse && sample_ce && coef && scalars, "loss_fwd: null pointer");
+    MMTG_REQUIRE(label_zero || P == 0 || topic_ids, "loss_fwd: topic_ids required");
+    MMTG_REQUIRE(MMTG_ALIGNED16(logits), "loss_fwd: logits must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const long M = (long)B * (P + L);
+    ProfScope prof(MMTG_PROF_LOSS, s, 4.0 * M * V, 4.0 * M * V);
+    hipLaunchKernelGGL(row_lse_kernel, dim3((unsigned)M), dim3(256), 0, s, logits, ldl, V, topic_ids, targets, label_zero, P, L, nll, lse);
+    hipLaunchKernelGGL(sample_loss_kernel, dim3(1), dim3(256), 0, s, nll, ratings, stage, B, P, L, batch_den, sample_ce, coef, scalars);
+    MMTG_LAUNCH_CHECK("loss_fwd");
+    return MMTG_OK;
+}
+
+extern "C" int mmtg_loss_bwd(int dtype, const float* logits, long ldl, int V, const long long* topic_ids,
+                             const long long* targets, const float* lse, const float* coef, float gscale, float lm_coef,
+                             int B, int P, int L, void* dlogits, long ldd, int Vpad, void* stream) {
+    MMTG_REQUIRE(B > 0 && L > 1 && V > 0 && Vpad >= V && ldd >= Vpad, "loss_bwd: bad sizes");
+    MMTG_REQUIRE(logits && targets && lse && coef && dlogits, "loss_bwd: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const long M = (long)B * (P + L);
+    ProfScope prof(MMTG_PROF_LOSS, s, 3.0 * M * V, (4.0 + (dtype == MMTG_F32 ? 4 : 2)) * M * V);
+    if (dtype == MMTG_F32)
+        hipLaunchKernelGGL(loss_bwd_kernel<float>, dim3((unsigned)M), dim3(256), 0, s, logits, ldl, V, topic_ids, targets, lse, coef, gscale, lm_coef, P, L, (float*)dlogits, ldd, Vpad);
+    else if (dtype == MMTG_BF16)
+        hipLaunchKernelGGL(loss_bwd_kernel<bf16>, dim3((unsigned)M), dim3(256), 0, s, logits, ldl, V, topic_ids, targets, lse, coef, gscale, lm_coef, P, L, (bf16*)dlogits, ldd, Vpad);
+    else MMTG_FAIL(MMTG_ERR_BAD_ARG, "loss_bwd: bad dtype");
+    MMTG_LAUNCH_CHECK("loss_bwd");
+    return MMTG_OK;
+}

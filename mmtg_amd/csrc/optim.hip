@@ -1,0 +1,131 @@
+// Step tail of the training loop (train.py:194-197): global grad-norm,
+// clip + transformers.AdamW update fused with the bf16 weight-copy refresh,
+// and the dtype casts the engine needs.  Pure HBM streaming kernels:
+// 16-byte vectors, grid-stride, <= 2048 blocks.
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long n, float* __restrict__ out) {
+    __shared__ float sh[4];
+    float a = 0.f;
+    const long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+        a += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    if (blockIdx.x == 0)
+        for (long i = (n4 << 2) + threadIdx.x; i < n; i += 256) a += x[i] * x[i];
+    a = wave_sum(a);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, sh[0] + sh[1] + sh[2] + sh[3]);
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+        float* __restrict__ m, float* __restrict__ v, bf16* __restrict__ pc, long n, float lr, float b1, float b2,
+        float eps, float wd, float step_size, const float* __restrict__ normsq, float max_norm, float gscale) {
+    float coef = gscale;
+    if (normsq) {
+        // torch.nn.utils.clip_grad_norm_: coef = max_norm / (norm + 1e-6), clamped to 1
+        const float nrm = sqrtf(*normsq) * gscale;
+        coef *= fminf(1.0f, max_norm / (nrm + 1e-6f));
+    }
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float gi = g[i] * coef;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        float pi = p[i] - step_size * (mi / (sqrtf(vi) + eps));
+        if (wd > 0.f) pi -= lr * wd * pi;
+        m[i] = mi; v[i] = vi; p[i] = pi;
+        if (pc) pc[i] = (bf16)pi;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void cast_from_f32_kernel(const float* __restrict__ src, T* __restrict__ dst, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = (T)src[i];
+}
+template <typename T>
+__global__ __launch_bounds__(256) void cast_to_f32_kernel(const T* __restrict__ src, float* __restrict__ dst, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = (float)src[i];
+}
+template <typename T>
+__global__ __launch_bounds__(256) void cast_pad_rows_kernel(const float* __restrict__ src, long lds_, T* __restrict__ dst,
+                                                            long ldd, int cols) {
+    const long r = blockIdx.x;
+    for (int c = threadIdx.x; c < ldd; c += 256) dst[r * ldd + c] = c < cols ? (T)src[r * lds_ + c] : (T)0.f;
+}
+__global__ __launch_bounds__(256) void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, float a, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] += a * x[i];
+}
+
+inline unsigned grid_for(long n) { return (unsigned)min((long)2048, (n + 255) / 256); }
+
+}  // namespace
+
+extern "C" int mmtg_sumsq(const float* x, long n, float* out, void* stream) {
+    MMTG_REQUIRE(x && out && n > 0 && MMTG_ALIGNED16(x), "sumsq: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(MMTG_PROF_OPTIM, s, 2.0 * n, 4.0 * n);
+    hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, s, x, n, out);
+    MMTG_LAUNCH_CHECK("sumsq");
+    return MMTG_OK;
+}
+
+extern "C" int mmtg_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, long n,
+                          float lr, float beta1, float beta2, float eps, float wd, int step,
+                          const float* normsq, float max_norm, float grad_scale, void* stream) {
+    MMTG_REQUIRE(p && g && m && v && n > 0 && step >= 1, "adamw: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(MMTG_PROF_OPTIM, s, 12.0 * n, (28.0 + (p_bf16 ? 2 : 0)) * n);
+    // transformers.AdamW(correct_bias=True): step_size = lr * sqrt(1-b2^t) / (1-b1^t)
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    const float step_size = (float)((double)lr * sqrt(bc2) / bc1);
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, s, p, g, m, v, (bf16*)p_bf16, n, lr, beta1, beta2,
+                       eps, wd, step_size, normsq, max_norm, grad_scale);
+    MMTG_LAUNCH_CHECK("adamw");
+    return MMTG_OK;
+}
+
+extern "C" int mmtg_cast_f32_to(int dtype, const float* src, void* dst, long n, void* stream) {
+    MMTG_REQUIRE(src && dst && n > 0, "cast_f32_to: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(MMTG_PROF_MISC, s, 0, 6.0 * n);
+    if (dtype == MMTG_BF16) hipLaunchKernelGGL(cast_from_f32_kernel<bf16>, dim3(grid_for(n)), dim3(256), 0, s, src, (bf16*)dst, n);
+    else if (dtype == MMTG_F32) hipLaunchKernelGGL(cast_from_f32_kernel<float>, dim3(grid_for(n)), dim3(256), 0, s, src, (float*)dst, n);
+    else MMTG_FAIL(MMTG_ERR_BAD_ARG, "cast_f32_to: bad dtype");
+    MMTG_LAUNCH_CHECK("cast_f32_to");
+    return MMTG_OK;
+}
+
+extern "C" int mmtg_cast_to_f32(int dtype, const void* src, float* dst, long n, void* stream) {
+    MMTG_REQUIRE(src && dst && n > 0, "cast_to_f32: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(MMTG_PROF_MISC, s, 0, 6.0 * n);
+    if (dtype == MMTG_BF16) hipLaunchKernelGGL(cast_to_f32_kernel<bf16>, dim3(grid_for(n)), dim3(256), 0, s, (const bf16*)src, dst, n);
+    else if (dtype == MMTG_F32) hipLaunchKernelGGL(cast_to_f32_kernel<float>, dim3(grid_for(n)), dim3(256), 0, s, (const float*)src, dst, n);
+    else MMTG_FAIL(MMTG_ERR_BAD_ARG, "cast_to_f32: bad dtype");
+    MMTG_LAUNCH_CHECK("cast_to_f32");
+    return MMTG_OK;
+}
+
+extern "C" int mmtg_cast_pad_rows(int dtype, const float* src, long lds_, void* dst, long ldd, int rows, int cols, void* stream) {
+    MMTG_REQUIRE(src && dst && rows > 0 && cols > 0 && ldd >= cols && lds_ >= cols, "cast_pad_rows: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(MMTG_PROF_MISC, s, 0, 6.0 * rows * cols);
+    if (dtype == MMTG_BF16) hipLaunchKernelGGL(cast_pad_rows_kernel<bf16>, dim3(rows), dim3(256), 0, s, src, lds_, (bf16*)dst, ldd, cols);
+    else if (dtype == MMTG_F32) hipLaunchKernelGGL(cast_pad_rows_kernel<float>, dim3(rows), dim3(256), 0, s, src, lds_, (float*)dst, ldd, cols);
+    else MMTG_FAIL(MMTG_ERR_BAD_ARG, "cast_pad_rows: bad dtype");
+    MMTG_LAUNCH_CHECK("cast_pad_rows");
+    return MMTG_OK;
+}
+
+extern "C" int mmtg_axpy_f32(float* y, const float* x, float a, long n, void* stream) {
+    MMTG_REQUIRE(x && y && n > 0, "axpy: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(MMTG_PROF_MISC, s, 2.0 * n, 12.0 * n);
+    hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n)), dim3(256), 0, s, y, x, a, n);
+    MMTG_LAUNCH_CHECK("axpy");
+    return MMTG_OK;
+}

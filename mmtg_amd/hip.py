@@ -1,0 +1,280 @@
+"""ctypes binding of libmmtg_hip.so (the C ABI declared in include/mmtg_hip.h).
+
+PyTorch is plumbing here: tensors provide device memory (``data_ptr()``) and the
+current HIP stream; every compute step of the hot path is one of the entry
+points below.  There is NO fallback: if the library is missing or a call fails
+a RuntimeError is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+F32, BF16 = 0, 1
+EPI_NONE, EPI_GELU, EPI_TANH, EPI_RESID, EPI_DGELU, EPI_DTANH, EPI_ATOMIC = range(7)
+GEMM_NO_TR = 1
+PROF_CATS = ["gemm_bf16", "gemm_f32", "attn_fwd", "attn_bwd", "layernorm", "embed", "loss",
+             "optim", "encoder", "decode", "misc"]
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmmtg_hip.so")
+_lib = None
+
+_vp, _i, _l, _f, _u = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_uint
+
+_SIGS = {
+    "mmtg_abi_version": ([], _i),
+    "mmtg_last_error": ([], C.c_char_p),
+    "mmtg_prof_enable": ([_i], _i),
+    "mmtg_prof_read": ([_vp, _vp, _vp, _vp], _i),
+    "mmtg_gemm": ([_i, _i, _i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _vp, _i, _vp, _l, _vp, _i, _f, _i, _u, _u, _i, _vp], _i),
+    "mmtg_colsum": ([_i, _vp, _l, _i, _i, _vp, _vp], _i),
+    "mmtg_layernorm_fwd": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp], _i),
+    "mmtg_layernorm_bwd": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp], _i),
+    "mmtg_attn_fwd": ([_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _u, _u, _vp], _i),
+    "mmtg_attn_bwd": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _u, _u, _vp], _i),
+    "mmtg_embed_condition": ([_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
+    "mmtg_segment_sum": ([_i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp], _i),
+    "mmtg_embed_add": ([_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _u, _u, _vp], _i),
+    "mmtg_embed_add_bwd": ([_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _u, _u, _vp], _i),
+    "mmtg_dropout_apply": ([_i, _vp, _vp, _l, _i, _u, _u, _vp], _i),
+    "mmtg_loss_fwd": ([_vp, _l, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp], _i),
+    "mmtg_loss_bwd": ([_i, _vp, _l, _i, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _i, _vp, _l, _i, _vp], _i),
+    "mmtg_gru_cell_fwd": ([_i, _vp, _l, _vp, _vp, _l, _vp, _l, _vp, _i, _i, _vp], _i),
+    "mmtg_gru_cell_bwd": ([_i, _vp, _vp, _vp, _l, _vp, _l, _vp, _vp, _i, _i, _vp], _i),
+    "mmtg_alpha_attn_fwd": ([_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp], _i),
+    "mmtg_alpha_attn_bwd": ([_i, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _vp], _i),
+    "mmtg_beta_fuse_fwd": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp], _i),
+    "mmtg_beta_fuse_bwd": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp], _i),
+    "mmtg_sumsq": ([_vp, _l, _vp, _vp], _i),
+    "mmtg_adamw": ([_vp, _vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _i, _vp, _f, _f, _vp], _i),
+    "mmtg_cast_f32_to": ([_i, _vp, _vp, _l, _vp], _i),
+    "mmtg_cast_pad_rows": ([_i, _vp, _l, _vp, _l, _i, _i, _vp], _i),
+    "mmtg_cast_to_f32": ([_i, _vp, _vp, _l, _vp], _i),
+    "mmtg_axpy_f32": ([_vp, _vp, _f, _l, _vp], _i),
+    "mmtg_logits_process_argmax": ([_vp, _l, _i, _vp, _l, _vp, _f, _f, _vp, _i, _vp], _i),
+}
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+def exported_symbols():
+    return sorted(_SIGS)
+
+
+def lib():
+    """Load the shared library (once).  Raises if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise RuntimeError(
+                "libmmtg_hip.so is not built (%s). Run `python -m mmtg_amd.build` -- the MMTG hot "
+                "path has no CPU/PyTorch fallback." % _LIB_PATH)
+        L = C.CDLL(_LIB_PATH)
+        for name, (args, res) in _SIGS.items():
+            fn = getattr(L, name)  # AttributeError if the symbol is missing
+            fn.argtypes = args
+            fn.restype = res
+        if L.mmtg_abi_version() != 1:
+            raise RuntimeError("libmmtg_hip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed (%d): %s" % (what, rc, lib().mmtg_last_error().decode()))
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dt(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError("unsupported storage dtype %s" % t.dtype)
+
+
+def torch_dtype(code):
+    return torch.float32 if code == F32 else torch.bfloat16
+
+
+def drop_thresh(p):
+    """dropout probability -> 32-bit threshold (0 disables)."""
+    return 0 if p <= 0.0 else min(int(p * 4294967296.0), 4294967295)
+
+
+# ------------------------------------------------------------------ profiler
+def prof_enable(on=True):
+    _check(lib().mmtg_prof_enable(int(on)), "prof_enable")
+
+
+def prof_read():
+    n = len(PROF_CATS)
+    la = (C.c_int * n)()
+    ms = (C.c_double * n)()
+    fl = (C.c_double * n)()
+    by = (C.c_double * n)()
+    _check(lib().mmtg_prof_read(C.addressof(la), C.addressof(ms), C.addressof(fl), C.addressof(by)), "prof_read")
+    return {PROF_CATS[i]: {"launches": la[i], "ms": ms[i], "flops": fl[i], "bytes": by[i]} for i in range(n)}
+
+
+# ------------------------------------------------------------------ GEMM
+def gemm(A, B, C_, M, N, K, transA=False, transB=False, lda=None, ldb=None, ldc=None, bias=None,
+         epi=EPI_NONE, aux=None, ldaux=0, aux2=None, out_f32=False, alpha=1.0, splits=1,
+         drop_p=0.0, drop_seed=0, flags=0, dtype=None):
+    """C[M,N] = epi(opA * opB); see include/mmtg_hip.h (mmtg_gemm)."""
+    d = dt(A) if dtype is None else dtype
+    if lda is None:
+        lda = M if transA else K
+    if ldb is None:
+        ldb = K if transB else N
+    if ldc is None:
+        ldc = N
+    if aux is not None and not ldaux:
+        ldaux = N
+    _check(lib().mmtg_gemm(d, int(transA), int(transB), M, N, K, _p(A), lda, _p(B), ldb, _p(C_), ldc,
+                           _p(bias), epi, _p(aux), ldaux, _p(aux2), int(out_f32), float(alpha), splits,
+                           drop_thresh(drop_p), drop_seed & 0xFFFFFFFF, flags, _stream()), "gemm")
+
+
+def colsum(X, M, N, out, ldx=None):
+    _check(lib().mmtg_colsum(dt(X), _p(X), N if ldx is None else ldx, M, N, _p(out), _stream()), "colsum")
+
+
+# ------------------------------------------------------------------ LayerNorm
+def layernorm_fwd(x, y, gamma, beta, mean, rstd, rows, cols, eps=1e-5):
+    _check(lib().mmtg_layernorm_fwd(dt(x), _p(x), _p(y), _p(gamma), _p(beta), _p(mean), _p(rstd), rows, cols,
+                                    float(eps), _stream()), "layernorm_fwd")
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, cols):
+    _check(lib().mmtg_layernorm_bwd(dt(x), _p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx),
+                                    _p(dgamma), _p(dbeta), rows, cols, _stream()), "layernorm_bwd")
+
+
+# ------------------------------------------------------------------ attention
+def attn_fwd(qkv, keep, out, lse, B, T, nH, dh, drop_p=0.0, drop_seed=0):
+    _check(lib().mmtg_attn_fwd(dt(qkv), _p(qkv), _p(keep), _p(out), _p(lse), B, T, nH, dh,
+                               drop_thresh(drop_p), drop_seed & 0xFFFFFFFF, _stream()), "attn_fwd")
+
+
+def attn_bwd(qkv, keep, out, dout, lse, delta, dq32, dqkv, B, T, nH, dh, drop_p=0.0, drop_seed=0):
+    _check(lib().mmtg_attn_bwd(dt(qkv), _p(qkv), _p(keep), _p(out), _p(dout), _p(lse), _p(delta), _p(dq32),
+                               _p(dqkv), B, T, nH, dh, drop_thresh(drop_p), drop_seed & 0xFFFFFFFF, _stream()),
+           "attn_bwd")
+
+
+# ------------------------------------------------------------------ conditioning front end
+def embed_condition(table, topic_ids, targets, c, x, B, P, L, S, E, two_sents, V):
+    _check(lib().mmtg_embed_condition(dt(table), _p(table), _p(topic_ids), _p(targets), _p(c), _p(x),
+                                      B, P, L, S, E, two_sents, V, _stream()), "embed_condition")
+
+
+def segment_sum(g, out, B, P, L, S, H, two_sents):
+    _check(lib().mmtg_segment_sum(dt(g), _p(g), _p(out), B, P, L, S, H, two_sents, _stream()), "segment_sum")
+
+
+def embed_add(g, wpe, wte, type_ids, h, M, T, D, drop_p=0.0, drop_seed=0):
+    _check(lib().mmtg_embed_add(dt(g), _p(g), _p(wpe), _p(wte), _p(type_ids), _p(h), M, T, D,
+                                drop_thresh(drop_p), drop_seed & 0xFFFFFFFF, _stream()), "embed_add")
+
+
+def embed_add_bwd(dh, type_ids, dwpe, dwte, M, T, D, ntypes, drop_p=0.0, drop_seed=0):
+    _check(lib().mmtg_embed_add_bwd(dt(dh), _p(dh), _p(type_ids), _p(dwpe), _p(dwte), M, T, D, ntypes,
+                                    drop_thresh(drop_p), drop_seed & 0xFFFFFFFF, _stream()), "embed_add_bwd")
+
+
+def dropout_apply(x, y, n, drop_p, drop_seed):
+    _check(lib().mmtg_dropout_apply(dt(x), _p(x), _p(y), n, 0, drop_thresh(drop_p), drop_seed & 0xFFFFFFFF,
+                                    _stream()), "dropout_apply")
+
+
+# ------------------------------------------------------------------ loss
+def loss_fwd(logits, ldl, V, topic_ids, targets, ratings, stage, label_zero, B, P, L, batch_den,
+             nll, lse, sample_ce, coef, scalars):
+    _check(lib().mmtg_loss_fwd(_p(logits), ldl, V, _p(topic_ids), _p(targets), _p(ratings), stage,
+                               int(label_zero), B, P, L, float(batch_den), _p(nll), _p(lse), _p(sample_ce),
+                               _p(coef), _p(scalars), _stream()), "loss_fwd")
+
+
+def loss_bwd(logits, ldl, V, topic_ids, targets, lse, coef, gscale, B, P, L, dlogits, ldd, Vpad, lm_coef=0.0):
+    _check(lib().mmtg_loss_bwd(dt(dlogits), _p(logits), ldl, V, _p(topic_ids), _p(targets), _p(lse), _p(coef),
+                               float(gscale), float(lm_coef), B, P, L, _p(dlogits), ldd, Vpad, _stream()), "loss_bwd")
+
+
+# ------------------------------------------------------------------ encoder pieces
+def gru_cell_fwd(gi, gh, h_prev, h, save, B, H, ld_gi=None, ld_hp=None, ld_h=None):
+    _check(lib().mmtg_gru_cell_fwd(dt(gi), _p(gi), 3 * H if ld_gi is None else ld_gi, _p(gh), _p(h_prev),
+                                   H if ld_hp is None else ld_hp, _p(h), H if ld_h is None else ld_h, _p(save),
+                                   B, H, _stream()), "gru_cell_fwd")
+
+
+def gru_cell_bwd(dh, save, h_prev, dgi, dgh, dh_prev, B, H, ld_hp=None, ld_dgi=None):
+    _check(lib().mmtg_gru_cell_bwd(dt(dgi), _p(dh), _p(save), _p(h_prev), H if ld_hp is None else ld_hp, _p(dgi),
+                                   3 * H if ld_dgi is None else ld_dgi, _p(dgh), _p(dh_prev), B, H, _stream()),
+           "gru_cell_bwd")
+
+
+def alpha_attn_fwd(qkv, prior, ctx, probs, kl, B, S, H, heads):
+    _check(lib().mmtg_alpha_attn_fwd(dt(qkv), _p(qkv), _p(prior), _p(ctx), _p(probs), _p(kl), B, S, H, heads,
+                                     _stream()), "alpha_attn_fwd")
+
+
+def alpha_attn_bwd(qkv, prior, probs, dctx, dkl, dqkv, B, S, H, heads):
+    _check(lib().mmtg_alpha_attn_bwd(dt(qkv), _p(qkv), _p(prior), _p(probs), _p(dctx), float(dkl), _p(dqkv),
+                                     B, S, H, heads, _stream()), "alpha_attn_bwd")
+
+
+def beta_fuse_fwd(topic, img, txt, att_w, att_b, o, a, B, S, H):
+    _check(lib().mmtg_beta_fuse_fwd(dt(topic), _p(topic), _p(img), _p(txt), _p(att_w), _p(att_b), _p(o), _p(a),
+                                    B, S, H, _stream()), "beta_fuse_fwd")
+
+
+def beta_fuse_bwd(topic, img, txt, att_w, a, d_o, dtopic, dimg, dtxt, datt_w, datt_b, B, S, H):
+    _check(lib().mmtg_beta_fuse_bwd(dt(topic), _p(topic), _p(img), _p(txt), _p(att_w), _p(a), _p(d_o), _p(dtopic),
+                                    _p(dimg), _p(dtxt), _p(datt_w), _p(datt_b), B, S, H, _stream()), "beta_fuse_bwd")
+
+
+# ------------------------------------------------------------------ optimizer / casts
+def sumsq(x, n, out):
+    _check(lib().mmtg_sumsq(_p(x), n, _p(out), _stream()), "sumsq")
+
+
+def adamw(p, g, m, v, p_bf16, n, lr, beta1, beta2, eps, wd, step, normsq, max_norm, grad_scale=1.0):
+    _check(lib().mmtg_adamw(_p(p), _p(g), _p(m), _p(v), _p(p_bf16), n, float(lr), float(beta1), float(beta2),
+                            float(eps), float(wd), int(step), _p(normsq), float(max_norm), float(grad_scale),
+                            _stream()), "adamw")
+
+
+def cast_f32_to(src, dst, n):
+    _check(lib().mmtg_cast_f32_to(dt(dst), _p(src), _p(dst), n, _stream()), "cast_f32_to")
+
+
+def cast_pad_rows(src, lds, dst, ldd, rows, cols):
+    _check(lib().mmtg_cast_pad_rows(dt(dst), _p(src), lds, _p(dst), ldd, rows, cols, _stream()), "cast_pad_rows")
+
+
+def cast_to_f32(src, dst, n):
+    _check(lib().mmtg_cast_to_f32(dt(src), _p(src), _p(dst), n, _stream()), "cast_to_f32")
+
+
+def axpy_f32(y, x, a, n):
+    _check(lib().mmtg_axpy_f32(_p(y), _p(x), float(a), n, _stream()), "axpy_f32")
+
+
+# ------------------------------------------------------------------ generation
+def logits_process_argmax(logits, ldl, V, generated, ldg, gen_len, temperature, rep_penalty, nxt, B):
+    _check(lib().mmtg_logits_process_argmax(_p(logits), ldl, V, _p(generated), ldg, _p(gen_len),
+                                            float(temperature), float(rep_penalty), _p(nxt), B, _stream()),
+           "logits_process_argmax")

@@ -1,0 +1,504 @@
+"""Per-kernel parity tests: every C-ABI entry point against a plain fp32
+PyTorch/oracle restatement of the same op, on the same seeded inputs.
+
+f32 mode is the exact-fp32 MFMA path (tolerances ~1e-5 relative); bf16 mode
+feeds the reference the SAME bf16-rounded inputs and allows bf16 output
+rounding (2^-8 relative) plus fp32-accumulation-order noise.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from mmtg_amd import hip  # noqa: E402
+from oracle import mmtg_oracle as O  # noqa: E402
+
+DEV = "cuda"
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def rnd(*shape, dtype=torch.float32, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(*shape, generator=g) * scale
+    return x.to(dtype)
+
+
+def tol(dtype, k=1):
+    """(atol, rtol) for an output of O(1) magnitude reduced over k terms."""
+    if dtype == torch.float32:
+        return 2e-5 * max(1.0, math.sqrt(k) / 8), 2e-5
+    return 1e-2 * max(1.0, math.sqrt(k) / 16), 1.2e-2
+
+
+def close(got, ref, dtype, k=1, name="", scale=None):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    atol, rtol = tol(dtype, k)
+    s = float(ref.abs().max()) if scale is None else scale
+    atol *= max(s, 1e-6)
+    err = (got - ref).abs()
+    bad = err > atol + rtol * ref.abs()
+    assert not bad.any(), "%s: %d/%d mismatches, max err %.3e (ref max %.3e, atol %.2e)" % (
+        name, int(bad.sum()), bad.numel(), float(err.max()), s, atol)
+
+
+# ------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("layout", ["NT", "NN", "TN"])
+@pytest.mark.parametrize("shape", [(200, 136, 96), (712, 768, 512), (1024, 256, 2048)])
+@pytest.mark.parametrize("no_tr", [0, 1])
+def test_gemm_layouts(dtype, layout, shape, no_tr):
+    if no_tr and (dtype == torch.float32 or layout == "NT"):
+        pytest.skip("scalar-gather variant only differs for bf16 K-strided operands")
+    M, N, K = shape
+    a = rnd(M, K, dtype=dtype, seed=1)
+    b = rnd(K, N, dtype=dtype, seed=2)
+    ref = a.float() @ b.float()
+    if layout == "NT":
+        A, B, tA, tB = a, b.t().contiguous(), False, True
+    elif layout == "NN":
+        A, B, tA, tB = a, b, False, False
+    else:
+        A, B, tA, tB = a.t().contiguous(), b, True, False
+    A, B = A.to(DEV), B.to(DEV)
+    flags = hip.GEMM_NO_TR if no_tr else 0
+    if layout == "TN":
+        for splits in (1, 3):
+            Cf = torch.full((M, N), 0.5, device=DEV, dtype=torch.float32)
+            hip.gemm(A, B, Cf, M, N, K, transA=tA, transB=tB, epi=hip.EPI_ATOMIC, alpha=2.0, splits=splits, flags=flags)
+            close(Cf, 0.5 + 2.0 * ref, torch.float32 if dtype == torch.float32 else dtype, K, "gemm TN splits=%d" % splits)
+    else:
+        Cm = torch.empty(M, N, device=DEV, dtype=dtype)
+        hip.gemm(A, B, Cm, M, N, K, transA=tA, transB=tB, flags=flags)
+        close(Cm, ref, dtype, K, "gemm " + layout)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_epilogues(dtype):
+    M, N, K = 300, 192, 128
+    a = rnd(M, K, dtype=dtype, seed=3).to(DEV)
+    w = rnd(N, K, dtype=dtype, seed=4, scale=0.2).to(DEV)
+    bias = rnd(N, seed=5).to(DEV)
+    aux = rnd(M, N, dtype=dtype, seed=6).to(DEV)
+    acc = a.float() @ w.float().t()
+    lin = acc + bias
+
+    def run(epi, **kw):
+        out = torch.empty(M, N, device=DEV, dtype=kw.pop("odt", dtype))
+        hip.gemm(a, w, out, M, N, K, transB=True, epi=epi, **kw)
+        return out
+
+    close(run(hip.EPI_NONE, bias=bias), lin, dtype, K, "bias")
+    close(run(hip.EPI_NONE, bias=bias, out_f32=True, odt=torch.float32), lin, torch.float32 if dtype == torch.float32 else dtype, K, "out_f32")
+    close(run(hip.EPI_TANH, bias=bias), torch.tanh(lin), dtype, K, "tanh")
+    pre = torch.empty(M, N, device=DEV, dtype=dtype)
+    close(run(hip.EPI_GELU, bias=bias, aux2=pre), O.gelu_new(lin), dtype, K, "gelu")
+    close(pre, lin, dtype, K, "gelu pre-activation")
+    close(run(hip.EPI_RESID, bias=bias, aux=aux), lin + aux.float(), dtype, K, "resid")
+    x = aux.float().requires_grad_(True)
+    O.gelu_new(x).sum().backward()
+    close(run(hip.EPI_DGELU, aux=aux), acc * x.grad, dtype, K, "dgelu")
+    close(run(hip.EPI_DTANH, aux=aux), acc * (1 - aux.float() ** 2), dtype, K, "dtanh")
+    # fused dropout: deterministic mask, ~p zeros, survivors scaled by 1/(1-p)
+    zero = torch.zeros(M, N, device=DEV, dtype=dtype)
+    d1 = run(hip.EPI_RESID, bias=bias, aux=zero, drop_p=0.25, drop_seed=7)
+    d2 = run(hip.EPI_RESID, bias=bias, aux=zero, drop_p=0.25, drop_seed=7)
+    assert torch.equal(d1, d2)
+    frac = float((d1 == 0).float().mean())
+    assert 0.2 < frac < 0.3, frac
+    keep = d1 != 0
+    close(d1[keep], (lin / 0.75)[keep], dtype, K, "dropout survivors")
+    # the standalone mask kernel reproduces the epilogue's mask
+    ones = torch.ones(M * N, device=DEV, dtype=dtype)
+    mk = torch.empty_like(ones)
+    hip.dropout_apply(ones, mk, M * N, 0.25, 7)
+    assert bool((mk.view(M, N) != 0)[keep].all())
+    assert int(((mk.view(M, N) != 0) != keep).sum()) <= 8   # only where the linear output itself rounds to 0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_weight_gradient_ragged_tokens(dtype):
+    """X^T dY with a token count (reduction length) that is no multiple of anything."""
+    Mtok, Kin, Nout = 708, 256, 384
+    x = rnd(Mtok, Kin, dtype=dtype, seed=8)
+    dy = rnd(Mtok, Nout, dtype=dtype, seed=9)
+    ref = x.float().t() @ dy.float()
+    dW = torch.zeros(Kin, Nout, device=DEV)
+    hip.gemm(x.to(DEV), dy.to(DEV), dW, Kin, Nout, Mtok, transA=True, transB=False, lda=Kin, ldb=Nout,
+             epi=hip.EPI_ATOMIC, splits=4)
+    close(dW, ref, torch.float32 if dtype == torch.float32 else dtype, Mtok, "wgrad")
+
+
+def test_gemm_rejects_bad_arguments():
+    a = torch.zeros(16, 16, device=DEV)
+    with pytest.raises(RuntimeError, match="multiple"):
+        hip.gemm(a, a, a, 16, 16, 6, transB=True, lda=16, ldb=16)
+    with pytest.raises(RuntimeError, match="atomic"):
+        hip.gemm(a, a, a, 16, 16, 16, transA=True, transB=False)
+
+
+# ------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cols", [512, 768])
+def test_layernorm(dtype, cols):
+    rows = 333
+    x = rnd(rows, cols, dtype=dtype, seed=1, scale=2.0)
+    g = 1 + 0.1 * rnd(cols, seed=2)
+    b = 0.1 * rnd(cols, seed=3)
+    dy = rnd(rows, cols, dtype=dtype, seed=4)
+    dres = rnd(rows, cols, dtype=dtype, seed=5)
+    xr = x.float().requires_grad_(True)
+    gr, br = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(xr, (cols,), gr, br, 1e-5)
+    yr.backward(dy.float())
+    xd, gd, bd = x.to(DEV), g.to(DEV), b.to(DEV)
+    y = torch.empty_like(xd)
+    mean = torch.empty(rows, device=DEV)
+    rstd = torch.empty(rows, device=DEV)
+    hip.layernorm_fwd(xd, y, gd, bd, mean, rstd, rows, cols)
+    close(y, yr, dtype, 1, "ln fwd")
+    close(mean, x.float().mean(-1), torch.float32, 1, "ln mean")
+    dx = torch.empty_like(xd)
+    dg = torch.full((cols,), 1.0, device=DEV)
+    db = torch.full((cols,), -1.0, device=DEV)
+    hip.layernorm_bwd(dy.to(DEV), xd, gd, mean, rstd, dres.to(DEV), dx, dg, db, rows, cols)
+    close(dx, xr.grad + dres.float(), dtype, 4, "ln dx")
+    close(dg - 1.0, gr.grad, torch.float32, rows, "ln dgamma")
+    close(db + 1.0, br.grad, torch.float32, rows, "ln dbeta")
+    cs = torch.zeros(cols, device=DEV)
+    hip.colsum(dy.to(DEV), rows, cols, cs)
+    close(cs, dy.float().sum(0), torch.float32, rows, "colsum")
+
+
+# ------------------------------------------------------------------ attention
+def ref_attention(qkv, keep, nH):
+    B, T, D3 = qkv.shape
+    D = D3 // 3
+    dh = D // nH
+    q, k, v = (t.view(B, T, nH, dh).transpose(1, 2) for t in qkv.split(D, -1))
+    sc = q @ k.transpose(-1, -2) / math.sqrt(dh)
+    causal = torch.tril(torch.ones(T, T, dtype=torch.bool))
+    allow = causal[None, None] & keep.bool()[:, None, None, :]
+    sc = sc.masked_fill(~allow, float("-inf"))
+    p = torch.softmax(sc, -1)
+    return (p @ v).transpose(1, 2).reshape(B, T, D), torch.logsumexp(sc, -1)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("T", [236, 104, 64, 300])
+def test_attention(dtype, T):
+    B, nH, dh = 2, 3, 64
+    D = nH * dh
+    qkv = rnd(B, T, 3 * D, dtype=dtype, seed=T, scale=1.0)
+    keep = torch.ones(B, T, dtype=torch.int32)
+    keep[0, 9:15] = 0
+    keep[1, 20:41] = 0
+    keep[1, T - 3:] = 0
+    dout = rnd(B, T, D, dtype=dtype, seed=T + 1)
+    qr = qkv.float().requires_grad_(True)
+    oref, lref = ref_attention(qr, keep, nH)
+    oref.backward(dout.float())
+    qd = qkv.to(DEV)
+    kd = keep.to(DEV)
+    out = torch.empty(B, T, D, device=DEV, dtype=dtype)
+    lse = torch.empty(B, nH, T, device=DEV)
+    hip.attn_fwd(qd, kd, out, lse, B, T, nH, dh)
+    close(out, oref, dtype, 16, "attn out")
+    close(lse, lref, torch.float32 if dtype == torch.float32 else dtype, 16, "attn lse")
+    delta = torch.empty(B, nH, T, device=DEV)
+    dq32 = torch.empty(B * T, D, device=DEV)
+    dqkv = torch.full((B, T, 3 * D), float("nan"), device=DEV, dtype=dtype)
+    hip.attn_bwd(qd, kd, out, dout.to(DEV), lse, delta, dq32, dqkv, B, T, nH, dh)
+    g = qr.grad
+    for i, nm in enumerate("qkv"):
+        close(dqkv[..., i * D:(i + 1) * D], g[..., i * D:(i + 1) * D], dtype, 64, "attn d" + nm,
+              scale=float(g.abs().max()))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_attention_dropout_consistency(dtype):
+    """Forward/backward share one counter-based mask: check against an fp32
+    reference that uses the mask recovered from a probe run (V = identity rows)."""
+    B, nH, dh, T = 1, 1, 64, 64
+    D = nH * dh
+    p = 0.3
+    qkv = rnd(B, T, 3 * D, dtype=dtype, seed=5, scale=0.5)
+    keep = torch.ones(B, T, dtype=torch.int32)
+    probe = qkv.clone()
+    probe[..., :2 * D] = 0                       # uniform attention: P = 1/(t+1)
+    probe[..., 2 * D:] = torch.eye(T, dh)        # V = I  -> out[t, j] = mask[t, j] * P / (1-p)
+    out = torch.empty(B, T, D, device=DEV, dtype=dtype)
+    lse = torch.empty(B, nH, T, device=DEV)
+    hip.attn_fwd(probe.to(DEV), keep.to(DEV), out, lse, B, T, nH, dh, drop_p=p, drop_seed=11)
+    mask = (out[0].float().cpu() != 0).float()
+    tri = torch.tril(torch.ones(T, T))
+    frac = float((mask * tri).sum() / tri.sum())
+    assert 0.6 < frac < 0.8, frac
+    qr = qkv.float().requires_grad_(True)
+    q, k, v = qr[0].split(D, -1)
+    sc = (q @ k.t()) / 8.0
+    sc = sc.masked_fill(tri == 0, float("-inf"))
+    pr = torch.softmax(sc, -1) * mask / (1 - p)
+    oref = pr @ v
+    dout = rnd(B, T, D, dtype=dtype, seed=6)
+    oref.backward(dout[0].float())
+    hip.attn_fwd(qkv.to(DEV), keep.to(DEV), out, lse, B, T, nH, dh, drop_p=p, drop_seed=11)
+    close(out[0], oref, dtype, 16, "attn dropout out")
+    delta = torch.empty(B, nH, T, device=DEV)
+    dq32 = torch.empty(B * T, D, device=DEV)
+    dqkv = torch.empty(B, T, 3 * D, device=DEV, dtype=dtype)
+    hip.attn_bwd(qkv.to(DEV), keep.to(DEV), out, dout.to(DEV), lse, delta, dq32, dqkv, B, T, nH, dh, drop_p=p, drop_seed=11)
+    close(dqkv, qr.grad, dtype, 64, "attn dropout grads")
+
+
+# ------------------------------------------------------------------ conditioning front end
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("S", [5, 2])
+def test_embed_condition_and_segment_sum(dtype, S):
+    B, P, E, V, ts = 3, 15, 2048, 160, 44
+    L = ts * S + 1
+    table = rnd(V, E, dtype=dtype, seed=1)
+    c = rnd(B, S, E, dtype=dtype, seed=2)
+    g = torch.Generator().manual_seed(3)
+    topic = torch.randint(0, V, (B, P), generator=g)
+    targ = torch.randint(0, V, (B, L), generator=g)
+    ref = O.condition_embeddings(table.float(), topic, targ, c.float(), ts)
+    x = torch.empty(B, P + L, E, device=DEV, dtype=dtype)
+    hip.embed_condition(table.to(DEV), topic.to(DEV), targ.to(DEV), c.to(DEV), x, B, P, L, S, E, ts, V)
+    close(x, ref, dtype, 1, "embed_condition")
+    H = 512
+    gr = rnd(B, P + L, H, dtype=dtype, seed=4)
+    out = torch.empty(B, S, H, device=DEV, dtype=dtype)
+    hip.segment_sum(gr.to(DEV), out, B, P, L, S, H, ts)
+    refs = torch.stack([gr.float()[:, P + k * ts:P + min((k + 1) * ts, L)].sum(1) for k in range(S)], 1)
+    close(out, refs, dtype, ts, "segment_sum")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_embed_add_fwd_bwd(dtype):
+    B, T, D, NT = 3, 104, 768, 11
+    M = B * T
+    g = rnd(M, D, dtype=dtype, seed=1)
+    wpe = rnd(256, D, dtype=dtype, seed=2)
+    wte = rnd(40, D, dtype=dtype, seed=3)
+    ty = torch.randint(0, NT, (M,), generator=torch.Generator().manual_seed(4))
+    pos = torch.arange(M) % T
+    ref = g.float() + wpe.float()[pos] + wte.float()[ty]
+    h = torch.empty(M, D, device=DEV, dtype=dtype)
+    hip.embed_add(g.to(DEV), wpe.to(DEV), wte.to(DEV), ty.to(DEV), h, M, T, D)
+    close(h, ref, dtype, 1, "embed_add")
+    dh = rnd(M, D, dtype=dtype, seed=5)
+    dwpe = torch.zeros(256, D, device=DEV)
+    dwte = torch.zeros(40, D, device=DEV)
+    hip.embed_add_bwd(dh.to(DEV), ty.to(DEV), dwpe, dwte, M, T, D, NT)
+    rp = torch.zeros(256, D).index_add_(0, pos, dh.float())
+    rt = torch.zeros(40, D).index_add_(0, ty, dh.float())
+    close(dwpe, rp, torch.float32, B, "dwpe")
+    close(dwte, rt, torch.float32, M // NT, "dwte")
+
+
+# ------------------------------------------------------------------ loss
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("stage", [1, 2])
+def test_loss_fwd_bwd(dtype, stage):
+    B, P, L, V = 5, 15, 89, 333
+    Vpad = 384
+    T = P + L
+    gen = torch.Generator().manual_seed(stage)
+    logits = torch.randn(B, T, V, generator=gen) * 2
+    logits[1] += 6 * torch.nn.functional.one_hot(torch.randint(0, V, (T,), generator=gen), V)
+    topic = torch.randint(0, V, (B, P), generator=gen)
+    targ = torch.randint(0, V, (B, L), generator=gen)
+    # make sample 1 nearly perfectly predicted so p -> 1 exercises the 1-p+eps branch
+    lab = torch.cat([topic, targ], 1)
+    logits[1, :-1] = logits[1, :-1] + 9 * torch.nn.functional.one_hot(lab[1, 1:], V)
+    ratings = torch.tensor([1, 2, 3, 5, 4])
+    lr = logits.clone().requires_grad_(True)
+    ref = O.my_loss(lr, targ, ratings, stage, P)
+    ref.backward()
+    lm_ref = O.lm_loss_shifted(logits, lab)
+    pad = torch.zeros(B * T, Vpad)
+    pad[:, :V] = logits.view(-1, V)
+    ld = pad.to(DEV)
+    nll = torch.empty(B * T, device=DEV)
+    lse = torch.empty(B * T, device=DEV)
+    ce = torch.empty(B, device=DEV)
+    coef = torch.empty(B, device=DEV)
+    sc = torch.zeros(2, device=DEV)
+    hip.loss_fwd(ld, Vpad, V, topic.to(DEV), targ.to(DEV), ratings.to(DEV), stage, False, B, P, L, float(B),
+                 nll, lse, ce, coef, sc)
+    assert abs(sc[0].item() - ref.item()) < 2e-5 * max(1, abs(ref.item())), (sc[0].item(), ref.item())
+    assert abs(sc[1].item() - lm_ref.item()) < 2e-5 * max(1, abs(lm_ref.item()))
+    close(lse.view(B, T), torch.logsumexp(logits, -1), torch.float32, 1, "lse")
+    dl = torch.full((B * T, Vpad), float("nan"), device=DEV, dtype=dtype)
+    hip.loss_bwd(ld, Vpad, V, topic.to(DEV), targ.to(DEV), lse, coef, 1.0, B, P, L, dl, Vpad, Vpad)
+    assert float(dl[:, V:].float().abs().max()) == 0.0
+    close(dl[:, :V].view(B, T, V), lr.grad, dtype, 1, "dlogits", scale=float(lr.grad.abs().max()))
+    # inference branch: dummy zero labels (model.py:314)
+    hip.loss_fwd(ld, Vpad, V, topic.to(DEV), targ.to(DEV), None, stage, True, B, P, L, float(B), nll, lse, ce, coef, sc)
+    z = O.lm_loss_shifted(logits, torch.zeros(B, T, dtype=torch.long))
+    assert abs(sc[1].item() - z.item()) < 2e-5 * abs(z.item())
+
+
+# ------------------------------------------------------------------ encoder pieces
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gru_cell(dtype):
+    B, H = 7, 512
+    gi = rnd(B, 3 * H, dtype=dtype, seed=1)
+    gh = rnd(B, 3 * H, dtype=dtype, seed=2)
+    hp = rnd(B, H, dtype=dtype, seed=3)
+    dh = rnd(B, H, seed=4)
+    gir, ghr, hpr = (t.float().requires_grad_(True) for t in (gi, gh, hp))
+    i_r, i_z, i_n = gir.chunk(3, -1)
+    h_r, h_z, h_n = ghr.chunk(3, -1)
+    r = torch.sigmoid(i_r + h_r)
+    z = torch.sigmoid(i_z + h_z)
+    n = torch.tanh(i_n + r * h_n)
+    href = (1 - z) * n + z * hpr
+    href.backward(dh)
+    h = torch.empty(B, H, device=DEV, dtype=dtype)
+    save = torch.empty(4, B, H, device=DEV)
+    hip.gru_cell_fwd(gi.to(DEV), gh.to(DEV), hp.to(DEV), h, save, B, H)
+    close(h, href, dtype, 1, "gru h")
+    dgi = torch.empty(B, 3 * H, device=DEV, dtype=dtype)
+    dgh = torch.empty(B, 3 * H, device=DEV, dtype=dtype)
+    dhp = torch.empty(B, H, device=DEV)
+    hip.gru_cell_bwd(dh.to(DEV), save, hp.to(DEV), dgi, dgh, dhp, B, H)
+    close(dgi, gir.grad, dtype, 1, "gru dgi")
+    close(dgh, ghr.grad, dtype, 1, "gru dgh")
+    close(dhp, hpr.grad, torch.float32, 1, "gru dh_prev")
+    # first step: h_prev = None means zeros
+    hip.gru_cell_fwd(gi.to(DEV), gh.to(DEV), None, h, save, B, H)
+    close(h, ((1 - z) * n).detach(), dtype, 1, "gru h (h0=0)")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("S", [5, 2, 8])
+def test_alpha_attention(dtype, S):
+    B, H, heads = 4, 512, 4
+    qkv = rnd(B * S, 3 * H, dtype=dtype, seed=S, scale=0.7)
+    dctx = rnd(B, S, H, dtype=dtype, seed=S + 1)
+    pri = O.gaussian_priors(S)
+    qr = qkv.float().requires_grad_(True)
+    q, k, v = (t.view(B, S, heads, H // heads).permute(0, 2, 1, 3) for t in qr.view(B, S, 3 * H).split(H, -1))
+    sc = q @ k.transpose(-1, -2) / math.sqrt(H // heads)
+    pr = torch.softmax(sc, -1)
+    klr = ((pri * (pri.log() - pr.log())).sum((0, 1, 3)) / B).mean()
+    cr = (pr @ v).permute(0, 2, 1, 3).reshape(B, S, H)
+    dkl = 0.37
+    ((cr * dctx.float()).sum() + dkl * klr).backward()
+    ctx = torch.empty(B * S, H, device=DEV, dtype=dtype)
+    probs = torch.empty(B, heads, S, S, device=DEV)
+    kl = torch.zeros(1, device=DEV)
+    hip.alpha_attn_fwd(qkv.to(DEV), pri.to(DEV), ctx, probs, kl, B, S, H, heads)
+    close(ctx.view(B, S, H), cr, dtype, S, "alpha ctx")
+    close(probs, pr, torch.float32 if dtype == torch.float32 else dtype, 1, "alpha probs")
+    assert abs(kl.item() - klr.item()) < (2e-5 if dtype == torch.float32 else 2e-2) * max(1, abs(klr.item()))
+    dqkv = torch.empty(B * S, 3 * H, device=DEV, dtype=dtype)
+    hip.alpha_attn_bwd(qkv.to(DEV), pri.to(DEV), probs, dctx.to(DEV), dkl, dqkv, B, S, H, heads)
+    close(dqkv, qr.grad, dtype, S * 4, "alpha dqkv")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("S", [5, 2])
+def test_beta_fuser(dtype, S):
+    B, H = 6, 512
+    topic = rnd(B, H, dtype=dtype, seed=1)
+    img = rnd(B, S, H, dtype=dtype, seed=2)
+    txt = rnd(B, S, H, dtype=dtype, seed=3)
+    aw = rnd(S, H, seed=4, scale=0.1)
+    ab = rnd(S, seed=5)
+    do = rnd(B, S, H, dtype=dtype, seed=6)
+    tr, ir, xr = (t.float().requires_grad_(True) for t in (topic, img, txt))
+    awr, abr = aw.clone().requires_grad_(True), ab.clone().requires_grad_(True)
+    outs = []
+    for i in range(S):
+        src = torch.stack([tr, ir[:, i], xr[:, i]], 1)
+        a = torch.softmax((src @ awr[i]) + abr[i], -1)
+        outs.append((a.unsqueeze(1) @ src).squeeze(1))
+    oref = torch.stack(outs, 1)
+    (oref * do.float()).sum().backward()
+    o = torch.empty(B * S, H, device=DEV, dtype=dtype)
+    a = torch.empty(B, S, 3, device=DEV)
+    args = (topic.to(DEV), img.to(DEV).view(B * S, H), txt.to(DEV).view(B * S, H), aw.to(DEV))
+    hip.beta_fuse_fwd(*args, ab.to(DEV), o, a, B, S, H)
+    close(o.view(B, S, H), oref, dtype, 1, "beta o")
+    dt_ = torch.zeros(B, H, device=DEV)
+    di = torch.empty(B * S, H, device=DEV, dtype=dtype)
+    dx = torch.empty(B * S, H, device=DEV, dtype=dtype)
+    daw = torch.zeros(S, H, device=DEV)
+    dab = torch.zeros(S, device=DEV)
+    hip.beta_fuse_bwd(*args, a, do.to(DEV).view(B * S, H), dt_, di, dx, daw, dab, B, S, H)
+    close(dt_, tr.grad, torch.float32 if dtype == torch.float32 else dtype, S, "beta dtopic")
+    close(di.view(B, S, H), ir.grad, dtype, 1, "beta dimg")
+    close(dx.view(B, S, H), xr.grad, dtype, 1, "beta dtxt")
+    close(daw, awr.grad, torch.float32 if dtype == torch.float32 else dtype, B, "beta datt_w")
+    assert float(dab.abs().max()) < 1e-4
+
+
+# ------------------------------------------------------------------ optimizer
+def test_adamw_clip_and_casts():
+    n = 100003
+    p = rnd(n, seed=1)
+    g = rnd(n, seed=2, scale=3.0)
+    pr = [p.clone()]
+    gr = [g.clone()]
+    norm = O.clip_grad_norm(gr, 1.0)
+    st = {}
+    O.adamw_hf_step(pr, gr, st, 1e-3, 1)
+    g2 = rnd(n, seed=3, scale=1e-3)
+    gr2 = [g2.clone()]
+    O.clip_grad_norm(gr2, 1.0)
+    O.adamw_hf_step(pr, gr2, st, 5e-4, 2)
+    pd, gd = p.to(DEV), g.to(DEV)
+    m = torch.zeros(n, device=DEV)
+    v = torch.zeros(n, device=DEV)
+    pc = torch.empty(n, device=DEV, dtype=torch.bfloat16)
+    ns = torch.zeros(1, device=DEV)
+    hip.sumsq(gd, n, ns)
+    assert abs(math.sqrt(ns.item()) - norm.item()) < 1e-4 * norm.item()
+    hip.adamw(pd, gd, m, v, pc, n, 1e-3, 0.9, 0.999, 1e-6, 0.0, 1, ns, 1.0)
+    ns.zero_()
+    g2d = g2.to(DEV)
+    hip.sumsq(g2d, n, ns)
+    hip.adamw(pd, g2d, m, v, pc, n, 5e-4, 0.9, 0.999, 1e-6, 0.0, 2, ns, 1.0)
+    close(pd, pr[0], torch.float32, 1, "adamw params")
+    assert torch.equal(pc.float().cpu(), pd.cpu().to(torch.bfloat16).float())
+    x = rnd(37, 50, seed=4).to(DEV)
+    y = torch.empty(37, 64, device=DEV, dtype=torch.bfloat16)
+    hip.cast_pad_rows(x, 50, y, 64, 37, 50)
+    assert torch.equal(y[:, :50], x.to(torch.bfloat16)) and float(y[:, 50:].float().abs().max()) == 0
+    z = torch.empty(37 * 64, device=DEV)
+    hip.cast_to_f32(y, z, 37 * 64)
+    assert torch.equal(z.view(37, 64), y.float())
+    a = rnd(1000, seed=5).to(DEV)
+    b = rnd(1000, seed=6).to(DEV)
+    ref = a + 0.5 * b
+    hip.axpy_f32(a, b, 0.5, 1000)
+    close(a, ref, torch.float32, 1, "axpy")
+
+
+# ------------------------------------------------------------------ generation
+def test_logits_process_argmax():
+    B, V, G = 6, 500, 40
+    gen = torch.Generator().manual_seed(0)
+    logits = torch.randn(B, 512, generator=gen) * 3
+    generated = torch.randint(3, V, (B, G), generator=gen)
+    generated[0, :10] = 7
+    generated[1, -1] = 0           # sticky PAD
+    generated[2, 5] = 102
+    lens = torch.tensor([G, G, G, 1, 17, G], dtype=torch.int32)
+    logits[0, 7] = 50.0            # heavily penalised: 50 / 1.5^10
+    logits[4, 100] = 99.0          # banned id must not win
+    nxt = torch.empty(B, dtype=torch.long, device=DEV)
+    hip.logits_process_argmax(logits.to(DEV), 512, V, generated.to(DEV), G, lens.to(DEV), 1.1, 1.5, nxt, B)
+    for b in range(B):
+        gl = generated[b, :lens[b]]
+        if gl[-1].item() == 0:
+            want = 0
+        else:
+            want = int(torch.argmax(O.process_logits(logits[b, :V], gl, 1.1, 1.5)).item())
+        assert nxt[b].item() == want, (b, nxt[b].item(), want)
