@@ -141,14 +141,16 @@ int mmtg_loss_bwd(int dtype, const float* logits, long ldl, int V, const long lo
                   int B, int P, int L, void* dlogits, long ldd, int Vpad, void* stream);
 
 /* ---------------------------------------------------------------- encoder / fuser pieces
- * GRU cell (nn.GRU math, model.py:78-79): gi,gh [B,3H] pre-activations (r|z|n),
- * h_prev [B,H] -> h [B,H]; saves r,z,n,ghn (each [B,H]) in `save` [4,B,H] f32. */
-int mmtg_gru_cell_fwd(int dtype, const void* gi, const void* gh, const void* h_prev, void* h,
-                      float* save, int B, int H, void* stream);
-/* dh: total gradient wrt h_t (f32 [B,H]); outputs dgi,dgh [B,3H] of `dtype`,
- * dh_prev (f32 [B,H]) = dh * z (caller adds dgh * W_hh).                       */
-int mmtg_gru_cell_bwd(int dtype, const float* dh, const float* save, const void* h_prev,
-                      void* dgi, void* dgh, float* dh_prev, int B, int H, void* stream);
+ * GRU cell (nn.GRU math, model.py:78-79): gi (row stride ld_gi), gh [B,3H]
+ * pre-activations (r|z|n), h_prev (row stride ld_hp; null = zeros) -> h (row
+ * stride ld_h); saves r,z,n,ghn (each [B,H]) in `save` [4,B,H] f32.  The row
+ * strides address one step of a batch-first [B,S,*] sequence in place.         */
+int mmtg_gru_cell_fwd(int dtype, const void* gi, long ld_gi, const void* gh, const void* h_prev, long ld_hp,
+                      void* h, long ld_h, float* save, int B, int H, void* stream);
+/* dh: total gradient wrt h_t (f32 [B,H]); outputs dgi (row stride ld_dgi), dgh [B,3H]
+ * of `dtype`, dh_prev (f32 [B,H]) = dh * z (caller adds dgh * W_hh).           */
+int mmtg_gru_cell_bwd(int dtype, const float* dh, const float* save, const void* h_prev, long ld_hp,
+                      void* dgi, long ld_dgi, void* dgh, float* dh_prev, int B, int H, void* stream);
 /* alpha attention (model.py:138-161): qkv [B*S, 3H] -> ctx [B*S, H], probs [B,heads,S,S] f32,
  * kl += mean_i KLDiv_batchmean(log P[:,:,i,:], prior_i); prior [S,S] f32.       */
 int mmtg_alpha_attn_fwd(int dtype, const void* qkv, const float* prior, void* ctx, float* probs,
