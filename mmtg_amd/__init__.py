@@ -1,0 +1,24 @@
+"""mmtg_amd: MI355X-native implementation of MMTG's training + generation hot path.
+
+Public surface mirrors the reference (src/model.py, src/loss.py, src/generate.py,
+src/configs.py); the computation is hand-written HIP for gfx950 behind the C ABI
+in include/mmtg_hip.h.  Importing this package never imports the oracle.
+"""
+from .configs import data_config, gpt2_config, make_model_cfgs, model_cfgs  # noqa: F401
+
+
+def __getattr__(name):
+    # torch-dependent pieces are imported lazily so that `import mmtg_amd.synth` stays light
+    if name in ("MMTG", "GPT2_Decoder", "MultiModalEncoder", "InnerModalAttentionLayer", "MultiModalAttentionLayer"):
+        from . import model
+        return getattr(model, name)
+    if name == "MyLoss":
+        from .loss import MyLoss
+        return MyLoss
+    if name in ("sample_sequence", "top_k_top_p_filtering"):
+        from . import generate
+        return getattr(generate, name)
+    if name in ("MMTGTrainer",):
+        from . import trainer
+        return getattr(trainer, name)
+    raise AttributeError(name)

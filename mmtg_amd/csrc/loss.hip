@@ -140,7 +140,7 @@ extern "C" int mmtg_loss_fwd(const float* logits, long ldl, int V, const long lo
                              const long long* targets, const long long* ratings, int stage, int label_zero,
                              int B, int P, int L, float batch_den, float* nll, float* lse, float* sample_ce,
                              float* coef, float* scalars, void* stream) {
-    MMTG_REQUIRE(B > 0 && L > 1 && P >= 0 && V > 0 && ldl >= V && ldl % 4 == 0, "loss_fwd: bad sizes (V=%d ldl=%ld)", V, ldl);
+    MMTG_REQUIRE(B > 0 && L >= 1 && P >= 0 && P + L >= 2 && V > 0 && ldl >= V && ldl % 4 == 0, "loss_fwd: bad sizes (V=%d ldl=%ld L=%d)", V, ldl, L);
     MMTG_REQUIRE(logits && targets && nll && lse && sample_ce && coef && scalars, "loss_fwd: null pointer");
     MMTG_REQUIRE(label_zero || P == 0 || topic_ids, "loss_fwd: topic_ids required");
     MMTG_REQUIRE(MMTG_ALIGNED16(logits), "loss_fwd: logits must be 16-byte aligned");
@@ -156,7 +156,7 @@ extern "C" int mmtg_loss_fwd(const float* logits, long ldl, int V, const long lo
 extern "C" int mmtg_loss_bwd(int dtype, const float* logits, long ldl, int V, const long long* topic_ids,
                              const long long* targets, const float* lse, const float* coef, float gscale, float lm_coef,
                              int B, int P, int L, void* dlogits, long ldd, int Vpad, void* stream) {
-    MMTG_REQUIRE(B > 0 && L > 1 && V > 0 && Vpad >= V && ldd >= Vpad, "loss_bwd: bad sizes");
+    MMTG_REQUIRE(B > 0 && L >= 1 && P + L >= 2 && V > 0 && Vpad >= V && ldd >= Vpad, "loss_bwd: bad sizes");
     MMTG_REQUIRE(logits && targets && lse && coef && dlogits, "loss_bwd: null pointer");
     hipStream_t s = (hipStream_t)stream;
     const long M = (long)B * (P + L);

@@ -1,0 +1,641 @@
+"""Explicit forward/backward engine of the MMTG hot path on MI355X.
+
+No autograd, no tracing compiler: the training step is a fixed sequence of
+C-ABI kernel launches (mmtg_amd.hip) over caller-owned HBM buffers.  The
+forward keeps the activations the backward needs (288 GB of HBM3E: nothing is
+recomputed except attention probabilities), the backward walks the layers in
+reverse and deposits parameter gradients into ONE flat fp32 buffer whose
+element order is the order in which gradients become final -- so contiguous
+slices of it are the all-reduce buckets of the data-parallel path
+(mmtg_amd.ddp) and can be launched while the backward is still running.
+
+Reference semantics (file:line into /root/reference/src):
+  MMTG.forward model.py:356-400, GPT2_Decoder.forward :225-327, the GPT-2
+  arithmetic of transformers 4.12.3 behind model.py:282-288, MyLoss
+  loss.py:45-74.  The oracle (oracle/mmtg_oracle.py) restates the same maths
+  and is what the tests compare this engine against.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+from . import hip
+
+ALIGN = 64  # elements; keeps every pack 16-byte aligned in both f32 and bf16
+
+
+# --------------------------------------------------------------------------
+# flat parameter layout
+# --------------------------------------------------------------------------
+class ParamLayout:
+    """Flat layout of all parameters in gradient-ready order.
+
+    ``packs`` are contiguous runs (no inner padding) so that e.g. the three
+    alpha-attention projections form one [3H, H] GEMM operand."""
+
+    def __init__(self, model_cfgs, gpt2_cfg):
+        S = model_cfgs["seq_len"]
+        E = model_cfgs["topic"]["input_dim"]
+        H = model_cfgs["topic"]["hidden_dim"]
+        D = gpt2_cfg["n_embd"]
+        V = gpt2_cfg["vocab_size"]
+        NP = gpt2_cfg["n_positions"]
+        L = gpt2_cfg["n_layer"]
+        self.Vpad = (V + 127) // 128 * 128
+        pre = "decoder.gpt2.transformer."
+        packs = []  # (pack_name, [(key, shape)], pad_tail_elems)
+        packs.append(("ln_f.w", [(pre + "ln_f.weight", (D,))], 0))
+        packs.append(("ln_f.b", [(pre + "ln_f.bias", (D,))], 0))
+        self.layer_first_pack = {}
+        for l in range(L - 1, -1, -1):
+            p = f"{pre}h.{l}."
+            self.layer_first_pack[l] = len(packs)
+            for nm, shp in (("mlp.c_proj.weight", (4 * D, D)), ("mlp.c_proj.bias", (D,)),
+                            ("mlp.c_fc.weight", (D, 4 * D)), ("mlp.c_fc.bias", (4 * D,)),
+                            ("ln_2.weight", (D,)), ("ln_2.bias", (D,)),
+                            ("attn.c_proj.weight", (D, D)), ("attn.c_proj.bias", (D,)),
+                            ("attn.c_attn.weight", (D, 3 * D)), ("attn.c_attn.bias", (3 * D,)),
+                            ("ln_1.weight", (D,)), ("ln_1.bias", (D,))):
+                packs.append((p + nm, [(p + nm, shp)], 0))
+        packs.append(("wte", [(pre + "wte.weight", (V, D))], (self.Vpad - V) * D))
+        packs.append(("wpe", [(pre + "wpe.weight", (NP, D))], 0))
+        for nm, shp in (("decoder.projector_layer2.weight", (D, H)), ("decoder.projector_layer2.bias", (D,)),
+                        ("decoder.projector_layer1.weight", (H, E)), ("decoder.projector_layer1.bias", (H,)),
+                        ("mm_atten_layer.out_linear.weight", (E, H)), ("mm_atten_layer.out_linear.bias", (E,))):
+            packs.append((nm, [(nm, shp)], 0))
+        packs.append(("att_w", [(f"mm_atten_layer.att_matrices.{i}.weight", (1, H)) for i in range(S)], 0))
+        packs.append(("att_b", [(f"mm_atten_layer.att_matrices.{i}.bias", (1,)) for i in range(S)], 0))
+        for mod in ("text", "img"):
+            m = f"{mod}_inner_atten_layer."
+            packs.append((mod + "_qkv_w", [(m + n + ".weight", (H, H)) for n in ("query", "key", "value")], 0))
+            packs.append((mod + "_qkv_b", [(m + n + ".bias", (H,)) for n in ("query", "key", "value")], 0))
+        for i in (3, 2, 1):
+            packs.append((f"ln_layer{i}.weight", [(f"ln_layer{i}.weight", (H,))], 0))
+            packs.append((f"ln_layer{i}.bias", [(f"ln_layer{i}.bias", (H,))], 0))
+        for ch in ("text", "image"):
+            r = f"encoder.rnns_{ch}."
+            for nm, shp in (("weight_ih_l0", (3 * H, E)), ("weight_hh_l0", (3 * H, H)),
+                            ("bias_ih_l0", (3 * H,)), ("bias_hh_l0", (3 * H,))):
+                packs.append((r + nm, [(r + nm, shp)], 0))
+        packs.append(("encoder.topic_fc.weight", [("encoder.topic_fc.weight", (H, E))], 0))
+        packs.append(("encoder.topic_fc.bias", [("encoder.topic_fc.bias", (H,))], 0))
+
+        self.entries = {}      # key -> (offset, shape, numel)
+        self.pack_range = {}   # pack name -> (offset, numel incl. tail pad)
+        self.pack_order = []
+        off = 0
+        for name, members, tail in packs:
+            off = (off + ALIGN - 1) // ALIGN * ALIGN
+            start = off
+            for key, shape in members:
+                n = int(np.prod(shape))
+                self.entries[key] = (off, tuple(shape), n)
+                off += n
+            off += tail
+            self.pack_range[name] = (start, off - start)
+            self.pack_order.append(name)
+        self.total = (off + ALIGN - 1) // ALIGN * ALIGN
+        self.keys = [k for _, members, _ in packs for k, _ in members]
+
+    def view(self, flat, key):
+        off, shape, n = self.entries[key]
+        return flat[off:off + n].view(shape)
+
+    def pack(self, flat, name):
+        off, n = self.pack_range[name]
+        return flat[off:off + n]
+
+    def buckets(self, bucket_elems):
+        """Contiguous [start, end) ranges of ~bucket_elems elements on pack boundaries,
+        in gradient-ready order."""
+        out, start = [], 0
+        for name in self.pack_order:
+            o, n = self.pack_range[name]
+            end = o + n
+            if end - start >= bucket_elems:
+                out.append((start, end))
+                start = end
+        if start < self.total:
+            out.append((start, self.total))
+        return out
+
+
+class Shapes:
+    def __init__(self, model_cfgs, data_cfg, gpt2_cfg):
+        self.S = model_cfgs["seq_len"]
+        self.E = model_cfgs["topic"]["input_dim"]
+        self.H = model_cfgs["topic"]["hidden_dim"]
+        self.heads = model_cfgs["SELF_ATT"]["attention_heads"]
+        self.P = data_cfg["topic_prompt_length"]
+        self.msl = data_cfg["max_sent_length"]
+        self.max_seq_length = data_cfg["max_seq_length"]
+        self.two_sents = 2 * (self.msl + 2)
+        self.D = gpt2_cfg["n_embd"]
+        self.nH = gpt2_cfg["n_head"]
+        self.L = gpt2_cfg["n_layer"]
+        self.V = gpt2_cfg["vocab_size"]
+        self.NP = gpt2_cfg["n_positions"]
+        self.eps = gpt2_cfg.get("layer_norm_epsilon", 1e-5)
+        self.pdrop = (gpt2_cfg.get("embd_pdrop", 0.1), gpt2_cfg.get("attn_pdrop", 0.1), gpt2_cfg.get("resid_pdrop", 0.1))
+        if self.D % self.nH or self.D // self.nH != 64:
+            raise ValueError("the attention kernels are built for head dim 64 (n_embd=%d, n_head=%d)" % (self.D, self.nH))
+        if model_cfgs["MM_ATT"]["attention_dim"] != 1:
+            raise ValueError("MM_ATT.attention_dim must be 1 (the reference's broadcast at model.py:200 requires it)")
+
+
+def gaussian_prior(S):
+    """q_i[j] ~ N(j; i, 1) normalised over j < S (model.py:116-120, 5 generalised to S)."""
+    j = np.arange(S, dtype=np.float64)
+    rows = []
+    for i in range(S):
+        v = np.exp(-0.5 * (j - i) ** 2) / math.sqrt(2 * math.pi)
+        v32 = v.astype(np.float64)
+        rows.append((v32 / v32.sum()).astype(np.float32))
+    return np.stack(rows)
+
+
+def _wgrad_splits(M, N, K):
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    s = max(1, min(round(512 / tiles), K // 256))
+    return int(max(1, min(s, 64)))
+
+
+# --------------------------------------------------------------------------
+class Engine:
+    """Owns the flat buffers and runs forward / loss / backward / optimizer."""
+
+    def __init__(self, model_cfgs, data_cfg, gpt2_cfg, master, table, dtype=hip.BF16):
+        hip.lib()  # fail loudly if the extension is not built
+        if not master.is_cuda:
+            raise RuntimeError("the MMTG engine runs on an MI355X (cuda) device only -- there is no CPU path")
+        self.sh = Shapes(model_cfgs, data_cfg, gpt2_cfg)
+        self.layout = ParamLayout(model_cfgs, gpt2_cfg)
+        assert master.numel() == self.layout.total and master.dtype == torch.float32
+        self.dev = master.device
+        self.dtype = dtype
+        self.tdt = hip.torch_dtype(dtype)
+        self.master = master
+        self.grad = None
+        self.wc = master if dtype == hip.F32 else torch.zeros(self.layout.total, device=self.dev, dtype=torch.bfloat16)
+        self.copies_fresh = dtype == hip.F32
+        self.set_table(table)
+        self.prior = torch.from_numpy(gaussian_prior(self.sh.S)).to(self.dev)
+        self.ws = {}
+        self.act = None
+        self.training = False
+        self.drop_seed = 0x1234
+        self.step_count = 0
+        self.opt_m = None
+        self.opt_v = None
+        self.normsq = torch.zeros(1, device=self.dev)
+        self.bucket_hook = None   # callable(pack_index) fired as packs of gradients become final
+
+    # ---------------------------------------------------------------- buffers / views
+    def set_table(self, table):
+        """WenLan token table E[V, emb] (reference: host dict token_id2emb, model.py:215,221-223)."""
+        if table is None:
+            self.table = None
+            return
+        t = torch.as_tensor(table)
+        if t.shape[1] != self.sh.E:
+            raise ValueError("token table width %d != wenlan_emb_size %d" % (t.shape[1], self.sh.E))
+        self.table32 = t.to(self.dev, torch.float32).contiguous()
+        self.table = self.table32 if self.dtype == hip.F32 else self.table32.to(torch.bfloat16)
+
+    def buf(self, name, shape, dtype=None, zero=False):
+        dtype = self.tdt if dtype is None else dtype
+        key = (name, tuple(shape), dtype)
+        t = self.ws.get(key)
+        if t is None:
+            t = torch.zeros(shape, device=self.dev, dtype=dtype) if zero else torch.empty(shape, device=self.dev, dtype=dtype)
+            self.ws[key] = t
+        elif zero:
+            t.zero_()
+        return t
+
+    def P(self, key):   # fp32 master view
+        return self.layout.view(self.master, key)
+
+    def W(self, key):   # compute-dtype weight view
+        return self.layout.view(self.wc, key)
+
+    def G(self, key):   # fp32 gradient view
+        return self.layout.view(self.grad, key)
+
+    def Wp(self, pack):
+        return self.layout.pack(self.wc, pack)
+
+    def Pp(self, pack):
+        return self.layout.pack(self.master, pack)
+
+    def Gp(self, pack):
+        return self.layout.pack(self.grad, pack)
+
+    def ensure_grad(self):
+        if self.grad is None:
+            self.grad = torch.zeros(self.layout.total, device=self.dev, dtype=torch.float32)
+
+    def zero_grad(self):
+        self.ensure_grad()
+        self.grad.zero_()
+
+    def refresh_copies(self):
+        """bf16 mode: re-derive the GEMM weight copies from the fp32 masters (an
+        external optimizer may have updated them).  654 MB of traffic, ~0.15 ms."""
+        if self.dtype != hip.F32 and not self.copies_fresh:
+            hip.cast_f32_to(self.master, self.wc, self.layout.total)
+            self.copies_fresh = True
+
+    def invalidate_copies(self):
+        if self.dtype != hip.F32:
+            self.copies_fresh = False
+
+    # ---------------------------------------------------------------- GEMM helpers
+    def _fwd(self, x, wkey, out, M, kind, bias=None, lda=None, **kw):
+        """out[M,out] = x[M,in] W (+bias).  kind: 'linear' = [out,in], 'conv1d' = [in,out]."""
+        w = self.W(wkey)
+        if kind == "linear":
+            N, K = w.shape
+            hip.gemm(x, w, out, M, N, K, transB=True, lda=lda, ldb=K, bias=bias, **kw)
+        else:
+            K, N = w.shape
+            hip.gemm(x, w, out, M, N, K, transB=False, lda=lda, ldb=N, bias=bias, **kw)
+
+    def _dgrad(self, dy, wkey, dx, M, kind, **kw):
+        w = self.W(wkey)
+        if kind == "linear":
+            K, N = w.shape   # dy [M,out=K] @ W[out,in] -> [M,in=N]
+            hip.gemm(dy, w, dx, M, N, K, transB=False, ldb=N, **kw)
+        else:
+            N, K = w.shape   # dy [M,out=K] @ W[in,out]^T -> [M,in=N]
+            hip.gemm(dy, w, dx, M, N, K, transB=True, ldb=K, **kw)
+
+    def _wgrad(self, x, dy, wkey, bkey, Mtok, kind, ldx=None, ldy=None, bias_rows=None):
+        gw = self.G(wkey)
+        if kind == "linear":
+            out_f, in_f = gw.shape
+            hip.gemm(dy, x, gw, out_f, in_f, Mtok, transA=True, transB=False, lda=ldy or out_f, ldb=ldx or in_f,
+                     ldc=in_f, epi=hip.EPI_ATOMIC, splits=_wgrad_splits(out_f, in_f, Mtok))
+        else:
+            in_f, out_f = gw.shape
+            hip.gemm(x, dy, gw, in_f, out_f, Mtok, transA=True, transB=False, lda=ldx or in_f, ldb=ldy or out_f,
+                     ldc=out_f, epi=hip.EPI_ATOMIC, splits=_wgrad_splits(in_f, out_f, Mtok))
+        if bkey is not None:
+            hip.colsum(dy, Mtok if bias_rows is None else bias_rows, out_f, self.G(bkey), ldx=ldy or out_f)
+
+    # ---------------------------------------------------------------- forward
+    def _cast_in(self, t, name):
+        """Batch embeddings arrive f64/f32 (model.py:371-373 calls .float()); store in compute dtype."""
+        t = t.to(self.dev, torch.float32).contiguous()
+        if self.dtype == hip.F32:
+            return t
+        out = self.buf(name, t.shape)
+        hip.cast_f32_to(t, out, t.numel())
+        return out
+
+    def forward(self, batch, train_flag=True, training=False, per_row_infer=True, need_logits=True):
+        """MMTG.forward (model.py:356-400).  Returns dict(logits_pad [M,Vpad] f32, B, T, ...);
+        lm_loss / kl are device scalars in self.scalars after loss()."""
+        sh, dt = self.sh, self.dtype
+        if self.table is None:
+            raise RuntimeError("no WenLan token table set (vocab/token_id2emb_dict.pkl or set_token_table())")
+        self.refresh_copies()
+        self.training = training
+        pe, pa, pr = sh.pdrop if training else (0.0, 0.0, 0.0)
+        self.drop_seed = (self.drop_seed * 1664525 + 1013904223) & 0xFFFFFFFF
+        seed = self.drop_seed
+        S, E, H, D, P = sh.S, sh.E, sh.H, sh.D, sh.P
+        img = batch["img_embs"]
+        B = img.shape[0]
+        if img.shape[1] != S:
+            raise ValueError("batch has %d experience steps, model_cfgs['seq_len'] = %d" % (img.shape[1], S))
+        targets = batch["targets"].to(self.dev, torch.long).contiguous()
+        topic_ids = batch["topic_ids"].to(self.dev, torch.long).contiguous()
+        L = targets.shape[1]
+        T = P + L
+        M = B * T
+        if T > sh.NP:
+            raise ValueError("sequence length %d exceeds n_positions %d" % (T, sh.NP))
+        a = {"B": B, "L": L, "T": T, "M": M, "seed": seed, "pdrop": (pe, pa, pr), "train_flag": train_flag,
+             "targets": targets, "topic_ids": topic_ids}
+
+        # ---------------- encoder: topic_fc + 2 GRUs (model.py:63-81) + ln_layer1..3 (:380-382)
+        xt = self._cast_in(batch["topic_emb"], "xt")
+        xi = self._cast_in(img, "xi").view(B * S, E)
+        xr = self._cast_in(batch["r_embs"], "xr").view(B * S, E)
+        t_raw = self.buf("t_raw", (B, H))
+        self._fwd(xt, "encoder.topic_fc.weight", t_raw, B, "linear", bias=self.P("encoder.topic_fc.bias"))
+        t_ln = self.buf("t_ln", (B, H))
+        st = {}
+        st["ln1"] = (self.buf("ln1_mu", (B,), torch.float32), self.buf("ln1_rs", (B,), torch.float32))
+        hip.layernorm_fwd(t_raw, t_ln, self.P("ln_layer1.weight"), self.P("ln_layer1.bias"), *st["ln1"], B, H)
+        zeros_h = self.buf("zeros_h", (B, H), zero=True)
+        gh = self.buf("gh", (B, 3 * H))
+        enc = {}
+        for ch, x, lnk in (("image", xi, "ln_layer2"), ("text", xr, "ln_layer3")):
+            r = f"encoder.rnns_{ch}."
+            gi = self.buf("gi_" + ch, (B * S, 3 * H))
+            self._fwd(x, r + "weight_ih_l0", gi, B * S, "linear", bias=self.P(r + "bias_ih_l0"))
+            h_all = self.buf("h_" + ch, (B * S, H))
+            save = self.buf("gru_save_" + ch, (S, 4, B, H), torch.float32)
+            for t in range(S):
+                hp = zeros_h if t == 0 else h_all[t - 1:]
+                self._fwd(hp, r + "weight_hh_l0", gh, B, "linear", bias=self.P(r + "bias_hh_l0"),
+                          lda=H if t == 0 else S * H)
+                hip.gru_cell_fwd(gi[t:], gh, None if t == 0 else h_all[t - 1:], h_all[t:], save[t], B, H,
+                                 ld_gi=S * 3 * H, ld_hp=S * H, ld_h=S * H)
+            h_ln = self.buf("hln_" + ch, (B * S, H))
+            st[lnk] = (self.buf(lnk + "_mu", (B * S,), torch.float32), self.buf(lnk + "_rs", (B * S,), torch.float32))
+            hip.layernorm_fwd(h_all, h_ln, self.P(lnk + ".weight"), self.P(lnk + ".bias"), *st[lnk], B * S, H)
+            enc[ch] = (x, gi, h_all, save, h_ln)
+
+        # ---------------- alpha attention (model.py:133-161) on batch-first rows b*S+i
+        kl = self.buf("kl", (1,), torch.float32, zero=True)
+        alpha = {}
+        for mod, ch in (("img", "image"), ("text", "text")):
+            h_ln = enc[ch][4]
+            qkv = self.buf("aqkv_" + mod, (B * S, 3 * H))
+            hip.gemm(h_ln, self.Wp(mod + "_qkv_w"), qkv, B * S, 3 * H, H, transB=True, ldb=H, bias=self.Pp(mod + "_qkv_b"))
+            ctx = self.buf("actx_" + mod, (B * S, H))
+            probs = self.buf("aprobs_" + mod, (B, sh.heads, S, S), torch.float32)
+            hip.alpha_attn_fwd(qkv, self.prior, ctx, probs, kl, B, S, H, sh.heads)
+            alpha[mod] = (qkv, ctx, probs)
+
+        # ---------------- beta fuser (model.py:181-202) -> c [B,S,E]
+        o = self.buf("beta_o", (B * S, H))
+        ba = self.buf("beta_a", (B, S, 3), torch.float32)
+        hip.beta_fuse_fwd(t_ln, alpha["img"][1], alpha["text"][1], self.Pp("att_w"), self.Pp("att_b"), o, ba, B, S, H)
+        c = self.buf("c", (B * S, E))
+        self._fwd(o, "mm_atten_layer.out_linear.weight", c, B * S, "linear", bias=self.P("mm_atten_layer.out_linear.bias"))
+
+        # ---------------- decoder front end (model.py:251-281) + GPT-2 input embedding
+        x = self.buf("x_cond", (M, E))
+        hip.embed_condition(self.table, topic_ids, targets, c, x, B, P, L, S, E, sh.two_sents, self.table.shape[0])
+        if train_flag:
+            type_ids = torch.cat([batch["tpw_type_ids"].to(self.dev).long(), batch["type_ids"].to(self.dev).long()], 1)
+            keep = torch.cat([batch["tpw_attention_mask"].to(self.dev), batch["attention_mask"].to(self.dev)], 1)
+        else:
+            type_ids, keep = self._infer_types_mask(batch, targets, per_row_infer)
+        type_ids = type_ids.contiguous().view(-1)
+        keep = (keep != 0).to(torch.int32).contiguous()
+        h1 = self.buf("h1", (M, H))
+        self._fwd(x, "decoder.projector_layer1.weight", h1, M, "linear", bias=self.P("decoder.projector_layer1.bias"),
+                  epi=hip.EPI_TANH)
+        hcur = self.buf("resid_0", (M, D))
+        self._fwd(h1, "decoder.projector_layer2.weight", hcur, M, "linear", bias=self.P("decoder.projector_layer2.bias"))
+        pre = "decoder.gpt2.transformer."
+        hip.embed_add(hcur, self.W(pre + "wpe.weight"), self.W(pre + "wte.weight"), type_ids, hcur, M, T, D,
+                      drop_p=pe, drop_seed=seed)
+
+        # ---------------- GPT-2 blocks
+        layers = []
+        for l in range(sh.L):
+            p = f"{pre}h.{l}."
+            s = seed + 97 * (l + 1)
+            mu1 = self.buf(f"l{l}_mu1", (M,), torch.float32)
+            rs1 = self.buf(f"l{l}_rs1", (M,), torch.float32)
+            a1 = self.buf(f"l{l}_a", (M, D))
+            hip.layernorm_fwd(hcur, a1, self.P(p + "ln_1.weight"), self.P(p + "ln_1.bias"), mu1, rs1, M, D, sh.eps)
+            qkv = self.buf(f"l{l}_qkv", (M, 3 * D))
+            self._fwd(a1, p + "attn.c_attn.weight", qkv, M, "conv1d", bias=self.P(p + "attn.c_attn.bias"))
+            ctx = self.buf(f"l{l}_ctx", (M, D))
+            lse = self.buf(f"l{l}_lse", (B, sh.nH, T), torch.float32)
+            hip.attn_fwd(qkv, keep, ctx, lse, B, T, sh.nH, D // sh.nH, drop_p=pa, drop_seed=s)
+            xmid = self.buf(f"l{l}_xmid", (M, D))
+            self._fwd(ctx, p + "attn.c_proj.weight", xmid, M, "conv1d", bias=self.P(p + "attn.c_proj.bias"),
+                      epi=hip.EPI_RESID, aux=hcur, ldaux=D, drop_p=pr, drop_seed=s + 1)
+            mu2 = self.buf(f"l{l}_mu2", (M,), torch.float32)
+            rs2 = self.buf(f"l{l}_rs2", (M,), torch.float32)
+            m2 = self.buf(f"l{l}_m", (M, D))
+            hip.layernorm_fwd(xmid, m2, self.P(p + "ln_2.weight"), self.P(p + "ln_2.bias"), mu2, rs2, M, D, sh.eps)
+            u = self.buf(f"l{l}_u", (M, 4 * D))
+            gact = self.buf(f"l{l}_g", (M, 4 * D))
+            self._fwd(m2, p + "mlp.c_fc.weight", gact, M, "conv1d", bias=self.P(p + "mlp.c_fc.bias"),
+                      epi=hip.EPI_GELU, aux2=u)
+            xout = self.buf(f"resid_{l + 1}", (M, D))
+            self._fwd(gact, p + "mlp.c_proj.weight", xout, M, "conv1d", bias=self.P(p + "mlp.c_proj.bias"),
+                      epi=hip.EPI_RESID, aux=xmid, ldaux=D, drop_p=pr, drop_seed=s + 2)
+            layers.append((hcur, mu1, rs1, a1, qkv, ctx, lse, xmid, mu2, rs2, m2, u, gact, s))
+            hcur = xout
+        muf = self.buf("lnf_mu", (M,), torch.float32)
+        rsf = self.buf("lnf_rs", (M,), torch.float32)
+        hf = self.buf("hf", (M, D))
+        hip.layernorm_fwd(hcur, hf, self.P(pre + "ln_f.weight"), self.P(pre + "ln_f.bias"), muf, rsf, M, D, sh.eps)
+        Vp = self.layout.Vpad
+        logits = self.buf("logits", (M, Vp), torch.float32)
+        hip.gemm(hf, self.Wp("wte"), logits, M, Vp, D, transB=True, ldb=D, out_f32=True)
+        a.update(xt=xt, t_raw=t_raw, t_ln=t_ln, st=st, enc=enc, alpha=alpha, kl=kl, o=o, ba=ba, c=c, x=x, h1=h1,
+                 type_ids=type_ids, keep=keep, layers=layers, x_last=hcur, muf=muf, rsf=rsf, hf=hf, logits=logits)
+        self.act = a
+        return a
+
+    def _infer_types_mask(self, batch, targets, per_row):
+        """Inference branch of GPT2_Decoder.forward (model.py:290-312), vectorised: lyric
+        position i has type 0 if (i+1) % sent in {0,1} or the token is PAD, else
+        [1..max_sent_num-1, 1][i // sent]; mask 0 on PAD.  The reference decides from row 0
+        only (batch 1); per_row=True applies the rule to every row (batched decode)."""
+        sh = self.sh
+        sent = sh.msl + 2
+        n = targets.shape[1]
+        Bn = targets.shape[0]
+        src = targets if per_row else targets[:1].expand(Bn, n)
+        tlist = list(range(1, sh.max_seq_length // sent + 1)) + [1]
+        idx = torch.arange(n, device=self.dev)
+        slot = torch.tensor([tlist[min(i // sent, len(tlist) - 1)] for i in range(n)], device=self.dev, dtype=torch.long)
+        edge = ((idx + 1) % sent == 0) | ((idx + 1) % sent == 1)
+        is_pad = src == 0
+        types = torch.where(edge[None, :] | is_pad, torch.zeros_like(src), slot[None, :].expand(Bn, n))
+        mask = (~is_pad).long()
+        return (torch.cat([batch["tpw_type_ids"].to(self.dev).long(), types], 1),
+                torch.cat([batch["tpw_attention_mask"].to(self.dev).long(), mask], 1))
+
+    # ---------------------------------------------------------------- loss
+    def loss(self, ratings=None, stage=3, batch_den=None, label_zero=False):
+        """MyLoss (loss.py:45-74) + GPT-2's internal LM loss on the forward's logits.
+        scalars[0] = MyLoss, scalars[1] = LM loss; also fills coef for loss_backward()."""
+        a, sh = self.act, self.sh
+        B, L, M = a["B"], a["L"], a["M"]
+        nll = self.buf("nll", (M,), torch.float32)
+        lse = self.buf("lse_rows", (M,), torch.float32)
+        ce = self.buf("sample_ce", (B,), torch.float32)
+        coef = self.buf("coef", (B,), torch.float32)
+        sc = self.buf("loss_scalars", (2,), torch.float32)
+        r = None if ratings is None else ratings.to(self.dev, torch.long).contiguous()
+        hip.loss_fwd(a["logits"], self.layout.Vpad, sh.V, a["topic_ids"], a["targets"], r, stage, label_zero,
+                     B, sh.P, L, float(B if batch_den is None else batch_den), nll, lse, ce, coef, sc)
+        a.update(nll=nll, lse_rows=lse, coef=coef, scalars=sc)
+        return sc
+
+    def loss_backward(self, gscale=1.0, lm_coef=0.0):
+        """d(gscale * MyLoss + lm_scale * LM loss)/d logits into the engine's dlogits buffer."""
+        a, sh = self.act, self.sh
+        dl = self.buf("dlogits", (a["M"], self.layout.Vpad))
+        hip.loss_bwd(a["logits"], self.layout.Vpad, sh.V, a["topic_ids"], a["targets"], a["lse_rows"], a["coef"],
+                     gscale, a["B"], sh.P, a["L"], dl, self.layout.Vpad, self.layout.Vpad, lm_coef=lm_coef)
+        return dl
+
+    def dlogits_from(self, g32):
+        """External d(logits) [B,T,V] fp32 (drop-in autograd path) -> padded compute-dtype buffer."""
+        a = self.act
+        dl = self.buf("dlogits", (a["M"], self.layout.Vpad))
+        g32 = g32.contiguous().view(a["M"], self.sh.V)
+        hip.cast_pad_rows(g32, self.sh.V, dl, self.layout.Vpad, a["M"], self.sh.V)
+        return dl
+
+    # ---------------------------------------------------------------- backward
+    def _ready(self, pack):
+        if self.bucket_hook is not None:
+            self.bucket_hook(pack)
+
+    def backward(self, dlogits, dkl=0.0):
+        """Back-propagate d(logits) [M,Vpad] (compute dtype) and d(kl) through the whole
+        model; parameter gradients are ACCUMULATED into the flat fp32 buffer."""
+        a, sh = self.act, self.sh
+        self.ensure_grad()
+        B, T, M, L = a["B"], a["T"], a["M"], a["L"]
+        S, E, H, D, P = sh.S, sh.E, sh.H, sh.D, sh.P
+        pe, pa, pr = a["pdrop"]
+        Vp = self.layout.Vpad
+        pre = "decoder.gpt2.transformer."
+        # ---- LM head (tied wte)
+        dhf = self.buf("d_hf", (M, D))
+        hip.gemm(dlogits, self.Wp("wte"), dhf, M, D, Vp, transB=False, ldb=D)
+        # (Vpad rows: the pad columns of dlogits are zero, so the pad rows of the pack receive +0)
+        hip.gemm(dlogits, a["hf"], self.Gp("wte"), Vp, D, M, transA=True, transB=False, lda=Vp, ldb=D, ldc=D,
+                 epi=hip.EPI_ATOMIC, splits=_wgrad_splits(Vp, D, M))
+        dx = self.buf("d_resid_a", (M, D))
+        hip.layernorm_bwd(dhf, a["x_last"], self.P(pre + "ln_f.weight"), a["muf"], a["rsf"], None, dx,
+                          self.G(pre + "ln_f.weight"), self.G(pre + "ln_f.bias"), M, D)
+        self._ready("ln_f.b")
+        dx2 = self.buf("d_resid_b", (M, D))
+        dmask = self.buf("d_masked", (M, D)) if pr > 0 else None
+        du = self.buf("d_u", (M, 4 * D))
+        dm = self.buf("d_m", (M, D))
+        dctx = self.buf("d_ctx", (M, D))
+        dqkv = self.buf("d_qkv", (M, 3 * D))
+        da = self.buf("d_a", (M, D))
+        delta = self.buf("attn_delta", (B, sh.nH, T), torch.float32)
+        dq32 = self.buf("attn_dq32", (M, D), torch.float32)
+        for l in range(sh.L - 1, -1, -1):
+            p = f"{pre}h.{l}."
+            (xin, mu1, rs1, a1, qkv, ctx, lse, xmid, mu2, rs2, m2, u, gact, s) = a["layers"][l]
+            # x_out = x_mid + drop(gact W2 + b2)
+            dy = dx
+            if pr > 0:
+                hip.dropout_apply(dx, dmask, M * D, pr, s + 2)
+                dy = dmask
+            self._dgrad(dy, p + "mlp.c_proj.weight", du, M, "conv1d", epi=hip.EPI_DGELU, aux=u, ldaux=4 * D)
+            self._wgrad(gact, dy, p + "mlp.c_proj.weight", p + "mlp.c_proj.bias", M, "conv1d")
+            self._dgrad(du, p + "mlp.c_fc.weight", dm, M, "conv1d")
+            self._wgrad(m2, du, p + "mlp.c_fc.weight", p + "mlp.c_fc.bias", M, "conv1d")
+            hip.layernorm_bwd(dm, xmid, self.P(p + "ln_2.weight"), mu2, rs2, dx, dx2,
+                              self.G(p + "ln_2.weight"), self.G(p + "ln_2.bias"), M, D)
+            # x_mid = x_in + drop(ctx Wp + bp)
+            dy = dx2
+            if pr > 0:
+                hip.dropout_apply(dx2, dmask, M * D, pr, s + 1)
+                dy = dmask
+            self._dgrad(dy, p + "attn.c_proj.weight", dctx, M, "conv1d")
+            self._wgrad(ctx, dy, p + "attn.c_proj.weight", p + "attn.c_proj.bias", M, "conv1d")
+            hip.attn_bwd(qkv, a["keep"], ctx, dctx, lse, delta, dq32, dqkv, B, T, sh.nH, D // sh.nH,
+                         drop_p=pa, drop_seed=s)
+            self._dgrad(dqkv, p + "attn.c_attn.weight", da, M, "conv1d")
+            self._wgrad(a1, dqkv, p + "attn.c_attn.weight", p + "attn.c_attn.bias", M, "conv1d")
+            hip.layernorm_bwd(da, xin, self.P(p + "ln_1.weight"), mu1, rs1, dx2, dx,
+                              self.G(p + "ln_1.weight"), self.G(p + "ln_1.bias"), M, D)
+            self._ready(p + "ln_1.bias")
+        # ---- GPT-2 input embedding: h0 = drop(g + wpe + wte[type])
+        hip.embed_add_bwd(dx, a["type_ids"], self.G(pre + "wpe.weight"), self.G(pre + "wte.weight"), M, T, D,
+                          min(32, sh.V), drop_p=pe, drop_seed=a["seed"])
+        self._ready("wpe")
+        # ---- projector (model.py:279-281)
+        dh1 = self.buf("d_h1", (M, H))
+        self._dgrad(dx, "decoder.projector_layer2.weight", dh1, M, "linear", epi=hip.EPI_DTANH, aux=a["h1"], ldaux=H)
+        self._wgrad(a["h1"], dx, "decoder.projector_layer2.weight", "decoder.projector_layer2.bias", M, "linear")
+        self._wgrad(a["x"], dh1, "decoder.projector_layer1.weight", "decoder.projector_layer1.bias", M, "linear")
+        # d c[b,k] = (sum over the segment's tokens of d h1_pre) W1   (the add is linear)
+        seg = self.buf("d_seg", (B * S, H))
+        hip.segment_sum(dh1, seg, B, P, L, S, H, sh.two_sents)
+        dc = self.buf("d_c", (B * S, E))
+        self._dgrad(seg, "decoder.projector_layer1.weight", dc, B * S, "linear")
+        # ---- beta fuser
+        do = self.buf("d_o", (B * S, H))
+        self._dgrad(dc, "mm_atten_layer.out_linear.weight", do, B * S, "linear")
+        self._wgrad(a["o"], dc, "mm_atten_layer.out_linear.weight", "mm_atten_layer.out_linear.bias", B * S, "linear")
+        dtopic = self.buf("d_topic32", (B, H), torch.float32, zero=True)
+        dci = self.buf("d_actx_img", (B * S, H))
+        dct = self.buf("d_actx_text", (B * S, H))
+        hip.beta_fuse_bwd(a["t_ln"], a["alpha"]["img"][1], a["alpha"]["text"][1], self.Pp("att_w"), a["ba"], do,
+                          dtopic, dci, dct, self.Gp("att_w"), self.Gp("att_b"), B, S, H)
+        self._ready("att_b")
+        # ---- alpha attention + LayerNorm + GRU per modality
+        dh32 = self.buf("d_h32", (B, H), torch.float32)
+        dhp32 = self.buf("d_hp32", (B, H), torch.float32)
+        tmp32 = self.buf("d_tmp32", (B, H), torch.float32)
+        row32 = self.buf("d_row32", (B * S, H), torch.float32)
+        dgh = self.buf("d_gh", (B, 3 * H))
+        for mod, ch, lnk, dctx_a in (("text", "text", "ln_layer3", dct), ("img", "image", "ln_layer2", dci)):
+            qkv_a, ctx_a, probs = a["alpha"][mod]
+            x_in, gi, h_all, save, h_ln = a["enc"][ch]
+            dqkv_a = self.buf("d_aqkv", (B * S, 3 * H))
+            hip.alpha_attn_bwd(qkv_a, self.prior, probs, dctx_a, dkl, dqkv_a, B, S, H, sh.heads)
+            dhln = self.buf("d_hln", (B * S, H))
+            hip.gemm(dqkv_a, self.Wp(mod + "_qkv_w"), dhln, B * S, H, 3 * H, transB=False, ldb=H)
+            hip.gemm(dqkv_a, h_ln, self.Gp(mod + "_qkv_w"), 3 * H, H, B * S, transA=True, transB=False, lda=3 * H,
+                     ldb=H, ldc=H, epi=hip.EPI_ATOMIC, splits=1)
+            hip.colsum(dqkv_a, B * S, 3 * H, self.Gp(mod + "_qkv_b"))
+            dh_all = self.buf("d_hall", (B * S, H))
+            hip.layernorm_bwd(dhln, h_all, self.P(lnk + ".weight"), *a["st"][lnk], None, dh_all,
+                              self.G(lnk + ".weight"), self.G(lnk + ".bias"), B * S, H)
+            # BPTT over the S steps (rows b*S+t)
+            r = f"encoder.rnns_{ch}."
+            hip.cast_to_f32(dh_all, row32, B * S * H)
+            dgi = self.buf("d_gi", (B * S, 3 * H))
+            row3 = row32.view(B, S, H)
+            for t in range(S - 1, -1, -1):
+                # total gradient wrt h_t = LN path (row b*S+t) + carry from step t+1
+                self._gather_rows(row3, t, dh32)
+                if t < S - 1:
+                    hip.axpy_f32(dh32, dhp32, 1.0, B * H)
+                    hip.axpy_f32(dh32, tmp32, 1.0, B * H)
+                hip.gru_cell_bwd(dh32, save[t], None if t == 0 else h_all[t - 1:], dgi[t:], dgh, dhp32, B, H,
+                                 ld_hp=S * H, ld_dgi=S * 3 * H)
+                hip.colsum(dgh, B, 3 * H, self.G(r + "bias_hh_l0"))
+                if t > 0:
+                    hip.gemm(dgh, self.W(r + "weight_hh_l0"), tmp32, B, H, 3 * H, transB=False, ldb=H, out_f32=True)
+                    hip.gemm(dgh, h_all[t - 1:], self.G(r + "weight_hh_l0"), 3 * H, H, B, transA=True, transB=False,
+                             lda=3 * H, ldb=S * H, ldc=H, epi=hip.EPI_ATOMIC, splits=1)
+            self._wgrad(x_in, dgi, r + "weight_ih_l0", r + "bias_ih_l0", B * S, "linear")
+        # ---- topic channel
+        dt_ln = self.buf("d_tln", (B, H))
+        hip.cast_f32_to(dtopic, dt_ln, B * H)
+        dt_raw = self.buf("d_traw", (B, H))
+        hip.layernorm_bwd(dt_ln, a["t_raw"], self.P("ln_layer1.weight"), *a["st"]["ln1"], None, dt_raw,
+                          self.G("ln_layer1.weight"), self.G("ln_layer1.bias"), B, H)
+        self._wgrad(a["xt"], dt_raw, "encoder.topic_fc.weight", "encoder.topic_fc.bias", B, "linear")
+        self._ready("encoder.topic_fc.bias")
+
+    def _gather_rows(self, row3, t, out):
+        """out[b,:] = row3[b,t,:] -- strided device-to-device copy (data movement only)."""
+        out.copy_(row3[:, t, :])
+
+    # ---------------------------------------------------------------- optimizer (train.py:194-197)
+    def grad_norm_sq(self):
+        self.normsq.zero_()
+        hip.sumsq(self.grad, self.layout.total, self.normsq)
+        return self.normsq
+
+    def adamw_step(self, lr, max_norm=1.0, betas=(0.9, 0.999), eps=1e-6, wd=0.0, grad_scale=1.0, clip=True):
+        """clip_grad_norm_(1.0) + transformers.AdamW(lr, eps=1e-6, wd=0) over the flat buffers,
+        refreshing the bf16 weight copies in the same pass."""
+        if self.opt_m is None:
+            self.opt_m = torch.zeros_like(self.master)
+            self.opt_v = torch.zeros_like(self.master)
+        self.step_count += 1
+        ns = self.grad_norm_sq() if clip else None
+        hip.adamw(self.master, self.grad, self.opt_m, self.opt_v, None if self.dtype == hip.F32 else self.wc,
+                  self.layout.total, lr, betas[0], betas[1], eps, wd, self.step_count, ns, max_norm, grad_scale)
+        self.copies_fresh = True

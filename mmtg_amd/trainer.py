@@ -1,0 +1,83 @@
+"""Fused training step: the hot loop of the reference's src/train.py:177-200 as one
+host-sync-free sequence of HIP kernel launches.
+
+    filter rows by curriculum stage  -> forward -> MyLoss (+ alpha * KL) -> backward
+    -> bucketed RCCL all-reduce (overlapped) -> clip_grad_norm_(1.0) + AdamW + LR schedule
+
+Optimizer semantics are transformers.AdamW as train.py:137 constructs it
+(betas .9/.999, eps 1e-6, weight_decay 0, bias-corrected) with
+get_linear_schedule_with_warmup (train.py:146-148).
+"""
+from __future__ import annotations
+
+import torch
+
+from .ddp import GradReducer
+
+
+def curriculum_filter(ratings, stage):
+    """Row selection + order of train.py:178-183 (negatives first)."""
+    r = torch.as_tensor(ratings)
+    if stage == 1:
+        return torch.cat([torch.where(r < 2)[0], torch.where(r > 4)[0]])
+    if stage == 2:
+        return torch.cat([torch.where(r < 3)[0], torch.where(r > 3)[0]])
+    return torch.arange(len(r), device=r.device)
+
+
+def linear_schedule(step, warmup, total):
+    """LR multiplier of get_linear_schedule_with_warmup after `step` scheduler steps."""
+    if step < warmup:
+        return step / max(1, warmup)
+    return max(0.0, (total - step) / max(1, total - warmup))
+
+
+class MMTGTrainer:
+    def __init__(self, model, lr=1e-5, alpha=0.0, max_norm=1.0, betas=(0.9, 0.999), eps=1e-6,
+                 weight_decay=0.0, warmup_steps=0, total_steps=None, distributed=False, bucket_mb=64.0,
+                 lm_weight=0.0):
+        self.model = model
+        self.eng = model.engine()
+        self.lr, self.alpha, self.max_norm = lr, alpha, max_norm
+        self.betas, self.eps, self.wd = betas, eps, weight_decay
+        self.warmup, self.total = warmup_steps, total_steps
+        self.sched_step = 0
+        self.lm_weight = lm_weight
+        self.reducer = GradReducer(self.eng.layout, bucket_mb) if distributed else None
+        if self.reducer is not None:
+            self.eng.bucket_hook = lambda pack: self.reducer.on_pack_ready(self.eng.grad, pack)
+
+    def current_lr(self):
+        if self.total is None:
+            return self.lr
+        return self.lr * linear_schedule(self.sched_step, self.warmup, self.total)
+
+    def step(self, batch, stage=3, filter_rows=True):
+        """One optimisation step; returns device scalars (no host sync) {'loss','lm_loss','kl'}.
+        Returns None when the stage filter leaves no rows on a single rank (train.py:184-185)."""
+        eng = self.eng
+        if filter_rows and stage in (1, 2):
+            idx = curriculum_filter(batch["rating"], stage)
+            batch = {k: v[idx.to(v.device)] for k, v in batch.items()}
+        n_local = int(batch["rating"].shape[0]) if "rating" in batch else int(batch["targets"].shape[0])
+        world = self.reducer.world if self.reducer is not None else 1
+        if self.reducer is not None and filter_rows and stage in (1, 2):
+            n_global = self.reducer.global_count(n_local, eng.dev)
+        else:
+            n_global = n_local * world
+        if n_global == 0:
+            return None
+        eng.zero_grad()
+        out = None
+        if n_local > 0:
+            eng.forward(batch, train_flag=True, training=self.model.training)
+            sc = eng.loss(batch["rating"], stage, batch_den=n_global)
+            B, T = eng.act["B"], eng.act["T"]
+            dl = eng.loss_backward(1.0, lm_coef=self.lm_weight / (B * (T - 1)) if self.lm_weight else 0.0)
+            eng.backward(dl, dkl=self.alpha * n_local / n_global)
+            out = {"loss": sc[0], "lm_loss": sc[1], "kl": eng.act["kl"][0]}
+        if self.reducer is not None:
+            self.reducer.finish(eng.grad)
+        eng.adamw_step(self.current_lr(), self.max_norm, self.betas, self.eps, self.wd)
+        self.sched_step += 1
+        return out
