@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Per-shape timing of the GEMMs of one full-config training step (HIP events, bf16)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from mmtg_amd import hip
+
+dev = "cuda"
+M = int(os.environ.get("TOKENS", 64 * 236))
+D, V = 768, 13440
+dt = torch.bfloat16 if os.environ.get("DT", "bf16") == "bf16" else torch.float32
+
+def t(*s): return (torch.randn(*s, device=dev) * 0.5).to(dt)
+
+def timeit(fn, n=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n): fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / n * 1e3  # us
+
+rows = []
+def case(name, Mm, N, K, tA, tB, epi=hip.EPI_NONE, splits=1, out_f32=False):
+    A = t(K, Mm) if tA else t(Mm, K)
+    B = t(N, K) if tB else t(K, N)
+    C = torch.zeros(Mm, N, device=dev, dtype=torch.float32 if (out_f32 or epi == hip.EPI_ATOMIC) else dt)
+    kw = {}
+    if epi == hip.EPI_GELU: kw["aux2"] = torch.empty(Mm, N, device=dev, dtype=dt)
+    if epi in (hip.EPI_RESID, hip.EPI_DGELU): kw["aux"] = t(Mm, N)
+    bias = None if epi in (hip.EPI_ATOMIC, hip.EPI_DGELU) else torch.zeros(N, device=dev)
+    us = timeit(lambda: hip.gemm(A, B, C, Mm, N, K, transA=tA, transB=tB, epi=epi, splits=splits, out_f32=out_f32, bias=bias, **kw))
+    tf = 2.0 * Mm * N * K / us / 1e6
+    rows.append((name, Mm, N, K, us, tf))
+    print("%-28s M=%6d N=%6d K=%6d %9.1f us %8.1f TF/s" % (name, Mm, N, K, us, tf), flush=True)
+
+from mmtg_amd.engine import _wgrad_splits as ws
+case("fwd qkv (NN)", M, 3 * D, D, False, False)
+case("fwd attn proj (NN,resid)", M, D, D, False, False, hip.EPI_RESID)
+case("fwd fc1 (NN,gelu)", M, 4 * D, D, False, False, hip.EPI_GELU)
+case("fwd fc2 (NN,resid)", M, D, 4 * D, False, False, hip.EPI_RESID)
+case("fwd lm head (NT,f32 out)", M, V, D, False, True, out_f32=True)
+case("fwd proj1 (NT)", M, 512, 2048, False, True, hip.EPI_TANH)
+case("dgrad fc2 (NT,dgelu)", M, 4 * D, D, False, True, hip.EPI_DGELU)
+case("dgrad fc1 (NT)", M, D, 4 * D, False, True)
+case("dgrad proj (NT)", M, D, D, False, True)
+case("dgrad qkv (NT)", M, D, 3 * D, False, True)
+case("dgrad lm head (NN)", M, D, V, False, False)
+for nm, a, b in (("wgrad fc2", 4 * D, D), ("wgrad fc1", D, 4 * D), ("wgrad proj", D, D), ("wgrad qkv", D, 3 * D), ("wgrad lm head", V, D), ("wgrad proj1", 512, 2048)):
+    case(nm + " (TN,atomic s=%d)" % ws(a, b, M), a, b, M, True, False, hip.EPI_ATOMIC, ws(a, b, M))
+    case(nm + " (TN,atomic s=1)", a, b, M, True, False, hip.EPI_ATOMIC, 1)
+tot = sum(r[4] for r in rows)
+print("sum %.1f us" % tot)
