@@ -1,0 +1,286 @@
+// Shared pieces of the GEMM kernels: argument block, LDS tile layouts, fragment
+// loaders and the fused epilogue.
+//
+// LDS images (16 KB per operand tile, K advances 128 BYTES per tile):
+//   KC (K-contiguous operand): [128 rows][128 B], 16-byte chunk c of row r stored at c ^ (r & 7)
+//       -> ds_read_b128 fragment reads are bank-conflict free.
+//   KS (K-strided operand):    [k rows][128 cols], chunk c of row k stored at c ^ swz(k),
+//       swz(k) = ((k&3)<<1) | (((k>>3)&1)<<3) -> ds_read_b64_tr_b16 reads are conflict free.
+#pragma once
+#include "mma.h"
+
+namespace {
+
+enum { BM = 128, BN = 128, TILE_BYTES = 16384, NTHR = 256 };
+
+struct GemmArgs {
+    const void* A; const void* B; void* C;
+    const float* bias;     // [N] fp32 or null
+    const void* aux;       // residual / saved pre-activation (type T), ld = ldaux
+    void* aux2;            // second output (pre-activation for GELU), ld = ldc
+    int M, N, K;
+    long lda, ldb, ldc, ldaux;
+    int epi;               // MMTG_EPI_*
+    int out_f32;           // C is float regardless of T
+    int use_tr;            // bf16 KS fragments via ds_read_b64_tr_b16 (1) or scalar gathers (0)
+    int tiles_n;
+    int kper;              // K elements per split (multiple of BK)
+    float alpha;
+    uint32_t drop_thresh; uint32_t drop_seed; float drop_inv_keep;
+};
+
+template <typename T> struct GT {
+    static constexpr int EPC = 16 / sizeof(T);    // elements per 16-byte chunk
+    static constexpr int BK = 128 / sizeof(T);    // K elements per LDS tile
+    static constexpr int KSTEP = 64 / sizeof(T);  // K elements per fragment (64 B of K)
+    static constexpr int RB = 128 * sizeof(T);    // row bytes of a K-strided tile (128 columns)
+    static constexpr int CPR = RB / 16;           // 16-byte chunks per K-strided row
+};
+
+__device__ __forceinline__ int ks_swz(int k) { return ((k & 3) << 1) | (((k >> 3) & 1) << 3); }
+
+// ---- fragment reads --------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ typename Vec16<T>::type ld_frag_kc(const char* tile, int row, int kk, int g) {
+    int off = row * 128 + ((((kk << 2) + g) ^ (row & 7)) << 4);
+    return *reinterpret_cast<const typename Vec16<T>::type*>(tile + off);
+}
+
+__device__ __forceinline__ bf16x8 ld_frag_ks(const char* tile, int col0, int kk, int lane, int use_tr, bf16) {
+    const int g = lane >> 4;
+    bf16x8 out;
+    if (use_tr) {
+        const int q = (lane & 15) >> 2, p = lane & 3;
+        const int k = kk * 32 + 8 * g + q;
+        const int chunk = (col0 >> 3) + (p >> 1);
+        const int o1 = k * 256 + ((chunk ^ ks_swz(k)) << 4) + 8 * (p & 1);
+        const int o2 = (k + 4) * 256 + ((chunk ^ ks_swz(k + 4)) << 4) + 8 * (p & 1);
+        out = tr_read_pair(tile, o1, o2);
+    } else {
+        const int c = col0 + (lane & 15);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = kk * 32 + 8 * g + j;
+            const int o = k * 256 + (((c >> 3) ^ ks_swz(k)) << 4) + (c & 7) * 2;
+            out[j] = *reinterpret_cast<const bf16*>(tile + o);
+        }
+    }
+    return out;
+}
+__device__ __forceinline__ f32x4 ld_frag_ks(const char* tile, int col0, int kk, int lane, int, float) {
+    const int g = lane >> 4, c = col0 + (lane & 15);
+    f32x4 out;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int k = kk * 16 + 4 * g + s;
+        const int o = k * 512 + (((c >> 2) ^ ks_swz(k)) << 4) + (c & 3) * 4;
+        out[s] = *reinterpret_cast<const float*>(tile + o);
+    }
+    return out;
+}
+
+// ---- global -> register staging of one 16 KB operand tile -------------------
+template <typename T, bool KS>
+__device__ __forceinline__ void stage_load(const T* __restrict__ base, long ld, int row0, int nrows,
+                                           int k0, int kend, int tid, typename Vec16<T>::type (&r)[4]) {
+    typedef typename Vec16<T>::type V;
+    constexpr int EPC = GT<T>::EPC;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        V v;
+#pragma unroll
+        for (int e = 0; e < Vec16<T>::N; ++e) v[e] = (T)0.0f;
+        if (!KS) {
+            const int c = tid & 7, row = (tid >> 3) + 32 * i;
+            const int gr = row0 + row, gk = k0 + c * EPC;
+            if (gr < nrows && gk < kend) v = *reinterpret_cast<const V*>(base + (long)gr * ld + gk);
+        } else {
+            const int id = tid + NTHR * i;
+            const int k = id / GT<T>::CPR, c = id % GT<T>::CPR;
+            const int gk = k0 + k, gc = row0 + c * EPC;
+            if (gk < kend && gc < nrows) v = *reinterpret_cast<const V*>(base + (long)gk * ld + gc);
+        }
+        r[i] = v;
+    }
+}
+template <typename T, bool KS>
+__device__ __forceinline__ void stage_store(char* tile, int tid, const typename Vec16<T>::type (&r)[4]) {
+    typedef typename Vec16<T>::type V;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int off;
+        if (!KS) {
+            const int c = tid & 7, row = (tid >> 3) + 32 * i;
+            off = row * 128 + ((c ^ (row & 7)) << 4);
+        } else {
+            const int id = tid + NTHR * i;
+            const int k = id / GT<T>::CPR, c = id % GT<T>::CPR;
+            off = k * GT<T>::RB + ((c ^ ks_swz(k)) << 4);
+        }
+        *reinterpret_cast<V*>(tile + off) = r[i];
+    }
+}
+
+template <typename TO> __device__ __forceinline__ void store4(TO* p, const float (&v)[4]);
+template <> __device__ __forceinline__ void store4<float>(float* p, const float (&v)[4]) {
+    f32x4 o = {v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(p) = o;
+}
+template <> __device__ __forceinline__ void store4<bf16>(bf16* p, const float (&v)[4]) {
+    bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+    *reinterpret_cast<bf16x4*>(p) = o;
+}
+template <typename TI> __device__ __forceinline__ void load4(const TI* p, float (&v)[4]);
+template <> __device__ __forceinline__ void load4<float>(const float* p, float (&v)[4]) {
+    f32x4 o = *reinterpret_cast<const f32x4*>(p);
+    v[0] = o[0]; v[1] = o[1]; v[2] = o[2]; v[3] = o[3];
+}
+template <> __device__ __forceinline__ void load4<bf16>(const bf16* p, float (&v)[4]) {
+    bf16x4 o = *reinterpret_cast<const bf16x4*>(p);
+    v[0] = (float)o[0]; v[1] = (float)o[1]; v[2] = (float)o[2]; v[3] = (float)o[3];
+}
+
+
+// XCD-aware tile order: consecutive tiles (sharing the A row panel) land on one XCD's L2
+__device__ __forceinline__ void tile_origin(const GemmArgs& p, int& m0, int& n0) {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
+    const int swz = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+    m0 = (swz / p.tiles_n) * BM;
+    n0 = (swz % p.tiles_n) * BN;
+}
+
+// Per-lane byte offsets of the transposed-read fragments of a K-strided bf16 operand, hoisted out of
+// the K loop: ks_swz(k) only depends on k&3 and (k>>3)&1, which are lane constants (k = 8g+q [+4] [+32kk]),
+// so every fragment address is o[i] + kk*8192 (+1024 for the second 4-row block): one VGPR per 16-column
+// block, everything else an instruction immediate.
+__device__ __forceinline__ void ks_lane_offsets(int wq, int lane, int (&o)[4]) {
+    const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+    const int k = 8 * g + q;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int chunk = wq * 8 + 2 * i + (pp >> 1);
+        o[i] = k * 256 + ((chunk ^ ks_swz(k)) << 4) + 8 * (pp & 1);
+    }
+}
+
+// One K tile (two 64-byte k-blocks) of a wave's 64x64 quadrant: 16 fragment reads, 32 mma16.
+template <typename T, bool AKS, bool BKS, bool std_orient>
+__device__ __forceinline__ void compute_tile(const char* tA, const char* tB, f32x4 (&acc)[4][4],
+                                             int wm, int wn, int lane, int use_tr,
+                                             const int (&oa)[4], const int (&ob)[4]) {
+    typedef typename Vec16<T>::type V;
+    const int g = lane >> 4, l15 = lane & 15;
+    constexpr bool hoist = sizeof(T) == 2;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        V fa[4], fb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if constexpr (!AKS) fa[i] = ld_frag_kc<T>(tA, wm * 64 + i * 16 + l15, kk, g);
+            else if constexpr (hoist) {
+                if (use_tr) fa[i] = tr_read_pair(tA, oa[i] + kk * 8192, oa[i] + kk * 8192 + 1024);
+                else fa[i] = ld_frag_ks(tA, wm * 64 + i * 16, kk, lane, 0, T());
+            } else fa[i] = ld_frag_ks(tA, wm * 64 + i * 16, kk, lane, use_tr, T());
+            if constexpr (!BKS) fb[i] = ld_frag_kc<T>(tB, wn * 64 + i * 16 + l15, kk, g);
+            else if constexpr (hoist) {
+                if (use_tr) fb[i] = tr_read_pair(tB, ob[i] + kk * 8192, ob[i] + kk * 8192 + 1024);
+                else fb[i] = ld_frag_ks(tB, wn * 64 + i * 16, kk, lane, 0, T());
+            } else fb[i] = ld_frag_ks(tB, wn * 64 + i * 16, kk, lane, use_tr, T());
+        }
+        if (std_orient) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mma16(fa[i], fb[j], acc[i][j]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mma16(fb[j], fa[i], acc[i][j]);
+        }
+    }
+}
+
+// Fused epilogue.  STD orientation (weight gradients): lane holds D[m = 4g+r][n = l15] -> fp32 atomics,
+// 16 contiguous floats per row per wave-instruction.  Swapped orientation: lane holds 4 consecutive n
+// for m = l15 -> 8/16-byte vector stores.  The epilogue kind is dispatched ONCE (outside the unrolled
+// tile loops) so each instantiation stays small.
+template <typename T, int EPI>
+__device__ __forceinline__ void epi_tiles(const GemmArgs& p, f32x4 (&acc)[4][4], int m0, int n0,
+                                          int wm, int wn, int g, int l15) {
+    const T* aux = reinterpret_cast<const T*>(p.aux);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + i * 16 + l15;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + 4 * g;
+            if (n >= p.N) continue;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            if (p.bias) {
+                f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+                v[0] += bv[0]; v[1] += bv[1]; v[2] += bv[2]; v[3] += bv[3];
+            }
+            float a4[4];
+            if constexpr (EPI == MMTG_EPI_GELU) {
+                store4<T>(reinterpret_cast<T*>(p.aux2) + (long)m * p.ldc + n, v);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = gelu_new_f(v[r]);
+            } else if constexpr (EPI == MMTG_EPI_TANH) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
+            } else if constexpr (EPI == MMTG_EPI_RESID) {
+                if (p.drop_thresh) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        v[r] *= dropout_scale(p.drop_seed, (uint32_t)((long)m * p.N + n + r), p.drop_thresh, p.drop_inv_keep);
+                }
+                load4<T>(aux + (long)m * p.ldaux + n, a4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += a4[r];
+            } else if constexpr (EPI == MMTG_EPI_DGELU) {
+                load4<T>(aux + (long)m * p.ldaux + n, a4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= gelu_new_grad_f(a4[r]);
+            } else if constexpr (EPI == MMTG_EPI_DTANH) {
+                load4<T>(aux + (long)m * p.ldaux + n, a4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= (1.0f - a4[r] * a4[r]);
+            }
+            if (p.out_f32) store4<float>(reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n, v);
+            else store4<T>(reinterpret_cast<T*>(p.C) + (long)m * p.ldc + n, v);
+        }
+    }
+}
+
+template <typename T, bool std_orient>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4][4], int m0, int n0,
+                                              int wm, int wn, int g, int l15) {
+    if constexpr (std_orient) {
+        float* C = reinterpret_cast<float*>(p.C);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + wn * 64 + j * 16 + l15;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + wm * 64 + i * 16 + 4 * g + r;
+                    if (m < p.M && n < p.N) atomicAdd(C + (long)m * p.ldc + n, acc[i][j][r] * p.alpha);
+                }
+            }
+    } else {
+        switch (p.epi) {
+            case MMTG_EPI_GELU: epi_tiles<T, MMTG_EPI_GELU>(p, acc, m0, n0, wm, wn, g, l15); break;
+            case MMTG_EPI_TANH: epi_tiles<T, MMTG_EPI_TANH>(p, acc, m0, n0, wm, wn, g, l15); break;
+            case MMTG_EPI_RESID: epi_tiles<T, MMTG_EPI_RESID>(p, acc, m0, n0, wm, wn, g, l15); break;
+            case MMTG_EPI_DGELU: epi_tiles<T, MMTG_EPI_DGELU>(p, acc, m0, n0, wm, wn, g, l15); break;
+            case MMTG_EPI_DTANH: epi_tiles<T, MMTG_EPI_DTANH>(p, acc, m0, n0, wm, wn, g, l15); break;
+            default: epi_tiles<T, MMTG_EPI_NONE>(p, acc, m0, n0, wm, wn, g, l15); break;
+        }
+    }
+}
+
+}  // namespace

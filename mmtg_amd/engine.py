@@ -157,10 +157,23 @@ def gaussian_prior(S):
     return np.stack(rows)
 
 
-def _wgrad_splits(M, N, K):
+def _wgrad_splits(M, N, K, slots=512, t_iter=1.1, t_fixed=6.0):
+    """Split-K factor of a weight-gradient GEMM (K = tokens).  The 128x128-tile kernel keeps two
+    workgroups per CU (512 slots on 256 CUs); a grid of tiles*s workgroups runs in
+    ceil(tiles*s/512) rounds of (K/(64 s)) K-iterations each.  Pick the s with the smallest
+    estimate -- e.g. 144 tiles: s=3 (432 WGs, one round) beats s=4 (576 WGs, two rounds) by 30 %
+    on the GPU (profiles/r01_gemm_tn_split_sweep.log)."""
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    s = max(1, min(round(512 / tiles), K // 256))
-    return int(max(1, min(s, 64)))
+    best, best_t = 1, None
+    for s in range(1, 33):
+        if s > 1 and K // s < 256:
+            break
+        rounds = -(-tiles * s // slots)
+        # + the fp32 atomic epilogue: 64 KB of adds per workgroup at the chip-wide ~1.3 TB/s atomic rate
+        t = rounds * (K / (64.0 * s) * t_iter + t_fixed) + tiles * s * 65536 / 1.3e6
+        if best_t is None or t < best_t * 0.97:
+            best, best_t = s, t
+    return best
 
 
 # --------------------------------------------------------------------------

@@ -49,10 +49,13 @@ def close(got, ref, dtype, k=1, name="", scale=None):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("layout", ["NT", "NN", "TN"])
 @pytest.mark.parametrize("shape", [(200, 136, 96), (712, 768, 512), (1024, 256, 2048)])
-@pytest.mark.parametrize("no_tr", [0, 1])
-def test_gemm_layouts(dtype, layout, shape, no_tr):
+@pytest.mark.parametrize("variant", ["dma2", "dma3", "regstage", "no_tr"])
+def test_gemm_layouts(dtype, layout, shape, variant):
+    no_tr = variant == "no_tr"
     if no_tr and (dtype == torch.float32 or layout == "NT"):
         pytest.skip("scalar-gather variant only differs for bf16 K-strided operands")
+    if dtype == torch.float32 and variant != "dma2":
+        pytest.skip("f32 has one pipeline (register-staged)")
     M, N, K = shape
     a = rnd(M, K, dtype=dtype, seed=1)
     b = rnd(K, N, dtype=dtype, seed=2)
@@ -64,7 +67,7 @@ def test_gemm_layouts(dtype, layout, shape, no_tr):
     else:
         A, B, tA, tB = a.t().contiguous(), b, True, False
     A, B = A.to(DEV), B.to(DEV)
-    flags = hip.GEMM_NO_TR if no_tr else 0
+    flags = {"dma2": 0, "dma3": hip.GEMM_3STAGE, "regstage": hip.GEMM_REGSTAGE, "no_tr": hip.GEMM_NO_TR}[variant]
     if layout == "TN":
         for splits in (1, 3):
             Cf = torch.full((M, N), 0.5, device=DEV, dtype=torch.float32)

@@ -22,6 +22,7 @@ def timeit(fn, n=20):
     return a.elapsed_time(b) / n * 1e3  # us
 
 rows = []
+FLAGS = int(os.environ.get("FLAGS", "0"))
 def case(name, Mm, N, K, tA, tB, epi=hip.EPI_NONE, splits=1, out_f32=False):
     A = t(K, Mm) if tA else t(Mm, K)
     B = t(N, K) if tB else t(K, N)
@@ -30,12 +31,44 @@ def case(name, Mm, N, K, tA, tB, epi=hip.EPI_NONE, splits=1, out_f32=False):
     if epi == hip.EPI_GELU: kw["aux2"] = torch.empty(Mm, N, device=dev, dtype=dt)
     if epi in (hip.EPI_RESID, hip.EPI_DGELU): kw["aux"] = t(Mm, N)
     bias = None if epi in (hip.EPI_ATOMIC, hip.EPI_DGELU) else torch.zeros(N, device=dev)
-    us = timeit(lambda: hip.gemm(A, B, C, Mm, N, K, transA=tA, transB=tB, epi=epi, splits=splits, out_f32=out_f32, bias=bias, **kw))
+    us = timeit(lambda: hip.gemm(A, B, C, Mm, N, K, transA=tA, transB=tB, epi=epi, splits=splits, out_f32=out_f32, bias=bias, flags=FLAGS, **kw))
     tf = 2.0 * Mm * N * K / us / 1e6
     rows.append((name, Mm, N, K, us, tf))
     print("%-28s M=%6d N=%6d K=%6d %9.1f us %8.1f TF/s" % (name, Mm, N, K, us, tf), flush=True)
 
 from mmtg_amd.engine import _wgrad_splits as ws
+if os.environ.get("PMC"):
+    # one launch per layout at comparable work, for rocprofv3 --pmc
+    timeit_n = 2
+    def once(name, Mm, N, K, tA, tB, epi=hip.EPI_NONE, splits=1):
+        A = t(K, Mm) if tA else t(Mm, K)
+        B = t(N, K) if tB else t(K, N)
+        C = torch.zeros(Mm, N, device=dev, dtype=torch.float32 if epi == hip.EPI_ATOMIC else dt)
+        for _ in range(2):
+            hip.gemm(A, B, C, Mm, N, K, transA=tA, transB=tB, epi=epi, splits=splits, flags=FLAGS)
+        torch.cuda.synchronize()
+    once("NT", M, D, 4 * D, False, True)
+    once("NN", M, D, 4 * D, False, False)
+    once("TN", 4 * D, D, M, True, False, hip.EPI_ATOMIC, 3)
+    sys.exit(0)
+if os.environ.get("TNSWEEP"):
+    for K in (64, 256, 1024, 4096, 15104):
+        case("TN 3072x768 s=1 K-sweep", 4 * D, D, K, True, False, hip.EPI_ATOMIC, 1)
+    for s_ in (1, 2, 3, 4, 6, 8):
+        case("TN 3072x768 K=15104 s=%d" % s_, 4 * D, D, M, True, False, hip.EPI_ATOMIC, s_)
+    for s_ in (1, 2, 3, 4):
+        case("TN 13440x768 K=15104 s=%d" % s_, V, D, M, True, False, hip.EPI_ATOMIC, s_)
+    for s_ in (3, 4, 5, 8):
+        case("TN 768x2304 K=15104 s=%d" % s_, D, 3 * D, M, True, False, hip.EPI_ATOMIC, s_)
+    sys.exit(0)
+if os.environ.get("KSWEEP"):
+    for K in (64, 128, 256, 512, 768, 1536, 3072):
+        case("NT N=3072 K-sweep", M, 4 * D, K, False, True)
+    for K in (64, 256, 768, 3072):
+        case("NT N=768 K-sweep", M, D, K, False, True)
+    for K in (64, 768):
+        case("NT gelu N=3072 K-sweep", M, 4 * D, K, False, True, hip.EPI_GELU)
+    sys.exit(0)
 case("fwd qkv (NN)", M, 3 * D, D, False, False)
 case("fwd attn proj (NN,resid)", M, D, D, False, False, hip.EPI_RESID)
 case("fwd fc1 (NN,gelu)", M, 4 * D, D, False, False, hip.EPI_GELU)
