@@ -43,7 +43,6 @@ enum {
 };
 #define MMTG_GEMM_NO_TR 1 /* flags: gather K-strided bf16 fragments without ds_read_b64_tr_b16 */
 #define MMTG_GEMM_REGSTAGE 2 /* flags: register-staged v1 pipeline instead of the LDS-DMA one (bf16) */
-#define MMTG_GEMM_3STAGE 4   /* flags: 3-deep LDS-DMA ring (96 KB, 1 workgroup/CU) instead of 2-deep */
 
 /* profiling categories (mmtg_prof_*) */
 enum {

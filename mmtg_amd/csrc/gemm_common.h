@@ -27,6 +27,7 @@ struct GemmArgs {
     int kper;              // K elements per split (multiple of BK)
     float alpha;
     uint32_t drop_thresh; uint32_t drop_seed; float drop_inv_keep;
+    int bytesA, bytesB;    // operand extents for the LDS-DMA buffer descriptors
 };
 
 template <typename T> struct GT {
@@ -165,9 +166,9 @@ __device__ __forceinline__ void ks_lane_offsets(int wq, int lane, int (&o)[4]) {
 }
 
 // One K tile (two 64-byte k-blocks) of a wave's 64x64 quadrant: 16 fragment reads, 32 mma16.
-template <typename T, bool AKS, bool BKS, bool std_orient>
+template <typename T, bool AKS, bool BKS, bool std_orient, bool use_tr>
 __device__ __forceinline__ void compute_tile(const char* tA, const char* tB, f32x4 (&acc)[4][4],
-                                             int wm, int wn, int lane, int use_tr,
+                                             int wm, int wn, int lane,
                                              const int (&oa)[4], const int (&ob)[4]) {
     typedef typename Vec16<T>::type V;
     const int g = lane >> 4, l15 = lane & 15;
@@ -178,15 +179,11 @@ __device__ __forceinline__ void compute_tile(const char* tA, const char* tB, f32
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if constexpr (!AKS) fa[i] = ld_frag_kc<T>(tA, wm * 64 + i * 16 + l15, kk, g);
-            else if constexpr (hoist) {
-                if (use_tr) fa[i] = tr_read_pair(tA, oa[i] + kk * 8192, oa[i] + kk * 8192 + 1024);
-                else fa[i] = ld_frag_ks(tA, wm * 64 + i * 16, kk, lane, 0, T());
-            } else fa[i] = ld_frag_ks(tA, wm * 64 + i * 16, kk, lane, use_tr, T());
+            else if constexpr (hoist && use_tr) fa[i] = tr_read_pair(tA, oa[i] + kk * 8192, oa[i] + kk * 8192 + 1024);
+            else fa[i] = ld_frag_ks(tA, wm * 64 + i * 16, kk, lane, 0, T());
             if constexpr (!BKS) fb[i] = ld_frag_kc<T>(tB, wn * 64 + i * 16 + l15, kk, g);
-            else if constexpr (hoist) {
-                if (use_tr) fb[i] = tr_read_pair(tB, ob[i] + kk * 8192, ob[i] + kk * 8192 + 1024);
-                else fb[i] = ld_frag_ks(tB, wn * 64 + i * 16, kk, lane, 0, T());
-            } else fb[i] = ld_frag_ks(tB, wn * 64 + i * 16, kk, lane, use_tr, T());
+            else if constexpr (hoist && use_tr) fb[i] = tr_read_pair(tB, ob[i] + kk * 8192, ob[i] + kk * 8192 + 1024);
+            else fb[i] = ld_frag_ks(tB, wn * 64 + i * 16, kk, lane, 0, T());
         }
         if (std_orient) {
 #pragma unroll

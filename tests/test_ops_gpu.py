@@ -49,7 +49,7 @@ def close(got, ref, dtype, k=1, name="", scale=None):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("layout", ["NT", "NN", "TN"])
 @pytest.mark.parametrize("shape", [(200, 136, 96), (712, 768, 512), (1024, 256, 2048)])
-@pytest.mark.parametrize("variant", ["dma2", "dma3", "regstage", "no_tr"])
+@pytest.mark.parametrize("variant", ["dma2", "regstage", "no_tr"])
 def test_gemm_layouts(dtype, layout, shape, variant):
     no_tr = variant == "no_tr"
     if no_tr and (dtype == torch.float32 or layout == "NT"):
@@ -67,7 +67,7 @@ def test_gemm_layouts(dtype, layout, shape, variant):
     else:
         A, B, tA, tB = a.t().contiguous(), b, True, False
     A, B = A.to(DEV), B.to(DEV)
-    flags = {"dma2": 0, "dma3": hip.GEMM_3STAGE, "regstage": hip.GEMM_REGSTAGE, "no_tr": hip.GEMM_NO_TR}[variant]
+    flags = {"dma2": 0, "regstage": hip.GEMM_REGSTAGE, "no_tr": hip.GEMM_NO_TR}[variant]
     if layout == "TN":
         for splits in (1, 3):
             Cf = torch.full((M, N), 0.5, device=DEV, dtype=torch.float32)
