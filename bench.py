@@ -84,6 +84,62 @@ def cpu_baseline(mcfg, dcfg, gcfg, V, T, seconds_budget=25.0):
                       "(fwd+MyLoss+bwd+clip+AdamW), dropout off" % (V, B, T, n)}
 
 
+def bench_decode(args, world, rank, dev):
+    """Greedy decode tokens/s: every rank decodes its own batch (replicas only, no exchange)."""
+    from mmtg_amd import MMTG, hip, synth
+    from mmtg_amd.configs import data_config, gpt2_config, make_model_cfgs
+    from mmtg_amd.decode import GreedyDecoder
+    S, V = 5, 13317
+    mcfg, dcfg = make_model_cfgs(seq_len=S), data_config(seq_len=S)
+    gcfg = gpt2_config(n_layer=args.layers, vocab_size=V)
+    model = MMTG(mcfg, dcfg, V, gpt2_config=gcfg, compute_dtype=args.dtype, token_table=synth.make_token_table(V, seed=2))
+    model.reset_parameters(seed=0)
+    model.to(dev).eval()
+    B, Ln = args.decode_batch, args.decode_len
+    nb = synth.make_batch(B, mcfg, dcfg, V, seed=7 + rank)
+    batch = {k: torch.from_numpy(np.asarray(v)).to(dev) for k, v in nb.items() if k not in ("rating", "targets")}
+    if os.environ.get("MMTG_DECODE_PROF"):
+        dec = GreedyDecoder(model, max_batch=B, max_len=Ln, use_graph=False)
+        dec.generate(batch, Ln, temperature=1.1, repitition_penalty=1.5)
+        hip.prof_enable(True)
+        dec.generate(batch, Ln, temperature=1.1, repitition_penalty=1.5)
+        hip.prof_enable(False)
+        pr = hip.prof_read()
+        print({k: (v["launches"], round(v["ms"], 2)) for k, v in pr.items() if v["launches"]})
+        return
+    dec = GreedyDecoder(model, max_batch=B, max_len=Ln)
+    for _ in range(max(1, args.warmup)):
+        dec.generate(batch, Ln, temperature=1.1, repitition_penalty=1.5)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ids = dec.generate(batch, Ln, temperature=1.1, repitition_penalty=1.5)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    if rank == 0:
+        steps_per_seq = dcfg.topic_prompt_length + Ln
+        out = {"metric": "greedy-decode tokens/sec, full MMTG config", "value": round(B * world * Ln * args.steps / el, 1),
+               "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(1e3 * el / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+               "config": {"workload": "batched greedy generation, KV cache + hipGraph replay per token: batch %d, "
+                                      "%d generated positions after a 15-token prompt, GPT-2 %dL/768/12H V=%d"
+                                      % (B, Ln, args.layers, V),
+                          "us_per_token_step": round(1e6 * el / args.steps / steps_per_seq, 2),
+                          "parallelism": "replicas x%d" % world}}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -95,6 +151,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--bucket-mb", type=float, default=64.0)
+    ap.add_argument("--mode", default="train", choices=["train", "decode"],
+                    help="decode: batched greedy generation (BASELINE configs[3]: batch 256, max_len 128)")
+    ap.add_argument("--decode-batch", type=int, default=256)
+    ap.add_argument("--decode-len", type=int, default=128)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -112,6 +172,9 @@ def main():
     from mmtg_amd import MMTG, hip, synth
     from mmtg_amd.configs import data_config, gpt2_config, make_model_cfgs
     from mmtg_amd.trainer import MMTGTrainer
+
+    if args.mode == "decode":
+        return bench_decode(args, world, rank, dev)
 
     S, V = 5, 13317
     mcfg = make_model_cfgs(seq_len=S)

@@ -82,10 +82,17 @@ int mmtg_colsum(int dtype, const void* X, long ldx, int M, int N, float* out, vo
  * torch.nn.LayerNorm (model.py:380-382) and GPT-2's ln_1/ln_2/ln_f.          */
 int mmtg_layernorm_fwd(int dtype, const void* x, void* y, const float* gamma, const float* beta,
                        float* mean, float* rstd, int rows, int cols, float eps, void* stream);
-/* dx = LN'(dy) (+ dres if non-null); dgamma/dbeta accumulated (+=) in fp32   */
+/* dx = LN'(dy) (+ dres if non-null); dgamma/dbeta accumulated (+=) in fp32.
+ * Optional fused tail for the residual stream: dx_masked = dx * dropout_mask(drop_seed) (the
+ * gradient entering the previous residual branch; null = not needed) and
+ * dcolsum[c] += sum_rows dx_masked (that branch's bias gradient; without dx_masked: of dx).
+ * ws: caller-owned scratch of >= mmtg_layernorm_bwd_ws(rows, cols) floats.     */
+long mmtg_layernorm_bwd_ws(int rows, int cols);
 int mmtg_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma,
                        const float* mean, const float* rstd, const void* dres, void* dx,
-                       float* dgamma, float* dbeta, int rows, int cols, void* stream);
+                       float* dgamma, float* dbeta, int rows, int cols,
+                       void* dx_masked, unsigned drop_thresh, unsigned drop_seed, float* dcolsum,
+                       float* ws, long ws_floats, void* stream);
 
 /* ---------------------------------------------------------------- causal self-attention
  * GPT2Attention._attn: softmax(QK^T/sqrt(dh) + causal + key padding) V with
@@ -189,6 +196,28 @@ int mmtg_axpy_f32(float* y, const float* x, float a, long n, void* stream);
 int mmtg_logits_process_argmax(const float* logits, long ldl, int V, const long long* generated,
                                long ldg, const int* gen_len, float temperature, float rep_penalty,
                                long long* next, int B, void* stream);
+
+/* ---------------------------------------------------------------- KV-cached decode step (generate.py:117-142)
+ * Batched, lock-step: every row is at position *pos_ptr (a DEVICE int, so a captured hipGraph of
+ * the step replays for every position).  seq[B, ldseq] = prompt ids (0..P-1) then lyric ids.
+ * decode_embed: x[b] = E[seq[b,pos]] (+ c[b,(pos-P)/two_sents]) and the inference-branch type id /
+ *   key mask of the token (model.py:296-312): type_out[b], keep[b,pos].
+ * decode_embed_add: h = g + wpe[pos] + wte[type].
+ * decode_attn: appends the token's K/V to the caches [B,nH,Tmax,64] and attends over keys 0..pos.
+ * decode_select: next lyric token = forced [#EOS#]/[#START#] by the 22-slot cadence, sticky PAD, or
+ *   arg-max of the processed logits (null logits: forced tokens only); writes seq[b, pos+1].
+ * decode_advance: *pos_ptr += 1.                                                              */
+int mmtg_decode_embed(int dtype, const void* table, const long long* seq, long ldseq, const void* c, void* x,
+                      const int* pos_ptr, const long long* tpw_type, const long long* tpw_mask,
+                      long long* type_out, int* keep, long ldkeep, int B, int P, int S, int E, int two_sents,
+                      int V, int sent, int max_sent_num, void* stream);
+int mmtg_decode_embed_add(int dtype, const void* g, const void* wpe, const void* wte, const long long* type_ids,
+                          const int* pos_ptr, void* h, int B, int D, void* stream);
+int mmtg_decode_attn(int dtype, const void* qkv, void* kcache, void* vcache, const int* keep, long ldkeep,
+                     const int* pos_ptr, void* out, int B, int nH, int dh, int Tmax, void* stream);
+int mmtg_decode_select(const float* logits, long ldl, int V, long long* seq, long ldseq, const int* pos_ptr,
+                       int P, int sent, float temperature, float rep_penalty, int B, void* stream);
+int mmtg_decode_advance(int* pos_ptr, void* stream);
 
 #ifdef __cplusplus
 }

@@ -65,3 +65,237 @@ extern "C" int mmtg_logits_process_argmax(const float* logits, long ldl, int V, 
     MMTG_LAUNCH_CHECK("logits_process_argmax");
     return MMTG_OK;
 }
+
+// =====================================================================================
+// KV-cached single-token decode step (batched, lock-step positions).
+//
+// The whole step is device-driven: the current position lives in device memory (`pos_ptr`),
+// so one captured hipGraph of the step can be replayed for every position without any
+// host-side argument changes.  Sequence buffer seq[B, ldseq] holds prompt ids (positions
+// 0..P-1) followed by lyric ids (lyric index j = pos - P, j = 0 is the initial [#START#]).
+// Type ids / key mask follow the inference branch of GPT2_Decoder.forward (model.py:290-312).
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(256) void decode_embed_kernel(const T* __restrict__ table, const long long* __restrict__ seq,
+        long ldseq, const T* __restrict__ c, T* __restrict__ x, const int* __restrict__ pos_ptr,
+        const long long* __restrict__ tpw_type, const long long* __restrict__ tpw_mask,
+        long long* __restrict__ type_out, int* __restrict__ keep, long ldkeep,
+        int P, int S, int E, int two_sents, int V, int sent, int max_sent_num) {
+    typedef typename Vec16<T>::type V16t;
+    constexpr int N = Vec16<T>::N;
+    const int b = blockIdx.x, pos = *pos_ptr;
+    long long tok = seq[(long)b * ldseq + pos];
+    if (threadIdx.x == 0) {
+        long long ty;
+        int kp;
+        if (pos < P) {
+            ty = tpw_type[(long)b * P + pos];
+            kp = tpw_mask[(long)b * P + pos] != 0;
+        } else {
+            const int i = pos - P;
+            const bool pad = tok == 0;
+            const bool edge = ((i + 1) % sent == 0) || ((i + 1) % sent == 1);
+            const int sidx = i / sent;
+            const int slot = sidx < max_sent_num - 1 ? sidx + 1 : 1;     // [1..max_sent_num-1, 1]
+            ty = (edge || pad) ? 0 : slot;
+            kp = !pad;
+        }
+        type_out[b] = ty;
+        keep[(long)b * ldkeep + pos] = kp;
+    }
+    if (tok < 0) tok = 0;
+    if (tok >= V) tok = V - 1;
+    const int seg = pos < P ? -1 : (pos - P) / two_sents;
+    const T* src = table + tok * E;
+    const T* cs = (seg >= 0 && seg < S) ? c + ((long)b * S + seg) * E : nullptr;
+    T* dst = x + (long)b * E;
+    for (int e = threadIdx.x * N; e < E; e += 256 * N) {
+        V16t v = *reinterpret_cast<const V16t*>(src + e);
+        if (cs) {
+            V16t w = *reinterpret_cast<const V16t*>(cs + e);
+#pragma unroll
+            for (int k = 0; k < N; ++k) v[k] = (T)((float)v[k] + (float)w[k]);
+        }
+        *reinterpret_cast<V16t*>(dst + e) = v;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void decode_embed_add_kernel(const T* __restrict__ g, const T* __restrict__ wpe,
+        const T* __restrict__ wte, const long long* __restrict__ type_ids, const int* __restrict__ pos_ptr,
+        T* __restrict__ h, int D) {
+    const int b = blockIdx.x, pos = *pos_ptr;
+    const long long ty = type_ids[b];
+    for (int d = threadIdx.x; d < D; d += 256)
+        h[(long)b * D + d] = (T)((float)g[(long)b * D + d] + (float)wpe[(long)pos * D + d] + (float)wte[ty * D + d]);
+}
+
+// One wave per (b, head): append this token's K/V to the cache, then attend over keys 0..pos.
+// Cache layout [B, nH, Tmax, 64].  Scores: lane <-> key (4 keys per lane for Tmax <= 256 handled in
+// a loop), dot products over the 64-wide head; output: lane <-> channel.
+template <typename T>
+__global__ __launch_bounds__(64) void decode_attn_kernel(const T* __restrict__ qkv, T* __restrict__ kc, T* __restrict__ vc,
+        const int* __restrict__ keep, long ldkeep, const int* __restrict__ pos_ptr, T* __restrict__ out,
+        int nH, int Tmax) {
+    __shared__ float sp[1024];
+    __shared__ float sq[64];
+    const int h = blockIdx.x, b = blockIdx.y, lane = threadIdx.x, pos = *pos_ptr;
+    const int D = nH * 64;
+    const T* row = qkv + (long)b * 3 * D + h * 64;
+    T* kbase = kc + (((long)b * nH + h) * Tmax) * 64;
+    T* vbase = vc + (((long)b * nH + h) * Tmax) * 64;
+    sq[lane] = (float)row[lane] * 0.125f;
+    kbase[(long)pos * 64 + lane] = row[D + lane];
+    vbase[(long)pos * 64 + lane] = row[2 * D + lane];
+    __syncthreads();
+    const int nkeys = pos + 1;
+    float mx = -INFINITY;
+    for (int k0 = 0; k0 < nkeys; k0 += 64) {
+        const int key = k0 + lane;
+        float s = -INFINITY;
+        if (key < nkeys && keep[(long)b * ldkeep + key]) {
+            const T* kr = kbase + (long)key * 64;
+            float a = 0.f;
+#pragma unroll 8
+            for (int d = 0; d < 64; ++d) a += sq[d] * (float)kr[d];
+            s = a;
+        }
+        sp[key] = s;
+        mx = fmaxf(mx, s);
+    }
+    mx = wave_max(mx);
+    const float muse = mx == -INFINITY ? 0.f : mx;
+    float sum = 0.f;
+    for (int k0 = 0; k0 < nkeys; k0 += 64) {
+        const int key = k0 + lane;
+        if (key < nkeys) {
+            const float s = sp[key];
+            const float p = s == -INFINITY ? 0.f : expf(s - muse);
+            sp[key] = p;
+            sum += p;
+        }
+    }
+    sum = wave_sum(sum);
+    __syncthreads();
+    float acc = 0.f;
+    for (int key = 0; key < nkeys; ++key) acc += sp[key] * (float)vbase[(long)key * 64 + lane];
+    out[(long)b * D + h * 64 + lane] = (T)(sum > 0.f ? acc / sum : 0.f);
+}
+
+// logits processor + arg-max + forced-token cadence + append (generate.py:117-142), device-driven.
+__global__ __launch_bounds__(256) void decode_select_kernel(const float* __restrict__ logits, long ldl, int V,
+        long long* __restrict__ seq, long ldseq, const int* __restrict__ pos_ptr, int P, int sent,
+        float temperature, float rep_penalty, int have_logits) {
+    __shared__ int sgen[MAXGEN];
+    __shared__ float sval[4];
+    __shared__ int sidx[4];
+    const int b = blockIdx.x, tid = threadIdx.x, pos = *pos_ptr;
+    const int j = pos + 1 - P;                 // lyric index of the token to append
+    if (j < 1) return;                         // still inside the prompt / the initial [#START#]
+    long long* gen = seq + (long)b * ldseq + P;
+    if (j > 1 && (j + 1) % sent == 0) { if (tid == 0) gen[j] = 2; return; }     // [#EOS#]
+    if (j > 1 && (j + 1) % sent == 1) { if (tid == 0) gen[j] = 1; return; }     // [#START#]
+    if (!have_logits) return;
+    const int n = min(j, MAXGEN);
+    for (int i = tid; i < n; i += 256) sgen[i] = (int)gen[i];
+    __syncthreads();
+    if (sgen[n - 1] == 0) { if (tid == 0) gen[j] = 0; return; }                  // sticky PAD
+    const float* row = logits + (long)b * ldl;
+    float best = -INFINITY;
+    int besti = 0x7fffffff;
+    for (int v = tid; v < V; v += 256) {
+        float x = row[v];
+        if (v != 0 && v != 102) {
+            for (int i = 0; i < n; ++i)
+                if (sgen[i] == v) x = x / rep_penalty;
+        }
+        x = x / temperature;
+        if (v == 1 || v == 2 || v == 100 || v == 102) x = -INFINITY;
+        if (x > best || (x == best && v < besti)) { best = x; besti = v; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(besti, o, 64);
+        if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
+    }
+    if ((tid & 63) == 0) { sval[tid >> 6] = best; sidx[tid >> 6] = besti; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (sval[w] > best || (sval[w] == best && sidx[w] < besti)) { best = sval[w]; besti = sidx[w]; }
+        gen[j] = besti == 0x7fffffff ? 0 : besti;
+    }
+}
+
+__global__ void decode_advance_kernel(int* pos_ptr) { *pos_ptr += 1; }
+
+}  // namespace
+
+extern "C" int mmtg_decode_embed(int dtype, const void* table, const long long* seq, long ldseq, const void* c, void* x,
+                                 const int* pos_ptr, const long long* tpw_type, const long long* tpw_mask,
+                                 long long* type_out, int* keep, long ldkeep, int B, int P, int S, int E, int two_sents,
+                                 int V, int sent, int max_sent_num, void* stream) {
+    MMTG_REQUIRE(table && seq && c && x && pos_ptr && tpw_type && tpw_mask && type_out && keep, "decode_embed: null pointer");
+    MMTG_REQUIRE(B > 0 && E % 8 == 0 && sent > 1 && max_sent_num > 1, "decode_embed: bad sizes");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(MMTG_PROF_DECODE, s, (double)B * E, (dtype == MMTG_F32 ? 12.0 : 6.0) * B * E);
+    if (dtype == MMTG_F32)
+        hipLaunchKernelGGL(decode_embed_kernel<float>, dim3(B), dim3(256), 0, s, (const float*)table, seq, ldseq, (const float*)c, (float*)x, pos_ptr, tpw_type, tpw_mask, type_out, keep, ldkeep, P, S, E, two_sents, V, sent, max_sent_num);
+    else if (dtype == MMTG_BF16)
+        hipLaunchKernelGGL(decode_embed_kernel<bf16>, dim3(B), dim3(256), 0, s, (const bf16*)table, seq, ldseq, (const bf16*)c, (bf16*)x, pos_ptr, tpw_type, tpw_mask, type_out, keep, ldkeep, P, S, E, two_sents, V, sent, max_sent_num);
+    else MMTG_FAIL(MMTG_ERR_BAD_ARG, "decode_embed: bad dtype");
+    MMTG_LAUNCH_CHECK("decode_embed");
+    return MMTG_OK;
+}
+
+extern "C" int mmtg_decode_embed_add(int dtype, const void* g, const void* wpe, const void* wte, const long long* type_ids,
+                                     const int* pos_ptr, void* h, int B, int D, void* stream) {
+    MMTG_REQUIRE(g && wpe && wte && type_ids && pos_ptr && h && B > 0 && D > 0, "decode_embed_add: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(MMTG_PROF_DECODE, s, 2.0 * B * D, (dtype == MMTG_F32 ? 16.0 : 8.0) * B * D);
+    if (dtype == MMTG_F32)
+        hipLaunchKernelGGL(decode_embed_add_kernel<float>, dim3(B), dim3(256), 0, s, (const float*)g, (const float*)wpe, (const float*)wte, type_ids, pos_ptr, (float*)h, D);
+    else if (dtype == MMTG_BF16)
+        hipLaunchKernelGGL(decode_embed_add_kernel<bf16>, dim3(B), dim3(256), 0, s, (const bf16*)g, (const bf16*)wpe, (const bf16*)wte, type_ids, pos_ptr, (bf16*)h, D);
+    else MMTG_FAIL(MMTG_ERR_BAD_ARG, "decode_embed_add: bad dtype");
+    MMTG_LAUNCH_CHECK("decode_embed_add");
+    return MMTG_OK;
+}
+
+extern "C" int mmtg_decode_attn(int dtype, const void* qkv, void* kcache, void* vcache, const int* keep, long ldkeep,
+                                const int* pos_ptr, void* out, int B, int nH, int dh, int Tmax, void* stream) {
+    MMTG_REQUIRE(qkv && kcache && vcache && keep && pos_ptr && out, "decode_attn: null pointer");
+    MMTG_REQUIRE(dh == 64 && B > 0 && nH > 0 && Tmax > 0 && Tmax <= 1024, "decode_attn: head dim 64, Tmax <= 1024");
+    hipStream_t s = (hipStream_t)stream;
+    const double esz = dtype == MMTG_F32 ? 4 : 2;
+    ProfScope prof(MMTG_PROF_DECODE, s, 4.0 * B * nH * (double)Tmax * dh, esz * 2.0 * B * nH * (double)Tmax * dh);
+    dim3 grid(nH, B), block(64);
+    if (dtype == MMTG_F32)
+        hipLaunchKernelGGL(decode_attn_kernel<float>, grid, block, 0, s, (const float*)qkv, (float*)kcache, (float*)vcache, keep, ldkeep, pos_ptr, (float*)out, nH, Tmax);
+    else if (dtype == MMTG_BF16)
+        hipLaunchKernelGGL(decode_attn_kernel<bf16>, grid, block, 0, s, (const bf16*)qkv, (bf16*)kcache, (bf16*)vcache, keep, ldkeep, pos_ptr, (bf16*)out, nH, Tmax);
+    else MMTG_FAIL(MMTG_ERR_BAD_ARG, "decode_attn: bad dtype");
+    MMTG_LAUNCH_CHECK("decode_attn");
+    return MMTG_OK;
+}
+
+extern "C" int mmtg_decode_select(const float* logits, long ldl, int V, long long* seq, long ldseq, const int* pos_ptr,
+                                  int P, int sent, float temperature, float rep_penalty, int B, void* stream) {
+    MMTG_REQUIRE(seq && pos_ptr && B > 0 && sent > 1, "decode_select: bad args");
+    MMTG_REQUIRE(!logits || (V > 0 && ldl >= V && temperature > 0.f && rep_penalty > 0.f), "decode_select: bad logits args");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(MMTG_PROF_DECODE, s, 4.0 * B * V, 4.0 * B * V);
+    hipLaunchKernelGGL(decode_select_kernel, dim3(B), dim3(256), 0, s, logits, ldl, V, seq, ldseq, pos_ptr, P, sent,
+                       temperature, rep_penalty, logits != nullptr);
+    MMTG_LAUNCH_CHECK("decode_select");
+    return MMTG_OK;
+}
+
+extern "C" int mmtg_decode_advance(int* pos_ptr, void* stream) {
+    MMTG_REQUIRE(pos_ptr, "decode_advance: null pointer");
+    hipLaunchKernelGGL(decode_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, pos_ptr);
+    MMTG_LAUNCH_CHECK("decode_advance");
+    return MMTG_OK;
+}

@@ -72,23 +72,27 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, T*
     if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
 }
 
-// One block = 4 waves; each wave strides over rows, keeps dgamma/dbeta partials in
-// registers, block-reduces them through LDS and issues one atomic per column per block.
+// One block = 4 waves; each wave strides over rows and keeps its dgamma / dbeta (/ column-sum)
+// partials in registers; the block reduces them through LDS and writes ONE partial row per block to
+// a workspace, a second tiny kernel sums the <= 512 partial rows per column.  (Atomics from ~1000
+// blocks onto the same `cols` addresses ran 3x slower than the streaming part of the kernel.)
+// Optionally also emits dx * dropout-mask (the gradient entering the previous residual branch's
+// dropout) and its column sum (= that branch's bias gradient), saving two more passes over dx.
 template <typename T>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const T* __restrict__ dres,
-                                                     T* __restrict__ dx, float* __restrict__ dgamma,
-                                                     float* __restrict__ dbeta, int rows, int cols) {
-    __shared__ float sg[4][1024];
-    __shared__ float sb[4][1024];
+                                                     T* __restrict__ dx, T* __restrict__ dxm, float* __restrict__ ws,
+                                                     int rows, int cols, int want_colsum,
+                                                     uint32_t thresh, uint32_t seed, float inv_keep) {
+    __shared__ float sred[3][4][1024];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float ag[LN_MAXIT][4], ab[LN_MAXIT][4], gm[LN_MAXIT][4];
+    float ag[LN_MAXIT][4], ab[LN_MAXIT][4], ac[LN_MAXIT][4], gm[LN_MAXIT][4];
 #pragma unroll
     for (int it = 0; it < LN_MAXIT; ++it) {
         const int c = it * 256 + lane * 4;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { ag[it][e] = 0.f; ab[it][e] = 0.f; gm[it][e] = 0.f; }
+        for (int e = 0; e < 4; ++e) { ag[it][e] = 0.f; ab[it][e] = 0.f; ac[it][e] = 0.f; gm[it][e] = 0.f; }
         if (c < cols) ld4<float>(gamma + c, gm[it]);
     }
     for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
@@ -128,6 +132,17 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                     for (int e = 0; e < 4; ++e) o[e] += r4[e];
                 }
                 st4<T>(dx + (long)row * cols + c, o);
+                if (want_colsum || dxm) {
+                    // the consumer sees the rounded dx: mask / sum exactly what it will read
+                    float m4[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        m4[e] = (float)(T)o[e];
+                        if (thresh) m4[e] *= dropout_scale(seed, (uint32_t)((long)row * cols + c + e), thresh, inv_keep);
+                        ac[it][e] += (float)(T)m4[e];
+                    }
+                    if (dxm) st4<T>(dxm + (long)row * cols + c, m4);
+                }
             }
         }
     }
@@ -136,14 +151,37 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
         const int c = it * 256 + lane * 4;
         if (c < cols) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { sg[wave][c + e] = ag[it][e]; sb[wave][c + e] = ab[it][e]; }
+            for (int e = 0; e < 4; ++e) {
+                sred[0][wave][c + e] = ag[it][e];
+                sred[1][wave][c + e] = ab[it][e];
+                sred[2][wave][c + e] = ac[it][e];
+            }
         }
     }
     __syncthreads();
+    float* out = ws + (long)blockIdx.x * 3 * cols;
     for (int c = threadIdx.x; c < cols; c += 256) {
-        atomicAdd(dgamma + c, sg[0][c] + sg[1][c] + sg[2][c] + sg[3][c]);
-        atomicAdd(dbeta + c, sb[0][c] + sb[1][c] + sb[2][c] + sb[3][c]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            out[k * cols + c] = sred[k][0][c] + sred[k][1][c] + sred[k][2][c] + sred[k][3][c];
     }
+}
+
+// grid (cols/64, 3): block = 64 columns x 4 row groups of one quantity (dgamma / dbeta / colsum)
+__global__ __launch_bounds__(256) void ln_bwd_finalize_kernel(const float* __restrict__ ws, int nblocks, int cols,
+        float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dcol) {
+    __shared__ float red[4][64];
+    const int q = blockIdx.y;
+    float* dst = q == 0 ? dgamma : q == 1 ? dbeta : dcol;
+    if (!dst) return;
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    float a = 0.f;
+    if (c < cols)
+        for (int k = rg; k < nblocks; k += 4) a += ws[((long)k * 3 + q) * cols + c];
+    red[rg][cl] = a;
+    __syncthreads();
+    if (rg == 0 && c < cols) dst[c] += red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
 }
 
 // out[n] += sum_m X[m,n]: block = 256 threads -> 64 column-quads x 4 row lanes
@@ -189,20 +227,33 @@ extern "C" int mmtg_layernorm_fwd(int dtype, const void* x, void* y, const float
     return MMTG_OK;
 }
 
+static inline int ln_bwd_blocks(int rows) { return min(cdiv(rows, 4), 512); }
+
+extern "C" long mmtg_layernorm_bwd_ws(int rows, int cols) { return (long)ln_bwd_blocks(rows) * 3 * cols; }
+
 extern "C" int mmtg_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma,
                                   const float* mean, const float* rstd, const void* dres, void* dx,
-                                  float* dgamma, float* dbeta, int rows, int cols, void* stream) {
+                                  float* dgamma, float* dbeta, int rows, int cols,
+                                  void* dx_masked, unsigned drop_thresh, unsigned drop_seed, float* dcolsum,
+                                  float* ws, long ws_floats, void* stream) {
     MMTG_REQUIRE(rows > 0 && cols > 0 && cols % 4 == 0 && cols <= 1024, "layernorm_bwd: cols=%d must be a multiple of 4 and <= 1024", cols);
     MMTG_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta, "layernorm_bwd: null pointer");
+    MMTG_REQUIRE(ws && ws_floats >= mmtg_layernorm_bwd_ws(rows, cols), "layernorm_bwd: workspace of %ld floats required",
+                 mmtg_layernorm_bwd_ws(rows, cols));
+    MMTG_REQUIRE(!drop_thresh || dx_masked, "layernorm_bwd: dropout mask requested without dx_masked");
     hipStream_t s = (hipStream_t)stream;
     const double esz = dtype == MMTG_F32 ? 4 : 2;
-    ProfScope prof(MMTG_PROF_LAYERNORM, s, 16.0 * rows * cols, (dres ? 4.0 : 3.0) * esz * rows * cols);
-    dim3 grid(min(cdiv(rows, 4), 1024)), block(256);
+    ProfScope prof(MMTG_PROF_LAYERNORM, s, 16.0 * rows * cols, ((dres ? 4.0 : 3.0) + (dx_masked ? 1.0 : 0.0)) * esz * rows * cols);
+    const int nb = ln_bwd_blocks(rows);
+    dim3 grid(nb), block(256);
+    const float ik = drop_thresh ? (float)(4294967296.0 / (4294967296.0 - (double)drop_thresh)) : 1.0f;
+    const int want = dcolsum != nullptr;
     if (dtype == MMTG_F32)
-        hipLaunchKernelGGL(ln_bwd_kernel<float>, grid, block, 0, s, (const float*)dy, (const float*)x, gamma, mean, rstd, (const float*)dres, (float*)dx, dgamma, dbeta, rows, cols);
+        hipLaunchKernelGGL(ln_bwd_kernel<float>, grid, block, 0, s, (const float*)dy, (const float*)x, gamma, mean, rstd, (const float*)dres, (float*)dx, (float*)dx_masked, ws, rows, cols, want, drop_thresh, drop_seed, ik);
     else if (dtype == MMTG_BF16)
-        hipLaunchKernelGGL(ln_bwd_kernel<bf16>, grid, block, 0, s, (const bf16*)dy, (const bf16*)x, gamma, mean, rstd, (const bf16*)dres, (bf16*)dx, dgamma, dbeta, rows, cols);
+        hipLaunchKernelGGL(ln_bwd_kernel<bf16>, grid, block, 0, s, (const bf16*)dy, (const bf16*)x, gamma, mean, rstd, (const bf16*)dres, (bf16*)dx, (bf16*)dx_masked, ws, rows, cols, want, drop_thresh, drop_seed, ik);
     else MMTG_FAIL(MMTG_ERR_BAD_ARG, "layernorm_bwd: bad dtype");
+    hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3(cdiv(cols, 64), 3), dim3(256), 0, s, ws, nb, cols, dgamma, dbeta, dcolsum);
     MMTG_LAUNCH_CHECK("layernorm_bwd");
     return MMTG_OK;
 }

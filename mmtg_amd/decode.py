@@ -1,0 +1,145 @@
+"""Batched greedy generation with a KV cache and a replayed hipGraph per token.
+
+The reference decodes one sample at a time and re-runs the whole model on the growing
+prefix for every token (src/generate.py:117-145, O(L^2), ~198 full forwards per sample).
+Here every row of a batch advances in lock step, one token per step, against per-layer
+K/V caches; the step is a fixed launch sequence whose only varying input -- the position --
+lives in device memory, so it is captured once into a hipGraph and replayed.
+
+Semantics kept from the reference: forced [#EOS#]/[#START#] cadence every 22 slots,
+per-occurrence repetition penalty, temperature, banned ids, sticky PAD, inference-branch
+type ids / key mask.  The type-id / mask rule is applied per row (the reference reads row 0
+only because it never batches; identical at batch 1).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import hip
+
+
+class GreedyDecoder:
+    def __init__(self, model, max_batch, max_len=None, use_graph=True):
+        self.model = model
+        self.eng = model.engine()
+        sh = self.eng.sh
+        self.B = max_batch
+        self.max_len = sh.max_seq_length if max_len is None else max_len      # lyric positions incl. the first [#START#]
+        self.Tmax = sh.P + self.max_len + 1
+        if self.Tmax > sh.NP:
+            raise ValueError("prompt + max_len exceeds n_positions")
+        self.use_graph = use_graph
+        dev, tdt = self.eng.dev, self.eng.tdt
+        B, D, H, E = self.B, sh.D, sh.H, sh.E
+        self.seq = torch.zeros(B, self.Tmax, dtype=torch.long, device=dev)
+        self.pos = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.keep = torch.zeros(B, self.Tmax, dtype=torch.int32, device=dev)
+        self.types = torch.zeros(B, dtype=torch.long, device=dev)
+        self.tpw_type = torch.zeros(B, sh.P, dtype=torch.long, device=dev)
+        self.tpw_mask = torch.zeros(B, sh.P, dtype=torch.long, device=dev)
+        self.c = torch.zeros(B * sh.S, E, dtype=tdt, device=dev)
+        self.kc = torch.zeros(sh.L, B, sh.nH, self.Tmax, 64, dtype=tdt, device=dev)
+        self.vc = torch.zeros_like(self.kc)
+        z = lambda *s: torch.empty(*s, dtype=tdt, device=dev)
+        self.x, self.h1 = z(B, E), z(B, H)
+        self.h, self.h2 = z(B, D), z(B, D)
+        self.a, self.qkv, self.ctx = z(B, D), z(B, 3 * D), z(B, D)
+        self.u, self.g = z(B, 4 * D), z(B, 4 * D)
+        self.mu = torch.empty(B, dtype=torch.float32, device=dev)
+        self.rs = torch.empty(B, dtype=torch.float32, device=dev)
+        self.logits = torch.empty(B, self.eng.layout.Vpad, dtype=torch.float32, device=dev)
+        self.graphs = {}
+        self.params = None
+
+    # ------------------------------------------------------------------ one token
+    def _step(self, with_head):
+        eng, sh, B = self.eng, self.eng.sh, self.B
+        D, H, E = sh.D, sh.H, sh.E
+        pre = "decoder.gpt2.transformer."
+        temperature, rep = self.params
+        sent = sh.msl + 2
+        hip.decode_embed(eng.table, self.seq, self.c, self.x, self.pos, self.tpw_type, self.tpw_mask, self.types,
+                         self.keep, B, sh.P, sh.S, E, sh.two_sents, eng.table.shape[0], sent,
+                         sh.max_seq_length // sent + 1)
+        eng._fwd(self.x, "decoder.projector_layer1.weight", self.h1, B, "linear",
+                 bias=eng.P("decoder.projector_layer1.bias"), epi=hip.EPI_TANH)
+        eng._fwd(self.h1, "decoder.projector_layer2.weight", self.h, B, "linear", bias=eng.P("decoder.projector_layer2.bias"))
+        hip.decode_embed_add(self.h, eng.W(pre + "wpe.weight"), eng.W(pre + "wte.weight"), self.types, self.pos, self.h, B, D)
+        hcur, hnext = self.h, self.h2
+        for l in range(sh.L):
+            p = f"{pre}h.{l}."
+            hip.layernorm_fwd(hcur, self.a, eng.P(p + "ln_1.weight"), eng.P(p + "ln_1.bias"), self.mu, self.rs, B, D, sh.eps)
+            eng._fwd(self.a, p + "attn.c_attn.weight", self.qkv, B, "conv1d", bias=eng.P(p + "attn.c_attn.bias"))
+            hip.decode_attn(self.qkv, self.kc[l], self.vc[l], self.keep, self.pos, self.ctx, B, sh.nH, 64, self.Tmax)
+            eng._fwd(self.ctx, p + "attn.c_proj.weight", hnext, B, "conv1d", bias=eng.P(p + "attn.c_proj.bias"),
+                     epi=hip.EPI_RESID, aux=hcur, ldaux=D)
+            hip.layernorm_fwd(hnext, self.a, eng.P(p + "ln_2.weight"), eng.P(p + "ln_2.bias"), self.mu, self.rs, B, D, sh.eps)
+            eng._fwd(self.a, p + "mlp.c_fc.weight", self.g, B, "conv1d", bias=eng.P(p + "mlp.c_fc.bias"),
+                     epi=hip.EPI_GELU, aux2=self.u)
+            eng._fwd(self.g, p + "mlp.c_proj.weight", hcur, B, "conv1d", bias=eng.P(p + "mlp.c_proj.bias"),
+                     epi=hip.EPI_RESID, aux=hnext, ldaux=D)
+        if with_head:
+            hip.layernorm_fwd(hcur, self.a, eng.P(pre + "ln_f.weight"), eng.P(pre + "ln_f.bias"), self.mu, self.rs, B, D, sh.eps)
+            Vp = eng.layout.Vpad
+            hip.gemm(self.a, eng.Wp("wte"), self.logits, B, Vp, D, transB=True, ldb=D, out_f32=True)
+            hip.decode_select(self.logits, Vp, min(sh.V, 13317), self.seq, self.pos, sh.P, sent, temperature, rep, B)
+        else:
+            hip.decode_select(None, 0, 0, self.seq, self.pos, sh.P, sent, temperature, rep, B)
+        hip.decode_advance(self.pos)
+
+    def _run_step(self, with_head):
+        if not self.use_graph:
+            self._step(with_head)
+            return
+        key = (with_head, self.params)
+        g = self.graphs.get(key)
+        if g is None:
+            # warm-up outside capture (lazy LDS-attribute / module loading), then rewind the position
+            saved = (self.pos.clone(), self.seq.clone(), self.keep.clone())
+            self._step(with_head)
+            torch.cuda.synchronize()
+            self.pos.copy_(saved[0]); self.seq.copy_(saved[1]); self.keep.copy_(saved[2])
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._step(with_head)
+            self.graphs[key] = g
+            self.pos.copy_(saved[0]); self.seq.copy_(saved[1]); self.keep.copy_(saved[2])
+        g.replay()
+
+    # ------------------------------------------------------------------ public
+    @torch.no_grad()
+    def generate(self, batch, length, temperature=1.0, repitition_penalty=1.0):
+        """batch: dict with topic_ids/tpw_* [B,P], topic_emb, img_embs, r_embs (no targets needed).
+        Runs `length` iterations of the reference loop and returns the lyric ids
+        [B, 1 + length] (column 0 is the initial [#START#])."""
+        eng, sh = self.eng, self.eng.sh
+        B = batch["img_embs"].shape[0]
+        if B != self.B:
+            raise ValueError("decoder was built for batch %d, got %d" % (self.B, B))
+        if length > self.max_len:
+            raise ValueError("length %d exceeds max_len %d" % (length, self.max_len))
+        self.params = (float(temperature), float(repitition_penalty))
+        eng.invalidate_copies()
+        a = eng.forward(batch, train_flag=False, training=False, encode_only=True)
+        self.c.copy_(a["c"])
+        self.seq.zero_()
+        self.seq[:, :sh.P] = batch["topic_ids"].to(eng.dev).long()
+        self.seq[:, sh.P] = 1                                   # [#START#]
+        self.tpw_type.copy_(batch["tpw_type_ids"].to(eng.dev).long())
+        self.tpw_mask.copy_(batch["tpw_attention_mask"].to(eng.dev).long())
+        self.keep.zero_()
+        self.pos.zero_()
+        n_steps = sh.P + length                                 # positions 0 .. P+length-1 are consumed
+        for pos in range(n_steps):
+            j = pos + 1 - sh.P                                  # lyric index appended after this step
+            forced = j < 1 or (j > 1 and (j + 1) % (sh.msl + 2) in (0, 1))
+            self._run_step(with_head=not forced)
+        return self.seq[:, sh.P:sh.P + 1 + length].clone()
+
+    @staticmethod
+    def reference_return(ids_row, length, sent=22):
+        """What the reference's sample_sequence returns for one row: the sequence as it stood
+        before the append of the last iteration that called the model (generate.py:126,144)."""
+        last_call = max(i for i in range(length) if not (i > 0 and (i + 2) % sent in (0, 1)))
+        return list(ids_row[:1 + last_call])

@@ -309,7 +309,8 @@ class Engine:
         hip.cast_f32_to(t, out, t.numel())
         return out
 
-    def forward(self, batch, train_flag=True, training=False, per_row_infer=True, need_logits=True):
+    def forward(self, batch, train_flag=True, training=False, per_row_infer=True, need_logits=True,
+                encode_only=False):
         """MMTG.forward (model.py:356-400).  Returns dict(logits_pad [M,Vpad] f32, B, T, ...);
         lm_loss / kl are device scalars in self.scalars after loss()."""
         sh, dt = self.sh, self.dtype
@@ -325,13 +326,17 @@ class Engine:
         B = img.shape[0]
         if img.shape[1] != S:
             raise ValueError("batch has %d experience steps, model_cfgs['seq_len'] = %d" % (img.shape[1], S))
-        targets = batch["targets"].to(self.dev, torch.long).contiguous()
-        topic_ids = batch["topic_ids"].to(self.dev, torch.long).contiguous()
-        L = targets.shape[1]
-        T = P + L
-        M = B * T
-        if T > sh.NP:
-            raise ValueError("sequence length %d exceeds n_positions %d" % (T, sh.NP))
+        if encode_only:          # decode: only the experience vectors c[B,S,E] are needed
+            targets = topic_ids = None
+            L = T = M = 0
+        else:
+            targets = batch["targets"].to(self.dev, torch.long).contiguous()
+            topic_ids = batch["topic_ids"].to(self.dev, torch.long).contiguous()
+            L = targets.shape[1]
+            T = P + L
+            M = B * T
+            if T > sh.NP:
+                raise ValueError("sequence length %d exceeds n_positions %d" % (T, sh.NP))
         a = {"B": B, "L": L, "T": T, "M": M, "seed": seed, "pdrop": (pe, pa, pr), "train_flag": train_flag,
              "targets": targets, "topic_ids": topic_ids}
 
@@ -384,6 +389,10 @@ class Engine:
         c = self.buf("c", (B * S, E))
         self._fwd(o, "mm_atten_layer.out_linear.weight", c, B * S, "linear", bias=self.P("mm_atten_layer.out_linear.bias"))
 
+        if encode_only:
+            a.update(c=c, kl=kl)
+            self.act = a
+            return a
         # ---------------- decoder front end (model.py:251-281) + GPT-2 input embedding
         x = self.buf("x_cond", (M, E))
         hip.embed_condition(self.table, topic_ids, targets, c, x, B, P, L, S, E, sh.two_sents, self.table.shape[0])
@@ -519,12 +528,19 @@ class Engine:
         # (Vpad rows: the pad columns of dlogits are zero, so the pad rows of the pack receive +0)
         hip.gemm(dlogits, a["hf"], self.Gp("wte"), Vp, D, M, transA=True, transB=False, lda=Vp, ldb=D, ldc=D,
                  epi=hip.EPI_ATOMIC, splits=_wgrad_splits(Vp, D, M))
+        # Every LayerNorm backward on the residual stream also emits, in the same pass, the
+        # dropout-masked gradient entering the previous residual branch and that branch's bias
+        # gradient (column sum) -- see mmtg_layernorm_bwd.
+        lnws = self.buf("ln_bwd_ws", (hip.lib().mmtg_layernorm_bwd_ws(M, max(D, H)),), torch.float32)
         dx = self.buf("d_resid_a", (M, D))
-        hip.layernorm_bwd(dhf, a["x_last"], self.P(pre + "ln_f.weight"), a["muf"], a["rsf"], None, dx,
-                          self.G(pre + "ln_f.weight"), self.G(pre + "ln_f.bias"), M, D)
-        self._ready("ln_f.b")
         dx2 = self.buf("d_resid_b", (M, D))
         dmask = self.buf("d_masked", (M, D)) if pr > 0 else None
+        lastp = f"{pre}h.{sh.L - 1}."
+        hip.layernorm_bwd(dhf, a["x_last"], self.P(pre + "ln_f.weight"), a["muf"], a["rsf"], None, dx,
+                          self.G(pre + "ln_f.weight"), self.G(pre + "ln_f.bias"), M, D,
+                          dx_masked=dmask, drop_p=pr, drop_seed=a["layers"][sh.L - 1][13] + 2,
+                          dcolsum=self.G(lastp + "mlp.c_proj.bias"), ws=lnws)
+        self._ready("ln_f.b")
         du = self.buf("d_u", (M, 4 * D))
         dm = self.buf("d_m", (M, D))
         dctx = self.buf("d_ctx", (M, D))
@@ -535,30 +551,32 @@ class Engine:
         for l in range(sh.L - 1, -1, -1):
             p = f"{pre}h.{l}."
             (xin, mu1, rs1, a1, qkv, ctx, lse, xmid, mu2, rs2, m2, u, gact, s) = a["layers"][l]
-            # x_out = x_mid + drop(gact W2 + b2)
-            dy = dx
-            if pr > 0:
-                hip.dropout_apply(dx, dmask, M * D, pr, s + 2)
-                dy = dmask
+            # x_out = x_mid + drop(gact W2 + b2): dy = dx * mask (already produced, with its bias gradient)
+            dy = dmask if pr > 0 else dx
             self._dgrad(dy, p + "mlp.c_proj.weight", du, M, "conv1d", epi=hip.EPI_DGELU, aux=u, ldaux=4 * D)
-            self._wgrad(gact, dy, p + "mlp.c_proj.weight", p + "mlp.c_proj.bias", M, "conv1d")
+            self._wgrad(gact, dy, p + "mlp.c_proj.weight", None, M, "conv1d")
             self._dgrad(du, p + "mlp.c_fc.weight", dm, M, "conv1d")
             self._wgrad(m2, du, p + "mlp.c_fc.weight", p + "mlp.c_fc.bias", M, "conv1d")
             hip.layernorm_bwd(dm, xmid, self.P(p + "ln_2.weight"), mu2, rs2, dx, dx2,
-                              self.G(p + "ln_2.weight"), self.G(p + "ln_2.bias"), M, D)
+                              self.G(p + "ln_2.weight"), self.G(p + "ln_2.bias"), M, D,
+                              dx_masked=dmask, drop_p=pr, drop_seed=s + 1,
+                              dcolsum=self.G(p + "attn.c_proj.bias"), ws=lnws)
             # x_mid = x_in + drop(ctx Wp + bp)
-            dy = dx2
-            if pr > 0:
-                hip.dropout_apply(dx2, dmask, M * D, pr, s + 1)
-                dy = dmask
+            dy = dmask if pr > 0 else dx2
             self._dgrad(dy, p + "attn.c_proj.weight", dctx, M, "conv1d")
-            self._wgrad(ctx, dy, p + "attn.c_proj.weight", p + "attn.c_proj.bias", M, "conv1d")
+            self._wgrad(ctx, dy, p + "attn.c_proj.weight", None, M, "conv1d")
             hip.attn_bwd(qkv, a["keep"], ctx, dctx, lse, delta, dq32, dqkv, B, T, sh.nH, D // sh.nH,
                          drop_p=pa, drop_seed=s)
             self._dgrad(dqkv, p + "attn.c_attn.weight", da, M, "conv1d")
             self._wgrad(a1, dqkv, p + "attn.c_attn.weight", p + "attn.c_attn.bias", M, "conv1d")
-            hip.layernorm_bwd(da, xin, self.P(p + "ln_1.weight"), mu1, rs1, dx2, dx,
-                              self.G(p + "ln_1.weight"), self.G(p + "ln_1.bias"), M, D)
+            if l > 0:
+                hip.layernorm_bwd(da, xin, self.P(p + "ln_1.weight"), mu1, rs1, dx2, dx,
+                                  self.G(p + "ln_1.weight"), self.G(p + "ln_1.bias"), M, D,
+                                  dx_masked=dmask, drop_p=pr, drop_seed=a["layers"][l - 1][13] + 2,
+                                  dcolsum=self.G(f"{pre}h.{l - 1}.mlp.c_proj.bias"), ws=lnws)
+            else:
+                hip.layernorm_bwd(da, xin, self.P(p + "ln_1.weight"), mu1, rs1, dx2, dx,
+                                  self.G(p + "ln_1.weight"), self.G(p + "ln_1.bias"), M, D, ws=lnws)
             self._ready(p + "ln_1.bias")
         # ---- GPT-2 input embedding: h0 = drop(g + wpe + wte[type])
         hip.embed_add_bwd(dx, a["type_ids"], self.G(pre + "wpe.weight"), self.G(pre + "wte.weight"), M, T, D,
@@ -602,7 +620,7 @@ class Engine:
             hip.colsum(dqkv_a, B * S, 3 * H, self.Gp(mod + "_qkv_b"))
             dh_all = self.buf("d_hall", (B * S, H))
             hip.layernorm_bwd(dhln, h_all, self.P(lnk + ".weight"), *a["st"][lnk], None, dh_all,
-                              self.G(lnk + ".weight"), self.G(lnk + ".bias"), B * S, H)
+                              self.G(lnk + ".weight"), self.G(lnk + ".bias"), B * S, H, ws=lnws)
             # BPTT over the S steps (rows b*S+t)
             r = f"encoder.rnns_{ch}."
             hip.cast_to_f32(dh_all, row32, B * S * H)
@@ -627,7 +645,7 @@ class Engine:
         hip.cast_f32_to(dtopic, dt_ln, B * H)
         dt_raw = self.buf("d_traw", (B, H))
         hip.layernorm_bwd(dt_ln, a["t_raw"], self.P("ln_layer1.weight"), *a["st"]["ln1"], None, dt_raw,
-                          self.G("ln_layer1.weight"), self.G("ln_layer1.bias"), B, H)
+                          self.G("ln_layer1.weight"), self.G("ln_layer1.bias"), B, H, ws=lnws)
         self._wgrad(a["xt"], dt_raw, "encoder.topic_fc.weight", "encoder.topic_fc.bias", B, "linear")
         self._ready("encoder.topic_fc.bias")
 

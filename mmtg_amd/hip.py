@@ -31,7 +31,8 @@ _SIGS = {
     "mmtg_gemm": ([_i, _i, _i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _vp, _i, _vp, _l, _vp, _i, _f, _i, _u, _u, _i, _vp], _i),
     "mmtg_colsum": ([_i, _vp, _l, _i, _i, _vp, _vp], _i),
     "mmtg_layernorm_fwd": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp], _i),
-    "mmtg_layernorm_bwd": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp], _i),
+    "mmtg_layernorm_bwd_ws": ([_i, _i], _l),
+    "mmtg_layernorm_bwd": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _u, _u, _vp, _vp, _l, _vp], _i),
     "mmtg_attn_fwd": ([_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _u, _u, _vp], _i),
     "mmtg_attn_bwd": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _u, _u, _vp], _i),
     "mmtg_embed_condition": ([_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
@@ -54,6 +55,11 @@ _SIGS = {
     "mmtg_cast_to_f32": ([_i, _vp, _vp, _l, _vp], _i),
     "mmtg_axpy_f32": ([_vp, _vp, _f, _l, _vp], _i),
     "mmtg_logits_process_argmax": ([_vp, _l, _i, _vp, _l, _vp, _f, _f, _vp, _i, _vp], _i),
+    "mmtg_decode_embed": ([_i, _vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
+    "mmtg_decode_embed_add": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp], _i),
+    "mmtg_decode_attn": ([_i, _vp, _vp, _vp, _vp, _l, _vp, _vp, _i, _i, _i, _i, _vp], _i),
+    "mmtg_decode_select": ([_vp, _l, _i, _vp, _l, _vp, _i, _i, _f, _f, _i, _vp], _i),
+    "mmtg_decode_advance": ([_vp, _vp], _i),
 }
 
 
@@ -158,9 +164,20 @@ def layernorm_fwd(x, y, gamma, beta, mean, rstd, rows, cols, eps=1e-5):
                                     float(eps), _stream()), "layernorm_fwd")
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, cols):
+_ln_ws = {}
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, cols, dx_masked=None, drop_p=0.0,
+                  drop_seed=0, dcolsum=None, ws=None):
+    if ws is None:   # convenience for tests; the engine passes its own workspace
+        need = lib().mmtg_layernorm_bwd_ws(rows, cols)
+        key = (x.device, need)
+        ws = _ln_ws.get(key)
+        if ws is None:
+            ws = _ln_ws[key] = torch.empty(need, device=x.device, dtype=torch.float32)
     _check(lib().mmtg_layernorm_bwd(dt(x), _p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx),
-                                    _p(dgamma), _p(dbeta), rows, cols, _stream()), "layernorm_bwd")
+                                    _p(dgamma), _p(dbeta), rows, cols, _p(dx_masked), drop_thresh(drop_p),
+                                    drop_seed & 0xFFFFFFFF, _p(dcolsum), _p(ws), ws.numel(), _stream()), "layernorm_bwd")
 
 
 # ------------------------------------------------------------------ attention
@@ -278,3 +295,29 @@ def logits_process_argmax(logits, ldl, V, generated, ldg, gen_len, temperature, 
     _check(lib().mmtg_logits_process_argmax(_p(logits), ldl, V, _p(generated), ldg, _p(gen_len),
                                             float(temperature), float(rep_penalty), _p(nxt), B, _stream()),
            "logits_process_argmax")
+
+
+# ------------------------------------------------------------------ KV-cached decode step
+def decode_embed(table, seq, c, x, pos, tpw_type, tpw_mask, type_out, keep, B, P, S, E, two_sents, V, sent, max_sent_num):
+    _check(lib().mmtg_decode_embed(dt(table), _p(table), _p(seq), seq.stride(0), _p(c), _p(x), _p(pos), _p(tpw_type),
+                                   _p(tpw_mask), _p(type_out), _p(keep), keep.stride(0), B, P, S, E, two_sents, V, sent,
+                                   max_sent_num, _stream()), "decode_embed")
+
+
+def decode_embed_add(g, wpe, wte, type_ids, pos, h, B, D):
+    _check(lib().mmtg_decode_embed_add(dt(g), _p(g), _p(wpe), _p(wte), _p(type_ids), _p(pos), _p(h), B, D, _stream()),
+           "decode_embed_add")
+
+
+def decode_attn(qkv, kcache, vcache, keep, pos, out, B, nH, dh, Tmax):
+    _check(lib().mmtg_decode_attn(dt(qkv), _p(qkv), _p(kcache), _p(vcache), _p(keep), keep.stride(0), _p(pos), _p(out),
+                                  B, nH, dh, Tmax, _stream()), "decode_attn")
+
+
+def decode_select(logits, ldl, V, seq, pos, P, sent, temperature, rep_penalty, B):
+    _check(lib().mmtg_decode_select(_p(logits), ldl, V, _p(seq), seq.stride(0), _p(pos), P, sent, float(temperature),
+                                    float(rep_penalty), B, _stream()), "decode_select")
+
+
+def decode_advance(pos):
+    _check(lib().mmtg_decode_advance(_p(pos), _stream()), "decode_advance")

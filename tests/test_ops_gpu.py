@@ -174,6 +174,20 @@ def test_layernorm(dtype, cols):
     cs = torch.zeros(cols, device=DEV)
     hip.colsum(dy.to(DEV), rows, cols, cs)
     close(cs, dy.float().sum(0), torch.float32, rows, "colsum")
+    # fused tail: masked copy (same mask as the standalone kernel) + its column sum
+    dxm = torch.empty_like(xd)
+    dcs = torch.full((cols,), 2.0, device=DEV)
+    dg.zero_(); db.zero_()
+    hip.layernorm_bwd(dy.to(DEV), xd, gd, mean, rstd, dres.to(DEV), dx, dg, db, rows, cols,
+                      dx_masked=dxm, drop_p=0.2, drop_seed=99, dcolsum=dcs)
+    ref_m = torch.empty_like(xd)
+    hip.dropout_apply(dx, ref_m, rows * cols, 0.2, 99)
+    assert torch.equal(dxm, ref_m)
+    close(dcs - 2.0, ref_m.float().sum(0), torch.float32, rows, "ln fused colsum")
+    close(dg, gr.grad, torch.float32, rows, "ln dgamma (fused)")
+    dcs.zero_()
+    hip.layernorm_bwd(dy.to(DEV), xd, gd, mean, rstd, dres.to(DEV), dx, dg, db, rows, cols, dcolsum=dcs)
+    close(dcs, dx.float().sum(0), torch.float32, rows, "ln colsum without mask")
 
 
 # ------------------------------------------------------------------ attention
