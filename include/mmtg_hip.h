@@ -43,6 +43,8 @@ enum {
 };
 #define MMTG_GEMM_NO_TR 1 /* flags: gather K-strided bf16 fragments without ds_read_b64_tr_b16 */
 #define MMTG_GEMM_REGSTAGE 2 /* flags: register-staged v1 pipeline instead of the LDS-DMA one (bf16) */
+#define MMTG_GEMM_SKINNY 4    /* flags: force the 256x32-tile small-M configuration (bf16, transA=0,transB=1) */
+#define MMTG_GEMM_NO_SKINNY 8 /* flags: never pick it automatically (it is the default for M <= 256) */
 
 /* profiling categories (mmtg_prof_*) */
 enum {

@@ -74,12 +74,18 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_kernel(GemmArgs p) {
         }
         __syncthreads();
     }
-    gemm_epilogue<T, std_orient>(p, acc, m0, n0, wm, wn, g, l15);
+    gemm_epilogue<T, std_orient, 4, 4>(p, acc, m0 + wm * 64, n0 + wn * 64, g, l15);
 }
 
-// ------------------------------------------------------------------ LDS-DMA pipeline
+// ------------------------------------------------------------------ LDS-DMA pipeline (bf16)
+// Tile configuration: a BM x BN output tile per workgroup of WM x WN waves, each wave a
+// (BM/WM) x (BN/WN) sub-tile of TM x TN MFMA 16x16 tiles.  Built configurations:
+//   128x128, 2x2 waves (64x64 per wave)      training GEMMs, all three layouts, 2 workgroups/CU
+//   256x32,  4x1 waves (64x32 per wave)      decode (M = batch <= 256): N/32 workgroups stream the
+//                                            weights once each; NT layout only; 4-deep ring (144 KB)
+//                                            because a lone workgroup per CU must hide the load
+//                                            latency itself
 // One wave-instruction moves 64 lanes x 16 B = 1 KB into LDS at (wave-uniform base + lane*16).
-// Tile = 16 such 1-KB blocks; wave w issues blocks 4w..4w+3 of each operand tile.
 // Addressing is buffer-style: a wave-uniform descriptor over the whole operand, a per-lane byte
 // offset that is computed ONCE (the lane's swizzled source chunk relative to the tile origin) and a
 // scalar offset that advances by one K tile per iteration -> no vector address arithmetic in the
@@ -87,100 +93,164 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_kernel(GemmArgs p) {
 // returns zeros); only a ragged last K tile recomputes its offsets.
 constexpr int OOB = 0x7FFFFFF0;
 
-template <typename T, bool KS>
+// lane offset of 1-KB block `blk` of an operand tile.  KC: R rows x 128 B.  KS: 64 k-rows x (W*2) B.
+template <bool KS, int EXT>
 __device__ __forceinline__ int dma_voff(long ld, int row0, int nrows, int krem, int blk, int lane) {
-    constexpr int EPC = GT<T>::EPC;
-    if (!KS) {   // tile rows = operand rows (m or n), chunks along K
+    constexpr int EPC = 8;
+    if constexpr (!KS) {
         const int r = blk * 8 + (lane >> 3), pc = lane & 7;
         const int c = pc ^ (r & 7);
         const bool ok = (row0 + r < nrows) && (c * EPC < krem);
-        return ok ? (int)(((long)r * ld + c * EPC) * sizeof(T)) : OOB;
-    } else {     // tile rows = K, chunks along the operand's contiguous (m or n) extent
-        constexpr int CPR = GT<T>::CPR, RPB = 64 / CPR;
+        return ok ? (int)(((long)r * ld + c * EPC) * 2) : OOB;
+    } else {
+        constexpr int CPR = EXT / 8, RPB = 64 / CPR;      // chunks per k-row, k-rows per 1-KB block
+        static_assert(CPR >= 16, "K-strided tiles need >= 128 columns for the transposed-read swizzle");
         const int k = blk * RPB + lane / CPR, pc = lane % CPR;
         const int c = pc ^ ks_swz(k);
         const bool ok = (k < krem) && (row0 + c * EPC < nrows);
-        return ok ? (int)(((long)k * ld + c * EPC) * sizeof(T)) : OOB;
+        return ok ? (int)(((long)k * ld + c * EPC) * 2) : OOB;
     }
 }
 
-template <bool AKS, bool BKS, typename T>
-__device__ __forceinline__ void dma_offsets(const GemmArgs& p, int m0, int n0, int krem, int wave, int lane,
-                                            int (&va)[4], int (&vb)[4]) {
+// per-lane offsets of the transposed-read fragments of a K-strided tile of EXT columns (row bytes 2*EXT)
+template <int EXT, int NT>
+__device__ __forceinline__ void ks_offsets(int col0, int lane, int (&o)[NT]) {
+    const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+    const int k = 8 * g + q;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        va[i] = dma_voff<T, AKS>(p.lda, m0, p.M, krem, wave * 4 + i, lane);
-        vb[i] = dma_voff<T, BKS>(p.ldb, n0, p.N, krem, wave * 4 + i, lane);
+    for (int i = 0; i < NT; ++i) {
+        const int chunk = ((col0 + i * 16) >> 3) + (pp >> 1);
+        o[i] = k * (2 * EXT) + ((chunk ^ ks_swz(k)) << 4) + 8 * (pp & 1);
     }
 }
 
-__device__ __forceinline__ void dma_issue(__amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb, const int (&va)[4],
-                                          const int (&vb)[4], int sa, int sb, char* stage, int wave) {
+template <bool AKS, bool BKS, int TBM, int TBN, int NBA, int NBB>
+__device__ __forceinline__ void dma_issue_tile(const GemmArgs& p, __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb,
+                                               const int (&va)[NBA], const int (&vb)[NBB], int sa, int sb, char* stage, int TA,
+                                               int t, int nk_full, int nk, int klen, int m0, int n0, int wave, int lane,
+                                               bool dummy_tail) {
+    if (t < nk_full) {          // full tile: loop-invariant lane offsets
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, LDS_PTR(void, stage + (wave * 4 + i) * 1024), 16, va[i], sa, 0, 0);
+        for (int i = 0; i < NBA; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, LDS_PTR(void, stage + (wave * NBA + i) * 1024), 16, va[i], sa, 0, 0);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, LDS_PTR(void, stage + TILE_BYTES + (wave * 4 + i) * 1024), 16, vb[i], sb, 0, 0);
+        for (int i = 0; i < NBB; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, LDS_PTR(void, stage + TA + (wave * NBB + i) * 1024), 16, vb[i], sb, 0, 0);
+    } else if (t < nk) {        // ragged last K tile: recompute the offsets with the remaining K
+        const int krem = klen - t * 64;
+#pragma unroll
+        for (int i = 0; i < NBA; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, LDS_PTR(void, stage + (wave * NBA + i) * 1024), 16,
+                                                     dma_voff<AKS, TBM>(p.lda, m0, p.M, krem, wave * NBA + i, lane), sa, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NBB; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, LDS_PTR(void, stage + TA + (wave * NBB + i) * 1024), 16,
+                                                     dma_voff<BKS, TBN>(p.ldb, n0, p.N, krem, wave * NBB + i, lane), sb, 0, 0);
+    } else if (dummy_tail) {    // deep rings: keep the per-tile load count uniform for the counted vmcnt
+#pragma unroll
+        for (int i = 0; i < NBA; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, LDS_PTR(void, stage + (wave * NBA + i) * 1024), 16, OOB, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NBB; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, LDS_PTR(void, stage + TA + (wave * NBB + i) * 1024), 16, OOB, 0, 0, 0);
+    }
 }
 
-template <typename T, bool AKS, bool BKS>
-__global__ __launch_bounds__(NTHR, 2) void gemm_dma_kernel(GemmArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages of [A tile | B tile]
+template <int TBM, int TBN, int WM, int WN, int NBUF> struct DmaCfg {
+    // two workgroups per CU when their LDS rings fit in 80 KB each
+    static constexpr int MINW = ((TBM + TBN) * 128 * NBUF <= 80 * 1024 ? 2 : 1) * WM * WN / 4;
+};
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// NBUF-deep LDS ring: tile t+NBUF-1 is issued right after the barrier of tile t; the wait before that
+// barrier leaves the (NBUF-2) younger tiles in flight (counted vmcnt, raw s_barrier).
+template <bool AKS, bool BKS, int TBM, int TBN, int WM, int WN, int NBUF>
+__global__ __launch_bounds__((64 * WM * WN), (DmaCfg<TBM, TBN, WM, WN, NBUF>::MINW)) void gemm_dma_kernel(GemmArgs p) {
+    typedef bf16 T;
+    constexpr int NW = WM * WN, WTM = TBM / WM, WTN = TBN / WN, TM = WTM / 16, TN = WTN / 16;
+    constexpr int TA = TBM * 128, TB = TBN * 128, STAGE = TA + TB;     // bytes
+    constexpr int NBA = TBM / 8 / NW, NBB = TBN / 8 / NW;                // 1-KB DMA blocks per wave
+    static_assert(NBA >= 1 && NBB >= 1 && TBM % (8 * NW) == 0 && TBN % (8 * NW) == 0, "tile / wave mismatch");
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // NBUF stages of [A tile | B tile]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, l15 = lane & 15;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     int m0, n0;
-    tile_origin(p, m0, n0);
-    constexpr int BK = GT<T>::BK;
+    tile_origin(p, m0, n0, TBM, TBN);
+    constexpr int BK = 64;
     const int kbeg = blockIdx.z * p.kper;
     const int kend = min(p.K, kbeg + p.kper);
     const int nk = (kend - kbeg + BK - 1) / BK;
     const int nk_full = (kend - kbeg) / BK;
     constexpr bool std_orient = AKS && BKS;
-    constexpr int STAGE = 2 * TILE_BYTES;
-    int oa[4], ob[4];
-    ks_lane_offsets(wm, lane, oa);
-    ks_lane_offsets(wn, lane, ob);
 
-    // descriptors over the whole operands (bounds check = zero fill), scalar tile-origin offsets
+    // fragment addressing: KC rows via ld_frag_kc; KS via hoisted transposed-read offsets
+    int oa[TM], ob[TN];
+    if constexpr (AKS) ks_offsets<TBM, TM>(wm * WTM, lane, oa);
+    if constexpr (BKS) ks_offsets<TBN, TN>(wn * WTN, lane, ob);
+
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, p.bytesA, 0x00020000);
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, p.bytesB, 0x00020000);
-    int sa = (int)((AKS ? ((long)kbeg * p.lda + m0) : ((long)m0 * p.lda + kbeg)) * sizeof(T));
-    int sb = (int)((BKS ? ((long)kbeg * p.ldb + n0) : ((long)n0 * p.ldb + kbeg)) * sizeof(T));
-    const int stepa = (int)((AKS ? (long)BK * p.lda : (long)BK) * sizeof(T));
-    const int stepb = (int)((BKS ? (long)BK * p.ldb : (long)BK) * sizeof(T));
-    int va[4], vb[4];
-    dma_offsets<AKS, BKS, T>(p, m0, n0, BK, wave, lane, va, vb);
-
-    f32x4 acc[4][4];
+    int sa = (int)((AKS ? ((long)kbeg * p.lda + m0) : ((long)m0 * p.lda + kbeg)) * 2);
+    int sb = (int)((BKS ? ((long)kbeg * p.ldb + n0) : ((long)n0 * p.ldb + kbeg)) * 2);
+    const int stepa = (int)((AKS ? (long)BK * p.lda : (long)BK) * 2);
+    const int stepb = (int)((BKS ? (long)BK * p.ldb : (long)BK) * 2);
+    int va[NBA], vb[NBB];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NBA; ++i) va[i] = dma_voff<AKS, TBM>(p.lda, m0, p.M, BK, wave * NBA + i, lane);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < NBB; ++i) vb[i] = dma_voff<BKS, TBN>(p.ldb, n0, p.N, BK, wave * NBB + i, lane);
 
-    // issue tile `t` into stage t&1 (full tiles: loop-invariant lane offsets; ragged last tile: recomputed)
-    auto issue = [&](int t) {
-        if (t < nk_full) {
-            dma_issue(ra, rb, va, vb, sa, sb, smem + (t & 1) * STAGE, wave);
-        } else if (t < nk) {
-            int ta[4], tb[4];
-            dma_offsets<AKS, BKS, T>(p, m0, n0, kend - kbeg - t * BK, wave, lane, ta, tb);
-            dma_issue(ra, rb, ta, tb, sa, sb, smem + (t & 1) * STAGE, wave);
-        }
-        sa += stepa;
-        sb += stepb;
-    };
-    issue(0);
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // (a __device__ helper, not a lambda: a lambda in a __global__ body is host+device to clang and
+    //  the amdgcn LDS-DMA builtin inside it silently drops the kernel's host stub)
+#define ISSUE_TILE(t)                                                                                          \
+    do {                                                                                                       \
+        dma_issue_tile<AKS, BKS, TBM, TBN, NBA, NBB>(p, ra, rb, va, vb, sa, sb, smem + ((t) % NBUF) * STAGE, TA, \
+                                                     (t), nk_full, nk, kend - kbeg, m0, n0, wave, lane, NBUF > 2); \
+        sa += stepa;                                                                                           \
+        sb += stepb;                                                                                           \
+    } while (0)
+#pragma unroll
+    for (int t0 = 0; t0 < NBUF - 1; ++t0) ISSUE_TILE(t0);
     for (int kt = 0; kt < nk; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my part of tile kt has landed
+        wait_vmcnt<(NBUF - 2) * (NBA + NBB)>();            // my part of tile kt has landed
         __builtin_amdgcn_s_barrier();      // ... and everyone's; every wave is done reading tile kt-1
-        issue(kt + 1);                     // overwrites the stage tile kt-1 lived in
-        const char* tA = smem + (kt & 1) * STAGE;
-        compute_tile<T, AKS, BKS, std_orient, true>(tA, tA + TILE_BYTES, acc, wm, wn, lane, oa, ob);
+        ISSUE_TILE(kt + NBUF - 1);         // overwrites the stage tile kt-1 lived in
+        const char* tA = smem + (kt % NBUF) * STAGE;
+        const char* tB = tA + TA;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                if constexpr (!AKS) fa[i] = ld_frag_kc<T>(tA, wm * WTM + i * 16 + l15, kk, g);
+                else fa[i] = tr_read_pair(tA, oa[i] + kk * 32 * 2 * TBM, oa[i] + kk * 32 * 2 * TBM + 4 * 2 * TBM);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if constexpr (!BKS) fb[j] = ld_frag_kc<T>(tB, wn * WTN + j * 16 + l15, kk, g);
+                else fb[j] = tr_read_pair(tB, ob[j] + kk * 32 * 2 * TBN, ob[j] + kk * 32 * 2 * TBN + 4 * 2 * TBN);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if constexpr (std_orient) mma16(fa[i], fb[j], acc[i][j]);
+                    else mma16(fb[j], fa[i], acc[i][j]);
+                }
+        }
     }
-    gemm_epilogue<T, std_orient>(p, acc, m0, n0, wm, wn, g, l15);
+#undef ISSUE_TILE
+    if constexpr (NBUF > 2) wait_vmcnt<0>();   // drain the dummy tail loads before the LDS is released
+    gemm_epilogue<T, std_orient, TM, TN>(p, acc, m0 + wm * WTM, n0 + wn * WTN, g, l15);
 }
 
 // ------------------------------------------------------------------ launch
@@ -205,23 +275,29 @@ int launch_regstage(const GemmArgs& a, int transA, int transB, dim3 grid, hipStr
     return MMTG_OK;
 }
 
-template <typename T>
-int launch_dma(const GemmArgs& a, int transA, int transB, dim3 grid, hipStream_t stream) {
-    dim3 block(NTHR);
-    const size_t shm = (size_t)4 * TILE_BYTES;
-    static bool attr_done[3] = {false, false, false};
-    const int li = (!transA && transB) ? 0 : (!transA && !transB) ? 1 : 2;
-    if (!attr_done[li]) {
-        int rc = li == 0 ? set_lds(gemm_dma_kernel<T, false, false>, shm)
-               : li == 1 ? set_lds(gemm_dma_kernel<T, false, true>, shm)
-                         : set_lds(gemm_dma_kernel<T, true, true>, shm);
+template <bool AKS, bool BKS, int BM_, int BN_, int WM, int WN, int NBUF>
+int launch_dma_cfg(const GemmArgs& a, int splits, hipStream_t stream) {
+    static bool attr_done = false;
+    const size_t shm = (size_t)NBUF * (BM_ + BN_) * 128;
+    if (!attr_done) {
+        int rc = set_lds(gemm_dma_kernel<AKS, BKS, BM_, BN_, WM, WN, NBUF>, shm);
         if (rc) return rc;
-        attr_done[li] = true;
+        attr_done = true;
     }
-    if (li == 0) hipLaunchKernelGGL((gemm_dma_kernel<T, false, false>), grid, block, shm, stream, a);
-    else if (li == 1) hipLaunchKernelGGL((gemm_dma_kernel<T, false, true>), grid, block, shm, stream, a);
-    else hipLaunchKernelGGL((gemm_dma_kernel<T, true, true>), grid, block, shm, stream, a);
+    GemmArgs b = a;
+    b.tiles_n = cdiv(a.N, BN_);
+    dim3 grid(cdiv(a.M, BM_) * b.tiles_n, 1, splits), block(64 * WM * WN);
+    hipLaunchKernelGGL((gemm_dma_kernel<AKS, BKS, BM_, BN_, WM, WN, NBUF>), grid, block, shm, stream, b);
     return MMTG_OK;
+}
+
+int launch_dma(const GemmArgs& a, int transA, int transB, int splits, int skinny, hipStream_t stream) {
+    if (!transA && transB) {
+        if (skinny) return launch_dma_cfg<false, false, 256, 32, 4, 1, 4>(a, splits, stream);
+        return launch_dma_cfg<false, false, 128, 128, 2, 2, 2>(a, splits, stream);
+    }
+    if (!transA && !transB) return launch_dma_cfg<false, true, 128, 128, 2, 2, 2>(a, splits, stream);
+    return launch_dma_cfg<true, true, 128, 128, 2, 2, 2>(a, splits, stream);
 }
 
 }  // namespace
@@ -277,10 +353,12 @@ extern "C" int mmtg_gemm(int dtype, int transA, int transB, int M, int N, int K,
     ProfScope prof(dtype == MMTG_F32 ? MMTG_PROF_GEMM_F32 : MMTG_PROF_GEMM_BF16, s, 2.0 * M * N * (double)K,
                    (double)(dtype == MMTG_F32 ? 4 : 2) * ((double)M * K + (double)N * K) + (double)M * N * (out_f32 ? 4 : (dtype == MMTG_F32 ? 4 : 2)));
     dim3 grid(cdiv(M, BM) * cdiv(N, BN), 1, splits);
+    // small-M products with K-contiguous weights (decode): 256x32 tiles -> N/32 workgroups
+    const int skinny = (flags & MMTG_GEMM_SKINNY) || (!transA && transB && M <= 256 && !(flags & MMTG_GEMM_NO_SKINNY));
     int rc;
     if (dtype == MMTG_F32) rc = launch_regstage<float>(a, transA, transB, grid, s);
     else if ((flags & (MMTG_GEMM_REGSTAGE | MMTG_GEMM_NO_TR)) || !small) rc = launch_regstage<bf16>(a, transA, transB, grid, s);
-    else rc = launch_dma<bf16>(a, transA, transB, grid, s);
+    else rc = launch_dma(a, transA, transB, splits, skinny && !transA && transB, s);
     if (rc) return rc;
     MMTG_LAUNCH_CHECK("gemm");
     return MMTG_OK;

@@ -143,12 +143,12 @@ template <> __device__ __forceinline__ void load4<bf16>(const bf16* p, float (&v
 
 
 // XCD-aware tile order: consecutive tiles (sharing the A row panel) land on one XCD's L2
-__device__ __forceinline__ void tile_origin(const GemmArgs& p, int& m0, int& n0) {
+__device__ __forceinline__ void tile_origin(const GemmArgs& p, int& m0, int& n0, int bm = BM, int bn = BN) {
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
     const int swz = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
-    m0 = (swz / p.tiles_n) * BM;
-    n0 = (swz % p.tiles_n) * BN;
+    m0 = (swz / p.tiles_n) * bm;
+    n0 = (swz % p.tiles_n) * bn;
 }
 
 // Per-lane byte offsets of the transposed-read fragments of a K-strided bf16 operand, hoisted out of
@@ -203,17 +203,16 @@ __device__ __forceinline__ void compute_tile(const char* tA, const char* tB, f32
 // 16 contiguous floats per row per wave-instruction.  Swapped orientation: lane holds 4 consecutive n
 // for m = l15 -> 8/16-byte vector stores.  The epilogue kind is dispatched ONCE (outside the unrolled
 // tile loops) so each instantiation stays small.
-template <typename T, int EPI>
-__device__ __forceinline__ void epi_tiles(const GemmArgs& p, f32x4 (&acc)[4][4], int m0, int n0,
-                                          int wm, int wn, int g, int l15) {
+template <typename T, int EPI, int TM, int TN>
+__device__ __forceinline__ void epi_tiles(const GemmArgs& p, f32x4 (&acc)[TM][TN], int mw0, int nw0, int g, int l15) {
     const T* aux = reinterpret_cast<const T*>(p.aux);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm * 64 + i * 16 + l15;
+    for (int i = 0; i < TM; ++i) {
+        const int m = mw0 + i * 16 + l15;
         if (m >= p.M) continue;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn * 64 + j * 16 + 4 * g;
+        for (int j = 0; j < TN; ++j) {
+            const int n = nw0 + j * 16 + 4 * g;
             if (n >= p.N) continue;
             float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
             if (p.bias) {
@@ -252,30 +251,30 @@ __device__ __forceinline__ void epi_tiles(const GemmArgs& p, f32x4 (&acc)[4][4],
     }
 }
 
-template <typename T, bool std_orient>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4][4], int m0, int n0,
-                                              int wm, int wn, int g, int l15) {
+// mw0 / nw0: global row / column of the wave's sub-tile origin
+template <typename T, bool std_orient, int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM][TN], int mw0, int nw0, int g, int l15) {
     if constexpr (std_orient) {
         float* C = reinterpret_cast<float*>(p.C);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int n = n0 + wn * 64 + j * 16 + l15;
+            for (int j = 0; j < TN; ++j) {
+                const int n = nw0 + j * 16 + l15;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int m = m0 + wm * 64 + i * 16 + 4 * g + r;
+                    const int m = mw0 + i * 16 + 4 * g + r;
                     if (m < p.M && n < p.N) atomicAdd(C + (long)m * p.ldc + n, acc[i][j][r] * p.alpha);
                 }
             }
     } else {
         switch (p.epi) {
-            case MMTG_EPI_GELU: epi_tiles<T, MMTG_EPI_GELU>(p, acc, m0, n0, wm, wn, g, l15); break;
-            case MMTG_EPI_TANH: epi_tiles<T, MMTG_EPI_TANH>(p, acc, m0, n0, wm, wn, g, l15); break;
-            case MMTG_EPI_RESID: epi_tiles<T, MMTG_EPI_RESID>(p, acc, m0, n0, wm, wn, g, l15); break;
-            case MMTG_EPI_DGELU: epi_tiles<T, MMTG_EPI_DGELU>(p, acc, m0, n0, wm, wn, g, l15); break;
-            case MMTG_EPI_DTANH: epi_tiles<T, MMTG_EPI_DTANH>(p, acc, m0, n0, wm, wn, g, l15); break;
-            default: epi_tiles<T, MMTG_EPI_NONE>(p, acc, m0, n0, wm, wn, g, l15); break;
+            case MMTG_EPI_GELU: epi_tiles<T, MMTG_EPI_GELU, TM, TN>(p, acc, mw0, nw0, g, l15); break;
+            case MMTG_EPI_TANH: epi_tiles<T, MMTG_EPI_TANH, TM, TN>(p, acc, mw0, nw0, g, l15); break;
+            case MMTG_EPI_RESID: epi_tiles<T, MMTG_EPI_RESID, TM, TN>(p, acc, mw0, nw0, g, l15); break;
+            case MMTG_EPI_DGELU: epi_tiles<T, MMTG_EPI_DGELU, TM, TN>(p, acc, mw0, nw0, g, l15); break;
+            case MMTG_EPI_DTANH: epi_tiles<T, MMTG_EPI_DTANH, TM, TN>(p, acc, mw0, nw0, g, l15); break;
+            default: epi_tiles<T, MMTG_EPI_NONE, TM, TN>(p, acc, mw0, nw0, g, l15); break;
         }
     }
 }

@@ -51,6 +51,34 @@ class GreedyDecoder:
         self.logits = torch.empty(B, self.eng.layout.Vpad, dtype=torch.float32, device=dev)
         self.graphs = {}
         self.params = None
+        self.wT = {}
+
+    def _refresh_transposed(self):
+        """bf16 mode: K-contiguous ([out,in]) copies of the Conv1D ([in,out]) weights, so every decode
+        product is the NT layout the 256x32 small-M GEMM configuration serves (one 170 MB transpose per
+        generate() call; weights do not change while decoding)."""
+        eng = self.eng
+        if eng.dtype == hip.F32:
+            return
+        eng.refresh_copies()
+        pre = "decoder.gpt2.transformer."
+        for l in range(eng.sh.L):
+            for nm in ("attn.c_attn", "attn.c_proj", "mlp.c_fc", "mlp.c_proj"):
+                key = f"{pre}h.{l}.{nm}.weight"
+                src = eng.W(key)
+                dst = self.wT.get(key)
+                if dst is None:
+                    dst = self.wT[key] = torch.empty(src.shape[1], src.shape[0], dtype=src.dtype, device=src.device)
+                dst.copy_(src.t())
+
+    def _conv1d(self, x, wkey, out, **kw):
+        eng, B = self.eng, self.B
+        wt = self.wT.get(wkey)
+        if wt is None:
+            eng._fwd(x, wkey, out, B, "conv1d", **kw)
+        else:
+            N, K = wt.shape
+            hip.gemm(x, wt, out, B, N, K, transB=True, ldb=K, **kw)
 
     # ------------------------------------------------------------------ one token
     def _step(self, with_head):
@@ -70,15 +98,15 @@ class GreedyDecoder:
         for l in range(sh.L):
             p = f"{pre}h.{l}."
             hip.layernorm_fwd(hcur, self.a, eng.P(p + "ln_1.weight"), eng.P(p + "ln_1.bias"), self.mu, self.rs, B, D, sh.eps)
-            eng._fwd(self.a, p + "attn.c_attn.weight", self.qkv, B, "conv1d", bias=eng.P(p + "attn.c_attn.bias"))
+            self._conv1d(self.a, p + "attn.c_attn.weight", self.qkv, bias=eng.P(p + "attn.c_attn.bias"))
             hip.decode_attn(self.qkv, self.kc[l], self.vc[l], self.keep, self.pos, self.ctx, B, sh.nH, 64, self.Tmax)
-            eng._fwd(self.ctx, p + "attn.c_proj.weight", hnext, B, "conv1d", bias=eng.P(p + "attn.c_proj.bias"),
-                     epi=hip.EPI_RESID, aux=hcur, ldaux=D)
+            self._conv1d(self.ctx, p + "attn.c_proj.weight", hnext, bias=eng.P(p + "attn.c_proj.bias"),
+                         epi=hip.EPI_RESID, aux=hcur, ldaux=D)
             hip.layernorm_fwd(hnext, self.a, eng.P(p + "ln_2.weight"), eng.P(p + "ln_2.bias"), self.mu, self.rs, B, D, sh.eps)
-            eng._fwd(self.a, p + "mlp.c_fc.weight", self.g, B, "conv1d", bias=eng.P(p + "mlp.c_fc.bias"),
-                     epi=hip.EPI_GELU, aux2=self.u)
-            eng._fwd(self.g, p + "mlp.c_proj.weight", hcur, B, "conv1d", bias=eng.P(p + "mlp.c_proj.bias"),
-                     epi=hip.EPI_RESID, aux=hnext, ldaux=D)
+            self._conv1d(self.a, p + "mlp.c_fc.weight", self.g, bias=eng.P(p + "mlp.c_fc.bias"),
+                         epi=hip.EPI_GELU, aux2=self.u)
+            self._conv1d(self.g, p + "mlp.c_proj.weight", hcur, bias=eng.P(p + "mlp.c_proj.bias"),
+                         epi=hip.EPI_RESID, aux=hnext, ldaux=D)
         if with_head:
             hip.layernorm_fwd(hcur, self.a, eng.P(pre + "ln_f.weight"), eng.P(pre + "ln_f.bias"), self.mu, self.rs, B, D, sh.eps)
             Vp = eng.layout.Vpad
@@ -121,6 +149,7 @@ class GreedyDecoder:
             raise ValueError("length %d exceeds max_len %d" % (length, self.max_len))
         self.params = (float(temperature), float(repitition_penalty))
         eng.invalidate_copies()
+        self._refresh_transposed()
         a = eng.forward(batch, train_flag=False, training=False, encode_only=True)
         self.c.copy_(a["c"])
         self.seq.zero_()

@@ -135,6 +135,31 @@ def test_gemm_weight_gradient_ragged_tokens(dtype):
     close(dW, ref, torch.float32 if dtype == torch.float32 else dtype, Mtok, "wgrad")
 
 
+@pytest.mark.parametrize("shape", [(256, 768, 3072), (200, 2304, 768), (37, 136, 96), (256, 13440, 768)])
+def test_gemm_skinny_config(shape):
+    """256x32-tile small-M configuration (decode): forced and default selection, every epilogue it serves."""
+    M, N, K = shape
+    dtype = torch.bfloat16
+    a = rnd(M, K, dtype=dtype, seed=11).to(DEV)
+    w = rnd(N, K, dtype=dtype, seed=12, scale=0.1).to(DEV)
+    bias = rnd(N, seed=13).to(DEV)
+    aux = rnd(M, N, dtype=dtype, seed=14).to(DEV)
+    lin = a.float() @ w.float().t() + bias
+    for flags in (hip.GEMM_SKINNY, 0, hip.GEMM_NO_SKINNY):
+        out = torch.empty(M, N, device=DEV, dtype=dtype)
+        hip.gemm(a, w, out, M, N, K, transB=True, bias=bias, flags=flags)
+        close(out, lin, dtype, K, "skinny flags=%d" % flags)
+    out = torch.empty(M, N, device=DEV, dtype=dtype)
+    hip.gemm(a, w, out, M, N, K, transB=True, bias=bias, epi=hip.EPI_RESID, aux=aux, flags=hip.GEMM_SKINNY)
+    close(out, lin + aux.float(), dtype, K, "skinny resid")
+    pre = torch.empty(M, N, device=DEV, dtype=dtype)
+    hip.gemm(a, w, out, M, N, K, transB=True, bias=bias, epi=hip.EPI_GELU, aux2=pre, flags=hip.GEMM_SKINNY)
+    close(out, O.gelu_new(lin), dtype, K, "skinny gelu")
+    of = torch.empty(M, N, device=DEV, dtype=torch.float32)
+    hip.gemm(a, w, of, M, N, K, transB=True, out_f32=True, flags=hip.GEMM_SKINNY)
+    close(of, lin - bias, dtype, K, "skinny f32 out")
+
+
 def test_gemm_rejects_bad_arguments():
     a = torch.zeros(16, 16, device=DEV)
     with pytest.raises(RuntimeError, match="multiple"):
