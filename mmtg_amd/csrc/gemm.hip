@@ -74,7 +74,9 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_kernel(GemmArgs p) {
         }
         __syncthreads();
     }
-    gemm_epilogue<T, std_orient, 4, 4>(p, acc, m0 + wm * 64, n0 + wn * 64, g, l15);
+    // (the loop's final __syncthreads() already separates the last tile reads from this overlay)
+    gemm_epilogue<T, std_orient, 4, 4>(p, acc, m0 + wm * 64, n0 + wn * 64, g, l15,
+                                       smem + wave * epi_scratch_bytes<4, 4>(), lane);
 }
 
 // ------------------------------------------------------------------ LDS-DMA pipeline (bf16)
@@ -250,7 +252,10 @@ __global__ __launch_bounds__((64 * WM * WN), (DmaCfg<TBM, TBN, WM, WN, NBUF>::MI
     }
 #undef ISSUE_TILE
     if constexpr (NBUF > 2) wait_vmcnt<0>();   // drain the dummy tail loads before the LDS is released
-    gemm_epilogue<T, std_orient, TM, TN>(p, acc, m0 + wm * WTM, n0 + wn * WTN, g, l15);
+    static_assert(NW * epi_scratch_bytes<TM, TN>() <= NBUF * STAGE, "epilogue scratch must fit the ring");
+    if constexpr (!std_orient) __builtin_amdgcn_s_barrier();   // every wave is done reading the last tile
+    gemm_epilogue<T, std_orient, TM, TN>(p, acc, m0 + wm * WTM, n0 + wn * WTN, g, l15,
+                                         smem + wave * epi_scratch_bytes<TM, TN>(), lane);
 }
 
 // ------------------------------------------------------------------ launch
@@ -321,15 +326,15 @@ extern "C" int mmtg_gemm(int dtype, int transA, int transB, int M, int N, int K,
     MMTG_REQUIRE((epi == MMTG_EPI_ATOMIC) == (transA && !transB),
                  "gemm: the atomic epilogue and the transA=1,transB=0 (weight-gradient) layout go together");
     if (epi != MMTG_EPI_ATOMIC) {
-        MMTG_REQUIRE(N % 4 == 0 && ldc % 4 == 0, "gemm: N and ldc must be multiples of 4 (N=%d ldc=%ld)", N, ldc);
+        MMTG_REQUIRE(N % 8 == 0 && ldc % 8 == 0, "gemm: N and ldc must be multiples of 8 (N=%d ldc=%ld)", N, ldc);
         MMTG_REQUIRE(!bias || MMTG_ALIGNED16(bias), "gemm: bias must be 16-byte aligned");
         MMTG_REQUIRE(splits <= 1, "gemm: split-K needs the atomic epilogue");
     } else {
         MMTG_REQUIRE(!bias, "gemm: atomic epilogue takes no bias");
     }
     if (epi == MMTG_EPI_RESID || epi == MMTG_EPI_DGELU || epi == MMTG_EPI_DTANH)
-        MMTG_REQUIRE(aux && ldaux % 4 == 0 && (((uintptr_t)aux) & 7) == 0, "gemm: epilogue %d needs an aligned aux operand", epi);
-    if (epi == MMTG_EPI_GELU) MMTG_REQUIRE(aux2, "gemm: GELU epilogue needs aux2 for the pre-activation");
+        MMTG_REQUIRE(aux && ldaux % 8 == 0 && MMTG_ALIGNED16(aux), "gemm: epilogue %d needs a 16-byte aligned aux operand with ldaux %% 8 == 0", epi);
+    if (epi == MMTG_EPI_GELU) MMTG_REQUIRE(aux2 && MMTG_ALIGNED16(aux2), "gemm: GELU epilogue needs a 16-byte aligned aux2 for the pre-activation");
     GemmArgs a;
     memset(&a, 0, sizeof(a));
     a.A = A; a.B = B; a.C = C; a.bias = bias; a.aux = aux; a.aux2 = aux2;

@@ -203,57 +203,107 @@ __device__ __forceinline__ void compute_tile(const char* tA, const char* tB, f32
 // 16 contiguous floats per row per wave-instruction.  Swapped orientation: lane holds 4 consecutive n
 // for m = l15 -> 8/16-byte vector stores.  The epilogue kind is dispatched ONCE (outside the unrolled
 // tile loops) so each instantiation stays small.
+// 8 consecutive elements of T <-> floats (16 B of bf16, 32 B of f32)
+template <typename T> __device__ __forceinline__ void load8(const T* p, float (&v)[8]);
+template <> __device__ __forceinline__ void load8<float>(const float* p, float (&v)[8]) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = b[e]; }
+}
+template <> __device__ __forceinline__ void load8<bf16>(const bf16* p, float (&v)[8]) {
+    bf16x8 a = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (float)a[e];
+}
+template <typename TO> __device__ __forceinline__ void store8(TO* p, const float (&v)[8]);
+template <> __device__ __forceinline__ void store8<float>(float* p, const float (&v)[8]) {
+    *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
+}
+template <> __device__ __forceinline__ void store8<bf16>(bf16* p, const float (&v)[8]) {
+    bf16x8 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3], (bf16)v[4], (bf16)v[5], (bf16)v[6], (bf16)v[7]};
+    *reinterpret_cast<bf16x8*>(p) = o;
+}
+
+// Epilogue through LDS.  The accumulator layout gives a lane 4 consecutive columns of ONE row per
+// 16x16 tile, i.e. 32-byte global segments; staged through a wave-private LDS image
+// ([rows][WTN floats], row stride WTN*4+16 B) the same data is re-read with 8 consecutive columns per
+// lane and WTN/8 lanes per row, so every global access (output, pre-activation, residual / aux) is a
+// 16-byte vector and a wave touches whole rows of the tile.  Two passes of TM/2 tile-rows keep the
+// image within the main loop's LDS allocation.  `lds` = this wave's scratch (HALF*LDW*4 bytes).
 template <typename T, int EPI, int TM, int TN>
-__device__ __forceinline__ void epi_tiles(const GemmArgs& p, f32x4 (&acc)[TM][TN], int mw0, int nw0, int g, int l15) {
+__device__ __forceinline__ void epi_tiles(const GemmArgs& p, f32x4 (&acc)[TM][TN], int mw0, int nw0, int g, int l15,
+                                          char* lds, int lane) {
+    static_assert(TM % 2 == 0, "two passes of TM/2 tile rows");
+    constexpr int WTN = TN * 16;               // wave-tile columns
+    constexpr int LDW = WTN + 4;               // padded row stride in floats
+    constexpr int HALF = TM / 2 * 16;          // rows per pass
+    constexpr int LPR = WTN / 8;               // lanes per row on read-back
+    constexpr int RPI = 64 / LPR;              // rows per read instruction
+    float* img = reinterpret_cast<float*>(lds);
     const T* aux = reinterpret_cast<const T*>(p.aux);
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int m = mw0 + i * 16 + l15;
-        if (m >= p.M) continue;
+    for (int h = 0; h < 2; ++h) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = nw0 + j * 16 + 4 * g;
-            if (n >= p.N) continue;
-            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+        for (int ii = 0; ii < TM / 2; ++ii)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                *reinterpret_cast<f32x4*>(img + (ii * 16 + l15) * LDW + j * 16 + 4 * g) = acc[h * (TM / 2) + ii][j];
+        // same wave wrote and reads: LDS operations of one wave complete in order
+#pragma unroll
+        for (int q = 0; q < HALF / RPI; ++q) {
+            const int row = q * RPI + lane / LPR, col = (lane % LPR) * 8;
+            const int m = mw0 + h * HALF + row, n = nw0 + col;
+            float v[8];
+            load8<float>(img + row * LDW + col, v);
+            if (m >= p.M || n >= p.N) continue;
             if (p.bias) {
-                f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
-                v[0] += bv[0]; v[1] += bv[1]; v[2] += bv[2]; v[3] += bv[3];
-            }
-            float a4[4];
-            if constexpr (EPI == MMTG_EPI_GELU) {
-                store4<T>(reinterpret_cast<T*>(p.aux2) + (long)m * p.ldc + n, v);
+                float b8[8];
+                load8<float>(p.bias + n, b8);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = gelu_new_f(v[r]);
+                for (int e = 0; e < 8; ++e) v[e] += b8[e];
+            }
+            float a8[8];
+            if constexpr (EPI == MMTG_EPI_GELU) {
+                store8<T>(reinterpret_cast<T*>(p.aux2) + (long)m * p.ldc + n, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = gelu_new_f(v[e]);
             } else if constexpr (EPI == MMTG_EPI_TANH) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
+                for (int e = 0; e < 8; ++e) v[e] = tanhf(v[e]);
             } else if constexpr (EPI == MMTG_EPI_RESID) {
                 if (p.drop_thresh) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        v[r] *= dropout_scale(p.drop_seed, (uint32_t)((long)m * p.N + n + r), p.drop_thresh, p.drop_inv_keep);
+                    for (int e = 0; e < 8; ++e)
+                        v[e] *= dropout_scale(p.drop_seed, (uint32_t)((long)m * p.N + n + e), p.drop_thresh, p.drop_inv_keep);
                 }
-                load4<T>(aux + (long)m * p.ldaux + n, a4);
+                load8<T>(aux + (long)m * p.ldaux + n, a8);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += a4[r];
+                for (int e = 0; e < 8; ++e) v[e] += a8[e];
             } else if constexpr (EPI == MMTG_EPI_DGELU) {
-                load4<T>(aux + (long)m * p.ldaux + n, a4);
+                load8<T>(aux + (long)m * p.ldaux + n, a8);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] *= gelu_new_grad_f(a4[r]);
+                for (int e = 0; e < 8; ++e) v[e] *= gelu_new_grad_f(a8[e]);
             } else if constexpr (EPI == MMTG_EPI_DTANH) {
-                load4<T>(aux + (long)m * p.ldaux + n, a4);
+                load8<T>(aux + (long)m * p.ldaux + n, a8);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] *= (1.0f - a4[r] * a4[r]);
+                for (int e = 0; e < 8; ++e) v[e] *= (1.0f - a8[e] * a8[e]);
             }
-            if (p.out_f32) store4<float>(reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n, v);
-            else store4<T>(reinterpret_cast<T*>(p.C) + (long)m * p.ldc + n, v);
+            if (p.out_f32) store8<float>(reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n, v);
+            else store8<T>(reinterpret_cast<T*>(p.C) + (long)m * p.ldc + n, v);
         }
     }
 }
 
 // mw0 / nw0: global row / column of the wave's sub-tile origin
+// bytes of wave-private LDS scratch the staged epilogue needs
+template <int TM, int TN> constexpr int epi_scratch_bytes() { return (TM / 2 * 16) * (TN * 16 + 4) * 4; }
+
+// `lds`: this wave's scratch of epi_scratch_bytes<TM,TN>() bytes; the caller has made sure (barrier) that
+// no wave still reads the main-loop tiles it overlays.
 template <typename T, bool std_orient, int TM, int TN>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM][TN], int mw0, int nw0, int g, int l15) {
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM][TN], int mw0, int nw0, int g, int l15,
+                                              char* lds, int lane) {
     if constexpr (std_orient) {
         float* C = reinterpret_cast<float*>(p.C);
 #pragma unroll
@@ -269,12 +319,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
             }
     } else {
         switch (p.epi) {
-            case MMTG_EPI_GELU: epi_tiles<T, MMTG_EPI_GELU, TM, TN>(p, acc, mw0, nw0, g, l15); break;
-            case MMTG_EPI_TANH: epi_tiles<T, MMTG_EPI_TANH, TM, TN>(p, acc, mw0, nw0, g, l15); break;
-            case MMTG_EPI_RESID: epi_tiles<T, MMTG_EPI_RESID, TM, TN>(p, acc, mw0, nw0, g, l15); break;
-            case MMTG_EPI_DGELU: epi_tiles<T, MMTG_EPI_DGELU, TM, TN>(p, acc, mw0, nw0, g, l15); break;
-            case MMTG_EPI_DTANH: epi_tiles<T, MMTG_EPI_DTANH, TM, TN>(p, acc, mw0, nw0, g, l15); break;
-            default: epi_tiles<T, MMTG_EPI_NONE, TM, TN>(p, acc, mw0, nw0, g, l15); break;
+            case MMTG_EPI_GELU: epi_tiles<T, MMTG_EPI_GELU, TM, TN>(p, acc, mw0, nw0, g, l15, lds, lane); break;
+            case MMTG_EPI_TANH: epi_tiles<T, MMTG_EPI_TANH, TM, TN>(p, acc, mw0, nw0, g, l15, lds, lane); break;
+            case MMTG_EPI_RESID: epi_tiles<T, MMTG_EPI_RESID, TM, TN>(p, acc, mw0, nw0, g, l15, lds, lane); break;
+            case MMTG_EPI_DGELU: epi_tiles<T, MMTG_EPI_DGELU, TM, TN>(p, acc, mw0, nw0, g, l15, lds, lane); break;
+            case MMTG_EPI_DTANH: epi_tiles<T, MMTG_EPI_DTANH, TM, TN>(p, acc, mw0, nw0, g, l15, lds, lane); break;
+            default: epi_tiles<T, MMTG_EPI_NONE, TM, TN>(p, acc, mw0, nw0, g, l15, lds, lane); break;
         }
     }
 }
