@@ -39,7 +39,10 @@ enum {
     MMTG_EPI_RESID = 3,  /* C = dropout(acc + bias) + aux                     */
     MMTG_EPI_DGELU = 4,  /* C = acc * gelu_new'(aux)                          */
     MMTG_EPI_DTANH = 5,  /* C = acc * (1 - aux^2)                             */
-    MMTG_EPI_ATOMIC = 6  /* C(f32) += alpha * acc  (atomics; split-K allowed) */
+    MMTG_EPI_ATOMIC = 6, /* C(f32) += alpha * acc  (atomics; split-K allowed) */
+    MMTG_EPI_ROWDOT = 7  /* C = acc ; aux2(f32)[m, n/64] = sum over each 64-column group of C * aux
+                            (attention backward's delta = rowsum(dO * O) per head, fused into the
+                            GEMM that produces dO; N % 64 == 0, no bias) */
 };
 #define MMTG_GEMM_NO_TR 1 /* flags: gather K-strided bf16 fragments without ds_read_b64_tr_b16 */
 #define MMTG_GEMM_REGSTAGE 2 /* flags: register-staged v1 pipeline instead of the LDS-DMA one (bf16) */
@@ -103,10 +106,12 @@ int mmtg_layernorm_bwd(int dtype, const void* dy, const void* x, const float* ga
  * keep: [B,T] int32 key mask (1 = attend); out: [B*T, D]; lse: [B,nH,T] f32.  */
 int mmtg_attn_fwd(int dtype, const void* qkv, const int* keep, void* out, float* lse,
                   int B, int T, int nH, int dh, unsigned drop_thresh, unsigned drop_seed, void* stream);
-/* delta: [B,nH,T] f32 scratch; dq32: [B*T, D] f32 scratch (zeroed by the call);
+/* delta: [B*T, nH] f32, delta[m,h] = sum_d dout[m,h,d] * out[m,h,d]: computed by the call, or --
+ * delta_ready != 0 -- already filled by the caller (the GEMM producing dout with
+ * MMTG_EPI_ROWDOT does it for free); dq32: [B*T, D] f32 scratch (zeroed by the call);
  * dqkv: [B*T, 3*D] output.                                                    */
 int mmtg_attn_bwd(int dtype, const void* qkv, const int* keep, const void* out, const void* dout,
-                  const float* lse, float* delta, float* dq32, void* dqkv,
+                  const float* lse, float* delta, int delta_ready, float* dq32, void* dqkv,
                   int B, int T, int nH, int dh, unsigned drop_thresh, unsigned drop_seed, void* stream);
 
 /* ---------------------------------------------------------------- conditioning front end

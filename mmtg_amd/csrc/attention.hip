@@ -13,6 +13,8 @@
 //   registers; only dS crosses LDS (once) for dQ.
 // Both kernels are templated on the storage type: bf16 (v_mfma_f32_16x16x32_bf16)
 // and f32 (v_mfma_f32_16x16x4_f32, the exact parity-gate mode).
+#include <stdlib.h>
+
 #include "mma.h"
 
 namespace {
@@ -56,6 +58,12 @@ __device__ __forceinline__ f32x4 ld_ks(const char* img, int r_lo, int, int col0,
 #pragma unroll
     for (int s = 0; s < 4; ++s) o[s] = *reinterpret_cast<const float*>(img + off_ks<float>(r_lo + s, c >> 2) + (c & 3) * 4);
     return o;
+}
+
+// exp: accurate expf in the fp32 parity mode, hardware v_exp_f32 path for bf16 storage
+template <typename T> __device__ __forceinline__ float fexp(float x) {
+    if constexpr (sizeof(T) == 2) return __expf(x);
+    else return expf(x);
 }
 
 template <typename T> __device__ __forceinline__ typename Vec16<T>::type zero16() {
@@ -138,14 +146,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
         const float m_new = fmaxf(m_run, mloc);
         const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-        const float alpha = (m_run == -INFINITY) ? 0.f : expf(m_run - m_use);
+        const float alpha = (m_run == -INFINITY) ? 0.f : fexp<T>(m_run - m_use);
         float rs = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float s = s_acc[kt][r];
-                float p = (s == -INFINITY) ? 0.f : expf(s - m_use);
+                float p = (s == -INFINITY) ? 0.f : fexp<T>(s - m_use);
                 rs += p;
                 if (drop_thresh) {
                     const int kj = j0 + kt * 16 + 4 * g + r;
@@ -193,7 +201,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
 }
 
 // ======================================================================== backward
-// delta[b,h,q] = sum_d dO[b,q,h,d] * O[b,q,h,d]
+// delta[m, h] = sum_d dO[m,h,d] * O[m,h,d]   (m = b*T + q; layout [B*T, nH])
 template <typename T>
 __global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ o, const T* __restrict__ d_o,
                                                          float* __restrict__ delta, int Tn, int nH, long rows) {
@@ -203,10 +211,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ o
     const int h = (int)(w % nH), lane = threadIdx.x & 63;
     const long idx = row * (long)(nH * DH) + h * DH + lane;
     const float v = wave_sum((float)o[idx] * (float)d_o[idx]);
-    if (lane == 0) {
-        const long b = row / Tn, t = row % Tn;
-        delta[(b * nH + h) * Tn + t] = v;
-    }
+    if (lane == 0) delta[row * nH + h] = v;
 }
 
 template <typename T>
@@ -219,14 +224,17 @@ __global__ __launch_bounds__(256) void attn_dq_finish_kernel(const float* __rest
     }
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv, const int* __restrict__ keep,
+// NW waves share one key block of KB = 4*AT<T>::KPW keys (256 bf16 / 128 f32), KB/NW keys each.
+// bf16 runs NW = 8 (two waves per SIMD: one wave's LDS / softmax latency hides behind the other's
+// MFMAs; 64 accumulator registers per wave instead of 128), f32 NW = 4.
+template <typename T, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(const T* __restrict__ qkv, const int* __restrict__ keep,
         const T* __restrict__ d_out, const float* __restrict__ lse, const float* __restrict__ delta,
         float* __restrict__ dq32, T* __restrict__ dqkv, int Tn, int nH, int direct_dq,
-        uint32_t drop_thresh, uint32_t drop_seed, float inv_keep) {
+        uint32_t drop_thresh, uint32_t drop_seed, float inv_keep, int ablate) {
     typedef typename Vec16<T>::type V;
     typedef AT<T> A;
-    constexpr int KPW = A::KPW, KB = 4 * KPW, NKT = KPW / 16;
+    constexpr int KB = 4 * A::KPW, KPW = KB / NW, NKT = KPW / 16, NTHR = 64 * NW;
     constexpr int RBS = KB * sizeof(T);   // dS image row bytes (512)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sKr = smem;
@@ -250,7 +258,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
     const float scale = 0.125f;
 
     // stage this block's K (two images) and V (row image) once
-    for (int id = tid; id < KB * A::CPR; id += 256) {
+    for (int id = tid; id < KB * A::CPR; id += NTHR) {
         const int key = id / A::CPR, c = id % A::CPR;
         V kv = zero16<T>(), vv = zero16<T>();
         if (kb0 + key < Tn) {
@@ -262,7 +270,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
         *reinterpret_cast<V*>(sKt + off_ks<T>(key, c)) = kv;
         *reinterpret_cast<V*>(sVr + off_kc<T>(key, c)) = vv;
     }
-    for (int i = tid; i < KB; i += 256) sKeep[i] = (kb0 + i < Tn) ? keep[(long)b * Tn + kb0 + i] : 0;
+    for (int i = tid; i < KB; i += NTHR) sKeep[i] = (kb0 + i < Tn) ? keep[(long)b * Tn + kb0 + i] : 0;
 
     f32x4 dk_acc[4][NKT], dv_acc[4][NKT];
 #pragma unroll
@@ -275,10 +283,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
     for (int qt = kb0 / 32; qt < nqt; ++qt) {
         const int q0 = qt * 32;
         __syncthreads();
-        for (int id = tid; id < 32 * A::CPR; id += 256) {
+        for (int id = tid; id < 32 * A::CPR; id += NTHR) {
             const int r = id / A::CPR, c = id % A::CPR;
             V qv = zero16<T>(), ov = zero16<T>();
-            if (q0 + r < Tn) {
+            if (q0 + r < Tn && !((ablate & 8) && qt > kb0 / 32)) {
                 qv = *reinterpret_cast<const V*>(base + (long)(q0 + r) * ld + c * A::EPC);
                 ov = *reinterpret_cast<const V*>(dob + (long)(q0 + r) * D + c * A::EPC);
             }
@@ -290,7 +298,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
         if (tid < 32) {
             const bool ok = q0 + tid < Tn;
             sLse[tid] = ok ? lse[((long)b * nH + h) * Tn + q0 + tid] : 0.f;
-            sDel[tid] = ok ? delta[((long)b * nH + h) * Tn + q0 + tid] : 0.f;
+            sDel[tid] = ok ? delta[((long)b * Tn + q0 + tid) * nH + h] : 0.f;
         }
         __syncthreads();
 
@@ -313,7 +321,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
                     for (int r = 0; r < 4; ++r) {
                         const int ql = qs * 16 + 4 * g + r, q = q0 + ql;
                         const bool valid = key <= q && q < Tn && kp != 0;
-                        float p = valid ? expf(s_acc[r] * scale - sLse[ql]) : 0.f;
+                        float p = valid ? ((ablate & 1) ? s_acc[r] : fexp<T>(s_acc[r] * scale - sLse[ql])) : 0.f;
                         float dp = dp_acc[r];
                         if (drop_thresh) {
                             const float ms = dropout_scale(drop_seed, (uint32_t)((((long)b * nH + h) * Tn + q) * Tn + key), drop_thresh, inv_keep);
@@ -326,7 +334,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
                         dsT[qs][r] = ds;
                         // dS image [q][key] for the dQ product
                         const int byte = kl * (int)sizeof(T);
-                        *reinterpret_cast<T*>(sDS + ql * RBS + (((byte >> 4) ^ (ql & 7)) << 4) + (byte & 15)) = (T)ds;
+                        if (!(ablate & 2)) *reinterpret_cast<T*>(sDS + ql * RBS + (((byte >> 4) ^ (ql & 7)) << 4) + (byte & 15)) = (T)ds;
                     }
                 }
                 // dV^T[d][key] += dO^T[d][q] P[q][key] ;  dK^T[d][key] += Q^T[d][q] dS[q][key]
@@ -353,11 +361,14 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
 
         // dQ[q][d] = sum_key dS[q][key] K[key][d];  wave w owns d-tile w
         {
-            int nact = min(KB, min(q0 + 32, Tn) - kb0);          // keys that can be <= some q of this tile
+            int nact = (ablate & 4) ? 0 : min(KB, min(q0 + 32, Tn) - kb0);   // keys that can be <= some q of this tile
             const int nblk = (nact + A::KBE - 1) / A::KBE;        // k-blocks of 64 bytes of keys
-            const int dt = wave;
+            // 4 waves: wave w -> d-tile w, both 16-row query sub-tiles; 8 waves: one sub-tile each
+            const int dt = wave & 3;
+            constexpr int QS_PER_WAVE = NW == 8 ? 1 : 2;
 #pragma unroll
-            for (int qs = 0; qs < 2; ++qs) {
+            for (int qq = 0; qq < QS_PER_WAVE; ++qq) {
+                const int qs = NW == 8 ? (wave >> 2) : qq;
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
                 for (int kb = 0; kb < nblk; ++kb) {
                     const int row = qs * 16 + l15;
@@ -431,7 +442,7 @@ extern "C" int mmtg_attn_fwd(int dtype, const void* qkv, const int* keep, void* 
 }
 
 extern "C" int mmtg_attn_bwd(int dtype, const void* qkv, const int* keep, const void* out, const void* dout,
-                             const float* lse, float* delta, float* dq32, void* dqkv,
+                             const float* lse, float* delta, int delta_ready, float* dq32, void* dqkv,
                              int B, int T, int nH, int dh, unsigned drop_thresh, unsigned drop_seed, void* stream) {
     MMTG_REQUIRE(dh == DH, "attn_bwd: head dim %d unsupported (built for 64)", dh);
     MMTG_REQUIRE(B > 0 && T > 0 && nH > 0, "attn_bwd: bad sizes");
@@ -444,31 +455,32 @@ extern "C" int mmtg_attn_bwd(int dtype, const void* qkv, const int* keep, const 
     const int D = nH * dh;
     const float ik = inv_keep_of(drop_thresh);
     static bool attr_set[2] = {false, false};
+    static const int ablate = getenv("MMTG_ATTN_ABLATE") ? atoi(getenv("MMTG_ATTN_ABLATE")) : 0;   // timing experiments only
     if (dtype == MMTG_F32) {
         const int KB = 4 * AT<float>::KPW;
         const int nkb = cdiv(T, KB);
         const size_t shm = bwd_smem_bytes<float>();
         if (!attr_set[0]) {
-            if (hipFuncSetAttribute((const void*)attn_bwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
+            if (hipFuncSetAttribute((const void*)attn_bwd_kernel<float, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
                 MMTG_FAIL(MMTG_ERR_HIP, "attn_bwd: cannot raise dynamic LDS to %zu", shm);
             attr_set[0] = true;
         }
-        hipLaunchKernelGGL(attn_delta_kernel<float>, dim3(cdiv(rows * nH, 4)), dim3(256), 0, s, (const float*)out, (const float*)dout, delta, T, nH, rows);
+        if (!delta_ready) hipLaunchKernelGGL(attn_delta_kernel<float>, dim3(cdiv(rows * nH, 4)), dim3(256), 0, s, (const float*)out, (const float*)dout, delta, T, nH, rows);
         if (nkb > 1) { if (hipMemsetAsync(dq32, 0, rows * D * sizeof(float), s) != hipSuccess) MMTG_FAIL(MMTG_ERR_HIP, "attn_bwd: memset failed"); }
-        hipLaunchKernelGGL(attn_bwd_kernel<float>, dim3(nkb, nH, B), dim3(256), shm, s, (const float*)qkv, keep, (const float*)dout, lse, delta, dq32, (float*)dqkv, T, nH, nkb == 1, drop_thresh, drop_seed, ik);
+        hipLaunchKernelGGL((attn_bwd_kernel<float, 4>), dim3(nkb, nH, B), dim3(256), shm, s, (const float*)qkv, keep, (const float*)dout, lse, delta, dq32, (float*)dqkv, T, nH, nkb == 1, drop_thresh, drop_seed, ik, ablate);
         if (nkb > 1) hipLaunchKernelGGL(attn_dq_finish_kernel<float>, dim3(2048), dim3(256), 0, s, dq32, (float*)dqkv, rows, D);
     } else if (dtype == MMTG_BF16) {
         const int KB = 4 * AT<bf16>::KPW;
         const int nkb = cdiv(T, KB);
         const size_t shm = bwd_smem_bytes<bf16>();
         if (!attr_set[1]) {
-            if (hipFuncSetAttribute((const void*)attn_bwd_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
+            if (hipFuncSetAttribute((const void*)attn_bwd_kernel<bf16, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
                 MMTG_FAIL(MMTG_ERR_HIP, "attn_bwd: cannot raise dynamic LDS to %zu", shm);
             attr_set[1] = true;
         }
-        hipLaunchKernelGGL(attn_delta_kernel<bf16>, dim3(cdiv(rows * nH, 4)), dim3(256), 0, s, (const bf16*)out, (const bf16*)dout, delta, T, nH, rows);
+        if (!delta_ready) hipLaunchKernelGGL(attn_delta_kernel<bf16>, dim3(cdiv(rows * nH, 4)), dim3(256), 0, s, (const bf16*)out, (const bf16*)dout, delta, T, nH, rows);
         if (nkb > 1) { if (hipMemsetAsync(dq32, 0, rows * D * sizeof(float), s) != hipSuccess) MMTG_FAIL(MMTG_ERR_HIP, "attn_bwd: memset failed"); }
-        hipLaunchKernelGGL(attn_bwd_kernel<bf16>, dim3(nkb, nH, B), dim3(256), shm, s, (const bf16*)qkv, keep, (const bf16*)dout, lse, delta, dq32, (bf16*)dqkv, T, nH, nkb == 1, drop_thresh, drop_seed, ik);
+        hipLaunchKernelGGL((attn_bwd_kernel<bf16, 8>), dim3(nkb, nH, B), dim3(512), shm, s, (const bf16*)qkv, keep, (const bf16*)dout, lse, delta, dq32, (bf16*)dqkv, T, nH, nkb == 1, drop_thresh, drop_seed, ik, ablate);
         if (nkb > 1) hipLaunchKernelGGL(attn_dq_finish_kernel<bf16>, dim3(2048), dim3(256), 0, s, dq32, (bf16*)dqkv, rows, D);
     } else MMTG_FAIL(MMTG_ERR_BAD_ARG, "attn_bwd: bad dtype");
     MMTG_LAUNCH_CHECK("attn_bwd");

@@ -332,7 +332,10 @@ extern "C" int mmtg_gemm(int dtype, int transA, int transB, int M, int N, int K,
     } else {
         MMTG_REQUIRE(!bias, "gemm: atomic epilogue takes no bias");
     }
-    if (epi == MMTG_EPI_RESID || epi == MMTG_EPI_DGELU || epi == MMTG_EPI_DTANH)
+    if (epi == MMTG_EPI_ROWDOT)
+        MMTG_REQUIRE(aux2 && !bias && N % 64 == 0 && dtype == MMTG_BF16 && !transA && M > 256 && !(flags & (MMTG_GEMM_REGSTAGE | MMTG_GEMM_NO_TR | MMTG_GEMM_SKINNY)),
+                     "gemm: ROWDOT epilogue needs aux2 (f32 [M, N/64]), no bias, N %% 64 == 0, the bf16 128x128 LDS-DMA configuration");
+    if (epi == MMTG_EPI_RESID || epi == MMTG_EPI_DGELU || epi == MMTG_EPI_DTANH || epi == MMTG_EPI_ROWDOT)
         MMTG_REQUIRE(aux && ldaux % 8 == 0 && MMTG_ALIGNED16(aux), "gemm: epilogue %d needs a 16-byte aligned aux operand with ldaux %% 8 == 0", epi);
     if (epi == MMTG_EPI_GELU) MMTG_REQUIRE(aux2 && MMTG_ALIGNED16(aux2), "gemm: GELU epilogue needs a 16-byte aligned aux2 for the pre-activation");
     GemmArgs a;

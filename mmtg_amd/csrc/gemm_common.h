@@ -288,6 +288,18 @@ __device__ __forceinline__ void epi_tiles(const GemmArgs& p, f32x4 (&acc)[TM][TN
                 load8<T>(aux + (long)m * p.ldaux + n, a8);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] *= (1.0f - a8[e] * a8[e]);
+            } else if constexpr (EPI == MMTG_EPI_ROWDOT) {
+                // attention backward's delta[m, head] = sum over the head's 64 columns of out * aux
+                // (out = d ctx as stored, aux = ctx): a wave tile row IS one head (WTN == 64), held by 8 lanes
+                static_assert(WTN == 64, "ROWDOT needs 64-column wave tiles (one attention head)");
+                load8<T>(aux + (long)m * p.ldaux + n, a8);
+                float dot = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dot += (float)(T)v[e] * a8[e];
+                dot += __shfl_xor(dot, 1, 64);
+                dot += __shfl_xor(dot, 2, 64);
+                dot += __shfl_xor(dot, 4, 64);
+                if ((lane & 7) == 0) reinterpret_cast<float*>(p.aux2)[(long)m * (p.N >> 6) + (n >> 6)] = dot;
             }
             if (p.out_f32) store8<float>(reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n, v);
             else store8<T>(reinterpret_cast<T*>(p.C) + (long)m * p.ldc + n, v);
@@ -324,6 +336,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
             case MMTG_EPI_RESID: epi_tiles<T, MMTG_EPI_RESID, TM, TN>(p, acc, mw0, nw0, g, l15, lds, lane); break;
             case MMTG_EPI_DGELU: epi_tiles<T, MMTG_EPI_DGELU, TM, TN>(p, acc, mw0, nw0, g, l15, lds, lane); break;
             case MMTG_EPI_DTANH: epi_tiles<T, MMTG_EPI_DTANH, TM, TN>(p, acc, mw0, nw0, g, l15, lds, lane); break;
+            case MMTG_EPI_ROWDOT:
+                if constexpr (TN == 4) epi_tiles<T, MMTG_EPI_ROWDOT, TM, TN>(p, acc, mw0, nw0, g, l15, lds, lane);
+                break;
             default: epi_tiles<T, MMTG_EPI_NONE, TM, TN>(p, acc, mw0, nw0, g, l15, lds, lane); break;
         }
     }

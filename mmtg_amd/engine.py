@@ -546,7 +546,7 @@ class Engine:
         dctx = self.buf("d_ctx", (M, D))
         dqkv = self.buf("d_qkv", (M, 3 * D))
         da = self.buf("d_a", (M, D))
-        delta = self.buf("attn_delta", (B, sh.nH, T), torch.float32)
+        delta = self.buf("attn_delta", (M, sh.nH), torch.float32)
         dq32 = self.buf("attn_dq32", (M, D), torch.float32)
         for l in range(sh.L - 1, -1, -1):
             p = f"{pre}h.{l}."
@@ -563,10 +563,15 @@ class Engine:
                               dcolsum=self.G(p + "attn.c_proj.bias"), ws=lnws)
             # x_mid = x_in + drop(ctx Wp + bp)
             dy = dmask if pr > 0 else dx2
-            self._dgrad(dy, p + "attn.c_proj.weight", dctx, M, "conv1d")
+            # bf16: the dgrad GEMM's epilogue also emits delta = rowsum(d ctx * ctx) per head
+            fuse_delta = self.dtype == hip.BF16 and M > 256
+            if fuse_delta:
+                self._dgrad(dy, p + "attn.c_proj.weight", dctx, M, "conv1d", epi=hip.EPI_ROWDOT, aux=ctx, ldaux=D, aux2=delta)
+            else:
+                self._dgrad(dy, p + "attn.c_proj.weight", dctx, M, "conv1d")
             self._wgrad(ctx, dy, p + "attn.c_proj.weight", None, M, "conv1d")
             hip.attn_bwd(qkv, a["keep"], ctx, dctx, lse, delta, dq32, dqkv, B, T, sh.nH, D // sh.nH,
-                         drop_p=pa, drop_seed=s)
+                         drop_p=pa, drop_seed=s, delta_ready=fuse_delta)
             self._dgrad(dqkv, p + "attn.c_attn.weight", da, M, "conv1d")
             self._wgrad(a1, dqkv, p + "attn.c_attn.weight", p + "attn.c_attn.bias", M, "conv1d")
             if l > 0:

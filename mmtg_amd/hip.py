@@ -13,7 +13,7 @@ import os
 import torch
 
 F32, BF16 = 0, 1
-EPI_NONE, EPI_GELU, EPI_TANH, EPI_RESID, EPI_DGELU, EPI_DTANH, EPI_ATOMIC = range(7)
+EPI_NONE, EPI_GELU, EPI_TANH, EPI_RESID, EPI_DGELU, EPI_DTANH, EPI_ATOMIC, EPI_ROWDOT = range(8)
 GEMM_NO_TR, GEMM_REGSTAGE, GEMM_SKINNY, GEMM_NO_SKINNY = 1, 2, 4, 8
 PROF_CATS = ["gemm_bf16", "gemm_f32", "attn_fwd", "attn_bwd", "layernorm", "embed", "loss",
              "optim", "encoder", "decode", "misc"]
@@ -34,7 +34,7 @@ _SIGS = {
     "mmtg_layernorm_bwd_ws": ([_i, _i], _l),
     "mmtg_layernorm_bwd": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _u, _u, _vp, _vp, _l, _vp], _i),
     "mmtg_attn_fwd": ([_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _u, _u, _vp], _i),
-    "mmtg_attn_bwd": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _u, _u, _vp], _i),
+    "mmtg_attn_bwd": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _u, _u, _vp], _i),
     "mmtg_embed_condition": ([_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
     "mmtg_segment_sum": ([_i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp], _i),
     "mmtg_embed_add": ([_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _u, _u, _vp], _i),
@@ -186,8 +186,8 @@ def attn_fwd(qkv, keep, out, lse, B, T, nH, dh, drop_p=0.0, drop_seed=0):
                                drop_thresh(drop_p), drop_seed & 0xFFFFFFFF, _stream()), "attn_fwd")
 
 
-def attn_bwd(qkv, keep, out, dout, lse, delta, dq32, dqkv, B, T, nH, dh, drop_p=0.0, drop_seed=0):
-    _check(lib().mmtg_attn_bwd(dt(qkv), _p(qkv), _p(keep), _p(out), _p(dout), _p(lse), _p(delta), _p(dq32),
+def attn_bwd(qkv, keep, out, dout, lse, delta, dq32, dqkv, B, T, nH, dh, drop_p=0.0, drop_seed=0, delta_ready=False):
+    _check(lib().mmtg_attn_bwd(dt(qkv), _p(qkv), _p(keep), _p(out), _p(dout), _p(lse), _p(delta), int(delta_ready), _p(dq32),
                                _p(dqkv), B, T, nH, dh, drop_thresh(drop_p), drop_seed & 0xFFFFFFFF, _stream()),
            "attn_bwd")
 

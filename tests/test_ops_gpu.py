@@ -160,6 +160,21 @@ def test_gemm_skinny_config(shape):
     close(of, lin - bias, dtype, K, "skinny f32 out")
 
 
+def test_gemm_rowdot_epilogue_is_attention_delta():
+    M, N, K = 600, 192, 128
+    dtype = torch.bfloat16
+    a = rnd(M, K, dtype=dtype, seed=21).to(DEV)
+    w = rnd(N, K, dtype=dtype, seed=22, scale=0.2).to(DEV)
+    o = rnd(M, N, dtype=dtype, seed=23).to(DEV)
+    out = torch.empty(M, N, device=DEV, dtype=dtype)
+    delta = torch.full((M, N // 64), float("nan"), device=DEV)
+    hip.gemm(a, w, out, M, N, K, transB=True, epi=hip.EPI_ROWDOT, aux=o, aux2=delta)
+    ref = a.float() @ w.float().t()
+    close(out, ref, dtype, K, "rowdot out")
+    dref = (out.float() * o.float()).view(M, N // 64, 64).sum(-1)
+    close(delta, dref, torch.float32, 64, "rowdot delta")
+
+
 def test_gemm_rejects_bad_arguments():
     a = torch.zeros(16, 16, device=DEV)
     with pytest.raises(RuntimeError, match="multiple"):
@@ -250,7 +265,7 @@ def test_attention(dtype, T):
     hip.attn_fwd(qd, kd, out, lse, B, T, nH, dh)
     close(out, oref, dtype, 16, "attn out")
     close(lse, lref, torch.float32 if dtype == torch.float32 else dtype, 16, "attn lse")
-    delta = torch.empty(B, nH, T, device=DEV)
+    delta = torch.empty(B * T, nH, device=DEV)
     dq32 = torch.empty(B * T, D, device=DEV)
     dqkv = torch.full((B, T, 3 * D), float("nan"), device=DEV, dtype=dtype)
     hip.attn_bwd(qd, kd, out, dout.to(DEV), lse, delta, dq32, dqkv, B, T, nH, dh)
