@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                                                      T* __restrict__ dx, T* __restrict__ dxm, float* __restrict__ ws,
                                                      int rows, int cols, int want_colsum,
                                                      uint32_t thresh, uint32_t seed, float inv_keep) {
-    __shared__ float sred[3][4][1024];
+    __shared__ float sred[4][1024];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float ag[LN_MAXIT][4], ab[LN_MAXIT][4], ac[LN_MAXIT][4], gm[LN_MAXIT][4];
 #pragma unroll
@@ -146,24 +146,27 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
             }
         }
     }
+    // cross-wave reduction, one quantity at a time through a single 16 KB buffer (keeps LDS small
+    // enough for 8+ resident blocks per CU: this kernel lives on thread-level parallelism)
+    float* out = ws + (long)blockIdx.x * 3 * cols;
 #pragma unroll
-    for (int it = 0; it < LN_MAXIT; ++it) {
-        const int c = it * 256 + lane * 4;
-        if (c < cols) {
+    for (int k = 0; k < 3; ++k) {
+        if (k == 2 && !want_colsum && !dxm) {
+            for (int c = threadIdx.x; c < cols; c += 256) out[2 * cols + c] = 0.f;
+            break;
+        }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                sred[0][wave][c + e] = ag[it][e];
-                sred[1][wave][c + e] = ab[it][e];
-                sred[2][wave][c + e] = ac[it][e];
+        for (int it = 0; it < LN_MAXIT; ++it) {
+            const int c = it * 256 + lane * 4;
+            if (c < cols) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sred[wave][c + e] = k == 0 ? ag[it][e] : k == 1 ? ab[it][e] : ac[it][e];
             }
         }
-    }
-    __syncthreads();
-    float* out = ws + (long)blockIdx.x * 3 * cols;
-    for (int c = threadIdx.x; c < cols; c += 256) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-            out[k * cols + c] = sred[k][0][c] + sred[k][1][c] + sred[k][2][c] + sred[k][3][c];
+        __syncthreads();
+        for (int c = threadIdx.x; c < cols; c += 256)
+            out[k * cols + c] = sred[0][c] + sred[1][c] + sred[2][c] + sred[3][c];
+        __syncthreads();
     }
 }
 
@@ -176,12 +179,16 @@ __global__ __launch_bounds__(256) void ln_bwd_finalize_kernel(const float* __res
     if (!dst) return;
     const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
+    // gridDim.z slices of the partial rows (16-way atomics per output element at the end: cheap,
+    // and 16x the memory-level parallelism of one block per column group)
+    const int per = (nblocks + gridDim.z - 1) / gridDim.z;
+    const int k0 = blockIdx.z * per, k1 = min(nblocks, k0 + per);
     float a = 0.f;
     if (c < cols)
-        for (int k = rg; k < nblocks; k += 4) a += ws[((long)k * 3 + q) * cols + c];
+        for (int k = k0 + rg; k < k1; k += 4) a += ws[((long)k * 3 + q) * cols + c];
     red[rg][cl] = a;
     __syncthreads();
-    if (rg == 0 && c < cols) dst[c] += red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+    if (rg == 0 && c < cols) atomicAdd(dst + c, red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
 }
 
 // out[n] += sum_m X[m,n]: block = 256 threads -> 64 column-quads x 4 row lanes
@@ -227,7 +234,7 @@ extern "C" int mmtg_layernorm_fwd(int dtype, const void* x, void* y, const float
     return MMTG_OK;
 }
 
-static inline int ln_bwd_blocks(int rows) { return min(cdiv(rows, 4), 512); }
+static inline int ln_bwd_blocks(int rows) { return min(cdiv(rows, 4), 1024); }
 
 extern "C" long mmtg_layernorm_bwd_ws(int rows, int cols) { return (long)ln_bwd_blocks(rows) * 3 * cols; }
 
@@ -253,7 +260,7 @@ extern "C" int mmtg_layernorm_bwd(int dtype, const void* dy, const void* x, cons
     else if (dtype == MMTG_BF16)
         hipLaunchKernelGGL(ln_bwd_kernel<bf16>, grid, block, 0, s, (const bf16*)dy, (const bf16*)x, gamma, mean, rstd, (const bf16*)dres, (bf16*)dx, (bf16*)dx_masked, ws, rows, cols, want, drop_thresh, drop_seed, ik);
     else MMTG_FAIL(MMTG_ERR_BAD_ARG, "layernorm_bwd: bad dtype");
-    hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3(cdiv(cols, 64), 3), dim3(256), 0, s, ws, nb, cols, dgamma, dbeta, dcolsum);
+    hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3(cdiv(cols, 64), 3, 16), dim3(256), 0, s, ws, nb, cols, dgamma, dbeta, dcolsum);
     MMTG_LAUNCH_CHECK("layernorm_bwd");
     return MMTG_OK;
 }
