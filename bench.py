@@ -165,8 +165,10 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    force_ddp = bool(os.environ.get("MMTG_FORCE_DDP"))     # exercise the RCCL path on one GPU (self-test)
+    if world > 1 or force_ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from mmtg_amd import MMTG, hip, synth
@@ -186,7 +188,7 @@ def main():
     model.reset_parameters(seed=0)
     model.to(dev).train()
     trainer = MMTGTrainer(model, lr=1e-5, alpha=0.2, warmup_steps=10, total_steps=100000,
-                          distributed=world > 1, bucket_mb=args.bucket_mb)
+                          distributed=world > 1 or force_ddp, bucket_mb=args.bucket_mb)
     B = args.batch
     batches = []
     for i in range(2):
@@ -256,7 +258,7 @@ def main():
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

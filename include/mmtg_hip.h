@@ -48,6 +48,9 @@ enum {
 #define MMTG_GEMM_REGSTAGE 2 /* flags: register-staged v1 pipeline instead of the LDS-DMA one (bf16) */
 #define MMTG_GEMM_SKINNY 4    /* flags: force the 256x32-tile small-M configuration (bf16, transA=0,transB=1) */
 #define MMTG_GEMM_NO_SKINNY 8 /* flags: never pick it automatically (it is the default for M <= 256) */
+#define MMTG_GEMM_WIDE 16     /* flags: force 192x128 tiles / 6 waves (bf16, transA=0); chosen automatically when it
+                                 saves a partial round of workgroups (N = 768) or for N >= 4096 */
+#define MMTG_GEMM_NO_WIDE 32  /* flags: never pick 192x128 automatically */
 
 /* profiling categories (mmtg_prof_*) */
 enum {

@@ -68,6 +68,23 @@ __device__ __forceinline__ float gelu_new_grad_f(float x) {
 }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
+// Storage-type-aware transcendental helpers: exact libm tanhf in the fp32 parity mode, the
+// v_exp_f32-based form (4 instructions instead of ~25, error << bf16 rounding) for bf16 storage.
+template <typename T> __device__ __forceinline__ float tanh_t(float x) {
+    if constexpr (sizeof(T) == 2) return 1.0f - 2.0f / (1.0f + __expf(2.0f * x));
+    else return tanhf(x);
+}
+template <typename T> __device__ __forceinline__ float gelu_new_t(float x) {
+    const float k = 0.7978845608028654f;
+    return 0.5f * x * (1.0f + tanh_t<T>(k * (x + 0.044715f * x * x * x)));
+}
+template <typename T> __device__ __forceinline__ float gelu_new_grad_t(float x) {
+    const float k = 0.7978845608028654f;
+    const float x2 = x * x;
+    const float t = tanh_t<T>(k * (x + 0.044715f * x * x2));
+    return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * k * (1.0f + 3.0f * 0.044715f * x2);
+}
+
 // ---------------------------------------------------------------- wave reductions (64 lanes)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -126,7 +126,7 @@ __device__ __forceinline__ void ks_offsets(int col0, int lane, int (&o)[NT]) {
     }
 }
 
-template <bool AKS, bool BKS, int TBM, int TBN, int NBA, int NBB>
+template <bool AKS, bool BKS, int TBM, int TBN, int NBA, int NBB, int NW>
 __device__ __forceinline__ void dma_issue_tile(const GemmArgs& p, __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb,
                                                const int (&va)[NBA], const int (&vb)[NBB], int sa, int sb, char* stage, int TA,
                                                int t, int nk_full, int nk, int klen, int m0, int n0, int wave, int lane,
@@ -134,27 +134,31 @@ __device__ __forceinline__ void dma_issue_tile(const GemmArgs& p, __amdgpu_buffe
     if (t < nk_full) {          // full tile: loop-invariant lane offsets
 #pragma unroll
         for (int i = 0; i < NBA; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, LDS_PTR(void, stage + (wave * NBA + i) * 1024), 16, va[i], sa, 0, 0);
+            if (wave + NW * i < TBM / 8)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, LDS_PTR(void, stage + (wave + NW * i) * 1024), 16, va[i], sa, 0, 0);
 #pragma unroll
         for (int i = 0; i < NBB; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, LDS_PTR(void, stage + TA + (wave * NBB + i) * 1024), 16, vb[i], sb, 0, 0);
+            if (wave + NW * i < TBN / 8)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, LDS_PTR(void, stage + TA + (wave + NW * i) * 1024), 16, vb[i], sb, 0, 0);
     } else if (t < nk) {        // ragged last K tile: recompute the offsets with the remaining K
         const int krem = klen - t * 64;
 #pragma unroll
         for (int i = 0; i < NBA; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, LDS_PTR(void, stage + (wave * NBA + i) * 1024), 16,
-                                                     dma_voff<AKS, TBM>(p.lda, m0, p.M, krem, wave * NBA + i, lane), sa, 0, 0);
+            if (wave + NW * i < TBM / 8)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, LDS_PTR(void, stage + (wave + NW * i) * 1024), 16,
+                                                         dma_voff<AKS, TBM>(p.lda, m0, p.M, krem, wave + NW * i, lane), sa, 0, 0);
 #pragma unroll
         for (int i = 0; i < NBB; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, LDS_PTR(void, stage + TA + (wave * NBB + i) * 1024), 16,
-                                                     dma_voff<BKS, TBN>(p.ldb, n0, p.N, krem, wave * NBB + i, lane), sb, 0, 0);
+            if (wave + NW * i < TBN / 8)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, LDS_PTR(void, stage + TA + (wave + NW * i) * 1024), 16,
+                                                         dma_voff<BKS, TBN>(p.ldb, n0, p.N, krem, wave + NW * i, lane), sb, 0, 0);
     } else if (dummy_tail) {    // deep rings: keep the per-tile load count uniform for the counted vmcnt
 #pragma unroll
         for (int i = 0; i < NBA; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, LDS_PTR(void, stage + (wave * NBA + i) * 1024), 16, OOB, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, LDS_PTR(void, stage + (wave + NW * i) * 1024), 16, OOB, 0, 0, 0);
 #pragma unroll
         for (int i = 0; i < NBB; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, LDS_PTR(void, stage + TA + (wave * NBB + i) * 1024), 16, OOB, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, LDS_PTR(void, stage + TA + (wave + NW * i) * 1024), 16, OOB, 0, 0, 0);
     }
 }
 
@@ -172,8 +176,10 @@ __global__ __launch_bounds__((64 * WM * WN), (DmaCfg<TBM, TBN, WM, WN, NBUF>::MI
     typedef bf16 T;
     constexpr int NW = WM * WN, WTM = TBM / WM, WTN = TBN / WN, TM = WTM / 16, TN = WTN / 16;
     constexpr int TA = TBM * 128, TB = TBN * 128, STAGE = TA + TB;     // bytes
-    constexpr int NBA = TBM / 8 / NW, NBB = TBN / 8 / NW;                // 1-KB DMA blocks per wave
-    static_assert(NBA >= 1 && NBB >= 1 && TBM % (8 * NW) == 0 && TBN % (8 * NW) == 0, "tile / wave mismatch");
+    // 1-KB DMA blocks per wave: block b of a tile is issued by wave b % NW (uneven splits allowed for
+    // 2-deep rings, whose wait is vmcnt(0); deeper rings count loads per tile and need an even split)
+    constexpr int NBA = (TBM / 8 + NW - 1) / NW, NBB = (TBN / 8 + NW - 1) / NW;
+    static_assert(NBUF == 2 || (TBM % (8 * NW) == 0 && TBN % (8 * NW) == 0), "deep rings need an even block split");
     extern __shared__ __attribute__((aligned(16))) char smem[];      // NBUF stages of [A tile | B tile]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -201,9 +207,9 @@ __global__ __launch_bounds__((64 * WM * WN), (DmaCfg<TBM, TBN, WM, WN, NBUF>::MI
     const int stepb = (int)((BKS ? (long)BK * p.ldb : (long)BK) * 2);
     int va[NBA], vb[NBB];
 #pragma unroll
-    for (int i = 0; i < NBA; ++i) va[i] = dma_voff<AKS, TBM>(p.lda, m0, p.M, BK, wave * NBA + i, lane);
+    for (int i = 0; i < NBA; ++i) va[i] = dma_voff<AKS, TBM>(p.lda, m0, p.M, BK, wave + NW * i, lane);
 #pragma unroll
-    for (int i = 0; i < NBB; ++i) vb[i] = dma_voff<BKS, TBN>(p.ldb, n0, p.N, BK, wave * NBB + i, lane);
+    for (int i = 0; i < NBB; ++i) vb[i] = dma_voff<BKS, TBN>(p.ldb, n0, p.N, BK, wave + NW * i, lane);
 
     f32x4 acc[TM][TN];
 #pragma unroll
@@ -215,7 +221,7 @@ __global__ __launch_bounds__((64 * WM * WN), (DmaCfg<TBM, TBN, WM, WN, NBUF>::MI
     //  the amdgcn LDS-DMA builtin inside it silently drops the kernel's host stub)
 #define ISSUE_TILE(t)                                                                                          \
     do {                                                                                                       \
-        dma_issue_tile<AKS, BKS, TBM, TBN, NBA, NBB>(p, ra, rb, va, vb, sa, sb, smem + ((t) % NBUF) * STAGE, TA, \
+        dma_issue_tile<AKS, BKS, TBM, TBN, NBA, NBB, NW>(p, ra, rb, va, vb, sa, sb, smem + ((t) % NBUF) * STAGE, TA, \
                                                      (t), nk_full, nk, kend - kbeg, m0, n0, wave, lane, NBUF > 2); \
         sa += stepa;                                                                                           \
         sb += stepb;                                                                                           \
@@ -296,7 +302,11 @@ int launch_dma_cfg(const GemmArgs& a, int splits, hipStream_t stream) {
     return MMTG_OK;
 }
 
-int launch_dma(const GemmArgs& a, int transA, int transB, int splits, int skinny, hipStream_t stream) {
+int launch_dma(const GemmArgs& a, int transA, int transB, int splits, int skinny, int wide, hipStream_t stream) {
+    if (wide) {   // 192x128 tiles, 3x2 waves: N = 768 products of M = 15104 fit one round of 2 workgroups/CU
+        if (!transA && transB) return launch_dma_cfg<false, false, 192, 128, 3, 2, 2>(a, splits, stream);
+        if (!transA && !transB) return launch_dma_cfg<false, true, 192, 128, 3, 2, 2>(a, splits, stream);
+    }
     if (!transA && transB) {
         if (skinny) return launch_dma_cfg<false, false, 256, 32, 4, 1, 4>(a, splits, stream);
         return launch_dma_cfg<false, false, 128, 128, 2, 2, 2>(a, splits, stream);
@@ -366,7 +376,17 @@ extern "C" int mmtg_gemm(int dtype, int transA, int transB, int M, int N, int K,
     int rc;
     if (dtype == MMTG_F32) rc = launch_regstage<float>(a, transA, transB, grid, s);
     else if ((flags & (MMTG_GEMM_REGSTAGE | MMTG_GEMM_NO_TR)) || !small) rc = launch_regstage<bf16>(a, transA, transB, grid, s);
-    else rc = launch_dma(a, transA, transB, splits, skinny && !transA && transB, s);
+    else {
+        // Tile choice (measured, profiles/r01_gemm_tile_configs.log): 192x128 when it turns a
+        // 1.x-round grid of 128x128 tiles into one full round of the 512 workgroup slots (N = 768 at
+        // M = 15104: 708 -> 474 tiles, -27 %), and for very wide outputs (LM head, -12 %).
+        bool wide = (flags & MMTG_GEMM_WIDE) != 0;
+        if (!wide && !(flags & MMTG_GEMM_NO_WIDE) && !transA && !skinny && M >= 1024) {
+            const long t128 = (long)cdiv(M, 128) * cdiv(N, 128), t192 = (long)cdiv(M, 192) * cdiv(N, 128);
+            wide = (t128 > 512 && t192 <= 512) || N >= 4096;
+        }
+        rc = launch_dma(a, transA, transB, splits, skinny && !transA && transB, wide, s);
+    }
     if (rc) return rc;
     MMTG_LAUNCH_CHECK("gemm");
     return MMTG_OK;

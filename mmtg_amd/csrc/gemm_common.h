@@ -267,10 +267,10 @@ __device__ __forceinline__ void epi_tiles(const GemmArgs& p, f32x4 (&acc)[TM][TN
             if constexpr (EPI == MMTG_EPI_GELU) {
                 store8<T>(reinterpret_cast<T*>(p.aux2) + (long)m * p.ldc + n, v);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = gelu_new_f(v[e]);
+                for (int e = 0; e < 8; ++e) v[e] = gelu_new_t<T>(v[e]);
             } else if constexpr (EPI == MMTG_EPI_TANH) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = tanhf(v[e]);
+                for (int e = 0; e < 8; ++e) v[e] = tanh_t<T>(v[e]);
             } else if constexpr (EPI == MMTG_EPI_RESID) {
                 if (p.drop_thresh) {
 #pragma unroll
@@ -283,7 +283,7 @@ __device__ __forceinline__ void epi_tiles(const GemmArgs& p, f32x4 (&acc)[TM][TN
             } else if constexpr (EPI == MMTG_EPI_DGELU) {
                 load8<T>(aux + (long)m * p.ldaux + n, a8);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] *= gelu_new_grad_f(a8[e]);
+                for (int e = 0; e < 8; ++e) v[e] *= gelu_new_grad_t<T>(a8[e]);
             } else if constexpr (EPI == MMTG_EPI_DTANH) {
                 load8<T>(aux + (long)m * p.ldaux + n, a8);
 #pragma unroll

@@ -25,6 +25,8 @@ class GradReducer:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.layout = layout
+        # MMTG_FORCE_DDP: run the collectives even at world size 1 (single-GPU self-test of the RCCL path)
+        self.force = dist.is_initialized() and bool(__import__("os").environ.get("MMTG_FORCE_DDP"))
         self.buckets = layout.buckets(int(bucket_mb * 1024 * 1024 / 4))
         self.pack_end = {name: o + n for name, (o, n) in layout.pack_range.items()}
         self.reset()
@@ -38,7 +40,7 @@ class GradReducer:
 
     def on_ready(self, grad_flat, end_offset):
         """All gradient elements below end_offset are final: launch every complete bucket."""
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         while self.next_bucket < len(self.buckets) and self.buckets[self.next_bucket][1] <= end_offset:
             s, e = self.buckets[self.next_bucket]
@@ -47,7 +49,7 @@ class GradReducer:
 
     def finish(self, grad_flat):
         """Flush the remaining buckets and make the current stream wait for all of them."""
-        if self.world > 1:
+        if self.world > 1 or self.force:
             self.on_ready(grad_flat, self.layout.total)
             for h in self.handles:
                 h.wait()

@@ -49,13 +49,15 @@ def close(got, ref, dtype, k=1, name="", scale=None):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("layout", ["NT", "NN", "TN"])
 @pytest.mark.parametrize("shape", [(200, 136, 96), (712, 768, 512), (1024, 256, 2048)])
-@pytest.mark.parametrize("variant", ["dma2", "regstage", "no_tr"])
+@pytest.mark.parametrize("variant", ["dma2", "wide", "regstage", "no_tr"])
 def test_gemm_layouts(dtype, layout, shape, variant):
     no_tr = variant == "no_tr"
     if no_tr and (dtype == torch.float32 or layout == "NT"):
         pytest.skip("scalar-gather variant only differs for bf16 K-strided operands")
     if dtype == torch.float32 and variant != "dma2":
         pytest.skip("f32 has one pipeline (register-staged)")
+    if variant == "wide" and layout == "TN":
+        pytest.skip("192x128 tiles are built for the forward / dgrad layouts")
     M, N, K = shape
     a = rnd(M, K, dtype=dtype, seed=1)
     b = rnd(K, N, dtype=dtype, seed=2)
@@ -67,7 +69,7 @@ def test_gemm_layouts(dtype, layout, shape, variant):
     else:
         A, B, tA, tB = a.t().contiguous(), b, True, False
     A, B = A.to(DEV), B.to(DEV)
-    flags = {"dma2": 0, "regstage": hip.GEMM_REGSTAGE, "no_tr": hip.GEMM_NO_TR}[variant]
+    flags = {"dma2": hip.GEMM_NO_WIDE, "wide": hip.GEMM_WIDE, "regstage": hip.GEMM_REGSTAGE, "no_tr": hip.GEMM_NO_TR}[variant]
     if layout == "TN":
         for splits in (1, 3):
             Cf = torch.full((M, N), 0.5, device=DEV, dtype=torch.float32)
@@ -94,6 +96,10 @@ def test_gemm_epilogues(dtype):
         hip.gemm(a, w, out, M, N, K, transB=True, epi=epi, **kw)
         return out
 
+    if dtype == torch.bfloat16:   # the 192x128 configuration shares the epilogue code: spot-check it too
+        pre_w = torch.empty(M, N, device=DEV, dtype=dtype)
+        close(run(hip.EPI_GELU, bias=bias, aux2=pre_w, flags=hip.GEMM_WIDE), O.gelu_new(lin), dtype, K, "wide gelu")
+        close(run(hip.EPI_RESID, bias=bias, aux=aux, flags=hip.GEMM_WIDE), lin + aux.float(), dtype, K, "wide resid")
     close(run(hip.EPI_NONE, bias=bias), lin, dtype, K, "bias")
     close(run(hip.EPI_NONE, bias=bias, out_f32=True, odt=torch.float32), lin, torch.float32 if dtype == torch.float32 else dtype, K, "out_f32")
     close(run(hip.EPI_TANH, bias=bias), torch.tanh(lin), dtype, K, "tanh")
