@@ -35,8 +35,9 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_kernel(GemmArgs p) {
     const int g = lane >> 4, l15 = lane & 15;
     const int wm = wave >> 1, wn = wave & 1;
     int m0, n0;
-    tile_origin(p, m0, n0);
-    const int kbeg = blockIdx.z * p.kper;
+    int split;
+    tile_origin(p, m0, n0, split);
+    const int kbeg = split * p.kper;
     const int kend = min(p.K, kbeg + p.kper);
     const int nk = (kend - kbeg + GT<T>::BK - 1) / GT<T>::BK;
     const T* A = reinterpret_cast<const T*>(p.A);
@@ -186,9 +187,10 @@ __global__ __launch_bounds__((64 * WM * WN), (DmaCfg<TBM, TBN, WM, WN, NBUF>::MI
     const int g = lane >> 4, l15 = lane & 15;
     const int wm = wave / WN, wn = wave % WN;
     int m0, n0;
-    tile_origin(p, m0, n0, TBM, TBN);
+    int split;
+    tile_origin(p, m0, n0, split, TBM, TBN);
     constexpr int BK = 64;
-    const int kbeg = blockIdx.z * p.kper;
+    const int kbeg = split * p.kper;
     const int kend = min(p.K, kbeg + p.kper);
     const int nk = (kend - kbeg + BK - 1) / BK;
     const int nk_full = (kend - kbeg) / BK;
@@ -297,7 +299,8 @@ int launch_dma_cfg(const GemmArgs& a, int splits, hipStream_t stream) {
     }
     GemmArgs b = a;
     b.tiles_n = cdiv(a.N, BN_);
-    dim3 grid(cdiv(a.M, BM_) * b.tiles_n, 1, splits), block(64 * WM * WN);
+    b.ntiles = cdiv(a.M, BM_) * b.tiles_n;
+    dim3 grid(b.ntiles * splits), block(64 * WM * WN);
     hipLaunchKernelGGL((gemm_dma_kernel<AKS, BKS, BM_, BN_, WM, WN, NBUF>), grid, block, shm, stream, b);
     return MMTG_OK;
 }
@@ -370,7 +373,8 @@ extern "C" int mmtg_gemm(int dtype, int transA, int transB, int M, int N, int K,
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(dtype == MMTG_F32 ? MMTG_PROF_GEMM_F32 : MMTG_PROF_GEMM_BF16, s, 2.0 * M * N * (double)K,
                    (double)(dtype == MMTG_F32 ? 4 : 2) * ((double)M * K + (double)N * K) + (double)M * N * (out_f32 ? 4 : (dtype == MMTG_F32 ? 4 : 2)));
-    dim3 grid(cdiv(M, BM) * cdiv(N, BN), 1, splits);
+    a.ntiles = cdiv(M, BM) * cdiv(N, BN);
+    dim3 grid(a.ntiles * splits);
     // small-M products with K-contiguous weights (decode): 256x32 tiles -> N/32 workgroups
     const int skinny = (flags & MMTG_GEMM_SKINNY) || (!transA && transB && M <= 256 && !(flags & MMTG_GEMM_NO_SKINNY));
     int rc;

@@ -24,6 +24,7 @@ struct GemmArgs {
     int out_f32;           // C is float regardless of T
     int use_tr;            // bf16 KS fragments via ds_read_b64_tr_b16 (1) or scalar gathers (0)
     int tiles_n;
+    int ntiles;            // output tiles per K split (grid = ntiles * splits work items)
     int kper;              // K elements per split (multiple of BK)
     float alpha;
     uint32_t drop_thresh; uint32_t drop_seed; float drop_inv_keep;
@@ -142,13 +143,20 @@ template <> __device__ __forceinline__ void load4<bf16>(const bf16* p, float (&v
 }
 
 
-// XCD-aware tile order: consecutive tiles (sharing the A row panel) land on one XCD's L2
-__device__ __forceinline__ void tile_origin(const GemmArgs& p, int& m0, int& n0, int bm = BM, int bn = BN) {
+// XCD-aware work order over a 1-D grid of (split, tile) items.  Workgroups are dealt round-robin to
+// the 8 XCDs, so block b and b+8 share an L2: the bijective remap below gives every XCD one contiguous
+// run of the virtual order  v = split * ntiles + tile_m * tiles_n + tile_n.  Neighbours in v share
+// the A row panel, and -- for split-K weight gradients -- a whole XCD works inside ONE K slice, so
+// each slice of the activations is fetched by one or two XCDs instead of all eight (measured HBM
+// traffic of the wgrad GEMMs 2.3-2.8x algorithmic before, see profiles/).
+__device__ __forceinline__ void tile_origin(const GemmArgs& p, int& m0, int& n0, int& split, int bm = BM, int bn = BN) {
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
-    const int swz = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
-    m0 = (swz / p.tiles_n) * bm;
-    n0 = (swz % p.tiles_n) * bn;
+    const int v = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+    split = v / p.ntiles;
+    const int t = v - split * p.ntiles;
+    m0 = (t / p.tiles_n) * bm;
+    n0 = (t % p.tiles_n) * bn;
 }
 
 // Per-lane byte offsets of the transposed-read fragments of a K-strided bf16 operand, hoisted out of
