@@ -51,6 +51,10 @@ enum {
 #define MMTG_GEMM_WIDE 16     /* flags: force 192x128 tiles / 6 waves (bf16, transA=0); chosen automatically when it
                                  saves a partial round of workgroups (N = 768) or for N >= 4096 */
 #define MMTG_GEMM_NO_WIDE 32  /* flags: never pick 192x128 automatically */
+#define MMTG_GEMM_PERSIST 64  /* flags: use the persistent pipelined 128x128 kernel (one workgroup per CU slot walks the
+                                 (tile, K split) items, next item prefetched, epilogue deferred into it); opt-in:
+                                 measured on par with the plain launch */
+#define MMTG_GEMM_NO_PERSIST 128 /* flags: reserved (the persistent kernel is never picked automatically) */
 
 /* profiling categories (mmtg_prof_*) */
 enum {
@@ -82,6 +86,12 @@ int mmtg_gemm(int dtype, int transA, int transB, int M, int N, int K,
               const float* bias, int epi, const void* aux, long ldaux, void* aux2,
               int out_f32, float alpha, int splits, unsigned drop_thresh, unsigned drop_seed,
               int flags, void* stream);
+
+/* Diagnostic timeline of the bf16 LDS-DMA GEMM kernels (tools/gemm_timeline.py): while `buf` is
+ * non-null, wave 0 of workgroup w < max_wgs of every such launch writes 6 x u64 at buf + 48*w --
+ * s_memrealtime (100 MHz) at kernel entry, after the first K tile has landed, at the end of the K
+ * loop, at exit; the K tile count; the hardware id (XCC / SE / CU).  Null switches it off (default). */
+int mmtg_gemm_trace(void* buf, int max_wgs);
 
 /* column sums: out[n] += sum_m X[m,n]  (bias gradients), X of `dtype`, out f32 */
 int mmtg_colsum(int dtype, const void* X, long ldx, int M, int N, float* out, void* stream);

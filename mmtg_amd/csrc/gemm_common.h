@@ -26,6 +26,8 @@ struct GemmArgs {
     int tiles_n;
     int ntiles;            // output tiles per K split (grid = ntiles * splits work items)
     int kper;              // K elements per split (multiple of BK)
+    int nitems;            // ntiles * splits work items (a persistent launch has fewer workgroups)
+    unsigned long long* trace; int trace_n;   // diagnostic timeline (mmtg_gemm_trace) or null
     float alpha;
     uint32_t drop_thresh; uint32_t drop_seed; float drop_inv_keep;
     int bytesA, bytesB;    // operand extents for the LDS-DMA buffer descriptors
@@ -149,8 +151,9 @@ template <> __device__ __forceinline__ void load4<bf16>(const bf16* p, float (&v
 // the A row panel, and -- for split-K weight gradients -- a whole XCD works inside ONE K slice, so
 // each slice of the activations is fetched by one or two XCDs instead of all eight (measured HBM
 // traffic of the wgrad GEMMs 2.3-2.8x algorithmic before, see profiles/).
-__device__ __forceinline__ void tile_origin(const GemmArgs& p, int& m0, int& n0, int& split, int bm = BM, int bn = BN) {
-    const int nwg = gridDim.x, bid = blockIdx.x;
+// (`bid` of `nwg` work items; a persistent launch passes item numbers bid = blockIdx.x + i * gridDim.x
+//  with gridDim.x a multiple of 8, which keeps every item on the XCD the map assumes.)
+__device__ __forceinline__ void tile_origin(const GemmArgs& p, int bid, int nwg, int& m0, int& n0, int& split, int bm = BM, int bn = BN) {
     const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
     const int v = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
     split = v / p.ntiles;
@@ -232,46 +235,77 @@ template <> __device__ __forceinline__ void store8<bf16>(bf16* p, const float (&
     bf16x8 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3], (bf16)v[4], (bf16)v[5], (bf16)v[6], (bf16)v[7]};
     *reinterpret_cast<bf16x8*>(p) = o;
 }
-
 // Epilogue through LDS.  The accumulator layout gives a lane 4 consecutive columns of ONE row per
-// 16x16 tile, i.e. 32-byte global segments; staged through a wave-private LDS image
-// ([rows][WTN floats], row stride WTN*4+16 B) the same data is re-read with 8 consecutive columns per
-// lane and WTN/8 lanes per row, so every global access (output, pre-activation, residual / aux) is a
-// 16-byte vector and a wave touches whole rows of the tile.  Two passes of TM/2 tile-rows keep the
-// image within the main loop's LDS allocation.  `lds` = this wave's scratch (HALF*LDW*4 bytes).
-template <typename T, int EPI, int TM, int TN>
+// 16x16 tile, i.e. 32-byte global segments; staged through a wave-private LDS image the same data is
+// re-read with 8 consecutive columns per lane and WTN/8 lanes per row, so every global access
+// (output, pre-activation, residual / aux) is a 16-byte vector and a wave touches whole rows of the
+// tile.  One pass per 16-row band of the wave tile: the image is [16 rows][WTN floats] with the
+// 16-byte chunk c of row r stored at c ^ (r & (chunks-1)) -- conflict free for the accumulator
+// writes (16 rows, same c) and for the row-wise read-back -- i.e. 4 KB per wave at WTN = 64.
+// `lds` = this wave's scratch (epi_scratch_bytes); LDS operations of one wave complete in order, so
+// the passes need no barrier between them.
+template <typename T, int EPI, int TM, int TN, int PFD>
 __device__ __forceinline__ void epi_tiles(const GemmArgs& p, f32x4 (&acc)[TM][TN], int mw0, int nw0, int g, int l15,
                                           char* lds, int lane) {
-    static_assert(TM % 2 == 0, "two passes of TM/2 tile rows");
     constexpr int WTN = TN * 16;               // wave-tile columns
-    constexpr int LDW = WTN + 4;               // padded row stride in floats
-    constexpr int HALF = TM / 2 * 16;          // rows per pass
+    constexpr int NCH = WTN / 4;               // 16-byte chunks per image row
     constexpr int LPR = WTN / 8;               // lanes per row on read-back
     constexpr int RPI = 64 / LPR;              // rows per read instruction
-    float* img = reinterpret_cast<float*>(lds);
+    constexpr int NQ = 16 / RPI;               // read instructions per 16-row band
+    constexpr bool HAS_AUX = EPI == MMTG_EPI_RESID || EPI == MMTG_EPI_DGELU || EPI == MMTG_EPI_DTANH || EPI == MMTG_EPI_ROWDOT;
     const T* aux = reinterpret_cast<const T*>(p.aux);
+    // Everything that comes from global memory is requested ahead of its use -- the lane's 8 bias
+    // values once (its columns are the same in every band) and the aux vectors of its rows PFD bands
+    // ahead (all of them up front where the register budget allows) -- so the epilogue waits for one
+    // memory latency, under the LDS staging, instead of one per band (measured: the per-band loads
+    // were ~6 us of an 18 us 128x128x768 item).
+    const int col = (lane % LPR) * 8, n = nw0 + col, r0 = lane / LPR;
+    const bool nok = n < p.N;
+    float b8[8];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int e = 0; e < 8; ++e) b8[e] = 0.f;
+    if (p.bias && nok) load8<float>(p.bias + n, b8);
+    typedef typename Vec16<T>::type V;
+    constexpr int VPA = 8 / Vec16<T>::N;       // 16-byte vectors per 8 elements (bf16: 1, f32: 2)
+    constexpr int RING = PFD + 1 < TM ? PFD + 1 : TM;     // bands of aux vectors held at once
+    V ax[HAS_AUX ? RING * NQ * VPA : 1];
+    // (clamped address: rows past M are loaded from row M-1 and never stored)
+#define EPI_LOAD_BAND(hb)                                                                                   \
+    _Pragma("unroll") for (int q_ = 0; q_ < NQ; ++q_) {                                                     \
+        const int m_ = mw0 + (hb) * 16 + q_ * RPI + r0;                                                     \
+        const V* src_ = reinterpret_cast<const V*>(aux + (long)(m_ < p.M ? m_ : p.M - 1) * p.ldaux + (nok ? n : 0)); \
+        _Pragma("unroll") for (int u_ = 0; u_ < VPA; ++u_) ax[(((hb) % RING) * NQ + q_) * VPA + u_] = src_[u_]; \
+    }
+    if constexpr (HAS_AUX) {
 #pragma unroll
-        for (int ii = 0; ii < TM / 2; ++ii)
+        for (int hb = 0; hb < RING - 1; ++hb) { EPI_LOAD_BAND(hb) }
+    }
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-                *reinterpret_cast<f32x4*>(img + (ii * 16 + l15) * LDW + j * 16 + 4 * g) = acc[h * (TM / 2) + ii][j];
-        // same wave wrote and reads: LDS operations of one wave complete in order
+    for (int h = 0; h < TM; ++h) {
+        if constexpr (HAS_AUX) {
+            if (h + RING - 1 < TM) { EPI_LOAD_BAND(h + RING - 1) }
+        }
 #pragma unroll
-        for (int q = 0; q < HALF / RPI; ++q) {
-            const int row = q * RPI + lane / LPR, col = (lane % LPR) * 8;
-            const int m = mw0 + h * HALF + row, n = nw0 + col;
+        for (int j = 0; j < TN; ++j)
+            *reinterpret_cast<f32x4*>(lds + l15 * (WTN * 4) + (((j * 4 + g) ^ (l15 & (NCH - 1))) << 4)) = acc[h][j];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int row = q * RPI + r0;
+            const int m = mw0 + h * 16 + row;
             float v[8];
-            load8<float>(img + row * LDW + col, v);
-            if (m >= p.M || n >= p.N) continue;
-            if (p.bias) {
-                float b8[8];
-                load8<float>(p.bias + n, b8);
+            {
+                const int c0 = 2 * (lane % LPR), sw = row & (NCH - 1);
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(lds + row * (WTN * 4) + ((c0 ^ sw) << 4));
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(lds + row * (WTN * 4) + (((c0 + 1) ^ sw) << 4));
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += b8[e];
+                for (int e = 0; e < 4; ++e) { v[e] = lo[e] + b8[e]; v[4 + e] = hi[e] + b8[4 + e]; }
             }
+            if (m >= p.M || !nok) continue;
             float a8[8];
+            if constexpr (HAS_AUX) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a8[e] = (float)ax[((h % RING) * NQ + q) * VPA + e / Vec16<T>::N][e % Vec16<T>::N];
+            }
             if constexpr (EPI == MMTG_EPI_GELU) {
                 store8<T>(reinterpret_cast<T*>(p.aux2) + (long)m * p.ldc + n, v);
 #pragma unroll
@@ -285,22 +319,18 @@ __device__ __forceinline__ void epi_tiles(const GemmArgs& p, f32x4 (&acc)[TM][TN
                     for (int e = 0; e < 8; ++e)
                         v[e] *= dropout_scale(p.drop_seed, (uint32_t)((long)m * p.N + n + e), p.drop_thresh, p.drop_inv_keep);
                 }
-                load8<T>(aux + (long)m * p.ldaux + n, a8);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += a8[e];
             } else if constexpr (EPI == MMTG_EPI_DGELU) {
-                load8<T>(aux + (long)m * p.ldaux + n, a8);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] *= gelu_new_grad_t<T>(a8[e]);
             } else if constexpr (EPI == MMTG_EPI_DTANH) {
-                load8<T>(aux + (long)m * p.ldaux + n, a8);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] *= (1.0f - a8[e] * a8[e]);
             } else if constexpr (EPI == MMTG_EPI_ROWDOT) {
                 // attention backward's delta[m, head] = sum over the head's 64 columns of out * aux
                 // (out = d ctx as stored, aux = ctx): a wave tile row IS one head (WTN == 64), held by 8 lanes
                 static_assert(WTN == 64, "ROWDOT needs 64-column wave tiles (one attention head)");
-                load8<T>(aux + (long)m * p.ldaux + n, a8);
                 float dot = 0.f;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) dot += (float)(T)v[e] * a8[e];
@@ -315,13 +345,15 @@ __device__ __forceinline__ void epi_tiles(const GemmArgs& p, f32x4 (&acc)[TM][TN
     }
 }
 
+#undef EPI_LOAD_BAND
+
 // mw0 / nw0: global row / column of the wave's sub-tile origin
 // bytes of wave-private LDS scratch the staged epilogue needs
-template <int TM, int TN> constexpr int epi_scratch_bytes() { return (TM / 2 * 16) * (TN * 16 + 4) * 4; }
+template <int TM, int TN> constexpr int epi_scratch_bytes() { return 16 * (TN * 16) * 4; }
 
 // `lds`: this wave's scratch of epi_scratch_bytes<TM,TN>() bytes; the caller has made sure (barrier) that
 // no wave still reads the main-loop tiles it overlays.
-template <typename T, bool std_orient, int TM, int TN>
+template <typename T, bool std_orient, int TM, int TN, int PFD = TM>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM][TN], int mw0, int nw0, int g, int l15,
                                               char* lds, int lane) {
     if constexpr (std_orient) {
@@ -339,15 +371,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
             }
     } else {
         switch (p.epi) {
-            case MMTG_EPI_GELU: epi_tiles<T, MMTG_EPI_GELU, TM, TN>(p, acc, mw0, nw0, g, l15, lds, lane); break;
-            case MMTG_EPI_TANH: epi_tiles<T, MMTG_EPI_TANH, TM, TN>(p, acc, mw0, nw0, g, l15, lds, lane); break;
-            case MMTG_EPI_RESID: epi_tiles<T, MMTG_EPI_RESID, TM, TN>(p, acc, mw0, nw0, g, l15, lds, lane); break;
-            case MMTG_EPI_DGELU: epi_tiles<T, MMTG_EPI_DGELU, TM, TN>(p, acc, mw0, nw0, g, l15, lds, lane); break;
-            case MMTG_EPI_DTANH: epi_tiles<T, MMTG_EPI_DTANH, TM, TN>(p, acc, mw0, nw0, g, l15, lds, lane); break;
+            case MMTG_EPI_GELU: epi_tiles<T, MMTG_EPI_GELU, TM, TN, PFD>(p, acc, mw0, nw0, g, l15, lds, lane); break;
+            case MMTG_EPI_TANH: epi_tiles<T, MMTG_EPI_TANH, TM, TN, PFD>(p, acc, mw0, nw0, g, l15, lds, lane); break;
+            case MMTG_EPI_RESID: epi_tiles<T, MMTG_EPI_RESID, TM, TN, PFD>(p, acc, mw0, nw0, g, l15, lds, lane); break;
+            case MMTG_EPI_DGELU: epi_tiles<T, MMTG_EPI_DGELU, TM, TN, PFD>(p, acc, mw0, nw0, g, l15, lds, lane); break;
+            case MMTG_EPI_DTANH: epi_tiles<T, MMTG_EPI_DTANH, TM, TN, PFD>(p, acc, mw0, nw0, g, l15, lds, lane); break;
             case MMTG_EPI_ROWDOT:
-                if constexpr (TN == 4) epi_tiles<T, MMTG_EPI_ROWDOT, TM, TN>(p, acc, mw0, nw0, g, l15, lds, lane);
+                if constexpr (TN == 4) epi_tiles<T, MMTG_EPI_ROWDOT, TM, TN, PFD>(p, acc, mw0, nw0, g, l15, lds, lane);
                 break;
-            default: epi_tiles<T, MMTG_EPI_NONE, TM, TN>(p, acc, mw0, nw0, g, l15, lds, lane); break;
+            default: epi_tiles<T, MMTG_EPI_NONE, TM, TN, PFD>(p, acc, mw0, nw0, g, l15, lds, lane); break;
         }
     }
 }

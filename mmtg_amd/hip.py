@@ -15,6 +15,7 @@ import torch
 F32, BF16 = 0, 1
 EPI_NONE, EPI_GELU, EPI_TANH, EPI_RESID, EPI_DGELU, EPI_DTANH, EPI_ATOMIC, EPI_ROWDOT = range(8)
 GEMM_NO_TR, GEMM_REGSTAGE, GEMM_SKINNY, GEMM_NO_SKINNY, GEMM_WIDE, GEMM_NO_WIDE = 1, 2, 4, 8, 16, 32
+GEMM_PERSIST, GEMM_NO_PERSIST = 64, 128
 PROF_CATS = ["gemm_bf16", "gemm_f32", "attn_fwd", "attn_bwd", "layernorm", "embed", "loss",
              "optim", "encoder", "decode", "misc"]
 
@@ -28,6 +29,7 @@ _SIGS = {
     "mmtg_last_error": ([], C.c_char_p),
     "mmtg_prof_enable": ([_i], _i),
     "mmtg_prof_read": ([_vp, _vp, _vp, _vp], _i),
+    "mmtg_gemm_trace": ([_vp, _i], _i),
     "mmtg_gemm": ([_i, _i, _i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _vp, _i, _vp, _l, _vp, _i, _f, _i, _u, _u, _i, _vp], _i),
     "mmtg_colsum": ([_i, _vp, _l, _i, _i, _vp, _vp], _i),
     "mmtg_layernorm_fwd": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp], _i),
@@ -136,6 +138,11 @@ def prof_read():
 
 
 # ------------------------------------------------------------------ GEMM
+def gemm_trace(buf=None):
+    """Switch the in-kernel timeline of the LDS-DMA GEMMs on (buf: int64 CUDA tensor [max_wgs, 6]) or off."""
+    _check(lib().mmtg_gemm_trace(_p(buf), 0 if buf is None else buf.shape[0]), "gemm_trace")
+
+
 def gemm(A, B, C_, M, N, K, transA=False, transB=False, lda=None, ldb=None, ldc=None, bias=None,
          epi=EPI_NONE, aux=None, ldaux=0, aux2=None, out_f32=False, alpha=1.0, splits=1,
          drop_p=0.0, drop_seed=0, flags=0, dtype=None):

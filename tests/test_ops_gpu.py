@@ -81,6 +81,51 @@ def test_gemm_layouts(dtype, layout, shape, variant):
         close(Cm, ref, dtype, K, "gemm " + layout)
 
 
+@pytest.mark.parametrize("layout", ["NT", "NN", "TN"])
+@pytest.mark.parametrize("K", [64, 200, 4744])
+def test_gemm_persistent_pipeline_matches_plain(layout, K):
+    """More work items than CU slots: the persistent kernel (next item's first K tile prefetched under
+    the last one, epilogue deferred into the next item) must reproduce the one-item-per-workgroup
+    kernel -- bit for bit where the K order is the same (stores), to rounding for the atomics.
+    Ragged M, N and K; K = 64 is the single-K-tile item."""
+    dtype = torch.bfloat16
+    if layout == "TN":
+        M, N, splits = 768, 776, 20
+    else:
+        M, N, splits = 4741, 2120, 1
+    a = rnd(M, K, dtype=dtype, seed=11)
+    b = rnd(K, N, dtype=dtype, seed=12)
+    if layout == "NT":
+        A, B, tA, tB = a, b.t().contiguous(), False, True
+    elif layout == "NN":
+        A, B, tA, tB = a, b, False, False
+    else:
+        A, B, tA, tB = a.t().contiguous(), b, True, False
+    A, B = A.to(DEV), B.to(DEV)
+    outs = []
+    for flags in (hip.GEMM_NO_PERSIST | hip.GEMM_NO_WIDE, hip.GEMM_PERSIST | hip.GEMM_NO_WIDE):
+        if layout == "TN":
+            C = torch.zeros(M, N, device=DEV, dtype=torch.float32)
+            hip.gemm(A, B, C, M, N, K, transA=True, transB=False, epi=hip.EPI_ATOMIC, splits=splits, flags=flags)
+            outs.append((C,))
+        else:
+            bias = rnd(N, seed=13).to(DEV)
+            C = torch.empty(M, N, device=DEV, dtype=dtype)
+            pre = torch.empty(M, N, device=DEV, dtype=dtype)
+            hip.gemm(A, B, C, M, N, K, transA=tA, transB=tB, bias=bias, epi=hip.EPI_GELU, aux2=pre, flags=flags)
+            Cf = torch.empty(M, N, device=DEV, dtype=torch.float32)
+            hip.gemm(A, B, Cf, M, N, K, transA=tA, transB=tB, out_f32=True, flags=flags)
+            outs.append((C, pre, Cf))
+    ref = a.float() @ b.float()
+    if layout == "TN":
+        close(outs[1][0], ref, dtype, K, "persistent TN vs fp32")
+        close(outs[1][0], outs[0][0], torch.float32, K, "persistent TN vs plain")
+    else:
+        close(outs[1][2], ref, dtype, K, "persistent %s vs fp32" % layout)
+        for x, y in zip(outs[0], outs[1]):
+            assert torch.equal(x, y)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_epilogues(dtype):
     M, N, K = 300, 192, 128

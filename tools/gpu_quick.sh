@@ -1,4 +1,6 @@
 #!/bin/bash
-timeout 900 python -m pytest tests/test_ops_gpu.py -m gpu -q --no-header -p no:cacheprovider -k "gemm" 2>&1 | tail -3
-timeout 600 python tools/bench_gemm.py 2>&1 | grep -v amdgpu.ids | grep -v "s=1)" | tail -8
-TNSWEEP=1 timeout 600 python tools/bench_gemm.py 2>&1 | grep -v amdgpu.ids | grep "K=15104 s="
+# scratch: in-kernel timelines, persistent kernel
+mkdir -p gpurun_out
+for args in "15104 3072 768 NT 0 64" "15104 3072 768 NN 1 64" ; do
+  timeout 120 python tools/gemm_timeline.py $args 2>&1 | grep -v amdgpu.ids
+done | tee gpurun_out/gemm_timeline_pp.log
