@@ -55,6 +55,7 @@ enum {
                                  (tile, K split) items, next item prefetched, epilogue deferred into it); opt-in:
                                  measured on par with the plain launch */
 #define MMTG_GEMM_NO_PERSIST 128 /* flags: reserved (the persistent kernel is never picked automatically) */
+#define MMTG_GEMM_ROW_ORDER 256  /* flags: weight gradients keep the tile_n-fastest item order (A/B measurements) */
 
 /* profiling categories (mmtg_prof_*) */
 enum {
@@ -209,6 +210,11 @@ int mmtg_cast_f32_to(int dtype, const float* src, void* dst, long n, void* strea
 int mmtg_cast_pad_rows(int dtype, const float* src, long lds_, void* dst, long ldd, int rows, int cols, void* stream);
 int mmtg_cast_to_f32(int dtype, const void* src, float* dst, long n, void* stream);
 int mmtg_axpy_f32(float* y, const float* x, float a, long n, void* stream);
+/* Batched transpose (bf16 mode keeps K-contiguous [out,in] copies of GPT-2's Conv1D [in,out] weights
+ * so that forward products run in the NT layout): matrix i = [rows, cols] row-major at src + desc[4i]
+ * elements -> [cols, rows] at dst + desc[4i+3]; desc = n x {src_off, rows, cols, dst_off} (long, device);
+ * every offset / extent a multiple of 16 bytes; max_rows / max_cols bound the grid.                    */
+int mmtg_transpose_batch(int dtype, const void* src, void* dst, const long* desc, int n, int max_rows, int max_cols, void* stream);
 
 /* ---------------------------------------------------------------- generation (generate.py:127-141)
  * per row: repetition penalty per occurrence (ids 0 and 102 skipped), /temperature,

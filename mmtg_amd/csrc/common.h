@@ -70,19 +70,38 @@ __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __ex
 
 // Storage-type-aware transcendental helpers: exact libm tanhf in the fp32 parity mode, the
 // v_exp_f32-based form (4 instructions instead of ~25, error << bf16 rounding) for bf16 storage.
+// bf16 storage: v_exp_f32 + v_rcp_f32 (1 ulp each, far below the bf16 rounding of the result) and no
+// IEEE division -- `a / b` alone expands to ~10 instructions (v_div_scale/fmas/fixup), which made
+// the GELU epilogues VALU-bound (6.8 us vs 2.5 us per 128x128 tile, profiles/r01_v4_gemm_timeline.log).
+// gelu_new(x) = x * s,  s = sigmoid(2u) = 1 / (1 + 2^(-2u log2 e)),  u = k (x + a x^3);  saturates
+// cleanly (2^+inf = inf -> rcp = 0; 2^-inf = 0 -> rcp(1) = 1).
+__device__ __forceinline__ float gelu_sigmoid_fast(float x, float x2) {
+    const float c0 = 2.0f * 0.7978845608028654f * 1.4426950408889634f, c1 = c0 * 0.044715f;
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-x * (c0 + c1 * x2)));
+}
 template <typename T> __device__ __forceinline__ float tanh_t(float x) {
-    if constexpr (sizeof(T) == 2) return 1.0f - 2.0f / (1.0f + __expf(2.0f * x));
+    if constexpr (sizeof(T) == 2)
+        return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * (2.0f * 1.4426950408889634f)));
     else return tanhf(x);
 }
 template <typename T> __device__ __forceinline__ float gelu_new_t(float x) {
-    const float k = 0.7978845608028654f;
-    return 0.5f * x * (1.0f + tanh_t<T>(k * (x + 0.044715f * x * x * x)));
+    if constexpr (sizeof(T) == 2) return x * gelu_sigmoid_fast(x, x * x);
+    else {
+        const float k = 0.7978845608028654f;
+        return 0.5f * x * (1.0f + tanhf(k * (x + 0.044715f * x * x * x)));
+    }
 }
 template <typename T> __device__ __forceinline__ float gelu_new_grad_t(float x) {
     const float k = 0.7978845608028654f;
     const float x2 = x * x;
-    const float t = tanh_t<T>(k * (x + 0.044715f * x * x2));
-    return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * k * (1.0f + 3.0f * 0.044715f * x2);
+    if constexpr (sizeof(T) == 2) {
+        // d/dx [x s] = s + x s (1 - s) 2k (1 + 3a x^2)
+        const float s = gelu_sigmoid_fast(x, x2);
+        return s * (1.0f + x * (1.0f - s) * (2.0f * k + (6.0f * k * 0.044715f) * x2));
+    } else {
+        const float t = tanhf(k * (x + 0.044715f * x * x2));
+        return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * k * (1.0f + 3.0f * 0.044715f * x2);
+    }
 }
 
 // ---------------------------------------------------------------- wave reductions (64 lanes)

@@ -531,6 +531,11 @@ int launch_dma_cfg(const GemmArgs& a, int splits, hipStream_t stream) {
     b.tiles_n = cdiv(a.N, BN_);
     b.ntiles = cdiv(a.M, BM_) * b.tiles_n;
     b.nitems = b.ntiles * splits;
+    // Weight gradients (both operands are K slices of activations, fetched from HBM): order the items
+    // so that the run of consecutive items an XCD gets is the squarer block of the tile grid -- with
+    // 6 x 24 tiles and 54 items per XCD, 6 rows x 9 columns (15 operand panels) instead of 2.25 rows x
+    // 24 columns (27 panels).
+    b.tiles_m_fast = AKS && BKS && b.tiles_n > cdiv(a.M, BM_) && !(a.dbg_flags & 1);
     dim3 grid(b.nitems), block(64 * WM * WN);
     hipLaunchKernelGGL((gemm_dma_kernel<AKS, BKS, BM_, BN_, WM, WN, NBUF>), grid, block, shm, stream, b);
     return MMTG_OK;
@@ -624,6 +629,7 @@ extern "C" int mmtg_gemm(int dtype, int transA, int transB, int M, int N, int K,
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldaux = ldaux;
     a.epi = epi; a.out_f32 = out_f32; a.use_tr = !(flags & MMTG_GEMM_NO_TR);
     a.trace = g_trace; a.trace_n = g_trace_n;
+    a.dbg_flags = (flags & MMTG_GEMM_ROW_ORDER) ? 1 : 0;
     a.tiles_n = cdiv(N, BN); a.alpha = alpha;
     // byte extents for the buffer descriptors of the LDS-DMA pipeline (offsets are 32-bit)
     const long esz = dtype == MMTG_F32 ? 4 : 2;

@@ -24,10 +24,12 @@ struct GemmArgs {
     int out_f32;           // C is float regardless of T
     int use_tr;            // bf16 KS fragments via ds_read_b64_tr_b16 (1) or scalar gathers (0)
     int tiles_n;
+    int tiles_m_fast;      // item order inside a K split: tile_m fastest (1) or tile_n fastest (0)
     int ntiles;            // output tiles per K split (grid = ntiles * splits work items)
     int kper;              // K elements per split (multiple of BK)
     int nitems;            // ntiles * splits work items (a persistent launch has fewer workgroups)
     unsigned long long* trace; int trace_n;   // diagnostic timeline (mmtg_gemm_trace) or null
+    int dbg_flags;         // 1: keep the tile_n-fastest item order (MMTG_GEMM_ROW_ORDER, A/B only)
     float alpha;
     uint32_t drop_thresh; uint32_t drop_seed; float drop_inv_keep;
     int bytesA, bytesB;    // operand extents for the LDS-DMA buffer descriptors
@@ -158,8 +160,14 @@ __device__ __forceinline__ void tile_origin(const GemmArgs& p, int bid, int nwg,
     const int v = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
     split = v / p.ntiles;
     const int t = v - split * p.ntiles;
-    m0 = (t / p.tiles_n) * bm;
-    n0 = (t % p.tiles_n) * bn;
+    if (p.tiles_m_fast) {       // tile_m fastest: an XCD's run is (all tile rows) x (a few tile columns)
+        const int tm = p.ntiles / p.tiles_n;
+        m0 = (t % tm) * bm;
+        n0 = (t / tm) * bn;
+    } else {
+        m0 = (t / p.tiles_n) * bm;
+        n0 = (t % p.tiles_n) * bn;
+    }
 }
 
 // Per-lane byte offsets of the transposed-read fragments of a K-strided bf16 operand, hoisted out of

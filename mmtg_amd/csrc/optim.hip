@@ -60,6 +60,43 @@ __global__ __launch_bounds__(256) void axpy_kernel(float* __restrict__ y, const 
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] += a * x[i];
 }
 
+// Batched matrix transpose (weight-copy maintenance): matrix i is [rows, cols] row-major at
+// src + desc[4i], written as [cols, rows] at dst + desc[4i+3].  One 64x64 tile per workgroup through
+// a padded LDS image; 16-byte global vectors on both sides (rows, cols multiples of 16/sizeof(T)).
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_batch_kernel(const T* __restrict__ src, T* __restrict__ dst,
+                                                              const long* __restrict__ desc) {
+    typedef typename Vec16<T>::type V;
+    constexpr int EPC = Vec16<T>::N, CPR = 64 / EPC, RPP = 256 / CPR;   // chunks per tile row, rows per pass
+    constexpr int LDT = 64 + EPC;                                         // padded LDS row (16-byte multiple)
+    __shared__ __attribute__((aligned(16))) T tile[64 * LDT];
+    const long* d = desc + 4 * blockIdx.y;
+    const long so = d[0], dof = d[3];
+    const int rows = (int)d[1], cols = (int)d[2];
+    const int tc = (cols + 63) >> 6, tr = (rows + 63) >> 6;
+    if ((int)blockIdx.x >= tr * tc) return;
+    const int r0 = ((int)blockIdx.x / tc) * 64, c0 = ((int)blockIdx.x % tc) * 64;
+    const int tid = threadIdx.x, ch = tid % CPR, rr = tid / CPR;
+#pragma unroll
+    for (int ps = 0; ps < 64 / RPP; ++ps) {
+        const int r = rr + ps * RPP;
+        V v;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) v[e] = (T)0.0f;
+        if (r0 + r < rows && c0 + ch * EPC < cols) v = *reinterpret_cast<const V*>(src + so + (long)(r0 + r) * cols + c0 + ch * EPC);
+        *reinterpret_cast<V*>(tile + r * LDT + ch * EPC) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ps = 0; ps < 64 / RPP; ++ps) {
+        const int j = rr + ps * RPP;          // source column = destination row
+        V v;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) v[e] = tile[(ch * EPC + e) * LDT + j];
+        if (c0 + j < cols && r0 + ch * EPC < rows) *reinterpret_cast<V*>(dst + dof + (long)(c0 + j) * rows + r0 + ch * EPC) = v;
+    }
+}
+
 inline unsigned grid_for(long n) { return (unsigned)min((long)2048, (n + 255) / 256); }
 
 }  // namespace
@@ -127,5 +164,18 @@ extern "C" int mmtg_axpy_f32(float* y, const float* x, float a, long n, void* st
     ProfScope prof(MMTG_PROF_MISC, s, 2.0 * n, 12.0 * n);
     hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n)), dim3(256), 0, s, y, x, a, n);
     MMTG_LAUNCH_CHECK("axpy");
+    return MMTG_OK;
+}
+
+extern "C" int mmtg_transpose_batch(int dtype, const void* src, void* dst, const long* desc, int n, int max_rows, int max_cols, void* stream) {
+    MMTG_REQUIRE(src && dst && desc && n > 0 && max_rows > 0 && max_cols > 0, "transpose_batch: bad args");
+    MMTG_REQUIRE(MMTG_ALIGNED16(src) && MMTG_ALIGNED16(dst), "transpose_batch: 16-byte aligned buffers required");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(MMTG_PROF_MISC, s, 0, 0);
+    dim3 grid(cdiv(max_rows, 64) * cdiv(max_cols, 64), n);
+    if (dtype == MMTG_BF16) hipLaunchKernelGGL(transpose_batch_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)src, (bf16*)dst, desc);
+    else if (dtype == MMTG_F32) hipLaunchKernelGGL(transpose_batch_kernel<float>, grid, dim3(256), 0, s, (const float*)src, (float*)dst, desc);
+    else MMTG_FAIL(MMTG_ERR_BAD_ARG, "transpose_batch: bad dtype");
+    MMTG_LAUNCH_CHECK("transpose_batch");
     return MMTG_OK;
 }

@@ -51,34 +51,11 @@ class GreedyDecoder:
         self.logits = torch.empty(B, self.eng.layout.Vpad, dtype=torch.float32, device=dev)
         self.graphs = {}
         self.params = None
-        self.wT = {}
-
-    def _refresh_transposed(self):
-        """bf16 mode: K-contiguous ([out,in]) copies of the Conv1D ([in,out]) weights, so every decode
-        product is the NT layout the 256x32 small-M GEMM configuration serves (one 170 MB transpose per
-        generate() call; weights do not change while decoding)."""
-        eng = self.eng
-        if eng.dtype == hip.F32:
-            return
-        eng.refresh_copies()
-        pre = "decoder.gpt2.transformer."
-        for l in range(eng.sh.L):
-            for nm in ("attn.c_attn", "attn.c_proj", "mlp.c_fc", "mlp.c_proj"):
-                key = f"{pre}h.{l}.{nm}.weight"
-                src = eng.W(key)
-                dst = self.wT.get(key)
-                if dst is None:
-                    dst = self.wT[key] = torch.empty(src.shape[1], src.shape[0], dtype=src.dtype, device=src.device)
-                dst.copy_(src.t())
 
     def _conv1d(self, x, wkey, out, **kw):
-        eng, B = self.eng, self.B
-        wt = self.wT.get(wkey)
-        if wt is None:
-            eng._fwd(x, wkey, out, B, "conv1d", **kw)
-        else:
-            N, K = wt.shape
-            hip.gemm(x, wt, out, B, N, K, transB=True, ldb=K, **kw)
+        # bf16: Engine._fwd routes Conv1D weights through their [out,in] copies (NT layout), which is
+        # what the 256x32 small-M GEMM configuration serves; the engine keeps the copies fresh.
+        self.eng._fwd(x, wkey, out, self.B, "conv1d", **kw)
 
     # ------------------------------------------------------------------ one token
     def _step(self, with_head):
@@ -149,7 +126,7 @@ class GreedyDecoder:
             raise ValueError("length %d exceeds max_len %d" % (length, self.max_len))
         self.params = (float(temperature), float(repitition_penalty))
         eng.invalidate_copies()
-        self._refresh_transposed()
+        self.eng.refresh_copies()
         a = eng.forward(batch, train_flag=False, training=False, encode_only=True)
         self.c.copy_(a["c"])
         self.seq.zero_()

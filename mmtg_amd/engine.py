@@ -194,6 +194,7 @@ class Engine:
         self.grad = None
         self.wc = master if dtype == hip.F32 else torch.zeros(self.layout.total, device=self.dev, dtype=torch.bfloat16)
         self.copies_fresh = dtype == hip.F32
+        self._init_transposed()
         self.set_table(table)
         self.prior = torch.from_numpy(gaussian_prior(self.sh.S)).to(self.dev)
         self.ws = {}
@@ -255,11 +256,42 @@ class Engine:
         self.ensure_grad()
         self.grad.zero_()
 
+    def _init_transposed(self):
+        """bf16 mode: K-contiguous [out,in] copies of GPT-2's Conv1D [in,out] weights.  With them every
+        forward product is the NT layout (both operands K-contiguous in LDS, one ds_read_b128 per
+        fragment); the NN layout reads its K-strided weights with two transposed 8-byte LDS reads per
+        fragment and measured 5-15 % slower per product (profiles/r01_v4_gemm_per_shape.log)."""
+        self.wt = None
+        self.wt_entries = {}
+        if self.dtype == hip.F32:
+            return
+        pre, desc, off = "decoder.gpt2.transformer.", [], 0
+        for l in range(self.sh.L):
+            for nm in ("attn.c_attn", "attn.c_proj", "mlp.c_fc", "mlp.c_proj"):
+                key = "%sh.%d.%s.weight" % (pre, l, nm)
+                soff, shape, n = self.layout.entries[key]
+                assert soff % 8 == 0 and shape[0] % 8 == 0 and shape[1] % 8 == 0
+                desc.append((soff, shape[0], shape[1], off))
+                self.wt_entries[key] = (off, (shape[1], shape[0]), n)
+                off += n
+        self.wt = torch.zeros(off, device=self.dev, dtype=torch.bfloat16)
+        self.wt_desc = torch.tensor(desc, dtype=torch.int64, device=self.dev)
+        self.wt_max = (max(d[1] for d in desc), max(d[2] for d in desc))
+
+    def Wt(self, key):   # [out, in] copy of a Conv1D weight (bf16 mode)
+        off, shape, n = self.wt_entries[key]
+        return self.wt[off:off + n].view(shape)
+
+    def _refresh_transposed(self):
+        if self.wt is not None:
+            hip.transpose_batch(self.wc, self.wt, self.wt_desc, self.wt_desc.shape[0], *self.wt_max)
+
     def refresh_copies(self):
         """bf16 mode: re-derive the GEMM weight copies from the fp32 masters (an
         external optimizer may have updated them).  654 MB of traffic, ~0.15 ms."""
         if self.dtype != hip.F32 and not self.copies_fresh:
             hip.cast_f32_to(self.master, self.wc, self.layout.total)
+            self._refresh_transposed()
             self.copies_fresh = True
 
     def invalidate_copies(self):
@@ -273,6 +305,9 @@ class Engine:
         if kind == "linear":
             N, K = w.shape
             hip.gemm(x, w, out, M, N, K, transB=True, lda=lda, ldb=K, bias=bias, **kw)
+        elif wkey in self.wt_entries:   # bf16: the [out,in] copy -> NT layout
+            K, N = w.shape
+            hip.gemm(x, self.Wt(wkey), out, M, N, K, transB=True, lda=lda, ldb=K, bias=bias, **kw)
         else:
             K, N = w.shape
             hip.gemm(x, w, out, M, N, K, transB=False, lda=lda, ldb=N, bias=bias, **kw)
@@ -674,4 +709,5 @@ class Engine:
         ns = self.grad_norm_sq() if clip else None
         hip.adamw(self.master, self.grad, self.opt_m, self.opt_v, None if self.dtype == hip.F32 else self.wc,
                   self.layout.total, lr, betas[0], betas[1], eps, wd, self.step_count, ns, max_norm, grad_scale)
+        self._refresh_transposed()
         self.copies_fresh = True

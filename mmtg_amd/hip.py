@@ -56,6 +56,7 @@ _SIGS = {
     "mmtg_cast_pad_rows": ([_i, _vp, _l, _vp, _l, _i, _i, _vp], _i),
     "mmtg_cast_to_f32": ([_i, _vp, _vp, _l, _vp], _i),
     "mmtg_axpy_f32": ([_vp, _vp, _f, _l, _vp], _i),
+    "mmtg_transpose_batch": ([_i, _vp, _vp, _vp, _i, _i, _i, _vp], _i),
     "mmtg_logits_process_argmax": ([_vp, _l, _i, _vp, _l, _vp, _f, _f, _vp, _i, _vp], _i),
     "mmtg_decode_embed": ([_i, _vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
     "mmtg_decode_embed_add": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp], _i),
@@ -295,6 +296,11 @@ def cast_to_f32(src, dst, n):
 
 def axpy_f32(y, x, a, n):
     _check(lib().mmtg_axpy_f32(_p(y), _p(x), float(a), n, _stream()), "axpy_f32")
+
+
+def transpose_batch(src, dst, desc, n, max_rows, max_cols):
+    """Matrix i ([rows, cols] at src + desc[i,0]) -> [cols, rows] at dst + desc[i,3]; desc: int64 CUDA [n,4]."""
+    _check(lib().mmtg_transpose_batch(dt(src), _p(src), _p(dst), _p(desc), n, max_rows, max_cols, _stream()), "transpose_batch")
 
 
 # ------------------------------------------------------------------ generation

@@ -589,6 +589,22 @@ def test_adamw_clip_and_casts():
     close(a, ref, torch.float32, 1, "axpy")
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_transpose_batch(dtype):
+    """Batched weight transpose (the [out,in] copies of Conv1D weights): exact, ragged 64x64 tiles."""
+    shapes = [(768, 2304), (72, 40), (3072, 768), (8, 200)]
+    offs, total = [], 0
+    for r, c in shapes:
+        offs.append(total)
+        total += r * c
+    src = rnd(total, dtype=dtype, seed=21).to(DEV)
+    dst = torch.zeros(total, dtype=dtype, device=DEV)
+    desc = torch.tensor([[o, r, c, o] for o, (r, c) in zip(offs, shapes)], dtype=torch.int64, device=DEV)
+    hip.transpose_batch(src, dst, desc, len(shapes), max(r for r, _ in shapes), max(c for _, c in shapes))
+    for o, (r, c) in zip(offs, shapes):
+        assert torch.equal(dst[o:o + r * c].view(c, r), src[o:o + r * c].view(r, c).t())
+
+
 # ------------------------------------------------------------------ generation
 def test_logits_process_argmax():
     B, V, G = 6, 500, 40

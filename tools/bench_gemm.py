@@ -12,7 +12,18 @@ dt = torch.bfloat16 if os.environ.get("DT", "bf16") == "bf16" else torch.float32
 
 def t(*s): return (torch.randn(*s, device=dev) * 0.5).to(dt)
 
+COLD = bool(os.environ.get("COLD"))
+_flush = torch.empty(1 << 28, device=dev, dtype=torch.float32) if COLD else None   # 1 GiB > L2 + MALL
+
 def timeit(fn, n=20):
+    if COLD:   # every launch behind a 1 GiB fill: operands come from HBM, as inside a training step
+        tot = 0.0
+        for _ in range(8):
+            _flush.fill_(1.0)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); fn(); b.record(); torch.cuda.synchronize()
+            tot += a.elapsed_time(b)
+        return tot / 8 * 1e3
     for _ in range(3): fn()
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -1,6 +1,5 @@
 #!/bin/bash
-# scratch: in-kernel timelines, persistent kernel
+# scratch: 256x128 tiles with a 3-deep ring, warm and HBM-cold
 mkdir -p gpurun_out
-for args in "15104 3072 768 NT 0 64" "15104 3072 768 NN 1 64" ; do
-  timeout 120 python tools/gemm_timeline.py $args 2>&1 | grep -v amdgpu.ids
-done | tee gpurun_out/gemm_timeline_pp.log
+echo "=== warm 256x128x3 (flags=512)"; FLAGS=512 timeout 600 python tools/bench_gemm.py 2>&1 | grep -v "amdgpu.ids\|s=1)"
+echo "=== cold 256x128x3 (flags=512)"; COLD=1 FLAGS=512 timeout 600 python tools/bench_gemm.py 2>&1 | grep -v "amdgpu.ids\|s=1)"
