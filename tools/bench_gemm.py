@@ -61,6 +61,9 @@ if os.environ.get("PMC"):
     once("NT", M, D, 4 * D, False, True)
     once("NN", M, D, 4 * D, False, False)
     once("TN", 4 * D, D, M, True, False, hip.EPI_ATOMIC, 3)
+    once("TN fc1", D, 4 * D, M, True, False, hip.EPI_ATOMIC, 3)
+    FLAGS = 256   # tile_n-fastest item order
+    once("TN fc1 row order", D, 4 * D, M, True, False, hip.EPI_ATOMIC, 3)
     sys.exit(0)
 if os.environ.get("TNSWEEP"):
     for K in (64, 256, 1024, 4096, 15104):
