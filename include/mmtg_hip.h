@@ -37,7 +37,8 @@ enum {
     MMTG_EPI_GELU = 1,   /* aux2 = acc + bias ; C = gelu_new(aux2)            */
     MMTG_EPI_TANH = 2,   /* C = tanh(acc + bias)                              */
     MMTG_EPI_RESID = 3,  /* C = dropout(acc + bias) + aux                     */
-    MMTG_EPI_DGELU = 4,  /* C = acc * gelu_new'(aux)                          */
+    MMTG_EPI_DGELU = 4,  /* C = acc * gelu_new'(aux) ; optional aux2 (f32 [N]) += column sums of C
+                            (the c_fc bias gradient, fused into the product that yields d pre-activation) */
     MMTG_EPI_DTANH = 5,  /* C = acc * (1 - aux^2)                             */
     MMTG_EPI_ATOMIC = 6, /* C(f32) += alpha * acc  (atomics; split-K allowed) */
     MMTG_EPI_ROWDOT = 7  /* C = acc ; aux2(f32)[m, n/64] = sum over each 64-column group of C * aux
@@ -123,9 +124,10 @@ int mmtg_attn_fwd(int dtype, const void* qkv, const int* keep, void* out, float*
 /* delta: [B*T, nH] f32, delta[m,h] = sum_d dout[m,h,d] * out[m,h,d]: computed by the call, or --
  * delta_ready != 0 -- already filled by the caller (the GEMM producing dout with
  * MMTG_EPI_ROWDOT does it for free); dq32: [B*T, D] f32 scratch (zeroed by the call);
- * dqkv: [B*T, 3*D] output.                                                    */
+ * dqkv: [B*T, 3*D] output; dbias (optional): f32 [3*D] += column sums of dqkv as stored (the
+ * c_attn bias gradient, accumulated by the workgroups that produce each head's columns).          */
 int mmtg_attn_bwd(int dtype, const void* qkv, const int* keep, const void* out, const void* dout,
-                  const float* lse, float* delta, int delta_ready, float* dq32, void* dqkv,
+                  const float* lse, float* delta, int delta_ready, float* dq32, void* dqkv, float* dbias,
                   int B, int T, int nH, int dh, unsigned drop_thresh, unsigned drop_seed, void* stream);
 
 /* ---------------------------------------------------------------- conditioning front end

@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void attn_dq_finish_kernel(const float* __rest
 template <typename T, int NW>
 __global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(const T* __restrict__ qkv, const int* __restrict__ keep,
         const T* __restrict__ d_out, const float* __restrict__ lse, const float* __restrict__ delta,
-        float* __restrict__ dq32, T* __restrict__ dqkv, int Tn, int nH, int direct_dq,
+        float* __restrict__ dq32, T* __restrict__ dqkv, float* __restrict__ dbias, int Tn, int nH, int direct_dq,
         uint32_t drop_thresh, uint32_t drop_seed, float inv_keep, int ablate) {
     typedef typename Vec16<T>::type V;
     typedef AT<T> A;
@@ -280,6 +280,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(const T* __restrict__
 
     const int kw0 = KPW * wave;  // this wave's first key (block-local)
     const int nqt = (Tn + 31) / 32;
+    float dq_cs = 0.f;           // column sum (over queries) of this lane's dQ column, as stored
     for (int qt = kb0 / 32; qt < nqt; ++qt) {
         const int q0 = qt * 32;
         __syncthreads();
@@ -382,8 +383,10 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(const T* __restrict__
                 for (int r = 0; r < 4; ++r) {
                     const int q = q0 + qs * 16 + 4 * g + r;
                     if (q < Tn) {
-                        if (direct_dq) dqkv[((long)b * Tn + q) * ld + h * DH + dt * 16 + l15] = (T)acc[r];
-                        else atomicAdd(dq32 + ((long)b * Tn + q) * D + h * DH + dt * 16 + l15, acc[r]);
+                        if (direct_dq) {
+                            dqkv[((long)b * Tn + q) * ld + h * DH + dt * 16 + l15] = (T)acc[r];
+                            dq_cs += (float)(T)acc[r];
+                        } else atomicAdd(dq32 + ((long)b * Tn + q) * D + h * DH + dt * 16 + l15, acc[r]);
                     }
                 }
             }
@@ -405,6 +408,44 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(const T* __restrict__
                 *reinterpret_cast<T4*>(dst + 2 * D + dt * 16 + 4 * g) = vv;
             }
         }
+    }
+
+    // c_attn bias gradient = column sums of d(qkv) over all tokens, of the values as stored: this
+    // workgroup's share is head h's 64 columns of the q, k and v parts (saves a pass over [B*T, 3D]).
+    // The waves' partial sums are combined in LDS first: one global atomic per column per workgroup
+    // (per-wave global atomics -- 512 adds per address, all at the end of the launch -- cost +36 us).
+    if (dbias) {
+        float* sB = reinterpret_cast<float*>(smem);      // [3][64], overlays the K image
+        __syncthreads();                                  // every wave is done with the staged tiles
+        if (tid < 3 * DH) sB[tid] = 0.f;
+        __syncthreads();
+        if (direct_dq) {         // lane: column (wave & 3) * 16 + l15, rows 4g + r of its query sub-tiles
+            dq_cs += __shfl_xor(dq_cs, 16, 64);
+            dq_cs += __shfl_xor(dq_cs, 32, 64);
+            if (g == 0) atomicAdd(sB + (wave & 3) * 16 + l15, dq_cs);
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            float sk[4] = {0.f, 0.f, 0.f, 0.f}, sv[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) {
+                if (kb0 + kw0 + kt * 16 + l15 < Tn) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { sk[r] += (float)(T)dk_acc[dt][kt][r]; sv[r] += (float)(T)dv_acc[dt][kt][r]; }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { sk[r] += __shfl_xor(sk[r], o, 64); sv[r] += __shfl_xor(sv[r], o, 64); }
+                if (l15 == 0) {
+                    atomicAdd(sB + DH + dt * 16 + 4 * g + r, sk[r]);
+                    atomicAdd(sB + 2 * DH + dt * 16 + 4 * g + r, sv[r]);
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < 3 * DH && (direct_dq || tid >= DH)) atomicAdd(dbias + (tid / DH) * D + h * DH + tid % DH, sB[tid]);
     }
 }
 
@@ -441,8 +482,10 @@ extern "C" int mmtg_attn_fwd(int dtype, const void* qkv, const int* keep, void* 
     return MMTG_OK;
 }
 
+extern "C" int mmtg_colsum(int dtype, const void* X, long ldx, int M, int N, float* out, void* stream);
+
 extern "C" int mmtg_attn_bwd(int dtype, const void* qkv, const int* keep, const void* out, const void* dout,
-                             const float* lse, float* delta, int delta_ready, float* dq32, void* dqkv,
+                             const float* lse, float* delta, int delta_ready, float* dq32, void* dqkv, float* dbias,
                              int B, int T, int nH, int dh, unsigned drop_thresh, unsigned drop_seed, void* stream) {
     MMTG_REQUIRE(dh == DH, "attn_bwd: head dim %d unsupported (built for 64)", dh);
     MMTG_REQUIRE(B > 0 && T > 0 && nH > 0, "attn_bwd: bad sizes");
@@ -467,7 +510,7 @@ extern "C" int mmtg_attn_bwd(int dtype, const void* qkv, const int* keep, const 
         }
         if (!delta_ready) hipLaunchKernelGGL(attn_delta_kernel<float>, dim3(cdiv(rows * nH, 4)), dim3(256), 0, s, (const float*)out, (const float*)dout, delta, T, nH, rows);
         if (nkb > 1) { if (hipMemsetAsync(dq32, 0, rows * D * sizeof(float), s) != hipSuccess) MMTG_FAIL(MMTG_ERR_HIP, "attn_bwd: memset failed"); }
-        hipLaunchKernelGGL((attn_bwd_kernel<float, 4>), dim3(nkb, nH, B), dim3(256), shm, s, (const float*)qkv, keep, (const float*)dout, lse, delta, dq32, (float*)dqkv, T, nH, nkb == 1, drop_thresh, drop_seed, ik, ablate);
+        hipLaunchKernelGGL((attn_bwd_kernel<float, 4>), dim3(nkb, nH, B), dim3(256), shm, s, (const float*)qkv, keep, (const float*)dout, lse, delta, dq32, (float*)dqkv, dbias, T, nH, nkb == 1, drop_thresh, drop_seed, ik, ablate);
         if (nkb > 1) hipLaunchKernelGGL(attn_dq_finish_kernel<float>, dim3(2048), dim3(256), 0, s, dq32, (float*)dqkv, rows, D);
     } else if (dtype == MMTG_BF16) {
         const int KB = 4 * AT<bf16>::KPW;
@@ -480,9 +523,12 @@ extern "C" int mmtg_attn_bwd(int dtype, const void* qkv, const int* keep, const 
         }
         if (!delta_ready) hipLaunchKernelGGL(attn_delta_kernel<bf16>, dim3(cdiv(rows * nH, 4)), dim3(256), 0, s, (const bf16*)out, (const bf16*)dout, delta, T, nH, rows);
         if (nkb > 1) { if (hipMemsetAsync(dq32, 0, rows * D * sizeof(float), s) != hipSuccess) MMTG_FAIL(MMTG_ERR_HIP, "attn_bwd: memset failed"); }
-        hipLaunchKernelGGL((attn_bwd_kernel<bf16, 8>), dim3(nkb, nH, B), dim3(512), shm, s, (const bf16*)qkv, keep, (const bf16*)dout, lse, delta, dq32, (bf16*)dqkv, T, nH, nkb == 1, drop_thresh, drop_seed, ik, ablate);
+        hipLaunchKernelGGL((attn_bwd_kernel<bf16, 8>), dim3(nkb, nH, B), dim3(512), shm, s, (const bf16*)qkv, keep, (const bf16*)dout, lse, delta, dq32, (bf16*)dqkv, dbias, T, nH, nkb == 1, drop_thresh, drop_seed, ik, ablate);
         if (nkb > 1) hipLaunchKernelGGL(attn_dq_finish_kernel<bf16>, dim3(2048), dim3(256), 0, s, dq32, (bf16*)dqkv, rows, D);
     } else MMTG_FAIL(MMTG_ERR_BAD_ARG, "attn_bwd: bad dtype");
     MMTG_LAUNCH_CHECK("attn_bwd");
+    // several key blocks per head: dQ went through the fp32 atomics + finish pass; sum its columns here
+    if (dbias && cdiv(T, dtype == MMTG_F32 ? 4 * AT<float>::KPW : 4 * AT<bf16>::KPW) > 1)
+        return mmtg_colsum(dtype, dqkv, 3L * D, (int)rows, D, dbias, stream);
     return MMTG_OK;
 }

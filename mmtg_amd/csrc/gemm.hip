@@ -664,6 +664,10 @@ extern "C" int mmtg_gemm(int dtype, int transA, int transB, int M, int N, int K,
             const long t128 = (long)cdiv(M, 128) * cdiv(N, 128), t192 = (long)cdiv(M, 192) * cdiv(N, 128);
             wide = (t128 > 512 && t192 <= 512) || N >= 4096;
         }
+        if (epi == MMTG_EPI_DGELU && aux2) {   // the fused column sums are not built into the 6-wave kernel
+            MMTG_REQUIRE(!(flags & MMTG_GEMM_WIDE), "gemm: DGELU with column sums (aux2) has no 192x128 configuration");
+            wide = false;
+        }
         // The persistent pipelined kernel is opt-in: with more 128x128 items than CU slots it measured
         // within +-3 % of the plain launch (its deferred epilogue still occupies the wave for 2.8-7 us per
         // item; timelines in profiles/r01_v4_gemm_timeline.log).

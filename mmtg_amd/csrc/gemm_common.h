@@ -288,6 +288,10 @@ __device__ __forceinline__ void epi_tiles(const GemmArgs& p, f32x4 (&acc)[TM][TN
 #pragma unroll
         for (int hb = 0; hb < RING - 1; ++hb) { EPI_LOAD_BAND(hb) }
     }
+    // DGELU: column sums of this lane's 8 columns (not in the register-capped 6-wave configuration,
+    // PFD < TM, which the host never picks for a DGELU product with aux2)
+    constexpr bool COLSUM = EPI == MMTG_EPI_DGELU && PFD >= TM;
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int h = 0; h < TM; ++h) {
         if constexpr (HAS_AUX) {
@@ -331,7 +335,10 @@ __device__ __forceinline__ void epi_tiles(const GemmArgs& p, f32x4 (&acc)[TM][TN
                 for (int e = 0; e < 8; ++e) v[e] += a8[e];
             } else if constexpr (EPI == MMTG_EPI_DGELU) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] *= gelu_new_grad_t<T>(a8[e]);
+                for (int e = 0; e < 8; ++e) {
+                    v[e] *= gelu_new_grad_t<T>(a8[e]);
+                    if constexpr (COLSUM) cs[e] += (float)(T)v[e];      // column sums of the output as stored
+                }
             } else if constexpr (EPI == MMTG_EPI_DTANH) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] *= (1.0f - a8[e] * a8[e]);
@@ -349,6 +356,23 @@ __device__ __forceinline__ void epi_tiles(const GemmArgs& p, f32x4 (&acc)[TM][TN
             }
             if (p.out_f32) store8<float>(reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n, v);
             else store8<T>(reinterpret_cast<T*>(p.C) + (long)m * p.ldc + n, v);
+        }
+    }
+    if constexpr (COLSUM) {
+        // aux2 (optional): f32 [N] += column sums of the output = the bias gradient of the layer whose
+        // pre-activation gradient this product computes (saves a separate pass over the [M,N] result).
+        // Lanes with equal lane % LPR hold the same 8 columns for different rows: fold them, then the
+        // first LPR lanes add the wave tile's 8 x LPR column sums.
+        if (p.aux2) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+#pragma unroll
+                for (int o = LPR; o < 64; o <<= 1) cs[e] += __shfl_xor(cs[e], o, 64);
+            }
+            if (lane < LPR && nok) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) atomicAdd(reinterpret_cast<float*>(p.aux2) + n + e, cs[e]);
+            }
         }
     }
 }

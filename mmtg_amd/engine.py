@@ -588,10 +588,12 @@ class Engine:
             (xin, mu1, rs1, a1, qkv, ctx, lse, xmid, mu2, rs2, m2, u, gact, s) = a["layers"][l]
             # x_out = x_mid + drop(gact W2 + b2): dy = dx * mask (already produced, with its bias gradient)
             dy = dmask if pr > 0 else dx
-            self._dgrad(dy, p + "mlp.c_proj.weight", du, M, "conv1d", epi=hip.EPI_DGELU, aux=u, ldaux=4 * D)
+            # (the dGELU epilogue also accumulates the column sums of du = the c_fc bias gradient)
+            self._dgrad(dy, p + "mlp.c_proj.weight", du, M, "conv1d", epi=hip.EPI_DGELU, aux=u, ldaux=4 * D,
+                        aux2=self.G(p + "mlp.c_fc.bias"))
             self._wgrad(gact, dy, p + "mlp.c_proj.weight", None, M, "conv1d")
             self._dgrad(du, p + "mlp.c_fc.weight", dm, M, "conv1d")
-            self._wgrad(m2, du, p + "mlp.c_fc.weight", p + "mlp.c_fc.bias", M, "conv1d")
+            self._wgrad(m2, du, p + "mlp.c_fc.weight", None, M, "conv1d")
             hip.layernorm_bwd(dm, xmid, self.P(p + "ln_2.weight"), mu2, rs2, dx, dx2,
                               self.G(p + "ln_2.weight"), self.G(p + "ln_2.bias"), M, D,
                               dx_masked=dmask, drop_p=pr, drop_seed=s + 1,
@@ -606,9 +608,9 @@ class Engine:
                 self._dgrad(dy, p + "attn.c_proj.weight", dctx, M, "conv1d")
             self._wgrad(ctx, dy, p + "attn.c_proj.weight", None, M, "conv1d")
             hip.attn_bwd(qkv, a["keep"], ctx, dctx, lse, delta, dq32, dqkv, B, T, sh.nH, D // sh.nH,
-                         drop_p=pa, drop_seed=s, delta_ready=fuse_delta)
+                         drop_p=pa, drop_seed=s, delta_ready=fuse_delta, dbias=self.G(p + "attn.c_attn.bias"))
             self._dgrad(dqkv, p + "attn.c_attn.weight", da, M, "conv1d")
-            self._wgrad(a1, dqkv, p + "attn.c_attn.weight", p + "attn.c_attn.bias", M, "conv1d")
+            self._wgrad(a1, dqkv, p + "attn.c_attn.weight", None, M, "conv1d")
             if l > 0:
                 hip.layernorm_bwd(da, xin, self.P(p + "ln_1.weight"), mu1, rs1, dx2, dx,
                                   self.G(p + "ln_1.weight"), self.G(p + "ln_1.bias"), M, D,

@@ -155,6 +155,10 @@ def test_gemm_epilogues(dtype):
     x = aux.float().requires_grad_(True)
     O.gelu_new(x).sum().backward()
     close(run(hip.EPI_DGELU, aux=aux), acc * x.grad, dtype, K, "dgelu")
+    # ... with the fused column sums of the stored output (the c_fc bias gradient), accumulated (+=)
+    cs = torch.full((N,), 0.25, device=DEV, dtype=torch.float32)
+    dg = run(hip.EPI_DGELU, aux=aux, aux2=cs)
+    close(cs, 0.25 + dg.float().sum(0), torch.float32, M, "dgelu column sums")
     close(run(hip.EPI_DTANH, aux=aux), acc * (1 - aux.float() ** 2), dtype, K, "dtanh")
     # fused dropout: deterministic mask, ~p zeros, survivors scaled by 1/(1-p)
     zero = torch.zeros(M, N, device=DEV, dtype=dtype)
@@ -319,11 +323,14 @@ def test_attention(dtype, T):
     delta = torch.empty(B * T, nH, device=DEV)
     dq32 = torch.empty(B * T, D, device=DEV)
     dqkv = torch.full((B, T, 3 * D), float("nan"), device=DEV, dtype=dtype)
-    hip.attn_bwd(qd, kd, out, dout.to(DEV), lse, delta, dq32, dqkv, B, T, nH, dh)
+    dbias = torch.full((3 * D,), 0.5, device=DEV, dtype=torch.float32)
+    hip.attn_bwd(qd, kd, out, dout.to(DEV), lse, delta, dq32, dqkv, B, T, nH, dh, dbias=dbias)
     g = qr.grad
     for i, nm in enumerate("qkv"):
         close(dqkv[..., i * D:(i + 1) * D], g[..., i * D:(i + 1) * D], dtype, 64, "attn d" + nm,
               scale=float(g.abs().max()))
+    # fused c_attn bias gradient: += column sums over all tokens of d(qkv) as stored
+    close(dbias, 0.5 + dqkv.float().sum((0, 1)), torch.float32, B * T, "attn fused d(bias)")
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -1,5 +1,6 @@
 #!/bin/bash
-# scratch: 256x128 tiles with a 3-deep ring, warm and HBM-cold
+# scratch: fused bias gradients (dGELU epilogue, attention backward)
 mkdir -p gpurun_out
-echo "=== warm 256x128x3 (flags=512)"; FLAGS=512 timeout 600 python tools/bench_gemm.py 2>&1 | grep -v "amdgpu.ids\|s=1)"
-echo "=== cold 256x128x3 (flags=512)"; COLD=1 FLAGS=512 timeout 600 python tools/bench_gemm.py 2>&1 | grep -v "amdgpu.ids\|s=1)"
+timeout 900 python -m pytest tests/test_ops_gpu.py -m gpu -q --no-header -p no:cacheprovider -k "gemm_epilogues or attention" 2>&1 | tail -3
+timeout 1200 python -m pytest tests/test_model_gpu.py -m gpu -q --no-header -p no:cacheprovider 2>&1 | tail -3
+timeout 900 python bench.py --no-cpu-baseline 2>&1 | tail -1 | cut -c1-1400
