@@ -2,6 +2,7 @@
 // One 64-lane wave per row, 4 elements per lane per step (8 B bf16 / 16 B f32
 // coalesced vectors), statistics in fp32 via wave shuffles.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -170,6 +171,124 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     }
 }
 
+// v2 of the streaming part: a HALF-wave per row with 16-byte vectors (lane hl of the half owns the
+// chunks hl, hl+32, ... of the row: 512 contiguous bytes per load instruction and half), so a wave
+// has two rows in flight and every access is a full dwordx4.  Same partial-row workspace and
+// finalize kernel as v1.  NC = chunks per lane (cols <= 32 * NC * 16/sizeof(T)).
+template <typename T, int NC>
+__global__ __launch_bounds__(256) void ln_bwd2_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                      const float* __restrict__ rstd, const T* __restrict__ dres,
+                                                      T* __restrict__ dx, T* __restrict__ dxm, float* __restrict__ ws,
+                                                      int rows, int cols, int want_colsum,
+                                                      uint32_t thresh, uint32_t seed, float inv_keep) {
+    typedef typename Vec16<T>::type V;
+    constexpr int EPC = Vec16<T>::N;
+    __shared__ float sred[4][1024];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane & 31, half = lane >> 5;
+    const int nch = cols / EPC;
+    float gm[NC][EPC], ag[NC][EPC], ab[NC][EPC], ac[NC][EPC];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int ch = hl + 32 * i;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) { ag[i][e] = 0.f; ab[i][e] = 0.f; ac[i][e] = 0.f; gm[i][e] = 0.f; }
+        if (ch < nch) {
+#pragma unroll
+            for (int e = 0; e < EPC; e += 4) {
+                const f32x4 g4 = *reinterpret_cast<const f32x4*>(gamma + ch * EPC + e);
+                gm[i][e] = g4[0]; gm[i][e + 1] = g4[1]; gm[i][e + 2] = g4[2]; gm[i][e + 3] = g4[3];
+            }
+        }
+    }
+    const float inv_cols = 1.0f / cols;
+    for (int r2 = (blockIdx.x * 4 + wave) * 2; r2 < rows; r2 += gridDim.x * 8) {
+        const int row = r2 + half;
+        const bool ok = row < rows;
+        const long base = (long)row * cols;
+        const float mu = ok ? mean[row] : 0.f, rs = ok ? rstd[row] : 0.f;
+        float xh[NC][EPC], dg[NC][EPC];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const int ch = hl + 32 * i;
+            if (ok && ch < nch) {
+                const V xv = *reinterpret_cast<const V*>(x + base + ch * EPC);
+                const V dv = *reinterpret_cast<const V*>(dy + base + ch * EPC);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    const float d = (float)dv[e];
+                    xh[i][e] = ((float)xv[e] - mu) * rs;
+                    dg[i][e] = d * gm[i][e];
+                    s1 += dg[i][e];
+                    s2 += dg[i][e] * xh[i][e];
+                    ag[i][e] += d * xh[i][e];
+                    ab[i][e] += d;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) { xh[i][e] = 0.f; dg[i][e] = 0.f; }
+            }
+        }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+        const float c1 = s1 * inv_cols, c2 = s2 * inv_cols;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const int ch = hl + 32 * i;
+            if (ok && ch < nch) {
+                float o[EPC];
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) o[e] = rs * (dg[i][e] - c1 - xh[i][e] * c2);
+                if (dres) {
+                    const V rv = *reinterpret_cast<const V*>(dres + base + ch * EPC);
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) o[e] += (float)rv[e];
+                }
+                V ov;
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) ov[e] = (T)o[e];
+                *reinterpret_cast<V*>(dx + base + ch * EPC) = ov;
+                if (want_colsum || dxm) {
+                    // the consumer sees the rounded dx: mask / sum exactly what it will read
+                    V mv;
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) {
+                        float m = (float)ov[e];
+                        if (thresh) m *= dropout_scale(seed, (uint32_t)(base + ch * EPC + e), thresh, inv_keep);
+                        mv[e] = (T)m;
+                        ac[i][e] += (float)mv[e];
+                    }
+                    if (dxm) *reinterpret_cast<V*>(dxm + base + ch * EPC) = mv;
+                }
+            }
+        }
+    }
+    // fold the two halves of the wave, then the four waves through LDS, one quantity at a time
+    float* out = ws + (long)blockIdx.x * 3 * cols;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (k == 2 && !want_colsum && !dxm) {
+            for (int c = threadIdx.x; c < cols; c += 256) out[2 * cols + c] = 0.f;
+            break;
+        }
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const int ch = hl + 32 * i;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                float v = k == 0 ? ag[i][e] : k == 1 ? ab[i][e] : ac[i][e];
+                v += __shfl_xor(v, 32, 64);
+                if (half == 0 && ch < nch) sred[wave][ch * EPC + e] = v;
+            }
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < cols; c += 256)
+            out[k * cols + c] = sred[0][c] + sred[1][c] + sred[2][c] + sred[3][c];
+        __syncthreads();
+    }
+}
+
 // grid (cols/64, 3): block = 64 columns x 4 row groups of one quantity (dgamma / dbeta / colsum)
 __global__ __launch_bounds__(256) void ln_bwd_finalize_kernel(const float* __restrict__ ws, int nblocks, int cols,
         float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dcol) {
@@ -251,15 +370,41 @@ extern "C" int mmtg_layernorm_bwd(int dtype, const void* dy, const void* x, cons
     hipStream_t s = (hipStream_t)stream;
     const double esz = dtype == MMTG_F32 ? 4 : 2;
     ProfScope prof(MMTG_PROF_LAYERNORM, s, 16.0 * rows * cols, ((dres ? 4.0 : 3.0) + (dx_masked ? 1.0 : 0.0)) * esz * rows * cols);
-    const int nb = ln_bwd_blocks(rows);
-    dim3 grid(nb), block(256);
+    int nb = ln_bwd_blocks(rows);
     const float ik = drop_thresh ? (float)(4294967296.0 / (4294967296.0 - (double)drop_thresh)) : 1.0f;
     const int want = dcolsum != nullptr;
-    if (dtype == MMTG_F32)
-        hipLaunchKernelGGL(ln_bwd_kernel<float>, grid, block, 0, s, (const float*)dy, (const float*)x, gamma, mean, rstd, (const float*)dres, (float*)dx, (float*)dx_masked, ws, rows, cols, want, drop_thresh, drop_seed, ik);
-    else if (dtype == MMTG_BF16)
-        hipLaunchKernelGGL(ln_bwd_kernel<bf16>, grid, block, 0, s, (const bf16*)dy, (const bf16*)x, gamma, mean, rstd, (const bf16*)dres, (bf16*)dx, (bf16*)dx_masked, ws, rows, cols, want, drop_thresh, drop_seed, ik);
-    else MMTG_FAIL(MMTG_ERR_BAD_ARG, "layernorm_bwd: bad dtype");
+    MMTG_REQUIRE(dtype == MMTG_F32 || dtype == MMTG_BF16, "layernorm_bwd: bad dtype");
+    static const bool v1 = getenv("MMTG_LN_V1") != nullptr;      // A/B switch for measurements
+    const int epc = dtype == MMTG_F32 ? 4 : 8;
+    const bool vec = !v1 && cols % epc == 0 && MMTG_ALIGNED16(dy) && MMTG_ALIGNED16(x) && MMTG_ALIGNED16(dx) &&
+                     (!dres || MMTG_ALIGNED16(dres)) && (!dx_masked || MMTG_ALIGNED16(dx_masked)) && MMTG_ALIGNED16(gamma);
+    if (vec) {
+        // half-wave per row: a block covers 8 rows per sweep; equal sweeps per wave, <= the v1 block count
+        // one resident round: the v2 kernel holds ~200 VGPRs, i.e. two 4-wave blocks per CU; more blocks
+        // than that run as a second round (measured 42 us at 944 blocks, 34 us at 472, 44 us at 236)
+        static int cap = 0;
+        if (!cap) {
+            int dev = 0, cus = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+            cap = getenv("MMTG_LN_CAP") ? atoi(getenv("MMTG_LN_CAP")) : 2 * cus;
+        }
+        if (nb > cap) nb = cap;
+        const int sweeps = cdiv(cdiv(rows, 8), nb);
+        nb = cdiv(cdiv(rows, 8), sweeps);
+        const int nc = cdiv(cols / epc, 32);
+        dim3 grid(nb), block(256);
+#define LN2(T, NC) hipLaunchKernelGGL((ln_bwd2_kernel<T, NC>), grid, block, 0, s, (const T*)dy, (const T*)x, gamma, mean, rstd, \
+                                      (const T*)dres, (T*)dx, (T*)dx_masked, ws, rows, cols, want, drop_thresh, drop_seed, ik)
+        if (dtype == MMTG_BF16) { if (nc <= 2) LN2(bf16, 2); else if (nc == 3) LN2(bf16, 3); else LN2(bf16, 4); }
+        else { if (nc <= 4) LN2(float, 4); else if (nc <= 6) LN2(float, 6); else LN2(float, 8); }
+#undef LN2
+    } else {
+        dim3 grid(nb), block(256);
+        if (dtype == MMTG_F32)
+            hipLaunchKernelGGL(ln_bwd_kernel<float>, grid, block, 0, s, (const float*)dy, (const float*)x, gamma, mean, rstd, (const float*)dres, (float*)dx, (float*)dx_masked, ws, rows, cols, want, drop_thresh, drop_seed, ik);
+        else
+            hipLaunchKernelGGL(ln_bwd_kernel<bf16>, grid, block, 0, s, (const bf16*)dy, (const bf16*)x, gamma, mean, rstd, (const bf16*)dres, (bf16*)dx, (bf16*)dx_masked, ws, rows, cols, want, drop_thresh, drop_seed, ik);
+    }
     hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3(cdiv(cols, 64), 3, 16), dim3(256), 0, s, ws, nb, cols, dgamma, dbeta, dcolsum);
     MMTG_LAUNCH_CHECK("layernorm_bwd");
     return MMTG_OK;

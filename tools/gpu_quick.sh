@@ -1,6 +1,3 @@
 #!/bin/bash
-# scratch: fused bias gradients (dGELU epilogue, attention backward)
-mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_ops_gpu.py -m gpu -q --no-header -p no:cacheprovider -k "gemm_epilogues or attention" 2>&1 | tail -3
-timeout 1200 python -m pytest tests/test_model_gpu.py -m gpu -q --no-header -p no:cacheprovider 2>&1 | tail -3
-timeout 900 python bench.py --no-cpu-baseline 2>&1 | tail -1 | cut -c1-1400
+# scratch: LayerNorm backward v2 block-count sweep
+for cap in 1024 512 256; do echo "== cap $cap"; MMTG_LN_CAP=$cap timeout 300 python tools/bench_rowops.py 2>&1 | grep "ln bwd"; done
