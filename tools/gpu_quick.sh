@@ -1,3 +1,4 @@
 #!/bin/bash
-# scratch: LayerNorm backward v2 block-count sweep
-for cap in 1024 512 256; do echo "== cap $cap"; MMTG_LN_CAP=$cap timeout 300 python tools/bench_rowops.py 2>&1 | grep "ln bwd"; done
+# scratch: ABLATION (wrong results): K-strided fragments read with plain ds_read_b128
+timeout 600 python tools/bench_gemm.py 2>&1 | grep "wgrad\|NN" | grep -v "s=1)"
+for args in "3072 768 15104 TN 6 128 3"; do timeout 120 python tools/gemm_timeline.py $args 2>&1 | grep -v amdgpu.ids | head -6; done
