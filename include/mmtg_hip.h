@@ -41,9 +41,13 @@ enum {
                             (the c_fc bias gradient, fused into the product that yields d pre-activation) */
     MMTG_EPI_DTANH = 5,  /* C = acc * (1 - aux^2)                             */
     MMTG_EPI_ATOMIC = 6, /* C(f32) += alpha * acc  (atomics; split-K allowed) */
-    MMTG_EPI_ROWDOT = 7  /* C = acc ; aux2(f32)[m, n/64] = sum over each 64-column group of C * aux
+    MMTG_EPI_ROWDOT = 7, /* C = acc ; aux2(f32)[m, n/64] = sum over each 64-column group of C * aux
                             (attention backward's delta = rowsum(dO * O) per head, fused into the
                             GEMM that produces dO; N % 64 == 0, no bias) */
+    MMTG_EPI_SPLIT = 8   /* deterministic split-K for small M (decode): C is fp32 [splits][M][ldc]; K split s
+                            stores its raw partial product in slab s (plain stores; out_f32, no bias);
+                            mmtg_splitk_finish sums the slabs in order and applies bias / activation /
+                            residual (/ LayerNorm) */
 };
 #define MMTG_GEMM_NO_TR 1 /* flags: gather K-strided bf16 fragments without ds_read_b64_tr_b16 */
 #define MMTG_GEMM_REGSTAGE 2 /* flags: register-staged v1 pipeline instead of the LDS-DMA one (bf16) */
@@ -94,6 +98,14 @@ int mmtg_gemm(int dtype, int transA, int transB, int M, int N, int K,
  * s_memrealtime (100 MHz) at kernel entry, after the first K tile has landed, at the end of the K
  * loop, at exit; the K tile count; the hardware id (XCC / SE / CU).  Null switches it off (default). */
 int mmtg_gemm_trace(void* buf, int max_wgs);
+
+/* Second half of a MMTG_EPI_SPLIT product: out[m, :] = epi(sum_s part[s][m][:] + bias) in the storage type
+ * (slabs summed in index order -> deterministic); epi in {NONE, GELU, TANH, RESID (+ aux)}.  With ln_out the
+ * row just produced is also LayerNormed (gamma, beta, eps) into ln_out [M, N] -- in the KV-cached decode step
+ * (generate.py:117-126 -> GPT2Block) this replaces the ln_1 / ln_2 / ln_f launches.  part: [splits][M][ldp].   */
+int mmtg_splitk_finish(int dtype, const float* part, int splits, int M, int N, long ldp, const float* bias,
+                       int epi, const void* aux, long ldaux, void* out, long ldo,
+                       const float* ln_gamma, const float* ln_beta, void* ln_out, float eps, void* stream);
 
 /* column sums: out[n] += sum_m X[m,n]  (bias gradients), X of `dtype`, out f32 */
 int mmtg_colsum(int dtype, const void* X, long ldx, int M, int N, float* out, void* stream);

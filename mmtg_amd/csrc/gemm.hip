@@ -273,6 +273,8 @@ __global__ __launch_bounds__((64 * WM * WN), (DmaCfg<TBM, TBN, WM, WN, NBUF>::MI
     if constexpr (NBUF > 2) wait_vmcnt<0>();   // drain the dummy tail loads before the LDS is released
     static_assert(NW * epi_scratch_bytes<TM, TN>() <= NBUF * STAGE, "epilogue scratch must fit the ring");
     if constexpr (!std_orient) __builtin_amdgcn_s_barrier();   // every wave is done reading the last tile
+    // MMTG_EPI_SPLIT: K split s stores its raw partial product in slab s of the fp32 output
+    if constexpr (!std_orient) p.C = reinterpret_cast<char*>(p.C) + (long)split * p.split_stride;
     // (the 6-wave configuration has to stay within 128 VGPRs: aux vectors one band ahead, not all four)
     gemm_epilogue<T, std_orient, TM, TN, (WM * WN > 4 ? 1 : TM)>(p, acc, m0 + wm * WTM, n0 + wn * WTN, g, l15,
                                          smem + wave * epi_scratch_bytes<TM, TN>(), lane);
@@ -613,7 +615,10 @@ extern "C" int mmtg_gemm(int dtype, int transA, int transB, int M, int N, int K,
     if (epi != MMTG_EPI_ATOMIC) {
         MMTG_REQUIRE(N % 8 == 0 && ldc % 8 == 0, "gemm: N and ldc must be multiples of 8 (N=%d ldc=%ld)", N, ldc);
         MMTG_REQUIRE(!bias || MMTG_ALIGNED16(bias), "gemm: bias must be 16-byte aligned");
-        MMTG_REQUIRE(splits <= 1, "gemm: split-K needs the atomic epilogue");
+        MMTG_REQUIRE(splits <= 1 || epi == MMTG_EPI_SPLIT, "gemm: split-K needs the atomic or the split epilogue");
+        if (epi == MMTG_EPI_SPLIT)
+            MMTG_REQUIRE(out_f32 && !bias && dtype == MMTG_BF16 && !(flags & (MMTG_GEMM_REGSTAGE | MMTG_GEMM_NO_TR | MMTG_GEMM_PERSIST)),
+                         "gemm: the split epilogue stores raw fp32 partial products (out_f32, no bias) from the bf16 LDS-DMA kernels");
     } else {
         MMTG_REQUIRE(!bias, "gemm: atomic epilogue takes no bias");
     }
@@ -640,8 +645,10 @@ extern "C" int mmtg_gemm(int dtype, int transA, int transB, int M, int N, int K,
     const int bk = dtype == MMTG_F32 ? 32 : 64;
     if (splits < 1) splits = 1;
     int kper = cdiv(cdiv(K, splits), bk) * bk;
-    splits = cdiv(K, kper);
+    // (the split epilogue keeps the caller's slab count: a K slice past the end stores zeros)
+    if (epi != MMTG_EPI_SPLIT) splits = cdiv(K, kper);
     a.kper = kper;
+    a.split_stride = epi == MMTG_EPI_SPLIT ? (long)M * ldc * 4 : 0;
     a.drop_thresh = drop_thresh; a.drop_seed = drop_seed;
     a.drop_inv_keep = drop_thresh ? (float)(4294967296.0 / (4294967296.0 - (double)drop_thresh)) : 1.0f;
     hipStream_t s = (hipStream_t)stream;

@@ -27,6 +27,7 @@ struct GemmArgs {
     int tiles_m_fast;      // item order inside a K split: tile_m fastest (1) or tile_n fastest (0)
     int ntiles;            // output tiles per K split (grid = ntiles * splits work items)
     int kper;              // K elements per split (multiple of BK)
+    long split_stride;     // MMTG_EPI_SPLIT: bytes between the per-split output slabs (0 otherwise)
     int nitems;            // ntiles * splits work items (a persistent launch has fewer workgroups)
     unsigned long long* trace; int trace_n;   // diagnostic timeline (mmtg_gemm_trace) or null
     int dbg_flags;         // 1: keep the tile_n-fastest item order (MMTG_GEMM_ROW_ORDER, A/B only)

@@ -334,7 +334,102 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, lo
     if (cc < N) atomicAdd(out + cc, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
+// Second half of a deterministic split-K product (MMTG_EPI_SPLIT): one block per output row sums the
+// `splits` fp32 slabs in index order, adds the bias, applies the activation / residual, stores the row
+// in the storage type -- and, when asked, LayerNorms the row it just produced (two-pass statistics on
+// the values as stored, like ln_fwd_kernel) so the decode step needs no separate LayerNorm launches.
+// NV = 4-column vectors per thread (N <= 1024 * NV).
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ part, int splits, long slab, int N, long ldp,
+        const float* __restrict__ bias, int epi, const T* __restrict__ aux, long ldaux, T* __restrict__ out, long ldo,
+        const float* __restrict__ gamma, const float* __restrict__ beta, T* __restrict__ ln_out, float eps) {
+    __shared__ float red[4];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    float v[NV][4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (tid + 256 * i) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[i][e] = 0.f;
+        if (c < N) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+            for (int k = 0; k < splits; ++k) a += *reinterpret_cast<const f32x4*>(part + k * slab + (long)row * ldp + c);
+            if (bias) a += *reinterpret_cast<const f32x4*>(bias + c);
+            float o[4] = {a[0], a[1], a[2], a[3]};
+            if (epi == MMTG_EPI_GELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = gelu_new_t<T>(o[e]);
+            } else if (epi == MMTG_EPI_TANH) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = tanh_t<T>(o[e]);
+            } else if (epi == MMTG_EPI_RESID) {
+                float r4[4];
+                ld4<T>(aux + (long)row * ldaux + c, r4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] += r4[e];
+            }
+            st4<T>(out + (long)row * ldo + c, o);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[i][e] = (float)(T)o[e]; s += v[i][e]; }
+        }
+    }
+    if (!ln_out) return;
+    s = wave_sum(s);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    const float mu = (red[0] + red[1] + red[2] + red[3]) / N;
+    __syncthreads();
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        if ((tid + 256 * i) * 4 < N) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mu; q += d * d; }
+        }
+    }
+    q = wave_sum(q);
+    if ((tid & 63) == 0) red[tid >> 6] = q;
+    __syncthreads();
+    const float rs = rsqrtf((red[0] + red[1] + red[2] + red[3]) / N + eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (tid + 256 * i) * 4;
+        if (c < N) {
+            float gm[4], bt[4], o[4];
+            ld4<float>(gamma + c, gm);
+            ld4<float>(beta + c, bt);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mu) * rs * gm[e] + bt[e];
+            st4<T>(ln_out + (long)row * N + c, o);
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int mmtg_splitk_finish(int dtype, const float* part, int splits, int M, int N, long ldp, const float* bias,
+                                  int epi, const void* aux, long ldaux, void* out, long ldo,
+                                  const float* ln_gamma, const float* ln_beta, void* ln_out, float eps, void* stream) {
+    MMTG_REQUIRE(dtype == MMTG_F32 || dtype == MMTG_BF16, "splitk_finish: bad dtype");
+    MMTG_REQUIRE(part && out && splits > 0 && M > 0 && N > 0 && N % 4 == 0 && N <= 4096 && ldp % 4 == 0 && ldo % 4 == 0,
+                 "splitk_finish: N=%d must be a multiple of 4 and <= 4096", N);
+    MMTG_REQUIRE(epi == MMTG_EPI_NONE || epi == MMTG_EPI_GELU || epi == MMTG_EPI_TANH || epi == MMTG_EPI_RESID, "splitk_finish: epilogue %d unsupported", epi);
+    MMTG_REQUIRE(epi != MMTG_EPI_RESID || (aux && ldaux % 4 == 0), "splitk_finish: residual epilogue needs aux");
+    MMTG_REQUIRE(!ln_out || (ln_gamma && ln_beta), "splitk_finish: LayerNorm needs gamma and beta");
+    MMTG_REQUIRE(MMTG_ALIGNED16(part) && (!bias || MMTG_ALIGNED16(bias)), "splitk_finish: 16-byte alignment");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(MMTG_PROF_DECODE, s, (double)splits * M * N, 4.0 * splits * M * N);
+    const long slab = (long)M * ldp;
+    const int nv = cdiv(N, 1024);
+#define FIN(T, NV) hipLaunchKernelGGL((splitk_finish_kernel<T, NV>), dim3(M), dim3(256), 0, s, part, splits, slab, N, ldp, bias, epi, \
+                                      (const T*)aux, ldaux, (T*)out, ldo, ln_gamma, ln_beta, (T*)ln_out, eps)
+    if (dtype == MMTG_BF16) { if (nv == 1) FIN(bf16, 1); else if (nv == 2) FIN(bf16, 2); else if (nv == 3) FIN(bf16, 3); else FIN(bf16, 4); }
+    else { if (nv == 1) FIN(float, 1); else if (nv == 2) FIN(float, 2); else if (nv == 3) FIN(float, 3); else FIN(float, 4); }
+#undef FIN
+    MMTG_LAUNCH_CHECK("splitk_finish");
+    return MMTG_OK;
+}
 
 extern "C" int mmtg_layernorm_fwd(int dtype, const void* x, void* y, const float* gamma, const float* beta,
                                   float* mean, float* rstd, int rows, int cols, float eps, void* stream) {

@@ -13,6 +13,8 @@ only because it never batches; identical at batch 1).
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -49,6 +51,14 @@ class GreedyDecoder:
         self.mu = torch.empty(B, dtype=torch.float32, device=dev)
         self.rs = torch.empty(B, dtype=torch.float32, device=dev)
         self.logits = torch.empty(B, self.eng.layout.Vpad, dtype=torch.float32, device=dev)
+        # bf16: deterministic split-K products (K slices per product: c_attn, attn c_proj, c_fc, mlp c_proj)
+        self.fast = self.eng.dtype == hip.BF16 and not os.environ.get("MMTG_DECODE_PLAIN")
+        # (measured at batch 256, us per token step: 2,3,2,6 -> 1020; 4,6,3,12 -> 1248; 1,1,1,2 -> 1183; unsplit 1264)
+        self.splits = tuple(int(x) for x in os.environ.get("MMTG_DECODE_SPLITS", "2,3,2,6").split(","))
+        if self.fast:
+            D = self.eng.sh.D
+            slab = max(self.splits[0] * 3 * D, self.splits[1] * D, self.splits[2] * 4 * D, self.splits[3] * D)
+            self.part = torch.empty(slab * B, dtype=torch.float32, device=dev)
         self.graphs = {}
         self.params = None
 
@@ -72,6 +82,23 @@ class GreedyDecoder:
         eng._fwd(self.h1, "decoder.projector_layer2.weight", self.h, B, "linear", bias=eng.P("decoder.projector_layer2.bias"))
         hip.decode_embed_add(self.h, eng.W(pre + "wpe.weight"), eng.W(pre + "wte.weight"), self.types, self.pos, self.h, B, D)
         hcur, hnext = self.h, self.h2
+        if self.fast:
+            self._layers_split(hcur, hnext, with_head)
+        else:
+            self._layers_plain(hcur, hnext, with_head)
+        if with_head:
+            Vp = eng.layout.Vpad
+            hip.gemm(self.a, eng.Wp("wte"), self.logits, B, Vp, D, transB=True, ldb=D, out_f32=True)
+            hip.decode_select(self.logits, Vp, min(sh.V, 13317), self.seq, self.pos, sh.P, sent, temperature, rep, B)
+        else:
+            hip.decode_select(None, 0, 0, self.seq, self.pos, sh.P, sent, temperature, rep, B)
+        hip.decode_advance(self.pos)
+
+    def _layers_plain(self, hcur, hnext, with_head):
+        """One GPT-2 block per layer with the training-side kernels (fp32 parity mode)."""
+        eng, sh, B = self.eng, self.eng.sh, self.B
+        D = sh.D
+        pre = "decoder.gpt2.transformer."
         for l in range(sh.L):
             p = f"{pre}h.{l}."
             hip.layernorm_fwd(hcur, self.a, eng.P(p + "ln_1.weight"), eng.P(p + "ln_1.bias"), self.mu, self.rs, B, D, sh.eps)
@@ -86,12 +113,39 @@ class GreedyDecoder:
                          epi=hip.EPI_RESID, aux=hnext, ldaux=D)
         if with_head:
             hip.layernorm_fwd(hcur, self.a, eng.P(pre + "ln_f.weight"), eng.P(pre + "ln_f.bias"), self.mu, self.rs, B, D, sh.eps)
-            Vp = eng.layout.Vpad
-            hip.gemm(self.a, eng.Wp("wte"), self.logits, B, Vp, D, transB=True, ldb=D, out_f32=True)
-            hip.decode_select(self.logits, Vp, min(sh.V, 13317), self.seq, self.pos, sh.P, sent, temperature, rep, B)
-        else:
-            hip.decode_select(None, 0, 0, self.seq, self.pos, sh.P, sent, temperature, rep, B)
-        hip.decode_advance(self.pos)
+
+    def _split(self, x, wkey, out, splits, bias, **fin):
+        """Deterministic split-K product for the batch-sized M of a decode step: `splits` K slices store
+        fp32 partial products (N/32 x splits workgroups instead of N/32), splitk_finish sums them in order
+        and applies bias / activation / residual (/ the next LayerNorm)."""
+        wt = self.eng.Wt(wkey)
+        N, K = wt.shape
+        hip.gemm(x, wt, self.part, self.B, N, K, transB=True, ldb=K, ldc=N, epi=hip.EPI_SPLIT, out_f32=True, splits=splits)
+        hip.splitk_finish(self.part, splits, self.B, N, out, bias=bias, **fin)
+
+    def _layers_split(self, hcur, hnext, with_head):
+        """bf16 fast path: 4 split-K products + 4 finish kernels + attention per layer; every LayerNorm
+        rides on the finish kernel of the product before it (self.a always holds the next LN output)."""
+        eng, sh, B = self.eng, self.eng.sh, self.B
+        D = sh.D
+        pre = "decoder.gpt2.transformer."
+        sq, sp, s1, s2 = self.splits
+        hip.layernorm_fwd(hcur, self.a, eng.P(pre + "h.0.ln_1.weight"), eng.P(pre + "h.0.ln_1.bias"), self.mu, self.rs, B, D, sh.eps)
+        for l in range(sh.L):
+            p = f"{pre}h.{l}."
+            self._split(self.a, p + "attn.c_attn.weight", self.qkv, sq, eng.P(p + "attn.c_attn.bias"))
+            hip.decode_attn(self.qkv, self.kc[l], self.vc[l], self.keep, self.pos, self.ctx, B, sh.nH, 64, self.Tmax)
+            self._split(self.ctx, p + "attn.c_proj.weight", hnext, sp, eng.P(p + "attn.c_proj.bias"),
+                        epi=hip.EPI_RESID, aux=hcur, ldaux=D,
+                        ln_gamma=eng.P(p + "ln_2.weight"), ln_beta=eng.P(p + "ln_2.bias"), ln_out=self.a, eps=sh.eps)
+            self._split(self.a, p + "mlp.c_fc.weight", self.g, s1, eng.P(p + "mlp.c_fc.bias"), epi=hip.EPI_GELU)
+            if l + 1 < sh.L:
+                nxt = f"{pre}h.{l + 1}.ln_1."
+            else:
+                nxt = pre + "ln_f." if with_head else None
+            ln = {} if nxt is None else dict(ln_gamma=eng.P(nxt + "weight"), ln_beta=eng.P(nxt + "bias"), ln_out=self.a, eps=sh.eps)
+            self._split(self.g, p + "mlp.c_proj.weight", hcur, s2, eng.P(p + "mlp.c_proj.bias"),
+                        epi=hip.EPI_RESID, aux=hnext, ldaux=D, **ln)
 
     def _run_step(self, with_head):
         if not self.use_graph:

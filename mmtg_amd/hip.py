@@ -31,6 +31,7 @@ _SIGS = {
     "mmtg_prof_read": ([_vp, _vp, _vp, _vp], _i),
     "mmtg_gemm_trace": ([_vp, _i], _i),
     "mmtg_gemm": ([_i, _i, _i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _vp, _i, _vp, _l, _vp, _i, _f, _i, _u, _u, _i, _vp], _i),
+    "mmtg_splitk_finish": ([_i, _vp, _i, _i, _i, _l, _vp, _i, _vp, _l, _vp, _l, _vp, _vp, _vp, _f, _vp], _i),
     "mmtg_colsum": ([_i, _vp, _l, _i, _i, _vp, _vp], _i),
     "mmtg_layernorm_fwd": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp], _i),
     "mmtg_layernorm_bwd_ws": ([_i, _i], _l),
@@ -160,6 +161,17 @@ def gemm(A, B, C_, M, N, K, transA=False, transB=False, lda=None, ldb=None, ldc=
     _check(lib().mmtg_gemm(d, int(transA), int(transB), M, N, K, _p(A), lda, _p(B), ldb, _p(C_), ldc,
                            _p(bias), epi, _p(aux), ldaux, _p(aux2), int(out_f32), float(alpha), splits,
                            drop_thresh(drop_p), drop_seed & 0xFFFFFFFF, flags, _stream()), "gemm")
+
+
+EPI_SPLIT = 8
+
+
+def splitk_finish(part, splits, M, N, out, bias=None, epi=EPI_NONE, aux=None, ldaux=0, ldp=None, ldo=None,
+                  ln_gamma=None, ln_beta=None, ln_out=None, eps=1e-5):
+    """out = epi(sum of the `splits` fp32 slabs of an EPI_SPLIT product + bias) [, ln_out = LayerNorm(out)]."""
+    _check(lib().mmtg_splitk_finish(dt(out), _p(part), splits, M, N, N if ldp is None else ldp, _p(bias), epi, _p(aux),
+                                    ldaux or N, _p(out), N if ldo is None else ldo, _p(ln_gamma), _p(ln_beta), _p(ln_out),
+                                    float(eps), _stream()), "splitk_finish")
 
 
 def colsum(X, M, N, out, ldx=None):

@@ -215,6 +215,37 @@ def test_gemm_skinny_config(shape):
     close(of, lin - bias, dtype, K, "skinny f32 out")
 
 
+@pytest.mark.parametrize("shape", [(256, 768, 3072, 12), (200, 2304, 768, 4), (64, 776, 200, 3)])
+def test_gemm_split_k_finish(shape):
+    """Deterministic split-K for decode: EPI_SPLIT slabs + splitk_finish (bias, residual, fused LayerNorm).
+    (64, 776, 200, 3): the third K slice lies past the end and must contribute zeros."""
+    M, N, K, S = shape
+    dtype = torch.bfloat16
+    a = rnd(M, K, dtype=dtype, seed=31).to(DEV)
+    w = rnd(N, K, dtype=dtype, seed=32, scale=0.2).to(DEV)
+    bias = rnd(N, seed=33).to(DEV)
+    res = rnd(M, N, dtype=dtype, seed=34).to(DEV)
+    gam, bet = (1 + 0.1 * rnd(N, seed=35)).to(DEV), (0.1 * rnd(N, seed=36)).to(DEV)
+    part = torch.full((S, M, N), float("nan"), device=DEV, dtype=torch.float32)
+    outs = []
+    for _ in range(2):
+        hip.gemm(a, w, part, M, N, K, transB=True, epi=hip.EPI_SPLIT, out_f32=True, splits=S)
+        out = torch.empty(M, N, device=DEV, dtype=dtype)
+        kw = dict(ln_gamma=gam, ln_beta=bet, ln_out=torch.empty(M, N, device=DEV, dtype=dtype)) if N <= 1024 else {}
+        hip.splitk_finish(part, S, M, N, out, bias=bias, epi=hip.EPI_RESID, aux=res, **kw)
+        outs.append((out, kw.get("ln_out")))
+    ref = a.float() @ w.float().t() + bias + res.float()
+    close(outs[0][0], ref, dtype, K, "split-K + finish")
+    assert torch.equal(outs[0][0], outs[1][0])                       # fixed summation order
+    if N <= 1024:
+        x = outs[0][0].float()
+        ln = torch.nn.functional.layer_norm(x, (N,), gam, bet, 1e-5)
+        close(outs[0][1], ln, dtype, 1, "fused LayerNorm of the finished row")
+    g = torch.empty(M, N, device=DEV, dtype=dtype)
+    hip.splitk_finish(part, S, M, N, g, bias=bias, epi=hip.EPI_GELU)
+    close(g, O.gelu_new(a.float() @ w.float().t() + bias), dtype, K, "split-K + gelu")
+
+
 def test_gemm_rowdot_epilogue_is_attention_delta():
     M, N, K = 600, 192, 128
     dtype = torch.bfloat16
