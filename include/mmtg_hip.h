@@ -37,8 +37,9 @@ enum {
     MMTG_EPI_GELU = 1,   /* aux2 = acc + bias ; C = gelu_new(aux2)            */
     MMTG_EPI_TANH = 2,   /* C = tanh(acc + bias)                              */
     MMTG_EPI_RESID = 3,  /* C = dropout(acc + bias) + aux                     */
-    MMTG_EPI_DGELU = 4,  /* C = acc * gelu_new'(aux) ; optional aux2 (f32 [N]) += column sums of C
-                            (the c_fc bias gradient, fused into the product that yields d pre-activation) */
+    MMTG_EPI_DGELU = 4,  /* C = acc * gelu_new'(aux) ; optional aux2 (f32 [ceil(M/64)][N]) <- column sums of C
+                            per 64-row band; mmtg_colsum over the bands = the c_fc bias gradient, without a
+                            pass over the [M,N] pre-activation gradient */
     MMTG_EPI_DTANH = 5,  /* C = acc * (1 - aux^2)                             */
     MMTG_EPI_ATOMIC = 6, /* C(f32) += alpha * acc  (atomics; split-K allowed) */
     MMTG_EPI_ROWDOT = 7, /* C = acc ; aux2(f32)[m, n/64] = sum over each 64-column group of C * aux

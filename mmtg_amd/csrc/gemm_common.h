@@ -360,20 +360,21 @@ __device__ __forceinline__ void epi_tiles(const GemmArgs& p, f32x4 (&acc)[TM][TN
         }
     }
     if constexpr (COLSUM) {
-        // aux2 (optional): f32 [N] += column sums of the output = the bias gradient of the layer whose
-        // pre-activation gradient this product computes (saves a separate pass over the [M,N] result).
-        // Lanes with equal lane % LPR hold the same 8 columns for different rows: fold them, then the
-        // first LPR lanes add the wave tile's 8 x LPR column sums.
+        // aux2 (optional): f32 [ceil(M/64)][N] <- column sums of the output per 64-row band (this wave
+        // tile's rows), plain stores; summing the bands gives the bias gradient of the layer whose
+        // pre-activation gradient this product computes (a [M/64, N] reduction instead of a pass over
+        // the [M,N] result).  Not atomics onto [N]: 118 row tiles adding to the same addresses
+        // serialise in the L2 (+29 us on the 15104 x 3072 product, measured in the training step).
+        // Lanes with equal lane % LPR hold the same 8 columns for different rows: fold them first.
+        static_assert(!COLSUM || TM == 4, "band index assumes 64-row wave tiles");
         if (p.aux2) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
 #pragma unroll
                 for (int o = LPR; o < 64; o <<= 1) cs[e] += __shfl_xor(cs[e], o, 64);
             }
-            if (lane < LPR && nok) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) atomicAdd(reinterpret_cast<float*>(p.aux2) + n + e, cs[e]);
-            }
+            if (lane < LPR && nok && mw0 < p.M)
+                store8<float>(reinterpret_cast<float*>(p.aux2) + (long)(mw0 >> 6) * p.N + n, cs);
         }
     }
 }

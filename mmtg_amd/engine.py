@@ -588,9 +588,11 @@ class Engine:
             (xin, mu1, rs1, a1, qkv, ctx, lse, xmid, mu2, rs2, m2, u, gact, s) = a["layers"][l]
             # x_out = x_mid + drop(gact W2 + b2): dy = dx * mask (already produced, with its bias gradient)
             dy = dmask if pr > 0 else dx
-            # (the dGELU epilogue also accumulates the column sums of du = the c_fc bias gradient)
-            self._dgrad(dy, p + "mlp.c_proj.weight", du, M, "conv1d", epi=hip.EPI_DGELU, aux=u, ldaux=4 * D,
-                        aux2=self.G(p + "mlp.c_fc.bias"))
+            # (the dGELU epilogue also emits the column sums of du per 64-row band: a [M/64, 4D] reduction
+            #  gives the c_fc bias gradient instead of a pass over du)
+            bands = self.buf("d_u_bands", ((M + 63) // 64, 4 * D), torch.float32)
+            self._dgrad(dy, p + "mlp.c_proj.weight", du, M, "conv1d", epi=hip.EPI_DGELU, aux=u, ldaux=4 * D, aux2=bands)
+            hip.colsum(bands, bands.shape[0], 4 * D, self.G(p + "mlp.c_fc.bias"))
             self._wgrad(gact, dy, p + "mlp.c_proj.weight", None, M, "conv1d")
             self._dgrad(du, p + "mlp.c_fc.weight", dm, M, "conv1d")
             self._wgrad(m2, du, p + "mlp.c_fc.weight", None, M, "conv1d")

@@ -156,9 +156,10 @@ def test_gemm_epilogues(dtype):
     O.gelu_new(x).sum().backward()
     close(run(hip.EPI_DGELU, aux=aux), acc * x.grad, dtype, K, "dgelu")
     # ... with the fused column sums of the stored output (the c_fc bias gradient), accumulated (+=)
-    cs = torch.full((N,), 0.25, device=DEV, dtype=torch.float32)
-    dg = run(hip.EPI_DGELU, aux=aux, aux2=cs)
-    close(cs, 0.25 + dg.float().sum(0), torch.float32, M, "dgelu column sums")
+    bands = torch.full(((M + 63) // 64, N), float("nan"), device=DEV, dtype=torch.float32)
+    dg = run(hip.EPI_DGELU, aux=aux, aux2=bands)
+    for i in range(bands.shape[0]):          # per 64-row band, every entry written
+        close(bands[i], dg[64 * i:64 * i + 64].float().sum(0), torch.float32, 64, "dgelu column sums, band %d" % i)
     close(run(hip.EPI_DTANH, aux=aux), acc * (1 - aux.float() ** 2), dtype, K, "dtanh")
     # fused dropout: deterministic mask, ~p zeros, survivors scaled by 1/(1-p)
     zero = torch.zeros(M, N, device=DEV, dtype=dtype)
