@@ -138,9 +138,11 @@ int mmtg_attn_fwd(int dtype, const void* qkv, const int* keep, void* out, float*
  * delta_ready != 0 -- already filled by the caller (the GEMM producing dout with
  * MMTG_EPI_ROWDOT does it for free); dq32: [B*T, D] f32 scratch (zeroed by the call);
  * dqkv: [B*T, 3*D] output; dbias (optional): f32 [3*D] += column sums of dqkv as stored (the
- * c_attn bias gradient, accumulated by the workgroups that produce each head's columns).          */
+ * c_attn bias gradient, from the workgroups that produce each head's columns); dbias_ws (optional
+ * scratch, f32 [B * ceil(T / key block)][3*D], key block = 256 bf16 / 128 f32): partial rows that the
+ * call sums into dbias -- without it the workgroups use atomics on dbias (slower: contended).       */
 int mmtg_attn_bwd(int dtype, const void* qkv, const int* keep, const void* out, const void* dout,
-                  const float* lse, float* delta, int delta_ready, float* dq32, void* dqkv, float* dbias,
+                  const float* lse, float* delta, int delta_ready, float* dq32, void* dqkv, float* dbias, float* dbias_ws,
                   int B, int T, int nH, int dh, unsigned drop_thresh, unsigned drop_seed, void* stream);
 
 /* ---------------------------------------------------------------- conditioning front end

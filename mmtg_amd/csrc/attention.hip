@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void attn_dq_finish_kernel(const float* __rest
 template <typename T, int NW>
 __global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(const T* __restrict__ qkv, const int* __restrict__ keep,
         const T* __restrict__ d_out, const float* __restrict__ lse, const float* __restrict__ delta,
-        float* __restrict__ dq32, T* __restrict__ dqkv, float* __restrict__ dbias, int Tn, int nH, int direct_dq,
+        float* __restrict__ dq32, T* __restrict__ dqkv, float* __restrict__ dbias, int bias_rows, int Tn, int nH, int direct_dq,
         uint32_t drop_thresh, uint32_t drop_seed, float inv_keep, int ablate) {
     typedef typename Vec16<T>::type V;
     typedef AT<T> A;
@@ -445,7 +445,14 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(const T* __restrict__
             }
         }
         __syncthreads();
-        if (tid < 3 * DH && (direct_dq || tid >= DH)) atomicAdd(dbias + (tid / DH) * D + h * DH + tid % DH, sB[tid]);
+        if (tid < 3 * DH) {
+            const bool mine = direct_dq || tid >= DH;
+            const int col = (tid / DH) * D + h * DH + tid % DH;
+            // bias_rows: one partial row per workgroup (plain stores; the host sums the rows) -- the
+            // atomics onto [3D] from all batch rows at once cost +10 us per launch
+            if (bias_rows) dbias[((long)b * gridDim.x + blockIdx.x) * 3 * D + col] = mine ? sB[tid] : 0.f;
+            else if (mine) atomicAdd(dbias + col, sB[tid]);
+        }
     }
 }
 
@@ -485,7 +492,7 @@ extern "C" int mmtg_attn_fwd(int dtype, const void* qkv, const int* keep, void* 
 extern "C" int mmtg_colsum(int dtype, const void* X, long ldx, int M, int N, float* out, void* stream);
 
 extern "C" int mmtg_attn_bwd(int dtype, const void* qkv, const int* keep, const void* out, const void* dout,
-                             const float* lse, float* delta, int delta_ready, float* dq32, void* dqkv, float* dbias,
+                             const float* lse, float* delta, int delta_ready, float* dq32, void* dqkv, float* dbias, float* dbias_ws,
                              int B, int T, int nH, int dh, unsigned drop_thresh, unsigned drop_seed, void* stream) {
     MMTG_REQUIRE(dh == DH, "attn_bwd: head dim %d unsupported (built for 64)", dh);
     MMTG_REQUIRE(B > 0 && T > 0 && nH > 0, "attn_bwd: bad sizes");
@@ -497,6 +504,8 @@ extern "C" int mmtg_attn_bwd(int dtype, const void* qkv, const int* keep, const 
     const long rows = (long)B * T;
     const int D = nH * dh;
     const float ik = inv_keep_of(drop_thresh);
+    float* const bias_dst = dbias && dbias_ws ? dbias_ws : dbias;
+    const int bias_rows = dbias && dbias_ws ? 1 : 0;
     static bool attr_set[2] = {false, false};
     static const int ablate = getenv("MMTG_ATTN_ABLATE") ? atoi(getenv("MMTG_ATTN_ABLATE")) : 0;   // timing experiments only
     if (dtype == MMTG_F32) {
@@ -510,7 +519,7 @@ extern "C" int mmtg_attn_bwd(int dtype, const void* qkv, const int* keep, const 
         }
         if (!delta_ready) hipLaunchKernelGGL(attn_delta_kernel<float>, dim3(cdiv(rows * nH, 4)), dim3(256), 0, s, (const float*)out, (const float*)dout, delta, T, nH, rows);
         if (nkb > 1) { if (hipMemsetAsync(dq32, 0, rows * D * sizeof(float), s) != hipSuccess) MMTG_FAIL(MMTG_ERR_HIP, "attn_bwd: memset failed"); }
-        hipLaunchKernelGGL((attn_bwd_kernel<float, 4>), dim3(nkb, nH, B), dim3(256), shm, s, (const float*)qkv, keep, (const float*)dout, lse, delta, dq32, (float*)dqkv, dbias, T, nH, nkb == 1, drop_thresh, drop_seed, ik, ablate);
+        hipLaunchKernelGGL((attn_bwd_kernel<float, 4>), dim3(nkb, nH, B), dim3(256), shm, s, (const float*)qkv, keep, (const float*)dout, lse, delta, dq32, (float*)dqkv, bias_dst, bias_rows, T, nH, nkb == 1, drop_thresh, drop_seed, ik, ablate);
         if (nkb > 1) hipLaunchKernelGGL(attn_dq_finish_kernel<float>, dim3(2048), dim3(256), 0, s, dq32, (float*)dqkv, rows, D);
     } else if (dtype == MMTG_BF16) {
         const int KB = 4 * AT<bf16>::KPW;
@@ -523,12 +532,16 @@ extern "C" int mmtg_attn_bwd(int dtype, const void* qkv, const int* keep, const 
         }
         if (!delta_ready) hipLaunchKernelGGL(attn_delta_kernel<bf16>, dim3(cdiv(rows * nH, 4)), dim3(256), 0, s, (const bf16*)out, (const bf16*)dout, delta, T, nH, rows);
         if (nkb > 1) { if (hipMemsetAsync(dq32, 0, rows * D * sizeof(float), s) != hipSuccess) MMTG_FAIL(MMTG_ERR_HIP, "attn_bwd: memset failed"); }
-        hipLaunchKernelGGL((attn_bwd_kernel<bf16, 8>), dim3(nkb, nH, B), dim3(512), shm, s, (const bf16*)qkv, keep, (const bf16*)dout, lse, delta, dq32, (bf16*)dqkv, dbias, T, nH, nkb == 1, drop_thresh, drop_seed, ik, ablate);
+        hipLaunchKernelGGL((attn_bwd_kernel<bf16, 8>), dim3(nkb, nH, B), dim3(512), shm, s, (const bf16*)qkv, keep, (const bf16*)dout, lse, delta, dq32, (bf16*)dqkv, bias_dst, bias_rows, T, nH, nkb == 1, drop_thresh, drop_seed, ik, ablate);
         if (nkb > 1) hipLaunchKernelGGL(attn_dq_finish_kernel<bf16>, dim3(2048), dim3(256), 0, s, dq32, (bf16*)dqkv, rows, D);
     } else MMTG_FAIL(MMTG_ERR_BAD_ARG, "attn_bwd: bad dtype");
     MMTG_LAUNCH_CHECK("attn_bwd");
     // several key blocks per head: dQ went through the fp32 atomics + finish pass; sum its columns here
-    if (dbias && cdiv(T, dtype == MMTG_F32 ? 4 * AT<float>::KPW : 4 * AT<bf16>::KPW) > 1)
-        return mmtg_colsum(dtype, dqkv, 3L * D, (int)rows, D, dbias, stream);
+    const int nkb_ = cdiv(T, dtype == MMTG_F32 ? 4 * AT<float>::KPW : 4 * AT<bf16>::KPW);
+    if (bias_rows) {
+        int rc = mmtg_colsum(MMTG_F32, dbias_ws, 3L * D, B * nkb_, 3 * D, dbias, stream);
+        if (rc) return rc;
+    }
+    if (dbias && nkb_ > 1) return mmtg_colsum(dtype, dqkv, 3L * D, (int)rows, D, dbias, stream);
     return MMTG_OK;
 }

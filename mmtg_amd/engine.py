@@ -610,7 +610,8 @@ class Engine:
                 self._dgrad(dy, p + "attn.c_proj.weight", dctx, M, "conv1d")
             self._wgrad(ctx, dy, p + "attn.c_proj.weight", None, M, "conv1d")
             hip.attn_bwd(qkv, a["keep"], ctx, dctx, lse, delta, dq32, dqkv, B, T, sh.nH, D // sh.nH,
-                         drop_p=pa, drop_seed=s, delta_ready=fuse_delta, dbias=self.G(p + "attn.c_attn.bias"))
+                         drop_p=pa, drop_seed=s, delta_ready=fuse_delta, dbias=self.G(p + "attn.c_attn.bias"),
+                         dbias_ws=self.buf("attn_dbias_rows", (hip.attn_bwd_bias_rows(B, T, self.dtype), 3 * D), torch.float32))
             self._dgrad(dqkv, p + "attn.c_attn.weight", da, M, "conv1d")
             self._wgrad(a1, dqkv, p + "attn.c_attn.weight", None, M, "conv1d")
             if l > 0:

@@ -356,7 +356,11 @@ def test_attention(dtype, T):
     dq32 = torch.empty(B * T, D, device=DEV)
     dqkv = torch.full((B, T, 3 * D), float("nan"), device=DEV, dtype=dtype)
     dbias = torch.full((3 * D,), 0.5, device=DEV, dtype=torch.float32)
-    hip.attn_bwd(qd, kd, out, dout.to(DEV), lse, delta, dq32, dqkv, B, T, nH, dh, dbias=dbias)
+    rows = torch.full((hip.attn_bwd_bias_rows(B, T, hip.dt(qd)), 3 * D), float("nan"), device=DEV, dtype=torch.float32)
+    hip.attn_bwd(qd, kd, out, dout.to(DEV), lse, delta, dq32, dqkv, B, T, nH, dh, dbias=dbias, dbias_ws=rows)
+    dbias_at = torch.full((3 * D,), 0.5, device=DEV, dtype=torch.float32)     # atomics variant (no scratch)
+    hip.attn_bwd(qd, kd, out, dout.to(DEV), lse, delta, dq32, torch.empty_like(dqkv), B, T, nH, dh, dbias=dbias_at)
+    close(dbias_at, dbias, torch.float32, B * T, "attn fused d(bias): atomics vs partial rows")
     g = qr.grad
     for i, nm in enumerate("qkv"):
         close(dqkv[..., i * D:(i + 1) * D], g[..., i * D:(i + 1) * D], dtype, 64, "attn d" + nm,
