@@ -258,6 +258,11 @@ int mmtg_decode_embed_add(int dtype, const void* g, const void* wpe, const void*
                           const int* pos_ptr, void* h, int B, int D, void* stream);
 int mmtg_decode_attn(int dtype, const void* qkv, void* kcache, void* vcache, const int* keep, long ldkeep,
                      const int* pos_ptr, void* out, int B, int nH, int dh, int Tmax, void* stream);
+/* the same, taking the c_attn product as MMTG_EPI_SPLIT slabs (part: f32 [splits][B][3*D]) plus its bias:
+ * the slabs are summed in order and rounded to the storage type as mmtg_splitk_finish would (one launch less) */
+int mmtg_decode_attn_split(int dtype, const float* part, int splits, const float* bias, void* kcache, void* vcache,
+                           const int* keep, long ldkeep, const int* pos_ptr, void* out, int B, int nH, int dh, int Tmax,
+                           void* stream);
 int mmtg_decode_select(const float* logits, long ldl, int V, long long* seq, long ldseq, const int* pos_ptr,
                        int P, int sent, float temperature, float rep_penalty, int B, void* stream);
 int mmtg_decode_advance(int* pos_ptr, void* stream);

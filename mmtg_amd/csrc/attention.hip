@@ -105,6 +105,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
 #pragma unroll
     for (int i = 0; i < 4; ++i) o_acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m_run = -INFINITY, l_run = 0.f;
+    // dropout counter of (b, h, q, key) = ((b nH + h) T + q) T + key, low 32 bits: this lane's row part once
+    const uint32_t drow = ((uint32_t)(b * nH + h) * (uint32_t)Tn + (uint32_t)qi) * (uint32_t)Tn;
 
     for (int jb = 0; jb <= qb; ++jb) {
         const int j0 = jb * 64;
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
                 rs += p;
                 if (drop_thresh) {
                     const int kj = j0 + kt * 16 + 4 * g + r;
-                    p *= dropout_scale(drop_seed, (uint32_t)((((long)b * nH + h) * Tn + qi) * Tn + kj), drop_thresh, inv_keep);
+                    p *= dropout_scale(drop_seed, drow + (uint32_t)kj, drop_thresh, inv_keep);
                 }
                 s_acc[kt][r] = p;
             }
@@ -279,6 +281,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(const T* __restrict__
         for (int j = 0; j < NKT; ++j) { dk_acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; dv_acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
     const int kw0 = KPW * wave;  // this wave's first key (block-local)
+    const uint32_t dbase = (uint32_t)(b * nH + h) * (uint32_t)Tn;   // dropout counter ((b nH + h) T + q) T + key, low 32 bits
     const int nqt = (Tn + 31) / 32;
     float dq_cs = 0.f;           // column sum (over queries) of this lane's dQ column, as stored
     for (int qt = kb0 / 32; qt < nqt; ++qt) {
@@ -305,37 +308,54 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(const T* __restrict__
 
         const bool active = (kb0 + kw0 <= q0 + 31) && (kb0 + kw0 < Tn);
         if (active) {
+            // per-row quantities of this lane's 8 query rows (qs, r), hoisted out of the key-tile loop: the
+            // element loop below is VALU-bound (exp, dropout hash, masks, dS address), every op counts
+            float lse8[2][4], del8[2][4];
+            uint32_t drow8[2][4];
+            int dsrow8[2][4];
+            bool qok8[2][4];
+#pragma unroll
+            for (int qs = 0; qs < 2; ++qs)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ql = qs * 16 + 4 * g + r;
+                    lse8[qs][r] = sLse[ql];
+                    del8[qs][r] = sDel[ql];
+                    drow8[qs][r] = (dbase + (uint32_t)(q0 + ql)) * (uint32_t)Tn;
+                    dsrow8[qs][r] = ql * RBS;
+                    qok8[qs][r] = q0 + ql < Tn;
+                }
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt) {
                 f32x4 pT[2], dsT[2];
+                const int kl = kw0 + kt * 16 + l15, key = kb0 + kl;
+                const bool kpok = sKeep[kl] != 0;
+                const int byte = kl * (int)sizeof(T), bch = byte >> 4, blo = byte & 15;
 #pragma unroll
                 for (int qs = 0; qs < 2; ++qs) {
                     f32x4 s_acc = {0.f, 0.f, 0.f, 0.f}, dp_acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int ks = 0; ks < A::KSTEPS; ++ks) {
-                        mma16(ld_kc<T>(sQr, qs * 16 + l15, ks, g), ld_kc<T>(sKr, kw0 + kt * 16 + l15, ks, g), s_acc);
-                        mma16(ld_kc<T>(sOr, qs * 16 + l15, ks, g), ld_kc<T>(sVr, kw0 + kt * 16 + l15, ks, g), dp_acc);
+                        mma16(ld_kc<T>(sQr, qs * 16 + l15, ks, g), ld_kc<T>(sKr, kl, ks, g), s_acc);
+                        mma16(ld_kc<T>(sOr, qs * 16 + l15, ks, g), ld_kc<T>(sVr, kl, ks, g), dp_acc);
                     }
-                    const int kl = kw0 + kt * 16 + l15, key = kb0 + kl;
-                    const int kp = sKeep[kl];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int ql = qs * 16 + 4 * g + r, q = q0 + ql;
-                        const bool valid = key <= q && q < Tn && kp != 0;
-                        float p = valid ? ((ablate & 1) ? s_acc[r] : fexp<T>(s_acc[r] * scale - sLse[ql])) : 0.f;
+                        const int q = q0 + qs * 16 + 4 * g + r;
+                        const bool valid = key <= q && qok8[qs][r] && kpok;
+                        float p = valid ? ((ablate & 1) ? s_acc[r] : fexp<T>(s_acc[r] * scale - lse8[qs][r])) : 0.f;
                         float dp = dp_acc[r];
                         if (drop_thresh) {
-                            const float ms = dropout_scale(drop_seed, (uint32_t)((((long)b * nH + h) * Tn + q) * Tn + key), drop_thresh, inv_keep);
+                            const float ms = dropout_scale(drop_seed, drow8[qs][r] + (uint32_t)key, drop_thresh, inv_keep);
                             dp *= ms;
                             pT[qs][r] = p * ms;
                         } else {
                             pT[qs][r] = p;
                         }
-                        const float ds = p * (dp - sDel[ql]) * scale;
+                        const float ds = p * (dp - del8[qs][r]) * scale;
                         dsT[qs][r] = ds;
-                        // dS image [q][key] for the dQ product
-                        const int byte = kl * (int)sizeof(T);
-                        if (!(ablate & 2)) *reinterpret_cast<T*>(sDS + ql * RBS + (((byte >> 4) ^ (ql & 7)) << 4) + (byte & 15)) = (T)ds;
+                        // dS image [q][key] for the dQ product (chunk swizzle by the row's low 3 bits = (4g + r) & 7)
+                        if (!(ablate & 2)) *reinterpret_cast<T*>(sDS + dsrow8[qs][r] + ((bch ^ ((4 * g + r) & 7)) << 4) + blo) = (T)ds;
                     }
                 }
                 // dV^T[d][key] += dO^T[d][q] P[q][key] ;  dK^T[d][key] += Q^T[d][q] dS[q][key]

@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void decode_embed_add_kernel(const T* __restri
 template <typename T>
 __global__ __launch_bounds__(64) void decode_attn_kernel(const T* __restrict__ qkv, T* __restrict__ kc, T* __restrict__ vc,
         const int* __restrict__ keep, long ldkeep, const int* __restrict__ pos_ptr, T* __restrict__ out,
-        int nH, int Tmax) {
+        int nH, int Tmax, const float* __restrict__ part, int splits, long slab, const float* __restrict__ bias) {
     __shared__ float sp[1024];
     __shared__ float sq[64];
     const int h = blockIdx.x, b = blockIdx.y, lane = threadIdx.x, pos = *pos_ptr;
@@ -166,9 +166,21 @@ __global__ __launch_bounds__(64) void decode_attn_kernel(const T* __restrict__ q
     const T* row = qkv + (long)b * 3 * D + h * 64;
     T* kbase = kc + (((long)b * nH + h) * Tmax) * 64;
     T* vbase = vc + (((long)b * nH + h) * Tmax) * 64;
-    sq[lane] = (float)row[lane] * 0.125f;
-    kbase[(long)pos * 64 + lane] = row[D + lane];
-    vbase[(long)pos * 64 + lane] = row[2 * D + lane];
+    if (part) {
+        // the c_attn product arrives as split-K slabs (MMTG_EPI_SPLIT): sum them in order, add the bias
+        // and round to the storage type exactly as mmtg_splitk_finish would (saves that launch)
+        const float* pr = part + (long)b * 3 * D + h * 64 + lane;
+        float q = 0.f, k = 0.f, v = 0.f;
+        for (int s_ = 0; s_ < splits; ++s_) { q += pr[s_ * slab]; k += pr[s_ * slab + D]; v += pr[s_ * slab + 2 * D]; }
+        q += bias[h * 64 + lane]; k += bias[D + h * 64 + lane]; v += bias[2 * D + h * 64 + lane];
+        sq[lane] = (float)(T)q * 0.125f;
+        kbase[(long)pos * 64 + lane] = (T)k;
+        vbase[(long)pos * 64 + lane] = (T)v;
+    } else {
+        sq[lane] = (float)row[lane] * 0.125f;
+        kbase[(long)pos * 64 + lane] = row[D + lane];
+        vbase[(long)pos * 64 + lane] = row[2 * D + lane];
+    }
     __syncthreads();
     const int nkeys = pos + 1;
     float mx = -INFINITY;
@@ -283,11 +295,30 @@ extern "C" int mmtg_decode_attn(int dtype, const void* qkv, void* kcache, void* 
     ProfScope prof(MMTG_PROF_DECODE, s, 4.0 * B * nH * (double)Tmax * dh, esz * 2.0 * B * nH * (double)Tmax * dh);
     dim3 grid(nH, B), block(64);
     if (dtype == MMTG_F32)
-        hipLaunchKernelGGL(decode_attn_kernel<float>, grid, block, 0, s, (const float*)qkv, (float*)kcache, (float*)vcache, keep, ldkeep, pos_ptr, (float*)out, nH, Tmax);
+        hipLaunchKernelGGL(decode_attn_kernel<float>, grid, block, 0, s, (const float*)qkv, (float*)kcache, (float*)vcache, keep, ldkeep, pos_ptr, (float*)out, nH, Tmax, nullptr, 0, 0, nullptr);
     else if (dtype == MMTG_BF16)
-        hipLaunchKernelGGL(decode_attn_kernel<bf16>, grid, block, 0, s, (const bf16*)qkv, (bf16*)kcache, (bf16*)vcache, keep, ldkeep, pos_ptr, (bf16*)out, nH, Tmax);
+        hipLaunchKernelGGL(decode_attn_kernel<bf16>, grid, block, 0, s, (const bf16*)qkv, (bf16*)kcache, (bf16*)vcache, keep, ldkeep, pos_ptr, (bf16*)out, nH, Tmax, nullptr, 0, 0, nullptr);
     else MMTG_FAIL(MMTG_ERR_BAD_ARG, "decode_attn: bad dtype");
     MMTG_LAUNCH_CHECK("decode_attn");
+    return MMTG_OK;
+}
+
+extern "C" int mmtg_decode_attn_split(int dtype, const float* part, int splits, const float* bias, void* kcache, void* vcache,
+                                      const int* keep, long ldkeep, const int* pos_ptr, void* out, int B, int nH, int dh, int Tmax,
+                                      void* stream) {
+    MMTG_REQUIRE(part && bias && splits > 0 && kcache && vcache && keep && pos_ptr && out, "decode_attn_split: null pointer");
+    MMTG_REQUIRE(dh == 64 && B > 0 && nH > 0 && Tmax > 0 && Tmax <= 1024, "decode_attn_split: head dim 64, Tmax <= 1024");
+    hipStream_t s = (hipStream_t)stream;
+    const double esz = dtype == MMTG_F32 ? 4 : 2;
+    ProfScope prof(MMTG_PROF_DECODE, s, 4.0 * B * nH * (double)Tmax * dh, esz * 2.0 * B * nH * (double)Tmax * dh);
+    dim3 grid(nH, B), block(64);
+    const long slab = (long)B * 3 * nH * 64;
+    if (dtype == MMTG_F32)
+        hipLaunchKernelGGL(decode_attn_kernel<float>, grid, block, 0, s, (const float*)nullptr, (float*)kcache, (float*)vcache, keep, ldkeep, pos_ptr, (float*)out, nH, Tmax, part, splits, slab, bias);
+    else if (dtype == MMTG_BF16)
+        hipLaunchKernelGGL(decode_attn_kernel<bf16>, grid, block, 0, s, (const bf16*)nullptr, (bf16*)kcache, (bf16*)vcache, keep, ldkeep, pos_ptr, (bf16*)out, nH, Tmax, part, splits, slab, bias);
+    else MMTG_FAIL(MMTG_ERR_BAD_ARG, "decode_attn_split: bad dtype");
+    MMTG_LAUNCH_CHECK("decode_attn_split");
     return MMTG_OK;
 }
 

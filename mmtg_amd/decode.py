@@ -133,8 +133,15 @@ class GreedyDecoder:
         hip.layernorm_fwd(hcur, self.a, eng.P(pre + "h.0.ln_1.weight"), eng.P(pre + "h.0.ln_1.bias"), self.mu, self.rs, B, D, sh.eps)
         for l in range(sh.L):
             p = f"{pre}h.{l}."
-            self._split(self.a, p + "attn.c_attn.weight", self.qkv, sq, eng.P(p + "attn.c_attn.bias"))
-            hip.decode_attn(self.qkv, self.kc[l], self.vc[l], self.keep, self.pos, self.ctx, B, sh.nH, 64, self.Tmax)
+            if os.environ.get("MMTG_DECODE_ATTN_SPLIT", "1") == "1":
+                # c_attn: the attention kernel sums the split-K slabs itself (no finish launch)
+                wq = eng.Wt(p + "attn.c_attn.weight")
+                hip.gemm(self.a, wq, self.part, B, 3 * D, D, transB=True, ldb=D, ldc=3 * D, epi=hip.EPI_SPLIT, out_f32=True, splits=sq)
+                hip.decode_attn_split(self.part, sq, eng.P(p + "attn.c_attn.bias"), self.kc[l], self.vc[l], self.keep, self.pos,
+                                      self.ctx, B, sh.nH, 64, self.Tmax)
+            else:
+                self._split(self.a, p + "attn.c_attn.weight", self.qkv, sq, eng.P(p + "attn.c_attn.bias"))
+                hip.decode_attn(self.qkv, self.kc[l], self.vc[l], self.keep, self.pos, self.ctx, B, sh.nH, 64, self.Tmax)
             self._split(self.ctx, p + "attn.c_proj.weight", hnext, sp, eng.P(p + "attn.c_proj.bias"),
                         epi=hip.EPI_RESID, aux=hcur, ldaux=D,
                         ln_gamma=eng.P(p + "ln_2.weight"), ln_beta=eng.P(p + "ln_2.bias"), ln_out=self.a, eps=sh.eps)

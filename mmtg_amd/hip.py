@@ -62,6 +62,7 @@ _SIGS = {
     "mmtg_decode_embed": ([_i, _vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
     "mmtg_decode_embed_add": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp], _i),
     "mmtg_decode_attn": ([_i, _vp, _vp, _vp, _vp, _l, _vp, _vp, _i, _i, _i, _i, _vp], _i),
+    "mmtg_decode_attn_split": ([_i, _vp, _i, _vp, _vp, _vp, _vp, _l, _vp, _vp, _i, _i, _i, _i, _vp], _i),
     "mmtg_decode_select": ([_vp, _l, _i, _vp, _l, _vp, _i, _i, _f, _f, _i, _vp], _i),
     "mmtg_decode_advance": ([_vp, _vp], _i),
 }
@@ -343,6 +344,11 @@ def decode_embed_add(g, wpe, wte, type_ids, pos, h, B, D):
 def decode_attn(qkv, kcache, vcache, keep, pos, out, B, nH, dh, Tmax):
     _check(lib().mmtg_decode_attn(dt(qkv), _p(qkv), _p(kcache), _p(vcache), _p(keep), keep.stride(0), _p(pos), _p(out),
                                   B, nH, dh, Tmax, _stream()), "decode_attn")
+
+
+def decode_attn_split(part, splits, bias, kcache, vcache, keep, pos, out, B, nH, dh, Tmax):
+    _check(lib().mmtg_decode_attn_split(dt(out), _p(part), splits, _p(bias), _p(kcache), _p(vcache), _p(keep), keep.stride(0),
+                                        _p(pos), _p(out), B, nH, dh, Tmax, _stream()), "decode_attn_split")
 
 
 def decode_select(logits, ldl, V, seq, pos, P, sent, temperature, rep_penalty, B):

@@ -633,6 +633,42 @@ def test_adamw_clip_and_casts():
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_decode_attention_step(dtype):
+    """KV-cached single-token attention: appends this token's K/V at `pos`, attends over keys 0..pos under
+    the key mask; the split variant takes the c_attn product as fp32 slabs + bias and must agree exactly."""
+    B, nH, dh, Tmax, pos = 3, 2, 64, 40, 17
+    D = nH * dh
+    kc = rnd(B, nH, Tmax, dh, dtype=dtype, seed=41).to(DEV)
+    vc = rnd(B, nH, Tmax, dh, dtype=dtype, seed=42).to(DEV)
+    keep = torch.ones(B, Tmax, dtype=torch.int32)
+    keep[1, 3:7] = 0
+    keep = keep.to(DEV)
+    posd = torch.tensor([pos], dtype=torch.int32, device=DEV)
+    slabs = rnd(3, B, 3 * D, seed=43, scale=0.5).to(DEV)
+    bias = rnd(3 * D, seed=44, scale=0.1).to(DEV)
+    qkv = (slabs.sum(0) + bias).to(dtype)
+    # reference on the rounded qkv
+    q, k, v = (qkv.float()[:, i * D:(i + 1) * D].view(B, nH, dh) for i in range(3))
+    kr, vr = kc.float().clone(), vc.float().clone()
+    kr[:, :, pos], vr[:, :, pos] = k, v
+    sc = torch.einsum("bhd,bhtd->bht", q, kr[:, :, :pos + 1]) * 0.125
+    sc = sc.masked_fill(keep[:, None, :pos + 1] == 0, float("-inf"))
+    ref = torch.einsum("bht,bhtd->bhd", torch.softmax(sc, -1), vr[:, :, :pos + 1]).reshape(B, D)
+    outs = []
+    for split in (False, True):
+        k1, v1 = kc.clone(), vc.clone()
+        out = torch.empty(B, D, device=DEV, dtype=dtype)
+        if split:
+            hip.decode_attn_split(slabs, 3, bias, k1, v1, keep, posd, out, B, nH, dh, Tmax)
+        else:
+            hip.decode_attn(qkv, k1, v1, keep, posd, out, B, nH, dh, Tmax)
+        close(out, ref, dtype, dh, "decode attention split=%s" % split)
+        assert torch.equal(k1[:, :, pos].reshape(B, D), qkv[:, D:2 * D]) and torch.equal(v1[:, :, pos].reshape(B, D), qkv[:, 2 * D:])
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_transpose_batch(dtype):
     """Batched weight transpose (the [out,in] copies of Conv1D weights): exact, ragged 64x64 tiles."""
     shapes = [(768, 2304), (72, 40), (3072, 768), (8, 200)]
