@@ -41,21 +41,24 @@ __global__ __launch_bounds__(256) void row_lse_kernel(const float* __restrict__ 
     const long m = blockIdx.x;
     const int b = (int)(m / Tt), t = (int)(m % Tt);
     const float* row = logits + m * ldl;
-    float mx = -INFINITY;
+    // one pass: every thread keeps a running (max, sum of exp relative to it) over its 4-wide slices and
+    // rescales when the max moves; the block then combines the 256 pairs (exact up to fp32 rounding)
+    float mx = -INFINITY, sm = 0.f;
     const int V4 = V & ~3;
     for (int v = threadIdx.x * 4; v < V4; v += 1024) {
-        f32x4 x = *reinterpret_cast<const f32x4*>(row + v);
-        mx = fmaxf(fmaxf(mx, fmaxf(x[0], x[1])), fmaxf(x[2], x[3]));
-    }
-    for (int v = V4 + threadIdx.x; v < V; v += 256) mx = fmaxf(mx, row[v]);
-    mx = block_max(mx, sh);
-    float sm = 0.f;
-    for (int v = threadIdx.x * 4; v < V4; v += 1024) {
-        f32x4 x = *reinterpret_cast<const f32x4*>(row + v);
+        const f32x4 x = *reinterpret_cast<const f32x4*>(row + v);
+        const float m4 = fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3]));
+        if (m4 > mx) { sm *= expf(mx - m4); mx = m4; }
         sm += expf(x[0] - mx) + expf(x[1] - mx) + expf(x[2] - mx) + expf(x[3] - mx);
     }
-    for (int v = V4 + threadIdx.x; v < V; v += 256) sm += expf(row[v] - mx);
-    sm = block_sum(sm, sh);
+    for (int v = V4 + threadIdx.x; v < V; v += 256) {
+        const float x = row[v];
+        if (x > mx) { sm *= expf(mx - x); mx = x; }
+        sm += expf(x - mx);
+    }
+    const float gmx = block_max(mx, sh);
+    sm = block_sum(mx == -INFINITY ? 0.f : sm * expf(mx - gmx), sh);
+    mx = gmx;
     if (threadIdx.x == 0) {
         const float l = mx + logf(sm);
         lse[m] = l;
@@ -119,7 +122,15 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__
     T* drow = dlogits + m * ldd;
     const bool active = t + 1 < Tt && (t >= P || lm_coef != 0.f);
     if (!active) {
-        for (int v = threadIdx.x; v < Vpad; v += 256) drow[v] = (T)0.f;
+        if ((Vpad & 7) == 0 && (ldd & 7) == 0) {
+            typedef typename Vec16<T>::type V16;
+            V16 z;
+#pragma unroll
+            for (int e = 0; e < Vec16<T>::N; ++e) z[e] = (T)0.f;
+            for (int v = threadIdx.x * Vec16<T>::N; v < Vpad; v += 256 * Vec16<T>::N) *reinterpret_cast<V16*>(drow + v) = z;
+        } else {
+            for (int v = threadIdx.x; v < Vpad; v += 256) drow[v] = (T)0.f;
+        }
         return;
     }
     const float* row = logits + m * ldl;
@@ -127,6 +138,30 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__
     long long lab = label_of(topic_ids, targets, b, t + 1, P, L, 0);
     if (lab < 0) lab = 0;
     if (lab >= V) lab = V - 1;
+    const bool vec = (Vpad & 7) == 0 && (ldl & 3) == 0 && (ldd & 7) == 0;
+    if (vec) {
+        for (int v = threadIdx.x * 8; v < Vpad; v += 2048) {
+            float d[8];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                f32x4 x = {0.f, 0.f, 0.f, 0.f};
+                if (v + 4 * h < ldl) x = *reinterpret_cast<const f32x4*>(row + v + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int vv = v + 4 * h + e;
+                    d[4 * h + e] = vv < V ? cf * (expf(x[e] - l) - (vv == (int)lab ? 1.f : 0.f)) : 0.f;
+                }
+            }
+            if constexpr (sizeof(T) == 2) {
+                bf16x8 o = {(bf16)d[0], (bf16)d[1], (bf16)d[2], (bf16)d[3], (bf16)d[4], (bf16)d[5], (bf16)d[6], (bf16)d[7]};
+                *reinterpret_cast<bf16x8*>(drow + v) = o;
+            } else {
+                *reinterpret_cast<f32x4*>(drow + v) = f32x4{d[0], d[1], d[2], d[3]};
+                *reinterpret_cast<f32x4*>(drow + v + 4) = f32x4{d[4], d[5], d[6], d[7]};
+            }
+        }
+        return;
+    }
     for (int v = threadIdx.x; v < Vpad; v += 256) {
         float d = 0.f;
         if (v < V) d = cf * (expf(row[v] - l) - (v == (int)lab ? 1.f : 0.f));

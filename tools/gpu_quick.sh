@@ -1,2 +1,3 @@
 #!/bin/bash
-for v in 1 0; do echo "== attn split $v"; MMTG_DECODE_ATTN_SPLIT=$v timeout 600 python bench.py --mode decode --no-cpu-baseline 2>&1 | tail -1 | grep -o '"us_per_token_step": [0-9.]*'; done
+timeout 900 python -m pytest tests/test_ops_gpu.py tests/test_model_gpu.py -m gpu -q --no-header -p no:cacheprovider -k "loss or model or train" 2>&1 | tail -3
+timeout 900 python bench.py --no-cpu-baseline 2>&1 | tail -1 | grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*\|"loss": [0-9.]*'
