@@ -68,12 +68,15 @@ if os.environ.get("PMC"):
 if os.environ.get("TNSWEEP"):
     for K in (64, 256, 1024, 4096, 15104):
         case("TN 3072x768 s=1 K-sweep", 4 * D, D, K, True, False, hip.EPI_ATOMIC, 1)
-    for s_ in (1, 2, 3, 4, 6, 8):
+    wide = (1, 2, 3, 4, 5, 6, 7, 8, 10, 12) if os.environ.get("SWEEPWIDE") else None
+    for s_ in wide or (1, 2, 3, 4, 6, 8):
         case("TN 3072x768 K=15104 s=%d" % s_, 4 * D, D, M, True, False, hip.EPI_ATOMIC, s_)
-    for s_ in (1, 2, 3, 4):
+    for s_ in wide or (1, 2, 3, 4):
         case("TN 13440x768 K=15104 s=%d" % s_, V, D, M, True, False, hip.EPI_ATOMIC, s_)
-    for s_ in (3, 4, 5, 8):
+    for s_ in wide or (3, 4, 5, 8):
         case("TN 768x2304 K=15104 s=%d" % s_, D, 3 * D, M, True, False, hip.EPI_ATOMIC, s_)
+    for s_ in wide or ():
+        case("TN 768x768 K=15104 s=%d" % s_, D, D, M, True, False, hip.EPI_ATOMIC, s_)
     sys.exit(0)
 if os.environ.get("KSWEEP"):
     for K in (64, 128, 256, 512, 768, 1536, 3072):
