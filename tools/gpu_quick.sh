@@ -1,4 +1,2 @@
 #!/bin/bash
-timeout 600 python -m pytest tests/test_ops_gpu.py -m gpu -q --no-header -p no:cacheprovider -k "gemm_layouts or weight_gradient" 2>&1 | tail -3
-echo "== 256x128 weight-gradient kernel (flags=512), cold"; COLD=1 FLAGS=512 TNSWEEP=1 SWEEPWIDE=1 timeout 900 python tools/bench_gemm.py 2>&1 | grep "K=15104 s="
-echo "== 128x128 (flags=0), cold"; COLD=1 TNSWEEP=1 timeout 900 python tools/bench_gemm.py 2>&1 | grep "K=15104 s="
+for st in "0,0,0" "256,512,1" "256,512,2" "256,512,3" "0,512,2"; do echo "== stagger $st"; MMTG_STAGGER=$st KSWEEP=1 timeout 300 python tools/bench_gemm.py 2>&1 | grep "N=3072 K-sweep" | grep "K=   768\|K=  3072"; MMTG_STAGGER=$st timeout 100 python tools/gemm_timeline.py 15104 3072 768 NT 0 128 2>&1 | grep "span\|starts"; done
