@@ -62,6 +62,9 @@ enum {
                                  measured on par with the plain launch */
 #define MMTG_GEMM_NO_PERSIST 128 /* flags: reserved (the persistent kernel is never picked automatically) */
 #define MMTG_GEMM_ROW_ORDER 256  /* flags: weight gradients keep the tile_n-fastest item order (A/B measurements) */
+#define MMTG_GEMM_OCC4 512       /* flags: force the single-stage 128x128 kernel, four workgroups per CU (bf16); automatic for
+                                    weight gradients and for forward / dgrad products of more than 2 x CUs tiles */
+#define MMTG_GEMM_NO_OCC4 1024   /* flags: never pick it automatically (A/B measurements) */
 
 /* profiling categories (mmtg_prof_*) */
 enum {

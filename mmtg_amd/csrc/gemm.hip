@@ -276,7 +276,7 @@ __global__ __launch_bounds__((64 * WM * WN), (DmaCfg<TBM, TBN, WM, WN, NBUF>::MI
     // MMTG_EPI_SPLIT: K split s stores its raw partial product in slab s of the fp32 output
     if constexpr (!std_orient) p.C = reinterpret_cast<char*>(p.C) + (long)split * p.split_stride;
     // (the 6-wave configuration has to stay within 128 VGPRs: aux vectors one band ahead, not all four)
-    gemm_epilogue<T, std_orient, TM, TN, (WM * WN > 4 ? 1 : TM)>(p, acc, m0 + wm * WTM, n0 + wn * WTN, g, l15,
+    gemm_epilogue<T, std_orient, TM, TN, (WM * WN > 4 ? -1 : TM)>(p, acc, m0 + wm * WTM, n0 + wn * WTN, g, l15,
                                          smem + wave * epi_scratch_bytes<TM, TN>(), lane);
     if (tr && wave == 0 && (int)blockIdx.x < p.trace_n) {
         wait_vmcnt<0>();                       // the output stores are part of the epilogue's time
@@ -476,6 +476,102 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(GemmArgs p) {
 #undef PP_ISSUE
 }
 
+// ------------------------------------------------------------------ single-stage, 4-workgroups-per-CU kernel
+// One 32 KB LDS stage per workgroup and <= 128 VGPRs: four 128x128 workgroups share a CU (four waves
+// per SIMD).  A workgroup does not overlap its own DMA with its MFMAs at all -- the other three do.
+// (Bare-MFMA probe: the matrix pipe needs several waves per SIMD with MFMAs ready; two per SIMD that
+// each alternate 16 fragment reads / 32 MFMAs leave it at ~32 cycles per MFMA.)
+// (waves per SIMD the forward / dgrad instantiations are compiled for: their staged epilogue with
+//  prefetched aux vectors and the dGELU column sums does not fit 128 VGPRs without spilling)
+#ifndef OCC_FWD
+#define OCC_FWD 3
+#endif
+template <bool AKS, bool BKS>
+__global__ __launch_bounds__(256, (AKS && BKS ? 4 : OCC_FWD)) void gemm_occ4_kernel(GemmArgs p) {
+    typedef bf16 T;
+    constexpr int TBM = 128, TBN = 128, NW = 4, TM = 4, TN = 4, BK = 64, NB = 4;
+    constexpr int TA = TBM * 128;
+    constexpr bool std_orient = AKS && BKS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, l15 = lane & 15;
+    const int wm = wave >> 1, wn = wave & 1;
+    int m0, n0, split;
+    tile_origin(p, blockIdx.x, gridDim.x, m0, n0, split, TBM, TBN);
+    const int kbeg = split * p.kper;
+    const int klen = min(p.K, kbeg + p.kper) - kbeg;
+    const int nk = (klen + BK - 1) / BK, nk_full = klen / BK;
+    int oa[TM], ob[TN];
+    if constexpr (AKS) ks_offsets<TBM, TM>(wm * 64, lane, oa);
+    if constexpr (BKS) ks_offsets<TBN, TN>(wn * 64, lane, ob);
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, p.bytesA, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, p.bytesB, 0x00020000);
+    int sa = (int)((AKS ? ((long)kbeg * p.lda + m0) : ((long)m0 * p.lda + kbeg)) * 2);
+    int sb = (int)((BKS ? ((long)kbeg * p.ldb + n0) : ((long)n0 * p.ldb + kbeg)) * 2);
+    const int stepa = (int)((AKS ? (long)BK * p.lda : (long)BK) * 2);
+    const int stepb = (int)((BKS ? (long)BK * p.ldb : (long)BK) * 2);
+    int va[NB], vb[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        va[i] = dma_voff<AKS, TBM>(p.lda, m0, p.M, BK, wave + NW * i, lane);
+        vb[i] = dma_voff<BKS, TBN>(p.ldb, n0, p.N, BK, wave + NW * i, lane);
+    }
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt) __builtin_amdgcn_s_barrier();      // every wave is done reading the previous tile
+        {   // (inline, not dma_issue_tile: a second kernel instantiating that helper with the same
+            //  arguments trips hipcc's host pass)
+            const bool full = kt < nk_full;
+            const int krem = klen - kt * BK;
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int v = full ? va[i] : dma_voff<AKS, TBM>(p.lda, m0, p.M, krem, wave + NW * i, lane);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, LDS_PTR(void, smem + (wave + NW * i) * 1024), 16, v, sa, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int v = full ? vb[i] : dma_voff<BKS, TBN>(p.ldb, n0, p.N, krem, wave + NW * i, lane);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, LDS_PTR(void, smem + TA + (wave + NW * i) * 1024), 16, v, sb, 0, 0);
+            }
+        }
+        sa += stepa;
+        sb += stepb;
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();              // the tile is complete
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                if constexpr (!AKS) fa[i] = ld_frag_kc<T>(smem, wm * 64 + i * 16 + l15, kk, g);
+                else fa[i] = tr_read_pair(smem, oa[i] + kk * 32 * 2 * TBM, oa[i] + kk * 32 * 2 * TBM + 4 * 2 * TBM);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if constexpr (!BKS) fb[j] = ld_frag_kc<T>(smem + TA, wn * 64 + j * 16 + l15, kk, g);
+                else fb[j] = tr_read_pair(smem + TA, ob[j] + kk * 32 * 2 * TBN, ob[j] + kk * 32 * 2 * TBN + 4 * 2 * TBN);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if constexpr (std_orient) mma16(fa[i], fb[j], acc[i][j]);
+                    else mma16(fb[j], fa[i], acc[i][j]);
+                }
+        }
+    }
+    if constexpr (!std_orient) {
+        __builtin_amdgcn_s_barrier();
+        p.C = reinterpret_cast<char*>(p.C) + (long)split * p.split_stride;     // MMTG_EPI_SPLIT slab
+    }
+    gemm_epilogue<T, std_orient, TM, TN, 1>(p, acc, m0 + wm * 64, n0 + wn * 64, g, l15, smem + wave * epi_scratch_bytes<TM, TN>(), lane);
+}
+
 // ------------------------------------------------------------------ launch
 int num_cus() {
     static int n = 0;
@@ -565,7 +661,30 @@ int launch_pp(const GemmArgs& a, int splits, hipStream_t stream) {
     return MMTG_OK;
 }
 
+template <bool AKS, bool BKS>
+int launch_occ4(const GemmArgs& a, int splits, hipStream_t stream) {
+    static bool attr_done = false;
+    const size_t shm = (128 + 128) * 128;
+    if (!attr_done) {
+        int rc = set_lds(gemm_occ4_kernel<AKS, BKS>, shm, 256, "single-stage 128x128, 4 per CU");
+        if (rc) return rc;
+        attr_done = true;
+    }
+    GemmArgs b = a;
+    b.tiles_n = cdiv(a.N, 128);
+    b.ntiles = cdiv(a.M, 128) * b.tiles_n;
+    b.nitems = b.ntiles * splits;
+    b.tiles_m_fast = AKS && BKS && b.tiles_n > cdiv(a.M, 128);
+    hipLaunchKernelGGL((gemm_occ4_kernel<AKS, BKS>), dim3(b.nitems), dim3(256), shm, stream, b);
+    return MMTG_OK;
+}
+
 int launch_dma(const GemmArgs& a, int transA, int transB, int splits, int skinny, int wide, int persist, hipStream_t stream) {
+    if (a.dbg_flags & 2) {
+        if (!transA && transB) return launch_occ4<false, false>(a, splits, stream);
+        if (!transA && !transB) return launch_occ4<false, true>(a, splits, stream);
+        return launch_occ4<true, true>(a, splits, stream);
+    }
     if (persist && !wide && !skinny) {
         if (!transA && transB) return launch_pp<false, false>(a, splits, stream);
         if (!transA && !transB) return launch_pp<false, true>(a, splits, stream);
@@ -634,7 +753,7 @@ extern "C" int mmtg_gemm(int dtype, int transA, int transB, int M, int N, int K,
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldaux = ldaux;
     a.epi = epi; a.out_f32 = out_f32; a.use_tr = !(flags & MMTG_GEMM_NO_TR);
     a.trace = g_trace; a.trace_n = g_trace_n;
-    a.dbg_flags = (flags & MMTG_GEMM_ROW_ORDER) ? 1 : 0;
+    a.dbg_flags = (flags & MMTG_GEMM_ROW_ORDER) ? 1 : 0;     // bit 1 (value 2): single-stage kernel, set below
     a.tiles_n = cdiv(N, BN); a.alpha = alpha;
     // byte extents for the buffer descriptors of the LDS-DMA pipeline (offsets are 32-bit)
     const long esz = dtype == MMTG_F32 ? 4 : 2;
@@ -679,6 +798,15 @@ extern "C" int mmtg_gemm(int dtype, int transA, int transB, int M, int N, int K,
         // within +-3 % of the plain launch (its deferred epilogue still occupies the wave for 2.8-7 us per
         // item; timelines in profiles/r01_v4_gemm_timeline.log).
         const bool persist = (flags & MMTG_GEMM_PERSIST) != 0;
+        // Single-stage kernel at four workgroups per CU (measured, profiles/r01_v6_gemm_per_shape.log):
+        // weight gradients always (with the split counts of engine._wgrad_splits), forward / dgrad
+        // products whose 128x128 tiles make more than one round of the 2-per-CU kernel (qkv 84 -> 68 us,
+        // fc1+GELU 120 -> 103, dGELU 106 -> 94); the one-round 192x128 and the small-M cases keep theirs.
+        static const bool env_no_occ4 = getenv("MMTG_GEMM_NO_OCC4") != nullptr;      // A/B switch for whole-step runs
+        if (!(flags & MMTG_GEMM_NO_OCC4) && !env_no_occ4 && !persist && !skinny && !(flags & MMTG_GEMM_WIDE)) {
+            const long t128 = (long)cdiv(M, 128) * cdiv(N, 128);
+            if (transA || (flags & MMTG_GEMM_OCC4) || (!wide && t128 > 2L * num_cus())) a.dbg_flags |= 2;
+        }
         rc = launch_dma(a, transA, transB, splits, skinny && !transA && transB, wide, persist, s);
     }
     if (rc) return rc;

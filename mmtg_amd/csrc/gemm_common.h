@@ -276,7 +276,10 @@ __device__ __forceinline__ void epi_tiles(const GemmArgs& p, f32x4 (&acc)[TM][TN
     if (p.bias && nok) load8<float>(p.bias + n, b8);
     typedef typename Vec16<T>::type V;
     constexpr int VPA = 8 / Vec16<T>::N;       // 16-byte vectors per 8 elements (bf16: 1, f32: 2)
-    constexpr int RING = PFD + 1 < TM ? PFD + 1 : TM;     // bands of aux vectors held at once
+    // |PFD| = bands of aux vectors requested ahead; PFD < 0 additionally drops the DGELU column sums
+    // (the register-capped 6-wave configuration)
+    constexpr int DEPTH = PFD < 0 ? -PFD : PFD;
+    constexpr int RING = DEPTH + 1 < TM ? DEPTH + 1 : TM;     // bands of aux vectors held at once
     V ax[HAS_AUX ? RING * NQ * VPA : 1];
     // (clamped address: rows past M are loaded from row M-1 and never stored)
 #define EPI_LOAD_BAND(hb)                                                                                   \
@@ -291,7 +294,7 @@ __device__ __forceinline__ void epi_tiles(const GemmArgs& p, f32x4 (&acc)[TM][TN
     }
     // DGELU: column sums of this lane's 8 columns (not in the register-capped 6-wave configuration,
     // PFD < TM, which the host never picks for a DGELU product with aux2)
-    constexpr bool COLSUM = EPI == MMTG_EPI_DGELU && PFD >= TM;
+    constexpr bool COLSUM = EPI == MMTG_EPI_DGELU && PFD > 0;
     float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int h = 0; h < TM; ++h) {

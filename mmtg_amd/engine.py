@@ -157,13 +157,24 @@ def gaussian_prior(S):
     return np.stack(rows)
 
 
-def _wgrad_splits(M, N, K, slots=512, t_iter=1.1, t_fixed=6.0):
+import os as _os
+_NO_OCC4 = bool(_os.environ.get("MMTG_GEMM_NO_OCC4"))     # A/B switch, mirrors the library's
+
+
+def _wgrad_splits(M, N, K, occ4=False, slots=512, t_iter=1.1, t_fixed=6.0):
     """Split-K factor of a weight-gradient GEMM (K = tokens).  The 128x128-tile kernel keeps two
     workgroups per CU (512 slots on 256 CUs); a grid of tiles*s workgroups runs in
     ceil(tiles*s/512) rounds of (K/(64 s)) K-iterations each.  Pick the s with the smallest
     estimate -- e.g. 144 tiles: s=3 (432 WGs, one round) beats s=4 (576 WGs, two rounds) by 30 %
     on the GPU (profiles/r01_gemm_tn_split_sweep.log)."""
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    if occ4 and not _NO_OCC4:
+        # bf16: the single-stage kernel keeps FOUR workgroups per CU (1024 slots) and is throughput-bound,
+        # so only the fill of the last round and the atomic volume matter.  Measured optima
+        # (profiles/r01_v6_gemm_tn_split_sweep.log): 144 tiles -> 5, 108 -> 6..7, 630 -> 4, 36 -> 8+.
+        smax = max(1, K // 256)
+        s = round(760.0 / tiles) if tiles < 512 else round(2520.0 / tiles)
+        return int(max(1, min(smax, s, 12)))
     best, best_t = 1, None
     for s in range(1, 33):
         if s > 1 and K // s < 256:
@@ -326,11 +337,11 @@ class Engine:
         if kind == "linear":
             out_f, in_f = gw.shape
             hip.gemm(dy, x, gw, out_f, in_f, Mtok, transA=True, transB=False, lda=ldy or out_f, ldb=ldx or in_f,
-                     ldc=in_f, epi=hip.EPI_ATOMIC, splits=_wgrad_splits(out_f, in_f, Mtok))
+                     ldc=in_f, epi=hip.EPI_ATOMIC, splits=_wgrad_splits(out_f, in_f, Mtok, self.dtype == hip.BF16))
         else:
             in_f, out_f = gw.shape
             hip.gemm(x, dy, gw, in_f, out_f, Mtok, transA=True, transB=False, lda=ldx or in_f, ldb=ldy or out_f,
-                     ldc=out_f, epi=hip.EPI_ATOMIC, splits=_wgrad_splits(in_f, out_f, Mtok))
+                     ldc=out_f, epi=hip.EPI_ATOMIC, splits=_wgrad_splits(in_f, out_f, Mtok, self.dtype == hip.BF16))
         if bkey is not None:
             hip.colsum(dy, Mtok if bias_rows is None else bias_rows, out_f, self.G(bkey), ldx=ldy or out_f)
 
@@ -562,7 +573,7 @@ class Engine:
         hip.gemm(dlogits, self.Wp("wte"), dhf, M, D, Vp, transB=False, ldb=D)
         # (Vpad rows: the pad columns of dlogits are zero, so the pad rows of the pack receive +0)
         hip.gemm(dlogits, a["hf"], self.Gp("wte"), Vp, D, M, transA=True, transB=False, lda=Vp, ldb=D, ldc=D,
-                 epi=hip.EPI_ATOMIC, splits=_wgrad_splits(Vp, D, M))
+                 epi=hip.EPI_ATOMIC, splits=_wgrad_splits(Vp, D, M, self.dtype == hip.BF16))
         # Every LayerNorm backward on the residual stream also emits, in the same pass, the
         # dropout-masked gradient entering the previous residual branch and that branch's bias
         # gradient (column sum) -- see mmtg_layernorm_bwd.

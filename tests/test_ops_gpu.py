@@ -49,9 +49,11 @@ def close(got, ref, dtype, k=1, name="", scale=None):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("layout", ["NT", "NN", "TN"])
 @pytest.mark.parametrize("shape", [(200, 136, 96), (712, 768, 512), (1024, 256, 2048)])
-@pytest.mark.parametrize("variant", ["dma2", "wide", "regstage", "no_tr"])
+@pytest.mark.parametrize("variant", ["dma2", "wide", "regstage", "no_tr", "occ4"])
 def test_gemm_layouts(dtype, layout, shape, variant):
     no_tr = variant == "no_tr"
+    if variant == "occ4" and dtype == torch.float32:
+        pytest.skip("the single-stage 4-per-CU kernel is a bf16 configuration")
     if no_tr and (dtype == torch.float32 or layout == "NT"):
         pytest.skip("scalar-gather variant only differs for bf16 K-strided operands")
     if dtype == torch.float32 and variant != "dma2":
@@ -69,7 +71,8 @@ def test_gemm_layouts(dtype, layout, shape, variant):
     else:
         A, B, tA, tB = a.t().contiguous(), b, True, False
     A, B = A.to(DEV), B.to(DEV)
-    flags = {"dma2": hip.GEMM_NO_WIDE, "wide": hip.GEMM_WIDE, "regstage": hip.GEMM_REGSTAGE, "no_tr": hip.GEMM_NO_TR}[variant]
+    flags = {"dma2": hip.GEMM_NO_WIDE | hip.GEMM_NO_OCC4, "wide": hip.GEMM_WIDE, "regstage": hip.GEMM_REGSTAGE,
+             "no_tr": hip.GEMM_NO_TR, "occ4": hip.GEMM_OCC4 | hip.GEMM_NO_WIDE}[variant]
     if layout == "TN":
         for splits in (1, 3):
             Cf = torch.full((M, N), 0.5, device=DEV, dtype=torch.float32)
@@ -145,6 +148,13 @@ def test_gemm_epilogues(dtype):
         pre_w = torch.empty(M, N, device=DEV, dtype=dtype)
         close(run(hip.EPI_GELU, bias=bias, aux2=pre_w, flags=hip.GEMM_WIDE), O.gelu_new(lin), dtype, K, "wide gelu")
         close(run(hip.EPI_RESID, bias=bias, aux=aux, flags=hip.GEMM_WIDE), lin + aux.float(), dtype, K, "wide resid")
+        # ... and the single-stage 4-per-CU kernel (its epilogue requests aux one band ahead)
+        f4 = hip.GEMM_OCC4
+        close(run(hip.EPI_GELU, bias=bias, aux2=pre_w, flags=f4), O.gelu_new(lin), dtype, K, "occ4 gelu")
+        close(run(hip.EPI_RESID, bias=bias, aux=aux, flags=f4), lin + aux.float(), dtype, K, "occ4 resid")
+        b4 = torch.full(((M + 63) // 64, N), float("nan"), device=DEV, dtype=torch.float32)
+        d4 = run(hip.EPI_DGELU, aux=aux, aux2=b4, flags=f4)
+        close(b4.sum(0), d4.float().sum(0), torch.float32, M, "occ4 dgelu column sums")
     close(run(hip.EPI_NONE, bias=bias), lin, dtype, K, "bias")
     close(run(hip.EPI_NONE, bias=bias, out_f32=True, odt=torch.float32), lin, torch.float32 if dtype == torch.float32 else dtype, K, "out_f32")
     close(run(hip.EPI_TANH, bias=bias), torch.tanh(lin), dtype, K, "tanh")

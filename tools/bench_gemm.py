@@ -98,7 +98,8 @@ case("dgrad proj (NT)", M, D, D, False, True)
 case("dgrad qkv (NT)", M, D, 3 * D, False, True)
 case("dgrad lm head (NN)", M, D, V, False, False)
 for nm, a, b in (("wgrad fc2", 4 * D, D), ("wgrad fc1", D, 4 * D), ("wgrad proj", D, D), ("wgrad qkv", D, 3 * D), ("wgrad lm head", V, D), ("wgrad proj1", 512, 2048)):
-    case(nm + " (TN,atomic s=%d)" % ws(a, b, M), a, b, M, True, False, hip.EPI_ATOMIC, ws(a, b, M))
+    occ4 = not (FLAGS & hip.GEMM_NO_OCC4)
+    case(nm + " (TN,atomic s=%d)" % ws(a, b, M, occ4), a, b, M, True, False, hip.EPI_ATOMIC, ws(a, b, M, occ4))
     case(nm + " (TN,atomic s=1)", a, b, M, True, False, hip.EPI_ATOMIC, 1)
 tot = sum(r[4] for r in rows)
 print("sum %.1f us" % tot)
