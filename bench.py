@@ -231,7 +231,7 @@ def main():
         g = prof["gemm_bf16" if args.dtype == "bf16" else "gemm_f32"]
         peak = 2500.0 if args.dtype == "bf16" else 157.3
         ach = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
-        roof = {"bound": "mfma", "kernel": ("gemm_dma_kernel<bf16>" if args.dtype == "bf16" else "gemm_kernel<f32>"), "achieved": round(ach, 2), "peak": peak,
+        roof = {"bound": "mfma", "kernel": ("gemm_occ4_kernel / gemm_dma_kernel <bf16> (all instantiations)" if args.dtype == "bf16" else "gemm_kernel<f32>"), "achieved": round(ach, 2), "peak": peak,
                 "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
                 "launches_per_step": g["launches"] // args.steps,
                 "avg_launch_us": round(1e3 * g["ms"] / max(1, g["launches"]), 2),
@@ -241,12 +241,12 @@ def main():
         # figure is the committed rocprofv3 --pmc measurement of this same program (tools/gpu_pmc_bench.sh),
         # reported only for the configuration it was taken on; algorithmic bytes (A + B + C once) beside it.
         roof["algorithmic_bytes_per_launch"] = round(g["bytes"] / max(1, g["launches"]))
-        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_v5_bench_pmc_gemm_traffic.json")
+        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_v6_bench_pmc_gemm_traffic.json")
         if args.dtype == "bf16" and B == 64 and args.layers == 12 and os.path.exists(pmc):
             with open(pmc) as fh:
                 m = json.load(fh)
             roof["traffic"] = m["hbm_bytes_per_launch"]
-            roof["traffic_source"] = "profiles/r01_v5_bench_pmc_gemm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, per launch)"
+            roof["traffic_source"] = "profiles/r01_v6_bench_pmc_gemm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, per launch)"
         fwd_tok, enc = algorithmic_flops_per_token(S, T, gcfg["n_embd"], gcfg["n_layer"], V)
         step_flops = 3.0 * (fwd_tok * B * T + enc * B)
         roof["whole_step_tflops_per_gpu"] = round(step_flops / (ms_step * 1e-3) / 1e12, 2)
