@@ -74,8 +74,12 @@ template <typename T> __device__ __forceinline__ typename Vec16<T>::type zero16(
 }
 
 // ======================================================================== forward
+// (waves per SIMD the forward kernel is compiled for; 4 = at most 128 VGPRs, four workgroups per CU)
+#ifndef ATTN_FWD_WAVES
+#define ATTN_FWD_WAVES 4
+#endif
 template <typename T>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv, const int* __restrict__ keep,
+__global__ __launch_bounds__(256, ATTN_FWD_WAVES) void attn_fwd_kernel(const T* __restrict__ qkv, const int* __restrict__ keep,
         T* __restrict__ out, float* __restrict__ lse, int Tn, int nH,
         uint32_t drop_thresh, uint32_t drop_seed, float inv_keep) {
     typedef typename Vec16<T>::type V;
@@ -85,7 +89,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
     __shared__ int sKeep[64];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
-    const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int qb = gridDim.x - 1 - blockIdx.x, h = blockIdx.y, b = blockIdx.z;   // longest (most key blocks) first
     const int D = nH * DH;
     const long ld = 3L * D;
     const T* base = qkv + (long)b * Tn * ld + h * DH;

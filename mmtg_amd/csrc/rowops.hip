@@ -175,8 +175,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
 // chunks hl, hl+32, ... of the row: 512 contiguous bytes per load instruction and half), so a wave
 // has two rows in flight and every access is a full dwordx4.  Same partial-row workspace and
 // finalize kernel as v1.  NC = chunks per lane (cols <= 32 * NC * 16/sizeof(T)).
+#ifndef LN_BWD_WAVES
+#define LN_BWD_WAVES 2      // waves per SIMD the kernel is compiled for (3 = register cap 168 spills 35 VGPRs at NC = 3)
+#endif
 template <typename T, int NC>
-__global__ __launch_bounds__(256) void ln_bwd2_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+__global__ __launch_bounds__(256, LN_BWD_WAVES) void ln_bwd2_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                       const float* __restrict__ gamma, const float* __restrict__ mean,
                                                       const float* __restrict__ rstd, const T* __restrict__ dres,
                                                       T* __restrict__ dx, T* __restrict__ dxm, float* __restrict__ ws,
