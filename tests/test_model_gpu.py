@@ -222,3 +222,60 @@ def test_training_mode_dropout_runs_and_is_finite():
         assert np.isfinite(v)
         l0 = v if l0 is None else l0
     assert all(torch.isfinite(p).all() for p in model2.parameters())
+
+
+# ------------------------------------------------------------------ full-size properties (BASELINE configs[1])
+def _full_model(dtype="bf16", pdrop=0.0):
+    from mmtg_amd import synth
+    from mmtg_amd.configs import data_config, gpt2_config, make_model_cfgs
+    S, V = 5, 13317
+    mcfg, dcfg = make_model_cfgs(seq_len=S), data_config(seq_len=S)
+    gcfg = gpt2_config(n_layer=12, vocab_size=V, embd_pdrop=pdrop, attn_pdrop=pdrop, resid_pdrop=pdrop)
+    model = MMTG(mcfg, dcfg, V, train_flag=True, gpt2_config=gcfg, compute_dtype=dtype, token_table=synth.make_token_table(V, seed=2))
+    model.reset_parameters(seed=0)
+    model.to(DEV)
+    nb = synth.make_batch(16, mcfg, dcfg, V, seed=5)
+    return model, {k: torch.from_numpy(np.asarray(v)).to(DEV) for k, v in nb.items()}
+
+
+def _grad_of(eng, rows, batch, n_global, alpha=0.2):
+    b = {k: v[rows] for k, v in batch.items()}
+    eng.forward(b, train_flag=True, training=False)
+    sc = eng.loss(b["rating"], 3, batch_den=n_global)
+    dl = eng.loss_backward(1.0)
+    eng.backward(dl, dkl=alpha * len(rows) / n_global)
+    return float(sc[0])
+
+
+def test_full_size_gradient_is_additive_over_row_shards():
+    """Full 12-layer / V=13317 / T=236 model, bf16, dropout off: the gradient of 16 rows equals the sum of
+    the gradients of two 8-row shards that are pre-scaled by the GLOBAL row count -- the property the
+    data-parallel path (one process per GPU, SUM all-reduce) relies on, at a size the CPU oracle cannot reach.
+    Differences come only from fp32 summation order (split-K atomics) and the two shards' separate bf16
+    roundings of the bias-gradient partial sums."""
+    model, batch = _full_model()
+    eng = model.engine()
+    eng.zero_grad()
+    _grad_of(eng, list(range(16)), batch, 16)
+    g_full = eng.grad.clone()
+    eng.zero_grad()
+    l_a = _grad_of(eng, list(range(8)), batch, 16)
+    l_b = _grad_of(eng, list(range(8, 16)), batch, 16)
+    g_sum = eng.grad
+    assert np.isfinite(l_a) and np.isfinite(l_b)
+    cos = float(torch.nn.functional.cosine_similarity(g_full, g_sum, dim=0))
+    rel = float((g_full - g_sum).norm() / g_full.norm())
+    assert cos > 0.99999 and rel < 2e-3, (cos, rel)
+
+
+def test_full_size_training_reduces_the_loss_and_modes_agree():
+    """Same model: (a) the first bf16 step's loss is within 2e-3 relative of the exact-fp32 mode's on the same
+    batch; (b) five clip+AdamW steps on one fixed batch (lr 1e-4, dropout off) lower the MyLoss value."""
+    model, batch = _full_model("bf16")
+    tr = MMTGTrainer(model, lr=1e-4, alpha=0.2)
+    losses = [float(tr.step(batch, stage=3)["loss"]) for _ in range(5)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+    m32, _ = _full_model("f32")
+    tr32 = MMTGTrainer(m32, lr=1e-4, alpha=0.2)
+    l32 = float(tr32.step(batch, stage=3)["loss"])
+    assert abs(losses[0] - l32) <= 2e-3 * abs(l32), (losses[0], l32)
