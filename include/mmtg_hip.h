@@ -230,6 +230,12 @@ int mmtg_cast_f32_to(int dtype, const float* src, void* dst, long n, void* strea
 int mmtg_cast_pad_rows(int dtype, const float* src, long lds_, void* dst, long ldd, int rows, int cols, void* stream);
 int mmtg_cast_to_f32(int dtype, const void* src, float* dst, long n, void* stream);
 int mmtg_axpy_f32(float* y, const float* x, float a, long n, void* stream);
+/* Second half of a weight-gradient product computed as K-split slabs (mmtg_gemm with transA = 1 and
+ * MMTG_EPI_SPLIT: slab s = fp32 [M, ldc] at C + s * M * ldc): dst[i] (+)= sum_s part[s * stride + i],
+ * slabs added in order -- the deterministic replacement of the fp32-atomic epilogue for the autograd
+ * weight gradients of nn.Linear / Conv1D (model.py:77-79,134-136,199,279-281 and the GPT-2 products).
+ * n and stride in floats, multiples of 4; accumulate = 0 overwrites dst.                              */
+int mmtg_slab_sum(const float* part, int splits, long stride, float* dst, int accumulate, long n, void* stream);
 /* Batched transpose (bf16 mode keeps K-contiguous [out,in] copies of GPT-2's Conv1D [in,out] weights
  * so that forward products run in the NT layout): matrix i = [rows, cols] row-major at src + desc[4i]
  * elements -> [cols, rows] at dst + desc[4i+3]; desc = n x {src_off, rows, cols, dst_off} (long, device);

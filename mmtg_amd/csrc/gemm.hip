@@ -486,12 +486,15 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(GemmArgs p) {
 #ifndef OCC_FWD
 #define OCC_FWD 3
 #endif
-template <bool AKS, bool BKS>
+// SLAB (weight gradients only): instead of fp32 atomics, K split s stores its partial tile with plain
+// 16-byte stores into slab s of an fp32 workspace (MMTG_EPI_SPLIT); mmtg_slab_sum adds the slabs up.
+template <bool AKS, bool BKS, bool SLAB = false>
 __global__ __launch_bounds__(256, (AKS && BKS ? 4 : OCC_FWD)) void gemm_occ4_kernel(GemmArgs p) {
     typedef bf16 T;
-    constexpr int TBM = 128, TBN = 128, NW = 4, TM = 4, TN = 4, BK = 64, NB = 4;
+    constexpr int TBM = 128, TBN = 128, NW = 4, TM = 4, TN = 4, BK = 64;
+    constexpr int NB = TBM / 8 / NW, NBB = TBN / 8 / NW;         // 1-KB DMA blocks per wave: A, B
     constexpr int TA = TBM * 128;
-    constexpr bool std_orient = AKS && BKS;
+    constexpr bool std_orient = AKS && BKS && !SLAB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -511,12 +514,11 @@ __global__ __launch_bounds__(256, (AKS && BKS ? 4 : OCC_FWD)) void gemm_occ4_ker
     int sb = (int)((BKS ? ((long)kbeg * p.ldb + n0) : ((long)n0 * p.ldb + kbeg)) * 2);
     const int stepa = (int)((AKS ? (long)BK * p.lda : (long)BK) * 2);
     const int stepb = (int)((BKS ? (long)BK * p.ldb : (long)BK) * 2);
-    int va[NB], vb[NB];
+    int va[NB], vb[NBB];
 #pragma unroll
-    for (int i = 0; i < NB; ++i) {
-        va[i] = dma_voff<AKS, TBM>(p.lda, m0, p.M, BK, wave + NW * i, lane);
-        vb[i] = dma_voff<BKS, TBN>(p.ldb, n0, p.N, BK, wave + NW * i, lane);
-    }
+    for (int i = 0; i < NB; ++i) va[i] = dma_voff<AKS, TBM>(p.lda, m0, p.M, BK, wave + NW * i, lane);
+#pragma unroll
+    for (int i = 0; i < NBB; ++i) vb[i] = dma_voff<BKS, TBN>(p.ldb, n0, p.N, BK, wave + NW * i, lane);
     f32x4 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -534,7 +536,7 @@ __global__ __launch_bounds__(256, (AKS && BKS ? 4 : OCC_FWD)) void gemm_occ4_ker
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, LDS_PTR(void, smem + (wave + NW * i) * 1024), 16, v, sa, 0, 0);
             }
 #pragma unroll
-            for (int i = 0; i < NB; ++i) {
+            for (int i = 0; i < NBB; ++i) {
                 const int v = full ? vb[i] : dma_voff<BKS, TBN>(p.ldb, n0, p.N, krem, wave + NW * i, lane);
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, LDS_PTR(void, smem + TA + (wave + NW * i) * 1024), 16, v, sb, 0, 0);
             }
@@ -661,21 +663,22 @@ int launch_pp(const GemmArgs& a, int splits, hipStream_t stream) {
     return MMTG_OK;
 }
 
-template <bool AKS, bool BKS>
+template <bool AKS, bool BKS, bool SLAB = false>
 int launch_occ4(const GemmArgs& a, int splits, hipStream_t stream) {
     static bool attr_done = false;
-    const size_t shm = (128 + 128) * 128;
+    constexpr int TBM = 128;
+    const size_t shm = (TBM + 128) * 128;
     if (!attr_done) {
-        int rc = set_lds(gemm_occ4_kernel<AKS, BKS>, shm, 256, "single-stage 128x128, 4 per CU");
+        int rc = set_lds(gemm_occ4_kernel<AKS, BKS, SLAB>, shm, 256, "single-stage 128x128, 4 per CU");
         if (rc) return rc;
         attr_done = true;
     }
     GemmArgs b = a;
     b.tiles_n = cdiv(a.N, 128);
-    b.ntiles = cdiv(a.M, 128) * b.tiles_n;
+    b.ntiles = cdiv(a.M, TBM) * b.tiles_n;
     b.nitems = b.ntiles * splits;
-    b.tiles_m_fast = AKS && BKS && b.tiles_n > cdiv(a.M, 128);
-    hipLaunchKernelGGL((gemm_occ4_kernel<AKS, BKS>), dim3(b.nitems), dim3(256), shm, stream, b);
+    b.tiles_m_fast = AKS && BKS && b.tiles_n > cdiv(a.M, TBM);
+    hipLaunchKernelGGL((gemm_occ4_kernel<AKS, BKS, SLAB>), dim3(b.nitems), dim3(256), shm, stream, b);
     return MMTG_OK;
 }
 
@@ -683,6 +686,7 @@ int launch_dma(const GemmArgs& a, int transA, int transB, int splits, int skinny
     if (a.dbg_flags & 2) {
         if (!transA && transB) return launch_occ4<false, false>(a, splits, stream);
         if (!transA && !transB) return launch_occ4<false, true>(a, splits, stream);
+        if (a.epi == MMTG_EPI_SPLIT) return launch_occ4<true, true, true>(a, splits, stream);
         return launch_occ4<true, true>(a, splits, stream);
     }
     if (persist && !wide && !skinny) {
@@ -729,8 +733,10 @@ extern "C" int mmtg_gemm(int dtype, int transA, int transB, int M, int N, int K,
     // the contiguous extent of every operand tile is read in whole 16-byte chunks
     MMTG_REQUIRE((transA ? M : K) % epc == 0, "gemm: contiguous extent of A (%d) must be a multiple of %d", transA ? M : K, epc);
     MMTG_REQUIRE((transB ? K : N) % epc == 0, "gemm: contiguous extent of B (%d) must be a multiple of %d", transB ? K : N, epc);
-    MMTG_REQUIRE((epi == MMTG_EPI_ATOMIC) == (transA && !transB),
-                 "gemm: the atomic epilogue and the transA=1,transB=0 (weight-gradient) layout go together");
+    const bool wgrad = transA && !transB;
+    MMTG_REQUIRE(epi != MMTG_EPI_ATOMIC || wgrad, "gemm: the atomic epilogue belongs to the transA=1,transB=0 (weight-gradient) layout");
+    MMTG_REQUIRE(!wgrad || epi == MMTG_EPI_ATOMIC || epi == MMTG_EPI_SPLIT,
+                 "gemm: the weight-gradient layout has the atomic and the split (slab) epilogues only");
     if (epi != MMTG_EPI_ATOMIC) {
         MMTG_REQUIRE(N % 8 == 0 && ldc % 8 == 0, "gemm: N and ldc must be multiples of 8 (N=%d ldc=%ld)", N, ldc);
         MMTG_REQUIRE(!bias || MMTG_ALIGNED16(bias), "gemm: bias must be 16-byte aligned");
@@ -760,6 +766,7 @@ extern "C" int mmtg_gemm(int dtype, int transA, int transB, int M, int N, int K,
     const long bytesA = ((long)((transA ? K : M) - 1) * lda + (transA ? M : K)) * esz;
     const long bytesB = ((long)((transB ? N : K) - 1) * ldb + (transB ? K : N)) * esz;
     const bool small = bytesA < 0x7FFFFF00L && bytesB < 0x7FFFFF00L;
+    MMTG_REQUIRE(!(wgrad && epi == MMTG_EPI_SPLIT) || small, "gemm: the weight-gradient slab epilogue needs operands below 2 GiB");
     a.bytesA = (int)(small ? bytesA : 0); a.bytesB = (int)(small ? bytesB : 0);
     const int bk = dtype == MMTG_F32 ? 32 : 64;
     if (splits < 1) splits = 1;
@@ -807,6 +814,7 @@ extern "C" int mmtg_gemm(int dtype, int transA, int transB, int M, int N, int K,
             const long t128 = (long)cdiv(M, 128) * cdiv(N, 128);
             if (transA || (flags & MMTG_GEMM_OCC4) || (!wide && t128 > 2L * num_cus())) a.dbg_flags |= 2;
         }
+        if (wgrad && epi == MMTG_EPI_SPLIT) a.dbg_flags |= 2;      // the slab epilogue lives in the single-stage kernel only
         rc = launch_dma(a, transA, transB, splits, skinny && !transA && transB, wide, persist, s);
     }
     if (rc) return rc;

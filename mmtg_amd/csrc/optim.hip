@@ -60,6 +60,26 @@ __global__ __launch_bounds__(256) void axpy_kernel(float* __restrict__ y, const 
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] += a * x[i];
 }
 
+// Second half of a weight-gradient product stored as K-split slabs (mmtg_gemm, transA, MMTG_EPI_SPLIT):
+// dst[i] (+)= sum_s part[s * stride + i], slabs added in order (deterministic).  One float4 per lane;
+// the slabs were written just before and are still in the Infinity Cache.
+__global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ part, int splits, long stride,
+                                                       float* __restrict__ dst, int accumulate, long n4) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const f4* src = reinterpret_cast<const f4*>(part) + i;
+        f4 acc = accumulate ? reinterpret_cast<const f4*>(dst)[i] : f4{0.f, 0.f, 0.f, 0.f};
+        int s = 0;
+        for (; s + 4 <= splits; s += 4) {
+            const f4 a = src[(s + 0) * (stride / 4)], b = src[(s + 1) * (stride / 4)];
+            const f4 c = src[(s + 2) * (stride / 4)], d = src[(s + 3) * (stride / 4)];
+            acc += a; acc += b; acc += c; acc += d;
+        }
+        for (; s < splits; ++s) acc += src[s * (stride / 4)];
+        reinterpret_cast<f4*>(dst)[i] = acc;
+    }
+}
+
 // Batched matrix transpose (weight-copy maintenance): matrix i is [rows, cols] row-major at
 // src + desc[4i], written as [cols, rows] at dst + desc[4i+3].  One 64x64 tile per workgroup through
 // a padded LDS image; 16-byte global vectors on both sides (rows, cols multiples of 16/sizeof(T)).
@@ -164,6 +184,20 @@ extern "C" int mmtg_axpy_f32(float* y, const float* x, float a, long n, void* st
     ProfScope prof(MMTG_PROF_MISC, s, 2.0 * n, 12.0 * n);
     hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n)), dim3(256), 0, s, y, x, a, n);
     MMTG_LAUNCH_CHECK("axpy");
+    return MMTG_OK;
+}
+
+extern "C" int mmtg_slab_sum(const float* part, int splits, long stride, float* dst, int accumulate, long n, void* stream) {
+    MMTG_REQUIRE(part && dst && splits > 0 && n > 0, "slab_sum: bad args");
+    MMTG_REQUIRE(n % 4 == 0 && stride % 4 == 0 && stride >= n && MMTG_ALIGNED16(part) && MMTG_ALIGNED16(dst),
+                 "slab_sum: n and stride must be multiples of 4 floats, stride >= n, buffers 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(MMTG_PROF_MISC, s, (double)splits * n, 4.0 * n * (splits + 1 + (accumulate ? 1 : 0)));
+    const long n4 = n / 4;
+    long blocks = (n4 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, s, part, splits, stride, dst, accumulate, n4);
+    MMTG_LAUNCH_CHECK("slab_sum");
     return MMTG_OK;
 }
 

@@ -159,6 +159,7 @@ def gaussian_prior(S):
 
 import os as _os
 _NO_OCC4 = bool(_os.environ.get("MMTG_GEMM_NO_OCC4"))     # A/B switch, mirrors the library's
+_WGRAD_SLAB = not _os.environ.get("MMTG_WGRAD_ATOMIC")     # A/B switch: fp32-atomic weight gradients everywhere
 
 
 def _wgrad_splits(M, N, K, occ4=False, slots=512, t_iter=1.1, t_fixed=6.0):
@@ -334,14 +335,26 @@ class Engine:
 
     def _wgrad(self, x, dy, wkey, bkey, Mtok, kind, ldx=None, ldy=None, bias_rows=None):
         gw = self.G(wkey)
-        if kind == "linear":
+        if kind == "linear":    # gw[out,in] += dy^T x
             out_f, in_f = gw.shape
-            hip.gemm(dy, x, gw, out_f, in_f, Mtok, transA=True, transB=False, lda=ldy or out_f, ldb=ldx or in_f,
-                     ldc=in_f, epi=hip.EPI_ATOMIC, splits=_wgrad_splits(out_f, in_f, Mtok, self.dtype == hip.BF16))
-        else:
+            A, B, Mg, Ng, lda, ldb = dy, x, out_f, in_f, ldy or out_f, ldx or in_f
+        else:                   # Conv1D: gw[in,out] += x^T dy
             in_f, out_f = gw.shape
-            hip.gemm(x, dy, gw, in_f, out_f, Mtok, transA=True, transB=False, lda=ldx or in_f, ldb=ldy or out_f,
-                     ldc=out_f, epi=hip.EPI_ATOMIC, splits=_wgrad_splits(in_f, out_f, Mtok, self.dtype == hip.BF16))
+            A, B, Mg, Ng, lda, ldb = x, dy, in_f, out_f, ldx or in_f, ldy or out_f
+        bf = self.dtype == hip.BF16
+        splits = _wgrad_splits(Mg, Ng, Mtok, bf)
+        tiles = ((Mg + 127) // 128) * ((Ng + 127) // 128)
+        if bf and _WGRAD_SLAB and 1 < splits and tiles < 512 and Ng % 8 == 0:
+            # K-split slabs with plain stores + an ordered sum instead of fp32 atomics (deterministic)
+            part = self.buf("wgrad_slabs", (12 * 3072 * 768,), torch.float32)
+            if splits * Mg * Ng <= part.numel():
+                hip.gemm(A, B, part, Mg, Ng, Mtok, transA=True, transB=False, lda=lda, ldb=ldb, ldc=Ng,
+                         epi=hip.EPI_SPLIT, out_f32=True, splits=splits)
+                hip.slab_sum(part, splits, Mg * Ng, gw, Mg * Ng, accumulate=True)
+                splits = 0
+        if splits:
+            hip.gemm(A, B, gw, Mg, Ng, Mtok, transA=True, transB=False, lda=lda, ldb=ldb, ldc=Ng,
+                     epi=hip.EPI_ATOMIC, splits=splits)
         if bkey is not None:
             hip.colsum(dy, Mtok if bias_rows is None else bias_rows, out_f, self.G(bkey), ldx=ldy or out_f)
 

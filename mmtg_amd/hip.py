@@ -57,6 +57,7 @@ _SIGS = {
     "mmtg_cast_pad_rows": ([_i, _vp, _l, _vp, _l, _i, _i, _vp], _i),
     "mmtg_cast_to_f32": ([_i, _vp, _vp, _l, _vp], _i),
     "mmtg_axpy_f32": ([_vp, _vp, _f, _l, _vp], _i),
+    "mmtg_slab_sum": ([_vp, _i, _l, _vp, _i, _l, _vp], _i),
     "mmtg_transpose_batch": ([_i, _vp, _vp, _vp, _i, _i, _i, _vp], _i),
     "mmtg_logits_process_argmax": ([_vp, _l, _i, _vp, _l, _vp, _f, _f, _vp, _i, _vp], _i),
     "mmtg_decode_embed": ([_i, _vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
@@ -315,6 +316,11 @@ def cast_to_f32(src, dst, n):
 
 def axpy_f32(y, x, a, n):
     _check(lib().mmtg_axpy_f32(_p(y), _p(x), float(a), n, _stream()), "axpy_f32")
+
+
+def slab_sum(part, splits, stride, dst, n, accumulate=True):
+    """dst[0:n] (+)= sum of the `splits` fp32 slabs (stride floats apart) of a weight-gradient EPI_SPLIT product."""
+    _check(lib().mmtg_slab_sum(_p(part), splits, stride, _p(dst), int(accumulate), n, _stream()), "slab_sum")
 
 
 def transpose_batch(src, dst, desc, n, max_rows, max_cols):

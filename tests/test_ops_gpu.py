@@ -694,6 +694,34 @@ def test_transpose_batch(dtype):
         assert torch.equal(dst[o:o + r * c].view(c, r), src[o:o + r * c].view(r, c).t())
 
 
+@pytest.mark.parametrize("M,N,K,splits", [(768, 2304, 4744, 7), (200, 136, 1000, 3), (3072, 768, 2048, 5), (128, 128, 64, 4)])
+def test_weight_gradient_slabs(M, N, K, splits):
+    """Weight gradients as K-split slabs (plain stores) + mmtg_slab_sum: same product as the fp32-atomic
+    epilogue (tolerance: fp32 summation order only, 2e-5 relative to the largest entry), bit-identical
+    between runs, accumulate / overwrite semantics, slabs past the end of K hold zeros."""
+    A = rnd(K, M, dtype=torch.bfloat16, seed=31).to(DEV)
+    B = rnd(K, N, dtype=torch.bfloat16, seed=32).to(DEV)
+    ref = A.float().t() @ B.float()
+    scale = ref.abs().max().item()
+    atom = torch.zeros(M, N, device=DEV)
+    hip.gemm(A, B, atom, M, N, K, transA=True, epi=hip.EPI_ATOMIC, splits=splits)
+    outs = []
+    for _ in range(2):
+        part = torch.full((splits, M, N), float("nan"), device=DEV)
+        hip.gemm(A, B, part, M, N, K, transA=True, epi=hip.EPI_SPLIT, out_f32=True, splits=splits)
+        assert torch.isfinite(part).all()
+        acc = torch.ones(M, N, device=DEV)
+        hip.slab_sum(part, splits, M * N, acc, M * N, accumulate=True)
+        over = torch.full((M, N), 7.0, device=DEV)
+        hip.slab_sum(part, splits, M * N, over, M * N, accumulate=False)
+        assert torch.equal(over, part.sum(0)) or (over - part.sum(0)).abs().max().item() <= 2e-6 * scale
+        assert (acc - 1 - over).abs().max().item() <= 1e-6 * scale
+        outs.append(over)
+    assert torch.equal(outs[0], outs[1])
+    assert (outs[0] - ref).abs().max().item() <= 2e-5 * scale
+    assert (outs[0] - atom).abs().max().item() <= 2e-5 * scale
+
+
 # ------------------------------------------------------------------ generation
 def test_logits_process_argmax():
     B, V, G = 6, 500, 40

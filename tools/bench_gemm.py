@@ -34,9 +34,20 @@ def timeit(fn, n=20):
 
 rows = []
 FLAGS = int(os.environ.get("FLAGS", "0"))
+SLAB = int(os.environ.get("SLAB", "0"))   # weight gradients as K-split slabs + slab_sum (2: time the GEMM alone)
 def case(name, Mm, N, K, tA, tB, epi=hip.EPI_NONE, splits=1, out_f32=False):
     A = t(K, Mm) if tA else t(Mm, K)
     B = t(N, K) if tB else t(K, N)
+    if SLAB and epi == hip.EPI_ATOMIC:
+        part = torch.empty(splits, Mm, N, device=dev, dtype=torch.float32)
+        C = torch.zeros(Mm, N, device=dev, dtype=torch.float32)
+        def fn():
+            hip.gemm(A, B, part, Mm, N, K, transA=True, transB=False, epi=hip.EPI_SPLIT, splits=splits, out_f32=True, flags=FLAGS)
+            if SLAB == 1: hip.slab_sum(part, splits, Mm * N, C, Mm * N, accumulate=True)
+        us = timeit(fn)
+        tf = 2.0 * Mm * N * K / us / 1e6
+        print("%-28s M=%6d N=%6d K=%6d %9.1f us %8.1f TF/s" % (name + " slab", Mm, N, K, us, tf), flush=True)
+        return
     C = torch.zeros(Mm, N, device=dev, dtype=torch.float32 if (out_f32 or epi == hip.EPI_ATOMIC) else dt)
     kw = {}
     if epi == hip.EPI_GELU: kw["aux2"] = torch.empty(Mm, N, device=dev, dtype=dt)
