@@ -61,10 +61,13 @@ enum {
                                  (tile, K split) items, next item prefetched, epilogue deferred into it); opt-in:
                                  measured on par with the plain launch */
 #define MMTG_GEMM_NO_PERSIST 128 /* flags: reserved (the persistent kernel is never picked automatically) */
-#define MMTG_GEMM_ROW_ORDER 256  /* flags: weight gradients keep the tile_n-fastest item order (A/B measurements) */
+#define MMTG_GEMM_ROW_ORDER 256  /* flags: keep the plain tile_n-fastest item order: no tile_m-fastest weight gradients, no
+                                    column blocks for forward / dgrad products (A/B measurements) */
 #define MMTG_GEMM_OCC4 512       /* flags: force the single-stage 128x128 kernel, four workgroups per CU (bf16); automatic for
                                     weight gradients and for forward / dgrad products of more than 2 x CUs tiles */
 #define MMTG_GEMM_NO_OCC4 1024   /* flags: never pick it automatically (A/B measurements) */
+#define MMTG_GEMM_COL_BLOCK 2048 /* flags: force the column-blocked item order with blocks of two tile columns (test hook;
+                                    automatic when the weights do not stay in an XCD's L2 over several sweeps) */
 
 /* profiling categories (mmtg_prof_*) */
 enum {

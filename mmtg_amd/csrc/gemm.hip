@@ -592,6 +592,29 @@ template <typename K> int resident_wgs(K kern, int threads, size_t bytes) {
     return n;
 }
 
+// Column-block width of the item order of a forward / dgrad product (0 = plain tile_n-fastest order).
+// The B operand (weights, N x K) is re-read from the Infinity Cache by every XCD once per sweep over its
+// tile columns when it does not stay in the 4 MB L2 (measured: LM head 1.6 GB of fabric reads for 43 MB of
+// operands; L2-miss fills run at 13 B/clk/CU against 52 for hits, tools/micro/lds_fill.py).  Blocks of
+// `w` tile columns keep w B panels resident while the A rows stream by; A is then read once per block.
+int column_block(const GemmArgs& a, int bm, int bn, int slots) {
+    static const long budget = getenv("MMTG_GEMM_CB_KB") ? atol(getenv("MMTG_GEMM_CB_KB")) * 1024 : 2048L * 1024;
+    const long tiles_m = cdiv(a.M, bm), tiles_n = cdiv(a.N, bn);
+    if (a.dbg_flags & 16) return tiles_n > 2 ? 2 : 0;      // MMTG_GEMM_COL_BLOCK: test hook
+    if (budget <= 0) return 0;
+    const long panel = (long)bn * a.K * 2, bytesB = (long)a.N * a.K * 2, bytesA = (long)a.M * a.K * 2;
+    if (bytesB <= budget || tiles_n < 2) return 0;
+    const double passes = (double)(tiles_m * tiles_n) / slots;            // sweeps of an XCD over all columns
+    if (passes <= 1.0) return 0;
+    const long wmax = budget / panel;
+    if (wmax < 1) return 0;
+    const long nblocks = cdiv(tiles_n, wmax), w = cdiv(tiles_n, nblocks);
+    const double plain = (double)bytesA + 8.0 * bytesB * passes;
+    const double xcds = 8.0 * w / tiles_n;
+    const double blocked = (double)bytesA * nblocks + (double)bytesB * (xcds < 1.0 ? 1.0 : xcds);
+    return blocked < 0.8 * plain ? (int)w : 0;
+}
+
 template <typename K> int set_lds(K kern, size_t bytes, int threads = 0, const char* what = "") {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
         MMTG_FAIL(MMTG_ERR_HIP, "gemm: cannot raise dynamic LDS to %zu bytes", bytes);
@@ -636,6 +659,7 @@ int launch_dma_cfg(const GemmArgs& a, int splits, hipStream_t stream) {
     // 6 x 24 tiles and 54 items per XCD, 6 rows x 9 columns (15 operand panels) instead of 2.25 rows x
     // 24 columns (27 panels).
     b.tiles_m_fast = AKS && BKS && b.tiles_n > cdiv(a.M, BM_) && !(a.dbg_flags & 1);
+    if (!(AKS && BKS) && splits == 1 && !(a.dbg_flags & 1)) b.cbw = column_block(a, BM_, BN_, 2 * num_cus());
     dim3 grid(b.nitems), block(64 * WM * WN);
     hipLaunchKernelGGL((gemm_dma_kernel<AKS, BKS, BM_, BN_, WM, WN, NBUF>), grid, block, shm, stream, b);
     return MMTG_OK;
@@ -678,6 +702,7 @@ int launch_occ4(const GemmArgs& a, int splits, hipStream_t stream) {
     b.ntiles = cdiv(a.M, TBM) * b.tiles_n;
     b.nitems = b.ntiles * splits;
     b.tiles_m_fast = AKS && BKS && b.tiles_n > cdiv(a.M, TBM);
+    if (!(AKS && BKS) && splits == 1 && !(a.dbg_flags & 1)) b.cbw = column_block(a, TBM, 128, 3 * num_cus());
     hipLaunchKernelGGL((gemm_occ4_kernel<AKS, BKS, SLAB>), dim3(b.nitems), dim3(256), shm, stream, b);
     return MMTG_OK;
 }
@@ -759,7 +784,7 @@ extern "C" int mmtg_gemm(int dtype, int transA, int transB, int M, int N, int K,
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldaux = ldaux;
     a.epi = epi; a.out_f32 = out_f32; a.use_tr = !(flags & MMTG_GEMM_NO_TR);
     a.trace = g_trace; a.trace_n = g_trace_n;
-    a.dbg_flags = (flags & MMTG_GEMM_ROW_ORDER) ? 1 : 0;     // bit 1 (value 2): single-stage kernel, set below
+    a.dbg_flags = ((flags & MMTG_GEMM_ROW_ORDER) ? 1 : 0) | ((flags & MMTG_GEMM_COL_BLOCK) ? 16 : 0);     // bit 1 (value 2): single-stage kernel, set below
     a.tiles_n = cdiv(N, BN); a.alpha = alpha;
     // byte extents for the buffer descriptors of the LDS-DMA pipeline (offsets are 32-bit)
     const long esz = dtype == MMTG_F32 ? 4 : 2;

@@ -25,6 +25,7 @@ struct GemmArgs {
     int use_tr;            // bf16 KS fragments via ds_read_b64_tr_b16 (1) or scalar gathers (0)
     int tiles_n;
     int tiles_m_fast;      // item order inside a K split: tile_m fastest (1) or tile_n fastest (0)
+    int cbw;               // > 0: column-blocked order -- blocks of cbw tile columns, tile rows inside a block
     int ntiles;            // output tiles per K split (grid = ntiles * splits work items)
     int kper;              // K elements per split (multiple of BK)
     long split_stride;     // MMTG_EPI_SPLIT: bytes between the per-split output slabs (0 otherwise)
@@ -165,6 +166,12 @@ __device__ __forceinline__ void tile_origin(const GemmArgs& p, int bid, int nwg,
         const int tm = p.ntiles / p.tiles_n;
         m0 = (t % tm) * bm;
         n0 = (t / tm) * bn;
+    } else if (p.cbw > 0) {     // column blocks whose B panels stay in the XCD's L2 while the A rows stream by
+        const int per = (p.ntiles / p.tiles_n) * p.cbw;
+        const int cb = t / per, u = t - cb * per;
+        const int w = min(p.cbw, p.tiles_n - cb * p.cbw);
+        m0 = (u / w) * bm;
+        n0 = (cb * p.cbw + u % w) * bn;
     } else {
         m0 = (t / p.tiles_n) * bm;
         n0 = (t % p.tiles_n) * bn;

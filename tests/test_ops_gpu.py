@@ -84,6 +84,28 @@ def test_gemm_layouts(dtype, layout, shape, variant):
         close(Cm, ref, dtype, K, "gemm " + layout)
 
 
+@pytest.mark.parametrize("layout", ["NT", "NN"])
+@pytest.mark.parametrize("kernel", ["dma2", "wide", "occ4"])
+@pytest.mark.parametrize("shape", [(712, 648, 200), (1300, 904, 64), (256, 2304, 128)])
+def test_gemm_column_blocked_order_matches_plain(layout, kernel, shape):
+    """The column-blocked item order (blocks of tile columns whose weight panels stay in L2; here forced to
+    two columns, with a ragged last block) only renumbers the workgroups: results are bit-identical to the
+    plain tile_n-fastest order and every output element is written."""
+    M, N, K = shape
+    a = rnd(M, K, dtype=torch.bfloat16, seed=5).to(DEV)
+    b = rnd(K, N, dtype=torch.bfloat16, seed=6)
+    B = (b.t().contiguous() if layout == "NT" else b).to(DEV)
+    base = {"dma2": hip.GEMM_NO_WIDE | hip.GEMM_NO_OCC4, "wide": hip.GEMM_WIDE, "occ4": hip.GEMM_OCC4 | hip.GEMM_NO_WIDE}[kernel]
+    outs = []
+    for extra in (hip.GEMM_ROW_ORDER, hip.GEMM_COL_BLOCK):
+        C = torch.full((M, N), float("nan"), device=DEV, dtype=torch.bfloat16)
+        hip.gemm(a, B, C, M, N, K, transB=layout == "NT", flags=base | extra)
+        outs.append(C)
+    assert torch.isfinite(outs[1].float()).all()
+    assert torch.equal(outs[0], outs[1])
+    close(outs[1], a.float().cpu() @ b.float(), torch.bfloat16, K, "column-blocked " + layout)
+
+
 @pytest.mark.parametrize("layout", ["NT", "NN", "TN"])
 @pytest.mark.parametrize("K", [64, 200, 4744])
 def test_gemm_persistent_pipeline_matches_plain(layout, K):
