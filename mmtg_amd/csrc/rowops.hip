@@ -205,19 +205,55 @@ __global__ __launch_bounds__(256, LN_BWD_WAVES) void ln_bwd2_kernel(const T* __r
         }
     }
     const float inv_cols = 1.0f / cols;
+    // Software pipeline over rows: the x / dy vectors of the NEXT row pair (and the residual gradient of
+    // this one) are requested before this pair is reduced, so a wave keeps two row pairs of loads in flight.
+    // (only where the extra 8 * NC registers fit the 256-VGPR budget of two waves per SIMD)
+    constexpr bool PF = sizeof(T) == 2 ? NC <= 3 : NC <= 4;
+    V px[NC], pd[NC];
+    if constexpr (PF) {
+        const int row = (blockIdx.x * 4 + wave) * 2 + half;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const int ch = hl + 32 * i;
+            if (row < rows && ch < nch) {
+                px[i] = *reinterpret_cast<const V*>(x + (long)row * cols + ch * EPC);
+                pd[i] = *reinterpret_cast<const V*>(dy + (long)row * cols + ch * EPC);
+            }
+        }
+    }
     for (int r2 = (blockIdx.x * 4 + wave) * 2; r2 < rows; r2 += gridDim.x * 8) {
         const int row = r2 + half;
         const bool ok = row < rows;
         const long base = (long)row * cols;
         const float mu = ok ? mean[row] : 0.f, rs = ok ? rstd[row] : 0.f;
+        V cx[NC], cd[NC], rv[NC];
+        const int nrow = row + gridDim.x * 8;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const int ch = hl + 32 * i;
+            if constexpr (PF) {
+                cx[i] = px[i];
+                cd[i] = pd[i];
+                if (nrow < rows && ch < nch) {
+                    px[i] = *reinterpret_cast<const V*>(x + (long)nrow * cols + ch * EPC);
+                    pd[i] = *reinterpret_cast<const V*>(dy + (long)nrow * cols + ch * EPC);
+                }
+            }
+            if constexpr (PF)
+                if (dres && ok && ch < nch) rv[i] = *reinterpret_cast<const V*>(dres + base + ch * EPC);
+        }
         float xh[NC][EPC], dg[NC][EPC];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
             const int ch = hl + 32 * i;
             if (ok && ch < nch) {
-                const V xv = *reinterpret_cast<const V*>(x + base + ch * EPC);
-                const V dv = *reinterpret_cast<const V*>(dy + base + ch * EPC);
+                V xv, dv;
+                if constexpr (PF) { xv = cx[i]; dv = cd[i]; }
+                else {
+                    xv = *reinterpret_cast<const V*>(x + base + ch * EPC);
+                    dv = *reinterpret_cast<const V*>(dy + base + ch * EPC);
+                }
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) {
                     const float d = (float)dv[e];
@@ -244,9 +280,9 @@ __global__ __launch_bounds__(256, LN_BWD_WAVES) void ln_bwd2_kernel(const T* __r
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) o[e] = rs * (dg[i][e] - c1 - xh[i][e] * c2);
                 if (dres) {
-                    const V rv = *reinterpret_cast<const V*>(dres + base + ch * EPC);
+                    if constexpr (!PF) rv[i] = *reinterpret_cast<const V*>(dres + base + ch * EPC);
 #pragma unroll
-                    for (int e = 0; e < EPC; ++e) o[e] += (float)rv[e];
+                    for (int e = 0; e < EPC; ++e) o[e] += (float)rv[i][e];
                 }
                 V ov;
 #pragma unroll

@@ -37,7 +37,7 @@ for i in range(4):
 torch.cuda.synchronize()
 
 log = []
-EPI = ["none", "gelu", "tanh", "resid", "dgelu", "dtanh", "atomic", "rowdot"]
+EPI = ["none", "gelu", "tanh", "resid", "dgelu", "dtanh", "atomic", "rowdot", "slab"]
 
 
 def wrap(name, fn):
