@@ -279,3 +279,58 @@ def test_full_size_training_reduces_the_loss_and_modes_agree():
     tr32 = MMTGTrainer(m32, lr=1e-4, alpha=0.2)
     l32 = float(tr32.step(batch, stage=3)["loss"])
     assert abs(losses[0] - l32) <= 2e-3 * abs(l32), (losses[0], l32)
+
+
+# ------------------------------------------------------------------ BASELINE configs[4] shape family (GPT-2-medium widths)
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_medium_width_long_sequence_vs_oracle(dtype):
+    """SURVEY §8(d) C5 shapes at reduced depth: n_embd 1024 / 16 heads (GPT-2-medium widths), S = 8 experience
+    steps, max_sent_length 29 => 497 lyric positions, T = 512 decoder positions (two key blocks in the attention
+    backward), V = 600, 2 layers, B = 3 -- HIP engine vs the CPU oracle on identical seeded weights and batch.
+    f32 mode: logits <= 1e-3 abs, loss / KL 1e-4 rel, gradients <= 2e-3 of each tensor's max;
+    bf16 mode: logits <= 2.5 % of the largest |logit| (mean <= 0.3 %), gradient cosine >= 0.99."""
+    from mmtg_amd import synth
+    from mmtg_amd.configs import data_config, gpt2_config, make_model_cfgs
+    S, V, B = 8, 600, 3
+    mcfg = make_model_cfgs(seq_len=S, dropout=0.0)
+    dcfg = data_config(seq_len=S, max_sent_length=29)
+    gcfg = gpt2_config(n_layer=2, n_embd=1024, n_head=16, n_positions=512, n_ctx=512, vocab_size=V,
+                       embd_pdrop=0.0, attn_pdrop=0.0, resid_pdrop=0.0)
+    weights = synth.make_weights(mcfg, gcfg, seed=11)
+    table = synth.make_token_table(V, seed=12)
+    nb = synth.make_batch(B, mcfg, dcfg, V, seed=13)
+    assert 15 + np.asarray(nb["targets"]).shape[1] == 512
+    model = MMTG(mcfg, dcfg, V, train_flag=True, gpt2_config=gcfg, token_table=table, compute_dtype=dtype)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})
+    model.to(DEV)
+    model.eval()
+    tb = {k: torch.from_numpy(np.asarray(v)).to(DEV) for k, v in nb.items()}
+    lm, kl, logits = model(tb)
+    loss = MyLoss(dcfg, mcfg)(logits, tb["targets"], tb["rating"], 2)
+    (loss + 0.2 * kl).backward()
+
+    sh = O.Shapes(mcfg, dcfg, gcfg)
+    w = O.weights_to_torch(weights, True)
+    cb = {k: torch.from_numpy(np.asarray(v)) for k, v in nb.items()}
+    _, okl, ologits = O.mmtg_forward(w, sh, torch.from_numpy(table), cb, True)
+    oloss = O.my_loss(ologits, cb["targets"], cb["rating"], 2, sh.P)
+    (oloss + 0.2 * okl).backward()
+
+    err = (logits.detach().float().cpu() - ologits.detach()).abs()
+    f32 = dtype == "f32"
+    top = float(ologits.detach().abs().max())
+    assert float(err.max()) < (1e-3 if f32 else 0.025 * top), (float(err.max()), top)
+    assert f32 or float(err.mean()) < 0.003 * top, (float(err.mean()), top)
+    rel = 1e-4 if f32 else 3e-2
+    assert abs(loss.item() - oloss.item()) <= rel * max(1.0, abs(oloss.item()))
+    assert abs(kl.item() - okl.item()) <= rel * max(1.0, abs(okl.item()))
+    total = float(torch.sqrt(sum((t.grad.double() ** 2).sum() for t in {id(t): t for t in w.values()}.values())))
+    for k, p in model.named_parameters():
+        g, r = p.grad.float().cpu(), w[k].grad
+        if float(r.norm()) < 1e-5 * total:
+            continue
+        if f32:
+            assert float((g - r).abs().max()) <= 2e-3 * float(r.abs().max()) + 1e-7, k
+        else:
+            cos = float(torch.dot(g.flatten(), r.flatten()) / (g.norm() * r.norm() + 1e-30))
+            assert cos > 0.99, (k, cos)
