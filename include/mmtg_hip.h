@@ -180,15 +180,16 @@ int mmtg_dropout_apply(int dtype, const void* x, void* y, long n, int N, unsigne
  * Outputs (all f32): nll[M] (0 on each sample's last row), lse[M],
  * sample_ce[B], coef[B] = d loss / d CE_b / n_tok / batch_denominator,
  * scalars[0] = MyLoss (sum_b l_b / batch_den), scalars[1] = GPT-2 LM loss.    */
-int mmtg_loss_fwd(const float* logits, long ldl, int V, const long long* topic_ids,
+int mmtg_loss_fwd(int logits_dtype, const void* logits, long ldl, int V, const long long* topic_ids,
                   const long long* targets, const long long* ratings, int stage, int label_zero,
                   int B, int P, int L, float batch_den, float* nll, float* lse, float* sample_ce,
                   float* coef, float* scalars, void* stream);
 /* dlogits[m,v] = rc[m] * (softmax(logits[m])_v - [v == label]),
  * rc[m] = gscale * coef[b] on MyLoss rows (P <= t <= T-2) + lm_coef on GPT-2 LM-loss rows
  * (t <= T-2; pass d lm_loss / B / (T-1), 0 when the LM loss is unused as in train.py:188);
- * 0 on each sample's last row and on pad columns; dlogits of `dtype`, ld = ldd. */
-int mmtg_loss_bwd(int dtype, const float* logits, long ldl, int V, const long long* topic_ids,
+ * 0 on each sample's last row and on pad columns; dlogits of `dtype`, ld = ldd.  `logits_dtype` is the
+ * storage type of the logits (fp32, or bf16 with bf16 dlogits -- then dlogits may alias logits). */
+int mmtg_loss_bwd(int dtype, int logits_dtype, const void* logits, long ldl, int V, const long long* topic_ids,
                   const long long* targets, const float* lse, const float* coef, float gscale, float lm_coef,
                   int B, int P, int L, void* dlogits, long ldd, int Vpad, void* stream);
 

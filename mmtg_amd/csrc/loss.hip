@@ -32,27 +32,42 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
     return v;
 }
 
-// one block per row: lse[m], nll[m] = lse - logit[label]
-__global__ __launch_bounds__(256) void row_lse_kernel(const float* __restrict__ logits, long ldl, int V,
+// eight consecutive logits of a row as floats (fp32 rows: two 16-byte loads; bf16 rows: one)
+__device__ __forceinline__ void load8(const float* p, float (&x)[8]) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+    x[0] = a[0]; x[1] = a[1]; x[2] = a[2]; x[3] = a[3]; x[4] = b[0]; x[5] = b[1]; x[6] = b[2]; x[7] = b[3];
+}
+__device__ __forceinline__ void load8(const bf16* p, float (&x)[8]) {
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = (float)a[e];
+}
+
+// one block per row: lse[m], nll[m] = lse - logit[label].  LT = storage type of the logits (fp32, or
+// bf16 in the bf16 training path where the LM-head product stores them like every other activation).
+template <typename LT>
+__global__ __launch_bounds__(256) void row_lse_kernel(const LT* __restrict__ logits, long ldl, int V,
         const long long* __restrict__ topic_ids, const long long* __restrict__ targets, int label_zero,
         int P, int L, float* __restrict__ nll, float* __restrict__ lse) {
     __shared__ float sh[4];
     const int Tt = P + L;
     const long m = blockIdx.x;
     const int b = (int)(m / Tt), t = (int)(m % Tt);
-    const float* row = logits + m * ldl;
-    // one pass: every thread keeps a running (max, sum of exp relative to it) over its 4-wide slices and
+    const LT* row = logits + m * ldl;
+    // one pass: every thread keeps a running (max, sum of exp relative to it) over its 8-wide slices and
     // rescales when the max moves; the block then combines the 256 pairs (exact up to fp32 rounding)
     float mx = -INFINITY, sm = 0.f;
-    const int V4 = V & ~3;
-    for (int v = threadIdx.x * 4; v < V4; v += 1024) {
-        const f32x4 x = *reinterpret_cast<const f32x4*>(row + v);
-        const float m4 = fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3]));
-        if (m4 > mx) { sm *= expf(mx - m4); mx = m4; }
-        sm += expf(x[0] - mx) + expf(x[1] - mx) + expf(x[2] - mx) + expf(x[3] - mx);
+    const int V8 = V & ~7;
+    for (int v = threadIdx.x * 8; v < V8; v += 2048) {
+        float x[8];
+        load8(row + v, x);
+        const float m8 = fmaxf(fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])), fmaxf(fmaxf(x[4], x[5]), fmaxf(x[6], x[7])));
+        if (m8 > mx) { sm *= expf(mx - m8); mx = m8; }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sm += expf(x[e] - mx);
     }
-    for (int v = V4 + threadIdx.x; v < V; v += 256) {
-        const float x = row[v];
+    for (int v = V8 + threadIdx.x; v < V; v += 256) {
+        const float x = (float)row[v];
         if (x > mx) { sm *= expf(mx - x); mx = x; }
         sm += expf(x - mx);
     }
@@ -67,7 +82,7 @@ __global__ __launch_bounds__(256) void row_lse_kernel(const float* __restrict__ 
             long long lab = label_of(topic_ids, targets, b, t + 1, P, L, label_zero);
             if (lab < 0) lab = 0;
             if (lab >= V) lab = V - 1;
-            n = l - row[lab];
+            n = l - (float)row[lab];
         }
         nll[m] = n;
     }
@@ -111,11 +126,12 @@ __global__ __launch_bounds__(256) void sample_loss_kernel(const float* __restric
     }
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__ logits, long ldl, int V,
+// (dlogits may alias logits when both are stored in the same type: a thread rewrites only what it read)
+template <typename T, typename LT>
+__global__ __launch_bounds__(256) void loss_bwd_kernel(const LT* logits, long ldl, int V,
         const long long* __restrict__ topic_ids, const long long* __restrict__ targets,
         const float* __restrict__ lse, const float* __restrict__ coef, float gscale, float lm_coef, int P, int L,
-        T* __restrict__ dlogits, long ldd, int Vpad) {
+        T* dlogits, long ldd, int Vpad) {
     const int Tt = P + L;
     const long m = blockIdx.x;
     const int b = (int)(m / Tt), t = (int)(m % Tt);
@@ -133,24 +149,20 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__
         }
         return;
     }
-    const float* row = logits + m * ldl;
+    const LT* row = logits + m * ldl;
     const float l = lse[m], cf = (t >= P ? coef[b] * gscale : 0.f) + lm_coef;
     long long lab = label_of(topic_ids, targets, b, t + 1, P, L, 0);
     if (lab < 0) lab = 0;
     if (lab >= V) lab = V - 1;
-    const bool vec = (Vpad & 7) == 0 && (ldl & 3) == 0 && (ldd & 7) == 0;
+    const bool vec = (Vpad & 7) == 0 && (ldl & (sizeof(LT) == 4 ? 3 : 7)) == 0 && ldl >= Vpad && (ldd & 7) == 0;
     if (vec) {
         for (int v = threadIdx.x * 8; v < Vpad; v += 2048) {
-            float d[8];
+            float d[8], x[8];
+            load8(row + v, x);
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                f32x4 x = {0.f, 0.f, 0.f, 0.f};
-                if (v + 4 * h < ldl) x = *reinterpret_cast<const f32x4*>(row + v + 4 * h);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int vv = v + 4 * h + e;
-                    d[4 * h + e] = vv < V ? cf * (expf(x[e] - l) - (vv == (int)lab ? 1.f : 0.f)) : 0.f;
-                }
+            for (int e = 0; e < 8; ++e) {
+                const int vv = v + e;
+                d[e] = vv < V ? cf * (expf(x[e] - l) - (vv == (int)lab ? 1.f : 0.f)) : 0.f;
             }
             if constexpr (sizeof(T) == 2) {
                 bf16x8 o = {(bf16)d[0], (bf16)d[1], (bf16)d[2], (bf16)d[3], (bf16)d[4], (bf16)d[5], (bf16)d[6], (bf16)d[7]};
@@ -164,43 +176,52 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__
     }
     for (int v = threadIdx.x; v < Vpad; v += 256) {
         float d = 0.f;
-        if (v < V) d = cf * (expf(row[v] - l) - (v == (int)lab ? 1.f : 0.f));
+        if (v < V) d = cf * (expf((float)row[v] - l) - (v == (int)lab ? 1.f : 0.f));
         drow[v] = (T)d;
     }
 }
 
 }  // namespace
 
-extern "C" int mmtg_loss_fwd(const float* logits, long ldl, int V, const long long* topic_ids,
+extern "C" int mmtg_loss_fwd(int logits_dtype, const void* logits, long ldl, int V, const long long* topic_ids,
                              const long long* targets, const long long* ratings, int stage, int label_zero,
                              int B, int P, int L, float batch_den, float* nll, float* lse, float* sample_ce,
                              float* coef, float* scalars, void* stream) {
-    MMTG_REQUIRE(B > 0 && L >= 1 && P >= 0 && P + L >= 2 && V > 0 && ldl >= V && ldl % 4 == 0, "loss_fwd: bad sizes (V=%d ldl=%ld L=%d)", V, ldl, L);
+    MMTG_REQUIRE(logits_dtype == MMTG_F32 || logits_dtype == MMTG_BF16, "loss_fwd: bad logits dtype %d", logits_dtype);
+    MMTG_REQUIRE(B > 0 && L >= 1 && P >= 0 && P + L >= 2 && V > 0 && ldl >= V && ldl % (logits_dtype == MMTG_F32 ? 4 : 8) == 0, "loss_fwd: bad sizes (V=%d ldl=%ld L=%d)", V, ldl, L);
     MMTG_REQUIRE(logits && targets && nll && lse && sample_ce && coef && scalars, "loss_fwd: null pointer");
     MMTG_REQUIRE(label_zero || P == 0 || topic_ids, "loss_fwd: topic_ids required");
     MMTG_REQUIRE(MMTG_ALIGNED16(logits), "loss_fwd: logits must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     const long M = (long)B * (P + L);
-    ProfScope prof(MMTG_PROF_LOSS, s, 4.0 * M * V, 4.0 * M * V);
-    hipLaunchKernelGGL(row_lse_kernel, dim3((unsigned)M), dim3(256), 0, s, logits, ldl, V, topic_ids, targets, label_zero, P, L, nll, lse);
+    const double lsz = logits_dtype == MMTG_F32 ? 4 : 2;
+    ProfScope prof(MMTG_PROF_LOSS, s, 4.0 * M * V, lsz * M * V);
+    if (logits_dtype == MMTG_F32)
+        hipLaunchKernelGGL(row_lse_kernel<float>, dim3((unsigned)M), dim3(256), 0, s, (const float*)logits, ldl, V, topic_ids, targets, label_zero, P, L, nll, lse);
+    else
+        hipLaunchKernelGGL(row_lse_kernel<bf16>, dim3((unsigned)M), dim3(256), 0, s, (const bf16*)logits, ldl, V, topic_ids, targets, label_zero, P, L, nll, lse);
     hipLaunchKernelGGL(sample_loss_kernel, dim3(1), dim3(256), 0, s, nll, ratings, stage, B, P, L, batch_den, sample_ce, coef, scalars);
     MMTG_LAUNCH_CHECK("loss_fwd");
     return MMTG_OK;
 }
 
-extern "C" int mmtg_loss_bwd(int dtype, const float* logits, long ldl, int V, const long long* topic_ids,
+extern "C" int mmtg_loss_bwd(int dtype, int logits_dtype, const void* logits, long ldl, int V, const long long* topic_ids,
                              const long long* targets, const float* lse, const float* coef, float gscale, float lm_coef,
                              int B, int P, int L, void* dlogits, long ldd, int Vpad, void* stream) {
     MMTG_REQUIRE(B > 0 && L >= 1 && P + L >= 2 && V > 0 && Vpad >= V && ldd >= Vpad, "loss_bwd: bad sizes");
     MMTG_REQUIRE(logits && targets && lse && coef && dlogits, "loss_bwd: null pointer");
+    MMTG_REQUIRE(dtype == MMTG_F32 || dtype == MMTG_BF16, "loss_bwd: bad dtype");
+    MMTG_REQUIRE(logits_dtype == MMTG_F32 || (logits_dtype == MMTG_BF16 && dtype == MMTG_BF16), "loss_bwd: bf16 logits go with bf16 dlogits");
+    MMTG_REQUIRE(logits != dlogits || (logits_dtype == dtype && ldl == ldd), "loss_bwd: in-place needs one storage type and one row stride");
     hipStream_t s = (hipStream_t)stream;
     const long M = (long)B * (P + L);
-    ProfScope prof(MMTG_PROF_LOSS, s, 3.0 * M * V, (4.0 + (dtype == MMTG_F32 ? 4 : 2)) * M * V);
-    if (dtype == MMTG_F32)
-        hipLaunchKernelGGL(loss_bwd_kernel<float>, dim3((unsigned)M), dim3(256), 0, s, logits, ldl, V, topic_ids, targets, lse, coef, gscale, lm_coef, P, L, (float*)dlogits, ldd, Vpad);
-    else if (dtype == MMTG_BF16)
-        hipLaunchKernelGGL(loss_bwd_kernel<bf16>, dim3((unsigned)M), dim3(256), 0, s, logits, ldl, V, topic_ids, targets, lse, coef, gscale, lm_coef, P, L, (bf16*)dlogits, ldd, Vpad);
-    else MMTG_FAIL(MMTG_ERR_BAD_ARG, "loss_bwd: bad dtype");
+    ProfScope prof(MMTG_PROF_LOSS, s, 3.0 * M * V, ((logits_dtype == MMTG_F32 ? 4.0 : 2.0) + (dtype == MMTG_F32 ? 4 : 2)) * M * V);
+#define LB(T, LT) hipLaunchKernelGGL((loss_bwd_kernel<T, LT>), dim3((unsigned)M), dim3(256), 0, s, (const LT*)logits, ldl, V, topic_ids, targets, \
+                                     lse, coef, gscale, lm_coef, P, L, (T*)dlogits, ldd, Vpad)
+    if (dtype == MMTG_F32) LB(float, float);
+    else if (logits_dtype == MMTG_F32) LB(bf16, float);
+    else LB(bf16, bf16);
+#undef LB
     MMTG_LAUNCH_CHECK("loss_bwd");
     return MMTG_OK;
 }

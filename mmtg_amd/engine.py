@@ -368,7 +368,7 @@ class Engine:
         hip.cast_f32_to(t, out, t.numel())
         return out
 
-    def forward(self, batch, train_flag=True, training=False, per_row_infer=True, need_logits=True,
+    def forward(self, batch, train_flag=True, training=False, per_row_infer=True, need_logits=True, logits_f32=True,
                 encode_only=False):
         """MMTG.forward (model.py:356-400).  Returns dict(logits_pad [M,Vpad] f32, B, T, ...);
         lm_loss / kl are device scalars in self.scalars after loss()."""
@@ -506,8 +506,11 @@ class Engine:
         hf = self.buf("hf", (M, D))
         hip.layernorm_fwd(hcur, hf, self.P(pre + "ln_f.weight"), self.P(pre + "ln_f.bias"), muf, rsf, M, D, sh.eps)
         Vp = self.layout.Vpad
-        logits = self.buf("logits", (M, Vp), torch.float32)
-        hip.gemm(hf, self.Wp("wte"), logits, M, Vp, D, transB=True, ldb=D, out_f32=True)
+        # fp32 logits for the reference-shaped surface (MMTG.forward returns them); the fused trainer of the
+        # bf16 mode keeps them in bf16 like every other activation (logits_f32=False)
+        l32 = logits_f32 or self.dtype == hip.F32
+        logits = self.buf("logits" if l32 else "logits_c", (M, Vp), torch.float32 if l32 else self.tdt)
+        hip.gemm(hf, self.Wp("wte"), logits, M, Vp, D, transB=True, ldb=D, out_f32=l32)
         a.update(xt=xt, t_raw=t_raw, t_ln=t_ln, st=st, enc=enc, alpha=alpha, kl=kl, o=o, ba=ba, c=c, x=x, h1=h1,
                  type_ids=type_ids, keep=keep, layers=layers, x_last=hcur, muf=muf, rsf=rsf, hf=hf, logits=logits)
         self.act = a
@@ -553,7 +556,8 @@ class Engine:
     def loss_backward(self, gscale=1.0, lm_coef=0.0):
         """d(gscale * MyLoss + lm_scale * LM loss)/d logits into the engine's dlogits buffer."""
         a, sh = self.act, self.sh
-        dl = self.buf("dlogits", (a["M"], self.layout.Vpad))
+        # compute-dtype logits are overwritten in place by their gradient
+        dl = a["logits"] if a["logits"].dtype == self.tdt and self.dtype != hip.F32 else self.buf("dlogits", (a["M"], self.layout.Vpad))
         hip.loss_bwd(a["logits"], self.layout.Vpad, sh.V, a["topic_ids"], a["targets"], a["lse_rows"], a["coef"],
                      gscale, a["B"], sh.P, a["L"], dl, self.layout.Vpad, self.layout.Vpad, lm_coef=lm_coef)
         return dl

@@ -43,8 +43,8 @@ _SIGS = {
     "mmtg_embed_add": ([_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _u, _u, _vp], _i),
     "mmtg_embed_add_bwd": ([_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _u, _u, _vp], _i),
     "mmtg_dropout_apply": ([_i, _vp, _vp, _l, _i, _u, _u, _vp], _i),
-    "mmtg_loss_fwd": ([_vp, _l, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp], _i),
-    "mmtg_loss_bwd": ([_i, _vp, _l, _i, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _i, _vp, _l, _i, _vp], _i),
+    "mmtg_loss_fwd": ([_i, _vp, _l, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp], _i),
+    "mmtg_loss_bwd": ([_i, _i, _vp, _l, _i, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _i, _vp, _l, _i, _vp], _i),
     "mmtg_gru_cell_fwd": ([_i, _vp, _l, _vp, _vp, _l, _vp, _l, _vp, _i, _i, _vp], _i),
     "mmtg_gru_cell_bwd": ([_i, _vp, _vp, _vp, _l, _vp, _l, _vp, _vp, _i, _i, _vp], _i),
     "mmtg_alpha_attn_fwd": ([_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp], _i),
@@ -248,13 +248,13 @@ def dropout_apply(x, y, n, drop_p, drop_seed):
 # ------------------------------------------------------------------ loss
 def loss_fwd(logits, ldl, V, topic_ids, targets, ratings, stage, label_zero, B, P, L, batch_den,
              nll, lse, sample_ce, coef, scalars):
-    _check(lib().mmtg_loss_fwd(_p(logits), ldl, V, _p(topic_ids), _p(targets), _p(ratings), stage,
+    _check(lib().mmtg_loss_fwd(dt(logits), _p(logits), ldl, V, _p(topic_ids), _p(targets), _p(ratings), stage,
                                int(label_zero), B, P, L, float(batch_den), _p(nll), _p(lse), _p(sample_ce),
                                _p(coef), _p(scalars), _stream()), "loss_fwd")
 
 
 def loss_bwd(logits, ldl, V, topic_ids, targets, lse, coef, gscale, B, P, L, dlogits, ldd, Vpad, lm_coef=0.0):
-    _check(lib().mmtg_loss_bwd(dt(dlogits), _p(logits), ldl, V, _p(topic_ids), _p(targets), _p(lse), _p(coef),
+    _check(lib().mmtg_loss_bwd(dt(dlogits), dt(logits), _p(logits), ldl, V, _p(topic_ids), _p(targets), _p(lse), _p(coef),
                                float(gscale), float(lm_coef), B, P, L, _p(dlogits), ldd, Vpad, _stream()), "loss_bwd")
 
 

@@ -10,6 +10,8 @@ get_linear_schedule_with_warmup (train.py:146-148).
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from .ddp import GradReducer
@@ -30,6 +32,9 @@ def linear_schedule(step, warmup, total):
     if step < warmup:
         return step / max(1, warmup)
     return max(0.0, (total - step) / max(1, total - warmup))
+
+
+_LOGITS_F32 = bool(os.environ.get("MMTG_LOGITS_F32"))     # A/B switch: fp32 logits in the bf16 trainer too
 
 
 class MMTGTrainer:
@@ -70,7 +75,7 @@ class MMTGTrainer:
         eng.zero_grad()
         out = None
         if n_local > 0:
-            eng.forward(batch, train_flag=True, training=self.model.training)
+            eng.forward(batch, train_flag=True, training=self.model.training, logits_f32=_LOGITS_F32)
             sc = eng.loss(batch["rating"], stage, batch_den=n_global)
             B, T = eng.act["B"], eng.act["T"]
             dl = eng.loss_backward(1.0, lm_coef=self.lm_weight / (B * (T - 1)) if self.lm_weight else 0.0)

@@ -526,6 +526,35 @@ def test_loss_fwd_bwd(dtype, stage):
     assert abs(sc[1].item() - z.item()) < 2e-5 * abs(z.item())
 
 
+def test_loss_on_bf16_logits_in_place():
+    """bf16-stored logits (the bf16 trainer path): the loss of the ROUNDED logits is reproduced to fp32 accuracy
+    (2e-5 rel; the only difference to the fp32 path is the storage rounding of the inputs), and the gradient
+    written over the logits buffer equals the separately stored one bit for bit."""
+    B, P, L, V, Vpad, stage = 4, 15, 45, 333, 384, 2
+    T = P + L
+    gen = torch.Generator().manual_seed(7)
+    logits = (torch.randn(B, T, V, generator=gen) * 2).bfloat16()
+    topic = torch.randint(0, V, (B, P), generator=gen)
+    targ = torch.randint(0, V, (B, L), generator=gen)
+    ratings = torch.tensor([1, 5, 3, 4])
+    lr = logits.float().clone().requires_grad_(True)
+    ref = O.my_loss(lr, targ, ratings, stage, P)
+    ref.backward()
+    pad = torch.zeros(B * T, Vpad, dtype=torch.bfloat16)
+    pad[:, :V] = logits.view(-1, V)
+    ld = pad.to(DEV)
+    nll, lse = torch.empty(B * T, device=DEV), torch.empty(B * T, device=DEV)
+    ce, coef, sc = torch.empty(B, device=DEV), torch.empty(B, device=DEV), torch.zeros(2, device=DEV)
+    hip.loss_fwd(ld, Vpad, V, topic.to(DEV), targ.to(DEV), ratings.to(DEV), stage, False, B, P, L, float(B), nll, lse, ce, coef, sc)
+    assert abs(sc[0].item() - ref.item()) < 2e-5 * max(1, abs(ref.item())), (sc[0].item(), ref.item())
+    close(lse.view(B, T), torch.logsumexp(logits.float(), -1), torch.float32, 1, "lse of bf16 logits")
+    dl = torch.full((B * T, Vpad), float("nan"), device=DEV, dtype=torch.bfloat16)
+    hip.loss_bwd(ld, Vpad, V, topic.to(DEV), targ.to(DEV), lse, coef, 1.0, B, P, L, dl, Vpad, Vpad)
+    close(dl[:, :V].view(B, T, V), lr.grad, torch.bfloat16, 1, "dlogits", scale=float(lr.grad.abs().max()))
+    hip.loss_bwd(ld, Vpad, V, topic.to(DEV), targ.to(DEV), lse, coef, 1.0, B, P, L, ld, Vpad, Vpad)
+    assert torch.equal(ld, dl)
+
+
 # ------------------------------------------------------------------ encoder pieces
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_gru_cell(dtype):
