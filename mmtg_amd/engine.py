@@ -680,7 +680,6 @@ class Engine:
         dhp32 = self.buf("d_hp32", (B, H), torch.float32)
         tmp32 = self.buf("d_tmp32", (B, H), torch.float32)
         row32 = self.buf("d_row32", (B * S, H), torch.float32)
-        dgh = self.buf("d_gh", (B, 3 * H))
         for mod, ch, lnk, dctx_a in (("text", "text", "ln_layer3", dct), ("img", "image", "ln_layer2", dci)):
             qkv_a, ctx_a, probs = a["alpha"][mod]
             x_in, gi, h_all, save, h_ln = a["enc"][ch]
@@ -699,19 +698,36 @@ class Engine:
             hip.cast_to_f32(dh_all, row32, B * S * H)
             dgi = self.buf("d_gi", (B * S, 3 * H))
             row3 = row32.view(B, S, H)
+            # every step's d(gh) is kept (time-major) so that the recurrent weight / bias gradients are ONE
+            # product and ONE column sum after the loop instead of one per step
+            dgh_tm = self.buf("d_gh_tm", (S, B, 3 * H))
+            bf = self.dtype == hip.BF16
+            ks = 6 if bf and (3 * H) % (6 * 64) == 0 else 0      # split-K slabs of the carry product (bf16 kernels only)
+            part = self.buf("d_hp_slabs", (max(ks, 1), B, H), torch.float32)
             for t in range(S - 1, -1, -1):
                 # total gradient wrt h_t = LN path (row b*S+t) + carry from step t+1
                 self._gather_rows(row3, t, dh32)
                 if t < S - 1:
                     hip.axpy_f32(dh32, dhp32, 1.0, B * H)
-                    hip.axpy_f32(dh32, tmp32, 1.0, B * H)
+                    if ks:
+                        hip.slab_sum(part, ks, B * H, dh32, B * H, accumulate=True)
+                    else:
+                        hip.axpy_f32(dh32, tmp32, 1.0, B * H)
+                dgh = dgh_tm[t]
                 hip.gru_cell_bwd(dh32, save[t], None if t == 0 else h_all[t - 1:], dgi[t:], dgh, dhp32, B, H,
                                  ld_hp=S * H, ld_dgi=S * 3 * H)
-                hip.colsum(dgh, B, 3 * H, self.G(r + "bias_hh_l0"))
                 if t > 0:
-                    hip.gemm(dgh, self.W(r + "weight_hh_l0"), tmp32, B, H, 3 * H, transB=False, ldb=H, out_f32=True)
-                    hip.gemm(dgh, h_all[t - 1:], self.G(r + "weight_hh_l0"), 3 * H, H, B, transA=True, transB=False,
-                             lda=3 * H, ldb=S * H, ldc=H, epi=hip.EPI_ATOMIC, splits=1)
+                    if ks:
+                        hip.gemm(dgh, self.W(r + "weight_hh_l0"), part, B, H, 3 * H, transB=False, ldb=H,
+                                 epi=hip.EPI_SPLIT, out_f32=True, splits=ks)
+                    else:
+                        hip.gemm(dgh, self.W(r + "weight_hh_l0"), tmp32, B, H, 3 * H, transB=False, ldb=H, out_f32=True)
+            hip.colsum(dgh_tm, S * B, 3 * H, self.G(r + "bias_hh_l0"))
+            if S > 1:
+                hprev_tm = self.buf("h_prev_tm", (S - 1, B, H))
+                hprev_tm.copy_(h_all.view(B, S, H)[:, :S - 1].transpose(0, 1))     # data movement only
+                hip.gemm(dgh_tm[1:], hprev_tm, self.G(r + "weight_hh_l0"), 3 * H, H, (S - 1) * B, transA=True, transB=False,
+                         lda=3 * H, ldb=H, ldc=H, epi=hip.EPI_ATOMIC, splits=1)
             self._wgrad(x_in, dgi, r + "weight_ih_l0", r + "bias_ih_l0", B * S, "linear")
         # ---- topic channel
         dt_ln = self.buf("d_tln", (B, H))
