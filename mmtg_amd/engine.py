@@ -159,6 +159,7 @@ def gaussian_prior(S):
 
 import os as _os
 _NO_OCC4 = bool(_os.environ.get("MMTG_GEMM_NO_OCC4"))     # A/B switch, mirrors the library's
+_NO_FEW_ROWS = bool(_os.environ.get("MMTG_NO_FEW_ROWS"))   # A/B switch: plain launches for the encoder-sized products
 _WGRAD_SLAB = not _os.environ.get("MMTG_WGRAD_ATOMIC")     # A/B switch: fp32-atomic weight gradients everywhere
 
 
@@ -311,11 +312,30 @@ class Engine:
             self.copies_fresh = False
 
     # ---------------------------------------------------------------- GEMM helpers
+    def _gemm_few_rows(self, A, Bm, out, M, N, K, transB, ldb, bias=None, lda=None):
+        """Encoder-sized products (M = B or B*S rows, K >= 1024): a handful of output tiles each walking a long K
+        serially leaves most CUs idle, so the bf16 mode splits K into fp32 slabs (deterministic) and lets the
+        finish kernel add the bias.  Returns False when the plain launch should be used."""
+        if self.dtype != hip.BF16 or K < 1024 or K % 8 or N % 8 or out.dtype != self.tdt or _NO_FEW_ROWS:
+            return False
+        tiles = (N + 31) // 32 if (transB and M <= 256) else ((M + 127) // 128) * ((N + 127) // 128)
+        splits = min(K // 256, 384 // tiles)
+        if tiles > 48 or splits < 2:
+            return False
+        part = self.buf("few_rows_slabs", (8 * 320 * 2048,), torch.float32)
+        if splits * M * N > part.numel():
+            return False
+        hip.gemm(A, Bm, part, M, N, K, transB=transB, lda=lda, ldb=ldb, ldc=N, epi=hip.EPI_SPLIT, out_f32=True, splits=splits)
+        hip.splitk_finish(part, splits, M, N, out, bias=bias)
+        return True
+
     def _fwd(self, x, wkey, out, M, kind, bias=None, lda=None, **kw):
         """out[M,out] = x[M,in] W (+bias).  kind: 'linear' = [out,in], 'conv1d' = [in,out]."""
         w = self.W(wkey)
         if kind == "linear":
             N, K = w.shape
+            if not kw and self._gemm_few_rows(x, w, out, M, N, K, True, K, bias=bias, lda=lda):
+                return
             hip.gemm(x, w, out, M, N, K, transB=True, lda=lda, ldb=K, bias=bias, **kw)
         elif wkey in self.wt_entries:   # bf16: the [out,in] copy -> NT layout
             K, N = w.shape
@@ -328,6 +348,8 @@ class Engine:
         w = self.W(wkey)
         if kind == "linear":
             K, N = w.shape   # dy [M,out=K] @ W[out,in] -> [M,in=N]
+            if not kw and self._gemm_few_rows(dy, w, dx, M, N, K, False, N):
+                return
             hip.gemm(dy, w, dx, M, N, K, transB=False, ldb=N, **kw)
         else:
             N, K = w.shape   # dy [M,out=K] @ W[in,out]^T -> [M,in=N]
@@ -686,7 +708,8 @@ class Engine:
             dqkv_a = self.buf("d_aqkv", (B * S, 3 * H))
             hip.alpha_attn_bwd(qkv_a, self.prior, probs, dctx_a, dkl, dqkv_a, B, S, H, sh.heads)
             dhln = self.buf("d_hln", (B * S, H))
-            hip.gemm(dqkv_a, self.Wp(mod + "_qkv_w"), dhln, B * S, H, 3 * H, transB=False, ldb=H)
+            if not self._gemm_few_rows(dqkv_a, self.Wp(mod + "_qkv_w"), dhln, B * S, H, 3 * H, False, H):
+                hip.gemm(dqkv_a, self.Wp(mod + "_qkv_w"), dhln, B * S, H, 3 * H, transB=False, ldb=H)
             hip.gemm(dqkv_a, h_ln, self.Gp(mod + "_qkv_w"), 3 * H, H, B * S, transA=True, transB=False, lda=3 * H,
                      ldb=H, ldc=H, epi=hip.EPI_ATOMIC, splits=1)
             hip.colsum(dqkv_a, B * S, 3 * H, self.Gp(mod + "_qkv_b"))
