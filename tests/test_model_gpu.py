@@ -334,3 +334,56 @@ def test_medium_width_long_sequence_vs_oracle(dtype):
         else:
             cos = float(torch.dot(g.flatten(), r.flatten()) / (g.norm() * r.norm() + 1e-30))
             assert cos > 0.99, (k, cos)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_short_sequence_clipped_conditioning_vs_oracle(dtype):
+    """BASELINE configs[1] as literally stated (seq_len 128): 15 prompt + 113 lyric positions, so the third
+    experience segment's slice [88:132] is clipped at 113 and segments 4-5 receive nothing (model.py:268 slice
+    semantics); S = 5, 12 heads / 768, 2 layers, V = 600, B = 4.  HIP engine vs the CPU oracle, forward and gradients.
+    f32: logits <= 1e-3 abs, loss / KL 1e-4 rel, gradients <= 2e-3 of each tensor's max; bf16: logits <= 2.5 % of the
+    largest |logit|, gradient cosine >= 0.99."""
+    from mmtg_amd import synth
+    from mmtg_amd.configs import data_config, gpt2_config, make_model_cfgs
+    S, V, B, L = 5, 600, 4, 113
+    mcfg = make_model_cfgs(seq_len=S, dropout=0.0)
+    dcfg = data_config(seq_len=S, max_seq_length=L - 1)
+    gcfg = gpt2_config(n_layer=2, n_positions=256, vocab_size=V, embd_pdrop=0.0, attn_pdrop=0.0, resid_pdrop=0.0)
+    weights = synth.make_weights(mcfg, gcfg, seed=21)
+    table = synth.make_token_table(V, seed=22)
+    nb = synth.make_batch(B, mcfg, dcfg, V, seed=23)
+    for k in ("targets", "attention_mask", "type_ids"):
+        nb[k] = np.ascontiguousarray(np.asarray(nb[k])[:, :L])
+    model = MMTG(mcfg, dcfg, V, train_flag=True, gpt2_config=gcfg, token_table=table, compute_dtype=dtype)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})
+    model.to(DEV)
+    model.eval()
+    tb = {k: torch.from_numpy(np.asarray(v)).to(DEV) for k, v in nb.items()}
+    lm, kl, logits = model(tb)
+    assert tuple(logits.shape) == (B, 128, V)
+    loss = MyLoss(dcfg, mcfg)(logits, tb["targets"], tb["rating"], 3)
+    (loss + 0.2 * kl).backward()
+
+    sh = O.Shapes(mcfg, dcfg, gcfg)
+    w = O.weights_to_torch(weights, True)
+    cb = {k: torch.from_numpy(np.asarray(v)) for k, v in nb.items()}
+    _, okl, ologits = O.mmtg_forward(w, sh, torch.from_numpy(table), cb, True)
+    oloss = O.my_loss(ologits, cb["targets"], cb["rating"], 3, sh.P)
+    (oloss + 0.2 * okl).backward()
+    f32 = dtype == "f32"
+    err = (logits.detach().float().cpu() - ologits.detach()).abs()
+    top = float(ologits.detach().abs().max())
+    assert float(err.max()) < (1e-3 if f32 else 0.025 * top), (float(err.max()), top)
+    rel = 1e-4 if f32 else 3e-2
+    assert abs(loss.item() - oloss.item()) <= rel * max(1.0, abs(oloss.item()))
+    assert abs(kl.item() - okl.item()) <= rel * max(1.0, abs(okl.item()))
+    total = float(torch.sqrt(sum((t.grad.double() ** 2).sum() for t in {id(t): t for t in w.values()}.values())))
+    for k, p in model.named_parameters():
+        g, r = p.grad.float().cpu(), w[k].grad
+        if float(r.norm()) < 1e-5 * total:
+            continue
+        if f32:
+            assert float((g - r).abs().max()) <= 2e-3 * float(r.abs().max()) + 1e-7, k
+        else:
+            cos = float(torch.dot(g.flatten(), r.flatten()) / (g.norm() * r.norm() + 1e-30))
+            assert cos > 0.99, (k, cos)
