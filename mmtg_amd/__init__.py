@@ -18,6 +18,9 @@ def __getattr__(name):
     if name in ("sample_sequence", "top_k_top_p_filtering"):
         from . import generate
         return getattr(generate, name)
+    if name in ("MyDataset", "BinaryDataset", "DeviceLoader", "pack_binary"):
+        from . import data
+        return getattr(data, name)
     if name in ("MMTGTrainer",):
         from . import trainer
         return getattr(trainer, name)

@@ -307,15 +307,78 @@ def case_filtering(out_dir, ref_generate):
     print("wrote", path)
 
 
+def case_dataset(out_dir):
+    """MyDataset layout KAT (MyDataset.py:34-118): two synthetic records through the reference class with the
+    reference's own vocabulary; the fixture keeps the records' strings, the tokenizer's output for every string
+    (so the test needs no vocabulary file) and the resulting arrays."""
+    if REF_SRC not in sys.path:
+        sys.path.insert(0, REF_SRC)
+    from transformers import BertTokenizer
+    import MyDataset as ref_ds
+    tok = BertTokenizer(os.path.join(REF_SRC, "vocab", "vocab.txt"))
+    rng = np.random.default_rng(11)
+
+    class Cfg:
+        topic_prompt_length, max_sent_length = 15, 20
+
+    lyr_a = ["我站在 夏天的风里", "想起你说过的话", "城市的灯一盏一盏亮起", "谁还在等", "雨落下来\n打湿了回忆", "我们都没有说再见",
+             "时间把故事写成一首很长很长很长很长很长很长很长很长的歌谣没有尽头", "梦", "如果还能回到那个夏天", "我会记得抱紧你"]
+    lyr_b = ["hello 世界", "好", "春天来了", "花开了", "鸟儿唱", "风轻轻", "云淡淡", "水清清", "山高高", "路长长"]
+    recs = []
+    for topic, lyr, rating in (("爱情 夏天 回忆", lyr_a, 5), ("这是一个非常非常非常长的主题词列表需要被截断", lyr_b, 2)):
+        r = {"topic": topic, "topic_emb": rng.standard_normal(2048).astype(np.float32).tolist(), "lyrics": lyr, "rating": rating}
+        for i in range(5):
+            for ch in ("text", "img", "r"):
+                r["%s_%d" % (ch, i)] = "x"
+                r["%s_%d_emb" % (ch, i)] = rng.standard_normal(2048).astype(np.float32).tolist()
+        recs.append(r)
+    scratch = tempfile.mkdtemp(prefix="mmtg_ds_")
+    pk = os.path.join(scratch, "data.pkl")
+    with open(pk, "wb") as f:
+        pickle.dump(recs, f)
+    ds = ref_ds.MyDataset(pk, tok, Cfg(), if_train=True)
+    fx = {}
+    strings = {}
+    for n, r in enumerate(recs):
+        item = ds[n]
+        for k, v in item.items():
+            if "emb" in k:      # pass-through fields: shape and dtype only (the values are the record's own lists)
+                fx["item%d_%s_shape" % (n, k)] = np.asarray(np.asarray(v).shape)
+            else:
+                fx["item%d_%s" % (n, k)] = np.asarray(v)
+        strings["主题词：" + r["topic"]] = tok.tokenize("主题词：" + r["topic"])
+        for sent in r["lyrics"]:
+            for ch in (" ", "\n", "\t", "\r", "\xa0", "\u3000"):
+                sent = sent.replace(ch, "")
+            strings[sent] = tok.tokenize(sent)
+    vocab = {}
+    for toks in strings.values():
+        for t in toks:
+            vocab[t] = tok.convert_tokens_to_ids(t)
+    for t in ("[#START#]", "[#EOS#]", tok.pad_token, tok.sep_token):
+        vocab[t] = tok.convert_tokens_to_ids(t)
+    meta = {"records": [{"topic": r["topic"], "lyrics": r["lyrics"], "rating": r["rating"]} for r in recs],
+            "tokenize": strings, "vocab": vocab, "pad_token": tok.pad_token, "sep_token": tok.sep_token,
+            "pad_token_id": tok.pad_token_id, "emb_seed": 11}
+    fx["meta_json"] = np.array(json.dumps(meta, ensure_ascii=False))
+    path = os.path.join(out_dir, "dataset.npz")
+    np.savez_compressed(path, **fx)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
     ap.add_argument("--skip-full", action="store_true")
+    ap.add_argument("--only-dataset", action="store_true", help="regenerate tests/golden/dataset.npz only")
     args = ap.parse_args()
     out_dir = os.path.abspath(args.out)
     os.makedirs(out_dir, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(8)
+    case_dataset(out_dir)
+    if args.only_dataset:
+        return
     gen = case_model("tiny_s5", out_dir, S=5, n_layer=2, V=160, B=3, seed=100)
     case_filtering(out_dir, gen)
     case_model("tiny_s2", out_dir, S=2, n_layer=2, V=160, B=4, seed=200, with_decode=False)
