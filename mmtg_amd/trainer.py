@@ -57,6 +57,29 @@ class MMTGTrainer:
             return self.lr
         return self.lr * linear_schedule(self.sched_step, self.warmup, self.total)
 
+    # ---- true resume (the reference saves the model only, train.py:212)
+    def state_dict(self):
+        """Optimizer moments (flat fp32, the engine's parameter order), AdamW step count, scheduler position
+        and the dropout counter: together with ``model.state_dict()`` everything a bit-continuing run needs."""
+        eng = self.eng
+        return {"format": "mmtg-trainer-1", "layout_total": eng.layout.total,
+                "exp_avg": None if eng.opt_m is None else eng.opt_m.detach().cpu().clone(),
+                "exp_avg_sq": None if eng.opt_v is None else eng.opt_v.detach().cpu().clone(),
+                "step_count": eng.step_count, "sched_step": self.sched_step, "drop_seed": eng.drop_seed,
+                "hparams": {"lr": self.lr, "alpha": self.alpha, "max_norm": self.max_norm, "betas": tuple(self.betas),
+                            "eps": self.eps, "weight_decay": self.wd, "warmup_steps": self.warmup,
+                            "total_steps": self.total, "lm_weight": self.lm_weight}}
+
+    def load_state_dict(self, sd):
+        eng = self.eng
+        if sd.get("format") != "mmtg-trainer-1" or sd.get("layout_total") != eng.layout.total:
+            raise ValueError("trainer state of a different model layout (%s, %s parameters; this model has %d)"
+                             % (sd.get("format"), sd.get("layout_total"), eng.layout.total))
+        for name, key in (("opt_m", "exp_avg"), ("opt_v", "exp_avg_sq")):
+            v = sd[key]
+            setattr(eng, name, None if v is None else v.to(eng.dev, torch.float32).clone())
+        eng.step_count, self.sched_step, eng.drop_seed = int(sd["step_count"]), int(sd["sched_step"]), int(sd["drop_seed"])
+
     def step(self, batch, stage=3, filter_rows=True):
         """One optimisation step; returns device scalars (no host sync) {'loss','lm_loss','kl'}.
         Returns None when the stage filter leaves no rows on a single rank (train.py:184-185)."""
@@ -86,3 +109,22 @@ class MMTGTrainer:
         eng.adamw_step(self.current_lr(), self.max_norm, self.betas, self.eps, self.wd)
         self.sched_step += 1
         return out
+
+
+def save_checkpoint(path, model, trainer=None, args=None, model_cfgs=None):
+    """The reference's checkpoint dict ``{'model', 'args', 'model_cfgs'}`` (train.py:212; loads in the
+    reference as is) plus, when a trainer is given, ``'trainer'`` for resuming."""
+    ckpt = {"model": {k: v.detach().cpu() for k, v in model.state_dict().items()}, "args": args, "model_cfgs": model_cfgs}
+    if trainer is not None:
+        ckpt["trainer"] = trainer.state_dict()
+    torch.save(ckpt, path)
+
+
+def load_checkpoint(path, model, trainer=None):
+    """Loads a checkpoint written by ``save_checkpoint`` or by the reference's train.py ('module.' prefixes and
+    transformers-4.12.3 buffers accepted).  Returns the checkpoint dict."""
+    ckpt = torch.load(path, map_location="cpu", weights_only=False)
+    model.load_state_dict(ckpt["model"] if "model" in ckpt else ckpt)
+    if trainer is not None and ckpt.get("trainer") is not None:
+        trainer.load_state_dict(ckpt["trainer"])
+    return ckpt
