@@ -252,6 +252,15 @@ int mmtg_transpose_batch(int dtype, const void* src, void* dst, const long* desc
 int mmtg_logits_process_argmax(const float* logits, long ldl, int V, const long long* generated,
                                long ldg, const int* gen_len, float temperature, float rep_penalty,
                                long long* next, int B, void* stream);
+/* Stochastic counterpart (generate.py:64-94,127-141 with top_k / top_p as given): same processed logits, then the
+ * reference's top-k filter (values below the k-th largest dropped, ties kept; 0 = off) and nucleus filter (sorted
+ * descending, an id stays while the probability mass before it is <= top_p; 0 = off), softmax, and ONE draw per row
+ * by inverse CDF over the kept ids in index order with the caller's uniforms[b] in [0,1) (torch.multinomial's
+ * generator is not reproducible outside torch; the distribution is the reference's).  filtered (nullable, [B, ldl]):
+ * the filtered processed logits (-inf where dropped), as top_k_top_p_filtering returns them.                        */
+int mmtg_logits_process_sample(const float* logits, long ldl, int V, const long long* generated, long ldg,
+                               const int* gen_len, float temperature, float rep_penalty, int top_k, float top_p,
+                               const float* uniforms, long long* next, float* filtered, int B, void* stream);
 
 /* ---------------------------------------------------------------- KV-cached decode step (generate.py:117-142)
  * Batched, lock-step: every row is at position *pos_ptr (a DEVICE int, so a captured hipGraph of
@@ -278,6 +287,11 @@ int mmtg_decode_attn_split(int dtype, const float* part, int splits, const float
                            void* stream);
 int mmtg_decode_select(const float* logits, long ldl, int V, long long* seq, long ldseq, const int* pos_ptr,
                        int P, int sent, float temperature, float rep_penalty, int B, void* stream);
+/* decode_select with the stochastic selection above; the draw of position pos uses uniforms[pos * ldu + b]
+ * (a [positions, ldu] device array filled before the graph is replayed).                                    */
+int mmtg_decode_sample(const float* logits, long ldl, int V, long long* seq, long ldseq, const int* pos_ptr,
+                       int P, int sent, float temperature, float rep_penalty, int top_k, float top_p,
+                       const float* uniforms, long ldu, int B, void* stream);
 int mmtg_decode_advance(int* pos_ptr, void* stream);
 
 #ifdef __cplusplus

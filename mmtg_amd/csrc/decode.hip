@@ -71,6 +71,181 @@ __global__ __launch_bounds__(256) void logits_argmax_kernel(const float* __restr
     }
 }
 
+
+// ------------------------------------------------------------------ stochastic selection (generate.py:64-94,127-141)
+// One workgroup per row: processed logits (penalty, temperature, bans, as above) -> top-k filter
+// (`logits < kth largest` dropped, ties at the k-th value kept) -> nucleus filter over the survivors (sorted
+// descending, an element stays while the probability mass of the elements before it is <= top_p) -> softmax ->
+// one draw by inverse CDF over the kept ids in index order with the caller's uniform u in [0,1).
+// No sort: both thresholds come from a 4-pass radix select over the order-preserving integer image of the
+// floats -- by COUNT for top-k, by accumulated probability MASS for top-p.  px: V floats of LDS.
+__device__ __forceinline__ unsigned fkey(float x) {
+    const unsigned b = __float_as_uint(x);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+__device__ int sample_row(const float* row, int V, const unsigned* cnt, float* px, float temperature, float rep_penalty,
+                          int top_k, float top_p, float u, int tid, float* filtered) {
+    __shared__ unsigned hcnt[256];
+    __shared__ float hmass[256];
+    __shared__ float sred[4];
+    __shared__ unsigned s_prefix, s_rem;
+    __shared__ float s_acc;
+    __shared__ int s_pick;
+    for (int v = tid; v < V; v += 256) {
+        float x = row[v];
+        if (v != 0 && v != 102) {
+            const int c = (cnt[v >> 1] >> (16 * (v & 1))) & 0xFFFF;
+            for (int i = 0; i < c; ++i) x = x / rep_penalty;
+        }
+        x = x / temperature;
+        if (v == 1 || v == 2 || v == 100 || v == 102) x = -INFINITY;
+        px[v] = x;
+    }
+    __syncthreads();
+    // ---- top-k: key of the k-th largest value
+    unsigned keyk = 0u;
+    if (top_k > 0 && top_k < V) {
+        if (tid == 0) { s_prefix = 0u; s_rem = (unsigned)top_k; }
+        unsigned mask = 0u;
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            hcnt[tid] = 0u;
+            __syncthreads();
+            const unsigned prefix = s_prefix;
+            for (int v = tid; v < V; v += 256) {
+                const unsigned k = fkey(px[v]);
+                if ((k & mask) == prefix) atomicAdd(hcnt + ((k >> shift) & 255u), 1u);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                unsigned rem = s_rem;
+                int bin = 255;
+                for (; bin > 0; --bin) {
+                    if (hcnt[bin] >= rem) break;
+                    rem -= hcnt[bin];
+                }
+                s_rem = rem;
+                s_prefix = prefix | ((unsigned)bin << shift);
+            }
+            mask |= 255u << shift;
+            __syncthreads();
+        }
+        keyk = s_prefix;
+    }
+    // ---- max and total mass of the survivors
+    float mx = -INFINITY;
+    for (int v = tid; v < V; v += 256)
+        if (fkey(px[v]) >= keyk) mx = fmaxf(mx, px[v]);
+    mx = wave_max(mx);
+    if ((tid & 63) == 0) sred[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(sred[0], sred[1]), fmaxf(sred[2], sred[3]));
+    __syncthreads();
+    float tot = 0.f;
+    for (int v = tid; v < V; v += 256)
+        if (fkey(px[v]) >= keyk) tot += expf(px[v] - mx);
+    tot = wave_sum(tot);
+    if ((tid & 63) == 0) sred[tid >> 6] = tot;
+    __syncthreads();
+    tot = sred[0] + sred[1] + sred[2] + sred[3];
+    __syncthreads();
+    // ---- top-p: key of the first element (descending) whose inclusive mass exceeds top_p
+    unsigned keyp = 0u;
+    if (top_p > 0.f) {
+        const float P = top_p * tot;
+        if (tid == 0) { s_prefix = 0u; s_acc = 0.f; s_pick = 1; }
+        unsigned mask = 0u;
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            hmass[tid] = 0.f;
+            __syncthreads();
+            const unsigned prefix = s_prefix;
+            if (s_pick)
+                for (int v = tid; v < V; v += 256) {
+                    const unsigned k = fkey(px[v]);
+                    if (k >= keyk && (k & mask) == prefix) atomicAdd(hmass + ((k >> shift) & 255u), expf(px[v] - mx));
+                }
+            __syncthreads();
+            if (tid == 0 && s_pick) {
+                float acc = s_acc;
+                int bin = 255;
+                for (; bin >= 0; --bin) {
+                    if (acc + hmass[bin] > P) break;
+                    acc += hmass[bin];
+                }
+                if (bin < 0) s_pick = 0;                 // the whole mass stays within top_p: keep every survivor
+                else { s_acc = acc; s_prefix = prefix | ((unsigned)bin << shift); }
+            }
+            mask |= 255u << shift;
+            __syncthreads();
+        }
+        keyp = s_pick ? s_prefix : 0u;
+        __syncthreads();
+    }
+    const unsigned keyt = keyk > keyp ? keyk : keyp;
+    if (filtered)
+        for (int v = tid; v < V; v += 256) filtered[v] = fkey(px[v]) >= keyt ? px[v] : -INFINITY;
+    // ---- inverse CDF over the kept ids in index order
+    const int chunk = (V + 255) / 256, v0 = tid * chunk, v1 = min(V, v0 + chunk);
+    float mine = 0.f;
+    for (int v = v0; v < v1; ++v)
+        if (fkey(px[v]) >= keyt && px[v] > -INFINITY) mine += expf(px[v] - mx);
+    // inclusive scan of the 256 chunk sums (in hmass)
+    hmass[tid] = mine;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        const float add = tid >= o ? hmass[tid - o] : 0.f;
+        __syncthreads();
+        hmass[tid] += add;
+        __syncthreads();
+    }
+    const float Z = hmass[255], target = u * Z;
+    if (tid == 0) s_pick = 0x7fffffff;
+    __syncthreads();
+    const float before = tid ? hmass[tid - 1] : 0.f;
+    if (mine > 0.f && target < hmass[tid] && target >= before) {
+        float acc = before;
+        int pick = -1;
+        for (int v = v0; v < v1; ++v)
+            if (fkey(px[v]) >= keyt && px[v] > -INFINITY) {
+                acc += expf(px[v] - mx);
+                pick = v;
+                if (target < acc) break;
+            }
+        if (pick >= 0) atomicMin(&s_pick, pick);
+    }
+    __syncthreads();
+    if (s_pick == 0x7fffffff) {          // rounding at the upper end: the last kept id
+        int last = -1;
+        for (int v = v0; v < v1; ++v)
+            if (fkey(px[v]) >= keyt && px[v] > -INFINITY) last = v;
+        __syncthreads();
+        if (tid == 0) s_pick = -1;
+        __syncthreads();
+        if (last >= 0) atomicMax(&s_pick, last);
+        __syncthreads();
+    }
+    return s_pick < 0 ? 0 : s_pick;
+}
+
+__global__ __launch_bounds__(256) void logits_sample_kernel(const float* __restrict__ logits, long ldl, int V,
+        const long long* __restrict__ generated, long ldg, const int* __restrict__ gen_len,
+        float temperature, float rep_penalty, int top_k, float top_p, const float* __restrict__ uniforms,
+        long long* __restrict__ next, float* __restrict__ filtered) {
+    extern __shared__ unsigned cnt[];
+    float* px = reinterpret_cast<float*>(cnt + (V + 1) / 2);
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int n = min(gen_len[b], MAXGEN);
+    const long long* gen = generated + (long)b * ldg;
+    if (n > 0 && gen[n - 1] == 0) {  // sticky PAD (generate.py:137-138)
+        if (tid == 0) next[b] = 0;
+        return;
+    }
+    count_ids(cnt, V, gen, n, tid);
+    const int pick = sample_row(logits + (long)b * ldl, V, cnt, px, temperature, rep_penalty, top_k, top_p, uniforms[b], tid,
+                                filtered ? filtered + (long)b * ldl : nullptr);
+    if (tid == 0) next[b] = pick;
+}
+
 }  // namespace
 
 extern "C" int mmtg_logits_process_argmax(const float* logits, long ldl, int V, const long long* generated,
@@ -84,6 +259,27 @@ extern "C" int mmtg_logits_process_argmax(const float* logits, long ldl, int V, 
     hipLaunchKernelGGL(logits_argmax_kernel, dim3(B), dim3(256), (size_t)((V + 1) / 2) * 4, s, logits, ldl, V, generated, ldg, gen_len,
                        temperature, rep_penalty, next);
     MMTG_LAUNCH_CHECK("logits_process_argmax");
+    return MMTG_OK;
+}
+
+extern "C" int mmtg_logits_process_sample(const float* logits, long ldl, int V, const long long* generated, long ldg,
+                                          const int* gen_len, float temperature, float rep_penalty, int top_k, float top_p,
+                                          const float* uniforms, long long* next, float* filtered, int B, void* stream) {
+    MMTG_REQUIRE(logits && generated && gen_len && uniforms && next && B > 0 && V > 0 && ldl >= V, "logits_process_sample: bad args");
+    MMTG_REQUIRE(temperature > 0.f && rep_penalty > 0.f && top_k >= 0 && top_p >= 0.f, "logits_process_sample: bad sampling parameters");
+    MMTG_REQUIRE(V <= 24000, "logits_process_sample: vocabulary of %d exceeds the LDS row image (24000)", V);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(MMTG_PROF_DECODE, s, 12.0 * B * V, 4.0 * B * V);
+    const size_t shm = (size_t)((V + 1) / 2) * 4 + (size_t)V * 4;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)logits_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096) != hipSuccess)
+            MMTG_FAIL(MMTG_ERR_HIP, "logits_process_sample: cannot raise dynamic LDS");
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(logits_sample_kernel, dim3(B), dim3(256), shm, s, logits, ldl, V, generated, ldg, gen_len, temperature,
+                       rep_penalty, top_k, top_p, uniforms, next, filtered);
+    MMTG_LAUNCH_CHECK("logits_process_sample");
     return MMTG_OK;
 }
 
@@ -219,7 +415,8 @@ __global__ __launch_bounds__(64) void decode_attn_kernel(const T* __restrict__ q
 // logits processor + arg-max + forced-token cadence + append (generate.py:117-142), device-driven.
 __global__ __launch_bounds__(256) void decode_select_kernel(const float* __restrict__ logits, long ldl, int V,
         long long* __restrict__ seq, long ldseq, const int* __restrict__ pos_ptr, int P, int sent,
-        float temperature, float rep_penalty, int have_logits) {
+        float temperature, float rep_penalty, int have_logits, int top_k, float top_p,
+        const float* __restrict__ uniforms, long ldu) {
     extern __shared__ unsigned cnt[];
     __shared__ float sval[4];
     __shared__ int sidx[4];
@@ -233,6 +430,13 @@ __global__ __launch_bounds__(256) void decode_select_kernel(const float* __restr
     const int n = min(j, MAXGEN);
     if (gen[n - 1] == 0) { if (tid == 0) gen[j] = 0; return; }                   // sticky PAD
     count_ids(cnt, V, gen, n, tid);
+    if (uniforms) {            // stochastic: uniforms[pos, b] drives the draw (top_k == 1 and top_p == 0 is the greedy path)
+        float* px = reinterpret_cast<float*>(cnt + (V + 1) / 2);
+        const int pick = sample_row(logits + (long)b * ldl, V, cnt, px, temperature, rep_penalty, top_k, top_p,
+                                    uniforms[(long)pos * ldu + b], tid, nullptr);
+        if (tid == 0) gen[j] = pick;
+        return;
+    }
     float best;
     int besti;
     scan_row(logits + (long)b * ldl, V, cnt, temperature, rep_penalty, tid, best, besti);
@@ -322,15 +526,40 @@ extern "C" int mmtg_decode_attn_split(int dtype, const float* part, int splits, 
     return MMTG_OK;
 }
 
+static int decode_select_launch(const float* logits, long ldl, int V, long long* seq, long ldseq, const int* pos_ptr,
+                                int P, int sent, float temperature, float rep_penalty, int top_k, float top_p,
+                                const float* uniforms, long ldu, int B, void* stream);
+
 extern "C" int mmtg_decode_select(const float* logits, long ldl, int V, long long* seq, long ldseq, const int* pos_ptr,
                                   int P, int sent, float temperature, float rep_penalty, int B, void* stream) {
+    return decode_select_launch(logits, ldl, V, seq, ldseq, pos_ptr, P, sent, temperature, rep_penalty, 1, 0.f, nullptr, 0, B, stream);
+}
+
+extern "C" int mmtg_decode_sample(const float* logits, long ldl, int V, long long* seq, long ldseq, const int* pos_ptr,
+                                  int P, int sent, float temperature, float rep_penalty, int top_k, float top_p,
+                                  const float* uniforms, long ldu, int B, void* stream) {
+    MMTG_REQUIRE(uniforms && ldu >= B && top_k >= 0 && top_p >= 0.f, "decode_sample: uniforms [positions, ldu >= B], top_k >= 0, top_p >= 0");
+    return decode_select_launch(logits, ldl, V, seq, ldseq, pos_ptr, P, sent, temperature, rep_penalty, top_k, top_p, uniforms, ldu, B, stream);
+}
+
+static int decode_select_launch(const float* logits, long ldl, int V, long long* seq, long ldseq, const int* pos_ptr,
+                                int P, int sent, float temperature, float rep_penalty, int top_k, float top_p,
+                                const float* uniforms, long ldu, int B, void* stream) {
     MMTG_REQUIRE(seq && pos_ptr && B > 0 && sent > 1, "decode_select: bad args");
     MMTG_REQUIRE(!logits || (V > 0 && ldl >= V && temperature > 0.f && rep_penalty > 0.f), "decode_select: bad logits args");
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(MMTG_PROF_DECODE, s, 4.0 * B * V, 4.0 * B * V);
-    MMTG_REQUIRE(!logits || V <= 30000, "decode_select: vocabulary of %d exceeds the 60 KB LDS occurrence table", V);
-    hipLaunchKernelGGL(decode_select_kernel, dim3(B), dim3(256), logits ? (size_t)((V + 1) / 2) * 4 : 0, s, logits, ldl, V, seq, ldseq,
-                       pos_ptr, P, sent, temperature, rep_penalty, logits != nullptr);
+    MMTG_REQUIRE(!logits || V <= (uniforms ? 24000 : 30000), "decode_select: vocabulary of %d exceeds the LDS tables", V);
+    size_t shm = logits ? (size_t)((V + 1) / 2) * 4 : 0;
+    if (logits && uniforms) shm += (size_t)V * 4;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)decode_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096) != hipSuccess)
+            MMTG_FAIL(MMTG_ERR_HIP, "decode_select: cannot raise dynamic LDS");
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(decode_select_kernel, dim3(B), dim3(256), shm, s, logits, ldl, V, seq, ldseq,
+                       pos_ptr, P, sent, temperature, rep_penalty, logits != nullptr, top_k, top_p, logits ? uniforms : nullptr, ldu);
     MMTG_LAUNCH_CHECK("decode_select");
     return MMTG_OK;
 }

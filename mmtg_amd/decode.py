@@ -72,7 +72,7 @@ class GreedyDecoder:
         eng, sh, B = self.eng, self.eng.sh, self.B
         D, H, E = sh.D, sh.H, sh.E
         pre = "decoder.gpt2.transformer."
-        temperature, rep = self.params
+        temperature, rep, top_k, top_p = self.params
         sent = sh.msl + 2
         hip.decode_embed(eng.table, self.seq, self.c, self.x, self.pos, self.tpw_type, self.tpw_mask, self.types,
                          self.keep, B, sh.P, sh.S, E, sh.two_sents, eng.table.shape[0], sent,
@@ -89,7 +89,11 @@ class GreedyDecoder:
         if with_head:
             Vp = eng.layout.Vpad
             hip.gemm(self.a, eng.Wp("wte"), self.logits, B, Vp, D, transB=True, ldb=D, out_f32=True)
-            hip.decode_select(self.logits, Vp, min(sh.V, 13317), self.seq, self.pos, sh.P, sent, temperature, rep, B)
+            if top_k == 1 and top_p == 0.0:
+                hip.decode_select(self.logits, Vp, min(sh.V, 13317), self.seq, self.pos, sh.P, sent, temperature, rep, B)
+            else:        # stochastic: the draw of each position reads its row of the pre-filled uniforms
+                hip.decode_sample(self.logits, Vp, min(sh.V, 13317), self.seq, self.pos, sh.P, sent, temperature, rep,
+                                  top_k, top_p, self.uniforms, B)
         else:
             hip.decode_select(None, 0, 0, self.seq, self.pos, sh.P, sent, temperature, rep, B)
         hip.decode_advance(self.pos)
@@ -175,17 +179,24 @@ class GreedyDecoder:
 
     # ------------------------------------------------------------------ public
     @torch.no_grad()
-    def generate(self, batch, length, temperature=1.0, repitition_penalty=1.0):
+    def generate(self, batch, length, temperature=1.0, repitition_penalty=1.0, top_k=1, top_p=0.0, generator=None):
         """batch: dict with topic_ids/tpw_* [B,P], topic_emb, img_embs, r_embs (no targets needed).
         Runs `length` iterations of the reference loop and returns the lyric ids
-        [B, 1 + length] (column 0 is the initial [#START#])."""
+        [B, 1 + length] (column 0 is the initial [#START#]).  top_k = 1, top_p = 0 is the greedy setting;
+        anything else samples on the device (generate.py:137-141): one uniform per row and position is drawn
+        from `generator` (a CUDA torch.Generator; default: the global one) before the steps are replayed."""
         eng, sh = self.eng, self.eng.sh
         B = batch["img_embs"].shape[0]
         if B != self.B:
             raise ValueError("decoder was built for batch %d, got %d" % (self.B, B))
         if length > self.max_len:
             raise ValueError("length %d exceeds max_len %d" % (length, self.max_len))
-        self.params = (float(temperature), float(repitition_penalty))
+        self.params = (float(temperature), float(repitition_penalty), int(top_k), float(top_p))
+        if not (int(top_k) == 1 and float(top_p) == 0.0):
+            if getattr(self, "uniforms", None) is None:
+                self.uniforms = torch.empty(sh.P + self.max_len + 1, self.B, device=eng.dev, dtype=torch.float32)
+            self.uniforms.uniform_(0.0, 1.0, generator=generator)
+            self.uniforms.clamp_(max=1.0 - 2.0 ** -24)
         eng.invalidate_copies()
         self.eng.refresh_copies()
         a = eng.forward(batch, train_flag=False, training=False, encode_only=True)

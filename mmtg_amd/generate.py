@@ -4,8 +4,9 @@
 ``repitition_penalty``), its forced [#START#]/[#EOS#] cadence, sticky PAD and the
 lagging return value.  The model call is the HIP engine; the greedy setting
 (top_k=1, top_p=0) post-processes logits with the fused HIP kernel
-(mmtg_logits_process_argmax); the stochastic setting follows the reference's
-filtering + multinomial on the device.
+(mmtg_logits_process_argmax); the stochastic setting uses mmtg_logits_process_sample (the reference's
+penalty / temperature / bans / top-k / top-p, then one draw by inverse CDF with a uniform from torch's generator --
+torch.multinomial's own stream cannot be reproduced outside torch; the distribution is the reference's).
 """
 from __future__ import annotations
 
@@ -74,18 +75,11 @@ def sample_sequence(model, start_input, length, tokenizer, temperature=1.0, top_
                                           generated.shape[1], glen, temperature, repitition_penalty, nxt, 1)
                 next_token = nxt.view(1, 1).clone()
             else:
-                logits = outputs[0, -1, :].clone()
-                for tok in generated[0].tolist():       # once per occurrence (reference quirk)
-                    if tok in (0, 102):
-                        continue
-                    logits[tok] /= repitition_penalty
-                logits = logits / temperature
-                for bid in BANNED:
-                    logits[bid] = -float("Inf")
-                if generated[0, -1].item() == 0:
-                    next_token = torch.zeros(1, 1, dtype=torch.long, device=device)
-                else:
-                    filt = top_k_top_p_filtering(logits, top_k=top_k, top_p=top_p)[:13317]
-                    next_token = torch.multinomial(F.softmax(filt, dim=-1), num_samples=1).unsqueeze(0)
+                row = outputs[0, -1, :]
+                glen.fill_(generated.shape[1])
+                u = torch.rand(1, device=device).clamp_(max=1.0 - 2.0 ** -24)
+                hip.logits_process_sample(row, row.shape[0], min(row.shape[0], 13317), generated.contiguous(),
+                                          generated.shape[1], glen, temperature, repitition_penalty, top_k, top_p, u, nxt, 1)
+                next_token = nxt.view(1, 1).clone()
             inputs["targets"] = torch.cat((generated, next_token), dim=-1)
     return generated.tolist()[0]

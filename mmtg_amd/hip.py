@@ -64,6 +64,8 @@ _SIGS = {
     "mmtg_decode_embed_add": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp], _i),
     "mmtg_decode_attn": ([_i, _vp, _vp, _vp, _vp, _l, _vp, _vp, _i, _i, _i, _i, _vp], _i),
     "mmtg_decode_attn_split": ([_i, _vp, _i, _vp, _vp, _vp, _vp, _l, _vp, _vp, _i, _i, _i, _i, _vp], _i),
+    "mmtg_logits_process_sample": ([_vp, _l, _i, _vp, _l, _vp, _f, _f, _i, _f, _vp, _vp, _vp, _i, _vp], _i),
+    "mmtg_decode_sample": ([_vp, _l, _i, _vp, _l, _vp, _i, _i, _f, _f, _i, _f, _vp, _l, _i, _vp], _i),
     "mmtg_decode_select": ([_vp, _l, _i, _vp, _l, _vp, _i, _i, _f, _f, _i, _vp], _i),
     "mmtg_decode_advance": ([_vp, _vp], _i),
 }
@@ -335,6 +337,14 @@ def logits_process_argmax(logits, ldl, V, generated, ldg, gen_len, temperature, 
            "logits_process_argmax")
 
 
+def logits_process_sample(logits, ldl, V, generated, ldg, gen_len, temperature, rep_penalty, top_k, top_p, uniforms, nxt, B,
+                          filtered=None):
+    """One draw per row from the reference's filtered distribution (include/mmtg_hip.h); uniforms: f32 [B] in [0,1)."""
+    _check(lib().mmtg_logits_process_sample(_p(logits), ldl, V, _p(generated), ldg, _p(gen_len), float(temperature),
+                                            float(rep_penalty), int(top_k), float(top_p), _p(uniforms), _p(nxt), _p(filtered),
+                                            B, _stream()), "logits_process_sample")
+
+
 # ------------------------------------------------------------------ KV-cached decode step
 def decode_embed(table, seq, c, x, pos, tpw_type, tpw_mask, type_out, keep, B, P, S, E, two_sents, V, sent, max_sent_num):
     _check(lib().mmtg_decode_embed(dt(table), _p(table), _p(seq), seq.stride(0), _p(c), _p(x), _p(pos), _p(tpw_type),
@@ -360,6 +370,12 @@ def decode_attn_split(part, splits, bias, kcache, vcache, keep, pos, out, B, nH,
 def decode_select(logits, ldl, V, seq, pos, P, sent, temperature, rep_penalty, B):
     _check(lib().mmtg_decode_select(_p(logits), ldl, V, _p(seq), seq.stride(0), _p(pos), P, sent, float(temperature),
                                     float(rep_penalty), B, _stream()), "decode_select")
+
+
+def decode_sample(logits, ldl, V, seq, pos, P, sent, temperature, rep_penalty, top_k, top_p, uniforms, B):
+    _check(lib().mmtg_decode_sample(_p(logits), ldl, V, _p(seq), seq.stride(0), _p(pos), P, sent, float(temperature),
+                                    float(rep_penalty), int(top_k), float(top_p), _p(uniforms), uniforms.stride(0), B, _stream()),
+           "decode_sample")
 
 
 def decode_advance(pos):

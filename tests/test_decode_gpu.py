@@ -159,3 +159,42 @@ def test_checkpoint_resume_continues_the_run(tmp_path):
         bad = t2.state_dict()
         bad["layout_total"] += 1
         t2.load_state_dict(bad)
+
+
+def test_batched_sampling_decode_rules_and_greedy_limit():
+    """Device-side sampling in the KV-cached decoder (top_k = 30 as in generate.sh): forced [#START#]/[#EOS#]
+    cadence, no banned id, sticky PAD, rows differ from each other and between seeds, the same CUDA generator
+    seed reproduces the ids; top_k = 1 reduces to the greedy decoder bit for bit."""
+    fx, meta, mcfg, gcfg, dcfg, weights, table, batch = load_case("tiny_s5")
+    model = MMTG(mcfg, dcfg, meta["V"], train_flag=False, gpt2_config=gcfg, token_table=table, compute_dtype="f32")
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})
+    model.to("cuda").eval()
+    tb = batch_to_torch(batch, "cuda")
+    B = tb["img_embs"].shape[0]
+    dec = GreedyDecoder(model, B, max_len=60, use_graph=True)
+    length = 50
+    greedy = dec.generate(tb, length, temperature=1.1, repitition_penalty=1.5)
+    k1 = dec.generate(tb, length, temperature=1.1, repitition_penalty=1.5, top_k=1, top_p=0.0)
+    assert torch.equal(greedy, k1)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(11)
+    s1 = dec.generate(tb, length, temperature=1.1, repitition_penalty=1.5, top_k=30, top_p=0.0, generator=g)
+    g.manual_seed(11)
+    s2 = dec.generate(tb, length, temperature=1.1, repitition_penalty=1.5, top_k=30, top_p=0.0, generator=g)
+    g.manual_seed(12)
+    s3 = dec.generate(tb, length, temperature=1.1, repitition_penalty=1.5, top_k=30, top_p=0.9, generator=g)
+    assert torch.equal(s1, s2) and not torch.equal(s1, s3) and not torch.equal(s1, greedy)
+    for ids in (s1, s3):
+        ids = ids.cpu()
+        assert (ids[:, 0] == 1).all()
+        for j in range(2, 1 + length):
+            forced = (j + 1) % 22
+            col = ids[:, j]
+            if forced == 0:
+                assert (col == 2).all()
+            elif forced == 1:
+                assert (col == 1).all()
+            else:
+                assert not any(int(v) in (1, 2, 100, 102) for v in col)
+                prev_pad = ids[:, j - 1] == 0
+                assert (col[prev_pad] == 0).all()

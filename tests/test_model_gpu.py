@@ -188,6 +188,31 @@ def test_greedy_decode_bit_exact(length, row):
     assert ids == fx[f"greedy_len{length}_row{row}"].tolist()
 
 
+def test_sample_sequence_stochastic_setting_follows_the_rules():
+    """generate.sh's default setting (top_k = 30) through the reference-shaped sample_sequence: the HIP selection
+    kernel draws with torch's generator, so a seed reproduces the ids; forced cadence, bans and the lagging
+    return value hold; a different seed changes the text."""
+    fx, meta, mcfg, gcfg, dcfg, weights, table, batch, model = build("tiny_s5", "f32", train_flag=False)
+    start = {k: np.asarray(v[0]) for k, v in batch.items() if k != "rating"}
+    start["targets"] = np.asarray([1])
+    torch.manual_seed(5)
+    a = sample_sequence(model, start, 46, None, temperature=1.1, top_k=30, top_p=0.0, repitition_penalty=1.5, device=DEV)
+    torch.manual_seed(5)
+    b = sample_sequence(model, start, 46, None, temperature=1.1, top_k=30, top_p=0.0, repitition_penalty=1.5, device=DEV)
+    torch.manual_seed(6)
+    c = sample_sequence(model, start, 46, None, temperature=1.1, top_k=30, top_p=0.9, repitition_penalty=1.5, device=DEV)
+    assert a == b and a != c and len(a) == len(c)
+    for ids in (a, c):
+        assert ids[0] == 1
+        for j in range(2, len(ids)):
+            if (j + 1) % 22 == 0:
+                assert ids[j] == 2
+            elif (j + 1) % 22 == 1:
+                assert ids[j] == 1
+            else:
+                assert ids[j] not in (1, 2, 100, 102)
+
+
 def test_inference_branch_logits_vs_golden():
     """Inference-branch forward (rebuilt type ids / mask, model.py:290-326) at a few prefix lengths."""
     fx, meta, mcfg, gcfg, dcfg, weights, table, batch, model = build("tiny_s5", "f32", train_flag=False)

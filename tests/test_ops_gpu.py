@@ -794,3 +794,68 @@ def test_logits_process_argmax():
         else:
             want = int(torch.argmax(O.process_logits(logits[b, :V], gl, 1.1, 1.5)).item())
         assert nxt[b].item() == want, (b, nxt[b].item(), want)
+
+
+@pytest.mark.parametrize("top_k,top_p", [(30, 0.0), (1, 0.0), (5, 0.0), (10, 0.7), (0, 0.9), (30, 0.3), (0, 0.0), (400, 0.0)])
+def test_logits_process_sample(top_k, top_p):
+    """Stochastic selection kernel against the oracle (whose filter is pinned by the reference's golden KATs):
+    (a) the filtered processed logits equal the oracle's bit for bit (same kept set, same values: the radix-select
+    thresholds reproduce `logits < kth` and the shifted cumulative-probability rule); (b) the id drawn for a uniform
+    u is the inverse CDF of the filtered softmax in index order -- checked against a float64 CDF with a 1e-5 band
+    around the interval ends; (c) sticky PAD, bans, penalty per occurrence."""
+    B, V, Vpad, G = 9, 500, 512, 40
+    gen = torch.Generator().manual_seed(top_k * 7 + int(top_p * 100))
+    logits = torch.zeros(B, Vpad)
+    logits[:, :V] = torch.randn(B, V, generator=gen) * 3
+    logits[2, 10] = logits[2, 11]                    # a tie
+    logits[2, 12] = logits[2, 10]
+    generated = torch.randint(3, V, (B, G), generator=gen)
+    generated[0, :10] = 7
+    generated[1, -1] = 0                              # sticky PAD
+    lens = torch.tensor([G, G, G, 1, 17, G, 5, G, 3], dtype=torch.int32)
+    u = torch.tensor([0.0, 0.5, 0.123, 0.999, 0.37, 0.61, 0.05, 0.88, 0.999999], dtype=torch.float32)
+    nxt = torch.full((B,), -7, dtype=torch.long, device=DEV)
+    filt = torch.full((B, Vpad), float("nan"), device=DEV)
+    hip.logits_process_sample(logits.to(DEV), Vpad, V, generated.to(DEV), G, lens.to(DEV), 1.1, 1.5, top_k, top_p,
+                              u.to(DEV), nxt, B, filtered=filt)
+    nxt, filt = nxt.cpu(), filt.cpu()
+    for b in range(B):
+        gl = generated[b, :lens[b]]
+        if int(gl[-1]) == 0:
+            assert int(nxt[b]) == 0
+            continue
+        proc = O.process_logits(logits[b, :V], gl, 1.1, 1.5)
+        want = O.top_k_top_p_filtering(proc.clone(), top_k, top_p)
+        assert torch.equal(filt[b, :V], want), (b, (filt[b, :V] != want).nonzero().flatten()[:8])
+        p64 = torch.softmax(want.double(), -1)
+        cdf = torch.cumsum(p64, -1)
+        t = int(nxt[b])
+        assert want[t] > -float("inf") and t not in (1, 2, 100, 102)
+        lo = float(cdf[t] - p64[t])
+        assert lo - 1e-5 <= float(u[b]) <= float(cdf[t]) + 1e-5, (b, t, lo, float(u[b]), float(cdf[t]))
+    if top_k == 1:      # a single survivor: every u picks the arg-max, i.e. the greedy kernel's choice
+        ref = torch.empty(B, dtype=torch.long, device=DEV)
+        hip.logits_process_argmax(logits.to(DEV), Vpad, V, generated.to(DEV), G, lens.to(DEV), 1.1, 1.5, ref, B)
+        assert torch.equal(ref.cpu(), nxt)
+
+
+def test_logits_process_sample_frequencies():
+    """20 000 draws of one row (top_k = 8): empirical frequencies match the filtered softmax (chi-square with 7
+    degrees of freedom < 24.3, the 0.1 % quantile) and nothing outside the top 8 is ever drawn."""
+    V, Vpad, N = 300, 304, 20000
+    g = torch.Generator().manual_seed(3)
+    row = torch.zeros(Vpad)
+    row[:V] = torch.randn(V, generator=g) * 2
+    logits = row.repeat(N, 1).to(DEV)
+    generated = torch.full((N, 1), 1, dtype=torch.long, device=DEV)
+    lens = torch.ones(N, dtype=torch.int32, device=DEV)
+    u = torch.rand(N, generator=g).to(DEV)
+    nxt = torch.empty(N, dtype=torch.long, device=DEV)
+    hip.logits_process_sample(logits, Vpad, V, generated, 1, lens, 1.0, 1.0, 8, 0.0, u, nxt, N)
+    want = O.top_k_top_p_filtering(O.process_logits(row[:V], torch.tensor([1]), 1.0, 1.0), 8, 0.0)
+    p = torch.softmax(want.double(), -1)
+    counts = torch.bincount(nxt.cpu(), minlength=V).double()
+    assert float(counts[p == 0].sum()) == 0
+    kept = p > 0
+    chi2 = float((((counts[kept] - N * p[kept]) ** 2) / (N * p[kept])).sum())
+    assert int(kept.sum()) == 8 and chi2 < 24.3, chi2
