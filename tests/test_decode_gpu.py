@@ -198,3 +198,31 @@ def test_batched_sampling_decode_rules_and_greedy_limit():
                 assert not any(int(v) in (1, 2, 100, 102) for v in col)
                 prev_pad = ids[:, j - 1] == 0
                 assert (col[prev_pad] == 0).all()
+
+
+def test_trainer_edge_cases_empty_stage_and_single_row():
+    """Curriculum edge cases of train.py:178-185: a stage-1 batch whose ratings are all 2..4 selects no row -- the
+    step is skipped (returns None) and neither the parameters nor the AdamW step count move; a batch of ONE row
+    (M = 236 tokens, ragged against every 128-row tile) trains; stage 2 drops exactly the rating-3 rows."""
+    import numpy as np
+    from mmtg_amd import MMTG, synth
+    from mmtg_amd.configs import data_config, gpt2_config, make_model_cfgs
+    from mmtg_amd.trainer import MMTGTrainer
+    S, V = 5, 300
+    mcfg, dcfg = make_model_cfgs(seq_len=S), data_config(seq_len=S)
+    gcfg = gpt2_config(n_layer=2, vocab_size=V, n_positions=256)
+    model = MMTG(mcfg, dcfg, V, train_flag=True, gpt2_config=gcfg, token_table=synth.make_token_table(V, seed=2), compute_dtype="bf16")
+    model.reset_parameters(seed=1)
+    model.to("cuda")
+    tr = MMTGTrainer(model, lr=1e-4, alpha=0.2)
+    b = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in synth.make_batch(5, mcfg, dcfg, V, seed=9).items()}
+    b["rating"] = torch.tensor([2, 3, 4, 3, 2], device="cuda")
+    before = model.engine().master.clone()
+    assert tr.step(b, stage=1) is None
+    assert torch.equal(before, model.engine().master) and model.engine().step_count == 0
+    out = tr.step(b, stage=2)                  # rows with rating 3 are dropped: three rows remain
+    assert out is not None and model.engine().act["B"] == 3 and np.isfinite(float(out["loss"]))
+    one = {k: v[:1] for k, v in b.items()}
+    out = tr.step(one, stage=3)
+    assert model.engine().act["B"] == 1 and np.isfinite(float(out["loss"])) and np.isfinite(float(out["kl"]))
+    assert torch.isfinite(model.engine().master).all()

@@ -364,7 +364,7 @@ def ref_attention(qkv, keep, nH):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("T", [236, 104, 64, 300])
+@pytest.mark.parametrize("T", [236, 104, 64, 300, 1, 17, 1024])
 def test_attention(dtype, T):
     B, nH, dh = 2, 3, 64
     D = nH * dh
@@ -372,7 +372,8 @@ def test_attention(dtype, T):
     keep = torch.ones(B, T, dtype=torch.int32)
     keep[0, 9:15] = 0
     keep[1, 20:41] = 0
-    keep[1, T - 3:] = 0
+    if T > 3:               # (T = 1: the single-token sequence; 1024 = GPT-2's n_positions, four key blocks in bf16)
+        keep[1, T - 3:] = 0
     dout = rnd(B, T, D, dtype=dtype, seed=T + 1)
     qr = qkv.float().requires_grad_(True)
     oref, lref = ref_attention(qr, keep, nH)
