@@ -6,7 +6,7 @@ mkdir -p gpurun_out/ev
 timeout 1800 python -m pytest tests -m gpu -q --no-header -p no:cacheprovider 2>&1 | tail -4 | tee gpurun_out/ev/pytest_gpu.txt
 timeout 600 python __graft_entry__.py smoke 2>&1 | tail -2 | tee gpurun_out/ev/smoke.txt
 bash tools/gpu_pmc_bench.sh > gpurun_out/ev/pmc_bench.txt 2>&1; tail -1 gpurun_out/ev/pmc_bench.txt
-cp gpurun_out/bench_pmc_gemm_traffic.json profiles/r01_v7_bench_pmc_gemm_traffic.json 2>/dev/null
+cp gpurun_out/bench_pmc_gemm_traffic.json gpurun_out/ev/bench_pmc_gemm_traffic.json 2>/dev/null   # copy to profiles/r01_vN_bench_pmc_gemm_traffic.json afterwards
 bash tools/gpu_prof.sh > gpurun_out/ev/prof.txt 2>&1
 python tools/step_breakdown.py 5 > gpurun_out/ev/step_breakdown.txt 2>&1; head -3 gpurun_out/ev/step_breakdown.txt
 python tools/bench_gemm.py > gpurun_out/ev/gemm_per_shape.txt 2>&1
