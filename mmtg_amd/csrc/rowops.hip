@@ -328,6 +328,151 @@ __global__ __launch_bounds__(256, LN_BWD_WAVES) void ln_bwd2_kernel(const T* __r
     }
 }
 
+
+// v3 (bf16, cols = 512*A + 256*B): a FULL wave per row -- lane l owns the 8 columns [512a + 8l, +8) of every
+// 512-column group (one 16-byte vector) and, when B, the 4 columns [512A + 4l, +4) of the 256-column rest
+// (one 8-byte vector): 12 columns per lane at 768 instead of the 24 of the half-wave layout, so the 3 x 12 column
+// accumulators + operands fit 128 VGPRs and FOUR waves per SIMD keep twice the bytes in flight.  Same
+// next-row prefetch, partial-row workspace and finalize kernel as v2.
+template <int A, int B>
+__global__ __launch_bounds__(256, (8 * A + 4 * B <= 8 ? 4 : 3)) void ln_bwd3_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x,
+                                                         const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                         const float* __restrict__ rstd, const bf16* __restrict__ dres,
+                                                         bf16* __restrict__ dx, bf16* __restrict__ dxm, float* __restrict__ ws,
+                                                         int rows, int want_colsum,
+                                                         uint32_t thresh, uint32_t seed, float inv_keep) {
+    typedef bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    constexpr int NE = 8 * A + 4 * B, cols = 512 * A + 256 * B;
+    __shared__ float sred[4][cols];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // column of element j of this lane
+#define LN3_COL(j) ((j) < 8 * A ? ((j) >> 3) * 512 + lane * 8 + ((j) & 7) : 512 * A + lane * 4 + ((j) - 8 * A))
+    float gm[NE], ag[NE], ab[NE], ac[NE];
+#pragma unroll
+    for (int j = 0; j < NE; ++j) { gm[j] = gamma[LN3_COL(j)]; ag[j] = 0.f; ab[j] = 0.f; ac[j] = 0.f; }
+    const float inv_cols = 1.0f / cols;
+    bf16x8 px[A], pd[A];
+    bf16x4 qx, qd;
+    const int row0 = blockIdx.x * 4 + wave, stride = gridDim.x * 4;
+    if (row0 < rows) {
+        const long base = (long)row0 * cols;
+#pragma unroll
+        for (int a = 0; a < A; ++a) {
+            px[a] = *reinterpret_cast<const bf16x8*>(x + base + a * 512 + lane * 8);
+            pd[a] = *reinterpret_cast<const bf16x8*>(dy + base + a * 512 + lane * 8);
+        }
+        if constexpr (B) {
+            qx = *reinterpret_cast<const bf16x4*>(x + base + 512 * A + lane * 4);
+            qd = *reinterpret_cast<const bf16x4*>(dy + base + 512 * A + lane * 4);
+        }
+    }
+    for (int row = row0; row < rows; row += stride) {
+        const long base = (long)row * cols;
+        const float mu = mean[row], rs = rstd[row];
+        float xv[NE], dv[NE], rv[NE];
+#pragma unroll
+        for (int a = 0; a < A; ++a)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { xv[8 * a + e] = (float)px[a][e]; dv[8 * a + e] = (float)pd[a][e]; }
+        if constexpr (B) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { xv[8 * A + e] = (float)qx[e]; dv[8 * A + e] = (float)qd[e]; }
+        }
+        const int nrow = row + stride;
+        if (nrow < rows) {
+            const long nb = (long)nrow * cols;
+#pragma unroll
+            for (int a = 0; a < A; ++a) {
+                px[a] = *reinterpret_cast<const bf16x8*>(x + nb + a * 512 + lane * 8);
+                pd[a] = *reinterpret_cast<const bf16x8*>(dy + nb + a * 512 + lane * 8);
+            }
+            if constexpr (B) {
+                qx = *reinterpret_cast<const bf16x4*>(x + nb + 512 * A + lane * 4);
+                qd = *reinterpret_cast<const bf16x4*>(dy + nb + 512 * A + lane * 4);
+            }
+        }
+        if (dres) {
+#pragma unroll
+            for (int a = 0; a < A; ++a) {
+                const bf16x8 t = *reinterpret_cast<const bf16x8*>(dres + base + a * 512 + lane * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) rv[8 * a + e] = (float)t[e];
+            }
+            if constexpr (B) {
+                const bf16x4 t = *reinterpret_cast<const bf16x4*>(dres + base + 512 * A + lane * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rv[8 * A + e] = (float)t[e];
+            }
+        }
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NE; ++j) {
+            const float d = dv[j];
+            xv[j] = (xv[j] - mu) * rs;          // xhat
+            dv[j] = d * gm[j];                  // dy * gamma
+            s1 += dv[j];
+            s2 += dv[j] * xv[j];
+            ag[j] += d * xv[j];
+            ab[j] += d;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+        const float c1 = s1 * inv_cols, c2 = s2 * inv_cols;
+        bf16 ov[NE], mv[NE];
+#pragma unroll
+        for (int j = 0; j < NE; ++j) {
+            float o = rs * (dv[j] - c1 - xv[j] * c2);
+            if (dres) o += rv[j];
+            ov[j] = (bf16)o;
+            if (want_colsum || dxm) {
+                float m = (float)ov[j];          // the consumer sees the rounded dx: mask / sum exactly what it will read
+                if (thresh) m *= dropout_scale(seed, (uint32_t)(base + LN3_COL(j)), thresh, inv_keep);
+                mv[j] = (bf16)m;
+                ac[j] += (float)mv[j];
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < A; ++a) {
+            bf16x8 t;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] = ov[8 * a + e];
+            *reinterpret_cast<bf16x8*>(dx + base + a * 512 + lane * 8) = t;
+            if (dxm) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) t[e] = mv[8 * a + e];
+                *reinterpret_cast<bf16x8*>(dxm + base + a * 512 + lane * 8) = t;
+            }
+        }
+        if constexpr (B) {
+            bf16x4 t;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[e] = ov[8 * A + e];
+            *reinterpret_cast<bf16x4*>(dx + base + 512 * A + lane * 4) = t;
+            if (dxm) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[e] = mv[8 * A + e];
+                *reinterpret_cast<bf16x4*>(dxm + base + 512 * A + lane * 4) = t;
+            }
+        }
+    }
+    // the four waves' column sums through LDS, one quantity at a time
+    float* out = ws + (long)blockIdx.x * 3 * cols;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (k == 2 && !want_colsum && !dxm) {
+            for (int c = threadIdx.x; c < cols; c += 256) out[2 * cols + c] = 0.f;
+            break;
+        }
+#pragma unroll
+        for (int j = 0; j < NE; ++j) sred[wave][LN3_COL(j)] = k == 0 ? ag[j] : k == 1 ? ab[j] : ac[j];
+        __syncthreads();
+        for (int c = threadIdx.x; c < cols; c += 256)
+            out[k * cols + c] = sred[0][c] + sred[1][c] + sred[2][c] + sred[3][c];
+        __syncthreads();
+    }
+#undef LN3_COL
+}
+
 // grid (cols/64, 3): block = 64 columns x 4 row groups of one quantity (dgamma / dbeta / colsum)
 __global__ __launch_bounds__(256) void ln_bwd_finalize_kernel(const float* __restrict__ ws, int nblocks, int cols,
         float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dcol) {
@@ -512,7 +657,24 @@ extern "C" int mmtg_layernorm_bwd(int dtype, const void* dy, const void* x, cons
     const int epc = dtype == MMTG_F32 ? 4 : 8;
     const bool vec = !v1 && cols % epc == 0 && MMTG_ALIGNED16(dy) && MMTG_ALIGNED16(x) && MMTG_ALIGNED16(dx) &&
                      (!dres || MMTG_ALIGNED16(dres)) && (!dx_masked || MMTG_ALIGNED16(dx_masked)) && MMTG_ALIGNED16(gamma);
-    if (vec) {
+    static const bool v2only = getenv("MMTG_LN_V2") != nullptr;  // A/B switch: half-wave-per-row kernel for bf16 too
+    if (vec && !v2only && dtype == MMTG_BF16 && (cols == 512 || cols == 768)) {     // (1024: 16 columns per lane spill at 168 VGPRs)
+        // full wave per row, four resident 4-wave blocks per CU
+        static int cap3 = 0;
+        if (!cap3) {
+            int dev = 0, cus = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+            cap3 = getenv("MMTG_LN_CAP") ? atoi(getenv("MMTG_LN_CAP")) : 3 * cus;
+        }
+        if (nb > cap3) nb = cap3;
+        const int sweeps = cdiv(cdiv(rows, 4), nb);
+        nb = cdiv(cdiv(rows, 4), sweeps);
+        dim3 grid(nb), block(256);
+#define LN3(A_, B_) hipLaunchKernelGGL((ln_bwd3_kernel<A_, B_>), grid, block, 0, s, (const bf16*)dy, (const bf16*)x, gamma, mean, rstd, \
+                                       (const bf16*)dres, (bf16*)dx, (bf16*)dx_masked, ws, rows, want, drop_thresh, drop_seed, ik)
+        if (cols == 512) LN3(1, 0); else LN3(1, 1);
+#undef LN3
+    } else if (vec) {
         // half-wave per row: a block covers 8 rows per sweep; equal sweeps per wave, <= the v1 block count
         // one resident round: the v2 kernel holds ~200 VGPRs, i.e. two 4-wave blocks per CU; more blocks
         // than that run as a second round (measured 42 us at 944 blocks, 34 us at 472, 44 us at 236)
