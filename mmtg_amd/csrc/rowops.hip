@@ -73,6 +73,73 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, T*
     if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
 }
 
+
+// bf16 rows of 512*A + 256*B columns, the column ownership of ln_bwd3_kernel (16-byte + 8-byte vectors per lane):
+// gamma / beta live in registers, a wave walks rows with the next row's vector(s) already requested.
+// Same arithmetic order per row as ln_fwd_kernel is NOT required (statistics are reductions over the row; the
+// two kernels agree to fp32 rounding), the stored mean / rstd feed the backward either way.
+template <int A, int B>
+__global__ __launch_bounds__(256) void ln_fwd3_kernel(const bf16* __restrict__ x, bf16* __restrict__ y,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      float* __restrict__ mean, float* __restrict__ rstd, int rows, float eps) {
+    typedef bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    constexpr int NE = 8 * A + 4 * B, cols = 512 * A + 256 * B;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#define LN3_COL(j) ((j) < 8 * A ? ((j) >> 3) * 512 + lane * 8 + ((j) & 7) : 512 * A + lane * 4 + ((j) - 8 * A))
+    float gm[NE], bt[NE];
+#pragma unroll
+    for (int j = 0; j < NE; ++j) { gm[j] = gamma[LN3_COL(j)]; bt[j] = beta[LN3_COL(j)]; }
+#undef LN3_COL
+    const int row0 = blockIdx.x * 4 + wave, stride = gridDim.x * 4;
+    bf16x8 px[A];
+    bf16x4 qx;
+    if (row0 < rows) {
+#pragma unroll
+        for (int a = 0; a < A; ++a) px[a] = *reinterpret_cast<const bf16x8*>(x + (long)row0 * cols + a * 512 + lane * 8);
+        if constexpr (B) qx = *reinterpret_cast<const bf16x4*>(x + (long)row0 * cols + 512 * A + lane * 4);
+    }
+    for (int row = row0; row < rows; row += stride) {
+        float v[NE];
+#pragma unroll
+        for (int a = 0; a < A; ++a)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[8 * a + e] = (float)px[a][e];
+        if constexpr (B) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[8 * A + e] = (float)qx[e];
+        }
+        const int nrow = row + stride;
+        if (nrow < rows) {
+#pragma unroll
+            for (int a = 0; a < A; ++a) px[a] = *reinterpret_cast<const bf16x8*>(x + (long)nrow * cols + a * 512 + lane * 8);
+            if constexpr (B) qx = *reinterpret_cast<const bf16x4*>(x + (long)nrow * cols + 512 * A + lane * 4);
+        }
+        float sm = 0.f;
+#pragma unroll
+        for (int j = 0; j < NE; ++j) sm += v[j];
+        const float mu = wave_sum(sm) / cols;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < NE; ++j) { const float d = v[j] - mu; q += d * d; }
+        const float rs = rsqrtf(wave_sum(q) / cols + eps);
+        bf16* yr = y + (long)row * cols;
+#pragma unroll
+        for (int a = 0; a < A; ++a) {
+            bf16x8 t;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] = (bf16)((v[8 * a + e] - mu) * rs * gm[8 * a + e] + bt[8 * a + e]);
+            *reinterpret_cast<bf16x8*>(yr + a * 512 + lane * 8) = t;
+        }
+        if constexpr (B) {
+            bf16x4 t;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[e] = (bf16)((v[8 * A + e] - mu) * rs * gm[8 * A + e] + bt[8 * A + e]);
+            *reinterpret_cast<bf16x4*>(yr + 512 * A + lane * 4) = t;
+        }
+        if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+    }
+}
+
 // One block = 4 waves; each wave strides over rows and keeps its dgamma / dbeta (/ column-sum)
 // partials in registers; the block reduces them through LDS and writes ONE partial row per block to
 // a workspace, a second tiny kernel sums the <= 512 partial rows per column.  (Atomics from ~1000
@@ -623,7 +690,21 @@ extern "C" int mmtg_layernorm_fwd(int dtype, const void* x, void* y, const float
     const double esz = dtype == MMTG_F32 ? 4 : 2;
     ProfScope prof(MMTG_PROF_LAYERNORM, s, 8.0 * rows * cols, 2.0 * esz * rows * cols);
     dim3 grid(cdiv(rows, 4)), block(256);
-    if (dtype == MMTG_F32)
+    static const bool fwd1 = getenv("MMTG_LN_V1") != nullptr || getenv("MMTG_LN_V2") != nullptr;   // A/B switch
+    if (dtype == MMTG_BF16 && !fwd1 && (cols == 512 || cols == 768 || cols == 1024) && rows >= 2048 && MMTG_ALIGNED16(x) && MMTG_ALIGNED16(y)) {
+        static int cusN = 0;
+        if (!cusN) {
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cusN, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cusN <= 0) cusN = 256;
+        }
+        const int capf = getenv("MMTG_LN_FWD_CAP") ? atoi(getenv("MMTG_LN_FWD_CAP")) : 6 * cusN;
+        int nbf = min(cdiv(rows, 4), capf > 0 ? capf : 1);
+        nbf = cdiv(cdiv(rows, 4), cdiv(cdiv(rows, 4), nbf));          // equal sweeps per wave
+        dim3 g3(nbf);
+        if (cols == 512) hipLaunchKernelGGL((ln_fwd3_kernel<1, 0>), g3, block, 0, s, (const bf16*)x, (bf16*)y, gamma, beta, mean, rstd, rows, eps);
+        else if (cols == 768) hipLaunchKernelGGL((ln_fwd3_kernel<1, 1>), g3, block, 0, s, (const bf16*)x, (bf16*)y, gamma, beta, mean, rstd, rows, eps);
+        else hipLaunchKernelGGL((ln_fwd3_kernel<2, 0>), g3, block, 0, s, (const bf16*)x, (bf16*)y, gamma, beta, mean, rstd, rows, eps);
+    } else if (dtype == MMTG_F32)
         hipLaunchKernelGGL(ln_fwd_kernel<float>, grid, block, 0, s, (const float*)x, (float*)y, gamma, beta, mean, rstd, rows, cols, eps);
     else if (dtype == MMTG_BF16)
         hipLaunchKernelGGL(ln_fwd_kernel<bf16>, grid, block, 0, s, (const bf16*)x, (bf16*)y, gamma, beta, mean, rstd, rows, cols, eps);

@@ -304,9 +304,10 @@ def test_gemm_rejects_bad_arguments():
 
 # ------------------------------------------------------------------ LayerNorm
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cols", [512, 768])
-def test_layernorm(dtype, cols):
-    rows = 333
+@pytest.mark.parametrize("cols,rows", [(512, 333), (768, 333), (768, 5001), (1024, 2100), (512, 2048)])
+def test_layernorm(dtype, cols, rows):
+    # 333 rows: the small-launch kernels; >= 2048 rows: the grid-stride bf16 kernels (a full wave per row with
+    # 16-byte + 8-byte vectors per lane, next row prefetched) incl. a ragged last sweep; 1024 columns: GPT-2-medium
     x = rnd(rows, cols, dtype=dtype, seed=1, scale=2.0)
     g = 1 + 0.1 * rnd(cols, seed=2)
     b = 0.1 * rnd(cols, seed=3)
