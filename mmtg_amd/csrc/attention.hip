@@ -112,19 +112,53 @@ __global__ __launch_bounds__(256, ATTN_FWD_WAVES) void attn_fwd_kernel(const T* 
     // dropout counter of (b, h, q, key) = ((b nH + h) T + q) T + key, low 32 bits: this lane's row part once
     const uint32_t drow = ((uint32_t)(b * nH + h) * (uint32_t)Tn + (uint32_t)qi) * (uint32_t)Tn;
 
+    // K / V tiles travel global -> registers -> LDS; the NEXT tile's vectors are requested right after the
+    // current ones are stored, so their latency hides behind this tile's MFMAs and softmax
+    // (bf16 only: the fp32 parity kernel has no registers to spare and loads in place)
+    constexpr int NIT = 64 * A::CPR / 256;
+    constexpr bool PF = sizeof(T) == 2;
+    V kreg[NIT], vreg[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int id = tid + 256 * it, key = id / A::CPR, c = id % A::CPR;
+        kreg[it] = zero16<T>();
+        vreg[it] = zero16<T>();
+        if (PF && key < Tn) {
+            const T* src = base + (long)key * ld + c * A::EPC;
+            kreg[it] = *reinterpret_cast<const V*>(src + D);
+            vreg[it] = *reinterpret_cast<const V*>(src + 2 * D);
+        }
+    }
     for (int jb = 0; jb <= qb; ++jb) {
         const int j0 = jb * 64;
         __syncthreads();
-        for (int id = tid; id < 64 * A::CPR; id += 256) {
-            const int key = id / A::CPR, c = id % A::CPR;
-            V kv = zero16<T>(), vv = zero16<T>();
-            if (j0 + key < Tn) {
-                const T* src = base + (long)(j0 + key) * ld + c * A::EPC;
-                kv = *reinterpret_cast<const V*>(src + D);
-                vv = *reinterpret_cast<const V*>(src + 2 * D);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int id = tid + 256 * it, key = id / A::CPR, c = id % A::CPR;
+            if constexpr (!PF) {
+                kreg[it] = zero16<T>();
+                vreg[it] = zero16<T>();
+                if (j0 + key < Tn) {
+                    const T* src = base + (long)(j0 + key) * ld + c * A::EPC;
+                    kreg[it] = *reinterpret_cast<const V*>(src + D);
+                    vreg[it] = *reinterpret_cast<const V*>(src + 2 * D);
+                }
             }
-            *reinterpret_cast<V*>(sK + off_kc<T>(key, c)) = kv;
-            *reinterpret_cast<V*>(sV + off_ks<T>(key, c)) = vv;
+            *reinterpret_cast<V*>(sK + off_kc<T>(key, c)) = kreg[it];
+            *reinterpret_cast<V*>(sV + off_ks<T>(key, c)) = vreg[it];
+        }
+        if (PF && jb < qb) {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int id = tid + 256 * it, key = id / A::CPR, c = id % A::CPR;
+                kreg[it] = zero16<T>();
+                vreg[it] = zero16<T>();
+                if (j0 + 64 + key < Tn) {
+                    const T* src = base + (long)(j0 + 64 + key) * ld + c * A::EPC;
+                    kreg[it] = *reinterpret_cast<const V*>(src + D);
+                    vreg[it] = *reinterpret_cast<const V*>(src + 2 * D);
+                }
+            }
         }
         if (tid < 64) sKeep[tid] = (j0 + tid < Tn) ? keep[(long)b * Tn + j0 + tid] : 0;
         __syncthreads();
