@@ -861,3 +861,33 @@ def test_logits_process_sample_frequencies():
     kept = p > 0
     chi2 = float((((counts[kept] - N * p[kept]) ** 2) / (N * p[kept])).sum())
     assert int(kept.sum()) == 8 and chi2 < 24.3, chi2
+
+
+def test_abi_error_behaviour():
+    """SURVEY §8(b) error contract: a bad call returns a negative code with a thread-local message (raised as
+    RuntimeError by the binding), launches nothing, and the library stays usable afterwards."""
+    x = torch.zeros(8, 2048, device=DEV, dtype=torch.bfloat16)
+    f = torch.zeros(2048, device=DEV)
+    with pytest.raises(RuntimeError, match="1024"):                       # LayerNorm rows wider than the kernels serve
+        hip.layernorm_fwd(x, x.clone(), f, f, torch.zeros(8, device=DEV), torch.zeros(8, device=DEV), 8, 2048)
+    with pytest.raises(RuntimeError, match="head dim"):                   # attention is built for dh = 64
+        hip.attn_fwd(torch.zeros(1, 4, 3 * 32, device=DEV, dtype=torch.bfloat16), torch.ones(1, 4, dtype=torch.int32, device=DEV),
+                     torch.zeros(1, 4, 32, device=DEV, dtype=torch.bfloat16), torch.zeros(1, 1, 4, device=DEV), 1, 4, 1, 32)
+    big = torch.zeros(1, 30000, device=DEV)
+    with pytest.raises(RuntimeError, match="exceeds"):                    # sampler's LDS row image
+        hip.logits_process_sample(big, 30000, 30000, torch.ones(1, 1, dtype=torch.long, device=DEV), 1,
+                                  torch.ones(1, dtype=torch.int32, device=DEV), 1.0, 1.0, 5, 0.0,
+                                  torch.zeros(1, device=DEV), torch.zeros(1, dtype=torch.long, device=DEV), 1)
+    with pytest.raises(RuntimeError, match="temperature"):
+        hip.logits_process_argmax(torch.zeros(1, 64, device=DEV), 64, 64, torch.ones(1, 1, dtype=torch.long, device=DEV), 1,
+                                  torch.ones(1, dtype=torch.int32, device=DEV), 0.0, 1.0, torch.zeros(1, dtype=torch.long, device=DEV), 1)
+    part = torch.zeros(2, 16, 16, device=DEV)
+    with pytest.raises(RuntimeError, match="stride"):                     # slab stride smaller than the slab
+        hip.slab_sum(part, 2, 8, torch.zeros(16, 16, device=DEV), 256)
+    with pytest.raises(RuntimeError, match="split"):                      # split-K without a split-capable epilogue
+        hip.gemm(x, x, torch.zeros(8, 8, device=DEV, dtype=torch.bfloat16), 8, 8, 2048, transB=True, splits=4)
+    # still alive: a valid call after the failures
+    a = rnd(64, 64, dtype=torch.bfloat16, seed=1).to(DEV)
+    c = torch.empty(64, 64, device=DEV, dtype=torch.bfloat16)
+    hip.gemm(a, a, c, 64, 64, 64, transB=True)
+    close(c, a.float() @ a.float().t(), torch.bfloat16, 64, "gemm after errors")
