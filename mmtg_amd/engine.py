@@ -214,6 +214,7 @@ class Engine:
         self.act = None
         self.training = False
         self.drop_seed = 0x1234
+        self.wgrad_overwrite = False   # set by MMTGTrainer.step around its backward
         self.step_count = 0
         self.opt_m = None
         self.opt_v = None
@@ -372,7 +373,8 @@ class Engine:
             if splits * Mg * Ng <= part.numel():
                 hip.gemm(A, B, part, Mg, Ng, Mtok, transA=True, transB=False, lda=lda, ldb=ldb, ldc=Ng,
                          epi=hip.EPI_SPLIT, out_f32=True, splits=splits)
-                hip.slab_sum(part, splits, Mg * Ng, gw, Mg * Ng, accumulate=True)
+                # (the fused trainer zeroes the gradients right before its single backward: the sum may then overwrite)
+                hip.slab_sum(part, splits, Mg * Ng, gw, Mg * Ng, accumulate=not self.wgrad_overwrite)
                 splits = 0
         if splits:
             hip.gemm(A, B, gw, Mg, Ng, Mtok, transA=True, transB=False, lda=lda, ldb=ldb, ldc=Ng,

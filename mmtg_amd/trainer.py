@@ -102,7 +102,11 @@ class MMTGTrainer:
             sc = eng.loss(batch["rating"], stage, batch_den=n_global)
             B, T = eng.act["B"], eng.act["T"]
             dl = eng.loss_backward(1.0, lm_coef=self.lm_weight / (B * (T - 1)) if self.lm_weight else 0.0)
-            eng.backward(dl, dkl=self.alpha * n_local / n_global)
+            eng.wgrad_overwrite = True      # gradients were zeroed above and every weight is written once
+            try:
+                eng.backward(dl, dkl=self.alpha * n_local / n_global)
+            finally:
+                eng.wgrad_overwrite = False
             out = {"loss": sc[0], "lm_loss": sc[1], "kl": eng.act["kl"][0]}
         if self.reducer is not None:
             self.reducer.finish(eng.grad)

@@ -412,3 +412,32 @@ def test_short_sequence_clipped_conditioning_vs_oracle(dtype):
         else:
             cos = float(torch.dot(g.flatten(), r.flatten()) / (g.norm() * r.norm() + 1e-30))
             assert cos > 0.99, (k, cos)
+
+
+def test_trainer_gradients_equal_the_accumulating_path():
+    """The fused trainer lets the ordered slab sums OVERWRITE the (freshly zeroed) weight gradients; the engine's
+    default accumulates.  Same batch, same seed state: the GPT-2 block weights (every one a slab-path gradient behind a
+    deterministic chain) must be identical bit for bit, the whole flat buffer to 1e-6 of its norm (the LayerNorm /
+    embedding gradients end in fp32 atomics whose order varies run to run).  bf16, dropout off, tiny 2-layer model."""
+    fx, meta, mcfg, gcfg, dcfg, weights, table, batch, model = build("tiny_s5", "bf16")
+    eng = model.engine()
+    tb = batch_to_torch(batch, DEV)
+    grads = []
+    for overwrite in (False, True):
+        eng.zero_grad()
+        eng.forward(tb, train_flag=True, training=False, logits_f32=False)
+        eng.loss(tb["rating"], 3, batch_den=len(tb["rating"]))
+        dl = eng.loss_backward(1.0)
+        eng.wgrad_overwrite = overwrite
+        eng.backward(dl, dkl=0.2)
+        eng.wgrad_overwrite = False
+        grads.append(eng.grad.clone())
+    assert float((grads[0] - grads[1]).norm() / grads[0].norm()) < 1e-6
+    n = 0
+    for l in range(2):
+        for w in ("attn.c_attn.weight", "attn.c_proj.weight", "mlp.c_fc.weight", "mlp.c_proj.weight"):
+            key = "decoder.gpt2.transformer.h.%d.%s" % (l, w)
+            a, b = eng.layout.view(grads[0], key), eng.layout.view(grads[1], key)
+            assert torch.equal(a, b) and float(a.abs().max()) > 0, key
+            n += 1
+    assert n == 8
