@@ -53,8 +53,9 @@ class GreedyDecoder:
         self.logits = torch.empty(B, self.eng.layout.Vpad, dtype=torch.float32, device=dev)
         # bf16: deterministic split-K products (K slices per product: c_attn, attn c_proj, c_fc, mlp c_proj)
         self.fast = self.eng.dtype == hip.BF16 and not os.environ.get("MMTG_DECODE_PLAIN")
-        # (measured at batch 256, us per token step: 2,3,2,6 -> 1020; 4,6,3,12 -> 1248; 1,1,1,2 -> 1183; unsplit 1264)
-        self.splits = tuple(int(x) for x in os.environ.get("MMTG_DECODE_SPLITS", "2,3,2,6").split(","))
+        # (measured at batch 256, us per token step: 2,3,2,6 -> 1020; 4,6,3,12 -> 1248; 1,1,1,2 -> 1183; unsplit 1264;
+        #  with the one-slice c_fc + fused GELU: 2,3,1,8 -> 940, 2,3,1,6 -> 943, 1,3,1,8 -> 963, 2,3,1,12 -> 1003)
+        self.splits = tuple(int(x) for x in os.environ.get("MMTG_DECODE_SPLITS", "2,3,1,8").split(","))
         if self.fast:
             D = self.eng.sh.D
             slab = max(self.splits[0] * 3 * D, self.splits[1] * D, self.splits[2] * 4 * D, self.splits[3] * D)
@@ -149,7 +150,10 @@ class GreedyDecoder:
             self._split(self.ctx, p + "attn.c_proj.weight", hnext, sp, eng.P(p + "attn.c_proj.bias"),
                         epi=hip.EPI_RESID, aux=hcur, ldaux=D,
                         ln_gamma=eng.P(p + "ln_2.weight"), ln_beta=eng.P(p + "ln_2.bias"), ln_out=self.a, eps=sh.eps)
-            self._split(self.a, p + "mlp.c_fc.weight", self.g, s1, eng.P(p + "mlp.c_fc.bias"), epi=hip.EPI_GELU)
+            if s1 == 1:     # one K slice: bias + GELU in the product's own epilogue, no finish launch
+                self._conv1d(self.a, p + "mlp.c_fc.weight", self.g, bias=eng.P(p + "mlp.c_fc.bias"), epi=hip.EPI_GELU, aux2=self.u)
+            else:
+                self._split(self.a, p + "mlp.c_fc.weight", self.g, s1, eng.P(p + "mlp.c_fc.bias"), epi=hip.EPI_GELU)
             if l + 1 < sh.L:
                 nxt = f"{pre}h.{l + 1}.ln_1."
             else:
