@@ -159,6 +159,8 @@ def gaussian_prior(S):
 
 import os as _os
 _NO_OCC4 = bool(_os.environ.get("MMTG_GEMM_NO_OCC4"))     # A/B switch, mirrors the library's
+_WG_NUM = float(_os.environ.get("MMTG_WGRAD_NUM", "760"))     # tuning knobs of the slab weight-gradient split count
+_WG_CAP = int(_os.environ.get("MMTG_WGRAD_CAP", "12"))
 _NO_FEW_ROWS = bool(_os.environ.get("MMTG_NO_FEW_ROWS"))   # A/B switch: plain launches for the encoder-sized products
 _WGRAD_SLAB = not _os.environ.get("MMTG_WGRAD_ATOMIC")     # A/B switch: fp32-atomic weight gradients everywhere
 
@@ -175,8 +177,8 @@ def _wgrad_splits(M, N, K, occ4=False, slots=512, t_iter=1.1, t_fixed=6.0):
         # so only the fill of the last round and the atomic volume matter.  Measured optima
         # (profiles/r01_v6_gemm_tn_split_sweep.log): 144 tiles -> 5, 108 -> 6..7, 630 -> 4, 36 -> 8+.
         smax = max(1, K // 256)
-        s = round(760.0 / tiles) if tiles < 512 else round(2520.0 / tiles)
-        return int(max(1, min(smax, s, 12)))
+        s = round(_WG_NUM / tiles) if tiles < 512 else round(2520.0 / tiles)
+        return int(max(1, min(smax, s, _WG_CAP)))
     best, best_t = 1, None
     for s in range(1, 33):
         if s > 1 and K // s < 256:
