@@ -44,12 +44,9 @@ def algorithmic_flops_per_token(S, T, D, L, V, H=512, E=2048):
     return fwd, enc_per_sample
 
 
-def cpu_baseline(mcfg, dcfg, gcfg, V, T, seconds_budget=25.0):
-    """Oracle train step (fwd + MyLoss + bwd + clip + AdamW) on the host cores, B=4."""
-    from mmtg_amd import synth
-    from oracle import mmtg_oracle as O
-    # threads = the cores this process may actually run on (the box advertises more logical
-    # CPUs than the job's affinity/cgroup grants; oversubscribing them stalls OpenMP)
+def _host_threads():
+    """Cores this process may actually run on (the box advertises more logical CPUs than the job's
+    affinity / cgroup grants; oversubscribing them stalls OpenMP)."""
     try:
         ncpu = len(os.sched_getaffinity(0))
     except AttributeError:
@@ -61,7 +58,14 @@ def cpu_baseline(mcfg, dcfg, gcfg, V, T, seconds_budget=25.0):
             quota = max(1, int(float(q) / float(per)))
     except Exception:
         pass
-    threads = max(1, min(ncpu, quota, 64))
+    return max(1, min(ncpu, quota, 64))
+
+
+def cpu_baseline(mcfg, dcfg, gcfg, V, T, seconds_budget=25.0):
+    """Oracle train step (fwd + MyLoss + bwd + clip + AdamW) on the host cores, B=4."""
+    from mmtg_amd import synth
+    from oracle import mmtg_oracle as O
+    threads = _host_threads()
     torch.set_num_threads(threads)
     B = 4
     weights = synth.make_weights(mcfg, gcfg, seed=1)
@@ -82,6 +86,33 @@ def cpu_baseline(mcfg, dcfg, gcfg, V, T, seconds_budget=25.0):
     return {"value": round(B * T * n / el, 2), "unit": "tokens/s", "cores": threads, "kind": "port", "host_logical_cpus": os.cpu_count(),
             "sample": "oracle (CPU PyTorch fp32 restatement) full config 12L/768/V=%d, B=%d x T=%d, %d train steps "
                       "(fwd+MyLoss+bwd+clip+AdamW), dropout off" % (V, B, T, n)}
+
+
+def cpu_decode_baseline(mcfg, dcfg, gcfg, V, positions=24):
+    """Oracle greedy decoding on the host cores exactly as the reference does it (generate.py:117-142: no KV
+    cache, the whole prefix is re-run for every token), one prompt, a bounded number of positions."""
+    from mmtg_amd import synth
+    from oracle import mmtg_oracle as O
+    threads = _host_threads()
+    torch.set_num_threads(threads)
+    weights = synth.make_weights(mcfg, gcfg, seed=1)
+    table = torch.from_numpy(synth.make_token_table(V, seed=2))
+    nb = synth.make_batch(1, mcfg, dcfg, V, seed=3)
+    sh = O.Shapes(mcfg, dcfg, gcfg)
+    w = O.weights_to_torch(weights, requires_grad=False)
+    start = {k: np.asarray(v[0]) for k, v in nb.items() if k not in ("rating", "targets")}
+    start["targets"] = np.asarray([1])
+
+    def fwd(inputs):
+        return O.mmtg_forward(w, sh, table, inputs, train_flag=False)[2]
+
+    O.sample_sequence(fwd, start, 2, temperature=1.1, top_k=1, top_p=0.0, repitition_penalty=1.5, greedy=True)   # warm-up
+    t0 = time.perf_counter()
+    O.sample_sequence(fwd, start, positions, temperature=1.1, top_k=1, top_p=0.0, repitition_penalty=1.5, greedy=True)
+    el = time.perf_counter() - t0
+    return {"value": round(positions / el, 2), "unit": "tokens/s", "cores": threads, "kind": "port", "host_logical_cpus": os.cpu_count(),
+            "sample": "oracle (CPU PyTorch fp32 restatement) greedy decoding as the reference runs it (no KV cache, prefix "
+                      "re-run per token), batch 1, %d positions after the 15-token prompt, full 12L/768/V=%d" % (positions, V)}
 
 
 def bench_decode(args, world, rank, dev):
@@ -124,6 +155,29 @@ def bench_decode(args, world, rank, dev):
         t = torch.tensor([el], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
+    roof = cpu = None
+    if rank == 0 and not args.no_roofline:
+        # dominant kernel of a decode step = the small-M split-K products streaming the weights (HBM bound): live
+        # HIP-event time and algorithmic bytes (weights + activations + fp32 slabs once) of every GEMM launch of
+        # one eager (un-captured) generation, as the library's profiling hooks count them
+        deg = GreedyDecoder(model, max_batch=B, max_len=Ln, use_graph=False)
+        deg.generate(batch, Ln, temperature=1.1, repitition_penalty=1.5)
+        hip.prof_enable(True)
+        deg.generate(batch, Ln, temperature=1.1, repitition_penalty=1.5)
+        hip.prof_enable(False)
+        pr = hip.prof_read()
+        g = pr["gemm_bf16" if args.dtype == "bf16" else "gemm_f32"]
+        ach = g["bytes"] / max(g["ms"], 1e-9) / 1e6          # GB/s
+        roof = {"bound": "hbm", "kernel": "gemm_dma_kernel<256x32, 4-deep ring> (split-K weight streaming)",
+                "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": None,
+                "launches_per_generation": g["launches"], "avg_launch_us": round(1e3 * g["ms"] / max(1, g["launches"]), 2),
+                "algorithmic_bytes_per_launch": round(g["bytes"] / max(1, g["launches"])),
+                "per_category_ms_per_generation": {k: round(v["ms"], 3) for k, v in pr.items() if v["launches"]},
+                "note": "a graph node costs >= 4.1 us here (profiles/r01_v8_decode_rocprofv3_kernel_stats.csv): the step is "
+                        "bound by ~110 dependent launches, not by HBM"}
+        del deg
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_decode_baseline(mcfg, dcfg, gcfg, V)
     if rank == 0:
         steps_per_seq = dcfg.topic_prompt_length + Ln
         out = {"metric": "greedy-decode tokens/sec, full MMTG config", "value": round(B * world * Ln * args.steps / el, 1),
@@ -135,6 +189,10 @@ def bench_decode(args, world, rank, dev):
                                       % (B, Ln, args.layers, V),
                           "us_per_token_step": round(1e6 * el / args.steps / steps_per_seq, 2),
                           "parallelism": "replicas x%d" % world}}
+        if roof is not None:
+            out["roofline"] = roof
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
