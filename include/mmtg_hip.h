@@ -204,6 +204,12 @@ int mmtg_gru_cell_fwd(int dtype, const void* gi, long ld_gi, const void* gh, con
  * of `dtype`, dh_prev (f32 [B,H]) = dh * z (caller adds dgh * W_hh).           */
 int mmtg_gru_cell_bwd(int dtype, const float* dh, const float* save, const void* h_prev, long ld_hp,
                       void* dgi, long ld_dgi, void* dgh, float* dh_prev, int B, int H, void* stream);
+/* The same with the assembly of dh_t fused in: dh_t = rows[b, :] (gradient arriving through the LayerNorm of step t,
+ * `dtype`, row stride ld_rows) + carry (f32 [B,H], nullable; may alias dh_prev) + the ordered sum of the `splits`
+ * fp32 slabs part[splits][B][H] of the carry product d(gh_{t+1}) W_hh (MMTG_EPI_SPLIT; splits = 0: none).          */
+int mmtg_gru_cell_bwd_fused(int dtype, const void* rows, long ld_rows, const float* carry, const float* part, int splits,
+                            const float* save, const void* h_prev, long ld_hp, void* dgi, long ld_dgi, void* dgh,
+                            float* dh_prev, int B, int H, void* stream);
 /* alpha attention (model.py:138-161): qkv [B*S, 3H] -> ctx [B*S, H], probs [B,heads,S,S] f32,
  * kl += mean_i KLDiv_batchmean(log P[:,:,i,:], prior_i); prior [S,S] f32.       */
 int mmtg_alpha_attn_fwd(int dtype, const void* qkv, const float* prior, void* ctx, float* probs,

@@ -50,6 +50,36 @@ __global__ __launch_bounds__(256) void gru_cell_bwd_kernel(const float* __restri
     dh_prev[i] = d * z;
 }
 
+// Same cell backward with the gradient assembly fused in (one launch per BPTT step instead of a strided copy,
+// two adds and the cell): dh_t = rows[b, :] (the LayerNorm path's gradient of step t, storage type, row stride
+// ld_rows) + carry (dh_{t+1} * z_{t+1}, f32, nullable) + the ordered sum of the `splits` fp32 slabs of the carry
+// product d(gh_{t+1}) W_hh (nullable).
+template <typename T>
+__global__ __launch_bounds__(256) void gru_cell_bwd_fused_kernel(const T* __restrict__ rows, long ld_rows,
+        const float* __restrict__ carry, const float* __restrict__ part, int splits, const float* __restrict__ save,
+        const T* __restrict__ h_prev, long ld_hp, T* __restrict__ dgi, long ld_dgi, T* __restrict__ dgh,
+        float* __restrict__ dh_prev, int B, int H) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)B * H) return;
+    const int b = (int)(i / H), j = (int)(i % H);
+    const long BH = (long)B * H;
+    float d = (float)rows[(long)b * ld_rows + j];
+    if (carry) d += carry[i];
+    for (int k = 0; k < splits; ++k) d += part[k * BH + i];
+    const float r = save[i], z = save[BH + i], n = save[2 * BH + i], ghn = save[3 * BH + i];
+    const float hp = h_prev ? (float)h_prev[(long)b * ld_hp + j] : 0.f;
+    const float dz = d * (hp - n);
+    const float dn = d * (1.f - z);
+    const float da = dn * (1.f - n * n);
+    const float dr = da * ghn;
+    const float dr_pre = dr * r * (1.f - r);
+    const float dz_pre = dz * z * (1.f - z);
+    const long o = (long)b * 3 * H + j, oi = (long)b * ld_dgi + j;
+    dgi[oi] = (T)dr_pre; dgi[oi + H] = (T)dz_pre; dgi[oi + 2 * H] = (T)da;
+    dgh[o] = (T)dr_pre; dgh[o + H] = (T)dz_pre; dgh[o + 2 * H] = (T)(da * r);
+    dh_prev[i] = d * z;
+}
+
 // ------------------------------------------------------------------ alpha attention
 // One wave per (b, head): S <= 8 steps, dh = H/heads <= 256.  Lane owns dh/64
 // consecutive channels; QK^T dot products by wave reduction.
@@ -238,6 +268,22 @@ extern "C" int mmtg_gru_cell_bwd(int dtype, const float* dh, const float* save, 
     DISPATCH(dtype, K_)
 #undef K_
     MMTG_LAUNCH_CHECK("gru_cell_bwd");
+    return MMTG_OK;
+}
+
+extern "C" int mmtg_gru_cell_bwd_fused(int dtype, const void* rows, long ld_rows, const float* carry, const float* part, int splits,
+                                       const float* save, const void* h_prev, long ld_hp, void* dgi, long ld_dgi, void* dgh,
+                                       float* dh_prev, int B, int H, void* stream) {
+    MMTG_REQUIRE(rows && save && dgi && dgh && dh_prev && B > 0 && H > 0 && splits >= 0 && (splits == 0 || part), "gru_cell_bwd_fused: bad args");
+    // (carry may alias dh_prev: a thread reads its element before it writes it)
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(MMTG_PROF_ENCODER, s, 24.0 * B * H, (44.0 + 4.0 * splits) * B * H);
+    dim3 grid(cdiv((long)B * H, 256)), block(256);
+#define K_(T) hipLaunchKernelGGL(gru_cell_bwd_fused_kernel<T>, grid, block, 0, s, (const T*)rows, ld_rows, carry, part, splits, save, \
+                                 (const T*)h_prev, ld_hp, (T*)dgi, ld_dgi, (T*)dgh, dh_prev, B, H)
+    DISPATCH(dtype, K_)
+#undef K_
+    MMTG_LAUNCH_CHECK("gru_cell_bwd_fused");
     return MMTG_OK;
 }
 

@@ -702,10 +702,8 @@ class Engine:
                           dtopic, dci, dct, self.Gp("att_w"), self.Gp("att_b"), B, S, H)
         self._ready("att_b")
         # ---- alpha attention + LayerNorm + GRU per modality
-        dh32 = self.buf("d_h32", (B, H), torch.float32)
         dhp32 = self.buf("d_hp32", (B, H), torch.float32)
         tmp32 = self.buf("d_tmp32", (B, H), torch.float32)
-        row32 = self.buf("d_row32", (B * S, H), torch.float32)
         for mod, ch, lnk, dctx_a in (("text", "text", "ln_layer3", dct), ("img", "image", "ln_layer2", dci)):
             qkv_a, ctx_a, probs = a["alpha"][mod]
             x_in, gi, h_all, save, h_ln = a["enc"][ch]
@@ -722,9 +720,7 @@ class Engine:
                               self.G(lnk + ".weight"), self.G(lnk + ".bias"), B * S, H, ws=lnws)
             # BPTT over the S steps (rows b*S+t)
             r = f"encoder.rnns_{ch}."
-            hip.cast_to_f32(dh_all, row32, B * S * H)
             dgi = self.buf("d_gi", (B * S, 3 * H))
-            row3 = row32.view(B, S, H)
             # every step's d(gh) is kept (time-major) so that the recurrent weight / bias gradients are ONE
             # product and ONE column sum after the loop instead of one per step
             dgh_tm = self.buf("d_gh_tm", (S, B, 3 * H))
@@ -732,17 +728,12 @@ class Engine:
             ks = 6 if bf and (3 * H) % (6 * 64) == 0 else 0      # split-K slabs of the carry product (bf16 kernels only)
             part = self.buf("d_hp_slabs", (max(ks, 1), B, H), torch.float32)
             for t in range(S - 1, -1, -1):
-                # total gradient wrt h_t = LN path (row b*S+t) + carry from step t+1
-                self._gather_rows(row3, t, dh32)
-                if t < S - 1:
-                    hip.axpy_f32(dh32, dhp32, 1.0, B * H)
-                    if ks:
-                        hip.slab_sum(part, ks, B * H, dh32, B * H, accumulate=True)
-                    else:
-                        hip.axpy_f32(dh32, tmp32, 1.0, B * H)
+                # total gradient wrt h_t = LN path (row b*S+t) + carry dh_{t+1} z_{t+1} + d(gh_{t+1}) W_hh, assembled in the cell kernel
+                last = t == S - 1
                 dgh = dgh_tm[t]
-                hip.gru_cell_bwd(dh32, save[t], None if t == 0 else h_all[t - 1:], dgi[t:], dgh, dhp32, B, H,
-                                 ld_hp=S * H, ld_dgi=S * 3 * H)
+                hip.gru_cell_bwd_fused(dh_all[t:], S * H, None if last else dhp32, None if last else (part if ks else tmp32),
+                                       0 if last else (ks or 1), save[t], None if t == 0 else h_all[t - 1:], dgi[t:], dgh, dhp32,
+                                       B, H, ld_hp=S * H, ld_dgi=S * 3 * H)
                 if t > 0:
                     if ks:
                         hip.gemm(dgh, self.W(r + "weight_hh_l0"), part, B, H, 3 * H, transB=False, ldb=H,

@@ -46,6 +46,7 @@ _SIGS = {
     "mmtg_loss_fwd": ([_i, _vp, _l, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp], _i),
     "mmtg_loss_bwd": ([_i, _i, _vp, _l, _i, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _i, _vp, _l, _i, _vp], _i),
     "mmtg_gru_cell_fwd": ([_i, _vp, _l, _vp, _vp, _l, _vp, _l, _vp, _i, _i, _vp], _i),
+    "mmtg_gru_cell_bwd_fused": ([_i, _vp, _l, _vp, _vp, _i, _vp, _vp, _l, _vp, _l, _vp, _vp, _i, _i, _vp], _i),
     "mmtg_gru_cell_bwd": ([_i, _vp, _vp, _vp, _l, _vp, _l, _vp, _vp, _i, _i, _vp], _i),
     "mmtg_alpha_attn_fwd": ([_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp], _i),
     "mmtg_alpha_attn_bwd": ([_i, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _vp], _i),
@@ -261,6 +262,14 @@ def loss_bwd(logits, ldl, V, topic_ids, targets, lse, coef, gscale, B, P, L, dlo
 
 
 # ------------------------------------------------------------------ encoder pieces
+def gru_cell_bwd_fused(rows, ld_rows, carry, part, splits, save, h_prev, dgi, dgh, dh_prev, B, H, ld_hp=None, ld_dgi=None):
+    """gru_cell_bwd with dh_t = rows + carry + sum of the carry product's slabs assembled in the kernel."""
+    _check(lib().mmtg_gru_cell_bwd_fused(dt(dgi), _p(rows), ld_rows, _p(carry), _p(part), splits, _p(save), _p(h_prev),
+                                         H if ld_hp is None else ld_hp, _p(dgi), 3 * H if ld_dgi is None else ld_dgi,
+                                         _p(dgh), _p(dh_prev), B, H, _stream()), "gru_cell_bwd_fused")
+
+
+
 def gru_cell_fwd(gi, gh, h_prev, h, save, B, H, ld_gi=None, ld_hp=None, ld_h=None):
     _check(lib().mmtg_gru_cell_fwd(dt(gi), _p(gi), 3 * H if ld_gi is None else ld_gi, _p(gh), _p(h_prev),
                                    H if ld_hp is None else ld_hp, _p(h), H if ld_h is None else ld_h, _p(save),
