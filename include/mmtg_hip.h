@@ -194,11 +194,12 @@ int mmtg_loss_bwd(int dtype, int logits_dtype, const void* logits, long ldl, int
                   int B, int P, int L, void* dlogits, long ldd, int Vpad, void* stream);
 
 /* ---------------------------------------------------------------- encoder / fuser pieces
- * GRU cell (nn.GRU math, model.py:78-79): gi (row stride ld_gi), gh [B,3H]
+ * GRU cell (nn.GRU math, model.py:78-79): gi (row stride ld_gi), gh (row stride ld_gh >= 3H, or 0 = one
+ * [3H] row for every b: at step 0, h_prev = 0, the recurrent product is just b_hh)
  * pre-activations (r|z|n), h_prev (row stride ld_hp; null = zeros) -> h (row
  * stride ld_h); saves r,z,n,ghn (each [B,H]) in `save` [4,B,H] f32.  The row
  * strides address one step of a batch-first [B,S,*] sequence in place.         */
-int mmtg_gru_cell_fwd(int dtype, const void* gi, long ld_gi, const void* gh, const void* h_prev, long ld_hp,
+int mmtg_gru_cell_fwd(int dtype, const void* gi, long ld_gi, const void* gh, long ld_gh, const void* h_prev, long ld_hp,
                       void* h, long ld_h, float* save, int B, int H, void* stream);
 /* dh: total gradient wrt h_t (f32 [B,H]); outputs dgi (row stride ld_dgi), dgh [B,3H]
  * of `dtype`, dh_prev (f32 [B,H]) = dh * z (caller adds dgh * W_hh).           */

@@ -11,12 +11,12 @@ namespace {
 // nn.GRU math (reference src/model.py:78-79):
 //   r = s(gi_r + gh_r)  z = s(gi_z + gh_z)  n = tanh(gi_n + r * gh_n)  h = (1-z) n + z h_prev
 template <typename T>
-__global__ __launch_bounds__(256) void gru_cell_fwd_kernel(const T* __restrict__ gi, long ld_gi, const T* __restrict__ gh,
+__global__ __launch_bounds__(256) void gru_cell_fwd_kernel(const T* __restrict__ gi, long ld_gi, const T* __restrict__ gh, long ld_gh,
         const T* __restrict__ h_prev, long ld_hp, T* __restrict__ h, long ld_h, float* __restrict__ save, int B, int H) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long)B * H) return;
     const int b = (int)(i / H), j = (int)(i % H);
-    const long o = (long)b * 3 * H + j, oi = (long)b * ld_gi + j;
+    const long o = (long)b * ld_gh + j, oi = (long)b * ld_gi + j;     // ld_gh = 0: one row for every b (step 0: gh = b_hh)
     const float r = sigmoid_f((float)gi[oi] + (float)gh[o]);
     const float z = sigmoid_f((float)gi[oi + H] + (float)gh[o + H]);
     const float ghn = (float)gh[o + 2 * H];
@@ -245,13 +245,13 @@ __global__ __launch_bounds__(64) void beta_bwd_kernel(const T* __restrict__ topi
     else if ((dtype) == MMTG_BF16) { KERN(bf16); }                          \
     else MMTG_FAIL(MMTG_ERR_BAD_ARG, "bad dtype %d", (dtype));
 
-extern "C" int mmtg_gru_cell_fwd(int dtype, const void* gi, long ld_gi, const void* gh, const void* h_prev, long ld_hp,
+extern "C" int mmtg_gru_cell_fwd(int dtype, const void* gi, long ld_gi, const void* gh, long ld_gh, const void* h_prev, long ld_hp,
                                  void* h, long ld_h, float* save, int B, int H, void* stream) {
-    MMTG_REQUIRE(gi && gh && h && save && B > 0 && H > 0, "gru_cell_fwd: bad args");
+    MMTG_REQUIRE(gi && gh && h && save && B > 0 && H > 0 && (ld_gh == 0 || ld_gh >= 3L * H), "gru_cell_fwd: bad args");
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(MMTG_PROF_ENCODER, s, 20.0 * B * H, 30.0 * B * H);
     dim3 grid(cdiv((long)B * H, 256)), block(256);
-#define K_(T) hipLaunchKernelGGL(gru_cell_fwd_kernel<T>, grid, block, 0, s, (const T*)gi, ld_gi, (const T*)gh, (const T*)h_prev, ld_hp, (T*)h, ld_h, save, B, H)
+#define K_(T) hipLaunchKernelGGL(gru_cell_fwd_kernel<T>, grid, block, 0, s, (const T*)gi, ld_gi, (const T*)gh, ld_gh, (const T*)h_prev, ld_hp, (T*)h, ld_h, save, B, H)
     DISPATCH(dtype, K_)
 #undef K_
     MMTG_LAUNCH_CHECK("gru_cell_fwd");

@@ -435,7 +435,6 @@ class Engine:
         st = {}
         st["ln1"] = (self.buf("ln1_mu", (B,), torch.float32), self.buf("ln1_rs", (B,), torch.float32))
         hip.layernorm_fwd(t_raw, t_ln, self.P("ln_layer1.weight"), self.P("ln_layer1.bias"), *st["ln1"], B, H)
-        zeros_h = self.buf("zeros_h", (B, H), zero=True)
         gh = self.buf("gh", (B, 3 * H))
         enc = {}
         for ch, x, lnk in (("image", xi, "ln_layer2"), ("text", xr, "ln_layer3")):
@@ -445,10 +444,12 @@ class Engine:
             h_all = self.buf("h_" + ch, (B * S, H))
             save = self.buf("gru_save_" + ch, (S, 4, B, H), torch.float32)
             for t in range(S):
-                hp = zeros_h if t == 0 else h_all[t - 1:]
-                self._fwd(hp, r + "weight_hh_l0", gh, B, "linear", bias=self.P(r + "bias_hh_l0"),
-                          lda=H if t == 0 else S * H)
-                hip.gru_cell_fwd(gi[t:], gh, None if t == 0 else h_all[t - 1:], h_all[t:], save[t], B, H,
+                if t == 0:      # h_prev = 0: the recurrent product is b_hh itself (one row, stride 0), no launch
+                    hip.gru_cell_fwd(gi[t:], self.W(r + "bias_hh_l0"), None, h_all[t:], save[t], B, H,
+                                     ld_gi=S * 3 * H, ld_hp=S * H, ld_h=S * H, ld_gh=0)
+                    continue
+                self._fwd(h_all[t - 1:], r + "weight_hh_l0", gh, B, "linear", bias=self.P(r + "bias_hh_l0"), lda=S * H)
+                hip.gru_cell_fwd(gi[t:], gh, h_all[t - 1:], h_all[t:], save[t], B, H,
                                  ld_gi=S * 3 * H, ld_hp=S * H, ld_h=S * H)
             h_ln = self.buf("hln_" + ch, (B * S, H))
             st[lnk] = (self.buf(lnk + "_mu", (B * S,), torch.float32), self.buf(lnk + "_rs", (B * S,), torch.float32))
@@ -755,10 +756,6 @@ class Engine:
                           self.G("ln_layer1.weight"), self.G("ln_layer1.bias"), B, H, ws=lnws)
         self._wgrad(a["xt"], dt_raw, "encoder.topic_fc.weight", "encoder.topic_fc.bias", B, "linear")
         self._ready("encoder.topic_fc.bias")
-
-    def _gather_rows(self, row3, t, out):
-        """out[b,:] = row3[b,t,:] -- strided device-to-device copy (data movement only)."""
-        out.copy_(row3[:, t, :])
 
     # ---------------------------------------------------------------- optimizer (train.py:194-197)
     def grad_norm_sq(self):

@@ -45,7 +45,7 @@ _SIGS = {
     "mmtg_dropout_apply": ([_i, _vp, _vp, _l, _i, _u, _u, _vp], _i),
     "mmtg_loss_fwd": ([_i, _vp, _l, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp], _i),
     "mmtg_loss_bwd": ([_i, _i, _vp, _l, _i, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _i, _vp, _l, _i, _vp], _i),
-    "mmtg_gru_cell_fwd": ([_i, _vp, _l, _vp, _vp, _l, _vp, _l, _vp, _i, _i, _vp], _i),
+    "mmtg_gru_cell_fwd": ([_i, _vp, _l, _vp, _l, _vp, _l, _vp, _l, _vp, _i, _i, _vp], _i),
     "mmtg_gru_cell_bwd_fused": ([_i, _vp, _l, _vp, _vp, _i, _vp, _vp, _l, _vp, _l, _vp, _vp, _i, _i, _vp], _i),
     "mmtg_gru_cell_bwd": ([_i, _vp, _vp, _vp, _l, _vp, _l, _vp, _vp, _i, _i, _vp], _i),
     "mmtg_alpha_attn_fwd": ([_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp], _i),
@@ -270,8 +270,8 @@ def gru_cell_bwd_fused(rows, ld_rows, carry, part, splits, save, h_prev, dgi, dg
 
 
 
-def gru_cell_fwd(gi, gh, h_prev, h, save, B, H, ld_gi=None, ld_hp=None, ld_h=None):
-    _check(lib().mmtg_gru_cell_fwd(dt(gi), _p(gi), 3 * H if ld_gi is None else ld_gi, _p(gh), _p(h_prev),
+def gru_cell_fwd(gi, gh, h_prev, h, save, B, H, ld_gi=None, ld_hp=None, ld_h=None, ld_gh=None):
+    _check(lib().mmtg_gru_cell_fwd(dt(gi), _p(gi), 3 * H if ld_gi is None else ld_gi, _p(gh), 3 * H if ld_gh is None else ld_gh, _p(h_prev),
                                    H if ld_hp is None else ld_hp, _p(h), H if ld_h is None else ld_h, _p(save),
                                    B, H, _stream()), "gru_cell_fwd")
 

@@ -587,6 +587,25 @@ def test_gru_cell(dtype):
     # first step: h_prev = None means zeros
     hip.gru_cell_fwd(gi.to(DEV), gh.to(DEV), None, h, save, B, H)
     close(h, ((1 - z) * n).detach(), dtype, 1, "gru h (h0=0)")
+    # step 0 of the sequence: the recurrent pre-activation is one bias row for every b (row stride 0)
+    row = gh[:1].contiguous()
+    h0 = torch.empty(B, H, device=DEV, dtype=dtype)
+    hip.gru_cell_fwd(gi.to(DEV), row.to(DEV), None, h0, save, B, H, ld_gh=0)
+    hb = torch.empty(B, H, device=DEV, dtype=dtype)
+    hip.gru_cell_fwd(gi.to(DEV), row.expand(B, 3 * H).contiguous().to(DEV), None, hb, save, B, H)
+    assert torch.equal(h0, hb)
+    # fused backward: dh_t assembled in the kernel from rows (storage type) + carry + the carry product's slabs
+    rows = rnd(B, H, dtype=dtype, seed=9).to(DEV)
+    carry = rnd(B, H, seed=10).to(DEV)
+    part = rnd(3, B, H, seed=11).to(DEV)
+    dtot = rows.float() + carry + part.sum(0)
+    hip.gru_cell_fwd(gi.to(DEV), gh.to(DEV), hp.to(DEV), h, save, B, H)
+    ref = [torch.empty(B, 3 * H, device=DEV, dtype=dtype), torch.empty(B, 3 * H, device=DEV, dtype=dtype), torch.empty(B, H, device=DEV)]
+    hip.gru_cell_bwd(dtot, save, hp.to(DEV), ref[0], ref[1], ref[2], B, H)
+    got = [torch.empty_like(ref[0]), torch.empty_like(ref[1]), carry.clone()]
+    hip.gru_cell_bwd_fused(rows, H, got[2], part, 3, save, hp.to(DEV), got[0], got[1], got[2], B, H)
+    for a, b_, nm in zip(got, ref, ("dgi", "dgh", "dh_prev")):
+        close(a, b_, dtype if nm != "dh_prev" else torch.float32, 1, "gru fused " + nm)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
