@@ -299,12 +299,12 @@ def main():
         # figure is the committed rocprofv3 --pmc measurement of this same program (tools/gpu_pmc_bench.sh),
         # reported only for the configuration it was taken on; algorithmic bytes (A + B + C once) beside it.
         roof["algorithmic_bytes_per_launch"] = round(g["bytes"] / max(1, g["launches"]))
-        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_v8_bench_pmc_gemm_traffic.json")
+        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_v9_bench_pmc_gemm_traffic.json")
         if args.dtype == "bf16" and B == 64 and args.layers == 12 and os.path.exists(pmc):
             with open(pmc) as fh:
                 m = json.load(fh)
             roof["traffic"] = m["hbm_bytes_per_launch"]
-            roof["traffic_source"] = "profiles/r01_v8_bench_pmc_gemm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, per launch)"
+            roof["traffic_source"] = "profiles/r01_v9_bench_pmc_gemm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, per launch)"
         fwd_tok, enc = algorithmic_flops_per_token(S, T, gcfg["n_embd"], gcfg["n_layer"], V)
         step_flops = 3.0 * (fwd_tok * B * T + enc * B)
         roof["whole_step_tflops_per_gpu"] = round(step_flops / (ms_step * 1e-3) / 1e12, 2)
