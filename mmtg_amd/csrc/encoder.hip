@@ -85,14 +85,18 @@ __global__ __launch_bounds__(256) void gru_cell_bwd_fused_kernel(const T* __rest
 // consecutive channels; QK^T dot products by wave reduction.
 constexpr int AS_MAX = 8;
 
-template <typename T>
+// (S is a template parameter: with a run-time S the score arrays are indexed dynamically and live in scratch
+//  memory -- 272 / 528 bytes per lane, 36 us per launch; unrolled they are registers)
+template <typename T, int S>
 __global__ __launch_bounds__(64) void alpha_fwd_kernel(const T* __restrict__ qkv, const float* __restrict__ prior,
-        T* __restrict__ ctx, float* __restrict__ probs, float* __restrict__ kl, int B, int S, int H, int heads) {
+        T* __restrict__ ctx, float* __restrict__ probs, float* __restrict__ kl, int B, int H, int heads) {
     const int b = blockIdx.x / heads, hd = blockIdx.x % heads;
     const int dh = H / heads, lane = threadIdx.x;
     const float scale = rsqrtf((float)dh);
-    float sc[AS_MAX][AS_MAX];
+    float sc[S][S];
+#pragma unroll
     for (int i = 0; i < S; ++i)
+#pragma unroll
         for (int j = 0; j < S; ++j) {
             float a = 0.f;
             for (int c = lane; c < dh; c += 64) {
@@ -103,12 +107,16 @@ __global__ __launch_bounds__(64) void alpha_fwd_kernel(const T* __restrict__ qkv
             sc[i][j] = wave_sum(a) * scale;
         }
     float klacc = 0.f;
+#pragma unroll
     for (int i = 0; i < S; ++i) {
         float mx = sc[i][0];
+#pragma unroll
         for (int j = 1; j < S; ++j) mx = fmaxf(mx, sc[i][j]);
         float sm = 0.f;
+#pragma unroll
         for (int j = 0; j < S; ++j) { sc[i][j] = expf(sc[i][j] - mx); sm += sc[i][j]; }
         const float inv = 1.f / sm;
+#pragma unroll
         for (int j = 0; j < S; ++j) {
             sc[i][j] *= inv;
             const float q = prior[i * S + j];
@@ -116,53 +124,68 @@ __global__ __launch_bounds__(64) void alpha_fwd_kernel(const T* __restrict__ qkv
         }
     }
     if (lane == 0) {
+#pragma unroll
         for (int i = 0; i < S; ++i)
+#pragma unroll
             for (int j = 0; j < S; ++j) probs[(((long)b * heads + hd) * S + i) * S + j] = sc[i][j];
         atomicAdd(kl, klacc / ((float)B * S));
     }
     for (int c = lane; c < dh; c += 64) {
-        float vv[AS_MAX];
+        float vv[S];
+#pragma unroll
         for (int j = 0; j < S; ++j) vv[j] = (float)qkv[((long)b * S + j) * 3 * H + 2 * H + hd * dh + c];
+#pragma unroll
         for (int i = 0; i < S; ++i) {
             float a = 0.f;
+#pragma unroll
             for (int j = 0; j < S; ++j) a += sc[i][j] * vv[j];
             ctx[((long)b * S + i) * H + hd * dh + c] = (T)a;
         }
     }
 }
 
-template <typename T>
+template <typename T, int S>
 __global__ __launch_bounds__(64) void alpha_bwd_kernel(const T* __restrict__ qkv, const float* __restrict__ prior,
         const float* __restrict__ probs, const T* __restrict__ dctx, float dkl, T* __restrict__ dqkv,
-        int B, int S, int H, int heads) {
+        int B, int H, int heads) {
     const int b = blockIdx.x / heads, hd = blockIdx.x % heads;
     const int dh = H / heads, lane = threadIdx.x;
     const float scale = rsqrtf((float)dh);
-    float P[AS_MAX][AS_MAX], dS[AS_MAX][AS_MAX];
+    float P[S][S], dS[S][S];
+#pragma unroll
     for (int i = 0; i < S; ++i)
+#pragma unroll
         for (int j = 0; j < S; ++j) P[i][j] = probs[(((long)b * heads + hd) * S + i) * S + j];
     // dP[i][j] = dctx[i] . V[j]  - dkl * prior[i][j] / (P[i][j] * B * S)
+#pragma unroll
     for (int i = 0; i < S; ++i)
+#pragma unroll
         for (int j = 0; j < S; ++j) {
             float a = 0.f;
             for (int c = lane; c < dh; c += 64)
                 a += (float)dctx[((long)b * S + i) * H + hd * dh + c] * (float)qkv[((long)b * S + j) * 3 * H + 2 * H + hd * dh + c];
             dS[i][j] = wave_sum(a) - dkl * prior[i * S + j] / (P[i][j] * (float)B * S);
         }
+#pragma unroll
     for (int i = 0; i < S; ++i) {
         float dot = 0.f;
+#pragma unroll
         for (int j = 0; j < S; ++j) dot += P[i][j] * dS[i][j];
+#pragma unroll
         for (int j = 0; j < S; ++j) dS[i][j] = P[i][j] * (dS[i][j] - dot) * scale;
     }
     for (int c = lane; c < dh; c += 64) {
-        float q[AS_MAX], k[AS_MAX], dc[AS_MAX];
+        float q[S], k[S], dc[S];
+#pragma unroll
         for (int j = 0; j < S; ++j) {
             q[j] = (float)qkv[((long)b * S + j) * 3 * H + hd * dh + c];
             k[j] = (float)qkv[((long)b * S + j) * 3 * H + H + hd * dh + c];
             dc[j] = (float)dctx[((long)b * S + j) * H + hd * dh + c];
         }
+#pragma unroll
         for (int i = 0; i < S; ++i) {
             float dq = 0.f, dk = 0.f, dv = 0.f;
+#pragma unroll
             for (int j = 0; j < S; ++j) {
                 dq += dS[i][j] * k[j];
                 dk += dS[j][i] * q[j];
@@ -294,9 +317,12 @@ extern "C" int mmtg_alpha_attn_fwd(int dtype, const void* qkv, const float* prio
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(MMTG_PROF_ENCODER, s, 4.0 * B * S * S * H, 8.0 * B * S * H);
     dim3 grid(B * heads), block(64);
-#define K_(T) hipLaunchKernelGGL(alpha_fwd_kernel<T>, grid, block, 0, s, (const T*)qkv, prior, (T*)ctx, probs, kl, B, S, H, heads)
+#define KS_(T, S_) hipLaunchKernelGGL((alpha_fwd_kernel<T, S_>), grid, block, 0, s, (const T*)qkv, prior, (T*)ctx, probs, kl, B, H, heads)
+#define K_(T) switch (S) { case 1: KS_(T, 1); break; case 2: KS_(T, 2); break; case 3: KS_(T, 3); break; case 4: KS_(T, 4); break; \
+                           case 5: KS_(T, 5); break; case 6: KS_(T, 6); break; case 7: KS_(T, 7); break; default: KS_(T, 8); break; }
     DISPATCH(dtype, K_)
 #undef K_
+#undef KS_
     MMTG_LAUNCH_CHECK("alpha_attn_fwd");
     return MMTG_OK;
 }
@@ -308,9 +334,12 @@ extern "C" int mmtg_alpha_attn_bwd(int dtype, const void* qkv, const float* prio
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(MMTG_PROF_ENCODER, s, 8.0 * B * S * S * H, 16.0 * B * S * H);
     dim3 grid(B * heads), block(64);
-#define K_(T) hipLaunchKernelGGL(alpha_bwd_kernel<T>, grid, block, 0, s, (const T*)qkv, prior, probs, (const T*)dctx, dkl, (T*)dqkv, B, S, H, heads)
+#define KS_(T, S_) hipLaunchKernelGGL((alpha_bwd_kernel<T, S_>), grid, block, 0, s, (const T*)qkv, prior, probs, (const T*)dctx, dkl, (T*)dqkv, B, H, heads)
+#define K_(T) switch (S) { case 1: KS_(T, 1); break; case 2: KS_(T, 2); break; case 3: KS_(T, 3); break; case 4: KS_(T, 4); break; \
+                           case 5: KS_(T, 5); break; case 6: KS_(T, 6); break; case 7: KS_(T, 7); break; default: KS_(T, 8); break; }
     DISPATCH(dtype, K_)
 #undef K_
+#undef KS_
     MMTG_LAUNCH_CHECK("alpha_attn_bwd");
     return MMTG_OK;
 }
