@@ -648,9 +648,11 @@ class Engine:
             bands = self.buf("d_u_bands", ((M + 63) // 64, 4 * D), torch.float32)
             self._dgrad(dy, p + "mlp.c_proj.weight", du, M, "conv1d", epi=hip.EPI_DGELU, aux=u, ldaux=4 * D, aux2=bands)
             hip.colsum(bands, bands.shape[0], 4 * D, self.G(p + "mlp.c_fc.bias"))
-            self._wgrad(gact, dy, p + "mlp.c_proj.weight", None, M, "conv1d")
+            # (both consumers of du run while it is still in the Infinity Cache; the c_proj weight gradient, whose
+            #  operands come from HBM either way, goes last -- it must precede the LayerNorm backward, which reuses dmask)
             self._dgrad(du, p + "mlp.c_fc.weight", dm, M, "conv1d")
             self._wgrad(m2, du, p + "mlp.c_fc.weight", None, M, "conv1d")
+            self._wgrad(gact, dy, p + "mlp.c_proj.weight", None, M, "conv1d")
             hip.layernorm_bwd(dm, xmid, self.P(p + "ln_2.weight"), mu2, rs2, dx, dx2,
                               self.G(p + "ln_2.weight"), self.G(p + "ln_2.bias"), M, D,
                               dx_masked=dmask, drop_p=pr, drop_seed=s + 1,
