@@ -10,7 +10,9 @@ from mmtg_amd import MMTG, synth
 from mmtg_amd.configs import data_config, gpt2_config, make_model_cfgs
 from mmtg_amd.trainer import MMTGTrainer
 
-S, V, B, steps = 5, 13317, 64, 120
+S, V, B = 5, 13317, 64
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 120
+every = max(10, steps // 12)
 mcfg, dcfg = make_model_cfgs(seq_len=S), data_config(seq_len=S)
 gcfg = gpt2_config(n_layer=12, vocab_size=V)
 model = MMTG(mcfg, dcfg, V, train_flag=True, gpt2_config=gcfg, compute_dtype="bf16", token_table=synth.make_token_table(V, seed=2))
@@ -22,7 +24,7 @@ tr = MMTGTrainer(model, lr=2e-4, alpha=0.2, warmup_steps=12, total_steps=steps)
 t0 = time.time()
 for i in range(steps):
     out = tr.step(batches[i % 4], stage=3)
-    if i % 10 == 0 or i == steps - 1:
+    if i % every == 0 or i == steps - 1:
         print("step %3d  lr %.2e  MyLoss %.4f  lm_loss %.4f  kl %.5f" % (i, tr.current_lr(), float(out["loss"]), float(out["lm_loss"]), float(out["kl"])), flush=True)
 torch.cuda.synchronize()
-print("%d steps in %.2f s (host-synchronised every 10 steps)" % (steps, time.time() - t0))
+print("%d steps in %.2f s; all parameters finite: %s" % (steps, time.time() - t0, bool(torch.isfinite(model.engine().master).all())))
