@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MMTG_ABI_VERSION 1
+#define MMTG_ABI_VERSION 2
 
 enum { MMTG_OK = 0, MMTG_ERR_BAD_ARG = -1, MMTG_ERR_HIP = -2, MMTG_ERR_UNSUPPORTED = -3 };
 enum { MMTG_F32 = 0, MMTG_BF16 = 1 };
@@ -232,10 +232,13 @@ int mmtg_beta_fuse_bwd(int dtype, const void* topic, const void* img, const void
  * sumsq: *out += sum x^2 (global grad-norm partial).                          */
 int mmtg_sumsq(const float* x, long n, float* out, void* stream);
 /* clip (coef = min(1, max_norm / (sqrt(*normsq) + 1e-6))) + transformers.AdamW
- * (bias-corrected, eps outside the sqrt, decoupled wd) + optional bf16 copy.  */
+ * (bias-corrected, eps outside the sqrt, decoupled wd) + optional bf16 copy.
+ * count (optional, device scalar): g holds a SUM over rows and *count the global row count
+ * (all-reduced on the device, never read by the host): the gradient is g * grad_scale / *count;
+ * *count == 0 leaves every buffer untouched (the reference skips an empty batch, train.py:184-185). */
 int mmtg_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, long n,
                float lr, float beta1, float beta2, float eps, float wd, int step,
-               const float* normsq, float max_norm, float grad_scale, void* stream);
+               const float* normsq, float max_norm, float grad_scale, const float* count, void* stream);
 int mmtg_cast_f32_to(int dtype, const float* src, void* dst, long n, void* stream);
 /* dst[r, 0:cols] = cast(src[r, 0:cols]); dst[r, cols:ldd] = 0 */
 int mmtg_cast_pad_rows(int dtype, const float* src, long lds_, void* dst, long ldd, int rows, int cols, void* stream);

@@ -24,7 +24,16 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
 
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
         float* __restrict__ m, float* __restrict__ v, bf16* __restrict__ pc, long n, float lr, float b1, float b2,
-        float eps, float wd, float step_size, const float* __restrict__ normsq, float max_norm, float gscale) {
+        float eps, float wd, float step_size, const float* __restrict__ normsq, float max_norm, float gscale,
+        const float* __restrict__ count) {
+    // data-parallel steps hand over SUMS of per-row gradients and the global row count as a device scalar
+    // (the all-reduced count never visits the host); an empty global batch leaves every buffer untouched,
+    // as the reference skips the step (train.py:184-185)
+    if (count) {
+        const float c = *count;
+        if (!(c > 0.f)) return;
+        gscale *= 1.0f / c;
+    }
     float coef = gscale;
     if (normsq) {
         // torch.nn.utils.clip_grad_norm_: coef = max_norm / (norm + 1e-6), clamped to 1
@@ -132,7 +141,7 @@ extern "C" int mmtg_sumsq(const float* x, long n, float* out, void* stream) {
 
 extern "C" int mmtg_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, long n,
                           float lr, float beta1, float beta2, float eps, float wd, int step,
-                          const float* normsq, float max_norm, float grad_scale, void* stream) {
+                          const float* normsq, float max_norm, float grad_scale, const float* count, void* stream) {
     MMTG_REQUIRE(p && g && m && v && n > 0 && step >= 1, "adamw: bad args");
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(MMTG_PROF_OPTIM, s, 12.0 * n, (28.0 + (p_bf16 ? 2 : 0)) * n);
@@ -140,7 +149,7 @@ extern "C" int mmtg_adamw(float* p, const float* g, float* m, float* v, void* p_
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
     const float step_size = (float)((double)lr * sqrt(bc2) / bc1);
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, s, p, g, m, v, (bf16*)p_bf16, n, lr, beta1, beta2,
-                       eps, wd, step_size, normsq, max_norm, grad_scale);
+                       eps, wd, step_size, normsq, max_norm, grad_scale, count);
     MMTG_LAUNCH_CHECK("adamw");
     return MMTG_OK;
 }

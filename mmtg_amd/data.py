@@ -176,7 +176,12 @@ class DeviceLoader:
     """Iterates ``(device batch dict)`` over a dataset: rows are collated into two alternating sets of pinned
     buffers and copied with ``non_blocking=True`` on a private stream while the previous batch trains; the
     consumer's stream waits on the copy's event only.  ``stage`` in (1, 2) applies ``stage_filter`` on the host
-    first (filtered rows are never copied)."""
+    first (filtered rows are never copied).
+
+    A pinned slot is rewritten only after the HOST has seen its previous copy complete (the training loop never
+    synchronises, so the host can run several batches ahead of the DMA engine).  With ``world > 1`` a batch the filter
+    empties is still yielded (zero rows): every rank must enter ``MMTGTrainer.step`` the same number of times or the
+    gradient all-reduce deadlocks; a single process skips it, as train.py:184-185 does."""
 
     def __init__(self, dataset, batch_size, device="cuda", shuffle=True, seed=0, stage=3, drop_last=True,
                  rank=0, world=1):
@@ -185,6 +190,7 @@ class DeviceLoader:
         self.rank, self.world = rank, world
         self.epoch = 0
         self._pinned = [None, None]
+        self._copied = [None, None]     # per slot: event of the last H2D copy that read the pinned buffers
         self._stream = torch.cuda.Stream(device=self.dev) if self.dev.type == "cuda" else None
 
     def __len__(self):
@@ -198,6 +204,9 @@ class DeviceLoader:
         return {k: np.stack([np.asarray(it[k]) for it in items]) for k in items[0]}
 
     def _to_pinned(self, slot, batch):
+        if self._copied[slot] is not None:
+            self._copied[slot].synchronize()    # normally long complete: the copy was issued two batches ago
+            self._copied[slot] = None
         pin = self._pinned[slot]
         if pin is None or any(pin[k].shape[0] < v.shape[0] or pin[k].shape[1:] != v.shape[1:] for k, v in batch.items()):
             pin = {}
@@ -221,7 +230,11 @@ class DeviceLoader:
             keep = stage_filter(batch["rating"], self.stage)
             batch = {k: v[keep] for k, v in batch.items()}
         if next(iter(batch.values())).shape[0] == 0:
-            return None
+            if self.world == 1:
+                return None
+            empty = {k: torch.from_numpy(np.ascontiguousarray(v)).to(torch.float32 if v.dtype.kind == "f" else torch.int64)
+                     for k, v in batch.items()}
+            return {k: v.to(self.dev) for k, v in empty.items()}, None
         host = self._to_pinned(slot, batch)
         if self._stream is None:
             return {k: v.clone() for k, v in host.items()}, None
@@ -229,6 +242,7 @@ class DeviceLoader:
             dev = {k: v.to(self.dev, non_blocking=True) for k, v in host.items()}
             ev = torch.cuda.Event()
             ev.record(self._stream)
+        self._copied[slot] = ev
         return dev, ev
 
     def __iter__(self):

@@ -11,7 +11,12 @@ asynchronously -- RCCL runs them on its own stream while the backward continues.
 xGMI is point-to-point (7 links x ~153 GB/s per GPU): buckets are large (default
 64 MB) so each ring step moves enough bytes per link to hide its latency.
 
-Works unchanged on CPU tensors with the gloo backend (tests/test_ddp_cpu.py).
+The global row count (curriculum filtering leaves the ranks with unequal shards) is all-reduced the same way as a
+one-element device tensor and consumed on the device by the clip + AdamW kernel: no host synchronisation.
+
+Works unchanged on CPU tensors with the gloo backend (tests/test_host_cpu.py::test_bucketed_allreduce_world2_gloo);
+executed on the GPU over RCCL by tests/test_ddp_gpu.py (world size 1 with MMTG_FORCE_DDP=1, and 2 ranks where two
+GPUs are visible).
 """
 from __future__ import annotations
 
@@ -31,16 +36,26 @@ class GradReducer:
         self.pack_end = {name: o + n for name, (o, n) in layout.pack_range.items()}
         self.reset()
 
+    @property
+    def active(self):
+        """True when collectives run: more than one rank, or the forced single-rank self-test."""
+        return self.world > 1 or self.force
+
     def reset(self):
         self.next_bucket = 0
         self.handles = []
+
+    def start_count(self, count):
+        """Asynchronous SUM all-reduce (in place) of the one-element device tensor holding this rank's row count."""
+        if self.active:
+            self.handles.append(dist.all_reduce(count, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def on_pack_ready(self, grad_flat, pack_name):
         self.on_ready(grad_flat, self.pack_end[pack_name])
 
     def on_ready(self, grad_flat, end_offset):
         """All gradient elements below end_offset are final: launch every complete bucket."""
-        if self.world == 1 and not self.force:
+        if not self.active:
             return
         while self.next_bucket < len(self.buckets) and self.buckets[self.next_bucket][1] <= end_offset:
             s, e = self.buckets[self.next_bucket]
@@ -48,20 +63,12 @@ class GradReducer:
             self.next_bucket += 1
 
     def finish(self, grad_flat):
-        """Flush the remaining buckets and make the current stream wait for all of them."""
-        if self.world > 1 or self.force:
+        """Flush the remaining buckets and make the current stream wait for all of them (and for the row count)."""
+        if self.active:
             self.on_ready(grad_flat, self.layout.total)
             for h in self.handles:
                 h.wait()
         self.reset()
-
-    def global_count(self, n_local, device):
-        """Sum of per-rank row counts (curriculum filtering makes them unequal)."""
-        if self.world == 1:
-            return int(n_local)
-        t = torch.tensor([float(n_local)], device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
-        return int(round(t.item()))
 
 
 def shard_rows(n_rows, rank, world):

@@ -183,7 +183,15 @@ class GreedyDecoder:
 
     # ------------------------------------------------------------------ public
     @torch.no_grad()
-    def generate(self, batch, length, temperature=1.0, repitition_penalty=1.0, top_k=1, top_p=0.0, generator=None):
+    def describe(self):
+        return "one hipGraph replay per token step" if self.use_graph else "eager launches per token step"
+
+    def kernel_name(self):
+        return ("decode token step: split-K gemm_dma_kernel<256x32> weight streaming + decode_attn KV-cache streaming + finish kernels"
+                if self.fast else "decode token step: training-side kernels per layer")
+
+    def generate(self, batch, length, temperature=1.0, repitition_penalty=1.0, top_k=1, top_p=0.0, generator=None,
+                 use_graph=None):
         """batch: dict with topic_ids/tpw_* [B,P], topic_emb, img_embs, r_embs (no targets needed).
         Runs `length` iterations of the reference loop and returns the lyric ids
         [B, 1 + length] (column 0 is the initial [#START#]).  top_k = 1, top_p = 0 is the greedy setting;
@@ -213,10 +221,16 @@ class GreedyDecoder:
         self.keep.zero_()
         self.pos.zero_()
         n_steps = sh.P + length                                 # positions 0 .. P+length-1 are consumed
-        for pos in range(n_steps):
-            j = pos + 1 - sh.P                                  # lyric index appended after this step
-            forced = j < 1 or (j > 1 and (j + 1) % (sh.msl + 2) in (0, 1))
-            self._run_step(with_head=not forced)
+        saved_mode = self.use_graph
+        if use_graph is not None:
+            self.use_graph = use_graph
+        try:
+            for pos in range(n_steps):
+                j = pos + 1 - sh.P                                  # lyric index appended after this step
+                forced = j < 1 or (j > 1 and (j + 1) % (sh.msl + 2) in (0, 1))
+                self._run_step(with_head=not forced)
+        finally:
+            self.use_graph = saved_mode
         return self.seq[:, sh.P:sh.P + 1 + length].clone()
 
     @staticmethod

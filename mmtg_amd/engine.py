@@ -158,6 +158,13 @@ def gaussian_prior(S):
 
 
 import os as _os
+
+
+def _dist_rank():
+    import torch.distributed as dist
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else int(_os.environ.get("RANK", "0"))
+
+
 _NO_OCC4 = bool(_os.environ.get("MMTG_GEMM_NO_OCC4"))     # A/B switch, mirrors the library's
 _WG_NUM = float(_os.environ.get("MMTG_WGRAD_NUM", "760"))     # tuning knobs of the slab weight-gradient split count
 _WG_CAP = int(_os.environ.get("MMTG_WGRAD_CAP", "12"))
@@ -191,6 +198,34 @@ def _wgrad_splits(M, N, K, occ4=False, slots=512, t_iter=1.1, t_fixed=6.0):
     return best
 
 
+def _round_capacity(n):
+    """Next value of {1, 1.25, 1.5, 1.75} x 2^k at or above n (<= 25 % slack, O(log) distinct sizes per buffer so the
+    caching allocator's freed blocks are reused instead of piling up)."""
+    if n <= 1024:
+        return 1024
+    k = 1 << (int(n - 1).bit_length() - 1)      # largest power of two below n
+    for q in (4, 5, 6, 7, 8):
+        if k * q // 4 >= n:
+            return k * q // 4
+    return 2 * k
+
+
+def mix_seed(seed, site):
+    """32-bit hash of (step seed, dropout site): sites get unrelated counter-hash streams instead of one stream
+    at small integer offsets (the kernels compute hash(element index * G + seed))."""
+    x = (seed ^ (0x9E3779B9 * (site + 1))) & 0xFFFFFFFF
+    x = ((x ^ (x >> 16)) * 0x7FEB352D) & 0xFFFFFFFF
+    x = ((x ^ (x >> 15)) * 0x846CA68B) & 0xFFFFFFFF
+    return (x ^ (x >> 16)) & 0xFFFFFFFF
+
+
+def initial_drop_seed(rank=0):
+    """Start of the dropout counter: a hash of torch's seed (train.py:88-94 seeds torch) and the data-parallel rank,
+    so replicas draw independent masks (the reference's DataParallel replicas do) and torch.manual_seed controls
+    the sequence."""
+    return mix_seed(torch.initial_seed() & 0xFFFFFFFF, 0x5EED + 7919 * rank)
+
+
 # --------------------------------------------------------------------------
 class Engine:
     """Owns the flat buffers and runs forward / loss / backward / optimizer."""
@@ -215,7 +250,7 @@ class Engine:
         self.ws = {}
         self.act = None
         self.training = False
-        self.drop_seed = 0x1234
+        self.drop_seed = initial_drop_seed(_dist_rank())
         self.wgrad_overwrite = False   # set by MMTGTrainer.step around its backward
         self.step_count = 0
         self.opt_m = None
@@ -236,15 +271,26 @@ class Engine:
         self.table = self.table32 if self.dtype == hip.F32 else self.table32.to(torch.bfloat16)
 
     def buf(self, name, shape, dtype=None, zero=False):
+        """Named workspace.  One allocation per (name, dtype), sized for the largest request seen so far (rounded up
+        on a coarse grid) and handed out as a ``[:numel].view(shape)`` slice: the curriculum filter (train.py:178-186)
+        changes the row count on almost every step of stages 1 and 2, and a buffer set per exact shape would grow
+        without bound (0.3 MB per token at the full configuration).  Every kernel takes its row count and leading
+        dimensions explicitly, so a slice of a larger allocation is as good as an exact one."""
         dtype = self.tdt if dtype is None else dtype
-        key = (name, tuple(shape), dtype)
+        n = 1
+        for d in shape:
+            n *= int(d)
+        key = (name, dtype)
         t = self.ws.get(key)
-        if t is None:
-            t = torch.zeros(shape, device=self.dev, dtype=dtype) if zero else torch.empty(shape, device=self.dev, dtype=dtype)
+        if t is None or t.numel() < n:
+            cap = _round_capacity(n)
+            t = torch.zeros(cap, device=self.dev, dtype=dtype) if zero else torch.empty(cap, device=self.dev, dtype=dtype)
             self.ws[key] = t
-        elif zero:
-            t.zero_()
-        return t
+            return t[:n].view(shape)
+        v = t[:n].view(shape)
+        if zero:
+            v.zero_()
+        return v
 
     def P(self, key):   # fp32 master view
         return self.layout.view(self.master, key)
@@ -502,7 +548,7 @@ class Engine:
         layers = []
         for l in range(sh.L):
             p = f"{pre}h.{l}."
-            s = seed + 97 * (l + 1)
+            s = (mix_seed(seed, 3 * l + 1), mix_seed(seed, 3 * l + 2), mix_seed(seed, 3 * l + 3))   # attn, resid 1, resid 2
             mu1 = self.buf(f"l{l}_mu1", (M,), torch.float32)
             rs1 = self.buf(f"l{l}_rs1", (M,), torch.float32)
             a1 = self.buf(f"l{l}_a", (M, D))
@@ -511,10 +557,10 @@ class Engine:
             self._fwd(a1, p + "attn.c_attn.weight", qkv, M, "conv1d", bias=self.P(p + "attn.c_attn.bias"))
             ctx = self.buf(f"l{l}_ctx", (M, D))
             lse = self.buf(f"l{l}_lse", (B, sh.nH, T), torch.float32)
-            hip.attn_fwd(qkv, keep, ctx, lse, B, T, sh.nH, D // sh.nH, drop_p=pa, drop_seed=s)
+            hip.attn_fwd(qkv, keep, ctx, lse, B, T, sh.nH, D // sh.nH, drop_p=pa, drop_seed=s[0])
             xmid = self.buf(f"l{l}_xmid", (M, D))
             self._fwd(ctx, p + "attn.c_proj.weight", xmid, M, "conv1d", bias=self.P(p + "attn.c_proj.bias"),
-                      epi=hip.EPI_RESID, aux=hcur, ldaux=D, drop_p=pr, drop_seed=s + 1)
+                      epi=hip.EPI_RESID, aux=hcur, ldaux=D, drop_p=pr, drop_seed=s[1])
             mu2 = self.buf(f"l{l}_mu2", (M,), torch.float32)
             rs2 = self.buf(f"l{l}_rs2", (M,), torch.float32)
             m2 = self.buf(f"l{l}_m", (M, D))
@@ -525,7 +571,7 @@ class Engine:
                       epi=hip.EPI_GELU, aux2=u)
             xout = self.buf(f"resid_{l + 1}", (M, D))
             self._fwd(gact, p + "mlp.c_proj.weight", xout, M, "conv1d", bias=self.P(p + "mlp.c_proj.bias"),
-                      epi=hip.EPI_RESID, aux=xmid, ldaux=D, drop_p=pr, drop_seed=s + 2)
+                      epi=hip.EPI_RESID, aux=xmid, ldaux=D, drop_p=pr, drop_seed=s[2])
             layers.append((hcur, mu1, rs1, a1, qkv, ctx, lse, xmid, mu2, rs2, m2, u, gact, s))
             hcur = xout
         muf = self.buf("lnf_mu", (M,), torch.float32)
@@ -628,7 +674,7 @@ class Engine:
         lastp = f"{pre}h.{sh.L - 1}."
         hip.layernorm_bwd(dhf, a["x_last"], self.P(pre + "ln_f.weight"), a["muf"], a["rsf"], None, dx,
                           self.G(pre + "ln_f.weight"), self.G(pre + "ln_f.bias"), M, D,
-                          dx_masked=dmask, drop_p=pr, drop_seed=a["layers"][sh.L - 1][13] + 2,
+                          dx_masked=dmask, drop_p=pr, drop_seed=a["layers"][sh.L - 1][13][2],
                           dcolsum=self.G(lastp + "mlp.c_proj.bias"), ws=lnws)
         self._ready("ln_f.b")
         du = self.buf("d_u", (M, 4 * D))
@@ -655,7 +701,7 @@ class Engine:
             self._wgrad(gact, dy, p + "mlp.c_proj.weight", None, M, "conv1d")
             hip.layernorm_bwd(dm, xmid, self.P(p + "ln_2.weight"), mu2, rs2, dx, dx2,
                               self.G(p + "ln_2.weight"), self.G(p + "ln_2.bias"), M, D,
-                              dx_masked=dmask, drop_p=pr, drop_seed=s + 1,
+                              dx_masked=dmask, drop_p=pr, drop_seed=s[1],
                               dcolsum=self.G(p + "attn.c_proj.bias"), ws=lnws)
             # x_mid = x_in + drop(ctx Wp + bp)
             dy = dmask if pr > 0 else dx2
@@ -667,14 +713,14 @@ class Engine:
                 self._dgrad(dy, p + "attn.c_proj.weight", dctx, M, "conv1d")
             self._wgrad(ctx, dy, p + "attn.c_proj.weight", None, M, "conv1d")
             hip.attn_bwd(qkv, a["keep"], ctx, dctx, lse, delta, dq32, dqkv, B, T, sh.nH, D // sh.nH,
-                         drop_p=pa, drop_seed=s, delta_ready=fuse_delta, dbias=self.G(p + "attn.c_attn.bias"),
+                         drop_p=pa, drop_seed=s[0], delta_ready=fuse_delta, dbias=self.G(p + "attn.c_attn.bias"),
                          dbias_ws=self.buf("attn_dbias_rows", (hip.attn_bwd_bias_rows(B, T, self.dtype), 3 * D), torch.float32))
             self._dgrad(dqkv, p + "attn.c_attn.weight", da, M, "conv1d")
             self._wgrad(a1, dqkv, p + "attn.c_attn.weight", None, M, "conv1d")
             if l > 0:
                 hip.layernorm_bwd(da, xin, self.P(p + "ln_1.weight"), mu1, rs1, dx2, dx,
                                   self.G(p + "ln_1.weight"), self.G(p + "ln_1.bias"), M, D,
-                                  dx_masked=dmask, drop_p=pr, drop_seed=a["layers"][l - 1][13] + 2,
+                                  dx_masked=dmask, drop_p=pr, drop_seed=a["layers"][l - 1][13][2],
                                   dcolsum=self.G(f"{pre}h.{l - 1}.mlp.c_proj.bias"), ws=lnws)
             else:
                 hip.layernorm_bwd(da, xin, self.P(p + "ln_1.weight"), mu1, rs1, dx2, dx,
@@ -765,15 +811,16 @@ class Engine:
         hip.sumsq(self.grad, self.layout.total, self.normsq)
         return self.normsq
 
-    def adamw_step(self, lr, max_norm=1.0, betas=(0.9, 0.999), eps=1e-6, wd=0.0, grad_scale=1.0, clip=True):
+    def adamw_step(self, lr, max_norm=1.0, betas=(0.9, 0.999), eps=1e-6, wd=0.0, grad_scale=1.0, clip=True, count=None):
         """clip_grad_norm_(1.0) + transformers.AdamW(lr, eps=1e-6, wd=0) over the flat buffers,
-        refreshing the bf16 weight copies in the same pass."""
+        refreshing the bf16 weight copies in the same pass.  count: device scalar, the global row count when the
+        flat buffer holds row SUMS (mmtg_adamw divides by it; zero rows = no update)."""
         if self.opt_m is None:
             self.opt_m = torch.zeros_like(self.master)
             self.opt_v = torch.zeros_like(self.master)
         self.step_count += 1
         ns = self.grad_norm_sq() if clip else None
         hip.adamw(self.master, self.grad, self.opt_m, self.opt_v, None if self.dtype == hip.F32 else self.wc,
-                  self.layout.total, lr, betas[0], betas[1], eps, wd, self.step_count, ns, max_norm, grad_scale)
+                  self.layout.total, lr, betas[0], betas[1], eps, wd, self.step_count, ns, max_norm, grad_scale, count=count)
         self._refresh_transposed()
         self.copies_fresh = True

@@ -13,6 +13,7 @@ import os
 import torch
 
 F32, BF16 = 0, 1
+ABI_VERSION = 2
 EPI_NONE, EPI_GELU, EPI_TANH, EPI_RESID, EPI_DGELU, EPI_DTANH, EPI_ATOMIC, EPI_ROWDOT = range(8)
 GEMM_NO_TR, GEMM_REGSTAGE, GEMM_SKINNY, GEMM_NO_SKINNY, GEMM_WIDE, GEMM_NO_WIDE = 1, 2, 4, 8, 16, 32
 GEMM_PERSIST, GEMM_NO_PERSIST, GEMM_ROW_ORDER, GEMM_OCC4, GEMM_NO_OCC4, GEMM_COL_BLOCK = 64, 128, 256, 512, 1024, 2048
@@ -53,7 +54,7 @@ _SIGS = {
     "mmtg_beta_fuse_fwd": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp], _i),
     "mmtg_beta_fuse_bwd": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp], _i),
     "mmtg_sumsq": ([_vp, _l, _vp, _vp], _i),
-    "mmtg_adamw": ([_vp, _vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _i, _vp, _f, _f, _vp], _i),
+    "mmtg_adamw": ([_vp, _vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _i, _vp, _f, _f, _vp, _vp], _i),
     "mmtg_cast_f32_to": ([_i, _vp, _vp, _l, _vp], _i),
     "mmtg_cast_pad_rows": ([_i, _vp, _l, _vp, _l, _i, _i, _vp], _i),
     "mmtg_cast_to_f32": ([_i, _vp, _vp, _l, _vp], _i),
@@ -76,6 +77,21 @@ def lib_path():
     return _LIB_PATH
 
 
+def source_sha():
+    """sha1 over the kernel sources and the ABI header the library is built from (csrc/*.hip, csrc/*.h,
+    include/mmtg_hip.h): ties a committed PMC measurement to the kernels it was taken on (bench.py roofline.traffic)."""
+    import hashlib
+    here = os.path.dirname(os.path.abspath(__file__))
+    csrc = os.path.join(here, "csrc")
+    h = hashlib.sha1()
+    for name in sorted(f for f in os.listdir(csrc) if f.endswith(".hip") or f.endswith(".h")):
+        with open(os.path.join(csrc, name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
+    with open(os.path.join(here, "..", "include", "mmtg_hip.h"), "rb") as f:
+        h.update(f.read())
+    return h.hexdigest()
+
+
 def exported_symbols():
     return sorted(_SIGS)
 
@@ -93,7 +109,7 @@ def lib():
             fn = getattr(L, name)  # AttributeError if the symbol is missing
             fn.argtypes = args
             fn.restype = res
-        if L.mmtg_abi_version() != 1:
+        if L.mmtg_abi_version() != ABI_VERSION:
             raise RuntimeError("libmmtg_hip.so ABI version mismatch")
         _lib = L
     return _lib
@@ -307,10 +323,11 @@ def sumsq(x, n, out):
     _check(lib().mmtg_sumsq(_p(x), n, _p(out), _stream()), "sumsq")
 
 
-def adamw(p, g, m, v, p_bf16, n, lr, beta1, beta2, eps, wd, step, normsq, max_norm, grad_scale=1.0):
+def adamw(p, g, m, v, p_bf16, n, lr, beta1, beta2, eps, wd, step, normsq, max_norm, grad_scale=1.0, count=None):
+    """count: optional device scalar (float32) = global row count; g is then a SUM over rows (see the header)."""
     _check(lib().mmtg_adamw(_p(p), _p(g), _p(m), _p(v), _p(p_bf16), n, float(lr), float(beta1), float(beta2),
                             float(eps), float(wd), int(step), _p(normsq), float(max_norm), float(grad_scale),
-                            _stream()), "adamw")
+                            _p(count), _stream()), "adamw")
 
 
 def cast_f32_to(src, dst, n):

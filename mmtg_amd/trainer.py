@@ -49,6 +49,7 @@ class MMTGTrainer:
         self.sched_step = 0
         self.lm_weight = lm_weight
         self.reducer = GradReducer(self.eng.layout, bucket_mb) if distributed else None
+        self._count = None
         if self.reducer is not None:
             self.eng.bucket_hook = lambda pack: self.reducer.on_pack_ready(self.eng.grad, pack)
 
@@ -81,44 +82,67 @@ class MMTGTrainer:
         eng.step_count, self.sched_step, eng.drop_seed = int(sd["step_count"]), int(sd["sched_step"]), int(sd["drop_seed"])
 
     def step(self, batch, stage=3, filter_rows=True):
-        """One optimisation step; returns device scalars (no host sync) {'loss','lm_loss','kl'}.
-        Returns None when the stage filter leaves no rows on a single rank (train.py:184-185)."""
+        """One optimisation step; returns device scalars (no host sync) {'loss','lm_loss','kl'} of the LOCAL rows.
+        Returns None when the stage filter leaves no rows on a single rank (train.py:184-185); in a data-parallel
+        group a rank without rows still takes part in the exchange and in the (identical) optimizer step.
+
+        Scaling.  The backward produces the SUM over local rows of the per-row gradients (loss coefficient n_local /
+        n_local, KL weight alpha * n_local); the global row count travels as a DEVICE scalar -- all-reduced next to the
+        gradient buckets when distributed, never read by the host -- and the clip + AdamW kernel divides by it.  Single
+        GPU and data-parallel steps therefore run the same arithmetic, and unequal shards after curriculum filtering
+        give the single-GPU global mean."""
         eng = self.eng
         if filter_rows and stage in (1, 2):
             idx = curriculum_filter(batch["rating"], stage)
             batch = {k: v[idx.to(v.device)] for k, v in batch.items()}
         n_local = int(batch["rating"].shape[0]) if "rating" in batch else int(batch["targets"].shape[0])
-        world = self.reducer.world if self.reducer is not None else 1
-        if self.reducer is not None and filter_rows and stage in (1, 2):
-            n_global = self.reducer.global_count(n_local, eng.dev)
-        else:
-            n_global = n_local * world
-        if n_global == 0:
+        red = self.reducer if (self.reducer is not None and self.reducer.active) else None
+        if red is None and n_local == 0:
             return None
+        if self._count is None:
+            self._count = torch.zeros(1, device=eng.dev, dtype=torch.float32)
+        self._count.fill_(float(n_local))           # asynchronous fill; the value is known on the host
+        if red is not None:
+            red.start_count(self._count)            # SUM over ranks, in place, asynchronous
         eng.zero_grad()
         out = None
         if n_local > 0:
             eng.forward(batch, train_flag=True, training=self.model.training, logits_f32=_LOGITS_F32)
-            sc = eng.loss(batch["rating"], stage, batch_den=n_global)
+            sc = eng.loss(batch["rating"], stage, batch_den=n_local)
             B, T = eng.act["B"], eng.act["T"]
-            dl = eng.loss_backward(1.0, lm_coef=self.lm_weight / (B * (T - 1)) if self.lm_weight else 0.0)
+            dl = eng.loss_backward(float(n_local), lm_coef=self.lm_weight / (T - 1) if self.lm_weight else 0.0)
             eng.wgrad_overwrite = True      # gradients were zeroed above and every weight is written once
             try:
-                eng.backward(dl, dkl=self.alpha * n_local / n_global)
+                eng.backward(dl, dkl=self.alpha * n_local)
             finally:
                 eng.wgrad_overwrite = False
             out = {"loss": sc[0], "lm_loss": sc[1], "kl": eng.act["kl"][0]}
-        if self.reducer is not None:
-            self.reducer.finish(eng.grad)
-        eng.adamw_step(self.current_lr(), self.max_norm, self.betas, self.eps, self.wd)
+        if red is not None:
+            red.finish(eng.grad)
+        eng.adamw_step(self.current_lr(), self.max_norm, self.betas, self.eps, self.wd, count=self._count)
         self.sched_step += 1
         return out
 
+    def grad_norm(self):
+        """Global gradient norm of the last step as clip_grad_norm_ saw it (device scalar): the flat buffer holds row
+        sums, so sqrt(sum g^2) / global row count."""
+        return torch.sqrt(self.eng.normsq[0]) / self._count[0]
 
-def save_checkpoint(path, model, trainer=None, args=None, model_cfgs=None):
-    """The reference's checkpoint dict ``{'model', 'args', 'model_cfgs'}`` (train.py:212; loads in the
-    reference as is) plus, when a trainer is given, ``'trainer'`` for resuming."""
-    ckpt = {"model": {k: v.detach().cpu() for k, v in model.state_dict().items()}, "args": args, "model_cfgs": model_cfgs}
+
+def save_checkpoint(path, model, trainer=None, args=None, model_cfgs=None, reference_compatible=False):
+    """The reference's checkpoint dict ``{'model', 'args', 'model_cfgs'}`` (train.py:212) plus, when a trainer is
+    given, ``'trainer'`` for resuming.
+
+    reference_compatible=True writes the state dict exactly as the reference's own run would have: keys carry the
+    ``module.`` prefix of its nn.DataParallel wrapper (train.py:113,212) and every GPT-2 block has the persistent
+    ``attn.bias`` / ``attn.masked_bias`` buffers of transformers 4.12.3, so the reference's strict
+    ``load_state_dict`` into its DataParallel-wrapped model (generate.py:191-192) accepts the file.  The default
+    writes ``model.state_dict()`` (what ``load_checkpoint`` and any unwrapped consumer read)."""
+    if reference_compatible:
+        sd = {"module." + k: v for k, v in model.legacy_state_dict().items()}
+    else:
+        sd = model.state_dict()
+    ckpt = {"model": {k: v.detach().cpu() for k, v in sd.items()}, "args": args, "model_cfgs": model_cfgs}
     if trainer is not None:
         ckpt["trainer"] = trainer.state_dict()
     torch.save(ckpt, path)

@@ -134,3 +134,33 @@ def test_loader_batches_filter_and_shards(fixture, tmp_path):
     s1 = sorted(int(v) for b in r1 for v in b["topic_ids"][:, 0])
     assert len(s0) == len(s1) == 6 and not set(s0) & set(s1) and sorted(s0 + s1) == list(range(1000, 1012))
     assert len([int(v) for b in r0 for v in b["topic_ids"][:, 0]]) == 6      # second epoch: reshuffled, same share size
+
+
+def test_loader_yields_empty_batches_when_distributed(fixture):
+    """A batch the stage filter empties is skipped by a single process (train.py:184-185) but must be yielded, with
+    zero rows, when the loader serves one rank of a data-parallel group: every rank has to enter the trainer's
+    step (and its all-reduces) the same number of times."""
+    fx, meta, recs = fixture
+    base = MyDataset(recs, FixtureTokenizer(meta), data_config())
+    items = []
+    for i in range(8):
+        it = dict(base[i % 2])
+        it["rating"] = 3 if i < 4 else 5           # rank 0's first batch (rows 0, 2) holds rating 3 only
+        items.append(it)
+
+    class ListDS(torch.utils.data.Dataset):
+        def __len__(self):
+            return len(items)
+
+        def __getitem__(self, i):
+            return items[i]
+
+    single = list(DeviceLoader(ListDS(), batch_size=4, device="cpu", shuffle=False, stage=1))
+    assert [int(b["rating"].shape[0]) for b in single] == [4]          # the all-rating-3 batch was dropped
+    counts = []
+    for rank in (0, 1):
+        ld = DeviceLoader(ListDS(), batch_size=2, device="cpu", shuffle=False, stage=1, rank=rank, world=2)
+        bs = list(ld)
+        counts.append([int(b["rating"].shape[0]) for b in bs])
+        assert all(tuple(b["img_embs"].shape[1:]) == (5, 2048) and b["targets"].dtype == torch.int64 for b in bs)
+    assert counts == [[0, 2], [0, 2]]                                   # same number of steps on both ranks

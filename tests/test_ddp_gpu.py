@@ -1,0 +1,88 @@
+"""The data-parallel exchange (mmtg_amd.ddp, replacing nn.DataParallel of train.py:112-114) executed over RCCL on the
+GPU.  Each test starts fresh child processes that join the "nccl" process group before any other GPU call."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _launch(mode, world, out, extra_env=None, timeout=600):
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "ddp_worker.py"), mode, out], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            o, _ = p.communicate()
+        logs.append(o)
+    for p, o in zip(procs, logs):
+        assert p.returncode == 0, o[-4000:]
+    return [torch.load(out + ".r%d" % r, weights_only=False) for r in range(world)]
+
+
+def test_forced_ddp_world1_equals_the_plain_trainer(tmp_path):
+    """WORLD_SIZE=1, MMTG_FORCE_DDP=1: the gradient buckets and the row count really go through RCCL all-reduces
+    (counted), and two optimizer steps (curriculum stage 1 filter, dropout on, identical mask seeds) leave the
+    parameters where the non-distributed trainer leaves them.  A SUM over one rank is the identity and both paths
+    run the same kernels in the same order, so every parameter behind a deterministic gradient chain (the GPT-2 block
+    matrices: slab weight gradients) is BIT-equal after the first step; gradients that end in fp32 atomics (LayerNorm
+    columns, embeddings, LM head) differ in summation order between any two runs, bounded here at 1e-6 of the
+    parameter norm after one step and 2e-5 after two."""
+    res = _launch("world1", 1, str(tmp_path / "w1"), {"MMTG_FORCE_DDP": "1"})[0]
+    assert res.get("ok") and res["backend"] == "nccl"
+    for dtype in ("bf16", "f32"):
+        n_all = res["%s_allreduce_elems" % dtype]
+        assert n_all[0] == 1 and len(n_all) >= 5 and sum(n_all[1:]) >= 38185989        # count + every gradient element
+        ddp, plain = res[dtype][True], res[dtype][False]
+        for step, tol in ((0, 1e-6), (1, 2e-5)):
+            a, b = ddp[step][0], plain[step][0]
+            rel = float((a - b).norm() / b.norm())
+            assert rel < tol, (dtype, step, rel)
+            assert abs(ddp[step][1] - plain[step][1]) <= 1e-6 * abs(plain[step][1]), (dtype, step)
+            assert abs(ddp[step][2] - plain[step][2]) <= 1e-4 * abs(plain[step][2]), (dtype, step)
+        if dtype == "bf16":
+            lay = res["bf16_layout"]
+            n = 0
+            for key, (off, numel) in lay.items():
+                if ".h." in key and key.endswith(".weight") and ".ln_" not in key:
+                    assert torch.equal(ddp[0][0][off:off + numel], plain[0][0][off:off + numel]), key
+                    n += 1
+            assert n == 8
+        # the step really moved the parameters
+        assert float((ddp[0][0] - ddp[1][0]).abs().max()) > 1e-4
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
+def test_two_rank_gradient_equals_single_rank_on_the_concatenated_batch(tmp_path):
+    """2 ranks, contiguous row shards of one 16-row batch, stage-1 filter per shard (unequal shards): the all-reduced
+    gradient divided by the all-reduced row count equals the single-process gradient of the whole batch."""
+    res = _launch("shards", 2, str(tmp_path / "w2"))
+    assert all(r.get("ok") for r in res)
+    assert res[0]["count"] == res[1]["count"] == res[0]["count_single"] == res[0]["n_local"] + res[1]["n_local"]
+    for r in res:
+        g, ref = r["grad"], res[0]["grad_single"]
+        assert float((g - ref).norm() / ref.norm()) < 1e-4
+    assert torch.equal(res[0]["grad"], res[1]["grad"])

@@ -78,6 +78,63 @@ def test_load_state_dict_variants_and_roundtrip(tmp_path):
     assert float(third._flat[off + V * D: off + n].abs().max()) == 0.0
 
 
+def test_reference_compatible_checkpoint_loads_strictly_into_the_reference_key_set(tmp_path):
+    """save_checkpoint(reference_compatible=True) against what the reference does with the file (generate.py:191-192):
+    its model is wrapped in nn.DataParallel first and then takes a STRICT load_state_dict.  The skeleton below has the
+    reference's own parameter names and shapes (the fixture's named_parameters() list, produced by running the
+    reference) plus the persistent attn.bias / attn.masked_bias buffers transformers 4.12.3 registers per block."""
+    from mmtg_amd.trainer import load_checkpoint, save_checkpoint
+    fx, meta, mcfg, gcfg, dcfg, weights, table, batch = load_case("tiny_s5")
+    model = MMTG(mcfg, dcfg, meta["V"], gpt2_config=gcfg)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})
+
+    class Skel(torch.nn.Module):
+        pass
+
+    def attach(root, dotted, t, buffer=False):
+        mod = root
+        parts = dotted.split(".")
+        for name in parts[:-1]:
+            if name not in mod._modules:
+                mod.add_module(name, Skel())
+            mod = mod._modules[name]
+        if buffer:
+            mod.register_buffer(parts[-1], t)
+        else:
+            mod.register_parameter(parts[-1], t)
+
+    skel = Skel()
+    params = {}
+    for k in (str(k) for k in fx["grad_keys"]):
+        params[k] = torch.nn.Parameter(torch.zeros(weights[k].shape))
+        attach(skel, k, params[k])
+    attach(skel, "decoder.gpt2.lm_head.weight", params["decoder.gpt2.transformer.wte.weight"])      # tied
+    NP = gcfg["n_positions"]
+    for l in range(gcfg["n_layer"]):
+        attach(skel, "decoder.gpt2.transformer.h.%d.attn.bias" % l, torch.zeros(1, 1, NP, NP, dtype=torch.uint8), buffer=True)
+        attach(skel, "decoder.gpt2.transformer.h.%d.attn.masked_bias" % l, torch.tensor(0.0), buffer=True)
+    wrapped = torch.nn.DataParallel(skel)
+    path = tmp_path / "ref_compat.pth"
+    save_checkpoint(path, model, args={"lr": 1e-5}, model_cfgs=mcfg, reference_compatible=True)
+    ckpt = torch.load(path, map_location="cpu", weights_only=False)
+    assert set(ckpt) >= {"model", "args", "model_cfgs"}
+    res = wrapped.load_state_dict(ckpt["model"], strict=True)          # raises on any missing / unexpected key
+    assert not res.missing_keys and not res.unexpected_keys
+    for k, p in params.items():
+        assert torch.equal(p.detach(), torch.from_numpy(weights[k])), k
+    b = skel.decoder.gpt2.transformer.h._modules["0"].attn.bias
+    assert b.dtype == torch.uint8 and bool(b[0, 0, 5, 5]) and not bool(b[0, 0, 5, 6])
+    # the plain file is NOT loadable there (the claim is made only for reference_compatible=True) ...
+    save_checkpoint(tmp_path / "plain.pth", model)
+    with pytest.raises(RuntimeError):
+        wrapped.load_state_dict(torch.load(tmp_path / "plain.pth", weights_only=False)["model"], strict=True)
+    # ... and both files load back here
+    for f in ("ref_compat.pth", "plain.pth"):
+        other = MMTG(mcfg, dcfg, meta["V"], gpt2_config=gcfg)
+        load_checkpoint(tmp_path / f, other)
+        assert all(torch.equal(other.state_dict()[k], model.state_dict()[k]) for k in model.state_dict())
+
+
 def test_parameters_are_views_of_one_flat_buffer():
     model, _, _ = tiny_model()
     base = model._flat.data_ptr()
@@ -105,7 +162,7 @@ def test_c_abi_exports_every_declared_symbol():
     lib = ctypes.CDLL(hip.lib_path())
     for name in declared:
         assert hasattr(lib, name), name
-    assert hip.lib().mmtg_abi_version() == 1
+    assert hip.lib().mmtg_abi_version() == hip.ABI_VERSION == 2
 
 
 def test_product_never_imports_the_oracle():
@@ -152,8 +209,10 @@ def _ddp_worker(rank, world, port, outdir):
             red.on_pack_ready(grad, pk)
             launched.append(red.next_bucket)
         assert launched == sorted(launched) and launched[0] <= 1 and launched[-1] >= len(red.buckets) - 1
+        cnt = torch.tensor([3.0 + rank])
+        red.start_count(cnt)            # the row count rides with the buckets (no host-side exchange of its own)
         red.finish(grad)
-        n = red.global_count(3 + rank, "cpu")
+        n = int(cnt.item())
         torch.save((rank, mine, grad, len(red.buckets), n, launched), os.path.join(outdir, 'r%d.pt' % rank))
     finally:
         dist.destroy_process_group()

@@ -86,6 +86,46 @@ def test_full_shape_spot_checks():
         assert abs(got - float(fx[f"myloss_stage{stage}"])) < 1e-4 * max(1, abs(float(fx[f"myloss_stage{stage}"])))
 
 
+def test_full_shape_gradients_and_greedy_calls():
+    """Full depth (12 layers, V = 13317): the oracle's backward against the reference's sampled gradients / norms,
+    and the oracle's logits at every call of the reference's 220-position greedy run (one causal forward over the
+    reference's own sequence) against the stored raw top-8 values and chosen ids."""
+    fx, meta, sh, w, table, batch = _setup("full_12l", requires_grad=True)
+    hp = json.loads(str(fx["train_hparams"]))
+    state = {}
+    total, loss, kl, gn = O.train_step(w, sh, table, batch, batch["rating"], hp["stage"], hp["alpha"], hp["lr"], 1, state, hp["clip"])
+    assert abs(total.item() - float(fx["train_total_loss"])) < 2e-5 * abs(float(fx["train_total_loss"]))
+    ref_gn = float(fx["grad_total_norm"])
+    assert abs(gn.item() - ref_gn) < 2e-4 * ref_gn
+    for k in (str(k) for k in fx["grad_keys"]):
+        if k == "decoder.gpt2.lm_head.weight":
+            continue
+        g = sample_like_fixture(w[k].grad.numpy(), fx["gidx_" + k])
+        scale = max(float(np.abs(fx["gval_" + k]).max()), float(fx["gnorm_" + k]) / ref_gn / np.sqrt(w[k].numel()), 1e-7)
+        assert float(np.abs(g - fx["gval_" + k]).max()) < 2e-3 * scale, k
+    # greedy calls
+    fx, meta, sh, w, table, batch = _setup("full_12l")
+    ids = fx["greedy_len220_row0"].tolist()
+    inp = {k: v[:1] for k, v in batch.items() if k != "rating"}
+    inp["targets"] = torch.tensor(ids).view(1, -1)
+    with torch.no_grad():
+        lg = O.mmtg_forward(w, sh, table, inp, train_flag=False)[2][0]
+    calls = [i for i in range(220) if not (i > 0 and (i + 2) % 22 in (0, 1))]
+    t8, v8 = fx["greedy_len220_row0_top8"], fx["greedy_len220_row0_top8_val"]
+    chosen, margin = fx["greedy_len220_row0_chosen"], fx["greedy_len220_row0_margin"]
+    n = 0
+    for c, i in enumerate(calls):
+        if i >= len(ids):
+            break
+        row = lg[sh.P + i]
+        np.testing.assert_allclose(row[t8[c].astype(np.int64)].numpy(), v8[c], atol=5e-4, rtol=0)
+        if ids[i] != 0 and margin[c] > 2e-3:
+            pl = O.process_logits(row, torch.tensor(ids[:i + 1]), 1.1, 1.5)
+            assert int(torch.argmax(pl)) == int(chosen[c]), c
+            n += 1
+    assert n > 150
+
+
 def test_filtering_kats():
     fx = np.load(__import__("os").path.join(__import__("helpers").GOLDEN, "filtering.npz"))
     for i in range(fx["in"].shape[0]):

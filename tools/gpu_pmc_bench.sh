@@ -7,10 +7,12 @@ mkdir -p gpurun_out/pmc_bench
 export TMPDIR=/tmp
 R=$(pwd)
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc_bench -o $c -- python3 bench.py --steps 2 --warmup 1 --no-roofline --no-cpu-baseline > gpurun_out/pmc_bench/$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc_bench -o $c -- python3 bench.py --steps 2 --warmup 1 --no-roofline --no-cpu-baseline --no-decode --no-check > gpurun_out/pmc_bench/$c.log 2>&1
 done
 python3 - <<'PY'
-import csv, glob, json
+import csv, glob, json, sys
+sys.path.insert(0, ".")
+from mmtg_amd import hip
 out = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = glob.glob("gpurun_out/pmc_bench/%s_counter_collection.csv" % c)
@@ -24,6 +26,7 @@ n = out["FETCH_SIZE"][0]
 read_b = out["FETCH_SIZE"][1] * 1024 * 2 / max(n, 1)      # KB units, x2 gfx950 correction
 write_b = out["WRITE_SIZE"][1] * 1024 / max(out["WRITE_SIZE"][0], 1)
 res = {"kernel": "gemm_occ4_kernel / gemm_dma_kernel <bf16> (all instantiations)", "launches_counted": n,
+       "kernel_source_sha": hip.source_sha(),
        "hbm_read_bytes_per_launch": round(read_b), "hbm_write_bytes_per_launch": round(write_b),
        "hbm_bytes_per_launch": round(read_b + write_b),
        "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over python3 bench.py --steps 2 --warmup 1; KB units; reads x2 (gfx950 FETCH_SIZE counts 128-B requests at 64 B)"}

@@ -141,8 +141,36 @@ def adamw_hf_step(params, lr, step, state, betas=(0.9, 0.999), eps=1e-6, wd=0.0)
             p.data.add_(p.data, alpha=-lr * wd)
 
 
+def greedy_margins(raw, temperature, penalty, length, sent_slot=22):
+    """Replay of the reference's logits processing (generate.py:127-136, restated in the oracle's process_logits,
+    itself pinned by the id lists) over the raw logits the reference produced per call: for every call the top-2 margin of
+    the processed logits (what a reduced-precision path must resolve to pick the same token) and the chosen id."""
+    from oracle import mmtg_oracle as O
+    targets = [1]
+    margins, chosen, j = [], [], 0
+    for i in range(length):
+        if i > 0 and (i + 2) % sent_slot == 0:
+            targets.append(2)
+            continue
+        if i > 0 and (i + 2) % sent_slot == 1:
+            targets.append(1)
+            continue
+        pl = O.process_logits(torch.from_numpy(raw[j]), torch.tensor(targets), temperature, penalty)[:13317]
+        j += 1
+        if targets[-1] == 0:
+            nxt, mg = 0, np.inf
+        else:
+            top = torch.topk(pl, 2).values
+            nxt, mg = int(torch.argmax(pl)), float(top[0] - top[1])
+        margins.append(mg)
+        chosen.append(nxt)
+        targets.append(nxt)
+    assert j == len(raw)
+    return np.asarray(margins, np.float32), np.asarray(chosen, np.int64), targets
+
+
 def case_model(name, out_dir, S, n_layer, V, B, seed, full_logits=True,
-               with_grads=True, with_decode=True):
+               with_grads=True, with_decode=True, decode_rows=(0, 1), store_rawlogits=True):
     mcfg = make_model_cfgs(seq_len=S)
     gcfg = gpt2_config(n_layer=n_layer, vocab_size=V, n_positions=256 if n_layer <= 2 else 1024,
                        embd_pdrop=0.0, attn_pdrop=0.0, resid_pdrop=0.0)
@@ -268,7 +296,7 @@ def case_model(name, out_dir, S, n_layer, V, B, seed, full_logits=True,
         model.forward = rec_forward
         keys = [k for k in batch_np if k != "rating"]
         for length in (30, 220 if S == 5 else 2 * S * 22):
-            for row in (0, 1):
+            for row in decode_rows:
                 rec.clear()
                 start = {k: np.asarray(batch_np[k][row]) for k in keys}
                 start["targets"] = np.asarray([1])
@@ -276,7 +304,19 @@ def case_model(name, out_dir, S, n_layer, V, B, seed, full_logits=True,
                     model, start, length, StubTokenizer(), temperature=1.1,
                     top_k=1, top_p=0.0, repitition_penalty=1.5, device="cpu")
                 fx[f"greedy_len{length}_row{row}"] = np.asarray(ids, np.int64)
-                fx[f"greedy_len{length}_row{row}_rawlogits"] = np.stack(rec).astype(np.float32)
+                raw = np.stack(rec).astype(np.float32)
+                if store_rawlogits:
+                    fx[f"greedy_len{length}_row{row}_rawlogits"] = raw
+                else:
+                    # V = 13317: keep the per-call top-2 margin of the processed logits, the chosen ids and the raw
+                    # top-8 (ids, values) instead of 12 MB of logits
+                    mg, ch, seq = greedy_margins(raw, 1.1, 1.5, length)
+                    assert seq[:len(ids)] == list(ids), "replayed processing disagrees with the reference's ids"
+                    fx[f"greedy_len{length}_row{row}_margin"] = mg
+                    fx[f"greedy_len{length}_row{row}_chosen"] = ch
+                    t8 = np.argsort(-raw, axis=-1)[:, :8]
+                    fx[f"greedy_len{length}_row{row}_top8"] = t8.astype(np.int32)
+                    fx[f"greedy_len{length}_row{row}_top8_val"] = np.take_along_axis(raw, t8, -1)
         model.forward = orig_forward
         fx["decode_params"] = json.dumps({"temperature": 1.1, "top_k": 1, "top_p": 0.0,
                                           "repitition_penalty": 1.5})
@@ -383,8 +423,10 @@ def main():
     case_filtering(out_dir, gen)
     case_model("tiny_s2", out_dir, S=2, n_layer=2, V=160, B=4, seed=200, with_decode=False)
     if not args.skip_full:
+        # (full size: sampled logits + top-5 + LSE, sampled gradients / gradient norms / parameters after one step,
+        #  and one greedy sample_sequence run of 30 and of 220 positions with its per-call top-2 margins)
         case_model("full_12l", out_dir, S=5, n_layer=12, V=13317, B=2, seed=300,
-                   full_logits=False, with_grads=False, with_decode=False)
+                   full_logits=False, with_grads=True, with_decode=True, decode_rows=(0,), store_rawlogits=False)
 
 
 if __name__ == "__main__":
