@@ -259,7 +259,25 @@ def _pmc_traffic(kernel_sha):
     return None, None
 
 
+_JSON_FD = None
+
+
+def _claim_stdout():
+    """Keep file descriptor 1 for the ONE JSON line: everything else that writes to stdout (RCCL prints its library
+    path there from C, after Python's own buffers are gone) is sent to stderr."""
+    global _JSON_FD
+    if _JSON_FD is None:
+        sys.stdout.flush()
+        _JSON_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def _emit(obj):
+    os.write(_JSON_FD if _JSON_FD is not None else 1, (json.dumps(obj) + "\n").encode())
+
+
 def main():
+    _claim_stdout()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -302,7 +320,7 @@ def main():
     if args.mode == "decode":
         out = bench_decode(args, world, rank, dev, args.steps, args.warmup)
         if rank == 0 and out is not None:
-            print(json.dumps(out))
+            _emit(out)
         if dist.is_initialized():
             dist.destroy_process_group()
         return
@@ -439,7 +457,7 @@ def main():
         }
         if decode is not None:
             out["decode"] = decode
-        print(json.dumps(out))
+        _emit(out)
     if dist.is_initialized():
         dist.destroy_process_group()
 

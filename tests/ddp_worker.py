@@ -83,6 +83,7 @@ def main():
                         flats[distributed].append((model._flat.detach().cpu().clone(), float(o["loss"]), float(tr.grad_norm())))
                 res[dtype] = flats
                 res["%s_launched" % dtype] = launched
+                res["layout_total"] = models[0][0].layout.total
                 res["%s_layout" % dtype] = {k: models[0][0].layout.entries[k][:1] + (models[0][0].layout.entries[k][2],)
                                             for k in models[0][0].layout.entries}
         elif mode == "shards":

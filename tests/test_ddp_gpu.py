@@ -50,14 +50,14 @@ def test_forced_ddp_world1_equals_the_plain_trainer(tmp_path):
     run the same kernels in the same order, so every parameter behind a deterministic gradient chain (the GPT-2 block
     matrices: slab weight gradients) is BIT-equal after the first step; gradients that end in fp32 atomics (LayerNorm
     columns, embeddings, LM head) differ in summation order between any two runs, bounded here at 1e-6 of the
-    parameter norm after one step and 2e-5 after two."""
+    parameter norm after one step and 2e-5 (f32) / 1e-4 (bf16: weight copies re-rounded) after two."""
     res = _launch("world1", 1, str(tmp_path / "w1"), {"MMTG_FORCE_DDP": "1"})[0]
     assert res.get("ok") and res["backend"] == "nccl"
     for dtype in ("bf16", "f32"):
         n_all = res["%s_allreduce_elems" % dtype]
-        assert n_all[0] == 1 and len(n_all) >= 5 and sum(n_all[1:]) >= 38185989        # count + every gradient element
+        assert n_all[0] == 1 and len(n_all) >= 5 and sum(n_all[1:]) == res["layout_total"]      # count + every gradient element
         ddp, plain = res[dtype][True], res[dtype][False]
-        for step, tol in ((0, 1e-6), (1, 2e-5)):
+        for step, tol in ((0, 1e-6), (1, 1e-4 if dtype == "bf16" else 2e-5)):
             a, b = ddp[step][0], plain[step][0]
             rel = float((a - b).norm() / b.norm())
             assert rel < tol, (dtype, step, rel)
