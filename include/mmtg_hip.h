@@ -147,6 +147,9 @@ int mmtg_attn_fwd(int dtype, const void* qkv, const int* keep, void* out, float*
  * c_attn bias gradient, from the workgroups that produce each head's columns); dbias_ws (optional
  * scratch, f32 [B * ceil(T / key block)][3*D], key block = 256 bf16 / 128 f32): partial rows that the
  * call sums into dbias -- without it the workgroups use atomics on dbias (slower: contended).       */
+/* diagnostic: per-wave timeline of the whole-head forward kernel (bf16, T <= 256): buf = u64 [B*nH*8][8]
+ * (s_memrealtime at entry / loads issued / first chunk landed / long tile done / stored / exit, XCC id, valid) or NULL */
+int mmtg_attn_trace(void* buf);
 int mmtg_attn_bwd(int dtype, const void* qkv, const int* keep, const void* out, const void* dout,
                   const float* lse, float* delta, int delta_ready, float* dq32, void* dqkv, float* dbias, float* dbias_ws,
                   int B, int T, int nH, int dh, unsigned drop_thresh, unsigned drop_seed, void* stream);

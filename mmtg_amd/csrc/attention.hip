@@ -514,6 +514,650 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(const T* __restrict__
     }
 }
 
+
+// ======================================================================== whole-head kernels (bf16, T <= 256)
+// One workgroup holds ALL keys of one (batch, head) in LDS -- 256 rows x 128 B per operand image, two images =
+// 64 KB, two workgroups per CU -- so K / V (forward, dQ) or Q / dO (dK, dV) are staged ONCE per head instead of
+// once per 64-query block (the tiled kernel above re-stages a head's K/V tiles 1+2+3+4 times at T = 236), and no
+// wave ever waits for another's arithmetic: every wave owns whole 16-row tiles of the output and walks the causal
+// range of the other operand on its own.  Work is balanced by giving wave w the tiles w and ntile-1-w (their
+// causal ranges add up to the same length for every w).
+//
+// Staging is streamed: the images arrive by LDS-DMA (buffer_load ... lds: global -> LDS, no register round trip,
+// 1 KB = 8 rows per wave-instruction) in four chunks of 64 rows, all requested up front; chunk c is readable after
+// a counted s_waitcnt + one workgroup barrier and the later chunks keep flying under the arithmetic on the earlier
+// ones.  The LDS side of an LDS-DMA is lane-linear, so the image's swizzle is applied to the lane's SOURCE chunk
+// (same 128-byte row segment, coalescing unchanged); rows beyond the tensor fall outside the buffer descriptor
+// and read as zero.  The per-row scalars (key-padding flags, LSE, delta) come the same way, 4 bytes per lane.
+// The number of DMA requests per wave is a compile-time constant, so the waits the compiler adds for the few
+// plain loads (this wave's register-resident fragments) are counted ones, not vmcnt(0).
+//
+// All images use ONE swizzle, chunk ^ vswz(row), which is bank-conflict free both for the ds_read_b128 row reads
+// of a 16x16x32 operand and for the ds_read_b64_tr_b16 column reads (16-lane groups / 32-lane halves checked
+// exhaustively for 128-byte rows), so a tile that is consumed both ways (K in dQ; Q and dO in dK / dV) is stored
+// once.
+//
+// Backward = two kernels, both without any cross-wave traffic:
+//   dK, dV:  Q and dO of the head in LDS; a wave keeps K / V fragments of its 16 keys and the dK^T / dV^T
+//            accumulators in registers and sweeps the 32-query blocks at or below the diagonal;
+//   dQ:      K and V in LDS; a wave keeps Q / dO fragments of its 16 queries and dQ^T in registers and sweeps the
+//            32-key blocks up to the diagonal.
+// S and dP are computed by both (7 products instead of 5): the matrix pipe has the time -- the element-wise part
+// (exp, dropout hash, masks) bounds these kernels -- and in exchange dS never crosses LDS and the three barriers per
+// query tile of the tiled kernel are gone.
+//
+// Dropout: every workgroup first builds the head's T x T keep-bit matrix in LDS (8 KB: one 32-bit word per query row
+// and 32 keys) and the element-wise code only tests bits (a sign-extending bit-field extract and an AND on the float's
+// bits; the 1 / (1 - p) scale is folded into the tile's final normalisation or into a constant of the dS formula).
+// A word is made by the bitwise Bernoulli construction: 12 xorshift32 steps from one counter hash of (seed, b, h, row,
+// word), combined LSB-first by OR / AND according to the 12 binary digits of the keep probability, so each bit is 1 with
+// probability round((1 - p) 2^12) / 2^12 -- about 2 vector instructions per decision instead of a 32-bit hash each,
+// and the three kernels (forward, dK/dV, dQ) rebuild identical matrices.  (The tiled kernels hash per element; a model
+// uses one family throughout.)
+constexpr int SM_MAXT = 256;
+constexpr float LOG2E = 1.4426950408889634f;
+
+__device__ __forceinline__ bf16x8 ld_row(const char* img, int row, int ks, int g) {
+    return *reinterpret_cast<const bf16x8*>(img + off_ks<bf16>(row, ks * 4 + g));
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rows_rsrc(const bf16* p, long ld_elems, int nrows) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p), 0, (int)(((long)(nrows - 1) * ld_elems + DH) * 2), 0x00020000);
+}
+// One chunk (64 rows) of both images = two requests per wave.  Chunk indices beyond the tensor's last chunk re-target
+// an existing chunk (same source, same destination -- harmless), so the number of requests is a compile-time constant
+// and the compiler's own waits for the few plain loads stay counted ones.
+__device__ __forceinline__ void dma_issue_chunk(char* imgA, __amdgpu_buffer_rsrc_t ra, long lda, char* imgB, __amdgpu_buffer_rsrc_t rb,
+                                                long ldb, int c4, int nchunk, int wave, int lane) {
+    const int c = c4 < nchunk ? c4 : c4 % nchunk;
+    const int blk = 8 * c + wave, row = blk * 8 + (lane >> 3);
+    const int ch = (lane & 7) ^ vswz(row);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, LDS_PTR(void, imgA + blk * 1024), 16, (int)(((long)row * lda + ch * 8) * 2), 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, LDS_PTR(void, imgB + blk * 1024), 16, (int)(((long)row * ldb + ch * 8) * 2), 0, 0, 0);
+}
+// 256 dwords (one per row), element i at src[i * stride]; wave w brings rows 64 (w & 3) .. (waves 4-7 repeat 0-3)
+__device__ __forceinline__ void dma_issue_scalars(void* dst, const void* src, int stride, int nvalid, int wave, int lane) {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(src), 0, (int)(((long)(nvalid - 1) * stride + 1) * 4), 0x00020000);
+    const int i = 64 * (wave & 3) + lane;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, LDS_PTR(void, (char*)dst + 256 * (wave & 3)), 4, i * stride * 4, 0, 0, 0);
+}
+// Streaming schedule shared by the three kernels: chunks 0 and 1 are requested in the prologue, chunk c + 2 right
+// after the barrier that publishes chunk c.  Before that barrier a wave waits until only its two youngest requests
+// (chunk c + 1) are outstanding -- or none, for the last of the four.
+__device__ __forceinline__ void dma_wait_chunk(int c) {
+    if (c < 3) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+// workgroup barrier WITHOUT the release fence of __syncthreads(): the fence would drain every outstanding LDS-DMA
+// request (vmcnt(0)) and serialise the streamed chunks; LDS stores of this wave are drained explicitly
+__device__ __forceinline__ void raw_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// keep-bit matrix of one head: sMask[row * 8 + w] bit j <-> (query row, key 32 w + j); bit = 1 keeps the element.
+// Only words at or below the diagonal of rows < Tn are ever read (a word is one work item: compacted index i ->
+// row-major enumeration of the pairs (row, w <= row / 32), 4 x 32 rows + 8 ... per 32-row band).
+constexpr int MASK_BITS = 12;          // keep probability in units of 2^-12
+__device__ __forceinline__ void gen_keep_mask(uint32_t* sMask, uint32_t bh, int Tn, uint32_t seed, uint32_t keepq, int tid) {
+    // band k (rows 32 k .. 32 k + 31) has k + 1 words per row: items before band k = 32 * k (k + 1) / 2
+    const int nband = (Tn + 31) >> 5, total = 16 * nband * (nband + 1);
+#pragma unroll 1
+    for (int i = tid; i < total; i += 512) {
+        int k = 0;
+        while (16 * (k + 1) * (k + 2) <= i) ++k;             // at most 8 steps
+        const int j = i - 16 * k * (k + 1), row = 32 * k + j / (k + 1), w = j % (k + 1);
+        uint32_t x = hash_u32(seed, (bh * (uint32_t)Tn + (uint32_t)row) * 8u + (uint32_t)w) | 1u;
+        uint32_t acc = 0;
+#pragma unroll
+        for (int bit = 0; bit < MASK_BITS; ++bit) {
+            x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+            acc = ((keepq >> bit) & 1u) ? (acc | x) : (acc & x);
+        }
+        sMask[row * 8 + w] = acc;
+    }
+}
+// float p kept (bit 1) or zeroed (bit 0); `w` holds the bit at position `pos`
+__device__ __forceinline__ float mask_keep(float p, uint32_t w, int pos) {
+    const int m = __builtin_amdgcn_sbfe(w, pos, 1);        // 0 or -1
+    return __builtin_bit_cast(float, __builtin_bit_cast(int, p) & m);
+}
+
+// ---- forward: running state of one 16-query tile, advanced by one 64-key chunk at a time
+struct FwdTile {
+    f32x4 o[4];
+    float m, l;       // running maximum (in log2 units: s * log2 e) and sum
+};
+
+template <bool DROP>
+__device__ __forceinline__ void fwd_small_chunk(FwdTile& st, const char* sK, const char* sV, const float* sBias, const uint32_t* sMask,
+                                                const bf16x8 (&qf)[2], int t, int j0, int lane) {
+    const int g = lane >> 4, l15 = lane & 15;
+    const int qi = 16 * t + l15, qlast = 16 * t + 15;
+    f32x4 s_acc[4];
+    float mloc = -INFINITY;
+    // per 16-key tile: S^T = K Q^T, then the masks -- key padding as an additive 0 / -inf per key (one 16-byte LDS
+    // read per four keys), the causal comparison only where the tile touches the diagonal; tiles wholly above the
+    // diagonal (wave-uniform) are skipped altogether
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+        s_acc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (j0 + 16 * kt <= qlast) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) mma16(ld_row(sK, j0 + kt * 16 + l15, ks, g), qf[ks], s_acc[kt]);
+            const int k0 = j0 + kt * 16 + 4 * g;
+            const f32x4 kb = *reinterpret_cast<const f32x4*>(sBias + k0);
+            if (j0 + 16 * kt + 15 > 16 * t) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s_acc[kt][r] = (k0 + r <= qi) ? s_acc[kt][r] * LOG2E + kb[r] : -INFINITY;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s_acc[kt][r] = s_acc[kt][r] * LOG2E + kb[r];
+            }
+            mloc = fmaxf(mloc, fmaxf(fmaxf(s_acc[kt][0], s_acc[kt][1]), fmaxf(s_acc[kt][2], s_acc[kt][3])));
+        }
+    }
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    const float m_new = fmaxf(st.m, mloc);
+    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = __builtin_amdgcn_exp2f(st.m - m_use);          // st.m = -inf -> 0
+    float rs = 0.f;
+    uint32_t w0 = 0, w1 = 0;
+    if constexpr (DROP) {       // this query row's keep bits of the chunk's 64 keys, pre-shifted to the lane's 4 g
+        const u32x2 w = *reinterpret_cast<const u32x2*>(sMask + qi * 8 + (j0 >> 5));
+        w0 = w[0] >> (4 * g);
+        w1 = w[1] >> (4 * g);
+    }
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+        if (j0 + 16 * kt <= qlast) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float p = __builtin_amdgcn_exp2f(s_acc[kt][r] - m_use);   // masked: exp2(-inf) = 0
+                rs += p;
+                if constexpr (DROP) p = mask_keep(p, kt < 2 ? w0 : w1, 16 * (kt & 1) + r);
+                s_acc[kt][r] = p;
+            }
+        }
+    }
+    rs += __shfl_xor(rs, 16, 64);
+    rs += __shfl_xor(rs, 32, 64);
+    st.l = st.l * alpha + rs;
+    st.m = m_new;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        st.o[dt][0] *= alpha; st.o[dt][1] *= alpha; st.o[dt][2] *= alpha; st.o[dt][3] *= alpha;
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        if (j0 + 32 * s2 <= qlast) {
+            const bf16x8 pb = acc_as_operand(s_acc[2 * s2], s_acc[2 * s2 + 1], bf16());
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                mma16(ld_ks(sV, j0 + 32 * s2 + 4 * g, j0 + 32 * s2 + 16 + 4 * g, dt * 16, lane, bf16()), pb, st.o[dt]);
+        }
+    }
+}
+
+__device__ __forceinline__ void fwd_small_store(const FwdTile& st, int t, int lane, int b, int h, int Tn, int nH, float inv_keep,
+                                                bf16* __restrict__ out, float* __restrict__ lse) {
+    const int g = lane >> 4, l15 = lane & 15, qi = 16 * t + l15, D = nH * DH;
+    if (qi < Tn) {
+        const float inv = st.l > 0.f ? inv_keep / st.l : 0.f;          // dropout's 1 / (1 - p) rides on the normalisation
+        bf16* dst = out + ((long)b * Tn + qi) * D + h * DH;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            bf16x4 o = {(bf16)(st.o[dt][0] * inv), (bf16)(st.o[dt][1] * inv), (bf16)(st.o[dt][2] * inv), (bf16)(st.o[dt][3] * inv)};
+            *reinterpret_cast<bf16x4*>(dst + dt * 16 + 4 * g) = o;
+        }
+        if (g == 0) lse[((long)b * nH + h) * Tn + qi] = st.l > 0.f ? st.m * (1.0f / LOG2E) + logf(st.l) : -INFINITY;
+    }
+}
+
+template <bool DROP>
+__global__ __launch_bounds__(512, 4) void attn_fwd_small_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keep,
+        bf16* __restrict__ out, float* __restrict__ lse, int Tn, int nH,
+        uint32_t keep16, uint32_t drop_seed, float inv_keep, unsigned long long* __restrict__ trace) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long ts[6] = {0, 0, 0, 0, 0, 0};
+    if (trace) ts[0] = __builtin_amdgcn_s_memrealtime();
+    const int nchunk = (Tn + 63) >> 6, rows_pad = nchunk << 6;
+    char* sK = smem;
+    char* sV = sK + rows_pad * 128;
+    int* sKeep = reinterpret_cast<int*>(sV + rows_pad * 128);            // [256] flags
+    float* sBias = reinterpret_cast<float*>(sKeep + 256);               // [256] 0 / -inf
+    uint32_t* sMask = reinterpret_cast<uint32_t*>(sBias + 256 + 256);   // [256][8] keep bits (after one spare [256])
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = blockIdx.x % nH, b = blockIdx.x / nH;
+    const int D = nH * DH;
+    const long ld = 3L * D;
+    const bf16* base = qkv + (long)b * Tn * ld + h * DH;
+    const int ntile = (Tn + 15) >> 4, npair = (ntile + 1) >> 1;
+    const int tA = wave, tB = ntile - 1 - wave;          // tB >= tA for wave < npair
+    const bool work = wave < npair;
+    // this wave's query fragments (B operand of S^T = K Q^T): plain loads, issued first
+    bf16x8 qfA[2], qfB[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        qfA[ks] = zero16<bf16>();
+        qfB[ks] = zero16<bf16>();
+        if (work) {
+            const int qa = 16 * tA + l15, qb = 16 * tB + l15;
+            if (qa < Tn) qfA[ks] = *reinterpret_cast<const bf16x8*>(base + (long)qa * ld + ks * 32 + g * 8);
+            if (qb < Tn) qfB[ks] = *reinterpret_cast<const bf16x8*>(base + (long)qb * ld + ks * 32 + g * 8);
+        }
+    }
+    const __amdgpu_buffer_rsrc_t rk = rows_rsrc(base + D, ld, Tn), rv = rows_rsrc(base + 2 * D, ld, Tn);
+    dma_issue_scalars(sKeep, keep + (long)b * Tn, 1, Tn, wave, lane);
+    dma_issue_chunk(sK, rk, ld, sV, rv, ld, 0, nchunk, wave, lane);
+    dma_issue_chunk(sK, rk, ld, sV, rv, ld, 1, nchunk, wave, lane);
+    if (trace) ts[1] = __builtin_amdgcn_s_memrealtime();
+    if constexpr (DROP) gen_keep_mask(sMask, (uint32_t)(b * nH + h), Tn, drop_seed, keep16, tid);
+    // 1/sqrt(64) pre-scale of the queries (exact in bf16); also the first use of the plain loads (a counted wait here)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            qfA[ks][e] = (bf16)((float)qfA[ks][e] * 0.125f);
+            qfB[ks][e] = (bf16)((float)qfB[ks][e] * 0.125f);
+        }
+    FwdTile st;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) st.o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    st.m = -INFINITY;
+    st.l = 0.f;
+    // the longer tile (B) consumes the key chunks as they land; the shorter one (A) runs afterwards on resident data
+#pragma unroll 1
+    for (int jb = 0; jb < nchunk; ++jb) {
+        dma_wait_chunk(jb);
+        raw_barrier();
+        if (jb < 2) dma_issue_chunk(sK, rk, ld, sV, rv, ld, jb + 2, nchunk, wave, lane);
+        if (jb == 0) {
+            if (tid < 256) sBias[tid] = sKeep[tid] != 0 ? 0.f : -INFINITY;       // key-padding flags -> additive bias
+            raw_barrier();
+            if (trace) ts[2] = __builtin_amdgcn_s_memrealtime();
+        }
+        const int j0 = jb * 64;
+        if (work && j0 <= 16 * tB + 15) fwd_small_chunk<DROP>(st, sK, sV, sBias, sMask, qfB, tB, j0, lane);
+    }
+    if (trace) ts[3] = __builtin_amdgcn_s_memrealtime();
+    if (work) fwd_small_store(st, tB, lane, b, h, Tn, nH, inv_keep, out, lse);
+    if (trace) ts[4] = __builtin_amdgcn_s_memrealtime();
+    if (work && tA != tB) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) st.o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        st.m = -INFINITY;
+        st.l = 0.f;
+#pragma unroll 1
+        for (int j0 = 0; j0 <= 16 * tA + 15; j0 += 64) fwd_small_chunk<DROP>(st, sK, sV, sBias, sMask, qfA, tA, j0, lane);
+        fwd_small_store(st, tA, lane, b, h, Tn, nH, inv_keep, out, lse);
+    }
+    if (trace && lane == 0) {
+        ts[5] = __builtin_amdgcn_s_memrealtime();
+        unsigned long long* r = trace + ((long)blockIdx.x * 8 + wave) * 8;
+        r[0] = ts[0]; r[1] = ts[1]; r[2] = ts[2]; r[3] = ts[3]; r[4] = ts[4]; r[5] = ts[5];
+        r[6] = __builtin_amdgcn_s_getreg((4 << 11) | 20);    // XCC_ID
+        r[7] = 1;
+    }
+}
+
+// ---- backward, dK / dV kernel: the 16 keys of tile t (K, V fragments in registers), one 32-query block
+struct BwdKeys {
+    f32x4 dk[4], dv[4];
+};
+template <bool DROP>
+__device__ __forceinline__ void bwd_small_keys_block(BwdKeys& st, const char* sQ, const char* sO, const float* sLse, const float* sDel,
+                                                     const uint32_t* sMask, const bf16x8 (&kf)[2], const bf16x8 (&vf)[2],
+                                                     int t, int q0, int lane, float ik_scale) {
+    const int g = lane >> 4, l15 = lane & 15;
+    const int key = 16 * t + l15;
+    const float c1 = 0.125f * LOG2E;
+    f32x4 pT[2], dsT[2];
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs) {
+        pT[qs] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dsT[qs] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (q0 + 16 * qs + 15 >= 16 * t) {          // wave-uniform: a query sub-block wholly above the diagonal contributes nothing
+            f32x4 s_acc = {0.f, 0.f, 0.f, 0.f}, dp_acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                mma16(ld_row(sQ, q0 + qs * 16 + l15, ks, g), kf[ks], s_acc);
+                mma16(ld_row(sO, q0 + qs * 16 + l15, ks, g), vf[ks], dp_acc);
+            }
+            const int qr = q0 + qs * 16 + 4 * g;
+            const f32x4 l4 = *reinterpret_cast<const f32x4*>(sLse + qr);       // LSE * log2 e per query row
+            const f32x4 d4 = *reinterpret_cast<const f32x4*>(sDel + qr);       // delta / sqrt(64)
+            const bool diag = q0 + 16 * qs < 16 * t + 15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float x = s_acc[r] * c1 - l4[r];            // (a padded key's column is zeroed at the store, not here)
+                if (diag) x = key <= qr + r ? x : -INFINITY;
+                const float p = __builtin_amdgcn_exp2f(x);
+                float dp = dp_acc[r];
+                if constexpr (DROP) {
+                    const uint32_t w = sMask[(qr + r) * 8 + (key >> 5)];
+                    dp = mask_keep(dp, w, key & 31);
+                    pT[qs][r] = mask_keep(p, w, key & 31);                     // (x 1/(1-p) at the end, on dV)
+                } else {
+                    pT[qs][r] = p;
+                }
+                dsT[qs][r] = p * (dp * ik_scale - d4[r]);                      // ik_scale = (1/(1-p)) / sqrt(64)
+            }
+        }
+    }
+    // dV^T[d][key] += dO^T[d][q] P[q][key] ;  dK^T[d][key] += Q^T[d][q] dS[q][key]
+    const bf16x8 pb = acc_as_operand(pT[0], pT[1], bf16());
+    const bf16x8 db = acc_as_operand(dsT[0], dsT[1], bf16());
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        mma16(ld_ks(sO, q0 + 4 * g, q0 + 16 + 4 * g, dt * 16, lane, bf16()), pb, st.dv[dt]);
+        mma16(ld_ks(sQ, q0 + 4 * g, q0 + 16 + 4 * g, dt * 16, lane, bf16()), db, st.dk[dt]);
+    }
+}
+__device__ __forceinline__ void bwd_small_keys_store(const BwdKeys& st, int t, int lane, int b, int h, int Tn, int nH, float inv_keep,
+                                                     bool kpok, bf16* __restrict__ dqkv, float* sB) {
+    const int g = lane >> 4, l15 = lane & 15, key = 16 * t + l15, D = nH * DH;
+    const long ld = 3L * D;
+    const bool kin = key < Tn;
+    // a padded key never receives attention: its probabilities are zero for every query, hence dK = dV = 0.  Each lane
+    // owns one key's column of both products, so the sweep runs unmasked and the column is zeroed here.
+    const float kz = kpok ? 1.f : 0.f, vz = kpok ? inv_keep : 0.f;
+    bf16x4 kk[4], vv[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        kk[dt] = bf16x4{(bf16)(st.dk[dt][0] * kz), (bf16)(st.dk[dt][1] * kz), (bf16)(st.dk[dt][2] * kz), (bf16)(st.dk[dt][3] * kz)};
+        vv[dt] = bf16x4{(bf16)(st.dv[dt][0] * vz), (bf16)(st.dv[dt][1] * vz), (bf16)(st.dv[dt][2] * vz), (bf16)(st.dv[dt][3] * vz)};
+    }
+    if (kin) {
+        bf16* dst = dqkv + ((long)b * Tn + key) * ld + h * DH;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            *reinterpret_cast<bf16x4*>(dst + D + dt * 16 + 4 * g) = kk[dt];
+            *reinterpret_cast<bf16x4*>(dst + 2 * D + dt * 16 + 4 * g) = vv[dt];
+        }
+    }
+    if (sB) {        // c_attn bias gradient: column sums over keys of the values as stored
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float sk = kin ? (float)kk[dt][r] : 0.f, sv = kin ? (float)vv[dt][r] : 0.f;
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { sk += __shfl_xor(sk, o, 64); sv += __shfl_xor(sv, o, 64); }
+                if (l15 == 0) {
+                    atomicAdd(sB + dt * 16 + 4 * g + r, sk);
+                    atomicAdd(sB + DH + dt * 16 + 4 * g + r, sv);
+                }
+            }
+    }
+}
+
+template <bool DROP>
+__global__ __launch_bounds__(512, 4) void attn_bwd_small_kv_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keep,
+        const bf16* __restrict__ d_out, const float* __restrict__ lse, const float* __restrict__ delta,
+        bf16* __restrict__ dqkv, float* __restrict__ dbias, int bias_rows, int Tn, int nH,
+        uint32_t keep16, uint32_t drop_seed, float inv_keep) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nchunk = (Tn + 63) >> 6, rows_pad = nchunk << 6;
+    char* sQ = smem;
+    char* sO = sQ + rows_pad * 128;
+    float* sLse = reinterpret_cast<float*>(sO + rows_pad * 128);    // [256]
+    float* sDel = sLse + 256;                                       // [256]
+    int* sKeep = reinterpret_cast<int*>(sDel + 256);                // [256]
+    float* sB = reinterpret_cast<float*>(sKeep + 256);              // [2][64] column sums of dK, dV (in a [256] slot)
+    uint32_t* sMask = reinterpret_cast<uint32_t*>(sB + 256);        // [256][8] keep bits
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = blockIdx.x % nH, b = blockIdx.x / nH;
+    const int D = nH * DH;
+    const long ld = 3L * D;
+    const bf16* base = qkv + (long)b * Tn * ld + h * DH;
+    const bf16* dob = d_out + (long)b * Tn * D + h * DH;
+    const int ntile = (Tn + 15) >> 4, npair = (ntile + 1) >> 1;
+    const int tA = wave, tB = ntile - 1 - wave;
+    const bool work = wave < npair;
+    float* const sBp = dbias ? sB : nullptr;
+    // K / V fragments of this wave's first key tile (B operands: lane holds row key = 16 t + l15, columns 32 ks + 8 g ..);
+    // the second tile's are fetched after the first sweep (registers)
+    bf16x8 kf[2], vf[2];
+    const int ka = 16 * tA + l15, kb = 16 * tB + l15;
+    bool kokA = false, kokB = false;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        kf[ks] = vf[ks] = zero16<bf16>();
+        if (work && ka < Tn) {
+            kf[ks] = *reinterpret_cast<const bf16x8*>(base + (long)ka * ld + D + ks * 32 + g * 8);
+            vf[ks] = *reinterpret_cast<const bf16x8*>(base + (long)ka * ld + 2 * D + ks * 32 + g * 8);
+        }
+    }
+    const __amdgpu_buffer_rsrc_t rq = rows_rsrc(base, ld, Tn), ro = rows_rsrc(dob, D, Tn);
+    dma_issue_scalars(sKeep, keep + (long)b * Tn, 1, Tn, wave, lane);
+    dma_issue_scalars(sLse, lse + ((long)b * nH + h) * Tn, 1, Tn, wave, lane);
+    dma_issue_scalars(sDel, delta + (long)b * Tn * nH + h, nH, Tn, wave, lane);
+    dma_issue_chunk(sQ, rq, ld, sO, ro, D, 0, nchunk, wave, lane);
+    dma_issue_chunk(sQ, rq, ld, sO, ro, D, 1, nchunk, wave, lane);
+    if constexpr (DROP) gen_keep_mask(sMask, (uint32_t)(b * nH + h), Tn, drop_seed, keep16, tid);
+    // first use of the plain loads: a counted wait here instead of a full drain inside the loop
+    asm volatile("" :: "v"(kf[0]), "v"(kf[1]), "v"(vf[0]), "v"(vf[1]));
+    BwdKeys st;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) st.dk[i] = st.dv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nqb = (Tn + 31) >> 5;
+    const float ik_scale = inv_keep * 0.125f;
+    // tile A (low keys) sweeps the query blocks from its diagonal on as they land; tile B (high keys, a short range
+    // at the end) runs afterwards on resident data
+#pragma unroll 1
+    for (int c = 0; c < nchunk; ++c) {
+        dma_wait_chunk(c);
+        raw_barrier();
+        if (c < 2) dma_issue_chunk(sQ, rq, ld, sO, ro, D, c + 2, nchunk, wave, lane);
+        if (c == 0) {
+            if (tid < 128) sB[tid] = 0.f;
+            if (tid < 256) { sLse[tid] *= LOG2E; sDel[tid] *= 0.125f; }
+            kokA = sKeep[ka & 255] != 0;
+            kokB = sKeep[kb & 255] != 0;
+            raw_barrier();
+        }
+#pragma unroll 1
+        for (int qb = 2 * c; qb < 2 * c + 2 && qb < nqb; ++qb)
+            if (work && qb >= ((16 * tA) >> 5))
+                bwd_small_keys_block<DROP>(st, sQ, sO, sLse, sDel, sMask, kf, vf, tA, 32 * qb, lane, ik_scale);
+    }
+    if (work) {
+        if (tA != tB) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                kf[ks] = vf[ks] = zero16<bf16>();
+                if (kb < Tn) {
+                    kf[ks] = *reinterpret_cast<const bf16x8*>(base + (long)kb * ld + D + ks * 32 + g * 8);
+                    vf[ks] = *reinterpret_cast<const bf16x8*>(base + (long)kb * ld + 2 * D + ks * 32 + g * 8);
+                }
+            }
+        }
+        bwd_small_keys_store(st, tA, lane, b, h, Tn, nH, inv_keep, kokA, dqkv, sBp);
+        if (tA != tB) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) st.dk[i] = st.dv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+            for (int qb = (16 * tB) >> 5; qb < nqb; ++qb)
+                bwd_small_keys_block<DROP>(st, sQ, sO, sLse, sDel, sMask, kf, vf, tB, 32 * qb, lane, ik_scale);
+            bwd_small_keys_store(st, tB, lane, b, h, Tn, nH, inv_keep, kokB, dqkv, sBp);
+        }
+    }
+    if (dbias) {
+        __syncthreads();
+        // this kernel owns the K and V parts of head h's columns: one partial row per batch row
+        // (bias_rows: plain stores into row b of the scratch; otherwise atomics onto the gradient)
+        if (tid < 2 * DH) {
+            const int col = (1 + tid / DH) * D + h * DH + tid % DH;
+            if (bias_rows) dbias[(long)b * 3 * D + col] = sB[tid];
+            else atomicAdd(dbias + col, sB[tid]);
+        }
+    }
+}
+
+// ---- backward, dQ kernel: the 16 queries of tile t (Q, dO fragments in registers), one 32-key block
+template <bool DROP>
+__device__ __forceinline__ void bwd_small_queries_block(f32x4 (&dq)[4], const char* sK, const char* sV, const float* sBias,
+                                                        const uint32_t* sMask, const bf16x8 (&qf)[2], const bf16x8 (&of)[2],
+                                                        float lse2_q, float dels_q, int t, int j0, int lane, float ik_scale) {
+    const int g = lane >> 4, l15 = lane & 15;
+    const int qi = 16 * t + l15, qlast = 16 * t + 15;
+    const float c1 = 0.125f * LOG2E;
+    f32x4 dsT[2];
+    uint32_t wq = 0;
+    if constexpr (DROP) wq = sMask[qi * 8 + (j0 >> 5)] >> (4 * g);      // this query row's keep bits of the block's 32 keys
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+        dsT[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (j0 + 16 * kt <= qlast) {
+            f32x4 s_acc = {0.f, 0.f, 0.f, 0.f}, dp_acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                mma16(ld_row(sK, j0 + kt * 16 + l15, ks, g), qf[ks], s_acc);       // S^T[key][q]
+                mma16(ld_row(sV, j0 + kt * 16 + l15, ks, g), of[ks], dp_acc);      // dP^T[key][q]
+            }
+            const int k0 = j0 + kt * 16 + 4 * g;
+            const f32x4 kb = *reinterpret_cast<const f32x4*>(sBias + k0);
+            const bool diag = j0 + 16 * kt + 15 > 16 * t;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float x = s_acc[r] * c1 - lse2_q + kb[r];
+                if (diag) x = k0 + r <= qi ? x : -INFINITY;
+                const float p = __builtin_amdgcn_exp2f(x);
+                float dp = dp_acc[r];
+                if constexpr (DROP) dp = mask_keep(dp, wq, 16 * kt + r);
+                dsT[kt][r] = p * (dp * ik_scale - dels_q);
+            }
+        }
+    }
+    // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
+    const bf16x8 db = acc_as_operand(dsT[0], dsT[1], bf16());
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+        mma16(ld_ks(sK, j0 + 4 * g, j0 + 16 + 4 * g, dt * 16, lane, bf16()), db, dq[dt]);
+}
+__device__ __forceinline__ void bwd_small_queries_store(const f32x4 (&dq)[4], int t, int lane, int b, int h, int Tn, int nH,
+                                                        bf16* __restrict__ dqkv, float* sB) {
+    const int g = lane >> 4, l15 = lane & 15, qi = 16 * t + l15, D = nH * DH;
+    const long ld = 3L * D;
+    const bool qok = qi < Tn;
+    if (qok) {
+        bf16* dst = dqkv + ((long)b * Tn + qi) * ld + h * DH;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            bf16x4 qq = {(bf16)dq[dt][0], (bf16)dq[dt][1], (bf16)dq[dt][2], (bf16)dq[dt][3]};
+            *reinterpret_cast<bf16x4*>(dst + dt * 16 + 4 * g) = qq;
+        }
+    }
+    if (sB) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float sq = qok ? (float)(bf16)dq[dt][r] : 0.f;
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) sq += __shfl_xor(sq, o, 64);
+                if (l15 == 0) atomicAdd(sB + dt * 16 + 4 * g + r, sq);
+            }
+    }
+}
+
+template <bool DROP>
+__global__ __launch_bounds__(512, 4) void attn_bwd_small_q_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keep,
+        const bf16* __restrict__ d_out, const float* __restrict__ lse, const float* __restrict__ delta,
+        bf16* __restrict__ dqkv, float* __restrict__ dbias, int bias_rows, int Tn, int nH,
+        uint32_t keep16, uint32_t drop_seed, float inv_keep) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nchunk = (Tn + 63) >> 6, rows_pad = nchunk << 6;
+    char* sK = smem;
+    char* sV = sK + rows_pad * 128;
+    int* sKeep = reinterpret_cast<int*>(sV + rows_pad * 128);      // [256]
+    float* sBias = reinterpret_cast<float*>(sKeep + 256);          // [256]
+    float* sB = sBias + 256;                                        // [64] column sums of dQ (in a [256] slot)
+    uint32_t* sMask = reinterpret_cast<uint32_t*>(sB + 512);        // [256][8] keep bits
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = blockIdx.x % nH, b = blockIdx.x / nH;
+    const int D = nH * DH;
+    const long ld = 3L * D;
+    const bf16* base = qkv + (long)b * Tn * ld + h * DH;
+    const bf16* dob = d_out + (long)b * Tn * D + h * DH;
+    const int ntile = (Tn + 15) >> 4, npair = (ntile + 1) >> 1;
+    const int tA = wave, tB = ntile - 1 - wave;
+    const bool work = wave < npair;
+    float* const sBp = dbias ? sB : nullptr;
+    bf16x8 qfA[2], ofA[2], qfB[2], ofB[2];
+    const int qa = 16 * tA + l15, qb_ = 16 * tB + l15;
+    float lseA = 0.f, delA = 0.f, lseB = 0.f, delB = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        qfA[ks] = ofA[ks] = qfB[ks] = ofB[ks] = zero16<bf16>();
+        if (work && qa < Tn) {
+            qfA[ks] = *reinterpret_cast<const bf16x8*>(base + (long)qa * ld + ks * 32 + g * 8);
+            ofA[ks] = *reinterpret_cast<const bf16x8*>(dob + (long)qa * D + ks * 32 + g * 8);
+        }
+        if (work && qb_ < Tn) {
+            qfB[ks] = *reinterpret_cast<const bf16x8*>(base + (long)qb_ * ld + ks * 32 + g * 8);
+            ofB[ks] = *reinterpret_cast<const bf16x8*>(dob + (long)qb_ * D + ks * 32 + g * 8);
+        }
+    }
+    if (work && qa < Tn) { lseA = lse[((long)b * nH + h) * Tn + qa]; delA = delta[((long)b * Tn + qa) * nH + h]; }
+    if (work && qb_ < Tn) { lseB = lse[((long)b * nH + h) * Tn + qb_]; delB = delta[((long)b * Tn + qb_) * nH + h]; }
+    const __amdgpu_buffer_rsrc_t rk = rows_rsrc(base + D, ld, Tn), rv = rows_rsrc(base + 2 * D, ld, Tn);
+    dma_issue_scalars(sKeep, keep + (long)b * Tn, 1, Tn, wave, lane);
+    dma_issue_chunk(sK, rk, ld, sV, rv, ld, 0, nchunk, wave, lane);
+    dma_issue_chunk(sK, rk, ld, sV, rv, ld, 1, nchunk, wave, lane);
+    if constexpr (DROP) gen_keep_mask(sMask, (uint32_t)(b * nH + h), Tn, drop_seed, keep16, tid);
+    // first use of the plain loads: a counted wait here instead of a full drain inside the loop
+    asm volatile("" :: "v"(qfA[0]), "v"(qfA[1]), "v"(ofA[0]), "v"(ofA[1]), "v"(qfB[0]), "v"(qfB[1]), "v"(ofB[0]), "v"(ofB[1]));
+    lseA *= LOG2E; lseB *= LOG2E; delA *= 0.125f; delB *= 0.125f;
+    f32x4 dq[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float ik_scale = inv_keep * 0.125f;
+    // tile B (high queries) consumes the key chunks as they land; tile A (a short range) runs afterwards
+#pragma unroll 1
+    for (int c = 0; c < nchunk; ++c) {
+        dma_wait_chunk(c);
+        raw_barrier();
+        if (c < 2) dma_issue_chunk(sK, rk, ld, sV, rv, ld, c + 2, nchunk, wave, lane);
+        if (c == 0) {
+            if (tid < 64) sB[tid] = 0.f;
+            if (tid < 256) sBias[tid] = sKeep[tid] != 0 ? 0.f : -INFINITY;
+            raw_barrier();
+        }
+#pragma unroll 1
+        for (int kb = 2 * c; kb < 2 * c + 2; ++kb)
+            if (work && 32 * kb <= 16 * tB + 15)
+                bwd_small_queries_block<DROP>(dq, sK, sV, sBias, sMask, qfB, ofB, lseB, delB, tB, 32 * kb, lane, ik_scale);
+    }
+    if (work) {
+        bwd_small_queries_store(dq, tB, lane, b, h, Tn, nH, dqkv, sBp);
+        if (tA != tB) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+            for (int j0 = 0; j0 <= 16 * tA + 15; j0 += 32)
+                bwd_small_queries_block<DROP>(dq, sK, sV, sBias, sMask, qfA, ofA, lseA, delA, tA, j0, lane, ik_scale);
+            bwd_small_queries_store(dq, tA, lane, b, h, Tn, nH, dqkv, sBp);
+        }
+    }
+    if (dbias) {
+        __syncthreads();
+        if (tid < DH) {         // the Q part of head h's columns
+            const int col = h * DH + tid;
+            if (bias_rows) dbias[(long)b * 3 * D + col] = sB[tid];
+            else atomicAdd(dbias + col, sB[tid]);
+        }
+    }
+}
+
+// two images + four [256]-dword scalar slots + the keep-bit matrix
+inline size_t small_smem(int T) { const int rp = ((T + 63) >> 6) << 6; return (size_t)rp * 256 + 4 * 256 * 4 + 256 * 8 * 4; }
+// keep probability of the whole-head kernels' dropout in units of 2^-12 and the matching scale
+inline unsigned small_keep16(unsigned thresh32) { return 4096u - ((thresh32 + 0x80000u) >> 20); }
+inline float small_inv_keep(unsigned keepq) { return (float)(4096.0 / (double)keepq); }
+
+
 template <typename T> size_t bwd_smem_bytes() {
     typedef AT<T> A;
     const int KB = 4 * A::KPW;
@@ -525,6 +1169,13 @@ inline float inv_keep_of(unsigned thresh) {
 }
 
 }  // namespace
+
+// diagnostic timeline of the whole-head kernels: per wave 8 x u64 (s_memrealtime stamps, XCC id, valid flag)
+static unsigned long long* g_attn_trace = nullptr;
+extern "C" int mmtg_attn_trace(void* buf) {
+    g_attn_trace = reinterpret_cast<unsigned long long*>(buf);
+    return MMTG_OK;
+}
 
 extern "C" int mmtg_attn_fwd(int dtype, const void* qkv, const int* keep, void* out, float* lse,
                              int B, int T, int nH, int dh, unsigned drop_thresh, unsigned drop_seed, void* stream) {
@@ -538,6 +1189,27 @@ extern "C" int mmtg_attn_fwd(int dtype, const void* qkv, const int* keep, void* 
     ProfScope prof(MMTG_PROF_ATTN_FWD, s, 2.0 * B * nH * (double)T * T * dh, esz * 4.0 * B * T * nH * dh);
     dim3 grid(cdiv(T, 64), nH, B), block(256);
     const float ik = inv_keep_of(drop_thresh);
+    static const bool legacy = getenv("MMTG_ATTN_TILED") != nullptr;      // A/B switch: the tiled kernel for every T
+    if (dtype == MMTG_BF16 && T <= SM_MAXT && !legacy) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute((const void*)attn_fwd_small_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)small_smem(SM_MAXT)) != hipSuccess ||
+                hipFuncSetAttribute((const void*)attn_fwd_small_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)small_smem(SM_MAXT)) != hipSuccess)
+                MMTG_FAIL(MMTG_ERR_HIP, "attn_fwd: cannot raise dynamic LDS");
+            attr_set = true;
+        }
+        const unsigned k16 = small_keep16(drop_thresh);
+        if (k16 < 4096u)
+            hipLaunchKernelGGL(attn_fwd_small_kernel<true>, dim3(B * nH), dim3(512), small_smem(T), s, (const bf16*)qkv, keep,
+                               (bf16*)out, lse, T, nH, k16, drop_seed, small_inv_keep(k16), g_attn_trace);
+        else
+            hipLaunchKernelGGL(attn_fwd_small_kernel<false>, dim3(B * nH), dim3(512), small_smem(T), s, (const bf16*)qkv, keep,
+                               (bf16*)out, lse, T, nH, 0u, drop_seed, 1.0f, g_attn_trace);
+        MMTG_LAUNCH_CHECK("attn_fwd");
+        return MMTG_OK;
+    }
     if (dtype == MMTG_F32)
         hipLaunchKernelGGL(attn_fwd_kernel<float>, grid, block, 0, s, (const float*)qkv, keep, (float*)out, lse, T, nH, drop_thresh, drop_seed, ik);
     else if (dtype == MMTG_BF16)
@@ -579,6 +1251,32 @@ extern "C" int mmtg_attn_bwd(int dtype, const void* qkv, const int* keep, const 
         if (nkb > 1) { if (hipMemsetAsync(dq32, 0, rows * D * sizeof(float), s) != hipSuccess) MMTG_FAIL(MMTG_ERR_HIP, "attn_bwd: memset failed"); }
         hipLaunchKernelGGL((attn_bwd_kernel<float, 4>), dim3(nkb, nH, B), dim3(256), shm, s, (const float*)qkv, keep, (const float*)dout, lse, delta, dq32, (float*)dqkv, bias_dst, bias_rows, T, nH, nkb == 1, drop_thresh, drop_seed, ik, ablate);
         if (nkb > 1) hipLaunchKernelGGL(attn_dq_finish_kernel<float>, dim3(2048), dim3(256), 0, s, dq32, (float*)dqkv, rows, D);
+    } else if (dtype == MMTG_BF16 && T <= SM_MAXT && !getenv("MMTG_ATTN_TILED")) {
+        static bool attr_small = false;
+        if (!attr_small) {
+            const int shm = (int)small_smem(SM_MAXT);
+            if (hipFuncSetAttribute((const void*)attn_bwd_small_kv_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, shm) != hipSuccess ||
+                hipFuncSetAttribute((const void*)attn_bwd_small_kv_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, shm) != hipSuccess ||
+                hipFuncSetAttribute((const void*)attn_bwd_small_q_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, shm) != hipSuccess ||
+                hipFuncSetAttribute((const void*)attn_bwd_small_q_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, shm) != hipSuccess)
+                MMTG_FAIL(MMTG_ERR_HIP, "attn_bwd: cannot raise dynamic LDS");
+            attr_small = true;
+        }
+        if (!delta_ready) hipLaunchKernelGGL(attn_delta_kernel<bf16>, dim3(cdiv(rows * nH, 4)), dim3(256), 0, s, (const bf16*)out, (const bf16*)dout, delta, T, nH, rows);
+        const unsigned th16 = small_keep16(drop_thresh);
+        const float ik16 = small_inv_keep(th16);
+        const size_t shm = small_smem(T);
+        if (th16 < 4096u) {
+            hipLaunchKernelGGL(attn_bwd_small_kv_kernel<true>, dim3(B * nH), dim3(512), shm, s, (const bf16*)qkv, keep, (const bf16*)dout, lse,
+                               delta, (bf16*)dqkv, bias_dst, bias_rows, T, nH, th16, drop_seed, ik16);
+            hipLaunchKernelGGL(attn_bwd_small_q_kernel<true>, dim3(B * nH), dim3(512), shm, s, (const bf16*)qkv, keep, (const bf16*)dout, lse,
+                               delta, (bf16*)dqkv, bias_dst, bias_rows, T, nH, th16, drop_seed, ik16);
+        } else {
+            hipLaunchKernelGGL(attn_bwd_small_kv_kernel<false>, dim3(B * nH), dim3(512), shm, s, (const bf16*)qkv, keep, (const bf16*)dout, lse,
+                               delta, (bf16*)dqkv, bias_dst, bias_rows, T, nH, 0u, drop_seed, 1.0f);
+            hipLaunchKernelGGL(attn_bwd_small_q_kernel<false>, dim3(B * nH), dim3(512), shm, s, (const bf16*)qkv, keep, (const bf16*)dout, lse,
+                               delta, (bf16*)dqkv, bias_dst, bias_rows, T, nH, 0u, drop_seed, 1.0f);
+        }
     } else if (dtype == MMTG_BF16) {
         const int KB = 4 * AT<bf16>::KPW;
         const int nkb = cdiv(T, KB);

@@ -38,6 +38,7 @@ _SIGS = {
     "mmtg_layernorm_bwd_ws": ([_i, _i], _l),
     "mmtg_layernorm_bwd": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _u, _u, _vp, _vp, _l, _vp], _i),
     "mmtg_attn_fwd": ([_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _u, _u, _vp], _i),
+    "mmtg_attn_trace": ([_vp], _i),
     "mmtg_attn_bwd": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _u, _u, _vp], _i),
     "mmtg_embed_condition": ([_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
     "mmtg_segment_sum": ([_i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp], _i),
@@ -232,6 +233,10 @@ def attn_bwd(qkv, keep, out, dout, lse, delta, dq32, dqkv, B, T, nH, dh, drop_p=
     _check(lib().mmtg_attn_bwd(dt(qkv), _p(qkv), _p(keep), _p(out), _p(dout), _p(lse), _p(delta), int(delta_ready), _p(dq32),
                                _p(dqkv), _p(dbias), _p(dbias_ws), B, T, nH, dh, drop_thresh(drop_p), drop_seed & 0xFFFFFFFF,
                                _stream()), "attn_bwd")
+
+
+def attn_trace(buf):
+    _check(lib().mmtg_attn_trace(_p(buf)), "attn_trace")
 
 
 def attn_bwd_bias_rows(B, T, dtype_code):

@@ -365,7 +365,7 @@ def ref_attention(qkv, keep, nH):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("T", [236, 104, 64, 300, 1, 17, 1024])
+@pytest.mark.parametrize("T", [236, 104, 64, 300, 1, 17, 1024, 256, 240, 33])
 def test_attention(dtype, T):
     B, nH, dh = 2, 3, 64
     D = nH * dh
