@@ -276,7 +276,7 @@ __global__ __launch_bounds__((64 * WM * WN), (DmaCfg<TBM, TBN, WM, WN, NBUF>::MI
     // MMTG_EPI_SPLIT: K split s stores its raw partial product in slab s of the fp32 output
     if constexpr (!std_orient) p.C = reinterpret_cast<char*>(p.C) + (long)split * p.split_stride;
     // (the 6-wave configuration has to stay within 128 VGPRs: aux vectors one band ahead, not all four)
-    gemm_epilogue<T, std_orient, TM, TN, (WM * WN > 4 ? -1 : TM)>(p, acc, m0 + wm * WTM, n0 + wn * WTN, g, l15,
+    gemm_epilogue<T, std_orient, TM, TN, (WM * WN > 4 ? -1 : (TM == 4 ? TM : -TM))>(p, acc, m0 + wm * WTM, n0 + wn * WTN, g, l15,
                                          smem + wave * epi_scratch_bytes<TM, TN>(), lane);
     if (tr && wave == 0 && (int)blockIdx.x < p.trace_n) {
         wait_vmcnt<0>();                       // the output stores are part of the epilogue's time
@@ -724,7 +724,23 @@ int launch_dma(const GemmArgs& a, int transA, int transB, int splits, int skinny
         if (!transA && !transB) return launch_dma_cfg<false, true, 192, 128, 3, 2, 2>(a, splits, stream);
     }
     if (!transA && transB) {
-        if (skinny) return launch_dma_cfg<false, false, 256, 32, 4, 1, 4>(a, splits, stream);
+        if (skinny) {
+            // batch-sized M (decode): tile shape of the weight-streaming products.  A workgroup pulls (BM + BN) x K
+            // bytes through its CU's L2 port, so with 256x32 tiles every workgroup re-reads ALL activation rows and
+            // the product is bound by that panel, not by the weights; 64x64 tiles pull less than half as much per
+            // workgroup and give 4x the workgroups (graph-replayed times at M = 256: c_attn 7.3 -> 5.8 us, attn c_proj
+            // 5.9 -> 4.1, c_fc 10.0 -> 6.7, mlp c_proj 7.7 -> 6.2, LM head 20.2 -> 16.0; profiles/r02_decode_gemm_tiles.log)
+            const char* e = getenv("MMTG_SKINNY_CFG");
+            const int cfg = e ? atoi(e) : 1;
+            switch (cfg) {
+                case 1: return launch_dma_cfg<false, false, 64, 64, 2, 2, 4>(a, splits, stream);
+                case 2: return launch_dma_cfg<false, false, 128, 64, 2, 2, 4>(a, splits, stream);
+                case 3: return launch_dma_cfg<false, false, 64, 128, 2, 2, 4>(a, splits, stream);
+                case 4: return launch_dma_cfg<false, false, 128, 32, 4, 1, 4>(a, splits, stream);
+                case 5: return launch_dma_cfg<false, false, 64, 32, 2, 1, 4>(a, splits, stream);
+                default: return launch_dma_cfg<false, false, 256, 32, 4, 1, 4>(a, splits, stream);
+            }
+        }
         return launch_dma_cfg<false, false, 128, 128, 2, 2, 2>(a, splits, stream);
     }
     if (!transA && !transB) return launch_dma_cfg<false, true, 128, 128, 2, 2, 2>(a, splits, stream);

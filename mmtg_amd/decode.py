@@ -55,7 +55,8 @@ class GreedyDecoder:
         self.fast = self.eng.dtype == hip.BF16 and not os.environ.get("MMTG_DECODE_PLAIN")
         # (measured at batch 256, us per token step: 2,3,2,6 -> 1020; 4,6,3,12 -> 1248; 1,1,1,2 -> 1183; unsplit 1264;
         #  with the one-slice c_fc + fused GELU: 2,3,1,8 -> 940, 2,3,1,6 -> 943, 1,3,1,8 -> 963, 2,3,1,12 -> 1003)
-        self.splits = tuple(int(x) for x in os.environ.get("MMTG_DECODE_SPLITS", "2,3,1,8").split(","))
+        #  round 2, 64x64 tiles (graph-replayed per-product times, profiles/r02_decode_gemm_tiles.log): 2,4,1,8)
+        self.splits = tuple(int(x) for x in os.environ.get("MMTG_DECODE_SPLITS", "2,4,1,8").split(","))
         if self.fast:
             D = self.eng.sh.D
             slab = max(self.splits[0] * 3 * D, self.splits[1] * D, self.splits[2] * 4 * D, self.splits[3] * D)
