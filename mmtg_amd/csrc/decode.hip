@@ -349,12 +349,17 @@ __global__ __launch_bounds__(256) void decode_embed_add_kernel(const T* __restri
 }
 
 // One wave per (b, head): append this token's K/V to the cache, then attend over keys 0..pos.
-// Cache layout [B, nH, Tmax, 64].  Scores: lane <-> key (4 keys per lane for Tmax <= 256 handled in
-// a loop), dot products over the 64-wide head; output: lane <-> channel.
+// Cache layout [B, nH, Tmax, 64].  Both passes over the cache use 16-byte vectors: a key's 64 channels are spread over
+// OCT = 8 (bf16) / 16 (f32) adjacent lanes, so one wave-instruction reads 64 / OCT whole cache rows -- 1 KB, fully
+// coalesced -- instead of one row per lane (scores) or one row per iteration (values): 18 dependent loads for a
+// 143-key prefix instead of 143.  Scores: partial dot products folded across the OCT lanes; values: each lane
+// accumulates its channel octet over its keys, the key groups are folded at the end.  Fixed summation order.
 template <typename T>
 __global__ __launch_bounds__(64) void decode_attn_kernel(const T* __restrict__ qkv, T* __restrict__ kc, T* __restrict__ vc,
         const int* __restrict__ keep, long ldkeep, const int* __restrict__ pos_ptr, T* __restrict__ out,
         int nH, int Tmax, const float* __restrict__ part, int splits, long slab, const float* __restrict__ bias) {
+    typedef typename Vec16<T>::type V;
+    constexpr int EPL = Vec16<T>::N, OCT = 64 / EPL, KPI = 64 / OCT;      // elements per lane, lanes per key, keys per instruction
     __shared__ float sp[1024];
     __shared__ float sq[64];
     const int h = blockIdx.x, b = blockIdx.y, lane = threadIdx.x, pos = *pos_ptr;
@@ -379,37 +384,76 @@ __global__ __launch_bounds__(64) void decode_attn_kernel(const T* __restrict__ q
     }
     __syncthreads();
     const int nkeys = pos + 1;
-    float mx = -INFINITY;
-    for (int k0 = 0; k0 < nkeys; k0 += 64) {
-        const int key = k0 + lane;
-        float s = -INFINITY;
-        if (key < nkeys && keep[(long)b * ldkeep + key]) {
-            const T* kr = kbase + (long)key * 64;
-            float a = 0.f;
-#pragma unroll 8
-            for (int d = 0; d < 64; ++d) a += sq[d] * (float)kr[d];
-            s = a;
+    const int oc = lane % OCT, kg = lane / OCT;
+    float qv[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) qv[e] = sq[oc * EPL + e];
+    // ---- scores: UN independent 16-byte loads per lane are requested before the first is used (a wave keeps up to
+    //      UN KB of the cache in flight: the pass is bound by HBM latency, not bandwidth, at 12 waves per CU)
+    constexpr int UN = 16;
+#pragma unroll 1
+    for (int k0 = 0; k0 < nkeys; k0 += UN * KPI) {
+        V kv[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int key = k0 + u * KPI + kg;
+            kv[u] = *reinterpret_cast<const V*>(kbase + (long)(key < nkeys ? key : pos) * 64 + oc * EPL);
         }
-        sp[key] = s;
-        mx = fmaxf(mx, s);
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int key = k0 + u * KPI + kg;
+            float a = 0.f;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) a += qv[e] * (float)kv[u][e];
+#pragma unroll
+            for (int o = 1; o < OCT; o <<= 1) a += __shfl_xor(a, o, 64);
+            if (oc == 0 && key < nkeys) sp[key] = keep[(long)b * ldkeep + key] ? a : -INFINITY;
+        }
     }
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int key = lane; key < nkeys; key += 64) mx = fmaxf(mx, sp[key]);
     mx = wave_max(mx);
     const float muse = mx == -INFINITY ? 0.f : mx;
     float sum = 0.f;
-    for (int k0 = 0; k0 < nkeys; k0 += 64) {
-        const int key = k0 + lane;
-        if (key < nkeys) {
-            const float s = sp[key];
-            const float p = s == -INFINITY ? 0.f : expf(s - muse);
-            sp[key] = p;
-            sum += p;
-        }
+    for (int key = lane; key < nkeys; key += 64) {
+        const float s = sp[key];
+        const float p = s == -INFINITY ? 0.f : expf(s - muse);
+        sp[key] = p;
+        sum += p;
     }
     sum = wave_sum(sum);
     __syncthreads();
-    float acc = 0.f;
-    for (int key = 0; key < nkeys; ++key) acc += sp[key] * (float)vbase[(long)key * 64 + lane];
-    out[(long)b * D + h * 64 + lane] = (T)(sum > 0.f ? acc / sum : 0.f);
+    // ---- values
+    float acc[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
+#pragma unroll 1
+    for (int k0 = 0; k0 < nkeys; k0 += UN * KPI) {
+        V vv[UN];
+        float pp[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int key = k0 + u * KPI + kg;
+            vv[u] = *reinterpret_cast<const V*>(vbase + (long)(key < nkeys ? key : pos) * 64 + oc * EPL);
+            pp[u] = key < nkeys ? sp[key] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) acc[e] += pp[u] * (float)vv[u][e];
+    }
+#pragma unroll
+    for (int e = 0; e < EPL; ++e)
+#pragma unroll
+        for (int o = OCT; o < 64; o <<= 1) acc[e] += __shfl_xor(acc[e], o, 64);
+    if (kg == 0) {
+        const float inv = sum > 0.f ? 1.f / sum : 0.f;
+        V o;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) o[e] = (T)(acc[e] * inv);
+        *reinterpret_cast<V*>(out + (long)b * D + h * 64 + oc * EPL) = o;
+    }
 }
 
 // logits processor + arg-max + forced-token cadence + append (generate.py:117-142), device-driven.
