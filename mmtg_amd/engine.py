@@ -417,13 +417,13 @@ class Engine:
         tiles = ((Mg + 127) // 128) * ((Ng + 127) // 128)
         if bf and _WGRAD_SLAB and 1 < splits and tiles < 512 and Ng % 8 == 0:
             # K-split slabs with plain stores + an ordered sum instead of fp32 atomics (deterministic)
-            part = self.buf("wgrad_slabs", (12 * 3072 * 768,), torch.float32)
-            if splits * Mg * Ng <= part.numel():
-                hip.gemm(A, B, part, Mg, Ng, Mtok, transA=True, transB=False, lda=lda, ldb=ldb, ldc=Ng,
-                         epi=hip.EPI_SPLIT, out_f32=True, splits=splits)
-                # (the fused trainer zeroes the gradients right before its single backward: the sum may then overwrite)
-                hip.slab_sum(part, splits, Mg * Ng, gw, Mg * Ng, accumulate=not self.wgrad_overwrite)
-                splits = 0
+            # (one workspace, sized for the largest request so far: 113 MB at GPT-2 base, 268 MB at GPT-2 medium)
+            part = self.buf("wgrad_slabs", (splits * Mg * Ng,), torch.float32)
+            hip.gemm(A, B, part, Mg, Ng, Mtok, transA=True, transB=False, lda=lda, ldb=ldb, ldc=Ng,
+                     epi=hip.EPI_SPLIT, out_f32=True, splits=splits)
+            # (the fused trainer zeroes the gradients right before its single backward: the sum may then overwrite)
+            hip.slab_sum(part, splits, Mg * Ng, gw, Mg * Ng, accumulate=not self.wgrad_overwrite)
+            splits = 0
         if splits:
             hip.gemm(A, B, gw, Mg, Ng, Mtok, transA=True, transB=False, lda=lda, ldb=ldb, ldc=Ng,
                      epi=hip.EPI_ATOMIC, splits=splits)

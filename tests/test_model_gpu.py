@@ -639,3 +639,58 @@ def test_workspace_stays_bounded_when_the_row_count_changes_every_step():
     grown = torch.cuda.memory_allocated()
     assert grown <= 1.3 * base, (base, grown)
     assert torch.cuda.memory_reserved() <= 1.6 * base
+
+
+# ------------------------------------------------------------------ BASELINE configs[4] at its stated size, one GPU
+def test_scaled_stress_config_full_size_properties():
+    """GPT-2-medium decoder (24 layers / 1024 / 16 heads), V = 13317, S = 8 experience steps, T = 15 + 497 = 512 decoder
+    positions (two key blocks in the tiled attention backward), rating skew K = 32 (low : high) with the curriculum
+    stage-2 filter inside the step -- the full configs[4] model on ONE GPU (the 8-GPU run shards rows).  No CPU oracle
+    reaches this size; checked through properties: (a) the bf16 gradient of 8 rows equals the sum of two 4-row shards
+    pre-scaled for the global count; (b) the first bf16 step's loss is within 3e-3 of the exact-fp32 mode's; (c) five
+    clip + AdamW steps on one fixed batch lower the loss; (d) a stage-2 step drops exactly the rating-3 rows."""
+    from mmtg_amd import synth
+    from mmtg_amd.configs import data_config, gpt2_config, make_model_cfgs
+    S, V = 8, 13317
+    mcfg = make_model_cfgs(seq_len=S, dropout=0.0)
+    dcfg = data_config(seq_len=S, max_sent_length=29)
+    gcfg = gpt2_config(n_layer=24, n_embd=1024, n_head=16, n_positions=512, n_ctx=512, vocab_size=V,
+                       embd_pdrop=0.0, attn_pdrop=0.0, resid_pdrop=0.0)
+    table = synth.make_token_table(V, seed=2)
+    nb = synth.make_batch(8, mcfg, dcfg, V, seed=5, low_to_high=32.0)
+    assert 15 + np.asarray(nb["targets"]).shape[1] == 512
+    assert int((np.asarray(nb["rating"]) > 3).sum()) == 1           # K = 32: one high-rating row of eight
+    batch = {k: torch.from_numpy(np.asarray(v)).to(DEV) for k, v in nb.items()}
+
+    def make(dtype):
+        m = MMTG(mcfg, dcfg, V, train_flag=True, gpt2_config=gcfg, compute_dtype=dtype, token_table=table)
+        m.reset_parameters(seed=0)
+        m.to(DEV)
+        return m
+
+    model = make("bf16")
+    assert sum(p.numel() for p in model.parameters()) > 3.2e8        # GPT-2 medium + the encoder / fuser
+    eng = model.engine()
+    eng.zero_grad()
+    _grad_of(eng, list(range(8)), batch, 8)
+    g_full = eng.grad.clone()
+    eng.zero_grad()
+    _grad_of(eng, list(range(4)), batch, 8)
+    _grad_of(eng, list(range(4, 8)), batch, 8)
+    cos = float(torch.nn.functional.cosine_similarity(g_full, eng.grad, dim=0))
+    rel = float((g_full - eng.grad).norm() / g_full.norm())
+    assert cos > 0.9999 and rel < 5e-3, (cos, rel)
+    del g_full
+    tr = MMTGTrainer(model, lr=1e-4, alpha=0.2)
+    losses = [float(tr.step(batch, stage=3)["loss"]) for _ in range(5)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+    # stage 2 drops the rating-3 rows (train.py:180-181) and still steps
+    n3 = int((np.asarray(nb["rating"]) == 3).sum())
+    out = tr.step(batch, stage=2)
+    assert eng.act["B"] == 8 - n3 and np.isfinite(float(out["loss"]))
+    del tr, model, eng
+    torch.cuda.empty_cache()
+    m32 = make("f32")
+    l32 = float(MMTGTrainer(m32, lr=1e-4, alpha=0.2).step(batch, stage=3)["loss"])
+    assert abs(losses[0] - l32) <= 3e-3 * abs(l32), (losses[0], l32)
+    _report("scaled_stress_full_size", additivity_cos=cos, additivity_rel=rel, loss_bf16=losses[0], loss_f32=l32, losses=losses)

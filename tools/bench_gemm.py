@@ -7,7 +7,7 @@ from mmtg_amd import hip
 
 dev = "cuda"
 M = int(os.environ.get("TOKENS", 64 * 236))
-D, V = 768, 13440
+D, V = int(os.environ.get("DMODEL", "768")), 13440
 dt = torch.bfloat16 if os.environ.get("DT", "bf16") == "bf16" else torch.float32
 
 def t(*s): return (torch.randn(*s, device=dev) * 0.5).to(dt)
