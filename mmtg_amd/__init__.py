@@ -15,7 +15,10 @@ def __getattr__(name):
     if name == "MyLoss":
         from .loss import MyLoss
         return MyLoss
-    if name in ("sample_sequence", "top_k_top_p_filtering"):
+    if name in ("pack_token_table", "load_token_table"):
+        from . import model
+        return getattr(model, name)
+    if name in ("sample_sequence", "top_k_top_p_filtering", "generate_samples", "postprocess_tokens"):
         from . import generate
         return getattr(generate, name)
     if name in ("MyDataset", "BinaryDataset", "DeviceLoader", "pack_binary"):

@@ -83,3 +83,62 @@ def sample_sequence(model, start_input, length, tokenizer, temperature=1.0, top_
                 next_token = nxt.view(1, 1).clone()
             inputs["targets"] = torch.cat((generated, next_token), dim=-1)
     return generated.tolist()[0]
+
+
+# ------------------------------------------------------------------ the sampling product path (generate.py:205-235)
+def postprocess_tokens(preds):
+    """The reference's cut rules and detokenisation of one sampled token list (generate.py:222-235):
+    cut after the 10th [#EOS#] when there are at least ten and no [SEP] before the last one, else after the first
+    [SEP], else append one; then join, drop [SEP] / [PAD] / [#START#], turn [#EOS#] into the full-width comma and strip
+    trailing commas.  (An all-special list leaves an empty string; the reference would raise IndexError there.)"""
+    preds = list(preds)
+    eos = [i for i, v in enumerate(preds) if v == "[#EOS#]"]
+    if len(eos) >= 10 and "[SEP]" not in preds[:eos[-1]]:
+        preds = preds[:eos[9] + 1] + ["[SEP]"]
+    elif "[SEP]" in preds:
+        preds = preds[:preds.index("[SEP]") + 1]
+    else:
+        preds = preds + ["[SEP]"]
+    text = "".join(preds).replace("[SEP]", "").replace("[PAD]", "").replace("[#START#]", "").replace("[#EOS#]", "，")
+    while text and text[-1] == "，":
+        text = text[:-1]
+    return text
+
+
+def generate_samples(model, rows, tokenizer, n_samples=10, length=None, temperature=1.1, top_k=10, top_p=0.7,
+                     repetition_penalty=1.5, max_batch=256, generator=None, decoder=None):
+    """n_samples texts per prompt (generate.sh's loop, generate.py:205-235) on the batched, graph-replayed decoder:
+    every prompt is replicated over n_samples rows, rows are decoded max_batch at a time with the device-side
+    top-k / top-p sampler (one uniform per row and position from `generator`), each row is cut back to what
+    sample_sequence would have returned (the sequence before the last model call's append) and post-processed.
+
+    rows: list of dataset items (dicts with topic_ids / tpw_* / topic_emb / img_embs / r_embs, numpy or tensors) or a dict of
+    stacked arrays.  Returns a list (one entry per prompt) of lists of n_samples strings."""
+    from .decode import GreedyDecoder
+    eng = model.engine()
+    sh = eng.sh
+    length = sh.max_seq_length if length is None else length
+    keys = ("topic_ids", "tpw_attention_mask", "tpw_type_ids", "topic_emb", "img_embs", "r_embs")
+    if isinstance(rows, dict):
+        stacked = {k: torch.as_tensor(np.asarray(rows[k])) for k in keys}
+    else:
+        stacked = {k: torch.as_tensor(np.stack([np.asarray(r[k]) for r in rows])) for k in keys}
+    n_prompts = stacked["topic_ids"].shape[0]
+    rep = {k: v.repeat_interleave(n_samples, dim=0) for k, v in stacked.items()}
+    total = n_prompts * n_samples
+    bsz = min(max_batch, total)
+    dec = decoder if decoder is not None and decoder.B == bsz else GreedyDecoder(model, max_batch=bsz, max_len=length)
+    texts = []
+    for lo in range(0, total, bsz):
+        hi = min(total, lo + bsz)
+        chunk = {k: v[lo:hi] for k, v in rep.items()}
+        if hi - lo < bsz:          # the decoder's batch is fixed: pad the last chunk by repeating its first row
+            pad = bsz - (hi - lo)
+            chunk = {k: torch.cat([v, v[:1].expand(pad, *v.shape[1:])], 0) for k, v in chunk.items()}
+        chunk = {k: v.to(eng.dev) for k, v in chunk.items()}
+        ids = dec.generate(chunk, length, temperature=temperature, repitition_penalty=repetition_penalty,
+                           top_k=top_k, top_p=top_p, generator=generator).cpu().numpy()
+        for r in range(hi - lo):
+            seq = GreedyDecoder.reference_return(ids[r].tolist(), length)
+            texts.append(postprocess_tokens(tokenizer.convert_ids_to_tokens(seq)))
+    return [texts[i * n_samples:(i + 1) * n_samples] for i in range(n_prompts)]

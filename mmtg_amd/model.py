@@ -63,6 +63,42 @@ def _load_gpt2_config(config_path, override):
     return cfg
 
 
+PACKED_TABLE_PATH = "./vocab/token_id2emb.safetensors"
+
+
+def table_from_dict(table):
+    """{id: list[emb]} (model.py:215) -> dense float32 [max id + 1, emb]; ids missing from the dict stay zero."""
+    n = max(int(k) for k in table) + 1
+    ids = np.fromiter((int(k) for k in table), dtype=np.int64, count=len(table))
+    arr = np.zeros((n, len(next(iter(table.values())))), np.float32)
+    arr[ids] = np.asarray(list(table.values()), np.float32)
+    return arr
+
+
+def pack_token_table(table, out_path=PACKED_TABLE_PATH, dtype=torch.bfloat16):
+    """One-time conversion of the reference's ``vocab/token_id2emb_dict.pkl`` (a pickled ``{id: list[2048 floats]}``, 246 MB,
+    ~14 s to unpickle) into a flat ``[V, 2048]`` tensor file (safetensors, 54.5 MB in bf16, memory-mapped on load).
+    ``table``: the pickle's path, the dict itself, or a [V, emb] array."""
+    from safetensors.torch import save_file
+    if isinstance(table, (str, os.PathLike)):
+        with open(table, "rb") as f:
+            table = pickle.load(f)
+    arr = table_from_dict(table) if isinstance(table, dict) else np.asarray(table, np.float32)
+    t = torch.from_numpy(np.ascontiguousarray(arr)).to(dtype).contiguous()
+    os.makedirs(os.path.dirname(os.path.abspath(out_path)), exist_ok=True)
+    save_file({"token_id2emb": t}, str(out_path), metadata={"format": "mmtg-token-table-1", "rows": str(t.shape[0]), "emb": str(t.shape[1])})
+    return out_path
+
+
+def load_token_table(path):
+    """[V, emb] tensor of a ``pack_token_table`` file (stored dtype, normally bf16)."""
+    from safetensors import safe_open
+    with safe_open(str(path), framework="pt") as f:
+        if (f.metadata() or {}).get("format") != "mmtg-token-table-1":
+            raise ValueError("not a packed token table: %s" % path)
+        return f.get_tensor("token_id2emb")
+
+
 class GPT2_Decoder(_Holder):
     """projector + GPT-2 parameters and the WenLan table (reference model.py:205-223).
 
@@ -79,8 +115,12 @@ class GPT2_Decoder(_Holder):
         self.model_name = model_name
         self.config = _load_gpt2_config(config_path, gpt2_config)
         self.token_id2emb = None
-        if token_table is None and os.path.exists("./vocab/token_id2emb_dict.pkl"):
-            token_table = self.load_token_id2emb("./vocab/token_id2emb_dict.pkl")
+        if token_table is None:
+            # the packed tensor file (pack_token_table) is preferred over the reference's 246 MB pickle of Python lists
+            if os.path.exists(PACKED_TABLE_PATH):
+                token_table = load_token_table(PACKED_TABLE_PATH)
+            elif os.path.exists("./vocab/token_id2emb_dict.pkl"):
+                token_table = self.load_token_id2emb("./vocab/token_id2emb_dict.pkl")
         self._table = None
         if token_table is not None:
             self.set_token_table(token_table)
@@ -90,15 +130,15 @@ class GPT2_Decoder(_Holder):
             return pickle.load(f)
 
     def set_token_table(self, table):
-        """Accepts the reference's ``{id: list[2048]}`` dict or a [V, 2048] array/tensor."""
+        """Accepts the reference's ``{id: list[2048]}`` dict, a [V, 2048] array / tensor (any float dtype; a bf16 tensor
+        from ``load_token_table`` is kept as is), or the path of a packed table file."""
+        if isinstance(table, (str, os.PathLike)):
+            table = load_token_table(table)
         if isinstance(table, dict):
             self.token_id2emb = table
-            n = max(table) + 1
-            arr = np.zeros((n, len(next(iter(table.values())))), np.float32)
-            for k, v in table.items():
-                arr[int(k)] = np.asarray(v, np.float32)
-            table = arr
-        self._table = torch.as_tensor(np.asarray(table) if not torch.is_tensor(table) else table).float()
+            table = table_from_dict(table)
+        t = table if torch.is_tensor(table) else torch.as_tensor(np.asarray(table))
+        self._table = t if t.dtype == torch.bfloat16 else t.float()
 
 
 class MMTG(nn.Module):

@@ -263,3 +263,38 @@ def test_full_size_batched_decode_rules():
             else:
                 assert not ((col == 1) | (col == 2) | (col == 100) | (col == 102)).any()
                 assert (col[ids[:, j - 1] == 0] == 0).all()
+
+
+def test_generate_samples_matches_the_reference_post_processing():
+    """generate_samples (n_samples per prompt on the batched decoder + the cut rules of generate.py:222-235): in the greedy
+    setting every sample of a prompt is the reference's own text -- its sample_sequence id list (golden) through its own
+    post-processing (golden strings in postprocess.npz) -- and the stochastic setting returns n_samples differing,
+    special-token-free strings per prompt."""
+    import os
+    from helpers import GOLDEN
+    from mmtg_amd.generate import generate_samples, postprocess_tokens
+    fx, batch, model = build("f32")
+    pp = np.load(os.path.join(GOLDEN, "postprocess.npz"))
+    vocab = {int(k): v for k, v in json.loads(str(pp["vocab_json"])).items()}
+    expected = json.loads(str(pp["expected_json"]))
+
+    class Tok:
+        def convert_ids_to_tokens(self, ids):
+            return [vocab.get(int(i), "tok%d" % int(i)) for i in ids]
+
+    rows = [{k: np.asarray(v[r]) for k, v in batch.items() if k not in ("rating", "targets")} for r in range(2)]
+    out = generate_samples(model, rows[:1], Tok(), n_samples=2, length=220, temperature=1.1, top_k=1, top_p=0.0,
+                           repetition_penalty=1.5)
+    assert out == [[expected[0], expected[0]]]            # postprocess.npz case 0 = greedy_len220_row0
+    out = generate_samples(model, rows, Tok(), n_samples=2, length=30, temperature=1.1, top_k=1, top_p=0.0, repetition_penalty=1.5)
+    want1 = postprocess_tokens(Tok().convert_ids_to_tokens(fx["greedy_len30_row1"].tolist()))
+    assert out == [[expected[1], expected[1]], [want1, want1]]
+    g = torch.Generator(device=DEV)
+    g.manual_seed(3)
+    out = generate_samples(model, rows, Tok(), n_samples=4, length=66, temperature=1.1, top_k=10, top_p=0.7,
+                           repetition_penalty=1.5, generator=g)
+    assert len(out) == 2 and all(len(o) == 4 for o in out)
+    for texts in out:
+        assert len(set(texts)) > 1                         # samples differ
+        for t in texts:
+            assert isinstance(t, str) and t and not any(s in t for s in ("[SEP]", "[PAD]", "[#START#]", "[#EOS#]")) and t[-1] != "，"

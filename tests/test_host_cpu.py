@@ -233,3 +233,44 @@ def test_bucketed_allreduce_world2_gloo(tmp_path):
         assert nb > 3            # really bucketed
         assert n == 7            # 3 + 4 rows across ranks
         assert torch.equal(reduced, total)
+
+
+def test_postprocess_cut_rules_vs_reference_goldens():
+    """generate.py:222-235 (10th-[#EOS#] / first-[SEP] cut, detokenise, comma join) -- expected strings were produced by
+    executing the reference's own block on these token lists (tools/make_golden.py::case_postprocess)."""
+    import json
+    from mmtg_amd.generate import postprocess_tokens
+    fx = np.load(os.path.join(ROOT, "tests", "golden", "postprocess.npz"))
+    vocab = {int(k): v for k, v in json.loads(str(fx["vocab_json"])).items()}
+    expected = json.loads(str(fx["expected_json"]))
+    assert int(fx["n"]) == len(expected) >= 8
+    for n, want in enumerate(expected):
+        toks = [vocab[int(i)] for i in fx["ids_%d" % n]]
+        assert postprocess_tokens(toks) == want, n
+    assert postprocess_tokens(["[#START#]", "[#EOS#]", "[PAD]"]) == ""       # (the reference raises IndexError on this one)
+
+
+def test_packed_token_table_round_trip(tmp_path):
+    """pack_token_table: the reference's {id: list[2048]} pickle (model.py:215) -> [V, 2048] bf16 tensor file; the decoder
+    picks it up from the path or as a tensor, ids missing from the dict stay zero."""
+    import pickle
+    from mmtg_amd.model import GPT2_Decoder, load_token_table, pack_token_table
+    rng = np.random.default_rng(3)
+    d = {i: rng.standard_normal(2048).astype(np.float32).tolist() for i in (0, 1, 2, 5, 9)}
+    pk = tmp_path / "token_id2emb_dict.pkl"
+    with open(pk, "wb") as f:
+        pickle.dump(d, f)
+    out = pack_token_table(str(pk), str(tmp_path / "t.safetensors"))
+    t = load_token_table(out)
+    assert t.dtype == torch.bfloat16 and tuple(t.shape) == (10, 2048)
+    for i in d:
+        assert torch.equal(t[i], torch.tensor(d[i]).to(torch.bfloat16))
+    assert float(t[3].abs().max()) == 0.0
+    dec = GPT2_Decoder(data_config(), token_table=out)
+    assert dec._table.dtype == torch.bfloat16 and torch.equal(dec._table, t)
+    dec2 = GPT2_Decoder(data_config(), token_table=d)            # the dict itself still works (float32 kept)
+    assert dec2._table.dtype == torch.float32 and torch.equal(dec2._table.to(torch.bfloat16), t)
+    with pytest.raises(ValueError):
+        from safetensors.torch import save_file
+        save_file({"x": torch.zeros(2)}, str(tmp_path / "bad.safetensors"))
+        load_token_table(tmp_path / "bad.safetensors")

@@ -406,22 +406,70 @@ def case_dataset(out_dir):
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 
 
+def case_postprocess(out_dir, golden_dir):
+    """Cut rules + detokenisation of generate.py:222-235.  That code lives inline in the reference's main(); it is
+    located in the source file at run time (between the two statements that bracket it), dedented and EXECUTED on
+    token lists -- nothing of it is stored here.  Inputs: the reference's own 220-position greedy id list (tiny_s5
+    fixture) and hand-made lists that reach every branch; tokens come from the reference's vocabulary."""
+    import textwrap
+    if REF_SRC not in sys.path:
+        sys.path.insert(0, REF_SRC)
+    from transformers import BertTokenizer
+    tok = BertTokenizer(os.path.join(REF_SRC, "vocab", "vocab.txt"))
+    lines = open(os.path.join(REF_SRC, "generate.py"), encoding="utf-8").read().split("\n")
+    a = next(i for i, l in enumerate(lines) if "all_idx_of_eos = [" in l)
+    b = next(i for i, l in enumerate(lines) if "n_preds += [tmp]" in l)
+    code = compile(textwrap.dedent("\n".join(lines[a:b])), "<reference generate.py:%d-%d>" % (a + 1, b), "exec")
+
+    def ref_post(tokens):
+        ns = {"preds": list(tokens)}
+        exec(code, ns)
+        return ns["tmp"]
+
+    fx0 = np.load(os.path.join(golden_dir, "tiny_s5.npz"))
+    cases = [fx0["greedy_len220_row0"].tolist(), fx0["greedy_len30_row0"].tolist()]
+    w = [104 + 7 * i for i in range(40)]
+    sent = lambda n, k: [1] + w[k:k + n] + [0] * (20 - n) + [2]
+    cases.append(sum((sent(5 + i, i) for i in range(10)), []) + [102])                      # ten sentences then [SEP]
+    cases.append(sum((sent(3, i) for i in range(4)), []) + [102] + sent(4, 9))              # early [SEP]: cut there
+    cases.append(sum((sent(6, i) for i in range(3)), []))                                   # no [SEP], fewer than ten [#EOS#]
+    cases.append(sum((sent(2, i) for i in range(12)), []))                                  # twelve [#EOS#], no [SEP]: cut at the 10th
+    cases.append(sum((sent(2, i) for i in range(11)), [])[:-1] + [102, 2])                  # [SEP] before the last [#EOS#]
+    cases.append([1, 105, 0, 0, 2, 2, 2])                                                   # trailing commas stripped
+    ids = sorted(set(i for c in cases for i in c))
+    vocab = {int(i): tok.convert_ids_to_tokens(int(i)) for i in ids}
+    fx = {"n": np.int64(len(cases)), "vocab_json": np.array(json.dumps(vocab, ensure_ascii=False))}
+    outs = []
+    for n, c in enumerate(cases):
+        fx["ids_%d" % n] = np.asarray(c, np.int64)
+        outs.append(ref_post(tok.convert_ids_to_tokens(c)))
+    fx["expected_json"] = np.array(json.dumps(outs, ensure_ascii=False))
+    path = os.path.join(out_dir, "postprocess.npz")
+    np.savez_compressed(path, **fx)
+    print("wrote", path, [o[:24] for o in outs])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
     ap.add_argument("--skip-full", action="store_true")
     ap.add_argument("--only-dataset", action="store_true", help="regenerate tests/golden/dataset.npz only")
+    ap.add_argument("--only-postprocess", action="store_true", help="regenerate tests/golden/postprocess.npz only")
     args = ap.parse_args()
     out_dir = os.path.abspath(args.out)
     os.makedirs(out_dir, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(8)
+    if args.only_postprocess:
+        case_postprocess(out_dir, os.path.join(REPO, "tests", "golden"))
+        return
     case_dataset(out_dir)
     if args.only_dataset:
         return
     gen = case_model("tiny_s5", out_dir, S=5, n_layer=2, V=160, B=3, seed=100)
     case_filtering(out_dir, gen)
     case_model("tiny_s2", out_dir, S=2, n_layer=2, V=160, B=4, seed=200, with_decode=False)
+    case_postprocess(out_dir, out_dir)
     if not args.skip_full:
         # (full size: sampled logits + top-5 + LSE, sampled gradients / gradient norms / parameters after one step,
         #  and one greedy sample_sequence run of 30 and of 220 positions with its per-call top-2 margins)
