@@ -566,13 +566,17 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t rows_rsrc(const bf16* p, long 
 // One chunk (64 rows) of both images = two requests per wave.  Chunk indices beyond the tensor's last chunk re-target
 // an existing chunk (same source, same destination -- harmless), so the number of requests is a compile-time constant
 // and the compiler's own waits for the few plain loads stay counted ones.
+template <int NW = 8>
 __device__ __forceinline__ void dma_issue_chunk(char* imgA, __amdgpu_buffer_rsrc_t ra, long lda, char* imgB, __amdgpu_buffer_rsrc_t rb,
                                                 long ldb, int c4, int nchunk, int wave, int lane) {
     const int c = c4 < nchunk ? c4 : c4 % nchunk;
-    const int blk = 8 * c + wave, row = blk * 8 + (lane >> 3);
-    const int ch = (lane & 7) ^ vswz(row);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, LDS_PTR(void, imgA + blk * 1024), 16, (int)(((long)row * lda + ch * 8) * 2), 0, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, LDS_PTR(void, imgB + blk * 1024), 16, (int)(((long)row * ldb + ch * 8) * 2), 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 8 / NW; ++i) {
+        const int blk = 8 * c + wave + NW * i, row = blk * 8 + (lane >> 3);
+        const int ch = (lane & 7) ^ vswz(row);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, LDS_PTR(void, imgA + blk * 1024), 16, (int)(((long)row * lda + ch * 8) * 2), 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, LDS_PTR(void, imgB + blk * 1024), 16, (int)(((long)row * ldb + ch * 8) * 2), 0, 0, 0);
+    }
 }
 // 256 dwords (one per row), element i at src[i * stride]; wave w brings rows 64 (w & 3) .. (waves 4-7 repeat 0-3)
 __device__ __forceinline__ void dma_issue_scalars(void* dst, const void* src, int stride, int nvalid, int wave, int lane) {
@@ -583,9 +587,11 @@ __device__ __forceinline__ void dma_issue_scalars(void* dst, const void* src, in
 // Streaming schedule shared by the three kernels: chunks 0 and 1 are requested in the prologue, chunk c + 2 right
 // after the barrier that publishes chunk c.  Before that barrier a wave waits until only its two youngest requests
 // (chunk c + 1) are outstanding -- or none, for the last of the four.
+template <int NW = 8>
 __device__ __forceinline__ void dma_wait_chunk(int c) {
-    if (c < 3) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (c >= 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (NW == 8) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
 }
 // workgroup barrier WITHOUT the release fence of __syncthreads(): the fence would drain every outstanding LDS-DMA
 // request (vmcnt(0)) and serialise the streamed chunks; LDS stores of this wave are drained explicitly
@@ -595,11 +601,12 @@ __device__ __forceinline__ void raw_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // Only words at or below the diagonal of rows < Tn are ever read (a word is one work item: compacted index i ->
 // row-major enumeration of the pairs (row, w <= row / 32), 4 x 32 rows + 8 ... per 32-row band).
 constexpr int MASK_BITS = 12;          // keep probability in units of 2^-12
+template <int NTHR = 512>
 __device__ __forceinline__ void gen_keep_mask(uint32_t* sMask, uint32_t bh, int Tn, uint32_t seed, uint32_t keepq, int tid) {
     // band k (rows 32 k .. 32 k + 31) has k + 1 words per row: items before band k = 32 * k (k + 1) / 2
     const int nband = (Tn + 31) >> 5, total = 16 * nband * (nband + 1);
 #pragma unroll 1
-    for (int i = tid; i < total; i += 512) {
+    for (int i = tid; i < total; i += NTHR) {
         int k = 0;
         while (16 * (k + 1) * (k + 2) <= i) ++k;             // at most 8 steps
         const int j = i - 16 * k * (k + 1), row = 32 * k + j / (k + 1), w = j % (k + 1);
@@ -890,8 +897,10 @@ __device__ __forceinline__ void bwd_small_keys_store(const BwdKeys& st, int t, i
     }
 }
 
-template <bool DROP>
-__global__ __launch_bounds__(512, 4) void attn_bwd_small_kv_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keep,
+// NW waves per workgroup: 8 (two workgroups = 16 waves per CU, <= 128 VGPRs) or 4 (two workgroups = 8 waves per CU, up to
+// 256 VGPRs, every wave owns two tile pairs)
+template <bool DROP, int NW>
+__global__ __launch_bounds__(64 * NW, NW / 2) void attn_bwd_small_kv_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keep,
         const bf16* __restrict__ d_out, const float* __restrict__ lse, const float* __restrict__ delta,
         bf16* __restrict__ dqkv, float* __restrict__ dbias, int bias_rows, int Tn, int nH,
         uint32_t keep16, uint32_t drop_seed, float inv_keep) {
@@ -912,29 +921,29 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_small_kv_kernel(const bf16* _
     const bf16* base = qkv + (long)b * Tn * ld + h * DH;
     const bf16* dob = d_out + (long)b * Tn * D + h * DH;
     const int ntile = (Tn + 15) >> 4, npair = (ntile + 1) >> 1;
-    const int tA = wave, tB = ntile - 1 - wave;
-    const bool work = wave < npair;
     float* const sBp = dbias ? sB : nullptr;
-    // K / V fragments of this wave's first key tile (B operands: lane holds row key = 16 t + l15, columns 32 ks + 8 g ..);
-    // the second tile's are fetched after the first sweep (registers)
+    // K / V fragments of a key tile (B operands: lane holds row key = 16 t + l15, columns 32 ks + 8 g ..)
     bf16x8 kf[2], vf[2];
-    const int ka = 16 * tA + l15, kb = 16 * tB + l15;
-    bool kokA = false, kokB = false;
+    auto load_frags = [&](int t) {
+        const int key = 16 * t + l15;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        kf[ks] = vf[ks] = zero16<bf16>();
-        if (work && ka < Tn) {
-            kf[ks] = *reinterpret_cast<const bf16x8*>(base + (long)ka * ld + D + ks * 32 + g * 8);
-            vf[ks] = *reinterpret_cast<const bf16x8*>(base + (long)ka * ld + 2 * D + ks * 32 + g * 8);
+        for (int ks = 0; ks < 2; ++ks) {
+            kf[ks] = vf[ks] = zero16<bf16>();
+            if (key < Tn) {
+                kf[ks] = *reinterpret_cast<const bf16x8*>(base + (long)key * ld + D + ks * 32 + g * 8);
+                vf[ks] = *reinterpret_cast<const bf16x8*>(base + (long)key * ld + 2 * D + ks * 32 + g * 8);
+            }
         }
-    }
+    };
+    if (wave < npair) load_frags(wave);
+    else { kf[0] = kf[1] = vf[0] = vf[1] = zero16<bf16>(); }
     const __amdgpu_buffer_rsrc_t rq = rows_rsrc(base, ld, Tn), ro = rows_rsrc(dob, D, Tn);
     dma_issue_scalars(sKeep, keep + (long)b * Tn, 1, Tn, wave, lane);
     dma_issue_scalars(sLse, lse + ((long)b * nH + h) * Tn, 1, Tn, wave, lane);
     dma_issue_scalars(sDel, delta + (long)b * Tn * nH + h, nH, Tn, wave, lane);
-    dma_issue_chunk(sQ, rq, ld, sO, ro, D, 0, nchunk, wave, lane);
-    dma_issue_chunk(sQ, rq, ld, sO, ro, D, 1, nchunk, wave, lane);
-    if constexpr (DROP) gen_keep_mask(sMask, (uint32_t)(b * nH + h), Tn, drop_seed, keep16, tid);
+    dma_issue_chunk<NW>(sQ, rq, ld, sO, ro, D, 0, nchunk, wave, lane);
+    dma_issue_chunk<NW>(sQ, rq, ld, sO, ro, D, 1, nchunk, wave, lane);
+    if constexpr (DROP) gen_keep_mask<64 * NW>(sMask, (uint32_t)(b * nH + h), Tn, drop_seed, keep16, tid);
     // first use of the plain loads: a counted wait here instead of a full drain inside the loop
     asm volatile("" :: "v"(kf[0]), "v"(kf[1]), "v"(vf[0]), "v"(vf[1]));
     BwdKeys st;
@@ -942,44 +951,49 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_small_kv_kernel(const bf16* _
     for (int i = 0; i < 4; ++i) st.dk[i] = st.dv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int nqb = (Tn + 31) >> 5;
     const float ik_scale = inv_keep * 0.125f;
-    // tile A (low keys) sweeps the query blocks from its diagonal on as they land; tile B (high keys, a short range
-    // at the end) runs afterwards on resident data
+    // The wave's first tile (low keys: the longest sweep) takes the query blocks from its diagonal on as they land;
+    // every later tile runs on resident data.
+    {
+        const int tA = wave;
+        const bool work = wave < npair;
 #pragma unroll 1
-    for (int c = 0; c < nchunk; ++c) {
-        dma_wait_chunk(c);
-        raw_barrier();
-        if (c < 2) dma_issue_chunk(sQ, rq, ld, sO, ro, D, c + 2, nchunk, wave, lane);
-        if (c == 0) {
-            if (tid < 128) sB[tid] = 0.f;
-            if (tid < 256) { sLse[tid] *= LOG2E; sDel[tid] *= 0.125f; }
-            kokA = sKeep[ka & 255] != 0;
-            kokB = sKeep[kb & 255] != 0;
+        for (int c = 0; c < nchunk; ++c) {
+            dma_wait_chunk<NW>(c);
             raw_barrier();
-        }
-#pragma unroll 1
-        for (int qb = 2 * c; qb < 2 * c + 2 && qb < nqb; ++qb)
-            if (work && qb >= ((16 * tA) >> 5))
-                bwd_small_keys_block<DROP>(st, sQ, sO, sLse, sDel, sMask, kf, vf, tA, 32 * qb, lane, ik_scale);
-    }
-    if (work) {
-        if (tA != tB) {
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                kf[ks] = vf[ks] = zero16<bf16>();
-                if (kb < Tn) {
-                    kf[ks] = *reinterpret_cast<const bf16x8*>(base + (long)kb * ld + D + ks * 32 + g * 8);
-                    vf[ks] = *reinterpret_cast<const bf16x8*>(base + (long)kb * ld + 2 * D + ks * 32 + g * 8);
-                }
+            if (c < 2) dma_issue_chunk<NW>(sQ, rq, ld, sO, ro, D, c + 2, nchunk, wave, lane);
+            if (c == 0) {
+                if (tid < 128) sB[tid] = 0.f;
+                for (int i = tid; i < 256; i += 64 * NW) { sLse[i] *= LOG2E; sDel[i] *= 0.125f; }
+                raw_barrier();
             }
+#pragma unroll 1
+            for (int qb = 2 * c; qb < 2 * c + 2 && qb < nqb; ++qb)
+                if (work && qb >= ((16 * tA) >> 5))
+                    bwd_small_keys_block<DROP>(st, sQ, sO, sLse, sDel, sMask, kf, vf, tA, 32 * qb, lane, ik_scale);
         }
-        bwd_small_keys_store(st, tA, lane, b, h, Tn, nH, inv_keep, kokA, dqkv, sBp);
+    }
+#pragma unroll 1
+    for (int pi = 0; pi < 8 / NW; ++pi) {
+        const int p = wave + NW * pi;
+        if (p >= npair) break;
+        const int tA = p, tB = ntile - 1 - p;
+        if (pi > 0) {
+            load_frags(tA);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) st.dk[i] = st.dv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+            for (int qb = (16 * tA) >> 5; qb < nqb; ++qb)
+                bwd_small_keys_block<DROP>(st, sQ, sO, sLse, sDel, sMask, kf, vf, tA, 32 * qb, lane, ik_scale);
+        }
+        if (tA != tB) load_frags(tB);
+        bwd_small_keys_store(st, tA, lane, b, h, Tn, nH, inv_keep, sKeep[(16 * tA + l15) & 255] != 0, dqkv, sBp);
         if (tA != tB) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) st.dk[i] = st.dv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
             for (int qb = (16 * tB) >> 5; qb < nqb; ++qb)
                 bwd_small_keys_block<DROP>(st, sQ, sO, sLse, sDel, sMask, kf, vf, tB, 32 * qb, lane, ik_scale);
-            bwd_small_keys_store(st, tB, lane, b, h, Tn, nH, inv_keep, kokB, dqkv, sBp);
+            bwd_small_keys_store(st, tB, lane, b, h, Tn, nH, inv_keep, sKeep[(16 * tB + l15) & 255] != 0, dqkv, sBp);
         }
     }
     if (dbias) {
@@ -1255,8 +1269,10 @@ extern "C" int mmtg_attn_bwd(int dtype, const void* qkv, const int* keep, const 
         static bool attr_small = false;
         if (!attr_small) {
             const int shm = (int)small_smem(SM_MAXT);
-            if (hipFuncSetAttribute((const void*)attn_bwd_small_kv_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, shm) != hipSuccess ||
-                hipFuncSetAttribute((const void*)attn_bwd_small_kv_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, shm) != hipSuccess ||
+            if (hipFuncSetAttribute((const void*)attn_bwd_small_kv_kernel<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, shm) != hipSuccess ||
+                hipFuncSetAttribute((const void*)attn_bwd_small_kv_kernel<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, shm) != hipSuccess ||
+                hipFuncSetAttribute((const void*)attn_bwd_small_kv_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, shm) != hipSuccess ||
+                hipFuncSetAttribute((const void*)attn_bwd_small_kv_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, shm) != hipSuccess ||
                 hipFuncSetAttribute((const void*)attn_bwd_small_q_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, shm) != hipSuccess ||
                 hipFuncSetAttribute((const void*)attn_bwd_small_q_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, shm) != hipSuccess)
                 MMTG_FAIL(MMTG_ERR_HIP, "attn_bwd: cannot raise dynamic LDS");
@@ -1266,13 +1282,21 @@ extern "C" int mmtg_attn_bwd(int dtype, const void* qkv, const int* keep, const 
         const unsigned th16 = small_keep16(drop_thresh);
         const float ik16 = small_inv_keep(th16);
         const size_t shm = small_smem(T);
+        // dK/dV kernel: with dropout the 4-wave build (160 VGPRs, no spills, each wave two tile pairs) wins (117 vs 135 us for
+        // backward + delta in isolation); without, the 8-wave build does (106 vs 111).  MMTG_ATTN_KV_NW=4|8 forces one.
+        static const int kv_nw = getenv("MMTG_ATTN_KV_NW") ? atoi(getenv("MMTG_ATTN_KV_NW")) : 0;
+        const bool kv4 = kv_nw ? kv_nw == 4 : th16 < 4096u;
         if (th16 < 4096u) {
-            hipLaunchKernelGGL(attn_bwd_small_kv_kernel<true>, dim3(B * nH), dim3(512), shm, s, (const bf16*)qkv, keep, (const bf16*)dout, lse,
+            if (kv4) hipLaunchKernelGGL((attn_bwd_small_kv_kernel<true, 4>), dim3(B * nH), dim3(256), shm, s, (const bf16*)qkv, keep, (const bf16*)dout, lse,
+                               delta, (bf16*)dqkv, bias_dst, bias_rows, T, nH, th16, drop_seed, ik16);
+            else hipLaunchKernelGGL((attn_bwd_small_kv_kernel<true, 8>), dim3(B * nH), dim3(512), shm, s, (const bf16*)qkv, keep, (const bf16*)dout, lse,
                                delta, (bf16*)dqkv, bias_dst, bias_rows, T, nH, th16, drop_seed, ik16);
             hipLaunchKernelGGL(attn_bwd_small_q_kernel<true>, dim3(B * nH), dim3(512), shm, s, (const bf16*)qkv, keep, (const bf16*)dout, lse,
                                delta, (bf16*)dqkv, bias_dst, bias_rows, T, nH, th16, drop_seed, ik16);
         } else {
-            hipLaunchKernelGGL(attn_bwd_small_kv_kernel<false>, dim3(B * nH), dim3(512), shm, s, (const bf16*)qkv, keep, (const bf16*)dout, lse,
+            if (kv4) hipLaunchKernelGGL((attn_bwd_small_kv_kernel<false, 4>), dim3(B * nH), dim3(256), shm, s, (const bf16*)qkv, keep, (const bf16*)dout, lse,
+                               delta, (bf16*)dqkv, bias_dst, bias_rows, T, nH, 0u, drop_seed, 1.0f);
+            else hipLaunchKernelGGL((attn_bwd_small_kv_kernel<false, 8>), dim3(B * nH), dim3(512), shm, s, (const bf16*)qkv, keep, (const bf16*)dout, lse,
                                delta, (bf16*)dqkv, bias_dst, bias_rows, T, nH, 0u, drop_seed, 1.0f);
             hipLaunchKernelGGL(attn_bwd_small_q_kernel<false>, dim3(B * nH), dim3(512), shm, s, (const bf16*)qkv, keep, (const bf16*)dout, lse,
                                delta, (bf16*)dqkv, bias_dst, bias_rows, T, nH, 0u, drop_seed, 1.0f);
