@@ -834,9 +834,11 @@ extern "C" int mmtg_gemm(int dtype, int transA, int transB, int M, int N, int K,
         // 1.x-round grid of 128x128 tiles into one full round of the 512 workgroup slots (N = 768 at
         // M = 15104: 708 -> 474 tiles, -27 %), and for very wide outputs (LM head, -12 %).
         bool wide = (flags & MMTG_GEMM_WIDE) != 0;
-        if (!wide && !(flags & MMTG_GEMM_NO_WIDE) && !transA && !skinny && M >= 1024) {
+        // MMTG_GEMM_WIDE_RULE (A/B): 0 = never, 1 = one-round rule only, 2 = one-round rule or N >= 4096 (round 1's)
+        static const int wide_rule = getenv("MMTG_GEMM_WIDE_RULE") ? atoi(getenv("MMTG_GEMM_WIDE_RULE")) : 1;
+        if (!wide && !(flags & MMTG_GEMM_NO_WIDE) && !transA && !skinny && M >= 1024 && wide_rule) {
             const long t128 = (long)cdiv(M, 128) * cdiv(N, 128), t192 = (long)cdiv(M, 192) * cdiv(N, 128);
-            wide = (t128 > 512 && t192 <= 512) || N >= 4096;
+            wide = (t128 > 512 && t192 <= 512) || (wide_rule >= 2 && N >= 4096);
         }
         if (epi == MMTG_EPI_DGELU && aux2) {   // the fused column sums are not built into the 6-wave kernel
             MMTG_REQUIRE(!(flags & MMTG_GEMM_WIDE), "gemm: DGELU with column sums (aux2) has no 192x128 configuration");
