@@ -62,7 +62,7 @@ def test_forced_ddp_world1_equals_the_plain_trainer(tmp_path):
             rel = float((a - b).norm() / b.norm())
             assert rel < tol, (dtype, step, rel)
             assert abs(ddp[step][1] - plain[step][1]) <= (1e-6 if step == 0 else 1e-4) * abs(plain[step][1]), (dtype, step)
-            assert abs(ddp[step][2] - plain[step][2]) <= 1e-4 * abs(plain[step][2]), (dtype, step)
+            assert abs(ddp[step][2] - plain[step][2]) <= (1e-4 if step == 0 else 2e-3) * abs(plain[step][2]), (dtype, step)
         if dtype == "bf16":
             lay = res["bf16_layout"]
             n = 0
