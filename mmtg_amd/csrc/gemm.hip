@@ -371,10 +371,13 @@ __device__ __forceinline__ void mma_stage(const char* tA, const char* tB, const 
     }
 }
 
-template <bool AKS, bool BKS>
-__global__ __launch_bounds__(256, 2) void gemm_pp_kernel(GemmArgs p) {
+// TBM = 128: 4 waves, 80 KB, two workgroups per CU.  TBM = 256 (round 2): 8 waves (4 x 2 of 64x64), two 48 KB stages + 32 KB of
+// epilogue scratch = 128 KB, ONE workgroup per CU whose eight waves are in the K loop together (two MFMA-issuing waves per
+// SIMD), a quarter fewer fill bytes per FLOP than 128x128 tiles.
+template <bool AKS, bool BKS, int TBM = 128>
+__global__ __launch_bounds__(TBM * 2, 2) void gemm_pp_kernel(GemmArgs p) {
     typedef bf16 T;
-    constexpr int TBM = 128, TBN = 128, NW = 4, TM = 4, TN = 4, NBA = 4, NBB = 4;
+    constexpr int TBN = 128, NW = TBM / 32, TM = 4, TN = 4, NBA = TBM / 8 / NW, NBB = TBN / 8 / NW;
     constexpr int TA = TBM * 128, STAGE = (TBM + TBN) * 128;
     constexpr bool std_orient = AKS && BKS;
     extern __shared__ __attribute__((aligned(16))) char smem[];      // 2 stages [A | B], then NW epilogue images
@@ -667,23 +670,25 @@ int launch_dma_cfg(const GemmArgs& a, int splits, hipStream_t stream) {
 
 // persistent pipelined 128x128 kernel: one workgroup per CU slot (a multiple of 8, so that the
 // item stride keeps every item on the XCD the tile order assumes)
-template <bool AKS, bool BKS>
+template <bool AKS, bool BKS, int TBM = 128>
 int launch_pp(const GemmArgs& a, int splits, hipStream_t stream) {
     static bool attr_done = false;
-    const size_t shm = 2 * (128 + 128) * 128 + 4 * epi_scratch_bytes<4, 4>();
-    static_assert(2 * (128 + 128) * 128 + 4 * epi_scratch_bytes<4, 4>() <= 80 * 1024, "two workgroups per CU");
+    constexpr int NW = TBM / 32;
+    const size_t shm = 2 * (TBM + 128) * 128 + NW * epi_scratch_bytes<4, 4>();
+    static_assert(TBM == 256 || 2 * (128 + 128) * 128 + 4 * epi_scratch_bytes<4, 4>() <= 80 * 1024, "two workgroups per CU");
     if (!attr_done) {
-        int rc = set_lds(gemm_pp_kernel<AKS, BKS>, shm, 256, "persistent 128x128");
+        int rc = set_lds(gemm_pp_kernel<AKS, BKS, TBM>, shm, 64 * NW, TBM == 256 ? "persistent 256x128" : "persistent 128x128");
         if (rc) return rc;
         attr_done = true;
     }
     GemmArgs b = a;
     b.tiles_n = cdiv(a.N, 128);
-    b.ntiles = cdiv(a.M, 128) * b.tiles_n;
+    b.ntiles = cdiv(a.M, TBM) * b.tiles_n;
     b.nitems = b.ntiles * splits;
-    const int slots = (2 * num_cus()) & ~7;
-    dim3 grid(b.nitems < slots ? b.nitems : slots), block(256);
-    hipLaunchKernelGGL((gemm_pp_kernel<AKS, BKS>), grid, block, shm, stream, b);
+    if (TBM == 256 && !(AKS && BKS) && splits == 1 && !(a.dbg_flags & 1)) b.cbw = column_block(a, TBM, 128, num_cus());
+    const int slots = ((TBM == 256 ? 1 : 2) * num_cus()) & ~7;
+    dim3 grid(b.nitems < slots ? b.nitems : slots), block(64 * NW);
+    hipLaunchKernelGGL((gemm_pp_kernel<AKS, BKS, TBM>), grid, block, shm, stream, b);
     return MMTG_OK;
 }
 
@@ -713,6 +718,10 @@ int launch_dma(const GemmArgs& a, int transA, int transB, int splits, int skinny
         if (!transA && !transB) return launch_occ4<false, true>(a, splits, stream);
         if (a.epi == MMTG_EPI_SPLIT) return launch_occ4<true, true, true>(a, splits, stream);
         return launch_occ4<true, true>(a, splits, stream);
+    }
+    if (persist && !wide && !skinny && (a.dbg_flags & 32)) {      // 256x128 persistent (NT / NN)
+        if (!transA && transB) return launch_pp<false, false, 256>(a, splits, stream);
+        if (!transA && !transB) return launch_pp<false, true, 256>(a, splits, stream);
     }
     if (persist && !wide && !skinny) {
         if (!transA && transB) return launch_pp<false, false>(a, splits, stream);
@@ -800,7 +809,7 @@ extern "C" int mmtg_gemm(int dtype, int transA, int transB, int M, int N, int K,
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldaux = ldaux;
     a.epi = epi; a.out_f32 = out_f32; a.use_tr = !(flags & MMTG_GEMM_NO_TR);
     a.trace = g_trace; a.trace_n = g_trace_n;
-    a.dbg_flags = ((flags & MMTG_GEMM_ROW_ORDER) ? 1 : 0) | ((flags & MMTG_GEMM_COL_BLOCK) ? 16 : 0);     // bit 1 (value 2): single-stage kernel, set below
+    a.dbg_flags = ((flags & MMTG_GEMM_ROW_ORDER) ? 1 : 0) | ((flags & MMTG_GEMM_COL_BLOCK) ? 16 : 0) | ((flags & MMTG_GEMM_P256) ? 32 : 0);     // bit 1 (value 2): single-stage kernel, set below
     a.tiles_n = cdiv(N, BN); a.alpha = alpha;
     // byte extents for the buffer descriptors of the LDS-DMA pipeline (offsets are 32-bit)
     const long esz = dtype == MMTG_F32 ? 4 : 2;
@@ -847,7 +856,19 @@ extern "C" int mmtg_gemm(int dtype, int transA, int transB, int M, int N, int K,
         // The persistent pipelined kernel is opt-in: with more 128x128 items than CU slots it measured
         // within +-3 % of the plain launch (its deferred epilogue still occupies the wave for 2.8-7 us per
         // item; timelines in profiles/r01_v4_gemm_timeline.log).
-        const bool persist = (flags & MMTG_GEMM_PERSIST) != 0;
+        bool persist = (flags & (MMTG_GEMM_PERSIST | MMTG_GEMM_P256)) != 0;
+        // 256x128 persistent kernel (round 2, MMTG_GEMM_P256): a quarter fewer fill bytes per FLOP, but ONE workgroup per CU,
+        // so every item's epilogue is exposed.  Warm and without dropout it wins on the N <= 1024, K >= 2048 products (fc2
+        // forward 88 -> 79 us, dgrad fc1 79 -> 77) and loses 20-50 % at K = 768 with N >= 2304; inside the training step
+        // (cold operands, dropout hashing in the exposed epilogue) the rule below costs +1.6 ms per step
+        // (profiles/r02_v4_gemm_p256_ab.txt), so it is OFF unless MMTG_GEMM_P256_RULE=1|2 asks for it.
+        static const int p256_rule = getenv("MMTG_GEMM_P256_RULE") ? atoi(getenv("MMTG_GEMM_P256_RULE")) : 0;
+        if (p256_rule && !persist && !transA && !skinny && !(flags & (MMTG_GEMM_WIDE | MMTG_GEMM_OCC4 | MMTG_GEMM_NO_PERSIST)) && M >= 4096 && N <= 1024 &&
+            K >= (p256_rule >= 2 ? 512 : 2048) && epi != MMTG_EPI_SPLIT && epi != MMTG_EPI_ROWDOT && epi != MMTG_EPI_DGELU) {
+            persist = true;
+            wide = false;
+            a.dbg_flags |= 32;
+        }
         // Single-stage kernel at four workgroups per CU (measured, profiles/r01_v6_gemm_per_shape.log):
         // weight gradients always (with the split counts of engine._wgrad_splits), forward / dgrad
         // products whose 128x128 tiles make more than one round of the 2-per-CU kernel (qkv 84 -> 68 us,

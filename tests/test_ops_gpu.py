@@ -128,7 +128,10 @@ def test_gemm_persistent_pipeline_matches_plain(layout, K):
         A, B, tA, tB = a.t().contiguous(), b, True, False
     A, B = A.to(DEV), B.to(DEV)
     outs = []
-    for flags in (hip.GEMM_NO_PERSIST | hip.GEMM_NO_WIDE, hip.GEMM_PERSIST | hip.GEMM_NO_WIDE):
+    variants = [hip.GEMM_NO_PERSIST | hip.GEMM_NO_WIDE, hip.GEMM_PERSIST | hip.GEMM_NO_WIDE]
+    if layout != "TN":
+        variants.append(hip.GEMM_P256 | hip.GEMM_NO_WIDE)        # 256x128 tiles, 8 waves, one workgroup per CU (323 items on 256 slots)
+    for flags in variants:
         if layout == "TN":
             C = torch.zeros(M, N, device=DEV, dtype=torch.float32)
             hip.gemm(A, B, C, M, N, K, transA=True, transB=False, epi=hip.EPI_ATOMIC, splits=splits, flags=flags)
@@ -147,8 +150,9 @@ def test_gemm_persistent_pipeline_matches_plain(layout, K):
         close(outs[1][0], outs[0][0], torch.float32, K, "persistent TN vs plain")
     else:
         close(outs[1][2], ref, dtype, K, "persistent %s vs fp32" % layout)
-        for x, y in zip(outs[0], outs[1]):
-            assert torch.equal(x, y)
+        for other in outs[1:]:
+            for x, y in zip(outs[0], other):
+                assert torch.equal(x, y)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
