@@ -348,6 +348,9 @@ def main():
         mcfg = make_model_cfgs(seq_len=S)
         dcfg = data_config(seq_len=S)
         gcfg = gpt2_config(n_layer=args.layers, vocab_size=V)          # GPT-2 base (zh vocab), pdrop 0.1 x3
+        if os.environ.get("MMTG_BENCH_PDROP"):                         # measurement switch (what dropout costs); not the benchmark
+            pd = float(os.environ["MMTG_BENCH_PDROP"])
+            gcfg.update(embd_pdrop=pd, attn_pdrop=pd, resid_pdrop=pd)
     torch.manual_seed(0)                                           # identical replicas on every rank
     model = MMTG(mcfg, dcfg, V, train_flag=True, gpt2_config=gcfg, compute_dtype=args.dtype,
                  token_table=synth.make_token_table(V, seed=2))

@@ -43,6 +43,14 @@ __device__ __forceinline__ void load8(const bf16* p, float (&x)[8]) {
     for (int e = 0; e < 8; ++e) x[e] = (float)a[e];
 }
 
+// exp for the log-sum-exp: libm expf in the fp32 parity mode; for bf16-stored logits the hardware exponential (v_exp_f32,
+// 1 ulp -- far below the bf16 rounding of the inputs): libm's ~20 instructions per element made the pass VALU-bound
+// (150 us for 406 MB; round 2)
+template <typename LT> __device__ __forceinline__ float lse_exp(float x) {
+    if constexpr (sizeof(LT) == 2) return __builtin_amdgcn_exp2f(x * 1.4426950408889634f);
+    else return expf(x);
+}
+
 // one block per row: lse[m], nll[m] = lse - logit[label].  LT = storage type of the logits (fp32, or
 // bf16 in the bf16 training path where the LM-head product stores them like every other activation).
 template <typename LT>
@@ -62,17 +70,17 @@ __global__ __launch_bounds__(256) void row_lse_kernel(const LT* __restrict__ log
         float x[8];
         load8(row + v, x);
         const float m8 = fmaxf(fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])), fmaxf(fmaxf(x[4], x[5]), fmaxf(x[6], x[7])));
-        if (m8 > mx) { sm *= expf(mx - m8); mx = m8; }
+        if (m8 > mx) { sm *= lse_exp<LT>(mx - m8); mx = m8; }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) sm += expf(x[e] - mx);
+        for (int e = 0; e < 8; ++e) sm += lse_exp<LT>(x[e] - mx);
     }
     for (int v = V8 + threadIdx.x; v < V; v += 256) {
         const float x = (float)row[v];
-        if (x > mx) { sm *= expf(mx - x); mx = x; }
-        sm += expf(x - mx);
+        if (x > mx) { sm *= lse_exp<LT>(mx - x); mx = x; }
+        sm += lse_exp<LT>(x - mx);
     }
     const float gmx = block_max(mx, sh);
-    sm = block_sum(mx == -INFINITY ? 0.f : sm * expf(mx - gmx), sh);
+    sm = block_sum(mx == -INFINITY ? 0.f : sm * lse_exp<LT>(mx - gmx), sh);
     mx = gmx;
     if (threadIdx.x == 0) {
         const float l = mx + logf(sm);

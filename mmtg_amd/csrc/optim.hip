@@ -40,7 +40,31 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
         const float nrm = sqrtf(*normsq) * gscale;
         coef *= fminf(1.0f, max_norm / (nrm + 1e-6f));
     }
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    // 16-byte vectors (four parameters per lane and pass); the flat buffers are 16-byte aligned and n is a multiple of 4
+    // for every layout the engine builds (a scalar tail covers anything else)
+    const bool vec_ok = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+                          reinterpret_cast<uintptr_t>(v)) & 15) == 0 && (reinterpret_cast<uintptr_t>(pc) & 7) == 0;
+    const long n4 = vec_ok ? n >> 2 : 0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const f32x4 g4 = reinterpret_cast<const f32x4*>(g)[i];
+        f32x4 m4 = reinterpret_cast<f32x4*>(m)[i], v4 = reinterpret_cast<f32x4*>(v)[i], p4 = reinterpret_cast<f32x4*>(p)[i];
+        bf16x4 c4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gi = g4[e] * coef;
+            const float mi = b1 * m4[e] + (1.f - b1) * gi;
+            const float vi = b2 * v4[e] + (1.f - b2) * gi * gi;
+            float pi = p4[e] - step_size * (mi / (sqrtf(vi) + eps));
+            if (wd > 0.f) pi -= lr * wd * pi;
+            m4[e] = mi; v4[e] = vi; p4[e] = pi;
+            c4[e] = (bf16)pi;
+        }
+        reinterpret_cast<f32x4*>(m)[i] = m4;
+        reinterpret_cast<f32x4*>(v)[i] = v4;
+        reinterpret_cast<f32x4*>(p)[i] = p4;
+        if (pc) reinterpret_cast<bf16x4*>(pc)[i] = c4;
+    }
+    for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         const float gi = g[i] * coef;
         const float mi = b1 * m[i] + (1.f - b1) * gi;
         const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
@@ -148,7 +172,7 @@ extern "C" int mmtg_adamw(float* p, const float* g, float* m, float* v, void* p_
     // transformers.AdamW(correct_bias=True): step_size = lr * sqrt(1-b2^t) / (1-b1^t)
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
     const float step_size = (float)((double)lr * sqrt(bc2) / bc1);
-    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, s, p, g, m, v, (bf16*)p_bf16, n, lr, beta1, beta2,
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, s, p, g, m, v, (bf16*)p_bf16, n, lr, beta1, beta2,
                        eps, wd, step_size, normsq, max_norm, grad_scale, count);
     MMTG_LAUNCH_CHECK("adamw");
     return MMTG_OK;
