@@ -232,6 +232,12 @@ int mmtg_beta_fuse_bwd(int dtype, const void* topic, const void* img, const void
                        float* dtopic, void* dimg, void* dtxt, float* datt_w, float* datt_b,
                        int B, int S, int H, void* stream);
 
+/* Software prefetch (no counterpart in the reference): streams `bytes` of `src` through the cache hierarchy with
+ * `workgroups` workgroups of 16-byte loads so that they sit in the 256 MB Infinity Cache when the next kernel of the
+ * backward pass reads them (saved activations are cold by then).  Launched on a side stream, gated by events; `sink` is a
+ * 4-byte device scratch that is never written in practice.                                                       */
+int mmtg_prefetch(const void* src, long bytes, int workgroups, void* sink, void* stream);
+
 /* ---------------------------------------------------------------- optimizer (train.py:194-197)
  * sumsq: *out += sum x^2 (global grad-norm partial).                          */
 int mmtg_sumsq(const float* x, long n, float* out, void* stream);

@@ -828,8 +828,14 @@ extern "C" int mmtg_gemm(int dtype, int transA, int transB, int M, int N, int K,
     a.drop_thresh = drop_thresh; a.drop_seed = drop_seed;
     a.drop_inv_keep = drop_thresh ? (float)(4294967296.0 / (4294967296.0 - (double)drop_thresh)) : 1.0f;
     hipStream_t s = (hipStream_t)stream;
-    ProfScope prof(dtype == MMTG_F32 ? MMTG_PROF_GEMM_F32 : MMTG_PROF_GEMM_BF16, s, 2.0 * M * N * (double)K,
-                   (double)(dtype == MMTG_F32 ? 4 : 2) * ((double)M * K + (double)N * K) + (double)M * N * (out_f32 ? 4 : (dtype == MMTG_F32 ? 4 : 2)));
+    // algorithmic bytes of the launch: A and B once, C once, plus what the fused epilogue must read or write by its
+    // definition -- the residual / saved pre-activation / attention context it consumes (aux) and the pre-activation it
+    // emits (GELU's aux2).  Extra split-K slabs are a design choice, not algorithmic bytes: C counts once.
+    const double esz_ = dtype == MMTG_F32 ? 4 : 2;
+    double alg_bytes = esz_ * ((double)M * K + (double)N * K) + (double)M * N * (out_f32 ? 4 : esz_);
+    if (epi == MMTG_EPI_RESID || epi == MMTG_EPI_DGELU || epi == MMTG_EPI_DTANH || epi == MMTG_EPI_ROWDOT) alg_bytes += esz_ * (double)M * N;
+    if (epi == MMTG_EPI_GELU) alg_bytes += esz_ * (double)M * N;
+    ProfScope prof(dtype == MMTG_F32 ? MMTG_PROF_GEMM_F32 : MMTG_PROF_GEMM_BF16, s, 2.0 * M * N * (double)K, alg_bytes);
     a.ntiles = cdiv(M, BM) * cdiv(N, BN);
     a.nitems = a.ntiles * splits;
     dim3 grid(a.nitems);

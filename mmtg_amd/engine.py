@@ -170,6 +170,7 @@ _WG_NUM = float(_os.environ.get("MMTG_WGRAD_NUM", "760"))     # tuning knobs of 
 _WG_CAP = int(_os.environ.get("MMTG_WGRAD_CAP", "12"))
 _NO_FEW_ROWS = bool(_os.environ.get("MMTG_NO_FEW_ROWS"))   # A/B switch: plain launches for the encoder-sized products
 _WGRAD_SLAB = not _os.environ.get("MMTG_WGRAD_ATOMIC")     # A/B switch: fp32-atomic weight gradients everywhere
+_PREFETCH = int(_os.environ.get("MMTG_PREFETCH", "0"))      # backward: Infinity-Cache prefetch of saved activations on a side stream (workgroups; 0 = off)
 
 
 def _wgrad_splits(M, N, K, occ4=False, slots=512, t_iter=1.1, t_fixed=6.0):
@@ -257,6 +258,7 @@ class Engine:
         self.opt_v = None
         self.normsq = torch.zeros(1, device=self.dev)
         self.bucket_hook = None   # callable(pack_index) fired as packs of gradients become final
+        self._pf_stream = None
 
     # ---------------------------------------------------------------- buffers / views
     def set_table(self, table):
@@ -646,6 +648,23 @@ class Engine:
         return dl
 
     # ---------------------------------------------------------------- backward
+    def _prefetch(self, *tensors):
+        """Saved activations are cold by the time the backward reads them (4.5 GB of activations against a 256 MB
+        Infinity Cache).  Called right before kernel k is enqueued: a side stream waits for that point and pulls the
+        operands of the kernels after k into the cache while k runs (mmtg_prefetch).  MEASURED NEGATIVE (round 2, same box):
+        16.41 ms per step without, 17.2-17.7 with 64 / 256 / 1024 prefetch workgroups -- the side-stream kernels take
+        workgroup slots and L2 bandwidth from the product they run beside -- so it is off unless MMTG_PREFETCH=<workgroups>."""
+        if not _PREFETCH:
+            return
+        if self._pf_stream is None:
+            self._pf_stream = torch.cuda.Stream(device=self.dev, priority=-1)
+            self._pf_sink = torch.zeros(1, device=self.dev, dtype=torch.int32)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._pf_stream.wait_event(ev)
+        for t in tensors:
+            hip.prefetch(t, self._pf_sink, _PREFETCH, stream=self._pf_stream)
+
     def _ready(self, pack):
         if self.bucket_hook is not None:
             self.bucket_hook(pack)
@@ -694,12 +713,14 @@ class Engine:
             # (the dGELU epilogue also emits the column sums of du per 64-row band: a [M/64, 4D] reduction
             #  gives the c_fc bias gradient instead of a pass over du)
             bands = self.buf("d_u_bands", ((M + 63) // 64, 4 * D), torch.float32)
+            self._prefetch(m2, gact)            # while dGELU runs: the operands of the two weight gradients after it
             self._dgrad(dy, p + "mlp.c_proj.weight", du, M, "conv1d", epi=hip.EPI_DGELU, aux=u, ldaux=4 * D, aux2=bands)
             hip.colsum(bands, bands.shape[0], 4 * D, self.G(p + "mlp.c_fc.bias"))
             # (both consumers of du run while it is still in the Infinity Cache; the c_proj weight gradient, whose
             #  operands come from HBM either way, goes last -- it must precede the LayerNorm backward, which reuses dmask)
             self._dgrad(du, p + "mlp.c_fc.weight", dm, M, "conv1d")
             self._wgrad(m2, du, p + "mlp.c_fc.weight", None, M, "conv1d")
+            self._prefetch(xmid, ctx)           # while the c_proj weight gradient runs: LayerNorm input, attention context
             self._wgrad(gact, dy, p + "mlp.c_proj.weight", None, M, "conv1d")
             hip.layernorm_bwd(dm, xmid, self.P(p + "ln_2.weight"), mu2, rs2, dx, dx2,
                               self.G(p + "ln_2.weight"), self.G(p + "ln_2.bias"), M, D,
@@ -713,11 +734,15 @@ class Engine:
                 self._dgrad(dy, p + "attn.c_proj.weight", dctx, M, "conv1d", epi=hip.EPI_ROWDOT, aux=ctx, ldaux=D, aux2=delta)
             else:
                 self._dgrad(dy, p + "attn.c_proj.weight", dctx, M, "conv1d")
+            self._prefetch(qkv)                 # while the c_proj weight gradient runs: the attention backward's rows
             self._wgrad(ctx, dy, p + "attn.c_proj.weight", None, M, "conv1d")
             hip.attn_bwd(qkv, a["keep"], ctx, dctx, lse, delta, dq32, dqkv, B, T, sh.nH, D // sh.nH,
                          drop_p=pa, drop_seed=s[0], delta_ready=fuse_delta, dbias=self.G(p + "attn.c_attn.bias"),
                          dbias_ws=self.buf("attn_dbias_rows", (hip.attn_bwd_bias_rows(B, T, self.dtype), 3 * D), torch.float32))
+            self._prefetch(a1, xin)             # while the c_attn dgrad runs: its weight gradient's operand, LayerNorm input
             self._dgrad(dqkv, p + "attn.c_attn.weight", da, M, "conv1d")
+            if l > 0:
+                self._prefetch(a["layers"][l - 1][11])      # the next layer's saved pre-activation (dGELU)
             self._wgrad(a1, dqkv, p + "attn.c_attn.weight", None, M, "conv1d")
             if l > 0:
                 hip.layernorm_bwd(da, xin, self.P(p + "ln_1.weight"), mu1, rs1, dx2, dx,

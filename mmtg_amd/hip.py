@@ -54,6 +54,7 @@ _SIGS = {
     "mmtg_alpha_attn_bwd": ([_i, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _vp], _i),
     "mmtg_beta_fuse_fwd": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp], _i),
     "mmtg_beta_fuse_bwd": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp], _i),
+    "mmtg_prefetch": ([_vp, _l, _i, _vp, _vp], _i),
     "mmtg_sumsq": ([_vp, _l, _vp, _vp], _i),
     "mmtg_adamw": ([_vp, _vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _i, _vp, _f, _f, _vp, _vp], _i),
     "mmtg_cast_f32_to": ([_i, _vp, _vp, _l, _vp], _i),
@@ -324,6 +325,12 @@ def beta_fuse_bwd(topic, img, txt, att_w, a, d_o, dtopic, dimg, dtxt, datt_w, da
 
 
 # ------------------------------------------------------------------ optimizer / casts
+def prefetch(t, sink, workgroups=256, stream=None):
+    """Pull tensor `t` into the Infinity Cache on `stream` (default: the current one)."""
+    _check(lib().mmtg_prefetch(_p(t), t.numel() * t.element_size(), int(workgroups), _p(sink),
+                               _stream() if stream is None else stream.cuda_stream), "prefetch")
+
+
 def sumsq(x, n, out):
     _check(lib().mmtg_sumsq(_p(x), n, _p(out), _stream()), "sumsq")
 
