@@ -45,10 +45,11 @@ enum {
     MMTG_EPI_ROWDOT = 7, /* C = acc ; aux2(f32)[m, n/64] = sum over each 64-column group of C * aux
                             (attention backward's delta = rowsum(dO * O) per head, fused into the
                             GEMM that produces dO; N % 64 == 0, no bias) */
-    MMTG_EPI_SPLIT = 8   /* deterministic split-K for small M (decode): C is fp32 [splits][M][ldc]; K split s
+    MMTG_EPI_SPLIT = 8,  /* deterministic split-K for small M (decode): C is fp32 [splits][M][ldc]; K split s
                             stores its raw partial product in slab s (plain stores; out_f32, no bias);
                             mmtg_splitk_finish sums the slabs in order and applies bias / activation /
                             residual (/ LayerNorm) */
+    MMTG_EPI_TANH_ADD = 9 /* C = tanh(acc + bias + aux[aux_rows[m]]) -- mmtg_gemm_gather only */
 };
 #define MMTG_GEMM_NO_TR 1 /* flags: gather K-strided bf16 fragments without ds_read_b64_tr_b16 */
 #define MMTG_GEMM_REGSTAGE 2 /* flags: register-staged v1 pipeline instead of the LDS-DMA one (bf16) */
@@ -100,6 +101,20 @@ int mmtg_gemm(int dtype, int transA, int transB, int M, int N, int K,
               const float* bias, int epi, const void* aux, long ldaux, void* aux2,
               int out_f32, float alpha, int splits, unsigned drop_thresh, unsigned drop_seed,
               int flags, void* stream);
+
+/* Products whose operand rows are GATHERED from a table by index -- the multi-modal conditioning front end of
+ * GPT2_Decoder.forward (model.py:254-281) without materialising X[m] = E[id_m] + c[b, seg_m] (62 MB at B = 64):
+ *   mode 0 (forward):  C[M, N] = epi( E[rows[m], :] . B[N, K]^T + bias [+ aux[aux_rows[m], :]] ), epi in {NONE, TANH, TANH_ADD}.
+ *                      By linearity (E[id] + c) W1^T = E[id] W1^T + (c W1^T)[b, seg]: the caller computes the small product
+ *                      c W1^T once ([B*S + 1, N], last row zero) and passes it as aux with aux_rows[m] = b*S + seg or B*S.
+ *                      The table row of output row m enters the LDS-DMA as the lane's source offset.
+ *   mode 1 (weight gradient):  slabs C[s][M, N] (fp32, MMTG_EPI_SPLIT layout) = A[k, M]^T . E[rows[k], :] over K split s
+ *                      (A = d(pre-activation) [K = tokens, M], K-strided; the table rows of a K tile are looked up one tile ahead);
+ *                      mmtg_slab_sum finishes it; the c-part of the gradient is the small product segment_sum(dA)^T . c.
+ * bf16 only; K % 64 == 0 (mode 0); rows / aux_rows: int32 device arrays; E: [*, ldb_or_lda] row-major, below 2 GiB.        */
+int mmtg_gemm_gather(int mode, int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C, long ldc,
+                     const float* bias, int epi, const int* rows, int table_rows, const void* aux, long ldaux, const int* aux_rows,
+                     int splits, void* stream);
 
 /* Diagnostic timeline of the bf16 LDS-DMA GEMM kernels (tools/gemm_timeline.py): while `buf` is
  * non-null, wave 0 of workgroup w < max_wgs of every such launch writes 6 x u64 at buf + 48*w --

@@ -164,6 +164,21 @@ __device__ __forceinline__ void dma_issue_tile(const GemmArgs& p, __amdgpu_buffe
     }
 }
 
+// full K tile with precomputed lane offsets (the gathered-row forward product)
+template <int TBM, int TBN, int NBA, int NBB, int NW>
+__device__ __forceinline__ void dma_issue_full(__amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb, const int (&va)[NBA], const int (&vb)[NBB],
+                                               int sa, int sb, char* stage, int TA, bool live, int wave) {
+    if (!live) return;
+#pragma unroll
+    for (int i = 0; i < NBA; ++i)
+        if (wave + NW * i < TBM / 8)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, LDS_PTR(void, stage + (wave + NW * i) * 1024), 16, va[i], sa, 0, 0);
+#pragma unroll
+    for (int i = 0; i < NBB; ++i)
+        if (wave + NW * i < TBN / 8)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, LDS_PTR(void, stage + TA + (wave + NW * i) * 1024), 16, vb[i], sb, 0, 0);
+}
+
 template <int TBM, int TBN, int WM, int WN, int NBUF> struct DmaCfg {
     // two workgroups per CU when their LDS rings fit in 80 KB each.  Waves per SIMD the register
     // budget must allow: the 6 waves of a 3x2 workgroup land 2,2,1,1 on the four SIMDs and the second
@@ -177,7 +192,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 
 // NBUF-deep LDS ring: tile t+NBUF-1 is issued right after the barrier of tile t; the wait before that
 // barrier leaves the (NBUF-2) younger tiles in flight (counted vmcnt, raw s_barrier).
-template <bool AKS, bool BKS, int TBM, int TBN, int WM, int WN, int NBUF>
+template <bool AKS, bool BKS, int TBM, int TBN, int WM, int WN, int NBUF, bool GATHER = false>
 __global__ __launch_bounds__((64 * WM * WN), (DmaCfg<TBM, TBN, WM, WN, NBUF>::MINW)) void gemm_dma_kernel(GemmArgs p) {
     typedef bf16 T;
     constexpr int NW = WM * WN, WTM = TBM / WM, WTN = TBN / WN, TM = WTM / 16, TN = WTN / 16;
@@ -221,6 +236,18 @@ __global__ __launch_bounds__((64 * WM * WN), (DmaCfg<TBM, TBN, WM, WN, NBUF>::MI
     for (int i = 0; i < NBA; ++i) va[i] = dma_voff<AKS, TBM>(p.lda, m0, p.M, BK, wave + NW * i, lane);
 #pragma unroll
     for (int i = 0; i < NBB; ++i) vb[i] = dma_voff<BKS, TBN>(p.ldb, n0, p.N, BK, wave + NW * i, lane);
+    if constexpr (GATHER) {
+        // mmtg_gemm_gather mode 0: output row m reads table row gather[m] -- the row index enters the lane's SOURCE offset
+        // (K-contiguous A image: 1-KB block = 8 rows x 128 B, chunk swizzle as in dma_voff); K % 64 == 0, so the offsets
+        // are loop-invariant and only the scalar K offset advances
+        static_assert(!AKS, "gathered A rows are K-contiguous");
+        sa = kbeg * 2;
+#pragma unroll
+        for (int i = 0; i < NBA; ++i) {
+            const int r = (wave + NW * i) * 8 + (lane >> 3), c = (lane & 7) ^ (r & 7);
+            va[i] = (wave + NW * i < TBM / 8 && m0 + r < p.M) ? (int)(((long)p.gather[m0 + r] * p.lda + c * 8) * 2) : OOB;
+        }
+    }
 
     f32x4 acc[TM][TN];
 #pragma unroll
@@ -230,10 +257,15 @@ __global__ __launch_bounds__((64 * WM * WN), (DmaCfg<TBM, TBN, WM, WN, NBUF>::MI
 
     // (a __device__ helper, not a lambda: a lambda in a __global__ body is host+device to clang and
     //  the amdgcn LDS-DMA builtin inside it silently drops the kernel's host stub)
+    // (the gather instantiation has its own issue helper: a second kernel instantiating dma_issue_tile with the same
+    //  arguments trips hipcc's host pass; its K is a multiple of 64, so every tile is a full one)
 #define ISSUE_TILE(t)                                                                                          \
     do {                                                                                                       \
-        dma_issue_tile<AKS, BKS, TBM, TBN, NBA, NBB, NW>(p, ra, rb, va, vb, sa, sb, smem + ((t) % NBUF) * STAGE, TA, \
-                                                     (t), nk_full, nk, kend - kbeg, m0, n0, wave, lane, NBUF > 2); \
+        if constexpr (GATHER)                                                                                  \
+            dma_issue_full<TBM, TBN, NBA, NBB, NW>(ra, rb, va, vb, sa, sb, smem + ((t) % NBUF) * STAGE, TA, (t) < nk, wave); \
+        else                                                                                                   \
+            dma_issue_tile<AKS, BKS, TBM, TBN, NBA, NBB, NW>(p, ra, rb, va, vb, sa, sb, smem + ((t) % NBUF) * STAGE, TA, \
+                                                         (t), nk_full, nk, kend - kbeg, m0, n0, wave, lane, NBUF > 2); \
         sa += stepa;                                                                                           \
         sb += stepb;                                                                                           \
     } while (0)
@@ -491,7 +523,7 @@ __global__ __launch_bounds__(TBM * 2, 2) void gemm_pp_kernel(GemmArgs p) {
 #endif
 // SLAB (weight gradients only): instead of fp32 atomics, K split s stores its partial tile with plain
 // 16-byte stores into slab s of an fp32 workspace (MMTG_EPI_SPLIT); mmtg_slab_sum adds the slabs up.
-template <bool AKS, bool BKS, bool SLAB = false>
+template <bool AKS, bool BKS, bool SLAB = false, bool GATHER = false>
 __global__ __launch_bounds__(256, (AKS && BKS ? 4 : OCC_FWD)) void gemm_occ4_kernel(GemmArgs p) {
     typedef bf16 T;
     constexpr int TBM = 128, TBN = 128, NW = 4, TM = 4, TN = 4, BK = 64;
@@ -522,6 +554,18 @@ __global__ __launch_bounds__(256, (AKS && BKS ? 4 : OCC_FWD)) void gemm_occ4_ker
     for (int i = 0; i < NB; ++i) va[i] = dma_voff<AKS, TBM>(p.lda, m0, p.M, BK, wave + NW * i, lane);
 #pragma unroll
     for (int i = 0; i < NBB; ++i) vb[i] = dma_voff<BKS, TBN>(p.ldb, n0, p.N, BK, wave + NW * i, lane);
+    // mmtg_gemm_gather mode 1: reduction index k reads table row gather[k] (K-strided B image: 1-KB block = 4 k-rows x 256 B);
+    // the four k-rows this lane fetches per K tile are looked up one tile ahead
+    int gid[GATHER ? NBB : 1];
+    if constexpr (GATHER) {
+        static_assert(BKS, "gathered B rows are the reduction index");
+        sb = 0;
+#pragma unroll
+        for (int i = 0; i < NBB; ++i) {
+            const int k = (wave + NW * i) * 4 + (lane >> 4);
+            gid[i] = (k < klen) ? p.gather[kbeg + k] : 0;
+        }
+    }
     f32x4 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -540,12 +584,25 @@ __global__ __launch_bounds__(256, (AKS && BKS ? 4 : OCC_FWD)) void gemm_occ4_ker
             }
 #pragma unroll
             for (int i = 0; i < NBB; ++i) {
-                const int v = full ? vb[i] : dma_voff<BKS, TBN>(p.ldb, n0, p.N, krem, wave + NW * i, lane);
+                int v;
+                if constexpr (GATHER) {
+                    const int k = (wave + NW * i) * 4 + (lane >> 4), pc = lane & 15, c = pc ^ ks_swz(k);
+                    v = (k < krem && n0 + c * 8 < p.N) ? (int)(((long)gid[i] * p.ldb + n0 + c * 8) * 2) : OOB;
+                } else {
+                    v = full ? vb[i] : dma_voff<BKS, TBN>(p.ldb, n0, p.N, krem, wave + NW * i, lane);
+                }
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, LDS_PTR(void, smem + TA + (wave + NW * i) * 1024), 16, v, sb, 0, 0);
+            }
+            if constexpr (GATHER) {
+#pragma unroll
+                for (int i = 0; i < NBB; ++i) {
+                    const int k = (kt + 1) * BK + (wave + NW * i) * 4 + (lane >> 4);
+                    gid[i] = (k < klen) ? p.gather[kbeg + k] : 0;
+                }
             }
         }
         sa += stepa;
-        sb += stepb;
+        if constexpr (!GATHER) sb += stepb;
         wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();              // the tile is complete
 #pragma unroll
@@ -765,6 +822,66 @@ extern "C" int mmtg_gemm_trace(void* buf, int max_wgs) {
     MMTG_REQUIRE(!buf || max_wgs > 0, "gemm_trace: max_wgs must be positive");
     g_trace = reinterpret_cast<unsigned long long*>(buf);
     g_trace_n = buf ? max_wgs : 0;
+    return MMTG_OK;
+}
+
+extern "C" int mmtg_gemm_gather(int mode, int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C, long ldc,
+                                const float* bias, int epi, const int* rows, int table_rows, const void* aux, long ldaux,
+                                const int* aux_rows, int splits, void* stream) {
+    MMTG_REQUIRE(mode == 0 || mode == 1, "gemm_gather: mode 0 (forward) or 1 (weight gradient)");
+    MMTG_REQUIRE(M > 0 && N > 0 && K > 0 && A && B && C && rows && table_rows > 0, "gemm_gather: bad arguments");
+    MMTG_REQUIRE(MMTG_ALIGNED16(A) && MMTG_ALIGNED16(B) && MMTG_ALIGNED16(C) && lda % 8 == 0 && ldb % 8 == 0, "gemm_gather: 16-byte alignment");
+    GemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.A = A; a.B = B; a.C = C; a.bias = bias; a.aux = aux; a.aux_rows = aux_rows; a.gather = rows;
+    a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldaux = ldaux;
+    a.epi = epi; a.use_tr = 1; a.alpha = 1.0f; a.drop_inv_keep = 1.0f;
+    hipStream_t s = (hipStream_t)stream;
+    if (mode == 0) {
+        // A = the table [table_rows, lda] (rows gathered), B = weights [N, K] K-contiguous
+        MMTG_REQUIRE(K % 64 == 0 && N % 8 == 0 && ldc % 8 == 0, "gemm_gather: forward needs K %% 64 == 0 and N, ldc %% 8 == 0");
+        MMTG_REQUIRE(epi == MMTG_EPI_NONE || epi == MMTG_EPI_TANH || (epi == MMTG_EPI_TANH_ADD && aux && ldaux % 8 == 0 && MMTG_ALIGNED16(aux)),
+                     "gemm_gather: forward epilogues are NONE, TANH and TANH_ADD (with aux)");
+        const long bytesA = ((long)(table_rows - 1) * lda + K) * 2, bytesB = ((long)(N - 1) * ldb + K) * 2;
+        MMTG_REQUIRE(bytesA < 0x7FFFFF00L && bytesB < 0x7FFFFF00L, "gemm_gather: operands must stay below 2 GiB");
+        a.bytesA = (int)bytesA; a.bytesB = (int)bytesB;
+        a.kper = K;
+        a.tiles_n = cdiv(N, 128);
+        a.ntiles = cdiv(M, 128) * a.tiles_n;
+        a.nitems = a.ntiles;
+        ProfScope prof(MMTG_PROF_GEMM_BF16, s, 2.0 * M * N * (double)K, 2.0 * ((double)M * K + (double)N * K + (double)M * N));
+        static bool attr_done = false;
+        const size_t shm = 2 * (128 + 128) * 128;
+        if (!attr_done) {
+            int rc = set_lds(gemm_dma_kernel<false, false, 128, 128, 2, 2, 2, true>, shm, 256, "gather forward 128x128");
+            if (rc) return rc;
+            attr_done = true;
+        }
+        hipLaunchKernelGGL((gemm_dma_kernel<false, false, 128, 128, 2, 2, 2, true>), dim3(a.nitems), dim3(256), shm, s, a);
+    } else {
+        // A = d(pre-activation) [K, lda >= M] (K-strided), B = the table [table_rows, ldb] (k-rows gathered), C = fp32 slabs
+        MMTG_REQUIRE(epi == MMTG_EPI_SPLIT && splits >= 1 && M % 8 == 0 && N % 8 == 0 && ldc % 8 == 0, "gemm_gather: weight gradient writes MMTG_EPI_SPLIT slabs");
+        const long bytesA = ((long)(K - 1) * lda + M) * 2, bytesB = ((long)(table_rows - 1) * ldb + N) * 2;
+        MMTG_REQUIRE(bytesA < 0x7FFFFF00L && bytesB < 0x7FFFFF00L, "gemm_gather: operands must stay below 2 GiB");
+        a.bytesA = (int)bytesA; a.bytesB = (int)bytesB;
+        a.out_f32 = 1;
+        a.kper = cdiv(cdiv(K, splits), 64) * 64;
+        a.split_stride = (long)M * ldc * 4;
+        a.tiles_n = cdiv(N, 128);
+        a.ntiles = cdiv(M, 128) * a.tiles_n;
+        a.nitems = a.ntiles * splits;
+        a.tiles_m_fast = a.tiles_n > cdiv(M, 128);
+        ProfScope prof(MMTG_PROF_GEMM_BF16, s, 2.0 * M * N * (double)K, 2.0 * ((double)M * K + (double)N * K) + 4.0 * (double)M * N);
+        static bool attr_done = false;
+        const size_t shm = (128 + 128) * 128;
+        if (!attr_done) {
+            int rc = set_lds(gemm_occ4_kernel<true, true, true, true>, shm, 256, "gather weight gradient");
+            if (rc) return rc;
+            attr_done = true;
+        }
+        hipLaunchKernelGGL((gemm_occ4_kernel<true, true, true, true>), dim3(a.nitems), dim3(256), shm, s, a);
+    }
+    MMTG_LAUNCH_CHECK("gemm_gather");
     return MMTG_OK;
 }
 

@@ -35,6 +35,8 @@ struct GemmArgs {
     float alpha;
     uint32_t drop_thresh; uint32_t drop_seed; float drop_inv_keep;
     int bytesA, bytesB;    // operand extents for the LDS-DMA buffer descriptors
+    const int* gather;     // mmtg_gemm_gather: table row of output row m (mode 0: A rows) / of reduction index k (mode 1: B rows)
+    const int* aux_rows;   // row of `aux` that output row m reads (null: row m)
 };
 
 template <typename T> struct GT {
@@ -268,7 +270,8 @@ __device__ __forceinline__ void epi_tiles(const GemmArgs& p, f32x4 (&acc)[TM][TN
     constexpr int LPR = WTN / 8;               // lanes per row on read-back
     constexpr int RPI = 64 / LPR;              // rows per read instruction
     constexpr int NQ = 16 / RPI;               // read instructions per 16-row band
-    constexpr bool HAS_AUX = EPI == MMTG_EPI_RESID || EPI == MMTG_EPI_DGELU || EPI == MMTG_EPI_DTANH || EPI == MMTG_EPI_ROWDOT;
+    constexpr bool HAS_AUX = EPI == MMTG_EPI_RESID || EPI == MMTG_EPI_DGELU || EPI == MMTG_EPI_DTANH || EPI == MMTG_EPI_ROWDOT ||
+                             EPI == MMTG_EPI_TANH_ADD;
     const T* aux = reinterpret_cast<const T*>(p.aux);
     // Everything that comes from global memory is requested ahead of its use -- the lane's 8 bias
     // values once (its columns are the same in every band) and the aux vectors of its rows PFD bands
@@ -292,7 +295,8 @@ __device__ __forceinline__ void epi_tiles(const GemmArgs& p, f32x4 (&acc)[TM][TN
 #define EPI_LOAD_BAND(hb)                                                                                   \
     _Pragma("unroll") for (int q_ = 0; q_ < NQ; ++q_) {                                                     \
         const int m_ = mw0 + (hb) * 16 + q_ * RPI + r0;                                                     \
-        const V* src_ = reinterpret_cast<const V*>(aux + (long)(m_ < p.M ? m_ : p.M - 1) * p.ldaux + (nok ? n : 0)); \
+        const int mc_ = m_ < p.M ? m_ : p.M - 1;                                                            \
+        const V* src_ = reinterpret_cast<const V*>(aux + (long)(p.aux_rows ? p.aux_rows[mc_] : mc_) * p.ldaux + (nok ? n : 0)); \
         _Pragma("unroll") for (int u_ = 0; u_ < VPA; ++u_) ax[(((hb) % RING) * NQ + q_) * VPA + u_] = src_[u_]; \
     }
     if constexpr (HAS_AUX) {
@@ -336,6 +340,9 @@ __device__ __forceinline__ void epi_tiles(const GemmArgs& p, f32x4 (&acc)[TM][TN
             } else if constexpr (EPI == MMTG_EPI_TANH) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = tanh_t<T>(v[e]);
+            } else if constexpr (EPI == MMTG_EPI_TANH_ADD) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = tanh_t<T>(v[e] + a8[e]);
             } else if constexpr (EPI == MMTG_EPI_RESID) {
                 if (p.drop_thresh) {
 #pragma unroll
@@ -417,6 +424,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
         switch (p.epi) {
             case MMTG_EPI_GELU: epi_tiles<T, MMTG_EPI_GELU, TM, TN, PFD>(p, acc, mw0, nw0, g, l15, lds, lane); break;
             case MMTG_EPI_TANH: epi_tiles<T, MMTG_EPI_TANH, TM, TN, PFD>(p, acc, mw0, nw0, g, l15, lds, lane); break;
+            case MMTG_EPI_TANH_ADD: epi_tiles<T, MMTG_EPI_TANH_ADD, TM, TN, PFD>(p, acc, mw0, nw0, g, l15, lds, lane); break;
             case MMTG_EPI_RESID: epi_tiles<T, MMTG_EPI_RESID, TM, TN, PFD>(p, acc, mw0, nw0, g, l15, lds, lane); break;
             case MMTG_EPI_DGELU: epi_tiles<T, MMTG_EPI_DGELU, TM, TN, PFD>(p, acc, mw0, nw0, g, l15, lds, lane); break;
             case MMTG_EPI_DTANH: epi_tiles<T, MMTG_EPI_DTANH, TM, TN, PFD>(p, acc, mw0, nw0, g, l15, lds, lane); break;

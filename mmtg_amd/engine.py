@@ -170,6 +170,7 @@ _WG_NUM = float(_os.environ.get("MMTG_WGRAD_NUM", "760"))     # tuning knobs of 
 _WG_CAP = int(_os.environ.get("MMTG_WGRAD_CAP", "12"))
 _NO_FEW_ROWS = bool(_os.environ.get("MMTG_NO_FEW_ROWS"))   # A/B switch: plain launches for the encoder-sized products
 _WGRAD_SLAB = not _os.environ.get("MMTG_WGRAD_ATOMIC")     # A/B switch: fp32-atomic weight gradients everywhere
+_NO_GATHER = bool(_os.environ.get("MMTG_NO_GATHER"))       # A/B switch: materialise the conditioned embeddings (round-1 path)
 _PREFETCH = int(_os.environ.get("MMTG_PREFETCH", "0"))      # backward: Infinity-Cache prefetch of saved activations on a side stream (workgroups; 0 = off)
 
 
@@ -259,6 +260,7 @@ class Engine:
         self.normsq = torch.zeros(1, device=self.dev)
         self.bucket_hook = None   # callable(pack_index) fired as packs of gradients become final
         self._pf_stream = None
+        self._rowmaps = {}
 
     # ---------------------------------------------------------------- buffers / views
     def set_table(self, table):
@@ -530,8 +532,6 @@ class Engine:
             self.act = a
             return a
         # ---------------- decoder front end (model.py:251-281) + GPT-2 input embedding
-        x = self.buf("x_cond", (M, E))
-        hip.embed_condition(self.table, topic_ids, targets, c, x, B, P, L, S, E, sh.two_sents, self.table.shape[0])
         if train_flag:
             type_ids = torch.cat([batch["tpw_type_ids"].to(self.dev).long(), batch["type_ids"].to(self.dev).long()], 1)
             keep = torch.cat([batch["tpw_attention_mask"].to(self.dev), batch["attention_mask"].to(self.dev)], 1)
@@ -540,8 +540,36 @@ class Engine:
         type_ids = type_ids.contiguous().view(-1)
         keep = (keep != 0).to(torch.int32).contiguous()
         h1 = self.buf("h1", (M, H))
-        self._fwd(x, "decoder.projector_layer1.weight", h1, M, "linear", bias=self.P("decoder.projector_layer1.bias"),
-                  epi=hip.EPI_TANH)
+        gather = self.dtype == hip.BF16 and M > 256 and not _NO_GATHER
+        if gather:
+            # Fused conditioning (model.py:254-281): X[m] = E[id_m] + c[b, seg_m] is never materialised.  By linearity
+            # X W1^T = E[id] W1^T + (c W1^T)[b, seg]: the projector product gathers its A rows straight from the WenLan table
+            # (the row index is the LDS-DMA lane's source offset) and its epilogue adds row b*S + seg of the small product
+            # c W1^T (row B*S = zeros for the prompt and the positions past the last segment) before the tanh.
+            ids32 = torch.cat([topic_ids, targets], 1).to(torch.int32).contiguous().view(-1)
+            rowmap = self._rowmaps.get((B, T))
+            if rowmap is None:          # depends on the shapes only: built once per (B, T)
+                lp = torch.arange(T, device=self.dev) - P
+                seg = torch.div(lp, sh.two_sents, rounding_mode="floor")
+                seg = torch.where((lp >= 0) & (seg < S), seg, torch.full_like(seg, -1))
+                rowmap = torch.where(seg >= 0, torch.arange(B, device=self.dev)[:, None] * S + seg[None, :],
+                                     torch.full((B, T), B * S, device=self.dev)).to(torch.int32).contiguous().view(-1)
+                if len(self._rowmaps) > 256:
+                    self._rowmaps.clear()
+                self._rowmaps[(B, T)] = rowmap
+            cW = self.buf("c_w1", (B * S + 1, H))
+            self._fwd(c, "decoder.projector_layer1.weight", cW[:B * S], B * S, "linear")
+            cW[B * S:].zero_()
+            hip.gemm_gather(0, self.table, self.W("decoder.projector_layer1.weight"), h1, M, H, E, ids32, self.table.shape[0],
+                            lda=E, ldb=E, bias=self.P("decoder.projector_layer1.bias"), epi=hip.EPI_TANH_ADD, aux=cW, ldaux=H,
+                            aux_rows=rowmap)
+            x = None
+        else:
+            ids32 = None
+            x = self.buf("x_cond", (M, E))
+            hip.embed_condition(self.table, topic_ids, targets, c, x, B, P, L, S, E, sh.two_sents, self.table.shape[0])
+            self._fwd(x, "decoder.projector_layer1.weight", h1, M, "linear", bias=self.P("decoder.projector_layer1.bias"),
+                      epi=hip.EPI_TANH)
         hcur = self.buf("resid_0", (M, D))
         self._fwd(h1, "decoder.projector_layer2.weight", hcur, M, "linear", bias=self.P("decoder.projector_layer2.bias"))
         pre = "decoder.gpt2.transformer."
@@ -588,7 +616,7 @@ class Engine:
         l32 = logits_f32 or self.dtype == hip.F32
         logits = self.buf("logits" if l32 else "logits_c", (M, Vp), torch.float32 if l32 else self.tdt)
         hip.gemm(hf, self.Wp("wte"), logits, M, Vp, D, transB=True, ldb=D, out_f32=l32)
-        a.update(xt=xt, t_raw=t_raw, t_ln=t_ln, st=st, enc=enc, alpha=alpha, kl=kl, o=o, ba=ba, c=c, x=x, h1=h1,
+        a.update(xt=xt, t_raw=t_raw, t_ln=t_ln, st=st, enc=enc, alpha=alpha, kl=kl, o=o, ba=ba, c=c, x=x, ids32=ids32, h1=h1,
                  type_ids=type_ids, keep=keep, layers=layers, x_last=hcur, muf=muf, rsf=rsf, hf=hf, logits=logits)
         self.act = a
         return a
@@ -761,10 +789,22 @@ class Engine:
         dh1 = self.buf("d_h1", (M, H))
         self._dgrad(dx, "decoder.projector_layer2.weight", dh1, M, "linear", epi=hip.EPI_DTANH, aux=a["h1"], ldaux=H)
         self._wgrad(a["h1"], dx, "decoder.projector_layer2.weight", "decoder.projector_layer2.bias", M, "linear")
-        self._wgrad(a["x"], dh1, "decoder.projector_layer1.weight", "decoder.projector_layer1.bias", M, "linear")
         # d c[b,k] = (sum over the segment's tokens of d h1_pre) W1   (the add is linear)
         seg = self.buf("d_seg", (B * S, H))
         hip.segment_sum(dh1, seg, B, P, L, S, H, sh.two_sents)
+        if a["ids32"] is not None:
+            # d W1 = d h1_pre^T X with X = E[id] + c[seg] never materialised: the table rows enter the K-strided operand of
+            # the weight-gradient product by index (mmtg_gemm_gather mode 1), the c part is the small product seg^T c
+            gw = self.G("decoder.projector_layer1.weight")
+            splits = _wgrad_splits(H, E, M, True)
+            part = self.buf("wgrad_slabs", (splits * H * E,), torch.float32)
+            hip.gemm_gather(1, dh1, self.table, part, H, E, M, a["ids32"], self.table.shape[0], lda=H, ldb=E, ldc=E,
+                            epi=hip.EPI_SPLIT, splits=splits)
+            hip.slab_sum(part, splits, H * E, gw, H * E, accumulate=not self.wgrad_overwrite)
+            hip.gemm(seg, a["c"], gw, H, E, B * S, transA=True, transB=False, lda=H, ldb=E, ldc=E, epi=hip.EPI_ATOMIC, splits=1)
+            hip.colsum(dh1, M, H, self.G("decoder.projector_layer1.bias"))
+        else:
+            self._wgrad(a["x"], dh1, "decoder.projector_layer1.weight", "decoder.projector_layer1.bias", M, "linear")
         dc = self.buf("d_c", (B * S, E))
         self._dgrad(seg, "decoder.projector_layer1.weight", dc, B * S, "linear")
         # ---- beta fuser

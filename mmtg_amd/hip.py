@@ -32,6 +32,7 @@ _SIGS = {
     "mmtg_prof_read": ([_vp, _vp, _vp, _vp], _i),
     "mmtg_gemm_trace": ([_vp, _i], _i),
     "mmtg_gemm": ([_i, _i, _i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _vp, _i, _vp, _l, _vp, _i, _f, _i, _u, _u, _i, _vp], _i),
+    "mmtg_gemm_gather": ([_i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _vp, _i, _vp, _i, _vp, _l, _vp, _i, _vp], _i),
     "mmtg_splitk_finish": ([_i, _vp, _i, _i, _i, _l, _vp, _i, _vp, _l, _vp, _l, _vp, _vp, _vp, _f, _vp], _i),
     "mmtg_colsum": ([_i, _vp, _l, _i, _i, _vp, _vp], _i),
     "mmtg_layernorm_fwd": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp], _i),
@@ -187,6 +188,14 @@ def gemm(A, B, C_, M, N, K, transA=False, transB=False, lda=None, ldb=None, ldc=
 
 
 EPI_SPLIT = 8
+EPI_TANH_ADD = 9
+
+
+def gemm_gather(mode, A, B, C_, M, N, K, rows, table_rows, lda, ldb, ldc=None, bias=None, epi=EPI_NONE, aux=None, ldaux=0,
+                aux_rows=None, splits=1):
+    """Products with table-gathered operand rows (include/mmtg_hip.h, mmtg_gemm_gather): mode 0 forward, mode 1 weight gradient."""
+    _check(lib().mmtg_gemm_gather(int(mode), M, N, K, _p(A), lda, _p(B), ldb, _p(C_), N if ldc is None else ldc, _p(bias), epi,
+                                  _p(rows), int(table_rows), _p(aux), ldaux or N, _p(aux_rows), int(splits), _stream()), "gemm_gather")
 
 
 def splitk_finish(part, splits, M, N, out, bias=None, epi=EPI_NONE, aux=None, ldaux=0, ldp=None, ldo=None,

@@ -914,3 +914,45 @@ def test_abi_error_behaviour():
     c = torch.empty(64, 64, device=DEV, dtype=torch.bfloat16)
     hip.gemm(a, a, c, 64, 64, 64, transB=True)
     close(c, a.float() @ a.float().t(), torch.bfloat16, 64, "gemm after errors")
+
+
+# ------------------------------------------------------------------ gathered-operand products (multi-modal conditioning, fused)
+def test_gemm_gather_forward_and_weight_gradient():
+    """mmtg_gemm_gather against the same products on an explicitly gathered operand: the forward (table rows as the A
+    operand's rows, K-contiguous) and the weight gradient (table rows as the reduction index of the K-strided B operand)
+    are bit-identical to mmtg_gemm on table[rows] -- only the source addresses of the LDS-DMA differ -- and the
+    TANH_ADD epilogue adds aux[aux_rows[m]] before the tanh (model.py:262-281: (E[id] + c) W1^T = E[id] W1^T + (c W1^T)[seg])."""
+    dtype = torch.bfloat16
+    Vt, E, H, M = 300, 2048, 512, 700          # table rows, embedding width, projector width, tokens (ragged: 700 = 5 x 128 + 60)
+    table = rnd(Vt, E, dtype=dtype, seed=1, scale=0.05).to(DEV)
+    w = rnd(H, E, dtype=dtype, seed=2, scale=0.03).to(DEV)
+    bias = rnd(H, seed=3).to(DEV)
+    g = torch.Generator().manual_seed(4)
+    rows = torch.randint(0, Vt, (M,), generator=g, dtype=torch.int32).to(DEV)
+    xg = table[rows.long()].contiguous()
+    # forward, plain
+    ref = torch.empty(M, H, device=DEV, dtype=dtype)
+    hip.gemm(xg, w, ref, M, H, E, transB=True, ldb=E, bias=bias, flags=hip.GEMM_NO_WIDE | hip.GEMM_NO_OCC4)
+    got = torch.full((M, H), float("nan"), device=DEV, dtype=dtype)
+    hip.gemm_gather(0, table, w, got, M, H, E, rows, Vt, lda=E, ldb=E, bias=bias)
+    assert torch.equal(got, ref)
+    # forward, tanh(acc + bias + aux[aux_rows])
+    nseg = 37
+    aux = rnd(nseg + 1, H, dtype=dtype, seed=5).to(DEV)
+    aux[nseg] = 0
+    amap = torch.randint(0, nseg + 1, (M,), generator=g, dtype=torch.int32).to(DEV)
+    got2 = torch.empty(M, H, device=DEV, dtype=dtype)
+    hip.gemm_gather(0, table, w, got2, M, H, E, rows, Vt, lda=E, ldb=E, bias=bias, epi=hip.EPI_TANH_ADD, aux=aux, ldaux=H, aux_rows=amap)
+    want = torch.tanh(xg.float() @ w.float().t() + bias + aux[amap.long()].float())
+    close(got2, want.cpu(), dtype, E, "gather forward tanh_add")
+    # weight gradient: slabs[s] = dA[k, :]^T . table[rows[k], :]
+    Kt, splits = 1000, 3                       # ragged token count
+    dA = rnd(Kt, H, dtype=dtype, seed=6).to(DEV)
+    rk = torch.randint(0, Vt, (Kt,), generator=g, dtype=torch.int32).to(DEV)
+    xk = table[rk.long()].contiguous()
+    ref_s = torch.empty(splits, H, E, device=DEV, dtype=torch.float32)
+    hip.gemm(dA, xk, ref_s, H, E, Kt, transA=True, transB=False, lda=H, ldb=E, ldc=E, epi=hip.EPI_SPLIT, out_f32=True, splits=splits)
+    got_s = torch.full((splits, H, E), float("nan"), device=DEV, dtype=torch.float32)
+    hip.gemm_gather(1, dA, table, got_s, H, E, Kt, rk, Vt, lda=H, ldb=E, ldc=E, epi=hip.EPI_SPLIT, splits=splits)
+    assert torch.equal(got_s, ref_s)
+    close(got_s.sum(0), dA.float().t() @ xk.float(), dtype, Kt, "gather weight gradient")
