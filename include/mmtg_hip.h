@@ -67,6 +67,9 @@ enum {
 #define MMTG_GEMM_OCC4 512       /* flags: force the single-stage 128x128 kernel, four workgroups per CU (bf16); automatic for
                                     weight gradients and for forward / dgrad products of more than 2 x CUs tiles */
 #define MMTG_GEMM_NO_OCC4 1024   /* flags: never pick it automatically (A/B measurements) */
+#define MMTG_GEMM_NO_P8 8192     /* flags: never pick the eight-phase 256x256 / 192x256 kernel (bf16, transA = 0, transB = 1, K % 128 == 0: the
+                                    default for M >= 1024, N >= 256) -- A/B measurements and bit-equality tests against the older kernels */
+#define MMTG_GEMM_P8 16384       /* flags: eight-phase kernel also for the dGELU product (otherwise on the single-stage kernel by measurement) */
 #define MMTG_GEMM_P256 4096      /* flags: persistent pipelined kernel with 256x128 tiles, 8 waves, one workgroup per CU (bf16, transA = 0) */
 #define MMTG_GEMM_COL_BLOCK 2048 /* flags: force the column-blocked item order with blocks of two tile columns (test hook;
                                     automatic when the weights do not stay in an XCD's L2 over several sweeps) */

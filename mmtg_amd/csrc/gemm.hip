@@ -128,7 +128,9 @@ __device__ __forceinline__ void ks_offsets(int col0, int lane, int (&o)[NT]) {
     }
 }
 
-template <bool AKS, bool BKS, int TBM, int TBN, int NBA, int NBB, int NW>
+// (TAG only makes the instance unique per calling kernel: a second kernel that instantiates this helper with the same
+//  arguments fails hipcc's host pass with "no matching function" -- see DESIGN.md 4b)
+template <bool AKS, bool BKS, int TBM, int TBN, int NBA, int NBB, int NW, int TAG>
 __device__ __forceinline__ void dma_issue_tile(const GemmArgs& p, __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb,
                                                const int (&va)[NBA], const int (&vb)[NBB], int sa, int sb, char* stage, int TA,
                                                int t, int nk_full, int nk, int klen, int m0, int n0, int wave, int lane,
@@ -264,7 +266,7 @@ __global__ __launch_bounds__((64 * WM * WN), (DmaCfg<TBM, TBN, WM, WN, NBUF>::MI
         if constexpr (GATHER)                                                                                  \
             dma_issue_full<TBM, TBN, NBA, NBB, NW>(ra, rb, va, vb, sa, sb, smem + ((t) % NBUF) * STAGE, TA, (t) < nk, wave); \
         else                                                                                                   \
-            dma_issue_tile<AKS, BKS, TBM, TBN, NBA, NBB, NW>(p, ra, rb, va, vb, sa, sb, smem + ((t) % NBUF) * STAGE, TA, \
+            dma_issue_tile<AKS, BKS, TBM, TBN, NBA, NBB, NW, NBUF>(p, ra, rb, va, vb, sa, sb, smem + ((t) % NBUF) * STAGE, TA, \
                                                          (t), nk_full, nk, kend - kbeg, m0, n0, wave, lane, NBUF > 2); \
         sa += stepa;                                                                                           \
         sb += stepb;                                                                                           \
@@ -749,6 +751,189 @@ int launch_pp(const GemmArgs& a, int splits, hipStream_t stream) {
     return MMTG_OK;
 }
 
+// ------------------------------------------------------------------ 256x256 eight-phase kernel (NT, bf16; round 2)
+// One 512-thread workgroup per CU computes a 256x256 tile; wave (wr, wc) of the 2x4 grid owns 128x64 of it as four
+// 64x32 quadrants (a0|a1) x (b0|b1).  A K tile (64 deep) is consumed in FOUR phases -- (a0,b0) (a0,b1) (a1,b1) (a1,b0),
+// 16 MFMAs each, fragments read at the start of the phase that first needs them (12 / 4 / 8 / 0 ds_read_b128) -- and the two
+// wave groups wr = 0 / 1 run exactly one barrier apart, so between two barriers one wave of every SIMD issues its 16 MFMAs
+// while the other reads its fragments and issues its share of the LDS-DMA prefetch: fills, fragment reads and MFMAs
+// overlap by construction instead of by luck of the wave scheduler.  Staging: two 64 KB stages (tiles kt, kt+1), each
+// K tile as four 16 KB "half tiles" named by the phase that retires them (B-b0, A-a0, B-b1, A-a1); every phase restages
+// ONE half tile (two 1-KB DMA blocks per wave) as soon as its last reader has passed a barrier, three half tiles ahead
+// of the tile being consumed; one counted vmcnt(6) per K tile (phase 4) retires the next tile, never vmcnt(0) in the loop.
+// (structure after the guide's 256^2 8-phase template; LDS images, swizzle, descriptors and epilogue are this file's own)
+__device__ __forceinline__ void p8_issue(__amdgpu_buffer_rsrc_t r, char* d0, char* d1, int v0, int v1, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, LDS_PTR(void, d0), 16, v0, soff, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, LDS_PTR(void, d1), 16, v1, soff, 0, 0);
+}
+__device__ __forceinline__ void p8_issue1(__amdgpu_buffer_rsrc_t r, char* d0, int v0, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, LDS_PTR(void, d0), 16, v0, soff, 0, 0);
+}
+
+template <int AH, int BH, int NA, int TMW>
+__device__ __forceinline__ void p8_mfma(const bf16x8 (&fa)[4][2], const bf16x8 (&fb)[2][2], f32x4 (&acc)[TMW][4]) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) mma16(fb[j][kk], fa[i][kk], acc[4 * AH + i][2 * BH + j]);
+    __builtin_amdgcn_s_setprio(0);
+}
+
+__device__ __forceinline__ bf16x8 p8_ld(const char* q) { return *reinterpret_cast<const bf16x8*>(q); }
+
+// TBM = 256: wave tile 128x64, a0 = a1 = 64 rows.  TBM = 192: wave tile 96x64, a0 = 64 rows, a1 = 32 rows (phases of
+// 16 / 16 / 8 / 8 MFMAs): 79 x 3 = 237 tiles for the N = 768 products of M = 15104 -- one 93 %-full round of the 256 CUs
+// instead of 177 tiles on 256 -- and 2.78 instead of 2.07 rounds at N = 2304.
+template <int TBM>
+__global__ __launch_bounds__(512, 1) void gemm_p8_kernel(GemmArgs p) {
+    typedef bf16 T;
+    static_assert(TBM == 256 || TBM == 192, "row tiles of 256 or 192");
+    constexpr int WTM = TBM / 2, TMW = WTM / 16, NA1 = TMW - 4;       // wave rows, 16-row tiles per wave, tiles in a1
+    constexpr int NBG = TBM / 16;                                     // DMA blocks (8 rows) per wave-row group
+    constexpr int TA = TBM * 128, STAGE = TA + 256 * 128;             // bytes: A tile | B tile, 128-byte rows (64 k)
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // two stages
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, l15 = lane & 15;
+    const int wr = wave >> 2, wc = wave & 3;
+    const bool tr = p.trace != nullptr;                     // diagnostic timeline (mmtg_gemm_trace)
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
+    if (tr) ts0 = __builtin_amdgcn_s_memrealtime();
+    int m0, n0, split;
+    tile_origin(p, blockIdx.x, gridDim.x, m0, n0, split, TBM, 256);
+    const int nk = p.K >> 6;                                // host: K % 128 == 0, no K splits
+
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, p.bytesA, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, p.bytesB, 0x00020000);
+    const int sa0 = (int)((long)m0 * p.lda * 2), sb0 = (int)((long)n0 * p.ldb * 2);
+    // DMA blocks (8 rows x 128 B) of this wave.  Half tile a0 = the first 64 rows of both wave-row groups -> blocks w and
+    // NBG + w; a1 = the rest of both groups -> 2 blocks per wave at 256 rows (8 + w, NBG + 8 + w), 1 at 192 rows
+    // (group w / 4, block 8 + w % 4).  Half tile b0 = columns 64 wc' + [0, 32) -> blocks 8 (i >> 2) + (i & 3), i = w, w + 8;
+    // b1 = those + 4.
+    const int bA0 = wave, bA1 = bA0 + NBG;
+    const int bA2 = TBM == 256 ? 8 + wave : (wave >> 2) * NBG + 8 + (wave & 3), bA3 = NBG + 8 + wave;      // bA3: 256 rows only
+    const int bB = 8 * (wave >> 2) + (wave & 3);
+    const int vA00 = dma_voff<false, TBM>(p.lda, m0, p.M, 64, bA0, lane), vA01 = dma_voff<false, TBM>(p.lda, m0, p.M, 64, bA1, lane);
+    const int vA10 = dma_voff<false, TBM>(p.lda, m0, p.M, 64, bA2, lane);
+    const int vA11 = TBM == 256 ? dma_voff<false, TBM>(p.lda, m0, p.M, 64, bA3, lane) : OOB;
+    const int vB00 = dma_voff<false, 256>(p.ldb, n0, p.N, 64, bB, lane), vB01 = dma_voff<false, 256>(p.ldb, n0, p.N, 64, bB + 16, lane);
+    const int vB10 = dma_voff<false, 256>(p.ldb, n0, p.N, 64, bB + 4, lane), vB11 = dma_voff<false, 256>(p.ldb, n0, p.N, 64, bB + 20, lane);
+    // half tile H of K tile t into stage t & 1 (a tile past the end issues out-of-range, zero-filling loads: uniform counts)
+#define P8_A0(t) p8_issue(ra, smem + ((t) & 1) * STAGE + bA0 * 1024, smem + ((t) & 1) * STAGE + bA1 * 1024, (t) < nk ? vA00 : OOB, (t) < nk ? vA01 : OOB, sa0 + (t) * 128)
+#define P8_A1(t)                                                                                                                       \
+    do {                                                                                                                               \
+        if constexpr (TBM == 256)                                                                                                      \
+            p8_issue(ra, smem + ((t) & 1) * STAGE + bA2 * 1024, smem + ((t) & 1) * STAGE + bA3 * 1024, (t) < nk ? vA10 : OOB, (t) < nk ? vA11 : OOB, sa0 + (t) * 128); \
+        else                                                                                                                           \
+            p8_issue1(ra, smem + ((t) & 1) * STAGE + bA2 * 1024, (t) < nk ? vA10 : OOB, sa0 + (t) * 128);                              \
+    } while (0)
+#define P8_B0(t) p8_issue(rb, smem + ((t) & 1) * STAGE + TA + bB * 1024, smem + ((t) & 1) * STAGE + TA + (bB + 16) * 1024, (t) < nk ? vB00 : OOB, (t) < nk ? vB01 : OOB, sb0 + (t) * 128)
+#define P8_B1(t) p8_issue(rb, smem + ((t) & 1) * STAGE + TA + (bB + 4) * 1024, smem + ((t) & 1) * STAGE + TA + (bB + 20) * 1024, (t) < nk ? vB10 : OOB, (t) < nk ? vB11 : OOB, sb0 + (t) * 128)
+
+    // lane offsets of the fragments inside a stage: A rows WTM wr + 64 ah + 16 i + l15, B rows (= columns) 64 wc + 32 bh + 16 j + l15;
+    // the chunk swizzle (row & 7) does not depend on wr / ah / bh / i / j (all multiples of 8), so one offset per kk serves all
+    const int rowa = WTM * wr + l15, rowb = 64 * wc + l15;
+    int oa[2], ob[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        oa[kk] = rowa * 128 + ((((kk << 2) + g) ^ (rowa & 7)) << 4);
+        ob[kk] = TA + rowb * 128 + ((((kk << 2) + g) ^ (rowb & 7)) << 4);
+    }
+
+    f32x4 acc[TMW][4];
+#pragma unroll
+    for (int i = 0; i < TMW; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // in flight behind the counted wait: B0, A0, B1 of the tile after next = 6 DMA requests per wave in both configurations
+    P8_B0(0); P8_A0(0); P8_B1(0); P8_A1(0);
+    P8_B0(1); P8_A0(1); P8_B1(1);
+    wait_vmcnt<6>();                       // K tile 0 has landed (mine; the barrier makes it everyone's)
+    asm volatile("s_barrier" ::: "memory");
+    if (tr) ts1 = __builtin_amdgcn_s_memrealtime();
+    if (wr == 1) asm volatile("s_barrier" ::: "memory");          // the second wave group runs one barrier behind the first
+
+    bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
+#define P8_RD_A(ST, AH, NA)                                                                                \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int i = 0; i < (NA); ++i)       \
+        fa[i][kk] = p8_ld(smem + (ST) * STAGE + oa[kk] + ((AH) * 64 + i * 16) * 128)
+#define P8_RD_B(ST, BH, F)                                                                                 \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int j = 0; j < 2; ++j)          \
+        F[j][kk] = p8_ld(smem + (ST) * STAGE + ob[kk] + ((BH) * 32 + j * 16) * 128)
+    // (asm with a memory clobber: the compiler may move neither LDS reads nor DMA issues across a barrier -- the RAW / WAR
+    //  argument above counts barriers in program order; sched_barrier keeps the MFMA clusters inside their phase)
+#define P8_SYNC_IN()  do { asm volatile("s_barrier\n\ts_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define P8_SYNC_OUT() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_barrier" ::: "memory"); } while (0)
+    // one K tile held in stage ST (a compile-time 0 / 1: every fragment address is lane offset + immediate)
+#define P8_TILE(ST, kt)                                                                                    \
+    do {                                                                                                   \
+        P8_RD_B(ST, 0, fb0);                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        P8_RD_A(ST, 0, 4);                                                                                 \
+        P8_A1((kt) + 1);                                                                                   \
+        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");     /* the four b0 reads are done: b0 may be restaged next phase */ \
+        P8_SYNC_IN(); p8_mfma<0, 0, 4, TMW>(fa, fb0, acc); P8_SYNC_OUT();                                   \
+        P8_RD_B(ST, 1, fb1);                                                                               \
+        P8_B0((kt) + 2);                                                                                   \
+        P8_SYNC_IN(); p8_mfma<0, 1, 4, TMW>(fa, fb1, acc); P8_SYNC_OUT();                                   \
+        P8_RD_A(ST, 1, NA1);                                                                               \
+        P8_A0((kt) + 2);                                                                                   \
+        P8_SYNC_IN(); p8_mfma<1, 1, NA1, TMW>(fa, fb1, acc); P8_SYNC_OUT();                                 \
+        P8_B1((kt) + 2);                                                                                   \
+        wait_vmcnt<6>();                                       /* K tile kt + 1 has landed */               \
+        P8_SYNC_IN(); p8_mfma<1, 0, NA1, TMW>(fa, fb0, acc); P8_SYNC_OUT();                                 \
+    } while (0)
+    for (int kt = 0; kt < nk; kt += 2) {
+        P8_TILE(0, kt);
+        P8_TILE(1, kt + 1);
+    }
+#undef P8_TILE
+#undef P8_RD_A
+#undef P8_RD_B
+#undef P8_A0
+#undef P8_A1
+#undef P8_B0
+#undef P8_B1
+    wait_vmcnt<0>();                                     // the zero-fill tail loads
+    if (tr) ts2 = __builtin_amdgcn_s_memrealtime();
+    if (wr == 0) asm volatile("s_barrier" ::: "memory");           // re-join the two groups
+    asm volatile("s_barrier" ::: "memory");                        // every wave is done with the stages: they become epilogue scratch
+    // (aux vectors two bands ahead; the 256-row configuration -- 128-row wave tiles -- also carries the dGELU column sums)
+    gemm_epilogue<T, false, TMW, 4, (TBM == 256 ? 2 : -2)>(p, acc, m0 + wr * WTM, n0 + wc * 64, g, l15, smem + wave * epi_scratch_bytes<TMW, 4>(), lane);
+    if (tr && wave == 0 && (int)blockIdx.x < p.trace_n) {
+        wait_vmcnt<0>();                       // the output stores are part of the epilogue's time
+        const unsigned long long ts3 = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0) {
+            unsigned long long* r = p.trace + 6 * (size_t)blockIdx.x;
+            r[0] = ts0; r[1] = ts1; r[2] = ts2; r[3] = ts3; r[4] = (unsigned long long)nk;
+            r[5] = ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        }
+    }
+}
+
+template <int TBM>
+int launch_p8(const GemmArgs& a, hipStream_t stream) {
+    static bool attr_done = false;
+    const size_t shm = 2 * (TBM + 256) * 128;
+    if (!attr_done) {
+        int rc = set_lds(gemm_p8_kernel<TBM>, shm, 512, TBM == 256 ? "eight-phase 256x256" : "eight-phase 192x256");
+        if (rc) return rc;
+        attr_done = true;
+    }
+    GemmArgs b = a;
+    b.tiles_n = cdiv(a.N, 256);
+    b.ntiles = cdiv(a.M, TBM) * b.tiles_n;
+    b.nitems = b.ntiles;
+    b.tiles_m_fast = 0;
+    if (!(a.dbg_flags & 1)) b.cbw = column_block(a, TBM, 256, num_cus());
+    hipLaunchKernelGGL(gemm_p8_kernel<TBM>, dim3(b.nitems), dim3(512), shm, stream, b);
+    return MMTG_OK;
+}
+
 template <bool AKS, bool BKS, bool SLAB = false>
 int launch_occ4(const GemmArgs& a, int splits, hipStream_t stream) {
     static bool attr_done = false;
@@ -789,6 +974,11 @@ int launch_dma(const GemmArgs& a, int transA, int transB, int splits, int skinny
         if (!transA && transB) return launch_dma_cfg<false, false, 192, 128, 3, 2, 2>(a, splits, stream);
         if (!transA && !transB) return launch_dma_cfg<false, true, 192, 128, 3, 2, 2>(a, splits, stream);
     }
+    if (!transA && transB && !skinny && (a.dbg_flags & 64)) {
+        // experiment (MMTG_GEMM_BIG=1): the vendor library's shape compiled from the generic kernel -- 256x256 tiles, FOUR waves of
+        // 128x128 (one per SIMD, 256 accumulator registers each), two 64 KB stages, one workgroup per CU
+        return launch_dma_cfg<false, false, 256, 256, 2, 2, 2>(a, splits, stream);
+    }
     if (!transA && transB) {
         if (skinny) {
             // batch-sized M (decode): tile shape of the weight-streaming products.  A workgroup pulls (BM + BN) x K
@@ -804,6 +994,8 @@ int launch_dma(const GemmArgs& a, int transA, int transB, int splits, int skinny
                 case 3: return launch_dma_cfg<false, false, 64, 128, 2, 2, 4>(a, splits, stream);
                 case 4: return launch_dma_cfg<false, false, 128, 32, 4, 1, 4>(a, splits, stream);
                 case 5: return launch_dma_cfg<false, false, 64, 32, 2, 1, 4>(a, splits, stream);
+                case 6: return launch_dma_cfg<false, false, 64, 64, 2, 2, 5>(a, splits, stream);    // 80 KB: still two per CU
+                case 7: return launch_dma_cfg<false, false, 64, 64, 2, 2, 8>(a, splits, stream);    // 128 KB: a 384-deep K slice all in flight
                 default: return launch_dma_cfg<false, false, 256, 32, 4, 1, 4>(a, splits, stream);
             }
         }
@@ -1002,6 +1194,32 @@ extern "C" int mmtg_gemm(int dtype, int transA, int transB, int M, int N, int K,
             if (transA || (flags & MMTG_GEMM_OCC4) || (!wide && t128 > 2L * num_cus())) a.dbg_flags |= 2;
         }
         if (wgrad && epi == MMTG_EPI_SPLIT) a.dbg_flags |= 2;      // the slab epilogue lives in the single-stage kernel only
+        // Eight-phase kernel (round 2): every K-contiguous x K-contiguous product of a training step -- forward and dgrad of the
+        // Conv1D / Linear layers through the [out,in] weight copies, the LM head -- with K a multiple of 128.  Row tiles of
+        // 192 where they fill the 256 CUs better (a 192-row tile costs 0.75 of a 256-row one): N = 768 -> 237 tiles in one
+        // round instead of 177, N = 2304 -> 2.78 rounds instead of 2.07.  MMTG_GEMM_P8=0 switches it off (A/B), MMTG_GEMM_BIG=1
+        // keeps the plain 256x256 four-wave experiment.
+        static const int big = getenv("MMTG_GEMM_BIG") ? atoi(getenv("MMTG_GEMM_BIG")) : 0;
+        static const int p8 = getenv("MMTG_GEMM_P8") ? atoi(getenv("MMTG_GEMM_P8")) : 1;
+        static const int p8_rows_env = getenv("MMTG_GEMM_P8_ROWS") ? atoi(getenv("MMTG_GEMM_P8_ROWS")) : 0;
+        const bool nt_big = !transA && transB && !skinny && !wgrad && M >= 1024 && N >= 256 && splits == 1 && epi != MMTG_EPI_SPLIT &&
+                            epi != MMTG_EPI_ATOMIC && !(flags & (MMTG_GEMM_WIDE | MMTG_GEMM_OCC4 | MMTG_GEMM_PERSIST | MMTG_GEMM_P256 | MMTG_GEMM_NO_P8));
+        if (big == 1 && nt_big && epi != MMTG_EPI_ROWDOT && !(epi == MMTG_EPI_DGELU && aux2)) {
+            wide = false; persist = false; a.dbg_flags &= ~(2 | 32); a.dbg_flags |= 64;
+        } else if (p8 && nt_big && K % 128 == 0 && (epi != MMTG_EPI_DGELU || p8 >= 2 || (flags & MMTG_GEMM_P8))) {
+            // (dGELU keeps the single-stage kernel: with the saved pre-activation read in its exposed epilogue the eight-phase
+            //  kernel measured 115.7 vs 112.5 us inside the training step; MMTG_GEMM_P8=2 or the MMTG_GEMM_P8 flag routes it here too -- bit-equal)
+            const long t256 = (long)cdiv(M, 256) * cdiv(N, 256), t192 = (long)cdiv(M, 192) * cdiv(N, 256);
+            const long ncu = num_cus();
+            const double c256 = (double)cdiv(t256, ncu), c192 = 0.75 * (double)cdiv(t192, ncu);
+            int rows = c192 < 0.95 * c256 ? 192 : 256;
+            if (p8_rows_env) rows = p8_rows_env;
+            if (epi == MMTG_EPI_DGELU && aux2) rows = 256;      // the fused column sums need 64-row-aligned wave tiles
+            rc = rows == 192 ? launch_p8<192>(a, s) : launch_p8<256>(a, s);
+            if (rc) return rc;
+            MMTG_LAUNCH_CHECK("gemm");
+            return MMTG_OK;
+        }
         rc = launch_dma(a, transA, transB, splits, skinny && !transA && transB, wide, persist, s);
     }
     if (rc) return rc;

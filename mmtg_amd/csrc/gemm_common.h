@@ -375,23 +375,27 @@ __device__ __forceinline__ void epi_tiles(const GemmArgs& p, f32x4 (&acc)[TM][TN
             if (p.out_f32) store8<float>(reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n, v);
             else store8<T>(reinterpret_cast<T*>(p.C) + (long)m * p.ldc + n, v);
         }
-    }
-    if constexpr (COLSUM) {
-        // aux2 (optional): f32 [ceil(M/64)][N] <- column sums of the output per 64-row band (this wave
-        // tile's rows), plain stores; summing the bands gives the bias gradient of the layer whose
-        // pre-activation gradient this product computes (a [M/64, N] reduction instead of a pass over
-        // the [M,N] result).  Not atomics onto [N]: 118 row tiles adding to the same addresses
-        // serialise in the L2 (+29 us on the 15104 x 3072 product, measured in the training step).
-        // Lanes with equal lane % LPR hold the same 8 columns for different rows: fold them first.
-        static_assert(!COLSUM || TM == 4, "band index assumes 64-row wave tiles");
-        if (p.aux2) {
+        if constexpr (COLSUM) {
+            // aux2 (optional): f32 [ceil(M/64)][N] <- column sums of the output per 64-row band (four 16-row passes of this
+            // wave tile), plain stores; summing the bands gives the bias gradient of the layer whose pre-activation
+            // gradient this product computes (a [M/64, N] reduction instead of a pass over the [M,N] result).  Not atomics
+            // onto [N]: 118 row tiles adding to the same addresses serialise in the L2 (+29 us on the 15104 x 3072 product,
+            // measured in the training step).  Lanes with equal lane % LPR hold the same 8 columns for different rows:
+            // fold them first.
+            static_assert(!COLSUM || TM % 4 == 0, "column-sum bands are 64 rows: wave tiles of 64 or 128 rows");
+            if (h % 4 == 3) {
+                if (p.aux2) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
+                    for (int e = 0; e < 8; ++e) {
 #pragma unroll
-                for (int o = LPR; o < 64; o <<= 1) cs[e] += __shfl_xor(cs[e], o, 64);
+                        for (int o = LPR; o < 64; o <<= 1) cs[e] += __shfl_xor(cs[e], o, 64);
+                    }
+                    if (lane < LPR && nok && mw0 + (h - 3) * 16 < p.M)
+                        store8<float>(reinterpret_cast<float*>(p.aux2) + (long)((mw0 >> 6) + (h >> 2)) * p.N + n, cs);
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) cs[e] = 0.f;
             }
-            if (lane < LPR && nok && mw0 < p.M)
-                store8<float>(reinterpret_cast<float*>(p.aux2) + (long)(mw0 >> 6) * p.N + n, cs);
         }
     }
 }

@@ -22,7 +22,7 @@ from . import hip
 
 
 class GreedyDecoder:
-    def __init__(self, model, max_batch, max_len=None, use_graph=True):
+    def __init__(self, model, max_batch, max_len=None, use_graph=True, lanes=None, _parent=None, _lane=0):
         self.model = model
         self.eng = model.engine()
         sh = self.eng.sh
@@ -34,33 +34,61 @@ class GreedyDecoder:
         self.use_graph = use_graph
         dev, tdt = self.eng.dev, self.eng.tdt
         B, D, H, E = self.B, sh.D, sh.H, sh.E
-        self.seq = torch.zeros(B, self.Tmax, dtype=torch.long, device=dev)
-        self.pos = torch.zeros(1, dtype=torch.int32, device=dev)
-        self.keep = torch.zeros(B, self.Tmax, dtype=torch.int32, device=dev)
-        self.types = torch.zeros(B, dtype=torch.long, device=dev)
-        self.tpw_type = torch.zeros(B, sh.P, dtype=torch.long, device=dev)
-        self.tpw_mask = torch.zeros(B, sh.P, dtype=torch.long, device=dev)
-        self.c = torch.zeros(B * sh.S, E, dtype=tdt, device=dev)
-        self.kc = torch.zeros(sh.L, B, sh.nH, self.Tmax, 64, dtype=tdt, device=dev)
-        self.vc = torch.zeros_like(self.kc)
-        z = lambda *s: torch.empty(*s, dtype=tdt, device=dev)
-        self.x, self.h1 = z(B, E), z(B, H)
-        self.h, self.h2 = z(B, D), z(B, D)
-        self.a, self.qkv, self.ctx = z(B, D), z(B, 3 * D), z(B, D)
-        self.u, self.g = z(B, 4 * D), z(B, 4 * D)
-        self.mu = torch.empty(B, dtype=torch.float32, device=dev)
-        self.rs = torch.empty(B, dtype=torch.float32, device=dev)
-        self.logits = torch.empty(B, self.eng.layout.Vpad, dtype=torch.float32, device=dev)
         # bf16: deterministic split-K products (K slices per product: c_attn, attn c_proj, c_fc, mlp c_proj)
         self.fast = self.eng.dtype == hip.BF16 and not os.environ.get("MMTG_DECODE_PLAIN")
+        # Lanes (opt-in, MMTG_DECODE_LANES / lanes=): the rows of a batch never interact, so the batch can be cut into
+        # `lanes` row blocks whose launch chains run side by side on their own streams (fork / join inside the captured
+        # graph).  Every row goes through the same arithmetic in the same order whatever the lane count, so the ids do
+        # not depend on it (tests/test_decode_gpu.py).  Measured at batch 256 (profiles/r02_v5_decode_lanes_ab.txt):
+        # 1 lane 758 us per token step, 2 lanes 825, 4 lanes 1452, 8 lanes 2785 -- hipGraph replay on this ROCm runs
+        # the branches one after another and adds a cross-stream dependency per fork / join, so the default stays 1.
+        if _parent is not None:
+            lanes = 1
+        elif lanes is None:
+            lanes = int(os.environ.get("MMTG_DECODE_LANES", "1")) if (self.fast and B >= 128) else 1
+        if lanes < 1 or B % lanes:
+            raise ValueError("batch %d does not divide into %d lanes" % (B, lanes))
+        self.lanes = lanes
+        if _parent is None:
+            self.seq = torch.zeros(B, self.Tmax, dtype=torch.long, device=dev)
+            self.pos_all = torch.zeros(lanes, dtype=torch.int32, device=dev)
+            self.keep = torch.zeros(B, self.Tmax, dtype=torch.int32, device=dev)
+            self.types = torch.zeros(B, dtype=torch.long, device=dev)
+            self.tpw_type = torch.zeros(B, sh.P, dtype=torch.long, device=dev)
+            self.tpw_mask = torch.zeros(B, sh.P, dtype=torch.long, device=dev)
+            self.c = torch.zeros(B * sh.S, E, dtype=tdt, device=dev)
+            self.kc = torch.zeros(sh.L, B, sh.nH, self.Tmax, 64, dtype=tdt, device=dev)
+            self.vc = torch.zeros_like(self.kc)
+            self.pos = self.pos_all[0:1]
+        else:       # a lane: row block [_lane*B, (_lane+1)*B) of the parent's state, private scratch
+            lo, hi = _lane * B, (_lane + 1) * B
+            self.seq, self.keep, self.types = _parent.seq[lo:hi], _parent.keep[lo:hi], _parent.types[lo:hi]
+            self.tpw_type, self.tpw_mask = _parent.tpw_type[lo:hi], _parent.tpw_mask[lo:hi]
+            self.c = _parent.c[lo * sh.S:hi * sh.S]
+            self.kc = [_parent.kc[l, lo:hi] for l in range(sh.L)]
+            self.vc = [_parent.vc[l, lo:hi] for l in range(sh.L)]
+            self.pos = _parent.pos_all[_lane:_lane + 1]
+        self.splits = tuple(int(x) for x in os.environ.get("MMTG_DECODE_SPLITS", "2,4,1,8").split(","))
         # (measured at batch 256, us per token step: 2,3,2,6 -> 1020; 4,6,3,12 -> 1248; 1,1,1,2 -> 1183; unsplit 1264;
         #  with the one-slice c_fc + fused GELU: 2,3,1,8 -> 940, 2,3,1,6 -> 943, 1,3,1,8 -> 963, 2,3,1,12 -> 1003)
         #  round 2, 64x64 tiles (graph-replayed per-product times, profiles/r02_decode_gemm_tiles.log): 2,4,1,8)
-        self.splits = tuple(int(x) for x in os.environ.get("MMTG_DECODE_SPLITS", "2,4,1,8").split(","))
-        if self.fast:
-            D = self.eng.sh.D
-            slab = max(self.splits[0] * 3 * D, self.splits[1] * D, self.splits[2] * 4 * D, self.splits[3] * D)
-            self.part = torch.empty(slab * B, dtype=torch.float32, device=dev)
+        self.children, self.side = [], []
+        if lanes > 1:
+            self.children = [GreedyDecoder(model, B // lanes, max_len, use_graph=False, _parent=self, _lane=i) for i in range(lanes)]
+            self.side = [torch.cuda.Stream(device=dev) for _ in range(lanes - 1)]
+        else:
+            z = lambda *s: torch.empty(*s, dtype=tdt, device=dev)
+            self.x, self.h1 = z(B, E), z(B, H)
+            self.h, self.h2 = z(B, D), z(B, D)
+            self.a, self.qkv, self.ctx = z(B, D), z(B, 3 * D), z(B, D)
+            self.u, self.g = z(B, 4 * D), z(B, 4 * D)
+            self.mu = torch.empty(B, dtype=torch.float32, device=dev)
+            self.rs = torch.empty(B, dtype=torch.float32, device=dev)
+            self.logits = torch.empty(B, self.eng.layout.Vpad, dtype=torch.float32, device=dev)
+            if self.fast:
+                slab = max(self.splits[0] * 3 * D, self.splits[1] * D, self.splits[2] * 4 * D, self.splits[3] * D)
+                self.part = torch.empty(slab * B, dtype=torch.float32, device=dev)
+        self.uniforms = None
         self.graphs = {}
         self.params = None
 
@@ -71,6 +99,21 @@ class GreedyDecoder:
 
     # ------------------------------------------------------------------ one token
     def _step(self, with_head):
+        if self.children:
+            # fork: lane 0 stays on the current stream, the others run on side streams; join before the step ends
+            cur = torch.cuda.current_stream()
+            for st in self.side:
+                st.wait_stream(cur)
+            for i, ch in enumerate(self.children):
+                ch.params = self.params
+                if i == 0:
+                    ch._step(with_head)
+                else:
+                    with torch.cuda.stream(self.side[i - 1]):
+                        ch._step(with_head)
+            for st in self.side:
+                cur.wait_stream(st)
+            return
         eng, sh, B = self.eng, self.eng.sh, self.B
         D, H, E = sh.D, sh.H, sh.E
         pre = "decoder.gpt2.transformer."
@@ -171,21 +214,22 @@ class GreedyDecoder:
         g = self.graphs.get(key)
         if g is None:
             # warm-up outside capture (lazy LDS-attribute / module loading), then rewind the position
-            saved = (self.pos.clone(), self.seq.clone(), self.keep.clone())
+            saved = (self.pos_all.clone(), self.seq.clone(), self.keep.clone())
             self._step(with_head)
             torch.cuda.synchronize()
-            self.pos.copy_(saved[0]); self.seq.copy_(saved[1]); self.keep.copy_(saved[2])
+            self.pos_all.copy_(saved[0]); self.seq.copy_(saved[1]); self.keep.copy_(saved[2])
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self._step(with_head)
             self.graphs[key] = g
-            self.pos.copy_(saved[0]); self.seq.copy_(saved[1]); self.keep.copy_(saved[2])
+            self.pos_all.copy_(saved[0]); self.seq.copy_(saved[1]); self.keep.copy_(saved[2])
         g.replay()
 
     # ------------------------------------------------------------------ public
     @torch.no_grad()
     def describe(self):
-        return "one hipGraph replay per token step" if self.use_graph else "eager launches per token step"
+        how = "one hipGraph replay per token step" if self.use_graph else "eager launches per token step"
+        return how + (", %d row blocks of %d side by side" % (self.lanes, self.B // self.lanes) if self.lanes > 1 else "")
 
     def kernel_name(self):
         return ("decode token step: split-K gemm_dma_kernel<256x32> weight streaming + decode_attn KV-cache streaming + finish kernels"
@@ -206,10 +250,15 @@ class GreedyDecoder:
             raise ValueError("length %d exceeds max_len %d" % (length, self.max_len))
         self.params = (float(temperature), float(repitition_penalty), int(top_k), float(top_p))
         if not (int(top_k) == 1 and float(top_p) == 0.0):
-            if getattr(self, "uniforms", None) is None:
+            if self.uniforms is None:
                 self.uniforms = torch.empty(sh.P + self.max_len + 1, self.B, device=eng.dev, dtype=torch.float32)
             self.uniforms.uniform_(0.0, 1.0, generator=generator)
             self.uniforms.clamp_(max=1.0 - 2.0 ** -24)
+            for i, ch in enumerate(self.children):      # a lane reads its own [position, row] block of the same draws
+                blk = self.uniforms[:, i * ch.B:(i + 1) * ch.B]
+                if ch.uniforms is None:
+                    ch.uniforms = torch.empty_like(blk, memory_format=torch.contiguous_format)
+                ch.uniforms.copy_(blk)
         eng.invalidate_copies()
         self.eng.refresh_copies()
         a = eng.forward(batch, train_flag=False, training=False, encode_only=True)
@@ -220,7 +269,7 @@ class GreedyDecoder:
         self.tpw_type.copy_(batch["tpw_type_ids"].to(eng.dev).long())
         self.tpw_mask.copy_(batch["tpw_attention_mask"].to(eng.dev).long())
         self.keep.zero_()
-        self.pos.zero_()
+        self.pos_all.zero_()
         n_steps = sh.P + length                                 # positions 0 .. P+length-1 are consumed
         saved_mode = self.use_graph
         if use_graph is not None:

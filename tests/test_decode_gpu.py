@@ -251,6 +251,16 @@ def test_full_size_batched_decode_rules():
     gen.manual_seed(3)
     smp = dec.generate(batch, Ln, temperature=1.1, repitition_penalty=1.5, top_k=30, top_p=0.9, generator=gen)
     assert not torch.equal(smp, g1)
+    # the lane count (row blocks decoded side by side on their own streams) never changes a row's ids
+    assert dec.lanes == 1
+    for lanes in (2, 4):
+        other = GreedyDecoder(model, max_batch=B, max_len=Ln, lanes=lanes)
+        assert torch.equal(other.generate(batch, Ln, temperature=1.1, repitition_penalty=1.5), g1), lanes
+        gen.manual_seed(3)
+        assert torch.equal(other.generate(batch, Ln, temperature=1.1, repitition_penalty=1.5, top_k=30, top_p=0.9, generator=gen), smp), lanes
+        del other
+    eager = dec.generate(batch, Ln, temperature=1.1, repitition_penalty=1.5, use_graph=False)
+    assert torch.equal(eager, g1)
     for ids in (g1.cpu(), smp.cpu()):
         assert tuple(ids.shape) == (B, 1 + Ln) and (ids[:, 0] == 1).all()
         assert int(ids.min()) >= 0 and int(ids.max()) < V

@@ -155,6 +155,56 @@ def test_gemm_persistent_pipeline_matches_plain(layout, K):
                 assert torch.equal(x, y)
 
 
+@pytest.mark.parametrize("shape", [(2000, 768, 256), (1310, 2304, 128), (1100, 3080, 384), (4200, 1000, 640)])
+def test_gemm_eight_phase_kernel_matches_older_kernels(shape):
+    """The eight-phase kernel (256x256 / 192x256 tiles, two wave groups one barrier apart; the default for K-contiguous
+    products with M >= 1024, N >= 256, K % 128 == 0) against the older kernels (GEMM_NO_P8) on the same inputs: every
+    fused epilogue bit for bit -- plain, f32 output, bias + GELU with the saved pre-activation, residual + dropout,
+    dGELU with its 64-row-band column sums, tanh, ROWDOT -- on ragged M / N edges; N = 768 and 2304 take 192-row tiles,
+    N ~ 3072 and 1000 take 256-row tiles.  Repeated launches must agree with themselves (race screen)."""
+    M, N, K = shape
+    dtype = torch.bfloat16
+    a = rnd(M, K, dtype=dtype, seed=61).to(DEV)
+    w = rnd(N, K, dtype=dtype, seed=62, scale=0.3).to(DEV)
+    bias = rnd(N, seed=63).to(DEV)
+    aux = rnd(M, N, dtype=dtype, seed=64).to(DEV)
+
+    def run(flags):
+        outs = []
+        c = torch.full((M, N), 9.0, device=DEV, dtype=dtype)
+        hip.gemm(a, w, c, M, N, K, transB=True, bias=bias, flags=flags)
+        outs.append(c)
+        cf = torch.full((M, N), 9.0, device=DEV, dtype=torch.float32)
+        hip.gemm(a, w, cf, M, N, K, transB=True, out_f32=True, flags=flags)
+        outs.append(cf)
+        c, pre = torch.full((M, N), 9.0, device=DEV, dtype=dtype), torch.full((M, N), 9.0, device=DEV, dtype=dtype)
+        hip.gemm(a, w, c, M, N, K, transB=True, bias=bias, epi=hip.EPI_GELU, aux2=pre, flags=flags)
+        outs += [c, pre]
+        c = torch.full((M, N), 9.0, device=DEV, dtype=dtype)
+        hip.gemm(a, w, c, M, N, K, transB=True, bias=bias, epi=hip.EPI_RESID, aux=aux, flags=flags, drop_p=0.1, drop_seed=77)
+        outs.append(c)
+        c = torch.full((M, N), 9.0, device=DEV, dtype=dtype)
+        bands = torch.full(((M + 63) // 64, N), 9.0, device=DEV)
+        hip.gemm(a, w, c, M, N, K, transB=True, epi=hip.EPI_DGELU, aux=aux, aux2=bands, flags=flags)
+        outs += [c, bands]
+        c = torch.full((M, N), 9.0, device=DEV, dtype=dtype)
+        hip.gemm(a, w, c, M, N, K, transB=True, bias=bias, epi=hip.EPI_TANH, flags=flags)
+        outs.append(c)
+        if N % 64 == 0:
+            c = torch.full((M, N), 9.0, device=DEV, dtype=dtype)
+            delta = torch.full((M, N // 64), 9.0, device=DEV)
+            hip.gemm(a, w, c, M, N, K, transB=True, epi=hip.EPI_ROWDOT, aux=aux, aux2=delta, flags=flags)
+            outs += [c, delta]
+        return outs
+
+    old = run(hip.GEMM_NO_P8)
+    close(old[1], a.float().cpu() @ w.float().cpu().t(), dtype, K, "older kernels vs fp32")
+    for rep in range(3):
+        new = run(hip.GEMM_P8 if rep else 0)      # default routing, then the dGELU product on the eight-phase kernel too
+        for i, (x, y) in enumerate(zip(old, new)):
+            assert torch.equal(x, y), (shape, rep, i)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_epilogues(dtype):
     M, N, K = 300, 192, 128

@@ -97,6 +97,21 @@ if os.environ.get("KSWEEP"):
     for K in (64, 768):
         case("NT gelu N=3072 K-sweep", M, 4 * D, K, False, True, hip.EPI_GELU)
     sys.exit(0)
+if os.environ.get("NTSET"):
+    # the forward / dgrad products as the trainer launches them (NT through the [out,in] weight copies) + calibration squares
+    case("NT qkv plain", M, 3 * D, D, False, True)
+    case("NT fc1 plain", M, 4 * D, D, False, True)
+    case("NT fc1 gelu", M, 4 * D, D, False, True, hip.EPI_GELU)
+    case("NT fc2-dgrad dgelu", M, 4 * D, D, False, True, hip.EPI_DGELU)
+    case("NT fc2 resid K=3072", M, D, 4 * D, False, True, hip.EPI_RESID)
+    case("NT fc1-dgrad K=3072", M, D, 4 * D, False, True)
+    case("NT qkv-dgrad K=2304", M, D, 3 * D, False, True)
+    case("NT proj resid", M, D, D, False, True, hip.EPI_RESID)
+    case("NT lm head", M, V, D, False, True)
+    case("NT square 4096", 4096, 4096, 4096, False, True)
+    case("NT square 8192", 8192, 8192, 8192, False, True)
+    case("NT 15104x3072x3072", M, 4 * D, 4 * D, False, True)
+    sys.exit(0)
 case("fwd qkv (NN)", M, 3 * D, D, False, False)
 case("fwd attn proj (NN,resid)", M, D, D, False, False, hip.EPI_RESID)
 case("fwd fc1 (NN,gelu)", M, 4 * D, D, False, False, hip.EPI_GELU)

@@ -5,7 +5,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int NACC>
-__global__ __launch_bounds__(256) void mfma_loop(float* out, int iters, float seed) {
+__global__ __launch_bounds__(256) void mfma_loop(float* out, int iters, float seed, unsigned long long* clk) {
+    // shader clock actually sustained under this load: s_memtime counts shader cycles, s_memrealtime a constant 100 MHz
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     bf16x8 a, b;
     for (int e = 0; e < 8; ++e) { a[e] = (__bf16)(seed + 0.001f * (threadIdx.x + e)); b[e] = (__bf16)(0.5f - 0.002f * (threadIdx.x % 7 + e)); }
     f32x4 acc[NACC];
@@ -17,15 +19,19 @@ __global__ __launch_bounds__(256) void mfma_loop(float* out, int iters, float se
     float s = 0.f;
     for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
     out[blockIdx.x * 256 + threadIdx.x] = s;
+    if (clk && blockIdx.x == 0 && threadIdx.x == 0) {
+        clk[0] = __builtin_amdgcn_s_memtime() - c0;
+        clk[1] = __builtin_amdgcn_s_memrealtime() - r0;
+    }
 }
 
-extern "C" float mfma_run(int blocks, int iters, int nacc, float* out) {
+extern "C" float mfma_run(int blocks, int iters, int nacc, float* out, unsigned long long* clk) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     for (int rep = 0; rep < 2; ++rep) {
         hipEventRecord(e0, 0);
-        if (nacc == 16) hipLaunchKernelGGL(mfma_loop<16>, dim3(blocks), dim3(256), 0, 0, out, iters, 0.25f);
-        else hipLaunchKernelGGL(mfma_loop<4>, dim3(blocks), dim3(256), 0, 0, out, iters, 0.25f);
+        if (nacc == 16) hipLaunchKernelGGL(mfma_loop<16>, dim3(blocks), dim3(256), 0, 0, out, iters, 0.25f, clk);
+        else hipLaunchKernelGGL(mfma_loop<4>, dim3(blocks), dim3(256), 0, 0, out, iters, 0.25f, clk);
         hipEventRecord(e1, 0);
         hipEventSynchronize(e1);
     }

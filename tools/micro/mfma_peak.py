@@ -4,12 +4,16 @@ ceiling the GEMM K loops are measured against."""
 import ctypes, os, torch
 L = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "mfma_peak.so"))
 L.mfma_run.restype = ctypes.c_float
-L.mfma_run.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+L.mfma_run.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
 out = torch.zeros(256 * 8 * 256, device="cuda")
+clk = torch.zeros(2, device="cuda", dtype=torch.int64)
 for wps, nacc in ((1, 16), (2, 16), (4, 16), (2, 4)):
     blocks = 256 * wps
     iters = 20000
-    ms = L.mfma_run(blocks, iters, nacc, out.data_ptr())
+    ms = L.mfma_run(blocks, iters, nacc, out.data_ptr(), clk.data_ptr())
+    c = clk.cpu().tolist()
+    ghz = c[0] / max(c[1], 1) * 0.1
     flops = blocks * 4 * iters * nacc * 2.0 * 16 * 16 * 32
-    print("waves/SIMD %d, %2d independent accumulators: %.1f ms -> %.0f TFLOP/s (%.1f cycles per MFMA per SIMD at 2.4 GHz)" % (
-        wps, nacc, ms, flops / ms / 1e9, ms * 1e-3 * 2.4e9 / (iters * nacc * wps)))
+    print("waves/SIMD %d, %2d independent accumulators: %.1f ms -> %.0f TFLOP/s; shader clock while running %.2f GHz (s_memtime / s_memrealtime) -> "
+          "%.1f cycles per MFMA per SIMD, dense peak at that clock %.0f TFLOP/s" % (
+        wps, nacc, ms, flops / ms / 1e9, ghz, ms * 1e-3 * ghz * 1e9 / (iters * nacc * wps), 2500.0 * ghz / 2.4))
