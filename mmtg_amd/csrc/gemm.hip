@@ -784,13 +784,31 @@ __device__ __forceinline__ void p8_mfma(const bf16x8 (&fa)[4][2], const bf16x8 (
 
 __device__ __forceinline__ bf16x8 p8_ld(const char* q) { return *reinterpret_cast<const bf16x8*>(q); }
 
+// phase boundaries (asm with a memory clobber: the compiler may move neither LDS reads nor DMA issues across a barrier -- the
+// RAW / WAR argument counts barriers in program order; sched_barrier keeps the MFMA clusters inside their phase)
+#define P8_SYNC_IN()  do { asm volatile("s_barrier\n\ts_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define P8_SYNC_OUT() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_barrier" ::: "memory"); } while (0)
+
 // TBM = 256: wave tile 128x64, a0 = a1 = 64 rows.  TBM = 192: wave tile 96x64, a0 = 64 rows, a1 = 32 rows (phases of
 // 16 / 16 / 8 / 8 MFMAs): 79 x 3 = 237 tiles for the N = 768 products of M = 15104 -- one 93 %-full round of the 256 CUs
 // instead of 177 tiles on 256 -- and 2.78 instead of 2.07 rounds at N = 2304.
-template <int TBM>
+// KS = true (weight gradients, both operands K-strided: A [K, M], B [K, N]; TBM = 256): the same protocol on transposed
+// images.  A half tile is a 64 k x 128 column image in the K-strided format of the older kernels (256-byte k-rows, chunk ^
+// ks_swz(k), fragments by ds_read_b64_tr_b16) whose 128 columns are GATHERED by the DMA lanes' source offsets: image a_h holds,
+// for each wave-row group, the 64 columns of its quadrant h (source columns 128 wr + 64 h + ...), image b_h the 32 columns of
+// quadrant h of each of the four wave columns -- so the quadrant / phase / restaging structure above carries over unchanged.
+// K split s covers k in [s kper, (s + 1) kper) (kper a multiple of 128) and stores its fp32 partial tile into slab s.
+template <int GRPCH>
+__device__ __forceinline__ int p8_ks_voff(long ld, int col0, int ncols, int h, int blk, int lane) {
+    const int k = blk * 4 + (lane >> 4), pc = lane & 15, c = pc ^ ks_swz(k);
+    const int col = (c / GRPCH) * (2 * GRPCH * 8) + h * (GRPCH * 8) + (c % GRPCH) * 8;
+    return (col0 + col < ncols) ? (int)(((long)k * ld + col) * 2) : OOB;
+}
+
+template <int TBM, bool KS = false>
 __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(GemmArgs p) {
     typedef bf16 T;
-    static_assert(TBM == 256 || TBM == 192, "row tiles of 256 or 192");
+    static_assert(TBM == 256 || (TBM == 192 && !KS), "row tiles of 256 or (K-contiguous operands) 192");
     constexpr int WTM = TBM / 2, TMW = WTM / 16, NA1 = TMW - 4;       // wave rows, 16-row tiles per wave, tiles in a1
     constexpr int NBG = TBM / 16;                                     // DMA blocks (8 rows) per wave-row group
     constexpr int TA = TBM * 128, STAGE = TA + 256 * 128;             // bytes: A tile | B tile, 128-byte rows (64 k)
@@ -804,43 +822,65 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(GemmArgs p) {
     if (tr) ts0 = __builtin_amdgcn_s_memrealtime();
     int m0, n0, split;
     tile_origin(p, blockIdx.x, gridDim.x, m0, n0, split, TBM, 256);
-    const int nk = p.K >> 6;                                // host: K % 128 == 0, no K splits
+    const int kbeg = KS ? split * p.kper : 0;               // host: K % 128 == 0; K splits (kper % 128 == 0) for KS only
+    const int nk = max(0, (KS ? min(p.K, kbeg + p.kper) : p.K) - kbeg) >> 6;
 
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, p.bytesA, 0x00020000);
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, p.bytesB, 0x00020000);
-    const int sa0 = (int)((long)m0 * p.lda * 2), sb0 = (int)((long)n0 * p.ldb * 2);
-    // DMA blocks (8 rows x 128 B) of this wave.  Half tile a0 = the first 64 rows of both wave-row groups -> blocks w and
-    // NBG + w; a1 = the rest of both groups -> 2 blocks per wave at 256 rows (8 + w, NBG + 8 + w), 1 at 192 rows
-    // (group w / 4, block 8 + w % 4).  Half tile b0 = columns 64 wc' + [0, 32) -> blocks 8 (i >> 2) + (i & 3), i = w, w + 8;
-    // b1 = those + 4.
-    const int bA0 = wave, bA1 = bA0 + NBG;
-    const int bA2 = TBM == 256 ? 8 + wave : (wave >> 2) * NBG + 8 + (wave & 3), bA3 = NBG + 8 + wave;      // bA3: 256 rows only
-    const int bB = 8 * (wave >> 2) + (wave & 3);
-    const int vA00 = dma_voff<false, TBM>(p.lda, m0, p.M, 64, bA0, lane), vA01 = dma_voff<false, TBM>(p.lda, m0, p.M, 64, bA1, lane);
-    const int vA10 = dma_voff<false, TBM>(p.lda, m0, p.M, 64, bA2, lane);
-    const int vA11 = TBM == 256 ? dma_voff<false, TBM>(p.lda, m0, p.M, 64, bA3, lane) : OOB;
-    const int vB00 = dma_voff<false, 256>(p.ldb, n0, p.N, 64, bB, lane), vB01 = dma_voff<false, 256>(p.ldb, n0, p.N, 64, bB + 16, lane);
-    const int vB10 = dma_voff<false, 256>(p.ldb, n0, p.N, 64, bB + 4, lane), vB11 = dma_voff<false, 256>(p.ldb, n0, p.N, 64, bB + 20, lane);
+    const int sa0 = (int)((KS ? (long)kbeg * p.lda + m0 : (long)m0 * p.lda) * 2), sb0 = (int)((KS ? (long)kbeg * p.ldb + n0 : (long)n0 * p.ldb) * 2);
+    const int stepa = KS ? (int)(64 * p.lda * 2) : 128, stepb = KS ? (int)(64 * p.ldb * 2) : 128;      // bytes per K tile
+    // DMA blocks of this wave (two per half tile; one for a1 at 192 rows) as byte offsets inside a stage, and their lane offsets.
+    // K-contiguous operands: a block is 8 rows x 128 B.  Half tile a0 = the first 64 rows of both wave-row groups -> blocks w and
+    // NBG + w; a1 = the rest of both groups -> 2 blocks per wave at 256 rows (8 + w, NBG + 8 + w), 1 at 192 rows (group w / 4,
+    // block 8 + w % 4).  Half tile b0 = columns 64 wc' + [0, 32) -> blocks 8 (i >> 2) + (i & 3), i = w, w + 8; b1 = those + 4.
+    // K-strided operands: half tile h is the 16 KB image at h * 16 KB, a block is 4 k-rows x 256 B -> blocks w and w + 8.
+    int lA00, lA01, lA10, lA11, lB00, lB01, lB10, lB11, vA00, vA01, vA10, vA11, vB00, vB01, vB10, vB11;
+    if constexpr (!KS) {
+        const int bA0 = wave, bA1 = bA0 + NBG;
+        const int bA2 = TBM == 256 ? 8 + wave : (wave >> 2) * NBG + 8 + (wave & 3), bA3 = NBG + 8 + wave;      // bA3: 256 rows only
+        const int bB = 8 * (wave >> 2) + (wave & 3);
+        lA00 = bA0 * 1024; lA01 = bA1 * 1024; lA10 = bA2 * 1024; lA11 = bA3 * 1024;
+        lB00 = TA + bB * 1024; lB01 = TA + (bB + 16) * 1024; lB10 = TA + (bB + 4) * 1024; lB11 = TA + (bB + 20) * 1024;
+        vA00 = dma_voff<false, TBM>(p.lda, m0, p.M, 64, bA0, lane); vA01 = dma_voff<false, TBM>(p.lda, m0, p.M, 64, bA1, lane);
+        vA10 = dma_voff<false, TBM>(p.lda, m0, p.M, 64, bA2, lane);
+        vA11 = TBM == 256 ? dma_voff<false, TBM>(p.lda, m0, p.M, 64, bA3, lane) : OOB;
+        vB00 = dma_voff<false, 256>(p.ldb, n0, p.N, 64, bB, lane); vB01 = dma_voff<false, 256>(p.ldb, n0, p.N, 64, bB + 16, lane);
+        vB10 = dma_voff<false, 256>(p.ldb, n0, p.N, 64, bB + 4, lane); vB11 = dma_voff<false, 256>(p.ldb, n0, p.N, 64, bB + 20, lane);
+    } else {
+        lA00 = wave * 1024; lA01 = (wave + 8) * 1024; lA10 = 16384 + lA00; lA11 = 16384 + lA01;
+        lB00 = TA + lA00; lB01 = TA + lA01; lB10 = TA + lA10; lB11 = TA + lA11;
+        vA00 = p8_ks_voff<8>(p.lda, m0, p.M, 0, wave, lane); vA01 = p8_ks_voff<8>(p.lda, m0, p.M, 0, wave + 8, lane);
+        vA10 = p8_ks_voff<8>(p.lda, m0, p.M, 1, wave, lane); vA11 = p8_ks_voff<8>(p.lda, m0, p.M, 1, wave + 8, lane);
+        vB00 = p8_ks_voff<4>(p.ldb, n0, p.N, 0, wave, lane); vB01 = p8_ks_voff<4>(p.ldb, n0, p.N, 0, wave + 8, lane);
+        vB10 = p8_ks_voff<4>(p.ldb, n0, p.N, 1, wave, lane); vB11 = p8_ks_voff<4>(p.ldb, n0, p.N, 1, wave + 8, lane);
+    }
     // half tile H of K tile t into stage t & 1 (a tile past the end issues out-of-range, zero-filling loads: uniform counts)
-#define P8_A0(t) p8_issue(ra, smem + ((t) & 1) * STAGE + bA0 * 1024, smem + ((t) & 1) * STAGE + bA1 * 1024, (t) < nk ? vA00 : OOB, (t) < nk ? vA01 : OOB, sa0 + (t) * 128)
+#define P8_A0(t) p8_issue(ra, smem + ((t) & 1) * STAGE + lA00, smem + ((t) & 1) * STAGE + lA01, (t) < nk ? vA00 : OOB, (t) < nk ? vA01 : OOB, sa0 + (t) * stepa)
 #define P8_A1(t)                                                                                                                       \
     do {                                                                                                                               \
         if constexpr (TBM == 256)                                                                                                      \
-            p8_issue(ra, smem + ((t) & 1) * STAGE + bA2 * 1024, smem + ((t) & 1) * STAGE + bA3 * 1024, (t) < nk ? vA10 : OOB, (t) < nk ? vA11 : OOB, sa0 + (t) * 128); \
+            p8_issue(ra, smem + ((t) & 1) * STAGE + lA10, smem + ((t) & 1) * STAGE + lA11, (t) < nk ? vA10 : OOB, (t) < nk ? vA11 : OOB, sa0 + (t) * stepa); \
         else                                                                                                                           \
-            p8_issue1(ra, smem + ((t) & 1) * STAGE + bA2 * 1024, (t) < nk ? vA10 : OOB, sa0 + (t) * 128);                              \
+            p8_issue1(ra, smem + ((t) & 1) * STAGE + lA10, (t) < nk ? vA10 : OOB, sa0 + (t) * stepa);                                  \
     } while (0)
-#define P8_B0(t) p8_issue(rb, smem + ((t) & 1) * STAGE + TA + bB * 1024, smem + ((t) & 1) * STAGE + TA + (bB + 16) * 1024, (t) < nk ? vB00 : OOB, (t) < nk ? vB01 : OOB, sb0 + (t) * 128)
-#define P8_B1(t) p8_issue(rb, smem + ((t) & 1) * STAGE + TA + (bB + 4) * 1024, smem + ((t) & 1) * STAGE + TA + (bB + 20) * 1024, (t) < nk ? vB10 : OOB, (t) < nk ? vB11 : OOB, sb0 + (t) * 128)
+#define P8_B0(t) p8_issue(rb, smem + ((t) & 1) * STAGE + lB00, smem + ((t) & 1) * STAGE + lB01, (t) < nk ? vB00 : OOB, (t) < nk ? vB01 : OOB, sb0 + (t) * stepb)
+#define P8_B1(t) p8_issue(rb, smem + ((t) & 1) * STAGE + lB10, smem + ((t) & 1) * STAGE + lB11, (t) < nk ? vB10 : OOB, (t) < nk ? vB11 : OOB, sb0 + (t) * stepb)
 
-    // lane offsets of the fragments inside a stage: A rows WTM wr + 64 ah + 16 i + l15, B rows (= columns) 64 wc + 32 bh + 16 j + l15;
-    // the chunk swizzle (row & 7) does not depend on wr / ah / bh / i / j (all multiples of 8), so one offset per kk serves all
+    // lane offsets of the fragments inside a stage.  K-contiguous: A rows WTM wr + 64 ah + 16 i + l15, B rows (= columns) 64 wc +
+    // 32 bh + 16 j + l15; the chunk swizzle (row & 7) does not depend on wr / ah / bh / i / j (all multiples of 8), so one offset
+    // per kk serves all.  K-strided: transposed-read offsets of columns 64 wr + 16 i (A images) / 32 wc + 16 j (B images).
     const int rowa = WTM * wr + l15, rowb = 64 * wc + l15;
-    int oa[2], ob[2];
+    int oa[KS ? 4 : 2], ob[2];
+    if constexpr (!KS) {
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-        oa[kk] = rowa * 128 + ((((kk << 2) + g) ^ (rowa & 7)) << 4);
-        ob[kk] = TA + rowb * 128 + ((((kk << 2) + g) ^ (rowb & 7)) << 4);
+        for (int kk = 0; kk < 2; ++kk) {
+            oa[kk] = rowa * 128 + ((((kk << 2) + g) ^ (rowa & 7)) << 4);
+            ob[kk] = TA + rowb * 128 + ((((kk << 2) + g) ^ (rowb & 7)) << 4);
+        }
+    } else {
+        ks_offsets<128, 4>(wr * 64, lane, oa);
+        ks_offsets<128, 2>(wc * 32, lane, ob);
+        ob[0] += TA; ob[1] += TA;
     }
 
     f32x4 acc[TMW][4];
@@ -859,15 +899,15 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(GemmArgs p) {
 
     bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
 #define P8_RD_A(ST, AH, NA)                                                                                \
-    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int i = 0; i < (NA); ++i)       \
-        fa[i][kk] = p8_ld(smem + (ST) * STAGE + oa[kk] + ((AH) * 64 + i * 16) * 128)
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int i = 0; i < (NA); ++i) {     \
+        if constexpr (!KS) fa[i][kk] = p8_ld(smem + (ST) * STAGE + oa[kk] + ((AH) * 64 + i * 16) * 128);    \
+        else fa[i][kk] = tr_read_pair(smem + (ST) * STAGE + (AH) * 16384, oa[KS ? i : 0] + kk * 8192, oa[KS ? i : 0] + kk * 8192 + 1024); \
+    }
 #define P8_RD_B(ST, BH, F)                                                                                 \
-    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int j = 0; j < 2; ++j)          \
-        F[j][kk] = p8_ld(smem + (ST) * STAGE + ob[kk] + ((BH) * 32 + j * 16) * 128)
-    // (asm with a memory clobber: the compiler may move neither LDS reads nor DMA issues across a barrier -- the RAW / WAR
-    //  argument above counts barriers in program order; sched_barrier keeps the MFMA clusters inside their phase)
-#define P8_SYNC_IN()  do { asm volatile("s_barrier\n\ts_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-#define P8_SYNC_OUT() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_barrier" ::: "memory"); } while (0)
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int j = 0; j < 2; ++j) {        \
+        if constexpr (!KS) F[j][kk] = p8_ld(smem + (ST) * STAGE + ob[kk] + ((BH) * 32 + j * 16) * 128);     \
+        else F[j][kk] = tr_read_pair(smem + (ST) * STAGE + (BH) * 16384, ob[j] + kk * 8192, ob[j] + kk * 8192 + 1024); \
+    }
     // one K tile held in stage ST (a compile-time 0 / 1: every fragment address is lane offset + immediate)
 #define P8_TILE(ST, kt)                                                                                    \
     do {                                                                                                   \
@@ -875,7 +915,9 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(GemmArgs p) {
         __builtin_amdgcn_sched_barrier(0);                                                                 \
         P8_RD_A(ST, 0, 4);                                                                                 \
         P8_A1((kt) + 1);                                                                                   \
-        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");     /* the four b0 reads are done: b0 may be restaged next phase */ \
+        /* the b0 reads are done: b0 may be restaged next phase (K-strided: 8 + 16 reads, the counter saturates at 15) */ \
+        if constexpr (!KS) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");                               \
+        else asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");                                           \
         P8_SYNC_IN(); p8_mfma<0, 0, 4, TMW>(fa, fb0, acc); P8_SYNC_OUT();                                   \
         P8_RD_B(ST, 1, fb1);                                                                               \
         P8_B0((kt) + 2);                                                                                   \
@@ -902,6 +944,7 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(GemmArgs p) {
     if (tr) ts2 = __builtin_amdgcn_s_memrealtime();
     if (wr == 0) asm volatile("s_barrier" ::: "memory");           // re-join the two groups
     asm volatile("s_barrier" ::: "memory");                        // every wave is done with the stages: they become epilogue scratch
+    if constexpr (KS) p.C = reinterpret_cast<char*>(p.C) + (long)split * p.split_stride;     // MMTG_EPI_SPLIT slab
     // (aux vectors two bands ahead; the 256-row configuration -- 128-row wave tiles -- also carries the dGELU column sums)
     gemm_epilogue<T, false, TMW, 4, (TBM == 256 ? 2 : -2)>(p, acc, m0 + wr * WTM, n0 + wc * 64, g, l15, smem + wave * epi_scratch_bytes<TMW, 4>(), lane);
     if (tr && wave == 0 && (int)blockIdx.x < p.trace_n) {
@@ -915,12 +958,142 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(GemmArgs p) {
     }
 }
 
+// Persistent form of the eight-phase kernel (K-contiguous operands): one workgroup per CU walks the output tiles
+// item, item + grid, ... and the staging protocol never stops -- the issue slots of an item's last two K tiles, which would
+// stage tiles nk and nk + 1, stage K tiles 0 and 1 of the NEXT item instead, so there is no prologue after the first item, no
+// launch gap between rounds, and the counted wait of the last tile's fourth phase is the next item's "tile 0 has landed".  The
+// epilogue runs between two items from a scratch area of its own behind the stages (2 x 64 KB + 8 x 4 KB = the whole 160 KB
+// LDS at 256 rows), without a barrier: its stores sit in the vmcnt queue in front of the next DMA requests and are retired
+// by the first counted wait of the next item (vmcnt counts loads, stores and LDS-DMA together, in issue order).  The DMA
+// lane offsets do not depend on the item (the tile origin travels in the scalar offset); only the row-limit tests do.
 template <int TBM>
-int launch_p8(const GemmArgs& a, hipStream_t stream) {
+__global__ __launch_bounds__(512, 1) void gemm_p8p_kernel(GemmArgs p) {
+    typedef bf16 T;
+    static_assert(TBM == 256 || TBM == 192, "row tiles of 256 or 192");
+    constexpr int WTM = TBM / 2, TMW = WTM / 16, NA1 = TMW - 4;
+    constexpr int NBG = TBM / 16;
+    constexpr int TA = TBM * 128, STAGE = TA + 256 * 128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // two stages | epilogue scratch
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, l15 = lane & 15, l8 = lane >> 3;
+    const int wr = wave >> 2, wc = wave & 3;
+    const int nk = p.K >> 6;                                // host: K % 128 == 0, no K splits
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, p.bytesA, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, p.bytesB, 0x00020000);
+    // this wave's DMA blocks (see gemm_p8_kernel): first row of each block, its LDS offset inside a stage, its lane offset
+    const int bA0 = wave, bA1 = bA0 + NBG;
+    const int bA2 = TBM == 256 ? 8 + wave : (wave >> 2) * NBG + 8 + (wave & 3), bA3 = NBG + 8 + wave;
+    const int bB0 = 8 * (wave >> 2) + (wave & 3), bB1 = bB0 + 16, bB2 = bB0 + 4, bB3 = bB0 + 20;
+    const int c8 = ((lane & 7) ^ l8) * 16;                   // chunk swizzle of dma_voff (block rows are multiples of 8)
+    const int vrA = (int)((long)l8 * p.lda * 2) + c8, vrB = (int)((long)l8 * p.ldb * 2) + c8;
+    const int vA00 = vrA + (int)((long)bA0 * 8 * p.lda * 2), vA01 = vrA + (int)((long)bA1 * 8 * p.lda * 2);
+    const int vA10 = vrA + (int)((long)bA2 * 8 * p.lda * 2), vA11 = vrA + (int)((long)bA3 * 8 * p.lda * 2);
+    const int vB00 = vrB + (int)((long)bB0 * 8 * p.ldb * 2), vB01 = vrB + (int)((long)bB1 * 8 * p.ldb * 2);
+    const int vB10 = vrB + (int)((long)bB2 * 8 * p.ldb * 2), vB11 = vrB + (int)((long)bB3 * 8 * p.ldb * 2);
+
+    int item = blockIdx.x, m0, n0, split, m0n = 0, n0n = 0;
+    tile_origin(p, item, p.nitems, m0, n0, split, TBM, 256);
+    bool has_next = false;
+    // K tile t of the current item (t < nk) or K tile t - nk of the next one; rows past M / N and tiles past the last item
+    // are requested out of range (zero fill, uniform request counts)
+#define P8P_SEL(t)                                                                                          \
+    const bool cur_ = (t) < nk;                                                                             \
+    const bool live_ = cur_ || has_next;                                                                    \
+    const int tt_ = cur_ ? (t) : (t) - nk;                                                                  \
+    const int mm_ = cur_ ? m0 : m0n, nn_ = cur_ ? n0 : n0n;                                                 \
+    const int sa_ = (int)(((long)mm_ * p.lda + (long)tt_ * 64) * 2), sb_ = (int)(((long)nn_ * p.ldb + (long)tt_ * 64) * 2); \
+    const int la_ = live_ ? p.M - mm_ : 0, lb_ = live_ ? p.N - nn_ : 0;                                     \
+    char* st_ = smem + ((t) & 1) * STAGE
+#define P8P_A0(t) do { P8P_SEL(t); (void)sb_; (void)lb_;                                                     \
+        p8_issue(ra, st_ + bA0 * 1024, st_ + bA1 * 1024, bA0 * 8 + l8 < la_ ? vA00 : OOB, bA1 * 8 + l8 < la_ ? vA01 : OOB, sa_); } while (0)
+#define P8P_A1(t) do { P8P_SEL(t); (void)sb_; (void)lb_;                                                     \
+        if constexpr (TBM == 256)                                                                           \
+            p8_issue(ra, st_ + bA2 * 1024, st_ + bA3 * 1024, bA2 * 8 + l8 < la_ ? vA10 : OOB, bA3 * 8 + l8 < la_ ? vA11 : OOB, sa_); \
+        else p8_issue1(ra, st_ + bA2 * 1024, bA2 * 8 + l8 < la_ ? vA10 : OOB, sa_); } while (0)
+#define P8P_B0(t) do { P8P_SEL(t); (void)sa_; (void)la_;                                                     \
+        p8_issue(rb, st_ + TA + bB0 * 1024, st_ + TA + bB1 * 1024, bB0 * 8 + l8 < lb_ ? vB00 : OOB, bB1 * 8 + l8 < lb_ ? vB01 : OOB, sb_); } while (0)
+#define P8P_B1(t) do { P8P_SEL(t); (void)sa_; (void)la_;                                                     \
+        p8_issue(rb, st_ + TA + bB2 * 1024, st_ + TA + bB3 * 1024, bB2 * 8 + l8 < lb_ ? vB10 : OOB, bB3 * 8 + l8 < lb_ ? vB11 : OOB, sb_); } while (0)
+
+    const int rowa = WTM * wr + l15, rowb = 64 * wc + l15;
+    int oa[2], ob[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        oa[kk] = rowa * 128 + ((((kk << 2) + g) ^ (rowa & 7)) << 4);
+        ob[kk] = TA + rowb * 128 + ((((kk << 2) + g) ^ (rowb & 7)) << 4);
+    }
+    f32x4 acc[TMW][4];
+#pragma unroll
+    for (int i = 0; i < TMW; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    P8P_B0(0); P8P_A0(0); P8P_B1(0); P8P_A1(0);
+    P8P_B0(1); P8P_A0(1); P8P_B1(1);
+    wait_vmcnt<6>();
+    asm volatile("s_barrier" ::: "memory");
+    if (wr == 1) asm volatile("s_barrier" ::: "memory");          // the second wave group runs one barrier behind the first
+
+    bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
+#define P8_RD_A(ST, AH, NA)                                                                                \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int i = 0; i < (NA); ++i)       \
+        fa[i][kk] = p8_ld(smem + (ST) * STAGE + oa[kk] + ((AH) * 64 + i * 16) * 128)
+#define P8_RD_B(ST, BH, F)                                                                                 \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int j = 0; j < 2; ++j)          \
+        F[j][kk] = p8_ld(smem + (ST) * STAGE + ob[kk] + ((BH) * 32 + j * 16) * 128)
+#define P8P_TILE(ST, kt)                                                                                   \
+    do {                                                                                                   \
+        P8_RD_B(ST, 0, fb0);                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        P8_RD_A(ST, 0, 4);                                                                                 \
+        P8P_A1((kt) + 1);                                                                                  \
+        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");                                                 \
+        P8_SYNC_IN(); p8_mfma<0, 0, 4, TMW>(fa, fb0, acc); P8_SYNC_OUT();                                   \
+        P8_RD_B(ST, 1, fb1);                                                                               \
+        P8P_B0((kt) + 2);                                                                                  \
+        P8_SYNC_IN(); p8_mfma<0, 1, 4, TMW>(fa, fb1, acc); P8_SYNC_OUT();                                   \
+        P8_RD_A(ST, 1, NA1);                                                                               \
+        P8P_A0((kt) + 2);                                                                                  \
+        P8_SYNC_IN(); p8_mfma<1, 1, NA1, TMW>(fa, fb1, acc); P8_SYNC_OUT();                                 \
+        P8P_B1((kt) + 2);                                                                                  \
+        wait_vmcnt<6>();                                                                                   \
+        P8_SYNC_IN(); p8_mfma<1, 0, NA1, TMW>(fa, fb0, acc); P8_SYNC_OUT();                                 \
+    } while (0)
+    for (;;) {
+        const int nxt = item + (int)gridDim.x;
+        has_next = nxt < p.nitems;
+        if (has_next) tile_origin(p, nxt, p.nitems, m0n, n0n, split, TBM, 256);
+        for (int kt = 0; kt < nk; kt += 2) {
+            P8P_TILE(0, kt);
+            P8P_TILE(1, kt + 1);
+        }
+        gemm_epilogue<T, false, TMW, 4, (TBM == 256 ? 2 : -2)>(p, acc, m0 + wr * WTM, n0 + wc * 64, g, l15,
+                                                               smem + 2 * STAGE + wave * epi_scratch_bytes<TMW, 4>(), lane);
+        if (!has_next) break;
+#pragma unroll
+        for (int i = 0; i < TMW; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        item = nxt; m0 = m0n; n0 = n0n;
+    }
+#undef P8P_TILE
+#undef P8_RD_A
+#undef P8_RD_B
+#undef P8P_A0
+#undef P8P_A1
+#undef P8P_B0
+#undef P8P_B1
+#undef P8P_SEL
+    if (wr == 0) asm volatile("s_barrier" ::: "memory");           // balance the second group's extra barrier
+}
+
+template <int TBM>
+int launch_p8p(const GemmArgs& a, hipStream_t stream) {
     static bool attr_done = false;
-    const size_t shm = 2 * (TBM + 256) * 128;
+    const size_t shm = 2 * (TBM + 256) * 128 + 8 * epi_scratch_bytes<TBM / 32, 4>();
     if (!attr_done) {
-        int rc = set_lds(gemm_p8_kernel<TBM>, shm, 512, TBM == 256 ? "eight-phase 256x256" : "eight-phase 192x256");
+        int rc = set_lds(gemm_p8p_kernel<TBM>, shm, 512, TBM == 256 ? "persistent eight-phase 256x256" : "persistent eight-phase 192x256");
         if (rc) return rc;
         attr_done = true;
     }
@@ -929,8 +1102,30 @@ int launch_p8(const GemmArgs& a, hipStream_t stream) {
     b.ntiles = cdiv(a.M, TBM) * b.tiles_n;
     b.nitems = b.ntiles;
     b.tiles_m_fast = 0;
+    b.cbw = 0;
     if (!(a.dbg_flags & 1)) b.cbw = column_block(a, TBM, 256, num_cus());
-    hipLaunchKernelGGL(gemm_p8_kernel<TBM>, dim3(b.nitems), dim3(512), shm, stream, b);
+    const int grid = b.nitems < num_cus() ? b.nitems : num_cus();      // (a multiple of 8 when it is not nitems: XCD-contiguous runs)
+    hipLaunchKernelGGL(gemm_p8p_kernel<TBM>, dim3(grid), dim3(512), shm, stream, b);
+    return MMTG_OK;
+}
+
+template <int TBM, bool KS = false>
+int launch_p8(const GemmArgs& a, int splits, hipStream_t stream) {
+    static bool attr_done = false;
+    const size_t shm = 2 * (TBM + 256) * 128;
+    if (!attr_done) {
+        int rc = set_lds(gemm_p8_kernel<TBM, KS>, shm, 512, KS ? "eight-phase 256x256 K-strided" : TBM == 256 ? "eight-phase 256x256" : "eight-phase 192x256");
+        if (rc) return rc;
+        attr_done = true;
+    }
+    GemmArgs b = a;
+    b.tiles_n = cdiv(a.N, 256);
+    b.ntiles = cdiv(a.M, TBM) * b.tiles_n;
+    b.nitems = b.ntiles * splits;
+    b.tiles_m_fast = KS && b.tiles_n > cdiv(a.M, TBM) && !(a.dbg_flags & 1);
+    b.cbw = 0;
+    if (!KS && !(a.dbg_flags & 1)) b.cbw = column_block(a, TBM, 256, num_cus());
+    hipLaunchKernelGGL((gemm_p8_kernel<TBM, KS>), dim3(b.nitems), dim3(512), shm, stream, b);
     return MMTG_OK;
 }
 
@@ -1203,7 +1398,8 @@ extern "C" int mmtg_gemm(int dtype, int transA, int transB, int M, int N, int K,
         static const int p8 = getenv("MMTG_GEMM_P8") ? atoi(getenv("MMTG_GEMM_P8")) : 1;
         static const int p8_rows_env = getenv("MMTG_GEMM_P8_ROWS") ? atoi(getenv("MMTG_GEMM_P8_ROWS")) : 0;
         const bool nt_big = !transA && transB && !skinny && !wgrad && M >= 1024 && N >= 256 && splits == 1 && epi != MMTG_EPI_SPLIT &&
-                            epi != MMTG_EPI_ATOMIC && !(flags & (MMTG_GEMM_WIDE | MMTG_GEMM_OCC4 | MMTG_GEMM_PERSIST | MMTG_GEMM_P256 | MMTG_GEMM_NO_P8));
+                            epi != MMTG_EPI_ATOMIC && !(flags & (MMTG_GEMM_WIDE | MMTG_GEMM_OCC4 | MMTG_GEMM_P256 | MMTG_GEMM_NO_P8)) &&
+                            (!(flags & MMTG_GEMM_PERSIST) || (flags & MMTG_GEMM_P8));
         if (big == 1 && nt_big && epi != MMTG_EPI_ROWDOT && !(epi == MMTG_EPI_DGELU && aux2)) {
             wide = false; persist = false; a.dbg_flags &= ~(2 | 32); a.dbg_flags |= 64;
         } else if (p8 && nt_big && K % 128 == 0 && (epi != MMTG_EPI_DGELU || p8 >= 2 || (flags & MMTG_GEMM_P8))) {
@@ -1215,7 +1411,30 @@ extern "C" int mmtg_gemm(int dtype, int transA, int transB, int M, int N, int K,
             int rows = c192 < 0.95 * c256 ? 192 : 256;
             if (p8_rows_env) rows = p8_rows_env;
             if (epi == MMTG_EPI_DGELU && aux2) rows = 256;      // the fused column sums need 64-row-aligned wave tiles
-            rc = rows == 192 ? launch_p8<192>(a, s) : launch_p8<256>(a, s);
+            // Persistent form (more than one round of tiles): OPT-IN, MMTG_GEMM_P8_PERSIST=1 or flags P8 | PERSIST.  Bit-equal, and
+            // measured slower (profiles/r02_v5_gemm_eight_phase_persistent_ab.txt): qkv 62.7 -> 74.9 us, fc1 + GELU 95.9 -> 102.0,
+            // LM head 316 -> 338, +0.2 ms per training step.  A workgroup that exits leaves its output stores to drain while the
+            // next workgroup of that CU is already fetching its first tiles; a persistent one has them in its own vmcnt queue in
+            // front of the next item's tiles, and every CU writes its 128-256 KB at the same moment.
+            static const int p8_persist = getenv("MMTG_GEMM_P8_PERSIST") ? atoi(getenv("MMTG_GEMM_P8_PERSIST")) : 0;
+            const long tiles = rows == 192 ? t192 : t256;
+            const bool want_persist = p8_persist || ((flags & MMTG_GEMM_P8) && (flags & MMTG_GEMM_PERSIST));
+            if (want_persist && tiles > ncu && ncu % 8 == 0) rc = rows == 192 ? launch_p8p<192>(a, s) : launch_p8p<256>(a, s);
+            else rc = rows == 192 ? launch_p8<192>(a, 1, s) : launch_p8<256>(a, 1, s);
+            if (rc) return rc;
+            MMTG_LAUNCH_CHECK("gemm");
+            return MMTG_OK;
+        }
+        // ... and its K-strided form for the weight gradients stored as K-split slabs: OPT-IN (MMTG_GEMM_P8T=1 or the MMTG_GEMM_P8
+        // flag).  One round of tiles x splits <= CUs workgroups (engine._wgrad_splits_p8).  Measured (profiles/
+        // r02_v5_gemm_eight_phase_tn.txt): the product alone 76 vs 82 us (fc, 7 vs 5 slabs), 64 vs 60 (qkv), with the slab sum 89
+        // vs 88 / 77 vs 68, and +0.47 ms per training step -- its K tile takes 2.0 us against 1.25-1.4 us for the K-contiguous
+        // form: 48 ds_read_b64_tr_b16 per wave and K tile do not fit under the other wave group's 16-MFMA phases, and with one
+        // workgroup per CU the cold first tiles and the 256 KB fp32 slab store of every item are exposed.
+        static const int p8t = getenv("MMTG_GEMM_P8T") ? atoi(getenv("MMTG_GEMM_P8T")) : 0;
+        if ((p8t || (flags & MMTG_GEMM_P8)) && wgrad && epi == MMTG_EPI_SPLIT && K % 128 == 0 && M >= 256 && N >= 256 && !(flags & (MMTG_GEMM_NO_P8 | MMTG_GEMM_PERSIST))) {
+            a.kper = cdiv(cdiv(K, splits), 128) * 128;
+            rc = launch_p8<256, true>(a, splits, s);
             if (rc) return rc;
             MMTG_LAUNCH_CHECK("gemm");
             return MMTG_OK;

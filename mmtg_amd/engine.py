@@ -200,6 +200,25 @@ def _wgrad_splits(M, N, K, occ4=False, slots=512, t_iter=1.1, t_fixed=6.0):
     return best
 
 
+_WTE_T = _os.environ.get("MMTG_NO_WTE_T") is None      # [D, Vpad] copy of wte for the LM head's dgrad (A/B switch)
+_P8T = _os.environ.get("MMTG_GEMM_P8T", "0") != "0"      # eight-phase K-strided kernel for the slab weight gradients (opt-in: measured slower in situ)
+
+
+def _wgrad_splits_p8(M, N, K, cus=256):
+    """Split count for the eight-phase weight-gradient kernel (256x256 tiles, ONE workgroup per CU): tiles x splits fills one
+    round of the CUs, every split a whole number of 128-deep K units, no empty trailing split.  None when the product is
+    not eligible (mmtg_gemm's rule: K % 128 == 0, M, N >= 256) or has too many tiles to gain from splitting."""
+    if not _P8T or K % 128 or M < 256 or N < 256:
+        return None
+    tiles = ((M + 255) // 256) * ((N + 255) // 256)
+    if tiles > cus // 2:
+        return None
+    units = K // 128
+    s0 = max(1, min(cus // tiles, units // 4))
+    per = -(-units // s0)
+    return -(-units // per)
+
+
 def _round_capacity(n):
     """Next value of {1, 1.25, 1.5, 1.75} x 2^k at or above n (<= 25 % slack, O(log) distinct sizes per buffer so the
     caching allocator's freed blocks are reused instead of piling up)."""
@@ -330,6 +349,7 @@ class Engine:
         fragment); the NN layout reads its K-strided weights with two transposed 8-byte LDS reads per
         fragment and measured 5-15 % slower per product (profiles/r01_v4_gemm_per_shape.log)."""
         self.wt = None
+        self.wte_t = None
         self.wt_entries = {}
         if self.dtype == hip.F32:
             return
@@ -345,6 +365,12 @@ class Engine:
         self.wt = torch.zeros(off, device=self.dev, dtype=torch.bfloat16)
         self.wt_desc = torch.tensor(desc, dtype=torch.int64, device=self.dev)
         self.wt_max = (max(d[1] for d in desc), max(d[2] for d in desc))
+        # ... and a [D, Vpad] copy of the tied embedding matrix: the LM head's dgrad d_h = dlogits @ wte contracts over the
+        # vocabulary, wte's ROW index -- through the copy it is a K-contiguous x K-contiguous product like every other
+        # forward / dgrad product (eight-phase kernel).  Its own launch: a shared grid would be sized by its 13440 rows.
+        woff, wn = self.layout.pack_range["wte"]
+        self.wte_t = torch.zeros(self.sh.D, self.layout.Vpad, device=self.dev, dtype=torch.bfloat16) if _WTE_T else None
+        self.wte_desc = torch.tensor([(woff, self.layout.Vpad, self.sh.D, 0)], dtype=torch.int64, device=self.dev)
 
     def Wt(self, key):   # [out, in] copy of a Conv1D weight (bf16 mode)
         off, shape, n = self.wt_entries[key]
@@ -353,6 +379,8 @@ class Engine:
     def _refresh_transposed(self):
         if self.wt is not None:
             hip.transpose_batch(self.wc, self.wt, self.wt_desc, self.wt_desc.shape[0], *self.wt_max)
+            if self.wte_t is not None:
+                hip.transpose_batch(self.wc, self.wte_t, self.wte_desc, 1, self.layout.Vpad, self.sh.D)
 
     def refresh_copies(self):
         """bf16 mode: re-derive the GEMM weight copies from the fp32 masters (an
@@ -421,6 +449,8 @@ class Engine:
         bf = self.dtype == hip.BF16
         splits = _wgrad_splits(Mg, Ng, Mtok, bf)
         tiles = ((Mg + 127) // 128) * ((Ng + 127) // 128)
+        if bf and _WGRAD_SLAB and Ng % 8 == 0:
+            splits = _wgrad_splits_p8(Mg, Ng, Mtok) or splits
         if bf and _WGRAD_SLAB and 1 < splits and tiles < 512 and Ng % 8 == 0:
             # K-split slabs with plain stores + an ordered sum instead of fp32 atomics (deterministic)
             # (one workspace, sized for the largest request so far: 113 MB at GPT-2 base, 268 MB at GPT-2 medium)
@@ -709,7 +739,10 @@ class Engine:
         pre = "decoder.gpt2.transformer."
         # ---- LM head (tied wte)
         dhf = self.buf("d_hf", (M, D))
-        hip.gemm(dlogits, self.Wp("wte"), dhf, M, D, Vp, transB=False, ldb=D)
+        if getattr(self, "wte_t", None) is not None and Vp % 128 == 0:
+            hip.gemm(dlogits, self.wte_t, dhf, M, D, Vp, transB=True, ldb=Vp)
+        else:
+            hip.gemm(dlogits, self.Wp("wte"), dhf, M, D, Vp, transB=False, ldb=D)
         # (Vpad rows: the pad columns of dlogits are zero, so the pad rows of the pack receive +0)
         hip.gemm(dlogits, a["hf"], self.Gp("wte"), Vp, D, M, transA=True, transB=False, lda=Vp, ldb=D, ldc=D,
                  epi=hip.EPI_ATOMIC, splits=_wgrad_splits(Vp, D, M, self.dtype == hip.BF16))

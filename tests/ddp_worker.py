@@ -80,7 +80,8 @@ def main():
                         else:
                             o = tr.step(batch, stage=1)
                         torch.cuda.synchronize()
-                        flats[distributed].append((model._flat.detach().cpu().clone(), float(o["loss"]), float(tr.grad_norm())))
+                        flats[distributed].append((model._flat.detach().cpu().clone(), float(o["loss"]), float(tr.grad_norm()),
+                                                   tr.eng.grad.detach().cpu().clone()))
                 res[dtype] = flats
                 res["%s_launched" % dtype] = launched
                 res["layout_total"] = models[0][0].layout.total

@@ -155,13 +155,16 @@ def test_gemm_persistent_pipeline_matches_plain(layout, K):
                 assert torch.equal(x, y)
 
 
-@pytest.mark.parametrize("shape", [(2000, 768, 256), (1310, 2304, 128), (1100, 3080, 384), (4200, 1000, 640)])
+@pytest.mark.parametrize("shape", [(2000, 768, 256), (1310, 2304, 128), (1100, 3080, 384), (4200, 1000, 640),
+                                   (8200, 2312, 128), (7672, 5112, 256)])
 def test_gemm_eight_phase_kernel_matches_older_kernels(shape):
     """The eight-phase kernel (256x256 / 192x256 tiles, two wave groups one barrier apart; the default for K-contiguous
     products with M >= 1024, N >= 256, K % 128 == 0) against the older kernels (GEMM_NO_P8) on the same inputs: every
     fused epilogue bit for bit -- plain, f32 output, bias + GELU with the saved pre-activation, residual + dropout,
     dGELU with its 64-row-band column sums, tanh, ROWDOT -- on ragged M / N edges; N = 768 and 2304 take 192-row tiles,
-    N ~ 3072 and 1000 take 256-row tiles.  Repeated launches must agree with themselves (race screen)."""
+    N ~ 3072 and 1000 take 256-row tiles; the last two shapes have more tiles than CUs and also run the PERSISTENT form (430
+    tiles of 192 rows, 600 tiles of 256 rows: two to three items per workgroup, the staging stream continuing across
+    items).  Repeated launches must agree with themselves (race screen)."""
     M, N, K = shape
     dtype = torch.bfloat16
     a = rnd(M, K, dtype=dtype, seed=61).to(DEV)
@@ -199,10 +202,40 @@ def test_gemm_eight_phase_kernel_matches_older_kernels(shape):
 
     old = run(hip.GEMM_NO_P8)
     close(old[1], a.float().cpu() @ w.float().cpu().t(), dtype, K, "older kernels vs fp32")
-    for rep in range(3):
-        new = run(hip.GEMM_P8 if rep else 0)      # default routing, then the dGELU product on the eight-phase kernel too
+    for rep in range(4):
+        # default routing; the dGELU product on the eight-phase kernel too (twice); the persistent form (opt-in)
+        new = run((0, hip.GEMM_P8, hip.GEMM_P8, hip.GEMM_P8 | hip.GEMM_PERSIST)[rep])
         for i, (x, y) in enumerate(zip(old, new)):
             assert torch.equal(x, y), (shape, rep, i)
+
+
+@pytest.mark.parametrize("shape", [(768, 2304, 1536, 3), (3072, 768, 2048, 4), (520, 776, 1280, 5), (256, 256, 128, 1)])
+def test_gemm_eight_phase_weight_gradient(shape):
+    """Slab weight gradients (transA, K-split slabs, MMTG_EPI_SPLIT) on the eight-phase K-strided kernel: with one split the
+    slab is bit-equal to the older single-stage kernel's (same K order); with several the slabs partition K in 128-deep units
+    -- their ordered sum matches the fp32 product to bf16-product accuracy and the older kernel's sum to fp32 rounding, the
+    launch is reproducible bit for bit, ragged M / N edges included."""
+    M, N, K, splits = shape
+    dtype = torch.bfloat16
+    a = rnd(K, M, dtype=dtype, seed=71).to(DEV)
+    b = rnd(K, N, dtype=dtype, seed=72).to(DEV)
+    ref = a.float().cpu().t() @ b.float().cpu()
+
+    def run(flags, sp):
+        part = torch.full((sp, M, N), 5.0, device=DEV, dtype=torch.float32)
+        hip.gemm(a, b, part, M, N, K, transA=True, transB=False, epi=hip.EPI_SPLIT, out_f32=True, splits=sp, flags=flags)
+        return part
+
+    P8 = hip.GEMM_P8      # (opt-in for weight gradients: the older single-stage kernel measured faster inside the step)
+    one_old, one_new = run(hip.GEMM_NO_P8, 1), run(P8, 1)
+    assert torch.equal(one_old, one_new)
+    close(one_new[0], ref, dtype, K, "one slab vs fp32")
+    if splits > 1:
+        new = run(P8, splits)
+        for _ in range(3):
+            assert torch.equal(run(P8, splits), new)
+        close(new.sum(0), ref, dtype, K, "slab sum vs fp32")
+        close(new.sum(0), run(hip.GEMM_NO_P8, splits).sum(0), torch.float32, K, "slab sum vs older kernel")
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -123,6 +123,14 @@ case("dgrad fc1 (NT)", M, D, 4 * D, False, True)
 case("dgrad proj (NT)", M, D, D, False, True)
 case("dgrad qkv (NT)", M, D, 3 * D, False, True)
 case("dgrad lm head (NN)", M, D, V, False, False)
+if os.environ.get("TNSET"):
+    # weight gradients as the trainer launches them: K-split slabs (+ the ordered slab sum), split count per kernel family
+    from mmtg_amd.engine import _wgrad_splits_p8 as ws8
+    SLAB = int(os.environ.get("SLAB", "1"))
+    for nm, a, b in (("wgrad fc2", 4 * D, D), ("wgrad fc1", D, 4 * D), ("wgrad proj", D, D), ("wgrad qkv", D, 3 * D)):
+        sp = (ws8(a, b, M) if os.environ.get("MMTG_GEMM_P8T", "0") != "0" else None) or ws(a, b, M, True)
+        case(nm + " (TN s=%d)" % sp, a, b, M, True, False, hip.EPI_ATOMIC, sp)
+    sys.exit(0)
 for nm, a, b in (("wgrad fc2", 4 * D, D), ("wgrad fc1", D, 4 * D), ("wgrad proj", D, D), ("wgrad qkv", D, 3 * D), ("wgrad lm head", V, D), ("wgrad proj1", 512, 2048)):
     occ4 = not (FLAGS & hip.GEMM_NO_OCC4)
     case(nm + " (TN,atomic s=%d)" % ws(a, b, M, occ4), a, b, M, True, False, hip.EPI_ATOMIC, ws(a, b, M, occ4))

@@ -1,0 +1,34 @@
+"""Two trainers from identical state, same batch, same dropout seed: which gradient tensors differ bit for bit after one
+backward?  (tests/test_ddp_gpu.py relies on the GPT-2 block matrices being reproducible.)"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+from ddp_worker import build
+from mmtg_amd import synth
+from mmtg_amd.trainer import MMTGTrainer
+dev = torch.device("cuda", 0)
+rows = int(os.environ.get("ROWS", "12"))
+for trial in range(int(os.environ.get("TRIALS", "8"))):
+    grads = []
+    for rep in range(2):
+        model, mcfg, dcfg, V = build("bf16", 0.1, dev)
+        tr = MMTGTrainer(model, lr=0.0, alpha=0.2, distributed=False)
+        tr.eng.drop_seed = 4242
+        nb = synth.make_batch(rows, mcfg, dcfg, V, seed=7)
+        batch = {k: torch.from_numpy(np.asarray(v)).to(dev) for k, v in nb.items()}
+        if rep:   # perturb allocator / cache history between the two runs
+            junk = torch.randn(64 << 20, device=dev)
+        tr.step(batch, stage=1)
+        torch.cuda.synchronize()
+        grads.append(tr.eng.grad.detach().cpu().clone())
+        lay = model.layout
+    bad = []
+    for k, (off, shape, n) in lay.entries.items():
+        a, b = grads[0][off:off + n], grads[1][off:off + n]
+        if not torch.equal(a, b):
+            bad.append((k, float((a - b).abs().max()), float(a.abs().max()), int((a != b).sum()), n))
+    mats = [x for x in bad if ".h." in x[0] and x[0].endswith(".weight") and ".ln_" not in x[0]]
+    print("trial", trial, "differing tensors:", len(bad), "of which GPT-2 block matrices:", len(mats))
+    for x in mats:
+        print("   ", x)
