@@ -124,6 +124,10 @@ int mmtg_gemm_gather(int mode, int M, int N, int K, const void* A, long lda, con
  * s_memrealtime (100 MHz) at kernel entry, after the first K tile has landed, at the end of the K
  * loop, at exit; the K tile count; the hardware id (XCC / SE / CU).  Null switches it off (default). */
 int mmtg_gemm_trace(void* buf, int max_wgs);
+/* CUs the tile-shape rule of the eight-phase kernel (one workgroup = one whole CU) may count on: 0 = all, > 0 = that many,
+ * < 0 = all but that many.  A rule input only -- results never depend on it.  mmtg_amd.ddp reserves CUs for the RCCL kernels
+ * that run beside the backward (replaces nothing in the reference: its nn.DataParallel, train.py:112-114, serialises). */
+int mmtg_gemm_cu_budget(int cus);
 
 /* Second half of a MMTG_EPI_SPLIT product: out[m, :] = epi(sum_s part[s][m][:] + bias) in the storage type
  * (slabs summed in index order -> deterministic); epi in {NONE, GELU, TANH, RESID (+ aux)}.  With ln_out the

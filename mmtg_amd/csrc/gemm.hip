@@ -1205,6 +1205,23 @@ int launch_dma(const GemmArgs& a, int transA, int transB, int splits, int skinny
 // C ABI ---------------------------------------------------------------------
 static unsigned long long* g_trace = nullptr;
 static int g_trace_n = 0;
+// CUs the tile-shape rule of the eight-phase kernel may count on (0 = all; > 0 = that many; < 0 = all but that many).  One
+// workgroup of that kernel takes a whole CU (all 512 registers per lane, 112-128 KB of LDS), so a long-running kernel on
+// another stream -- the RCCL collectives of the data-parallel step -- takes CUs away from it for its whole duration: a
+// 237-tile product sized for 256 CUs would need a second, almost empty round.  mmtg_amd.ddp reserves CUs when collectives run.
+static int g_cu_budget = 0;
+extern "C" int mmtg_gemm_cu_budget(int cus) {
+    g_cu_budget = cus;
+    return MMTG_OK;
+}
+static long p8_cus() {
+    const long n = num_cus();
+    long b = g_cu_budget > 0 ? g_cu_budget : n + g_cu_budget;
+    if (b > n) b = n;
+    if (b < 8) b = 8;
+    return b;
+}
+
 extern "C" int mmtg_gemm_trace(void* buf, int max_wgs) {
     MMTG_REQUIRE(!buf || max_wgs > 0, "gemm_trace: max_wgs must be positive");
     g_trace = reinterpret_cast<unsigned long long*>(buf);
@@ -1406,7 +1423,7 @@ extern "C" int mmtg_gemm(int dtype, int transA, int transB, int M, int N, int K,
             // (dGELU keeps the single-stage kernel: with the saved pre-activation read in its exposed epilogue the eight-phase
             //  kernel measured 115.7 vs 112.5 us inside the training step; MMTG_GEMM_P8=2 or the MMTG_GEMM_P8 flag routes it here too -- bit-equal)
             const long t256 = (long)cdiv(M, 256) * cdiv(N, 256), t192 = (long)cdiv(M, 192) * cdiv(N, 256);
-            const long ncu = num_cus();
+            const long ncu = p8_cus();
             const double c256 = (double)cdiv(t256, ncu), c192 = 0.75 * (double)cdiv(t192, ncu);
             int rows = c192 < 0.95 * c256 ? 192 : 256;
             if (p8_rows_env) rows = p8_rows_env;
@@ -1419,7 +1436,7 @@ extern "C" int mmtg_gemm(int dtype, int transA, int transB, int M, int N, int K,
             static const int p8_persist = getenv("MMTG_GEMM_P8_PERSIST") ? atoi(getenv("MMTG_GEMM_P8_PERSIST")) : 0;
             const long tiles = rows == 192 ? t192 : t256;
             const bool want_persist = p8_persist || ((flags & MMTG_GEMM_P8) && (flags & MMTG_GEMM_PERSIST));
-            if (want_persist && tiles > ncu && ncu % 8 == 0) rc = rows == 192 ? launch_p8p<192>(a, s) : launch_p8p<256>(a, s);
+            if (want_persist && tiles > num_cus() && num_cus() % 8 == 0) rc = rows == 192 ? launch_p8p<192>(a, s) : launch_p8p<256>(a, s);
             else rc = rows == 192 ? launch_p8<192>(a, 1, s) : launch_p8<256>(a, 1, s);
             if (rc) return rc;
             MMTG_LAUNCH_CHECK("gemm");

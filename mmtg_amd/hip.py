@@ -31,6 +31,7 @@ _SIGS = {
     "mmtg_prof_enable": ([_i], _i),
     "mmtg_prof_read": ([_vp, _vp, _vp, _vp], _i),
     "mmtg_gemm_trace": ([_vp, _i], _i),
+    "mmtg_gemm_cu_budget": ([_i], _i),
     "mmtg_gemm": ([_i, _i, _i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _vp, _i, _vp, _l, _vp, _i, _f, _i, _u, _u, _i, _vp], _i),
     "mmtg_gemm_gather": ([_i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _vp, _i, _vp, _i, _vp, _l, _vp, _i, _vp], _i),
     "mmtg_splitk_finish": ([_i, _vp, _i, _i, _i, _l, _vp, _i, _vp, _l, _vp, _l, _vp, _vp, _vp, _f, _vp], _i),
@@ -164,6 +165,11 @@ def prof_read():
 
 
 # ------------------------------------------------------------------ GEMM
+def gemm_cu_budget(cus):
+    """CUs the eight-phase kernel's tile rule may count on (0 = all, > 0 = that many, < 0 = all but that many)."""
+    _check(lib().mmtg_gemm_cu_budget(int(cus)), "gemm_cu_budget")
+
+
 def gemm_trace(buf=None):
     """Switch the in-kernel timeline of the LDS-DMA GEMMs on (buf: int64 CUDA tensor [max_wgs, 6]) or off."""
     _check(lib().mmtg_gemm_trace(_p(buf), 0 if buf is None else buf.shape[0]), "gemm_trace")

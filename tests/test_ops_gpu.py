@@ -209,6 +209,35 @@ def test_gemm_eight_phase_kernel_matches_older_kernels(shape):
             assert torch.equal(x, y), (shape, rep, i)
 
 
+def test_gemm_eight_phase_tile_rule_follows_the_cu_budget():
+    """mmtg_gemm_cu_budget (set by mmtg_amd.ddp when RCCL kernels run beside the backward): with all 256 CUs an
+    N = 768 product of 15104 rows takes 192-row tiles (79 x 3 = 237 workgroups, one round); with 32 CUs left to the
+    collectives 237 would spill into a second round, so the rule falls back to 256-row tiles (59 x 3 = 177).  The
+    result does not depend on the choice."""
+    M, N, K = 15104, 768, 256
+    dtype = torch.bfloat16
+    a = rnd(M, K, dtype=dtype, seed=81).to(DEV)
+    w = rnd(N, K, dtype=dtype, seed=82).to(DEV)
+    outs, counts = [], []
+    try:
+        for budget in (0, -32):
+            hip.gemm_cu_budget(budget)
+            buf = torch.zeros(4096, 6, device=DEV, dtype=torch.int64)
+            c = torch.empty(M, N, device=DEV, dtype=dtype)
+            hip.gemm_trace(buf)
+            hip.gemm(a, w, c, M, N, K, transB=True)
+            torch.cuda.synchronize()
+            hip.gemm_trace(None)
+            outs.append(c)
+            counts.append(int((buf[:, 3] != 0).sum()))
+    finally:
+        hip.gemm_cu_budget(0)
+        hip.gemm_trace(None)
+    assert torch.equal(outs[0], outs[1])
+    if torch.cuda.get_device_properties(0).multi_processor_count == 256:
+        assert counts == [237, 177], counts
+
+
 @pytest.mark.parametrize("shape", [(768, 2304, 1536, 3), (3072, 768, 2048, 4), (520, 776, 1280, 5), (256, 256, 128, 1)])
 def test_gemm_eight_phase_weight_gradient(shape):
     """Slab weight gradients (transA, K-split slabs, MMTG_EPI_SPLIT) on the eight-phase K-strided kernel: with one split the
