@@ -25,12 +25,37 @@ __global__ __launch_bounds__(256) void mfma_loop(float* out, int iters, float se
     }
 }
 
+// the 32x32x16 form: twice the work per instruction (16 accumulator registers per tile)
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+template <int NACC>
+__global__ __launch_bounds__(256) void mfma32_loop(float* out, int iters, float seed, unsigned long long* clk) {
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    bf16x8 a, b;
+    for (int e = 0; e < 8; ++e) { a[e] = (__bf16)(seed + 0.001f * (threadIdx.x + e)); b[e] = (__bf16)(0.5f - 0.002f * (threadIdx.x % 7 + e)); }
+    f32x16 acc[NACC];
+    for (int i = 0; i < NACC; ++i)
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int i = 0; i < NACC; ++i)
+        for (int e = 0; e < 16; ++e) s += acc[i][e];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+    if (clk && blockIdx.x == 0 && threadIdx.x == 0) {
+        clk[0] = __builtin_amdgcn_s_memtime() - c0;
+        clk[1] = __builtin_amdgcn_s_memrealtime() - r0;
+    }
+}
+
 extern "C" float mfma_run(int blocks, int iters, int nacc, float* out, unsigned long long* clk) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     for (int rep = 0; rep < 2; ++rep) {
         hipEventRecord(e0, 0);
-        if (nacc == 16) hipLaunchKernelGGL(mfma_loop<16>, dim3(blocks), dim3(256), 0, 0, out, iters, 0.25f, clk);
+        if (nacc == 32) hipLaunchKernelGGL(mfma32_loop<4>, dim3(blocks), dim3(256), 0, 0, out, iters, 0.25f, clk);
+        else if (nacc == 16) hipLaunchKernelGGL(mfma_loop<16>, dim3(blocks), dim3(256), 0, 0, out, iters, 0.25f, clk);
         else hipLaunchKernelGGL(mfma_loop<4>, dim3(blocks), dim3(256), 0, 0, out, iters, 0.25f, clk);
         hipEventRecord(e1, 0);
         hipEventSynchronize(e1);
