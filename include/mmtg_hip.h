@@ -259,6 +259,9 @@ int mmtg_beta_fuse_bwd(int dtype, const void* topic, const void* img, const void
  * backward pass reads them (saved activations are cold by then).  Launched on a side stream, gated by events; `sink` is a
  * 4-byte device scratch that is never written in practice.                                                       */
 int mmtg_prefetch(const void* src, long bytes, int workgroups, void* sink, void* stream);
+/* zero n ranges of an fp32 buffer in one launch: desc (device, int64) holds (first element, count) pairs, both multiples of 4
+ * (optimizer.zero_grad of train.py:192 for the gradients that are accumulated into; the rest is overwritten) */
+int mmtg_zero_ranges(float* base, const long* desc, int n, void* stream);
 
 /* ---------------------------------------------------------------- optimizer (train.py:194-197)
  * sumsq: *out += sum x^2 (global grad-norm partial).                          */

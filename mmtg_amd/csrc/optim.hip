@@ -161,6 +161,18 @@ __global__ __launch_bounds__(256) void prefetch_kernel(const u32x4* __restrict__
     if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x9E3779B9u && sink) *sink = 1u;      // (keeps the loads alive)
 }
 
+// Zero a list of ranges of one fp32 buffer in ONE launch: desc[2 r] = first element (a multiple of 4), desc[2 r + 1] = count (a
+// multiple of 4).  The fused trainer zeroes only the gradients that are ACCUMULATED into (LayerNorm / bias columns, embeddings,
+// LM head, encoder): the block matrices, 340 of the 497 MB, are overwritten by their slab sums.
+__global__ __launch_bounds__(256) void zero_ranges_kernel(float* __restrict__ base, const long* __restrict__ desc, int n) {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < n; ++r) {
+        f32x4* p = reinterpret_cast<f32x4*>(base + desc[2 * r]);
+        const long cnt = desc[2 * r + 1] >> 2;
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < cnt; i += (long)gridDim.x * 256) p[i] = z;
+    }
+}
+
 inline unsigned grid_for(long n) { return (unsigned)min((long)2048, (n + 255) / 256); }
 
 }  // namespace
@@ -169,6 +181,13 @@ extern "C" int mmtg_prefetch(const void* src, long bytes, int workgroups, void* 
     MMTG_REQUIRE(src && bytes >= 16 && MMTG_ALIGNED16(src) && workgroups > 0, "prefetch: bad args");
     hipLaunchKernelGGL(prefetch_kernel, dim3((unsigned)workgroups), dim3(256), 0, (hipStream_t)stream, (const u32x4*)src, bytes / 16, (unsigned*)sink);
     MMTG_LAUNCH_CHECK("prefetch");
+    return MMTG_OK;
+}
+
+extern "C" int mmtg_zero_ranges(float* base, const long* desc, int n, void* stream) {
+    MMTG_REQUIRE(base && desc && n > 0 && MMTG_ALIGNED16(base), "zero_ranges: bad args");
+    hipLaunchKernelGGL(zero_ranges_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, base, desc, n);
+    MMTG_LAUNCH_CHECK("zero_ranges");
     return MMTG_OK;
 }
 

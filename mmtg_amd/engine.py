@@ -200,6 +200,7 @@ def _wgrad_splits(M, N, K, occ4=False, slots=512, t_iter=1.1, t_fixed=6.0):
     return best
 
 
+_LAZY_ZERO = _os.environ.get("MMTG_FULL_ZERO_GRAD") is None   # zero only the accumulated gradients once a step shape is known (A/B switch)
 _WTE_T = _os.environ.get("MMTG_NO_WTE_T") is None      # [D, Vpad] copy of wte for the LM head's dgrad (A/B switch)
 _P8T = _os.environ.get("MMTG_GEMM_P8T", "0") != "0"      # eight-phase K-strided kernel for the slab weight gradients (opt-in: measured slower in situ)
 
@@ -273,6 +274,7 @@ class Engine:
         self.training = False
         self.drop_seed = initial_drop_seed(_dist_rank())
         self.wgrad_overwrite = False   # set by MMTGTrainer.step around its backward
+        self._ow_desc, self._ow_rec = {}, None   # zero lists per step shape / the record in progress (zero_grad)
         self.step_count = 0
         self.opt_m = None
         self.opt_v = None
@@ -339,9 +341,40 @@ class Engine:
         if self.grad is None:
             self.grad = torch.zeros(self.layout.total, device=self.dev, dtype=torch.float32)
 
-    def zero_grad(self):
+    def zero_grad(self, shape_key=None):
+        """Zero the flat gradient buffer.  With a shape key (the fused trainer: rows x positions of the step) only what is
+        ACCUMULATED into is zeroed once a step of that shape has shown which tensors its backward OVERWRITES (the slab-sum
+        block matrices, recorded by _wgrad: 340 of 497 MB at the full configuration) -- one launch over the complement."""
         self.ensure_grad()
+        self._ow_rec = None
+        if shape_key is not None and _LAZY_ZERO:
+            desc = self._ow_desc.get(shape_key)
+            if desc is not None:
+                hip.zero_ranges(self.grad, desc, desc.shape[0])
+                return
+            if len(self._ow_desc) < 64:
+                self._ow_rec = (shape_key, [])          # record this step's overwritten ranges
         self.grad.zero_()
+
+    def _finish_overwrite_record(self):
+        """After a recorded backward: the complement of the overwritten ranges becomes the zero list of that step shape."""
+        if self._ow_rec is None:
+            return
+        key, ranges = self._ow_rec
+        self._ow_rec = None
+        ranges = sorted(r for r in ranges if r[0] % 4 == 0 and r[1] % 4 == 0)
+        comp, pos = [], 0
+        for off, n in ranges:
+            if off < pos:
+                return                                # overlapping records: keep zeroing everything
+            if off > pos:
+                comp.append((pos, off - pos))
+            pos = off + n
+        if pos < self.layout.total:
+            comp.append((pos, self.layout.total - pos))
+        if not ranges or any(o % 4 or c % 4 for o, c in comp):
+            return
+        self._ow_desc[key] = torch.tensor(comp, dtype=torch.int64, device=self.dev)
 
     def _init_transposed(self):
         """bf16 mode: K-contiguous [out,in] copies of GPT-2's Conv1D [in,out] weights.  With them every
@@ -459,6 +492,8 @@ class Engine:
                      epi=hip.EPI_SPLIT, out_f32=True, splits=splits)
             # (the fused trainer zeroes the gradients right before its single backward: the sum may then overwrite)
             hip.slab_sum(part, splits, Mg * Ng, gw, Mg * Ng, accumulate=not self.wgrad_overwrite)
+            if self.wgrad_overwrite and self._ow_rec is not None:
+                self._ow_rec[1].append((self.layout.entries[wkey][0], Mg * Ng))
             splits = 0
         if splits:
             hip.gemm(A, B, gw, Mg, Ng, Mtok, transA=True, transB=False, lda=lda, ldb=ldb, ldc=Ng,

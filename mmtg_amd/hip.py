@@ -57,6 +57,7 @@ _SIGS = {
     "mmtg_beta_fuse_fwd": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp], _i),
     "mmtg_beta_fuse_bwd": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp], _i),
     "mmtg_prefetch": ([_vp, _l, _i, _vp, _vp], _i),
+    "mmtg_zero_ranges": ([_vp, _vp, _i, _vp], _i),
     "mmtg_sumsq": ([_vp, _l, _vp, _vp], _i),
     "mmtg_adamw": ([_vp, _vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _i, _vp, _f, _f, _vp, _vp], _i),
     "mmtg_cast_f32_to": ([_i, _vp, _vp, _l, _vp], _i),
@@ -165,6 +166,11 @@ def prof_read():
 
 
 # ------------------------------------------------------------------ GEMM
+def zero_ranges(base, desc, n):
+    """Zero n (first element, count) ranges of the fp32 tensor `base` in one launch; desc: int64 device tensor [n, 2]."""
+    _check(lib().mmtg_zero_ranges(_p(base), _p(desc), int(n), _stream()), "zero_ranges")
+
+
 def gemm_cu_budget(cus):
     """CUs the eight-phase kernel's tile rule may count on (0 = all, > 0 = that many, < 0 = all but that many)."""
     _check(lib().mmtg_gemm_cu_budget(int(cus)), "gemm_cu_budget")

@@ -104,7 +104,8 @@ class MMTGTrainer:
         self._count.fill_(float(n_local))           # asynchronous fill; the value is known on the host
         if red is not None:
             red.start_count(self._count)            # SUM over ranks, in place, asynchronous
-        eng.zero_grad()
+        # (a step without rows runs no backward: everything must be zero for the exchange)
+        eng.zero_grad((n_local, int(batch["targets"].shape[1])) if n_local > 0 and "targets" in batch else None)
         out = None
         if n_local > 0:
             eng.forward(batch, train_flag=True, training=self.model.training, logits_f32=_LOGITS_F32)
@@ -114,8 +115,10 @@ class MMTGTrainer:
             eng.wgrad_overwrite = True      # gradients were zeroed above and every weight is written once
             try:
                 eng.backward(dl, dkl=self.alpha * n_local)
+                eng._finish_overwrite_record()
             finally:
                 eng.wgrad_overwrite = False
+                eng._ow_rec = None
             out = {"loss": sc[0], "lm_loss": sc[1], "kl": eng.act["kl"][0]}
         if red is not None:
             red.finish(eng.grad)

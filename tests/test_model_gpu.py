@@ -443,6 +443,46 @@ def test_trainer_gradients_equal_the_accumulating_path():
     assert n == 8
 
 
+def test_trainer_zeroes_only_the_accumulated_gradients_after_the_first_step_of_a_shape():
+    """MMTGTrainer.step zeroes the whole flat gradient buffer the first time it sees a step shape and records which tensors
+    that backward OVERWRITES (the slab-sum block matrices); later steps of the same shape zero only the complement with one
+    mmtg_zero_ranges launch.  Poison the buffer before the third step: the result must not depend on it -- the block-matrix
+    gradients bit-equal to a trainer that always zeroes everything, every other gradient within summation-order noise -- and
+    a different row count falls back to the full zero (and records its own list)."""
+    from mmtg_amd.trainer import curriculum_filter  # noqa: F401  (the stage-3 step keeps every row)
+    fx, meta, mcfg, gcfg, dcfg, weights, table, batch, model = build("tiny_s5", "bf16")
+    fx2, meta2, mcfg2, gcfg2, dcfg2, weights2, table2, batch2, model2 = build("tiny_s5", "bf16")
+    tb = batch_to_torch(batch, DEV)
+    lazy, full = MMTGTrainer(model, lr=0.0, alpha=0.2), MMTGTrainer(model2, lr=0.0, alpha=0.2)
+    e1, e2 = lazy.eng, full.eng
+    orig = e2.zero_grad
+    e2.zero_grad = lambda shape_key=None: orig(None)              # the reference behaviour: zero everything, every step
+    for step in range(3):
+        e1.drop_seed = e2.drop_seed = 777 + step
+        if step == 2:
+            assert len(e1._ow_desc) == 1 and not e2._ow_desc
+            desc = next(iter(e1._ow_desc.values())).cpu()
+            kept = e1.layout.total - int(desc[:, 1].sum())
+            assert kept >= sum(e1.layout.entries["decoder.gpt2.transformer.h.%d.%s" % (l, w)][2] for l in range(2)
+                               for w in ("attn.c_attn.weight", "attn.c_proj.weight", "mlp.c_fc.weight", "mlp.c_proj.weight"))
+            e1.grad.fill_(1e30)                                    # anything left un-zeroed AND un-overwritten would show
+        lazy.step(tb, stage=3)
+        full.step(tb, stage=3)
+    torch.cuda.synchronize()
+    assert torch.isfinite(e1.grad).all()
+    assert float((e1.grad - e2.grad).norm() / e2.grad.norm()) < 1e-6
+    for l in range(2):
+        for w in ("attn.c_attn.weight", "attn.c_proj.weight", "mlp.c_fc.weight", "mlp.c_proj.weight"):
+            key = "decoder.gpt2.transformer.h.%d.%s" % (l, w)
+            assert torch.equal(e1.layout.view(e1.grad, key), e2.layout.view(e2.grad, key)), key
+    half = {k: v[:2] for k, v in tb.items()}                       # another row count: full zero again (and its own record, if any)
+    e1.drop_seed = e2.drop_seed = 999
+    e1.grad.fill_(1e30)
+    lazy.step(half, stage=3)
+    full.step(half, stage=3)
+    assert torch.isfinite(e1.grad).all() and float((e1.grad - e2.grad).norm() / e2.grad.norm()) < 1e-6
+
+
 # ------------------------------------------------------------------ the benchmarked mode at depth (12 layers, V = 13317)
 def _report(name, **kv):
     """Measured bounds are appended to $MMTG_TEST_REPORT (a JSON-lines file) when set -- DESIGN.md quotes them."""
