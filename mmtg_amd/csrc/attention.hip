@@ -859,8 +859,11 @@ __device__ __forceinline__ void bwd_small_keys_block(BwdKeys& st, const char* sQ
         mma16(ld_ks(sQ, q0 + 4 * g, q0 + 16 + 4 * g, dt * 16, lane, bf16()), db, st.dk[dt]);
     }
 }
+// ACC: the bias-gradient sums of this tile are added to the wave's register accumulators bk / bv (one cross-lane reduction per
+// wave at the end of the kernel, bwd_small_bias_flush) instead of being reduced over the 16 key lanes and added to LDS per tile
+template <bool ACC>
 __device__ __forceinline__ void bwd_small_keys_store(const BwdKeys& st, int t, int lane, int b, int h, int Tn, int nH, float inv_keep,
-                                                     bool kpok, bf16* __restrict__ dqkv, float* sB) {
+                                                     bool kpok, bf16* __restrict__ dqkv, float* sB, f32x4 (&bk)[4], f32x4 (&bv)[4]) {
     const int g = lane >> 4, l15 = lane & 15, key = 16 * t + l15, D = nH * DH;
     const long ld = 3L * D;
     const bool kin = key < Tn;
@@ -887,14 +890,35 @@ __device__ __forceinline__ void bwd_small_keys_store(const BwdKeys& st, int t, i
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float sk = kin ? (float)kk[dt][r] : 0.f, sv = kin ? (float)vv[dt][r] : 0.f;
+                if constexpr (ACC) {
+                    bk[dt][r] += sk;
+                    bv[dt][r] += sv;
+                } else {
 #pragma unroll
-                for (int o = 1; o < 16; o <<= 1) { sk += __shfl_xor(sk, o, 64); sv += __shfl_xor(sv, o, 64); }
-                if (l15 == 0) {
-                    atomicAdd(sB + dt * 16 + 4 * g + r, sk);
-                    atomicAdd(sB + DH + dt * 16 + 4 * g + r, sv);
+                    for (int o = 1; o < 16; o <<= 1) { sk += __shfl_xor(sk, o, 64); sv += __shfl_xor(sv, o, 64); }
+                    if (l15 == 0) {
+                        atomicAdd(sB + dt * 16 + 4 * g + r, sk);
+                        atomicAdd(sB + DH + dt * 16 + 4 * g + r, sv);
+                    }
                 }
             }
     }
+}
+// the wave's accumulated bias sums: one reduction over the 16 key lanes, one LDS add per (channel, wave)
+__device__ __forceinline__ void bwd_small_bias_flush(const f32x4 (&bk)[4], const f32x4 (&bv)[4], float* sB, int lane) {
+    const int g = lane >> 4, l15 = lane & 15;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float sk = bk[dt][r], sv = bv[dt][r];
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) { sk += __shfl_xor(sk, o, 64); sv += __shfl_xor(sv, o, 64); }
+            if (l15 == 0) {
+                atomicAdd(sB + dt * 16 + 4 * g + r, sk);
+                atomicAdd(sB + DH + dt * 16 + 4 * g + r, sv);
+            }
+        }
 }
 
 // NW waves per workgroup: 8 (two workgroups = 16 waves per CU, <= 128 VGPRs) or 4 (two workgroups = 8 waves per CU, up to
@@ -949,6 +973,11 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void attn_bwd_small_kv_kernel(cons
     BwdKeys st;
 #pragma unroll
     for (int i = 0; i < 4; ++i) st.dk[i] = st.dv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // (the 4-wave build has the registers to carry the bias sums over its four tiles: 32 more; the 8-wave build reduces per tile)
+    constexpr bool BACC = NW == 4;
+    f32x4 bk[4], bv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bk[i] = bv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int nqb = (Tn + 31) >> 5;
     const float ik_scale = inv_keep * 0.125f;
     // The wave's first tile (low keys: the longest sweep) takes the query blocks from its diagonal on as they land;
@@ -986,17 +1015,18 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void attn_bwd_small_kv_kernel(cons
                 bwd_small_keys_block<DROP>(st, sQ, sO, sLse, sDel, sMask, kf, vf, tA, 32 * qb, lane, ik_scale);
         }
         if (tA != tB) load_frags(tB);
-        bwd_small_keys_store(st, tA, lane, b, h, Tn, nH, inv_keep, sKeep[(16 * tA + l15) & 255] != 0, dqkv, sBp);
+        bwd_small_keys_store<BACC>(st, tA, lane, b, h, Tn, nH, inv_keep, sKeep[(16 * tA + l15) & 255] != 0, dqkv, sBp, bk, bv);
         if (tA != tB) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) st.dk[i] = st.dv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
             for (int qb = (16 * tB) >> 5; qb < nqb; ++qb)
                 bwd_small_keys_block<DROP>(st, sQ, sO, sLse, sDel, sMask, kf, vf, tB, 32 * qb, lane, ik_scale);
-            bwd_small_keys_store(st, tB, lane, b, h, Tn, nH, inv_keep, sKeep[(16 * tB + l15) & 255] != 0, dqkv, sBp);
+            bwd_small_keys_store<BACC>(st, tB, lane, b, h, Tn, nH, inv_keep, sKeep[(16 * tB + l15) & 255] != 0, dqkv, sBp, bk, bv);
         }
     }
     if (dbias) {
+        if constexpr (BACC) bwd_small_bias_flush(bk, bv, sB, lane);
         __syncthreads();
         // this kernel owns the K and V parts of head h's columns: one partial row per batch row
         // (bias_rows: plain stores into row b of the scratch; otherwise atomics onto the gradient)
@@ -1050,7 +1080,7 @@ __device__ __forceinline__ void bwd_small_queries_block(f32x4 (&dq)[4], const ch
         mma16(ld_ks(sK, j0 + 4 * g, j0 + 16 + 4 * g, dt * 16, lane, bf16()), db, dq[dt]);
 }
 __device__ __forceinline__ void bwd_small_queries_store(const f32x4 (&dq)[4], int t, int lane, int b, int h, int Tn, int nH,
-                                                        bf16* __restrict__ dqkv, float* sB) {
+                                                        bf16* __restrict__ dqkv, float* sB, f32x4 (&bq)[4]) {
     const int g = lane >> 4, l15 = lane & 15, qi = 16 * t + l15, D = nH * DH;
     const long ld = 3L * D;
     const bool qok = qi < Tn;
@@ -1062,17 +1092,24 @@ __device__ __forceinline__ void bwd_small_queries_store(const f32x4 (&dq)[4], in
             *reinterpret_cast<bf16x4*>(dst + dt * 16 + 4 * g) = qq;
         }
     }
-    if (sB) {
+    if (sB) {        // bias-gradient sums of the values as stored: into the wave's accumulators, reduced once after its last tile
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float sq = qok ? (float)(bf16)dq[dt][r] : 0.f;
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) sq += __shfl_xor(sq, o, 64);
-                if (l15 == 0) atomicAdd(sB + dt * 16 + 4 * g + r, sq);
-            }
+            for (int r = 0; r < 4; ++r) bq[dt][r] += qok ? (float)(bf16)dq[dt][r] : 0.f;
     }
+}
+__device__ __forceinline__ void bwd_small_bias_flush_q(const f32x4 (&bq)[4], float* sB, int lane) {
+    const int g = lane >> 4, l15 = lane & 15;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float sq = bq[dt][r];
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) sq += __shfl_xor(sq, o, 64);
+            if (l15 == 0) atomicAdd(sB + dt * 16 + 4 * g + r, sq);
+        }
 }
 
 template <bool DROP>
@@ -1144,18 +1181,22 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_small_q_kernel(const bf16* __
             if (work && 32 * kb <= 16 * tB + 15)
                 bwd_small_queries_block<DROP>(dq, sK, sV, sBias, sMask, qfB, ofB, lseB, delB, tB, 32 * kb, lane, ik_scale);
     }
+    f32x4 bq[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (work) {
-        bwd_small_queries_store(dq, tB, lane, b, h, Tn, nH, dqkv, sBp);
+        bwd_small_queries_store(dq, tB, lane, b, h, Tn, nH, dqkv, sBp, bq);
         if (tA != tB) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) dq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
             for (int j0 = 0; j0 <= 16 * tA + 15; j0 += 32)
                 bwd_small_queries_block<DROP>(dq, sK, sV, sBias, sMask, qfA, ofA, lseA, delA, tA, j0, lane, ik_scale);
-            bwd_small_queries_store(dq, tA, lane, b, h, Tn, nH, dqkv, sBp);
+            bwd_small_queries_store(dq, tA, lane, b, h, Tn, nH, dqkv, sBp, bq);
         }
     }
     if (dbias) {
+        if (work) bwd_small_bias_flush_q(bq, sB, lane);
         __syncthreads();
         if (tid < DH) {         // the Q part of head h's columns
             const int col = h * DH + tid;

@@ -27,3 +27,10 @@ for p in (0.0, 0.1):
     f = timeit(lambda: hip.attn_fwd(qkv, keep, out, lse, B, T, nH, dh, drop_p=p, drop_seed=1))
     bw = timeit(lambda: hip.attn_bwd(qkv, keep, out, dout, lse, delta, dq32, dqkv, B, T, nH, dh, drop_p=p, drop_seed=1))
     print("ablate=%s drop=%.1f fwd %.1f us  bwd(+delta) %.1f us" % (os.environ.get("MMTG_ATTN_ABLATE", "0"), p, f, bw))
+    # as the trainer calls it: delta from the preceding dgrad product's ROWDOT epilogue, the c_attn bias gradient from the kernels
+    dbias = torch.zeros(3 * D, device="cuda")
+    ws = torch.empty(hip.attn_bwd_bias_rows(B, T, hip.BF16), 3 * D, device="cuda")
+    b1 = timeit(lambda: hip.attn_bwd(qkv, keep, out, dout, lse, delta, dq32, dqkv, B, T, nH, dh, drop_p=p, drop_seed=1, delta_ready=True))
+    b2 = timeit(lambda: hip.attn_bwd(qkv, keep, out, dout, lse, delta, dq32, dqkv, B, T, nH, dh, drop_p=p, drop_seed=1, delta_ready=True,
+                                     dbias=dbias, dbias_ws=ws))
+    print("           drop=%.1f bwd without delta %.1f us; with the bias-gradient rows (trainer's call) %.1f us" % (p, b1, b2))
