@@ -410,6 +410,19 @@ def test_gemm_rowdot_epilogue_is_attention_delta():
     close(delta, dref, torch.float32, 64, "rowdot delta")
 
 
+def test_zero_ranges_touches_exactly_the_listed_ranges():
+    """mmtg_zero_ranges: one launch zeroes a list of (first element, count) ranges of an fp32 buffer and nothing else."""
+    n = 3_000_000
+    x = torch.arange(1, n + 1, device=DEV, dtype=torch.float32)
+    ranges = [(0, 4), (64, 1024), (4096, 4), (100_000, 2_000_000), (2_999_996, 4)]
+    desc = torch.tensor(ranges, dtype=torch.int64, device=DEV)
+    hip.zero_ranges(x, desc, len(ranges))
+    ref = torch.arange(1, n + 1, dtype=torch.float32)
+    for o, c in ranges:
+        ref[o:o + c] = 0
+    assert torch.equal(x.cpu(), ref)
+
+
 def test_gemm_rejects_bad_arguments():
     a = torch.zeros(16, 16, device=DEV)
     with pytest.raises(RuntimeError, match="multiple"):
