@@ -268,6 +268,104 @@ def _pmc_traffic(kernel_sha):
     return None, None
 
 
+def conditioning_probe(model, batch, iters=20):
+    """north_star's "multi-modal cross-attention over the 2048-d WenLan embeddings >= 40 % of the HBM roofline", reported as it
+    is: the conditioning kernel of the bf16 mode is mmtg_gemm_gather (the projector product gathering the table rows through
+    its LDS-DMA, SURVEY 8(d): B*T*2048*2 bytes of gathered rows per launch), timed alone with HIP events on the launch stream."""
+    from mmtg_amd import hip
+    eng = model.engine()
+    eng.forward(batch, train_flag=True, training=False, logits_f32=False)
+    a, sh = eng.act, eng.sh
+    if a.get("ids32") is None:
+        return None
+    B, T, M = a["B"], a["T"], a["M"]
+    rowmap = eng._rowmaps[(B, T)]
+    cW = eng.buf("c_w1", (B * sh.S + 1, sh.H))
+    W1, b1 = eng.W("decoder.projector_layer1.weight"), eng.P("decoder.projector_layer1.bias")
+
+    def call():
+        hip.gemm_gather(0, eng.table, W1, a["h1"], M, sh.H, sh.E, a["ids32"], eng.table.shape[0], lda=sh.E, ldb=sh.E, bias=b1,
+                        epi=hip.EPI_TANH_ADD, aux=cW, ldaux=sh.H, aux_rows=rowmap)
+
+    for _ in range(3):
+        call()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        call()
+    e1.record()
+    torch.cuda.synchronize()
+    us = 1e3 * e0.elapsed_time(e1) / iters
+    nbytes = M * sh.E * 2
+    flops = 2.0 * M * sh.H * sh.E
+    gbs = nbytes / us / 1e3
+    return {"kernel": "mmtg_gemm_gather mode 0 (gemm_dma_kernel<128x128, GATHER>: E[id] rows gathered by the LDS-DMA, "
+                      "+ (c W1^T)[b, seg] and tanh in the epilogue)",
+            "bytes": nbytes, "us": round(us, 2), "GB/s": round(gbs, 1), "frac_hbm": round(gbs / 8000.0, 4), "bound": "mfma",
+            "tflops": round(flops / us / 1e6, 1), "frac_mfma": round(flops / us / 1e6 / 2500.0, 4),
+            "note": "north_star's '>= 40 % of the HBM roofline' is NOT met as written: fused into the projector product the "
+                    "conditioning is MFMA-bound (2*M*512*2048 FLOP over the gathered rows), the gathered bytes move at frac_hbm; "
+                    "timed warm (the 54.5 MB table sits in the Infinity Cache, as it does inside the step)"}
+
+
+def allreduce_probe(trainer, steps, world, dev):
+    """Per-step cost of the gradient exchange alone (no compute beside it): the same bucketed all-reduces + row count
+    the trainer issues, on a scratch buffer, `steps` times between barriers."""
+    eng, red = trainer.eng, trainer.reducer
+    scratch = torch.zeros_like(eng.grad)
+    cnt = torch.ones(1, device=dev)
+
+    def run():
+        for _ in range(steps):
+            red.start_count(cnt)
+            red.finish(scratch)
+
+    run()
+    el = _timed(run, world, dev)
+    return 1e3 * el / steps
+
+
+def f32_object(args, dev, mcfg, dcfg, gcfg, V, steps=5, warmup=2):
+    """The mode north_star's numeric gates are stated on (compute_dtype="f32": logits within 1e-3, greedy ids bit-exact),
+    timed by the same driver run: a bounded number of train steps of the same workload + one batch-32 greedy generation."""
+    from mmtg_amd import MMTG, hip, synth
+    from mmtg_amd.trainer import MMTGTrainer
+    import copy
+    model = MMTG(mcfg, dcfg, V, train_flag=True, gpt2_config=gcfg, compute_dtype="f32", token_table=synth.make_token_table(V, seed=2))
+    model.reset_parameters(seed=0)
+    model.to(dev).train()
+    trainer = MMTGTrainer(model, lr=1e-5, alpha=0.2, warmup_steps=10, total_steps=100000)
+    B = args.batch
+    batches = [{k: torch.from_numpy(np.asarray(v)).to(dev) for k, v in synth.make_batch(B, mcfg, dcfg, V, seed=i).items()} for i in range(2)]
+    T = dcfg.topic_prompt_length + batches[0]["targets"].shape[1]
+
+    def run(n):
+        for i in range(n):
+            trainer.step(batches[i % 2], stage=3)
+
+    run(warmup)
+    el = _timed(lambda: run(steps), 1, dev)
+    hip.prof_enable(True)
+    _timed(lambda: run(steps), 1, dev)
+    hip.prof_enable(False)
+    g = hip.prof_read()["gemm_f32"]
+    ach = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
+    out = {"train": {"value": round(B * T * steps / el, 1), "unit": "tokens/s", "ms_per_step": round(1e3 * el / steps, 3),
+                     "steps": steps, "warmup": warmup, "rows": B, "seq_len": T,
+                     "roofline": {"bound": "mfma", "kernel": "gemm_kernel<f32> (v_mfma_f32_16x16x4_f32)", "achieved": round(ach, 2),
+                                  "peak": 157.3, "unit": "TFLOP/s", "frac": round(ach / 157.3, 4)}},
+           "note": "compute_dtype='f32': exact fp32 storage and MFMA end to end -- the mode tests/test_model_gpu.py holds to "
+                   "logits <= 1e-3 and bit-exact greedy ids against the reference's goldens"}
+    del trainer, model
+    torch.cuda.empty_cache()
+    a2 = copy.copy(args)
+    a2.dtype, a2.decode_batch, a2.no_roofline, a2.no_cpu_baseline = "f32", 32, True, True
+    d = bench_decode(a2, 1, 0, dev, steps=1, warmup=1, with_cpu=False)
+    out["decode"] = {"value": d["value"], "unit": "tokens/s", "ms_per_step": d["ms_per_step"], "batch": 32,
+                     "positions": args.decode_len, "us_per_token_step": d["config"]["us_per_token_step"], "check": d["check"]}
+    return out
+
+
 _JSON_FD = None
 
 
@@ -283,6 +381,77 @@ def _claim_stdout():
 
 def _emit(obj):
     os.write(_JSON_FD if _JSON_FD is not None else 1, (json.dumps(obj) + "\n").encode())
+
+
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def _self_launch(argv, n):
+    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): this process -- which has made NO GPU call and
+    makes none -- starts N fresh children, one rank per GPU, with the same environment contract torch.distributed.run
+    would give them (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT), forwards rank 0's stdout
+    (the ONE JSON line) to its own stdout, sends every other rank's stdout to stderr and exits with the worst child
+    return code.  Children are new processes (subprocess, not exec): nothing that has initialised the GPU is replaced."""
+    import subprocess
+    port = os.environ.get("MASTER_PORT") or str(_free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port, MMTG_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else 2))
+    import threading
+    lines = []
+    reader = threading.Thread(target=lambda: lines.extend(procs[0].stdout), daemon=True)   # rank 0's stdout: the JSON line
+    reader.start()
+    worst, deadline = 0, None
+    pending = list(procs)
+    while pending:
+        for p in list(pending):
+            rc = p.poll()
+            if rc is None:
+                continue
+            pending.remove(p)
+            if rc != 0:
+                worst = worst or rc
+                if deadline is None:                # a rank died: the others would wait in a collective for ever
+                    deadline = time.time() + float(os.environ.get("MMTG_BENCH_KILL_GRACE", "30"))
+        if deadline is not None and time.time() > deadline:
+            for p in pending:
+                p.kill()                            # exactly the PIDs this process started
+        time.sleep(0.05)
+    reader.join(timeout=5.0)
+    if worst == 0:
+        for raw in lines:
+            os.write(_JSON_FD if _JSON_FD is not None else 1, raw)
+    return worst
+
+
+def _dry_launch(args):
+    """--dry-launch: prove the launch contract without a GPU -- every rank joins a gloo group over the rendezvous the
+    launcher handed it, ranks are all-gathered, rank 0 prints the ONE JSON line."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    seen = [rank]
+    if os.environ.get("MMTG_DRY_FAIL_RANK") == str(rank):      # test hook: a rank that dies before the rendezvous
+        raise SystemExit(7)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        got = [None] * world
+        dist.all_gather_object(got, (rank, int(os.environ.get("LOCAL_RANK", "0")), os.getpid()))
+        seen = got
+        dist.barrier()
+        dist.destroy_process_group()
+    print("[bench dry-launch] rank %d of %d pid %d" % (rank, world, os.getpid()), file=sys.stderr)
+    if rank == 0:
+        _emit({"dry_launch": True, "n_gpus": args.gpus, "world": world, "ranks": seen,
+               "self_launched": bool(os.environ.get("MMTG_BENCH_CHILD"))})
 
 
 def main():
@@ -306,14 +475,22 @@ def main():
                     help="decode: batched greedy generation (BASELINE configs[3]: batch 256, max_len 128)")
     ap.add_argument("--decode-batch", type=int, default=256)
     ap.add_argument("--decode-len", type=int, default=128)
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="launch contract only (no GPU): ranks rendezvous over gloo, rank 0 prints one JSON line")
+    ap.add_argument("--no-f32", action="store_true", help="skip the f32 (parity-gate mode) object of the default line")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher: become one (before anything touches the GPU)
+        raise SystemExit(_self_launch(sys.argv[1:], args.gpus))
+    if args.dry_launch:
+        _dry_launch(args)
+        return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     dev = torch.device("cuda", local)
     force_ddp = bool(os.environ.get("MMTG_FORCE_DDP"))     # exercise the RCCL path on one GPU (self-test)
     if world > 1 or force_ddp:
@@ -436,6 +613,18 @@ def main():
              "note": "probe = MyLoss (stage 3) of a held-out synthetic batch in eval mode before the first and after the last "
                      "optimizer step of this process (lr warms up from 0 over 10 steps to 1e-5)"}
 
+    conditioning = None
+    if rank == 0 and not args.no_roofline and args.dtype == "bf16" and args.config == "base":
+        conditioning = conditioning_probe(model, batches[0])
+    ddp_info = None
+    if ddp:
+        ddp_info = {"rccl_world": dist.get_world_size(), "backend": dist.get_backend(),
+                    "buckets": len(trainer.reducer.buckets), "bucket_mb": args.bucket_mb,
+                    "gradient_bytes": int(trainer.eng.layout.total * 4),
+                    "allreduce_ms_per_step_isolated": round(allreduce_probe(trainer, max(3, min(args.steps, 10)), world, dev), 3),
+                    "note": "allreduce_ms_per_step_isolated = the step's bucketed SUM all-reduces (+ the row count) alone, nothing to "
+                            "overlap with; inside the step they run on RCCL's stream beside the backward"}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == "base":
         cpu = cpu_baseline(mcfg, dcfg, gcfg, V, T)
@@ -446,6 +635,12 @@ def main():
         model = None
         torch.cuda.empty_cache()
         decode = bench_decode(args, world, rank, dev, steps=3, warmup=1)
+    f32 = None
+    if (rank == 0 and world == 1 and not ddp and not args.no_f32 and not args.no_decode and args.config == "base" and args.layers == 12
+            and args.dtype == "bf16"):
+        trainer = model = None
+        torch.cuda.empty_cache()
+        f32 = f32_object(args, dev, mcfg, dcfg, gcfg, V)
 
     if rank == 0:
         if args.config == "medium":
@@ -467,8 +662,14 @@ def main():
             "config": {"workload": workload, "rows_per_gpu": B, "global_rows": B * world, "seq_len": T, "parallelism": par},
             "roofline": roof, "cpu_baseline": cpu, "check": check,
         }
+        if conditioning is not None:
+            out["conditioning"] = conditioning
+        if ddp_info is not None:
+            out["ddp"] = ddp_info
         if decode is not None:
             out["decode"] = decode
+        if f32 is not None:
+            out["f32"] = f32
         _emit(out)
     if dist.is_initialized():
         dist.destroy_process_group()

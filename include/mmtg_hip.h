@@ -28,6 +28,9 @@ extern "C" {
 
 #define MMTG_ABI_VERSION 2
 
+/* The library is built with -fvisibility=hidden: only the entry points below are exported. */
+#define MMTG_API __attribute__((visibility("default")))
+
 enum { MMTG_OK = 0, MMTG_ERR_BAD_ARG = -1, MMTG_ERR_HIP = -2, MMTG_ERR_UNSUPPORTED = -3 };
 enum { MMTG_F32 = 0, MMTG_BF16 = 1 };
 
@@ -81,15 +84,15 @@ enum {
     MMTG_PROF_DECODE, MMTG_PROF_MISC, MMTG_PROF_NCAT
 };
 
-int mmtg_abi_version(void);
-const char* mmtg_last_error(void);
+MMTG_API int mmtg_abi_version(void);
+MMTG_API const char* mmtg_last_error(void);
 
 /* Live per-kernel timing with HIP events recorded on the launch stream.
  * enable(1) starts bracketing every launch; read() synchronises the recorded
  * events and returns, per category, launches / total ms / algorithmic flops /
  * algorithmic bytes (arrays of MMTG_PROF_NCAT), then clears the log. */
-int mmtg_prof_enable(int on);
-int mmtg_prof_read(int* launches, double* ms, double* flops, double* bytes);
+MMTG_API int mmtg_prof_enable(int on);
+MMTG_API int mmtg_prof_read(int* launches, double* ms, double* flops, double* bytes);
 
 /* ---------------------------------------------------------------- GEMM
  * C[M,N] = epi(opA[M,K] * opB[K,N]).  transA=0: A[m*lda+k]; 1: A[k*lda+m].
@@ -99,7 +102,7 @@ int mmtg_prof_read(int* launches, double* ms, double* flops, double* bytes);
  * :199 (out_linear), :279-281 (projector), and the c_attn / c_proj / c_fc /
  * lm_head products inside GPT2LMHeadModel (call sites model.py:282-288,
  * 320-326), plus their autograd backward products (train.py:193).           */
-int mmtg_gemm(int dtype, int transA, int transB, int M, int N, int K,
+MMTG_API int mmtg_gemm(int dtype, int transA, int transB, int M, int N, int K,
               const void* A, long lda, const void* B, long ldb, void* C, long ldc,
               const float* bias, int epi, const void* aux, long ldaux, void* aux2,
               int out_f32, float alpha, int splits, unsigned drop_thresh, unsigned drop_seed,
@@ -115,7 +118,7 @@ int mmtg_gemm(int dtype, int transA, int transB, int M, int N, int K,
  *                      (A = d(pre-activation) [K = tokens, M], K-strided; the table rows of a K tile are looked up one tile ahead);
  *                      mmtg_slab_sum finishes it; the c-part of the gradient is the small product segment_sum(dA)^T . c.
  * bf16 only; K % 64 == 0 (mode 0); rows / aux_rows: int32 device arrays; E: [*, ldb_or_lda] row-major, below 2 GiB.        */
-int mmtg_gemm_gather(int mode, int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C, long ldc,
+MMTG_API int mmtg_gemm_gather(int mode, int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C, long ldc,
                      const float* bias, int epi, const int* rows, int table_rows, const void* aux, long ldaux, const int* aux_rows,
                      int splits, void* stream);
 
@@ -123,34 +126,34 @@ int mmtg_gemm_gather(int mode, int M, int N, int K, const void* A, long lda, con
  * non-null, wave 0 of workgroup w < max_wgs of every such launch writes 6 x u64 at buf + 48*w --
  * s_memrealtime (100 MHz) at kernel entry, after the first K tile has landed, at the end of the K
  * loop, at exit; the K tile count; the hardware id (XCC / SE / CU).  Null switches it off (default). */
-int mmtg_gemm_trace(void* buf, int max_wgs);
+MMTG_API int mmtg_gemm_trace(void* buf, int max_wgs);
 /* CUs the tile-shape rule of the eight-phase kernel (one workgroup = one whole CU) may count on: 0 = all, > 0 = that many,
  * < 0 = all but that many.  A rule input only -- results never depend on it.  mmtg_amd.ddp reserves CUs for the RCCL kernels
  * that run beside the backward (replaces nothing in the reference: its nn.DataParallel, train.py:112-114, serialises). */
-int mmtg_gemm_cu_budget(int cus);
+MMTG_API int mmtg_gemm_cu_budget(int cus);
 
 /* Second half of a MMTG_EPI_SPLIT product: out[m, :] = epi(sum_s part[s][m][:] + bias) in the storage type
  * (slabs summed in index order -> deterministic); epi in {NONE, GELU, TANH, RESID (+ aux)}.  With ln_out the
  * row just produced is also LayerNormed (gamma, beta, eps) into ln_out [M, N] -- in the KV-cached decode step
  * (generate.py:117-126 -> GPT2Block) this replaces the ln_1 / ln_2 / ln_f launches.  part: [splits][M][ldp].   */
-int mmtg_splitk_finish(int dtype, const float* part, int splits, int M, int N, long ldp, const float* bias,
+MMTG_API int mmtg_splitk_finish(int dtype, const float* part, int splits, int M, int N, long ldp, const float* bias,
                        int epi, const void* aux, long ldaux, void* out, long ldo,
                        const float* ln_gamma, const float* ln_beta, void* ln_out, float eps, void* stream);
 
 /* column sums: out[n] += sum_m X[m,n]  (bias gradients), X of `dtype`, out f32 */
-int mmtg_colsum(int dtype, const void* X, long ldx, int M, int N, float* out, void* stream);
+MMTG_API int mmtg_colsum(int dtype, const void* X, long ldx, int M, int N, float* out, void* stream);
 
 /* ---------------------------------------------------------------- LayerNorm
  * torch.nn.LayerNorm (model.py:380-382) and GPT-2's ln_1/ln_2/ln_f.          */
-int mmtg_layernorm_fwd(int dtype, const void* x, void* y, const float* gamma, const float* beta,
+MMTG_API int mmtg_layernorm_fwd(int dtype, const void* x, void* y, const float* gamma, const float* beta,
                        float* mean, float* rstd, int rows, int cols, float eps, void* stream);
 /* dx = LN'(dy) (+ dres if non-null); dgamma/dbeta accumulated (+=) in fp32.
  * Optional fused tail for the residual stream: dx_masked = dx * dropout_mask(drop_seed) (the
  * gradient entering the previous residual branch; null = not needed) and
  * dcolsum[c] += sum_rows dx_masked (that branch's bias gradient; without dx_masked: of dx).
  * ws: caller-owned scratch of >= mmtg_layernorm_bwd_ws(rows, cols) floats.     */
-long mmtg_layernorm_bwd_ws(int rows, int cols);
-int mmtg_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma,
+MMTG_API long mmtg_layernorm_bwd_ws(int rows, int cols);
+MMTG_API int mmtg_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma,
                        const float* mean, const float* rstd, const void* dres, void* dx,
                        float* dgamma, float* dbeta, int rows, int cols,
                        void* dx_masked, unsigned drop_thresh, unsigned drop_seed, float* dcolsum,
@@ -161,7 +164,7 @@ int mmtg_layernorm_bwd(int dtype, const void* dy, const void* x, const float* ga
  * attention dropout, heads merged (call sites model.py:282-288, 320-326).
  * qkv: [B*T, 3*D] rows = tokens, columns q|k|v with head h at h*dh (dh = 64);
  * keep: [B,T] int32 key mask (1 = attend); out: [B*T, D]; lse: [B,nH,T] f32.  */
-int mmtg_attn_fwd(int dtype, const void* qkv, const int* keep, void* out, float* lse,
+MMTG_API int mmtg_attn_fwd(int dtype, const void* qkv, const int* keep, void* out, float* lse,
                   int B, int T, int nH, int dh, unsigned drop_thresh, unsigned drop_seed, void* stream);
 /* delta: [B*T, nH] f32, delta[m,h] = sum_d dout[m,h,d] * out[m,h,d]: computed by the call, or --
  * delta_ready != 0 -- already filled by the caller (the GEMM producing dout with
@@ -172,8 +175,8 @@ int mmtg_attn_fwd(int dtype, const void* qkv, const int* keep, void* out, float*
  * call sums into dbias -- without it the workgroups use atomics on dbias (slower: contended).       */
 /* diagnostic: per-wave timeline of the whole-head forward kernel (bf16, T <= 256): buf = u64 [B*nH*8][8]
  * (s_memrealtime at entry / loads issued / first chunk landed / long tile done / stored / exit, XCC id, valid) or NULL */
-int mmtg_attn_trace(void* buf);
-int mmtg_attn_bwd(int dtype, const void* qkv, const int* keep, const void* out, const void* dout,
+MMTG_API int mmtg_attn_trace(void* buf);
+MMTG_API int mmtg_attn_bwd(int dtype, const void* qkv, const int* keep, const void* out, const void* dout,
                   const float* lse, float* delta, int delta_ready, float* dq32, void* dqkv, float* dbias, float* dbias_ws,
                   int B, int T, int nH, int dh, unsigned drop_thresh, unsigned drop_seed, void* stream);
 
@@ -182,21 +185,21 @@ int mmtg_attn_bwd(int dtype, const void* qkv, const int* keep, const void* out, 
  *   x[b,t] = E[topic_ids[b,t]]                           t <  P
  *   x[b,P+p] = E[targets[b,p]] + (p/two_sents < S ? c[b,p/two_sents] : 0)
  * table [V,E], c [B,S,E], x [B,P+L,E] of `dtype`; ids int64.                  */
-int mmtg_embed_condition(int dtype, const void* table, const long long* topic_ids,
+MMTG_API int mmtg_embed_condition(int dtype, const void* table, const long long* topic_ids,
                          const long long* targets, const void* c, void* x,
                          int B, int P, int L, int S, int E, int two_sents, int V, void* stream);
 /* out[b,k,:] = sum_{p in segment k} g[b,P+p,:]   (backward of the add), out of `dtype` */
-int mmtg_segment_sum(int dtype, const void* g, void* out, int B, int P, int L, int S, int H,
+MMTG_API int mmtg_segment_sum(int dtype, const void* g, void* out, int B, int P, int L, int S, int H,
                      int two_sents, void* stream);
 /* GPT-2 input embedding: h[m,:] = dropout(g[m,:] + wpe[m % T,:] + wte[type_ids[m],:])
  * (GPT2Model.forward via model.py:282-288).  In place on g allowed.           */
-int mmtg_embed_add(int dtype, const void* g, const void* wpe, const void* wte, const long long* type_ids,
+MMTG_API int mmtg_embed_add(int dtype, const void* g, const void* wpe, const void* wte, const long long* type_ids,
                    void* h, int M, int T, int D, unsigned drop_thresh, unsigned drop_seed, void* stream);
 /* backward: dwpe[t,:] += sum_b dh[b,t,:]; dwte[type,:] += sum dh; (dh masked in place if dropout) */
-int mmtg_embed_add_bwd(int dtype, void* dh, const long long* type_ids, float* dwpe, float* dwte,
+MMTG_API int mmtg_embed_add_bwd(int dtype, void* dh, const long long* type_ids, float* dwpe, float* dwte,
                        int M, int T, int D, int ntypes, unsigned drop_thresh, unsigned drop_seed, void* stream);
 /* elementwise dropout mask application (backward of a fused-epilogue dropout) */
-int mmtg_dropout_apply(int dtype, const void* x, void* y, long n, int N, unsigned drop_thresh,
+MMTG_API int mmtg_dropout_apply(int dtype, const void* x, void* y, long n, int N, unsigned drop_thresh,
                        unsigned drop_seed, void* stream);
 
 /* ---------------------------------------------------------------- LM head loss (loss.py:45-74 + GPT-2's internal CE)
@@ -206,7 +209,7 @@ int mmtg_dropout_apply(int dtype, const void* x, void* y, long n, int N, unsigne
  * Outputs (all f32): nll[M] (0 on each sample's last row), lse[M],
  * sample_ce[B], coef[B] = d loss / d CE_b / n_tok / batch_denominator,
  * scalars[0] = MyLoss (sum_b l_b / batch_den), scalars[1] = GPT-2 LM loss.    */
-int mmtg_loss_fwd(int logits_dtype, const void* logits, long ldl, int V, const long long* topic_ids,
+MMTG_API int mmtg_loss_fwd(int logits_dtype, const void* logits, long ldl, int V, const long long* topic_ids,
                   const long long* targets, const long long* ratings, int stage, int label_zero,
                   int B, int P, int L, float batch_den, float* nll, float* lse, float* sample_ce,
                   float* coef, float* scalars, void* stream);
@@ -215,7 +218,7 @@ int mmtg_loss_fwd(int logits_dtype, const void* logits, long ldl, int V, const l
  * (t <= T-2; pass d lm_loss / B / (T-1), 0 when the LM loss is unused as in train.py:188);
  * 0 on each sample's last row and on pad columns; dlogits of `dtype`, ld = ldd.  `logits_dtype` is the
  * storage type of the logits (fp32, or bf16 with bf16 dlogits -- then dlogits may alias logits). */
-int mmtg_loss_bwd(int dtype, int logits_dtype, const void* logits, long ldl, int V, const long long* topic_ids,
+MMTG_API int mmtg_loss_bwd(int dtype, int logits_dtype, const void* logits, long ldl, int V, const long long* topic_ids,
                   const long long* targets, const float* lse, const float* coef, float gscale, float lm_coef,
                   int B, int P, int L, void* dlogits, long ldd, int Vpad, void* stream);
 
@@ -225,31 +228,31 @@ int mmtg_loss_bwd(int dtype, int logits_dtype, const void* logits, long ldl, int
  * pre-activations (r|z|n), h_prev (row stride ld_hp; null = zeros) -> h (row
  * stride ld_h); saves r,z,n,ghn (each [B,H]) in `save` [4,B,H] f32.  The row
  * strides address one step of a batch-first [B,S,*] sequence in place.         */
-int mmtg_gru_cell_fwd(int dtype, const void* gi, long ld_gi, const void* gh, long ld_gh, const void* h_prev, long ld_hp,
+MMTG_API int mmtg_gru_cell_fwd(int dtype, const void* gi, long ld_gi, const void* gh, long ld_gh, const void* h_prev, long ld_hp,
                       void* h, long ld_h, float* save, int B, int H, void* stream);
 /* dh: total gradient wrt h_t (f32 [B,H]); outputs dgi (row stride ld_dgi), dgh [B,3H]
  * of `dtype`, dh_prev (f32 [B,H]) = dh * z (caller adds dgh * W_hh).           */
-int mmtg_gru_cell_bwd(int dtype, const float* dh, const float* save, const void* h_prev, long ld_hp,
+MMTG_API int mmtg_gru_cell_bwd(int dtype, const float* dh, const float* save, const void* h_prev, long ld_hp,
                       void* dgi, long ld_dgi, void* dgh, float* dh_prev, int B, int H, void* stream);
 /* The same with the assembly of dh_t fused in: dh_t = rows[b, :] (gradient arriving through the LayerNorm of step t,
  * `dtype`, row stride ld_rows) + carry (f32 [B,H], nullable; may alias dh_prev) + the ordered sum of the `splits`
  * fp32 slabs part[splits][B][H] of the carry product d(gh_{t+1}) W_hh (MMTG_EPI_SPLIT; splits = 0: none).          */
-int mmtg_gru_cell_bwd_fused(int dtype, const void* rows, long ld_rows, const float* carry, const float* part, int splits,
+MMTG_API int mmtg_gru_cell_bwd_fused(int dtype, const void* rows, long ld_rows, const float* carry, const float* part, int splits,
                             const float* save, const void* h_prev, long ld_hp, void* dgi, long ld_dgi, void* dgh,
                             float* dh_prev, int B, int H, void* stream);
 /* alpha attention (model.py:138-161): qkv [B*S, 3H] -> ctx [B*S, H], probs [B,heads,S,S] f32,
  * kl += mean_i KLDiv_batchmean(log P[:,:,i,:], prior_i); prior [S,S] f32.       */
-int mmtg_alpha_attn_fwd(int dtype, const void* qkv, const float* prior, void* ctx, float* probs,
+MMTG_API int mmtg_alpha_attn_fwd(int dtype, const void* qkv, const float* prior, void* ctx, float* probs,
                         float* kl, int B, int S, int H, int heads, void* stream);
-int mmtg_alpha_attn_bwd(int dtype, const void* qkv, const float* prior, const float* probs,
+MMTG_API int mmtg_alpha_attn_bwd(int dtype, const void* qkv, const float* prior, const float* probs,
                         const void* dctx, float dkl, void* dqkv, int B, int S, int H, int heads,
                         void* stream);
 /* beta attention / multi-modal fuser (model.py:191-198): topic [B,H], img/txt [B*S,H] (row b*S+i)
  * att_w [S,H] f32, att_b [S] f32 -> o [B*S,H], a [B,S,3] f32.                   */
-int mmtg_beta_fuse_fwd(int dtype, const void* topic, const void* img, const void* txt,
+MMTG_API int mmtg_beta_fuse_fwd(int dtype, const void* topic, const void* img, const void* txt,
                        const float* att_w, const float* att_b, void* o, float* a,
                        int B, int S, int H, void* stream);
-int mmtg_beta_fuse_bwd(int dtype, const void* topic, const void* img, const void* txt,
+MMTG_API int mmtg_beta_fuse_bwd(int dtype, const void* topic, const void* img, const void* txt,
                        const float* att_w, const float* a, const void* d_o,
                        float* dtopic, void* dimg, void* dtxt, float* datt_w, float* datt_b,
                        int B, int S, int H, void* stream);
@@ -258,43 +261,43 @@ int mmtg_beta_fuse_bwd(int dtype, const void* topic, const void* img, const void
  * `workgroups` workgroups of 16-byte loads so that they sit in the 256 MB Infinity Cache when the next kernel of the
  * backward pass reads them (saved activations are cold by then).  Launched on a side stream, gated by events; `sink` is a
  * 4-byte device scratch that is never written in practice.                                                       */
-int mmtg_prefetch(const void* src, long bytes, int workgroups, void* sink, void* stream);
+MMTG_API int mmtg_prefetch(const void* src, long bytes, int workgroups, void* sink, void* stream);
 /* zero n ranges of an fp32 buffer in one launch: desc (device, int64) holds (first element, count) pairs, both multiples of 4
  * (optimizer.zero_grad of train.py:192 for the gradients that are accumulated into; the rest is overwritten) */
-int mmtg_zero_ranges(float* base, const long* desc, int n, void* stream);
+MMTG_API int mmtg_zero_ranges(float* base, const long* desc, int n, void* stream);
 
 /* ---------------------------------------------------------------- optimizer (train.py:194-197)
  * sumsq: *out += sum x^2 (global grad-norm partial).                          */
-int mmtg_sumsq(const float* x, long n, float* out, void* stream);
+MMTG_API int mmtg_sumsq(const float* x, long n, float* out, void* stream);
 /* clip (coef = min(1, max_norm / (sqrt(*normsq) + 1e-6))) + transformers.AdamW
  * (bias-corrected, eps outside the sqrt, decoupled wd) + optional bf16 copy.
  * count (optional, device scalar): g holds a SUM over rows and *count the global row count
  * (all-reduced on the device, never read by the host): the gradient is g * grad_scale / *count;
  * *count == 0 leaves every buffer untouched (the reference skips an empty batch, train.py:184-185). */
-int mmtg_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, long n,
+MMTG_API int mmtg_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, long n,
                float lr, float beta1, float beta2, float eps, float wd, int step,
                const float* normsq, float max_norm, float grad_scale, const float* count, void* stream);
-int mmtg_cast_f32_to(int dtype, const float* src, void* dst, long n, void* stream);
+MMTG_API int mmtg_cast_f32_to(int dtype, const float* src, void* dst, long n, void* stream);
 /* dst[r, 0:cols] = cast(src[r, 0:cols]); dst[r, cols:ldd] = 0 */
-int mmtg_cast_pad_rows(int dtype, const float* src, long lds_, void* dst, long ldd, int rows, int cols, void* stream);
-int mmtg_cast_to_f32(int dtype, const void* src, float* dst, long n, void* stream);
-int mmtg_axpy_f32(float* y, const float* x, float a, long n, void* stream);
+MMTG_API int mmtg_cast_pad_rows(int dtype, const float* src, long lds_, void* dst, long ldd, int rows, int cols, void* stream);
+MMTG_API int mmtg_cast_to_f32(int dtype, const void* src, float* dst, long n, void* stream);
+MMTG_API int mmtg_axpy_f32(float* y, const float* x, float a, long n, void* stream);
 /* Second half of a weight-gradient product computed as K-split slabs (mmtg_gemm with transA = 1 and
  * MMTG_EPI_SPLIT: slab s = fp32 [M, ldc] at C + s * M * ldc): dst[i] (+)= sum_s part[s * stride + i],
  * slabs added in order -- the deterministic replacement of the fp32-atomic epilogue for the autograd
  * weight gradients of nn.Linear / Conv1D (model.py:77-79,134-136,199,279-281 and the GPT-2 products).
  * n and stride in floats, multiples of 4; accumulate = 0 overwrites dst.                              */
-int mmtg_slab_sum(const float* part, int splits, long stride, float* dst, int accumulate, long n, void* stream);
+MMTG_API int mmtg_slab_sum(const float* part, int splits, long stride, float* dst, int accumulate, long n, void* stream);
 /* Batched transpose (bf16 mode keeps K-contiguous [out,in] copies of GPT-2's Conv1D [in,out] weights
  * so that forward products run in the NT layout): matrix i = [rows, cols] row-major at src + desc[4i]
  * elements -> [cols, rows] at dst + desc[4i+3]; desc = n x {src_off, rows, cols, dst_off} (long, device);
  * every offset / extent a multiple of 16 bytes; max_rows / max_cols bound the grid.                    */
-int mmtg_transpose_batch(int dtype, const void* src, void* dst, const long* desc, int n, int max_rows, int max_cols, void* stream);
+MMTG_API int mmtg_transpose_batch(int dtype, const void* src, void* dst, const long* desc, int n, int max_rows, int max_cols, void* stream);
 
 /* ---------------------------------------------------------------- generation (generate.py:127-141)
  * per row: repetition penalty per occurrence (ids 0 and 102 skipped), /temperature,
  * ban {1,2,100,102}, sticky PAD, arg-max (lowest index on ties) -> next[B].     */
-int mmtg_logits_process_argmax(const float* logits, long ldl, int V, const long long* generated,
+MMTG_API int mmtg_logits_process_argmax(const float* logits, long ldl, int V, const long long* generated,
                                long ldg, const int* gen_len, float temperature, float rep_penalty,
                                long long* next, int B, void* stream);
 /* Stochastic counterpart (generate.py:64-94,127-141 with top_k / top_p as given): same processed logits, then the
@@ -303,7 +306,7 @@ int mmtg_logits_process_argmax(const float* logits, long ldl, int V, const long 
  * by inverse CDF over the kept ids in index order with the caller's uniforms[b] in [0,1) (torch.multinomial's
  * generator is not reproducible outside torch; the distribution is the reference's).  filtered (nullable, [B, ldl]):
  * the filtered processed logits (-inf where dropped), as top_k_top_p_filtering returns them.                        */
-int mmtg_logits_process_sample(const float* logits, long ldl, int V, const long long* generated, long ldg,
+MMTG_API int mmtg_logits_process_sample(const float* logits, long ldl, int V, const long long* generated, long ldg,
                                const int* gen_len, float temperature, float rep_penalty, int top_k, float top_p,
                                const float* uniforms, long long* next, float* filtered, int B, void* stream);
 
@@ -317,27 +320,27 @@ int mmtg_logits_process_sample(const float* logits, long ldl, int V, const long 
  * decode_select: next lyric token = forced [#EOS#]/[#START#] by the 22-slot cadence, sticky PAD, or
  *   arg-max of the processed logits (null logits: forced tokens only); writes seq[b, pos+1].
  * decode_advance: *pos_ptr += 1.                                                              */
-int mmtg_decode_embed(int dtype, const void* table, const long long* seq, long ldseq, const void* c, void* x,
+MMTG_API int mmtg_decode_embed(int dtype, const void* table, const long long* seq, long ldseq, const void* c, void* x,
                       const int* pos_ptr, const long long* tpw_type, const long long* tpw_mask,
                       long long* type_out, int* keep, long ldkeep, int B, int P, int S, int E, int two_sents,
                       int V, int sent, int max_sent_num, void* stream);
-int mmtg_decode_embed_add(int dtype, const void* g, const void* wpe, const void* wte, const long long* type_ids,
+MMTG_API int mmtg_decode_embed_add(int dtype, const void* g, const void* wpe, const void* wte, const long long* type_ids,
                           const int* pos_ptr, void* h, int B, int D, void* stream);
-int mmtg_decode_attn(int dtype, const void* qkv, void* kcache, void* vcache, const int* keep, long ldkeep,
+MMTG_API int mmtg_decode_attn(int dtype, const void* qkv, void* kcache, void* vcache, const int* keep, long ldkeep,
                      const int* pos_ptr, void* out, int B, int nH, int dh, int Tmax, void* stream);
 /* the same, taking the c_attn product as MMTG_EPI_SPLIT slabs (part: f32 [splits][B][3*D]) plus its bias:
  * the slabs are summed in order and rounded to the storage type as mmtg_splitk_finish would (one launch less) */
-int mmtg_decode_attn_split(int dtype, const float* part, int splits, const float* bias, void* kcache, void* vcache,
+MMTG_API int mmtg_decode_attn_split(int dtype, const float* part, int splits, const float* bias, void* kcache, void* vcache,
                            const int* keep, long ldkeep, const int* pos_ptr, void* out, int B, int nH, int dh, int Tmax,
                            void* stream);
-int mmtg_decode_select(const float* logits, long ldl, int V, long long* seq, long ldseq, const int* pos_ptr,
+MMTG_API int mmtg_decode_select(const float* logits, long ldl, int V, long long* seq, long ldseq, const int* pos_ptr,
                        int P, int sent, float temperature, float rep_penalty, int B, void* stream);
 /* decode_select with the stochastic selection above; the draw of position pos uses uniforms[pos * ldu + b]
  * (a [positions, ldu] device array filled before the graph is replayed).                                    */
-int mmtg_decode_sample(const float* logits, long ldl, int V, long long* seq, long ldseq, const int* pos_ptr,
+MMTG_API int mmtg_decode_sample(const float* logits, long ldl, int V, long long* seq, long ldseq, const int* pos_ptr,
                        int P, int sent, float temperature, float rep_penalty, int top_k, float top_p,
                        const float* uniforms, long ldu, int B, void* stream);
-int mmtg_decode_advance(int* pos_ptr, void* stream);
+MMTG_API int mmtg_decode_advance(int* pos_ptr, void* stream);
 
 #ifdef __cplusplus
 }

@@ -22,7 +22,7 @@ LIB = os.path.join(HERE, "libmmtg_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-         "-DNDEBUG"]
+         "-DNDEBUG", "-fvisibility=hidden"]
 
 
 def _sources():
@@ -66,7 +66,8 @@ def build(force=False, jobs=4, verbose=True):
             objs.append(obj)
             rebuilt |= did
     if rebuilt or not os.path.exists(LIB):
-        cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-Wl,--version-script=" + os.path.join(CSRC, "exports.map"),
+               "-o", LIB] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))

@@ -33,14 +33,30 @@ class GradReducer:
         # MMTG_FORCE_DDP: run the collectives even at world size 1 (single-GPU self-test of the RCCL path)
         self.force = dist.is_initialized() and bool(__import__("os").environ.get("MMTG_FORCE_DDP"))
         self.buckets = layout.buckets(int(bucket_mb * 1024 * 1024 / 4))
-        if self.world > 1:
+        self._budget_set = False
+        if self.world > 1 and torch.cuda.is_available():
             # the RCCL kernels run beside the backward and hold their CUs for the whole collective; a workgroup of the
             # eight-phase GEMM kernel needs a CU to itself, so its tile rule must not plan on all 256 (MMTG_DDP_GEMM_CUS:
-            # > 0 = CUs it may count on, < 0 = CUs to leave to the collectives; default 32 left)
+            # > 0 = CUs it may count on, < 0 = CUs to leave to the collectives; default 32 left).  GPU runs only: on CPU
+            # tensors (gloo tests) there is no library to tell.  The setting is process-global; close() restores it.
             from . import hip
             hip.gemm_cu_budget(int(__import__("os").environ.get("MMTG_DDP_GEMM_CUS", "-32")))
+            self._budget_set = True
         self.pack_end = {name: o + n for name, (o, n) in layout.pack_range.items()}
         self.reset()
+
+    def close(self):
+        """Give the CUs reserved for the collectives back to the GEMM tile rule (decode / inference in the same process)."""
+        if self._budget_set:
+            from . import hip
+            hip.gemm_cu_budget(0)
+            self._budget_set = False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     @property
     def active(self):

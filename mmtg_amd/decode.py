@@ -226,7 +226,6 @@ class GreedyDecoder:
         g.replay()
 
     # ------------------------------------------------------------------ public
-    @torch.no_grad()
     def describe(self):
         how = "one hipGraph replay per token step" if self.use_graph else "eager launches per token step"
         return how + (", %d row blocks of %d side by side" % (self.lanes, self.B // self.lanes) if self.lanes > 1 else "")
@@ -235,6 +234,7 @@ class GreedyDecoder:
         return ("decode token step: split-K gemm_dma_kernel<256x32> weight streaming + decode_attn KV-cache streaming + finish kernels"
                 if self.fast else "decode token step: training-side kernels per layer")
 
+    @torch.no_grad()
     def generate(self, batch, length, temperature=1.0, repitition_penalty=1.0, top_k=1, top_p=0.0, generator=None,
                  use_graph=None):
         """batch: dict with topic_ids/tpw_* [B,P], topic_emb, img_embs, r_embs (no targets needed).

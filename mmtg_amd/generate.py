@@ -10,6 +10,8 @@ torch.multinomial's own stream cannot be reproduced outside torch; the distribut
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -45,9 +47,42 @@ def _check_tokenizer(tokenizer):
         raise ValueError("tokenizer special ids %s differ from the reference vocabulary's %s" % (got, BANNED))
 
 
+def _cached_decoder(model, start_input, length):
+    """The KV-cached, graph-replayed decoder for this call, or None when the call is not the one the reference's
+    generate.py makes (an MMTG in inference mode on the GPU -- possibly inside the nn.DataParallel wrapper of generate.py:191 --
+    started from the single [#START#] token, generate.py:207-209).  MMTG_SAMPLE_RERUN=1 forces the prefix re-run loop."""
+    from .model import MMTG
+    m = getattr(model, "module", model)
+    if not isinstance(m, MMTG) or m.train_flag or not m._flat.is_cuda or os.environ.get("MMTG_SAMPLE_RERUN"):
+        return None
+    t = np.asarray(start_input["targets"]).reshape(-1)
+    sh = m.shapes
+    if t.shape[0] != 1 or int(t[0]) != 1 or length < 1 or sh.P + length + 1 > sh.NP:
+        return None
+    from .decode import GreedyDecoder
+    cache = m.__dict__.setdefault("_sample_decoders", {})
+    key = (m._flat.data_ptr(), int(length))
+    dec = cache.get(key)
+    if dec is None:
+        cache.clear()                       # one decoder (KV caches + graphs) at a time
+        dec = cache[key] = GreedyDecoder(m, max_batch=1, max_len=int(length))
+    return dec
+
+
 def sample_sequence(model, start_input, length, tokenizer, temperature=1.0, top_k=30, top_p=0.0,
                     repitition_penalty=1.0, device="cuda"):
+    """generate.py:97-145.  When the call is the reference's own (see _cached_decoder) the loop runs on the KV-cached decoder:
+    one captured token step replayed per position instead of a full forward over the growing prefix per token; the returned
+    list is what the reference loop returns (the sequence before the last model call's append).  Greedy ids are the same as
+    the re-run loop's bit for bit in the f32 mode (tests/test_decode_gpu.py)."""
     _check_tokenizer(tokenizer)
+    dec = _cached_decoder(model, start_input, length)
+    if dec is not None:
+        m = getattr(model, "module", model)
+        batch = {k: torch.as_tensor(np.asarray(v)).unsqueeze(0) for k, v in start_input.items() if k not in ("targets", "rating")}
+        ids = dec.generate(batch, int(length), temperature=temperature, repitition_penalty=repitition_penalty,
+                           top_k=int(top_k), top_p=float(top_p))
+        return dec.reference_return(ids[0].tolist(), int(length), sent=m.shapes.msl + 2)
     inputs = {}
     for k, v in start_input.items():
         if k == "targets":
@@ -139,6 +174,6 @@ def generate_samples(model, rows, tokenizer, n_samples=10, length=None, temperat
         ids = dec.generate(chunk, length, temperature=temperature, repitition_penalty=repetition_penalty,
                            top_k=top_k, top_p=top_p, generator=generator).cpu().numpy()
         for r in range(hi - lo):
-            seq = GreedyDecoder.reference_return(ids[r].tolist(), length)
+            seq = GreedyDecoder.reference_return(ids[r].tolist(), length, sent=sh.msl + 2)
             texts.append(postprocess_tokens(tokenizer.convert_ids_to_tokens(seq)))
     return [texts[i * n_samples:(i + 1) * n_samples] for i in range(n_prompts)]

@@ -90,15 +90,22 @@ class MMTGTrainer:
         n_local, KL weight alpha * n_local); the global row count travels as a DEVICE scalar -- all-reduced next to the
         gradient buckets when distributed, never read by the host -- and the clip + AdamW kernel divides by it.  Single
         GPU and data-parallel steps therefore run the same arithmetic, and unequal shards after curriculum filtering
-        give the single-GPU global mean."""
+        give the single-GPU global mean.
+
+        One documented difference: when EVERY rank of a multi-rank group is filtered to zero rows, the AdamW kernel sees a
+        global count of 0 and leaves parameters and moments untouched, but the host -- which never reads the count --
+        still advances the Adam step (bias correction) and the LR schedule by one.  A single process `continue`s before
+        either counter moves (train.py:184-185).  Shards of a shuffled global batch that are ALL empty after the stage
+        filter do not occur with the released data (every rating occurs in every batch of 64+ rows); the price of the
+        exact behaviour would be a host read of the all-reduced count every step."""
         eng = self.eng
         if filter_rows and stage in (1, 2):
             idx = curriculum_filter(batch["rating"], stage)
             batch = {k: v[idx.to(v.device)] for k, v in batch.items()}
         n_local = int(batch["rating"].shape[0]) if "rating" in batch else int(batch["targets"].shape[0])
         red = self.reducer if (self.reducer is not None and self.reducer.active) else None
-        if red is None and n_local == 0:
-            return None
+        if n_local == 0 and (red is None or red.world == 1):
+            return None             # nothing to exchange with: no counter moves, as train.py:184-185 `continue`s
         if self._count is None:
             self._count = torch.zeros(1, device=eng.dev, dtype=torch.float32)
         self._count.fill_(float(n_local))           # asynchronous fill; the value is known on the host

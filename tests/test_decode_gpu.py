@@ -24,7 +24,7 @@ def build(dtype):
 
 
 @pytest.mark.parametrize("use_graph", [False, True])
-def test_kv_cache_decode_matches_reference_ids(use_graph):
+def test_kv_cache_decode_matches_reference_ids(use_graph, monkeypatch):
     fx, batch, model = build("f32")
     dp = json.loads(str(fx["decode_params"]))
     tb = {k: v for k, v in batch_to_torch(batch, DEV).items() if k not in ("rating", "targets")}
@@ -46,6 +46,7 @@ def test_kv_cache_decode_matches_reference_ids(use_graph):
     # row 2 has no golden: compare with the (already pinned) no-cache path of the same engine
     start = {k: np.asarray(v[2]) for k, v in batch.items() if k != "rating"}
     start["targets"] = np.asarray([1])
+    monkeypatch.setenv("MMTG_SAMPLE_RERUN", "1")        # the prefix re-run loop, not the cached route
     ref = sample_sequence(model, start, 220, None, temperature=dp["temperature"], top_k=1, top_p=0.0,
                           repitition_penalty=dp["repitition_penalty"], device=DEV)
     assert GreedyDecoder.reference_return(ids[2].tolist(), 220) == ref

@@ -3,6 +3,7 @@ table, loud failure without a GPU, curriculum filter / LR schedule, and the N>1
 gradient exchange on the gloo backend (world_size 2)."""
 import ctypes
 import os
+import sys
 import re
 import socket
 
@@ -163,6 +164,12 @@ def test_c_abi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert hip.lib().mmtg_abi_version() == hip.ABI_VERSION == 2
+    # ... and nothing else: the library is built with -fvisibility=hidden + a linker version script, so no internal C++
+    # helper (mmtg_set_error, ProfScope, template instantiations, hipcc's __hip_cuid_*) leaks into the dynamic symbol table
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", hip.lib_path()], capture_output=True, text=True, check=True).stdout
+    names = [ln.split()[-1] for ln in out.splitlines() if ln.strip()]
+    assert sorted(names) == declared, sorted(set(names) - set(declared))
 
 
 def test_product_never_imports_the_oracle():
@@ -274,3 +281,35 @@ def test_packed_token_table_round_trip(tmp_path):
         from safetensors.torch import save_file
         save_file({"x": torch.zeros(2)}, str(tmp_path / "bad.safetensors"))
         load_token_table(tmp_path / "bad.safetensors")
+
+
+def _run_bench(argv, env=None, timeout=240):
+    import subprocess
+    e = dict(os.environ)
+    e.pop("WORLD_SIZE", None); e.pop("RANK", None); e.pop("LOCAL_RANK", None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True, env=e, timeout=timeout)
+
+
+def test_bench_launches_itself_for_n_gpus():
+    """`python bench.py --gpus N` with no launcher (how the driver starts every N): the parent -- before any GPU call -- starts N
+    fresh ranks with the torch.distributed.run environment contract; --dry-launch has them rendezvous over gloo instead of
+    running the workload.  N children, distinct ranks and local ranks, ONE JSON line on stdout, rc 0."""
+    import json
+    r = _run_bench(["--gpus", "3", "--dry-launch"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["dry_launch"] and d["world"] == 3 and d["n_gpus"] == 3 and d["self_launched"]
+    assert sorted(x[0] for x in d["ranks"]) == [0, 1, 2] and sorted(x[1] for x in d["ranks"]) == [0, 1, 2]
+    assert len({x[2] for x in d["ranks"]}) == 3                      # three different processes
+    assert r.stderr.count("[bench dry-launch] rank") == 3
+
+
+def test_bench_self_launch_reports_a_dead_rank():
+    """A rank that dies takes the job down with its return code (the parent kills exactly the children it started once one
+    has failed) instead of leaving the others waiting in the rendezvous."""
+    r = _run_bench(["--gpus", "2", "--dry-launch"], env={"MMTG_DRY_FAIL_RANK": "1", "MMTG_BENCH_KILL_GRACE": "2"})
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.strip()]     # no JSON line from a failed job

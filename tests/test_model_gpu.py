@@ -177,9 +177,17 @@ def test_bf16_vs_oracle(case):
         assert 0.9 < float(g.norm() / (r.norm() + 1e-30)) < 1.1, k
 
 
+@pytest.mark.parametrize("route", ["cached", "rerun"])
 @pytest.mark.parametrize("length,row", [(30, 0), (30, 1), (220, 0)])
-def test_greedy_decode_bit_exact(length, row):
+def test_greedy_decode_bit_exact(length, row, route, monkeypatch):
+    """The drop-in sample_sequence against the reference's own id lists, on both of its routes: the KV-cached graph-replayed
+    decoder (the default for the reference's call) and the reference-shaped loop that re-runs the prefix (MMTG_SAMPLE_RERUN)."""
+    from mmtg_amd import generate as G
+    if route == "rerun":
+        monkeypatch.setenv("MMTG_SAMPLE_RERUN", "1")
     fx, meta, mcfg, gcfg, dcfg, weights, table, batch, model = build("tiny_s5", "f32", train_flag=False)
+    probe = {"targets": np.asarray([1])}
+    assert (G._cached_decoder(model, probe, length) is not None) == (route == "cached")
     dp = json.loads(str(fx["decode_params"]))
     start = {k: np.asarray(v[row]) for k, v in batch.items() if k != "rating"}
     start["targets"] = np.asarray([1])
