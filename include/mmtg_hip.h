@@ -288,6 +288,24 @@ MMTG_API int mmtg_axpy_f32(float* y, const float* x, float a, long n, void* stre
  * weight gradients of nn.Linear / Conv1D (model.py:77-79,134-136,199,279-281 and the GPT-2 products).
  * n and stride in floats, multiples of 4; accumulate = 0 overwrites dst.                              */
 MMTG_API int mmtg_slab_sum(const float* part, int splits, long stride, float* dst, int accumulate, long n, void* stream);
+/* Grouped weight-gradient products with an in-kernel deterministic split-K reduction (csrc/wgrad.hip): ONE launch for
+ * the n <= 8 products  C_p[M_p, N_p] (fp32, ld = ldc_p) (+)= A_p^T . B_p,  A_p [K, lda_p], B_p [K, ldb_p] bf16 row-major with
+ * K = tokens -- the autograd weight gradients of the four Conv1D layers of a GPT-2 block (transformers 4.12.3 behind
+ * model.py:282-288), which become available within one block of the backward and otherwise need 5-12 K splits EACH to fill
+ * the chip.  Work items = (sum of 128x128 tiles) x splits.  K split s of a tile stores its raw partial tile in slot
+ * (tile, s) of `ws` (tile-contiguous, >= tiles * splits * 16384 floats); every wave then bumps the arrival counter of
+ * its 64x64 quadrant (`counters`: >= 4 * tiles unsigned, ZERO on entry, zero again on return) and the wave that arrives
+ * last adds the partial quadrants in split order and writes (accumulate = 0) or adds to (accumulate = 1) C.  No workgroup
+ * ever waits for another; results are bit-reproducible.  splits = 1 needs neither ws nor counters.
+ * `probs` is a HOST array (read during the call).  M, N, lda, ldb multiples of 8; operands below 2 GiB.                   */
+typedef struct mmtg_wgrad_problem {
+    const void* A; long lda;
+    const void* B; long ldb;
+    float* C; long ldc;
+    int M, N;
+} mmtg_wgrad_problem;
+MMTG_API int mmtg_wgrad_group(int n, const mmtg_wgrad_problem* probs, int K, int splits, float* ws, long ws_floats,
+                     unsigned* counters, long n_counters, int accumulate, void* stream);
 /* Batched transpose (bf16 mode keeps K-contiguous [out,in] copies of GPT-2's Conv1D [in,out] weights
  * so that forward products run in the NT layout): matrix i = [rows, cols] row-major at src + desc[4i]
  * elements -> [cols, rows] at dst + desc[4i+3]; desc = n x {src_off, rows, cols, dst_off} (long, device);

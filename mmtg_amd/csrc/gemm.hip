@@ -95,39 +95,6 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_kernel(GemmArgs p) {
 // scalar offset that advances by one K tile per iteration -> no vector address arithmetic in the
 // loop.  Rows/columns outside the matrix get an out-of-range offset (the descriptor's bounds check
 // returns zeros); only a ragged last K tile recomputes its offsets.
-constexpr int OOB = 0x7FFFFFF0;
-
-// lane offset of 1-KB block `blk` of an operand tile.  KC: R rows x 128 B.  KS: 64 k-rows x (W*2) B.
-template <bool KS, int EXT>
-__device__ __forceinline__ int dma_voff(long ld, int row0, int nrows, int krem, int blk, int lane) {
-    constexpr int EPC = 8;
-    if constexpr (!KS) {
-        const int r = blk * 8 + (lane >> 3), pc = lane & 7;
-        const int c = pc ^ (r & 7);
-        const bool ok = (row0 + r < nrows) && (c * EPC < krem);
-        return ok ? (int)(((long)r * ld + c * EPC) * 2) : OOB;
-    } else {
-        constexpr int CPR = EXT / 8, RPB = 64 / CPR;      // chunks per k-row, k-rows per 1-KB block
-        static_assert(CPR >= 16, "K-strided tiles need >= 128 columns for the transposed-read swizzle");
-        const int k = blk * RPB + lane / CPR, pc = lane % CPR;
-        const int c = pc ^ ks_swz(k);
-        const bool ok = (k < krem) && (row0 + c * EPC < nrows);
-        return ok ? (int)(((long)k * ld + c * EPC) * 2) : OOB;
-    }
-}
-
-// per-lane offsets of the transposed-read fragments of a K-strided tile of EXT columns (row bytes 2*EXT)
-template <int EXT, int NT>
-__device__ __forceinline__ void ks_offsets(int col0, int lane, int (&o)[NT]) {
-    const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
-    const int k = 8 * g + q;
-#pragma unroll
-    for (int i = 0; i < NT; ++i) {
-        const int chunk = ((col0 + i * 16) >> 3) + (pp >> 1);
-        o[i] = k * (2 * EXT) + ((chunk ^ ks_swz(k)) << 4) + 8 * (pp & 1);
-    }
-}
-
 // (TAG only makes the instance unique per calling kernel: a second kernel that instantiates this helper with the same
 //  arguments fails hipcc's host pass with "no matching function" -- see DESIGN.md 4b)
 template <bool AKS, bool BKS, int TBM, int TBN, int NBA, int NBB, int NW, int TAG>
@@ -190,7 +157,6 @@ template <int TBM, int TBN, int WM, int WN, int NBUF> struct DmaCfg {
     static constexpr int MINW = WGS * ((WM * WN + 3) / 4);
 };
 
-template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // NBUF-deep LDS ring: tile t+NBUF-1 is issued right after the barrier of tile t; the wait before that
 // barrier leaves the (NBUF-2) younger tiles in flight (counted vmcnt, raw s_barrier).

@@ -151,6 +151,42 @@ template <> __device__ __forceinline__ void load4<bf16>(const bf16* p, float (&v
 }
 
 
+// ---- LDS-DMA addressing (shared by gemm.hip and wgrad.hip) -------------------
+constexpr int OOB = 0x7FFFFFF0;
+
+// lane offset of 1-KB block `blk` of an operand tile.  KC: R rows x 128 B.  KS: 64 k-rows x (W*2) B.
+template <bool KS, int EXT>
+__device__ __forceinline__ int dma_voff(long ld, int row0, int nrows, int krem, int blk, int lane) {
+    constexpr int EPC = 8;
+    if constexpr (!KS) {
+        const int r = blk * 8 + (lane >> 3), pc = lane & 7;
+        const int c = pc ^ (r & 7);
+        const bool ok = (row0 + r < nrows) && (c * EPC < krem);
+        return ok ? (int)(((long)r * ld + c * EPC) * 2) : OOB;
+    } else {
+        constexpr int CPR = EXT / 8, RPB = 64 / CPR;      // chunks per k-row, k-rows per 1-KB block
+        static_assert(CPR >= 16, "K-strided tiles need >= 128 columns for the transposed-read swizzle");
+        const int k = blk * RPB + lane / CPR, pc = lane % CPR;
+        const int c = pc ^ ks_swz(k);
+        const bool ok = (k < krem) && (row0 + c * EPC < nrows);
+        return ok ? (int)(((long)k * ld + c * EPC) * 2) : OOB;
+    }
+}
+
+// per-lane offsets of the transposed-read fragments of a K-strided tile of EXT columns (row bytes 2*EXT)
+template <int EXT, int NT>
+__device__ __forceinline__ void ks_offsets(int col0, int lane, int (&o)[NT]) {
+    const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+    const int k = 8 * g + q;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int chunk = ((col0 + i * 16) >> 3) + (pp >> 1);
+        o[i] = k * (2 * EXT) + ((chunk ^ ks_swz(k)) << 4) + 8 * (pp & 1);
+    }
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
 // XCD-aware work order over a 1-D grid of (split, tile) items.  Workgroups are dealt round-robin to
 // the 8 XCDs, so block b and b+8 share an L2: the bijective remap below gives every XCD one contiguous
 // run of the virtual order  v = split * ntiles + tile_m * tiles_n + tile_n.  Neighbours in v share

@@ -203,6 +203,16 @@ def _wgrad_splits(M, N, K, occ4=False, slots=512, t_iter=1.1, t_fixed=6.0):
 _LAZY_ZERO = _os.environ.get("MMTG_FULL_ZERO_GRAD") is None   # zero only the accumulated gradients once a step shape is known (A/B switch)
 _WTE_T = _os.environ.get("MMTG_NO_WTE_T") is None      # [D, Vpad] copy of wte for the LM head's dgrad (A/B switch)
 _P8T = _os.environ.get("MMTG_GEMM_P8T", "0") != "0"      # eight-phase K-strided kernel for the slab weight gradients (opt-in: measured slower in situ)
+_WGRAD_GROUP = _os.environ.get("MMTG_WGRAD_GROUP", "1") != "0"   # one grouped launch per GPT-2 block for its four weight gradients (A/B switch)
+_WGRAD_GROUP_SPLITS = int(_os.environ.get("MMTG_WGRAD_GROUP_SPLITS", "0"))    # 0 = the one-round rule below
+
+
+def _group_splits(tiles, K, slots=1024):
+    """K splits of a grouped weight-gradient launch: tiles x splits workgroups in ONE round of the single-stage kernel's
+    slots (four 128x128 workgroups per CU), no K slice shorter than 1024 tokens."""
+    if _WGRAD_GROUP_SPLITS > 0:
+        return _WGRAD_GROUP_SPLITS
+    return int(max(1, min(slots // max(1, tiles), K // 1024, 16)))
 
 
 def _wgrad_splits_p8(M, N, K, cus=256):
@@ -275,6 +285,7 @@ class Engine:
         self.drop_seed = initial_drop_seed(_dist_rank())
         self.wgrad_overwrite = False   # set by MMTGTrainer.step around its backward
         self._ow_desc, self._ow_rec = {}, None   # zero lists per step shape / the record in progress (zero_grad)
+        self._lazy = None                        # ranges the last zero_grad left un-zeroed (the backward overwrites them)
         self.step_count = 0
         self.opt_m = None
         self.opt_v = None
@@ -347,10 +358,13 @@ class Engine:
         block matrices, recorded by _wgrad: 340 of 497 MB at the full configuration) -- one launch over the complement."""
         self.ensure_grad()
         self._ow_rec = None
+        self._lazy = None
         if shape_key is not None and _LAZY_ZERO:
-            desc = self._ow_desc.get(shape_key)
-            if desc is not None:
+            ent = self._ow_desc.get(shape_key)
+            if ent is not None:
+                desc, ranges = ent
                 hip.zero_ranges(self.grad, desc, desc.shape[0])
+                self._lazy = ranges          # these ranges were NOT zeroed: this step's backward must overwrite them
                 return
             if len(self._ow_desc) < 64:
                 self._ow_rec = (shape_key, [])          # record this step's overwritten ranges
@@ -374,7 +388,7 @@ class Engine:
             comp.append((pos, self.layout.total - pos))
         if not ranges or any(o % 4 or c % 4 for o, c in comp):
             return
-        self._ow_desc[key] = torch.tensor(comp, dtype=torch.int64, device=self.dev)
+        self._ow_desc[key] = (torch.tensor(comp, dtype=torch.int64, device=self.dev), frozenset(ranges))
 
     def _init_transposed(self):
         """bf16 mode: K-contiguous [out,in] copies of GPT-2's Conv1D [in,out] weights.  With them every
@@ -484,7 +498,10 @@ class Engine:
         tiles = ((Mg + 127) // 128) * ((Ng + 127) // 128)
         if bf and _WGRAD_SLAB and Ng % 8 == 0:
             splits = _wgrad_splits_p8(Mg, Ng, Mtok) or splits
-        if bf and _WGRAD_SLAB and 1 < splits and tiles < 512 and Ng % 8 == 0:
+        use_slab = bf and _WGRAD_SLAB and 1 < splits and tiles < 512 and Ng % 8 == 0
+        if self._lazy is not None and (self.layout.entries[wkey][0], Mg * Ng) in self._lazy and not (use_slab and self.wgrad_overwrite):
+            gw.zero_()          # the lazy zero_grad skipped this tensor expecting an overwrite that is not happening now
+        if use_slab:
             # K-split slabs with plain stores + an ordered sum instead of fp32 atomics (deterministic)
             # (one workspace, sized for the largest request so far: 113 MB at GPT-2 base, 268 MB at GPT-2 medium)
             part = self.buf("wgrad_slabs", (splits * Mg * Ng,), torch.float32)
@@ -785,9 +802,25 @@ class Engine:
         # dropout-masked gradient entering the previous residual branch and that branch's bias
         # gradient (column sum) -- see mmtg_layernorm_bwd.
         lnws = self.buf("ln_bwd_ws", (hip.lib().mmtg_layernorm_bwd_ws(M, max(D, H)),), torch.float32)
+        if self._lazy is not None and not self.wgrad_overwrite:
+            # (a backward that accumulates after a zero_grad(shape_key) that relied on overwrites: zero what it skipped)
+            self.grad.zero_()
+            self._lazy = None
         dx = self.buf("d_resid_a", (M, D))
         dx2 = self.buf("d_resid_b", (M, D))
+        # One grouped launch per block for its four weight gradients (mmtg_wgrad_group): the mlp.c_proj product's dy must then
+        # outlive the LayerNorm backward that produces the attention c_proj's dy, so the masked gradients alternate
+        # between two buffers.
+        group = _WGRAD_GROUP and self.dtype == hip.BF16 and M >= 1024 and D % 8 == 0
         dmask = self.buf("d_masked", (M, D)) if pr > 0 else None
+        dmask_b = (self.buf("d_masked_b", (M, D)) if group else dmask) if pr > 0 else None
+        if group:
+            gtiles = sum(((a_ + 127) // 128) * ((b_ + 127) // 128) for a_, b_ in ((D, 4 * D), (4 * D, D), (D, D), (D, 3 * D)))
+            gsplits = _group_splits(gtiles, M)
+            gws = self.buf("wgrad_group_ws", (gtiles * gsplits * 16384,), torch.float32) if gsplits > 1 else None
+            gcnt = self.ws.get(("wgrad_group_cnt", torch.int32))
+            if gcnt is None or gcnt.numel() < gtiles * 4:      # zero once: every launch leaves the counters zeroed
+                gcnt = self.ws[("wgrad_group_cnt", torch.int32)] = torch.zeros(gtiles * 4, device=self.dev, dtype=torch.int32)
         lastp = f"{pre}h.{sh.L - 1}."
         hip.layernorm_bwd(dhf, a["x_last"], self.P(pre + "ln_f.weight"), a["muf"], a["rsf"], None, dx,
                           self.G(pre + "ln_f.weight"), self.G(pre + "ln_f.bias"), M, D,
@@ -815,15 +848,17 @@ class Engine:
             # (both consumers of du run while it is still in the Infinity Cache; the c_proj weight gradient, whose
             #  operands come from HBM either way, goes last -- it must precede the LayerNorm backward, which reuses dmask)
             self._dgrad(du, p + "mlp.c_fc.weight", dm, M, "conv1d")
-            self._wgrad(m2, du, p + "mlp.c_fc.weight", None, M, "conv1d")
-            self._prefetch(xmid, ctx)           # while the c_proj weight gradient runs: LayerNorm input, attention context
-            self._wgrad(gact, dy, p + "mlp.c_proj.weight", None, M, "conv1d")
+            dy_fc2 = dy
+            if not group:
+                self._wgrad(m2, du, p + "mlp.c_fc.weight", None, M, "conv1d")
+                self._prefetch(xmid, ctx)           # while the c_proj weight gradient runs: LayerNorm input, attention context
+                self._wgrad(gact, dy, p + "mlp.c_proj.weight", None, M, "conv1d")
             hip.layernorm_bwd(dm, xmid, self.P(p + "ln_2.weight"), mu2, rs2, dx, dx2,
                               self.G(p + "ln_2.weight"), self.G(p + "ln_2.bias"), M, D,
-                              dx_masked=dmask, drop_p=pr, drop_seed=s[1],
+                              dx_masked=dmask_b, drop_p=pr, drop_seed=s[1],
                               dcolsum=self.G(p + "attn.c_proj.bias"), ws=lnws)
             # x_mid = x_in + drop(ctx Wp + bp)
-            dy = dmask if pr > 0 else dx2
+            dy = dmask_b if pr > 0 else dx2
             # bf16: the dgrad GEMM's epilogue also emits delta = rowsum(d ctx * ctx) per head
             fuse_delta = self.dtype == hip.BF16 and M > 256
             if fuse_delta:
@@ -831,7 +866,8 @@ class Engine:
             else:
                 self._dgrad(dy, p + "attn.c_proj.weight", dctx, M, "conv1d")
             self._prefetch(qkv)                 # while the c_proj weight gradient runs: the attention backward's rows
-            self._wgrad(ctx, dy, p + "attn.c_proj.weight", None, M, "conv1d")
+            if not group:
+                self._wgrad(ctx, dy, p + "attn.c_proj.weight", None, M, "conv1d")
             hip.attn_bwd(qkv, a["keep"], ctx, dctx, lse, delta, dq32, dqkv, B, T, sh.nH, D // sh.nH,
                          drop_p=pa, drop_seed=s[0], delta_ready=fuse_delta, dbias=self.G(p + "attn.c_attn.bias"),
                          dbias_ws=self.buf("attn_dbias_rows", (hip.attn_bwd_bias_rows(B, T, self.dtype), 3 * D), torch.float32))
@@ -839,7 +875,17 @@ class Engine:
             self._dgrad(dqkv, p + "attn.c_attn.weight", da, M, "conv1d")
             if l > 0:
                 self._prefetch(a["layers"][l - 1][11])      # the next layer's saved pre-activation (dGELU)
-            self._wgrad(a1, dqkv, p + "attn.c_attn.weight", None, M, "conv1d")
+            if group:
+                # gw[in, out] (+)= x^T dy for the block's four Conv1D layers: 432 tiles x 2 K halves at GPT-2 base, reduced in
+                # the kernel (must run before the LayerNorm backward below, which rewrites dmask / dx for the next block)
+                keys = (p + "mlp.c_fc.weight", p + "mlp.c_proj.weight", p + "attn.c_proj.weight", p + "attn.c_attn.weight")
+                probs = [(m2, du, self.G(keys[0]), D, 4 * D), (gact, dy_fc2, self.G(keys[1]), 4 * D, D),
+                         (ctx, dy, self.G(keys[2]), D, D), (a1, dqkv, self.G(keys[3]), D, 3 * D)]
+                hip.wgrad_group(probs, M, gsplits, gws, gcnt, accumulate=not self.wgrad_overwrite)
+                if self.wgrad_overwrite and self._ow_rec is not None:
+                    self._ow_rec[1].extend((self.layout.entries[k][0], self.layout.entries[k][2]) for k in keys)
+            else:
+                self._wgrad(a1, dqkv, p + "attn.c_attn.weight", None, M, "conv1d")
             if l > 0:
                 hip.layernorm_bwd(da, xin, self.P(p + "ln_1.weight"), mu1, rs1, dx2, dx,
                                   self.G(p + "ln_1.weight"), self.G(p + "ln_1.bias"), M, D,
@@ -939,6 +985,7 @@ class Engine:
                           self.G("ln_layer1.weight"), self.G("ln_layer1.bias"), B, H, ws=lnws)
         self._wgrad(a["xt"], dt_raw, "encoder.topic_fc.weight", "encoder.topic_fc.bias", B, "linear")
         self._ready("encoder.topic_fc.bias")
+        self._lazy = None
 
     # ---------------------------------------------------------------- optimizer (train.py:194-197)
     def grad_norm_sq(self):

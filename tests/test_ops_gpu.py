@@ -923,6 +923,82 @@ def test_weight_gradient_slabs(M, N, K, splits):
     assert (outs[0] - atom).abs().max().item() <= 2e-5 * scale
 
 
+@pytest.mark.parametrize("K,splits", [(4744, 2), (1000, 3), (15104, 2), (640, 1), (2048, 5)])
+def test_wgrad_group_in_kernel_reduction(K, splits):
+    """mmtg_wgrad_group: several weight-gradient products (ragged tile edges, leading dimensions wider than the extents, ragged
+    last K tile) in one launch, K splits reduced inside the kernel by the last-arriving wave of every quadrant.  Against the
+    fp32 product of the same bf16 inputs (fp32 summation order only), bit-identical between runs, equal to an explicit
+    sum of the per-split products in split order, overwrite / accumulate semantics, counters left zeroed."""
+    shapes = [(768, 384, 768, 384), (200, 136, 208, 144), (384, 768, 384, 768), (128, 128, 128, 128)]   # M, N, lda, ldb
+    ops = []
+    for i, (M, N, lda, ldb) in enumerate(shapes):
+        A = rnd(K, lda, dtype=torch.bfloat16, seed=40 + i).to(DEV)
+        B = rnd(K, ldb, dtype=torch.bfloat16, seed=50 + i).to(DEV)
+        ops.append((A, B, M, N, lda, ldb))
+    tiles = sum(((M + 127) // 128) * ((N + 127) // 128) for (_, _, M, N, _, _) in ops)
+    ws = torch.full((tiles * splits * 16384,), float("nan"), device=DEV)
+    cnt = torch.zeros(tiles * 4, dtype=torch.int32, device=DEV)
+    kper = -(-(-(-K // splits)) // 64) * 64
+    outs = []
+    for rep in range(3):
+        Cs = [torch.full((M, N + 8), 7.0, device=DEV) for (_, _, M, N, _, _) in ops]      # ldc = N + 8: the pad columns stay 7
+        probs = [(A, B, C_, M, N, lda, ldb, N + 8) for (A, B, M, N, lda, ldb), C_ in zip(ops, Cs)]
+        hip.wgrad_group(probs, K, splits, ws, cnt, accumulate=False)
+        assert int(cnt.abs().sum()) == 0
+        outs.append([c.clone() for c in Cs])
+        for (A, B, M, N, lda, ldb), C_ in zip(ops, Cs):
+            assert (C_[:, N:] == 7.0).all()
+            ref = A[:, :M].float().t() @ B[:, :N].float()
+            scale = ref.abs().max().item()
+            assert (C_[:, :N] - ref).abs().max().item() <= 2e-5 * scale
+            # the reduction order is the split order: equal to summing per-split fp32 products in that order up to the
+            # kernel's own in-tile accumulation order (tolerance), and independent of who arrived last (bit-equal runs)
+            acc = torch.zeros(M, N, device=DEV)
+            for s0 in range(0, K, kper):
+                acc += A[s0:s0 + kper, :M].float().t() @ B[s0:s0 + kper, :N].float()
+            assert (C_[:, :N] - acc).abs().max().item() <= 2e-5 * scale
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    for a, b in zip(outs[0], outs[2]):
+        assert torch.equal(a, b)
+    # accumulate = 1 adds to what is there
+    Cs = [torch.ones(M, N + 8, device=DEV) for (_, _, M, N, _, _) in ops]
+    probs = [(A, B, C_, M, N, lda, ldb, N + 8) for (A, B, M, N, lda, ldb), C_ in zip(ops, Cs)]
+    hip.wgrad_group(probs, K, splits, ws, cnt, accumulate=True)
+    for C_, o, (_, _, M, N, _, _) in zip(Cs, outs[0], ops):
+        scale = o[:, :N].abs().max().item()
+        assert (C_[:, :N] - 1.0 - o[:, :N]).abs().max().item() <= 1e-6 * scale
+        assert (C_[:, N:] == 1.0).all()
+
+
+def test_wgrad_group_repeated_launches_stay_bit_equal():
+    """Race screen at the training shapes: the four weight gradients of a GPT-2-base block (432 tiles x 2 K halves, every
+    quadrant reduced by whichever wave arrives last) launched 40 times back to back -- every result bit-equal to the first."""
+    K, D = 15104, 768
+    g = torch.Generator(device=DEV).manual_seed(3)
+    mk = lambda n: (torch.randn(K, n, device=DEV, generator=g) * 0.5).to(torch.bfloat16)
+    m2, du, gact, dy, ctx, dy2, a1, dqkv = mk(D), mk(4 * D), mk(4 * D), mk(D), mk(D), mk(D), mk(D), mk(3 * D)
+    shapes = [(m2, du, D, 4 * D), (gact, dy, 4 * D, D), (ctx, dy2, D, D), (a1, dqkv, D, 3 * D)]
+    tiles = sum((M // 128) * (N // 128) for (_, _, M, N) in shapes)
+    assert tiles == 432
+    ws = torch.empty(tiles * 2 * 16384, device=DEV)
+    cnt = torch.zeros(tiles * 4, dtype=torch.int32, device=DEV)
+    first = None
+    for it in range(40):
+        Cs = [torch.empty(M, N, device=DEV) for (_, _, M, N) in shapes]
+        hip.wgrad_group([(A, B, C_, M, N) for (A, B, M, N), C_ in zip(shapes, Cs)], K, 2, ws, cnt)
+        if first is None:
+            first = Cs
+            for (A, B, M, N), C_ in zip(shapes, Cs):
+                ref = A.float().t() @ B.float()
+                assert (C_ - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+        else:
+            for a, b in zip(first, Cs):
+                assert torch.equal(a, b), it
+    assert int(cnt.abs().sum()) == 0
+
+
+
 # ------------------------------------------------------------------ generation
 def test_logits_process_argmax():
     B, V, G = 6, 500, 40

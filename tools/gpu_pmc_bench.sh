@@ -18,7 +18,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = glob.glob("gpurun_out/pmc_bench/%s_counter_collection.csv" % c)
     n, tot = 0, 0.0
     for r in csv.DictReader(open(f[0])):
-        if any(k in r["Kernel_Name"] for k in ("gemm_dma_kernel", "gemm_occ4_kernel", "gemm_p8_kernel", "gemm_p8p_kernel")) and r["Counter_Name"] == c:
+        if any(k in r["Kernel_Name"] for k in ("gemm_dma_kernel", "gemm_occ4_kernel", "gemm_p8_kernel", "gemm_p8p_kernel", "wgrad_group_kernel")) and r["Counter_Name"] == c:
             n += 1
             tot += float(r["Counter_Value"])
     out[c] = (n, tot)
