@@ -297,14 +297,17 @@ MMTG_API int mmtg_slab_sum(const float* part, int splits, long stride, float* ds
  * its 64x64 quadrant (`counters`: >= 4 * tiles unsigned, ZERO on entry, zero again on return) and the wave that arrives
  * last adds the partial quadrants in split order and writes (accumulate = 0) or adds to (accumulate = 1) C.  No workgroup
  * ever waits for another; results are bit-reproducible.  splits = 1 needs neither ws nor counters.
- * `probs` is a HOST array (read during the call).  M, N, lda, ldb multiples of 8; operands below 2 GiB.                   */
+ * `probs` is a HOST array (read during the call).  M, N, lda, ldb multiples of 8; operands below 2 GiB.
+ * config 0: 128x128 tiles, four 256-thread workgroups per CU (any shape; 16384 floats and 4 counters per tile and split);
+ * config 1: 256x256 tiles on the eight-phase K-strided main loop, one 512-thread workgroup per CU (65536 floats and 8
+ *           counters per tile and split; K slices are multiples of 128).                                                  */
 typedef struct mmtg_wgrad_problem {
     const void* A; long lda;
     const void* B; long ldb;
     float* C; long ldc;
     int M, N;
 } mmtg_wgrad_problem;
-MMTG_API int mmtg_wgrad_group(int n, const mmtg_wgrad_problem* probs, int K, int splits, float* ws, long ws_floats,
+MMTG_API int mmtg_wgrad_group(int config, int n, const mmtg_wgrad_problem* probs, int K, int splits, float* ws, long ws_floats,
                      unsigned* counters, long n_counters, int accumulate, void* stream);
 /* Batched transpose (bf16 mode keeps K-contiguous [out,in] copies of GPT-2's Conv1D [in,out] weights
  * so that forward products run in the NT layout): matrix i = [rows, cols] row-major at src + desc[4i]

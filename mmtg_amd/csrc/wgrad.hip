@@ -86,6 +86,83 @@ __device__ __forceinline__ void ld4x4_agent(const float* p, f32x4 (&x)[4]) {    
                  : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]) : "v"(p) : "memory");
 }
 
+
+// Epilogue of both kernels, per WAVE (wave tile = TM bands of 16 rows x 64 columns at rows mw0.., columns nw0..): store / reduce /
+// write as described at the top of the file.  `scratch`: 4 KB of wave-private LDS.  TILE = elements of a workgroup tile.
+template <bool FENCE, int TM, int TILE>
+__device__ __forceinline__ void wg_reduce_store(const WgArgs& a, float* C, long ldc, int M, int N, int mw0, int nw0, int t, int split,
+                                                int nwaves, int wave, int lane, f32x4 (&acc)[TM][4], char* scratch) {
+    const int S = a.splits;
+    if (S == 1) {
+#pragma unroll
+        for (int h = 0; h < TM; ++h) wg_store_band(C, ldc, M, N, mw0, nw0, h, acc[h], scratch, lane, a.accumulate != 0);
+        return;
+    }
+    // my partial wave tile -> slot (t, split) of the workspace, accumulator order (1 KB per wave-instruction)
+    float* const slot0 = a.ws + ((long)t * S) * TILE + wave * (TM * 1024) + lane * 4;
+    {
+        float* const mine = slot0 + (long)split * TILE;
+#pragma unroll
+        for (int h = 0; h < TM; ++h)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (FENCE) *reinterpret_cast<f32x4*>(mine + (h * 4 + j) * 256) = acc[h][j];
+                else st4_agent(mine + (h * 4 + j) * 256, acc[h][j]);
+            }
+    }
+    if constexpr (FENCE) __threadfence();          // release: my stores are visible at device scope before the count moves
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // ... every write-through store has been acknowledged
+    unsigned* const cnt = a.cnt + (long)t * nwaves + wave;
+    unsigned old = 0;
+    if (lane == 0) old = atomicAdd(cnt, 1u);
+    old = __builtin_amdgcn_readfirstlane(old);
+    if (old != (unsigned)(S - 1)) return;          // not the last arriver of this wave tile: done
+    if constexpr (FENCE) __threadfence();          // acquire: the other splits' stores
+    if (lane == 0) *cnt = 0u;                      // leave the counters zeroed for the next launch
+#pragma unroll
+    for (int h = 0; h < TM; ++h) {
+        f32x4 sum[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sum[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < S; ++s) {              // split order, my own share from registers
+            if (s == split) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sum[j] += acc[h][j];
+            } else {
+                const float* src = slot0 + (long)s * TILE + h * 1024;
+                f32x4 x[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if constexpr (FENCE) x[j] = *reinterpret_cast<const f32x4*>(src + j * 256);
+                if constexpr (!FENCE) ld4x4_agent(src, x);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sum[j] += x[j];
+            }
+        }
+        wg_store_band(C, ldc, M, N, mw0, nw0, h, sum, scratch, lane, a.accumulate != 0);
+    }
+}
+
+// item -> (problem, tile origin, split): XCD-contiguous order (gemm_common.h, tile_origin) over v = split * ntiles + tile, so an XCD
+// works inside one K slice and the tiles of an XCD's run share operand panels in its L2
+template <int TB>
+__device__ __forceinline__ int wg_locate(const WgArgs& a, int& t, int& split, int& m0, int& n0) {
+    const int bid = blockIdx.x, nwg = gridDim.x;
+    const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
+    const int v = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+    split = v / a.ntiles;
+    t = v - split * a.ntiles;
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < WG_MAXP; ++i)
+        if (i < a.n && t >= a.pr[i].tile0) pi = i;
+    const WgProb& P = a.pr[pi];
+    const int tl = t - P.tile0;
+    if (P.m_fast) { m0 = (tl % P.tiles_m) * TB; n0 = (tl / P.tiles_m) * TB; }
+    else { m0 = (tl / P.tiles_n) * TB; n0 = (tl % P.tiles_n) * TB; }
+    return pi;
+}
+
 template <bool FENCE>
 __global__ __launch_bounds__(256, 4) void wgrad_group_kernel(WgArgs a) {
     constexpr int TBM = 128, TBN = 128, NW = 4, TM = 4, TN = 4, BK = 64;
@@ -95,23 +172,10 @@ __global__ __launch_bounds__(256, 4) void wgrad_group_kernel(WgArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    // XCD-contiguous item order (gemm_common.h, tile_origin): v = split * ntiles + tile, so an XCD works inside one K slice
-    const int bid = blockIdx.x, nwg = gridDim.x;
-    const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
-    const int v = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
-    const int split = v / a.ntiles;
-    const int t = v - split * a.ntiles;
-    int pi = 0;
-#pragma unroll
-    for (int i = 1; i < WG_MAXP; ++i)
-        if (i < a.n && t >= a.pr[i].tile0) pi = i;
-    const WgProb& P = a.pr[pi];
-    const int tl = t - P.tile0;
+    int t, split, m0, n0;
+    const WgProb& P = a.pr[wg_locate<128>(a, t, split, m0, n0)];
     const int M = P.M, N = P.N;
     const long lda = P.lda, ldb = P.ldb;
-    int m0, n0;
-    if (P.m_fast) { m0 = (tl % P.tiles_m) * TBM; n0 = (tl / P.tiles_m) * TBN; }
-    else { m0 = (tl / P.tiles_n) * TBM; n0 = (tl % P.tiles_n) * TBN; }
     const int kbeg = split * a.kper;
     const int klen = max(0, min(a.K, kbeg + a.kper) - kbeg);
     const int nk = (klen + BK - 1) / BK, nk_full = klen / BK;
@@ -167,62 +231,140 @@ __global__ __launch_bounds__(256, 4) void wgrad_group_kernel(WgArgs a) {
         }
     }
     __builtin_amdgcn_s_barrier();                  // the stage becomes the waves' private epilogue scratch
-    char* const scratch = smem + wave * 4096;
-    const int mw0 = m0 + wm * 64, nw0 = n0 + wn * 64;
-    const int S = a.splits;
-    if (S == 1) {
+    wg_reduce_store<FENCE, TM, TBM * TBN>(a, P.C, P.ldc, M, N, m0 + wm * 64, n0 + wn * 64, t, split, NW, wave, lane, acc,
+                                          smem + wave * 4096);
+}
+
+
+// ------------------------------------------------------------------ 256x256 eight-phase form (one workgroup per CU)
+// The same grouped launch on the eight-phase K-strided main loop of gemm.hip (gemm_p8_kernel<256, true>, restated here because
+// its phase / restaging protocol is a macro schedule inside that kernel): a 512-thread workgroup computes a 256x256 tile,
+// wave (wr, wc) of the 2x4 grid owns 128x64 of it; a 64-deep K tile is consumed in four phases of 16 MFMAs, the two wave-row
+// groups one barrier apart; two 64 KB stages, every K tile as four 16 KB half-tile images (64 k-rows x 128 gathered columns,
+// fragments by ds_read_b64_tr_b16) restaged three half tiles ahead of their use, one counted vmcnt(6) per K tile.  Half the
+// LDS fill bytes per FLOP of the 128x128 kernel (the fill path bounds that one: four workgroups pull 4 x 32 KB per K step
+// through the CU's 52 B/clk L2 port).  As a per-product kernel it lost (gemm.hip: 7-24 slabs per product, a 256 KB slab
+// store and a cold prologue exposed per 17-34 K tiles); grouped, a workgroup runs 118 K tiles and 108 tiles x 2 K halves =
+// 216 workgroups fill 84 % of the CUs in one round.  Rows of K past the end are zero-filled by the buffer descriptor.
+__device__ __forceinline__ void g8_issue(__amdgpu_buffer_rsrc_t r, char* d0, char* d1, int v0, int v1, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, LDS_PTR(void, d0), 16, v0, soff, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, LDS_PTR(void, d1), 16, v1, soff, 0, 0);
+}
+template <int AH, int BH>
+__device__ __forceinline__ void g8_mfma(const bf16x8 (&fa)[4][2], const bf16x8 (&fb)[2][2], f32x4 (&acc)[8][4]) {
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int h = 0; h < TM; ++h) wg_store_band(P.C, P.ldc, M, N, mw0, nw0, h, acc[h], scratch, lane, a.accumulate != 0);
-        return;
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) mma16(fb[j][kk], fa[i][kk], acc[4 * AH + i][2 * BH + j]);
+    __builtin_amdgcn_s_setprio(0);
+}
+// lane offset of 1-KB block `blk` (4 k-rows x 256 B) of half-tile image h: image chunk c holds source columns
+// (c / GRPCH) * 2 * GRPCH * 8 + h * GRPCH * 8 + (c % GRPCH) * 8 (GRPCH = 8: A, two wave-row groups of 64; 4: B, four wave columns of 32)
+template <int GRPCH>
+__device__ __forceinline__ int g8_voff(long ld, int col0, int ncols, int h, int blk, int lane) {
+    const int k = blk * 4 + (lane >> 4), pc = lane & 15, c = pc ^ ks_swz(k);
+    const int col = (c / GRPCH) * (2 * GRPCH * 8) + h * (GRPCH * 8) + (c % GRPCH) * 8;
+    return (col0 + col < ncols) ? (int)(((long)k * ld + col) * 2) : OOB;
+}
+#define G8_SYNC_IN()  do { asm volatile("s_barrier\n\ts_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define G8_SYNC_OUT() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_barrier" ::: "memory"); } while (0)
+
+__global__ __launch_bounds__(512, 1) void wgrad_group_p8_kernel(WgArgs a) {
+    constexpr int TA = 256 * 128, STAGE = 2 * TA;                   // bytes: A images | B images, two 16 KB half tiles each
+    extern __shared__ __attribute__((aligned(16))) char smem[];    // two stages
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    int t, split, m0, n0;
+    const WgProb& P = a.pr[wg_locate<256>(a, t, split, m0, n0)];
+    const int M = P.M, N = P.N;
+    const long lda = P.lda, ldb = P.ldb;
+    const int kbeg = split * a.kper;                                // kper % 128 == 0
+    const int klen = max(0, min(a.K, kbeg + a.kper) - kbeg);
+    const int nk = 2 * ((klen + 127) >> 7);                         // K tiles of 64, an even number (rows past K read zeros)
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(P.A), 0, P.bytesA, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(P.B), 0, P.bytesB, 0x00020000);
+    const int sa0 = (int)(((long)kbeg * lda + m0) * 2), sb0 = (int)(((long)kbeg * ldb + n0) * 2);
+    const int stepa = (int)(64 * lda * 2), stepb = (int)(64 * ldb * 2);
+    const int lA00 = wave * 1024, lA01 = (wave + 8) * 1024, lA10 = 16384 + lA00, lA11 = 16384 + lA01;
+    const int lB00 = TA + lA00, lB01 = TA + lA01, lB10 = TA + lA10, lB11 = TA + lA11;
+    const int vA00 = g8_voff<8>(lda, m0, M, 0, wave, lane), vA01 = g8_voff<8>(lda, m0, M, 0, wave + 8, lane);
+    const int vA10 = g8_voff<8>(lda, m0, M, 1, wave, lane), vA11 = g8_voff<8>(lda, m0, M, 1, wave + 8, lane);
+    const int vB00 = g8_voff<4>(ldb, n0, N, 0, wave, lane), vB01 = g8_voff<4>(ldb, n0, N, 0, wave + 8, lane);
+    const int vB10 = g8_voff<4>(ldb, n0, N, 1, wave, lane), vB11 = g8_voff<4>(ldb, n0, N, 1, wave + 8, lane);
+#define G8_A0(t_) g8_issue(ra, smem + ((t_) & 1) * STAGE + lA00, smem + ((t_) & 1) * STAGE + lA01, (t_) < nk ? vA00 : OOB, (t_) < nk ? vA01 : OOB, sa0 + (t_) * stepa)
+#define G8_A1(t_) g8_issue(ra, smem + ((t_) & 1) * STAGE + lA10, smem + ((t_) & 1) * STAGE + lA11, (t_) < nk ? vA10 : OOB, (t_) < nk ? vA11 : OOB, sa0 + (t_) * stepa)
+#define G8_B0(t_) g8_issue(rb, smem + ((t_) & 1) * STAGE + lB00, smem + ((t_) & 1) * STAGE + lB01, (t_) < nk ? vB00 : OOB, (t_) < nk ? vB01 : OOB, sb0 + (t_) * stepb)
+#define G8_B1(t_) g8_issue(rb, smem + ((t_) & 1) * STAGE + lB10, smem + ((t_) & 1) * STAGE + lB11, (t_) < nk ? vB10 : OOB, (t_) < nk ? vB11 : OOB, sb0 + (t_) * stepb)
+    int oa[4], ob[2];
+    ks_offsets<128, 4>(wr * 64, lane, oa);
+    ks_offsets<128, 2>(wc * 32, lane, ob);
+    ob[0] += TA; ob[1] += TA;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    G8_B0(0); G8_A0(0); G8_B1(0); G8_A1(0);
+    G8_B0(1); G8_A0(1); G8_B1(1);
+    wait_vmcnt<6>();                       // K tile 0 has landed (mine; the barrier makes it everyone's)
+    asm volatile("s_barrier" ::: "memory");
+    if (wr == 1) asm volatile("s_barrier" ::: "memory");          // the second wave group runs one barrier behind the first
+
+    bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
+#define G8_RD_A(ST, AH)                                                                                    \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int i = 0; i < 4; ++i)          \
+        fa[i][kk] = tr_read_pair(smem + (ST) * STAGE + (AH) * 16384, oa[i] + kk * 8192, oa[i] + kk * 8192 + 1024)
+#define G8_RD_B(ST, BH, F)                                                                                 \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int j = 0; j < 2; ++j)          \
+        F[j][kk] = tr_read_pair(smem + (ST) * STAGE + (BH) * 16384, ob[j] + kk * 8192, ob[j] + kk * 8192 + 1024)
+#define G8_TILE(ST, kt)                                                                                    \
+    do {                                                                                                   \
+        G8_RD_B(ST, 0, fb0);                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        G8_RD_A(ST, 0);                                                                                    \
+        G8_A1((kt) + 1);                                                                                   \
+        /* the b0 reads are done: b0 may be restaged next phase (8 + 16 reads, the counter saturates at 15) */ \
+        asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");                                                \
+        G8_SYNC_IN(); g8_mfma<0, 0>(fa, fb0, acc); G8_SYNC_OUT();                                           \
+        G8_RD_B(ST, 1, fb1);                                                                               \
+        G8_B0((kt) + 2);                                                                                   \
+        G8_SYNC_IN(); g8_mfma<0, 1>(fa, fb1, acc); G8_SYNC_OUT();                                           \
+        G8_RD_A(ST, 1);                                                                                    \
+        G8_A0((kt) + 2);                                                                                   \
+        G8_SYNC_IN(); g8_mfma<1, 1>(fa, fb1, acc); G8_SYNC_OUT();                                           \
+        G8_B1((kt) + 2);                                                                                   \
+        wait_vmcnt<6>();                                       /* K tile kt + 1 has landed */               \
+        G8_SYNC_IN(); g8_mfma<1, 0>(fa, fb0, acc); G8_SYNC_OUT();                                           \
+    } while (0)
+    for (int kt = 0; kt < nk; kt += 2) {
+        G8_TILE(0, kt);
+        G8_TILE(1, kt + 1);
     }
-    // my partial quadrant -> slot (t, split) of the workspace, accumulator order (1 KB per wave-instruction)
-    float* const slot0 = a.ws + ((long)t * S) * (TBM * TBN) + wave * 4096 + lane * 4;
-    {
-        float* const mine = slot0 + (long)split * (TBM * TBN);
-#pragma unroll
-        for (int h = 0; h < TM; ++h)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                if constexpr (FENCE) *reinterpret_cast<f32x4*>(mine + (h * 4 + j) * 256) = acc[h][j];
-                else st4_agent(mine + (h * 4 + j) * 256, acc[h][j]);
-            }
-    }
-    if constexpr (FENCE) __threadfence();          // release: my stores are visible at device scope before the count moves
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // ... every write-through store has been acknowledged
-    unsigned old = 0;
-    if (lane == 0) old = atomicAdd(a.cnt + (long)t * 4 + wave, 1u);
-    old = __builtin_amdgcn_readfirstlane(old);
-    if (old != (unsigned)(S - 1)) return;          // not the last arriver of this quadrant: done
-    if constexpr (FENCE) __threadfence();          // acquire: the other splits' stores
-    if (lane == 0) a.cnt[(long)t * 4 + wave] = 0u; // leave the counters zeroed for the next launch
-#pragma unroll
-    for (int h = 0; h < TM; ++h) {
-        f32x4 sum[4];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) sum[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int s = 0; s < S; ++s) {              // split order, my own share from registers
-            if (s == split) {
-#pragma unroll
-                for (int j = 0; j < TN; ++j) sum[j] += acc[h][j];
-            } else {
-                const float* src = slot0 + (long)s * (TBM * TBN) + h * 1024;
-                f32x4 x[4];
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    if constexpr (FENCE) x[j] = *reinterpret_cast<const f32x4*>(src + j * 256);
-                if constexpr (!FENCE) ld4x4_agent(src, x);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) sum[j] += x[j];
-            }
-        }
-        wg_store_band(P.C, P.ldc, M, N, mw0, nw0, h, sum, scratch, lane, a.accumulate != 0);
-    }
+#undef G8_TILE
+#undef G8_RD_A
+#undef G8_RD_B
+#undef G8_A0
+#undef G8_A1
+#undef G8_B0
+#undef G8_B1
+    wait_vmcnt<0>();                                     // the zero-fill tail loads
+    if (wr == 0) asm volatile("s_barrier" ::: "memory");           // re-join the two groups
+    asm volatile("s_barrier" ::: "memory");                        // every wave is done with the stages: they become epilogue scratch
+    wg_reduce_store<false, 8, 256 * 256>(a, P.C, P.ldc, M, N, m0 + wr * 128, n0 + wc * 64, t, split, 8, wave, lane, acc, smem + wave * 4096);
 }
 
 }  // namespace
 
-extern "C" int mmtg_wgrad_group(int n, const mmtg_wgrad_problem* probs, int K, int splits, float* ws, long ws_floats,
+extern "C" int mmtg_wgrad_group(int config, int n, const mmtg_wgrad_problem* probs, int K, int splits, float* ws, long ws_floats,
                                 unsigned* counters, long n_counters, int accumulate, void* stream) {
+    MMTG_REQUIRE(config == 0 || config == 1, "wgrad_group: config 0 (128x128 tiles) or 1 (256x256 eight-phase tiles)");
+    const int TB = config ? 256 : 128, NWV = config ? 8 : 4, KQ = config ? 128 : 64;
     MMTG_REQUIRE(n >= 1 && n <= WG_MAXP && probs, "wgrad_group: 1..%d problems", WG_MAXP);
     MMTG_REQUIRE(K > 0 && splits >= 1, "wgrad_group: K and splits must be positive");
     WgArgs a;
@@ -239,7 +381,7 @@ extern "C" int mmtg_wgrad_group(int n, const mmtg_wgrad_problem* probs, int K, i
         MMTG_REQUIRE(bytesA < 0x7FFFFF00L && bytesB < 0x7FFFFF00L, "wgrad_group: operands must stay below 2 GiB");
         WgProb& p = a.pr[i];
         p.A = q.A; p.B = q.B; p.C = q.C; p.lda = q.lda; p.ldb = q.ldb; p.ldc = q.ldc; p.M = q.M; p.N = q.N;
-        p.tiles_m = cdiv(q.M, 128); p.tiles_n = cdiv(q.N, 128);
+        p.tiles_m = cdiv(q.M, TB); p.tiles_n = cdiv(q.N, TB);
         p.tile0 = tiles;
         // the squarer block of the tile grid per XCD run (see launch_dma_cfg in gemm.hip)
         p.m_fast = p.tiles_n > p.tiles_m;
@@ -248,17 +390,29 @@ extern "C" int mmtg_wgrad_group(int n, const mmtg_wgrad_problem* probs, int K, i
         flops += 2.0 * q.M * q.N * (double)K;
         bytes += 2.0 * ((double)q.M * K + (double)q.N * K) + 4.0 * (double)q.M * q.N;
     }
-    const int kper = cdiv(cdiv(K, splits), 64) * 64;
+    const int kper = cdiv(cdiv(K, splits), KQ) * KQ;
     splits = cdiv(K, kper);                        // no empty K slice: every slot a last arriver reads was written
     MMTG_REQUIRE(splits == 1 || (ws && counters && MMTG_ALIGNED16(ws)), "wgrad_group: split products need the workspace and the counters");
-    MMTG_REQUIRE(splits == 1 || (ws_floats >= (long)tiles * splits * 16384 && n_counters >= (long)tiles * 4),
-                 "wgrad_group: workspace needs %ld floats and %ld counters", (long)tiles * splits * 16384, (long)tiles * 4);
+    MMTG_REQUIRE(splits == 1 || (ws_floats >= (long)tiles * splits * TB * TB && n_counters >= (long)tiles * NWV),
+                 "wgrad_group: workspace needs %ld floats and %ld counters", (long)tiles * splits * TB * TB, (long)tiles * NWV);
     a.n = n; a.K = K; a.kper = kper; a.splits = splits; a.ntiles = tiles; a.accumulate = accumulate;
     a.ws = ws; a.cnt = counters;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(MMTG_PROF_GEMM_BF16, s, flops, bytes);
     static bool attr_done = false;
     static const bool fence = getenv("MMTG_WGRAD_FENCE") != nullptr;
+    if (config == 1) {
+        const size_t shm8 = 2 * (256 + 256) * 128;
+        static bool attr8_done = false;
+        if (!attr8_done) {
+            if (hipFuncSetAttribute((const void*)wgrad_group_p8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm8) != hipSuccess)
+                MMTG_FAIL(MMTG_ERR_HIP, "wgrad_group: cannot raise dynamic LDS to %zu bytes", shm8);
+            attr8_done = true;
+        }
+        hipLaunchKernelGGL(wgrad_group_p8_kernel, dim3(tiles * splits), dim3(512), shm8, s, a);
+        MMTG_LAUNCH_CHECK("wgrad_group");
+        return MMTG_OK;
+    }
     const size_t shm = (128 + 128) * 128;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void*)wgrad_group_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess ||

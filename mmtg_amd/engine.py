@@ -205,11 +205,12 @@ _WTE_T = _os.environ.get("MMTG_NO_WTE_T") is None      # [D, Vpad] copy of wte f
 _P8T = _os.environ.get("MMTG_GEMM_P8T", "0") != "0"      # eight-phase K-strided kernel for the slab weight gradients (opt-in: measured slower in situ)
 _WGRAD_GROUP = _os.environ.get("MMTG_WGRAD_GROUP", "1") != "0"   # one grouped launch per GPT-2 block for its four weight gradients (A/B switch)
 _WGRAD_GROUP_SPLITS = int(_os.environ.get("MMTG_WGRAD_GROUP_SPLITS", "0"))    # 0 = the one-round rule below
+_WGRAD_GROUP_CFG = int(_os.environ.get("MMTG_WGRAD_GROUP_CFG", "0"))          # 0: 128x128 tiles, four workgroups per CU; 1: 256x256 eight-phase
 
 
 def _group_splits(tiles, K, slots=1024):
-    """K splits of a grouped weight-gradient launch: tiles x splits workgroups in ONE round of the single-stage kernel's
-    slots (four 128x128 workgroups per CU), no K slice shorter than 1024 tokens."""
+    """K splits of a grouped weight-gradient launch: tiles x splits workgroups in ONE round of the kernel's slots (four
+    128x128 workgroups per CU / one 256x256 workgroup per CU), no K slice shorter than 1024 tokens."""
     if _WGRAD_GROUP_SPLITS > 0:
         return _WGRAD_GROUP_SPLITS
     return int(max(1, min(slots // max(1, tiles), K // 1024, 16)))
@@ -811,16 +812,19 @@ class Engine:
         # One grouped launch per block for its four weight gradients (mmtg_wgrad_group): the mlp.c_proj product's dy must then
         # outlive the LayerNorm backward that produces the attention c_proj's dy, so the masked gradients alternate
         # between two buffers.
-        group = _WGRAD_GROUP and self.dtype == hip.BF16 and M >= 1024 and D % 8 == 0
+        group = _WGRAD_GROUP and self.dtype == hip.BF16 and M >= 256 and D % 8 == 0
         dmask = self.buf("d_masked", (M, D)) if pr > 0 else None
         dmask_b = (self.buf("d_masked_b", (M, D)) if group else dmask) if pr > 0 else None
         if group:
-            gtiles = sum(((a_ + 127) // 128) * ((b_ + 127) // 128) for a_, b_ in ((D, 4 * D), (4 * D, D), (D, D), (D, 3 * D)))
-            gsplits = _group_splits(gtiles, M)
-            gws = self.buf("wgrad_group_ws", (gtiles * gsplits * 16384,), torch.float32) if gsplits > 1 else None
+            gshapes = ((D, 4 * D), (4 * D, D), (D, D), (D, 3 * D))
+            gcfg = 1 if (_WGRAD_GROUP_CFG and D >= 256) else 0
+            gtiles = hip.wgrad_group_sizes(gshapes, 1, gcfg)[0]
+            gsplits = _group_splits(gtiles, M, 256 if gcfg else 1024)
+            _, nws, ncnt = hip.wgrad_group_sizes(gshapes, gsplits, gcfg)
+            gws = self.buf("wgrad_group_ws", (nws,), torch.float32) if gsplits > 1 else None
             gcnt = self.ws.get(("wgrad_group_cnt", torch.int32))
-            if gcnt is None or gcnt.numel() < gtiles * 4:      # zero once: every launch leaves the counters zeroed
-                gcnt = self.ws[("wgrad_group_cnt", torch.int32)] = torch.zeros(gtiles * 4, device=self.dev, dtype=torch.int32)
+            if gcnt is None or gcnt.numel() < ncnt:      # zero once: every launch leaves the counters zeroed
+                gcnt = self.ws[("wgrad_group_cnt", torch.int32)] = torch.zeros(ncnt, device=self.dev, dtype=torch.int32)
         lastp = f"{pre}h.{sh.L - 1}."
         hip.layernorm_bwd(dhf, a["x_last"], self.P(pre + "ln_f.weight"), a["muf"], a["rsf"], None, dx,
                           self.G(pre + "ln_f.weight"), self.G(pre + "ln_f.bias"), M, D,
@@ -881,7 +885,7 @@ class Engine:
                 keys = (p + "mlp.c_fc.weight", p + "mlp.c_proj.weight", p + "attn.c_proj.weight", p + "attn.c_attn.weight")
                 probs = [(m2, du, self.G(keys[0]), D, 4 * D), (gact, dy_fc2, self.G(keys[1]), 4 * D, D),
                          (ctx, dy, self.G(keys[2]), D, D), (a1, dqkv, self.G(keys[3]), D, 3 * D)]
-                hip.wgrad_group(probs, M, gsplits, gws, gcnt, accumulate=not self.wgrad_overwrite)
+                hip.wgrad_group(probs, M, gsplits, gws, gcnt, accumulate=not self.wgrad_overwrite, config=gcfg)
                 if self.wgrad_overwrite and self._ow_rec is not None:
                     self._ow_rec[1].extend((self.layout.entries[k][0], self.layout.entries[k][2]) for k in keys)
             else:

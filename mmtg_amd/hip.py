@@ -65,7 +65,7 @@ _SIGS = {
     "mmtg_cast_to_f32": ([_i, _vp, _vp, _l, _vp], _i),
     "mmtg_axpy_f32": ([_vp, _vp, _f, _l, _vp], _i),
     "mmtg_slab_sum": ([_vp, _i, _l, _vp, _i, _l, _vp], _i),
-    "mmtg_wgrad_group": ([_i, _vp, _i, _i, _vp, _l, _vp, _l, _i, _vp], _i),
+    "mmtg_wgrad_group": ([_i, _i, _vp, _i, _i, _vp, _l, _vp, _l, _i, _vp], _i),
     "mmtg_transpose_batch": ([_i, _vp, _vp, _vp, _i, _i, _i, _vp], _i),
     "mmtg_logits_process_argmax": ([_vp, _l, _i, _vp, _l, _vp, _f, _f, _vp, _i, _vp], _i),
     "mmtg_decode_embed": ([_i, _vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
@@ -391,11 +391,14 @@ class WgradProblem(C.Structure):
                 ("C", C.c_void_p), ("ldc", C.c_long), ("M", C.c_int), ("N", C.c_int)]
 
 
-def wgrad_group_tiles(problems):
-    return sum(((M + 127) // 128) * ((N + 127) // 128) for (_, _, _, M, N, *_) in problems)
+def wgrad_group_sizes(shapes, splits, config=0):
+    """(tiles, workspace floats, counters) of a grouped launch over problems of the given (M, N) shapes."""
+    tb, nw = (256, 8) if config else (128, 4)
+    tiles = sum(((M + tb - 1) // tb) * ((N + tb - 1) // tb) for (M, N) in shapes)
+    return tiles, tiles * splits * tb * tb, tiles * nw
 
 
-def wgrad_group(problems, K, splits, ws, counters, accumulate=False):
+def wgrad_group(problems, K, splits, ws, counters, accumulate=False, config=0):
     """Grouped weight gradients C (+)= A^T B (include/mmtg_hip.h, mmtg_wgrad_group).
     problems: list of (A [K, lda] bf16, B [K, ldb] bf16, C [M, ldc] f32, M, N[, lda, ldb, ldc])."""
     arr = (WgradProblem * len(problems))()
@@ -403,7 +406,7 @@ def wgrad_group(problems, K, splits, ws, counters, accumulate=False):
         A, B, C_, M, N = pr[:5]
         lda, ldb, ldc = (pr[5:8] if len(pr) >= 8 else (M, N, N))
         arr[i] = WgradProblem(_p(A), lda, _p(B), ldb, _p(C_), ldc, M, N)
-    _check(lib().mmtg_wgrad_group(len(problems), C.addressof(arr), int(K), int(splits), _p(ws), 0 if ws is None else ws.numel(),
+    _check(lib().mmtg_wgrad_group(int(config), len(problems), C.addressof(arr), int(K), int(splits), _p(ws), 0 if ws is None else ws.numel(),
                                   _p(counters), 0 if counters is None else counters.numel(), int(accumulate), _stream()), "wgrad_group")
 
 

@@ -469,7 +469,7 @@ def test_trainer_zeroes_only_the_accumulated_gradients_after_the_first_step_of_a
         e1.drop_seed = e2.drop_seed = 777 + step
         if step == 2:
             assert len(e1._ow_desc) == 1 and not e2._ow_desc
-            desc = next(iter(e1._ow_desc.values())).cpu()
+            desc = next(iter(e1._ow_desc.values()))[0].cpu()
             kept = e1.layout.total - int(desc[:, 1].sum())
             assert kept >= sum(e1.layout.entries["decoder.gpt2.transformer.h.%d.%s" % (l, w)][2] for l in range(2)
                                for w in ("attn.c_attn.weight", "attn.c_proj.weight", "mlp.c_fc.weight", "mlp.c_proj.weight"))
@@ -489,6 +489,41 @@ def test_trainer_zeroes_only_the_accumulated_gradients_after_the_first_step_of_a
     lazy.step(half, stage=3)
     full.step(half, stage=3)
     assert torch.isfinite(e1.grad).all() and float((e1.grad - e2.grad).norm() / e2.grad.norm()) < 1e-6
+
+
+def test_accumulating_backward_after_a_lazy_zero_grad_is_not_fooled():
+    """Engine.zero_grad(shape_key) skips the tensors the recorded backward of that shape OVERWRITES.  A backward that then
+    ACCUMULATES (wgrad_overwrite off: the drop-in autograd path) must not add onto the stale contents: the engine falls back to
+    a full zero.  Poisoned buffer, two accumulating backwards = exactly twice one."""
+    fx, meta, mcfg, gcfg, dcfg, weights, table, batch, model = build("tiny_s5", "bf16")
+    tb = batch_to_torch(batch, DEV)
+    tr = MMTGTrainer(model, lr=0.0, alpha=0.2)
+    eng = tr.eng
+    for _ in range(2):                                  # first step records, the second uses the lazy list
+        eng.drop_seed = 4242
+        tr.step(tb, stage=3)
+    key = next(iter(eng._ow_desc))
+    ref = eng.grad.clone()
+    eng.grad.fill_(1e30)
+    eng.zero_grad(key)
+    assert eng._lazy is not None
+    for rep in range(2):                                # accumulate twice, NOT in overwrite mode
+        eng.drop_seed = 4242 - 1664525 + 0              # (forward advances the seed; any fixed value serves: dropout is off below)
+        eng.forward(tb, train_flag=True, training=False, logits_f32=False)
+        eng.loss(tb["rating"], 3, batch_den=tb["rating"].shape[0])
+        dl = eng.loss_backward(float(tb["rating"].shape[0]))
+        eng.backward(dl, dkl=0.2 * tb["rating"].shape[0])
+    assert torch.isfinite(eng.grad).all()
+    # compare with an explicitly zeroed buffer going through the same two accumulating backwards
+    got = eng.grad.clone()
+    eng.zero_grad()
+    for rep in range(2):
+        eng.forward(tb, train_flag=True, training=False, logits_f32=False)
+        eng.loss(tb["rating"], 3, batch_den=tb["rating"].shape[0])
+        dl = eng.loss_backward(float(tb["rating"].shape[0]))
+        eng.backward(dl, dkl=0.2 * tb["rating"].shape[0])
+    assert float((got - eng.grad).norm() / eng.grad.norm()) < 1e-6
+    assert float(ref.norm()) > 0
 
 
 # ------------------------------------------------------------------ the benchmarked mode at depth (12 layers, V = 13317)

@@ -923,8 +923,9 @@ def test_weight_gradient_slabs(M, N, K, splits):
     assert (outs[0] - atom).abs().max().item() <= 2e-5 * scale
 
 
+@pytest.mark.parametrize("config", [0, 1])
 @pytest.mark.parametrize("K,splits", [(4744, 2), (1000, 3), (15104, 2), (640, 1), (2048, 5)])
-def test_wgrad_group_in_kernel_reduction(K, splits):
+def test_wgrad_group_in_kernel_reduction(K, splits, config):
     """mmtg_wgrad_group: several weight-gradient products (ragged tile edges, leading dimensions wider than the extents, ragged
     last K tile) in one launch, K splits reduced inside the kernel by the last-arriving wave of every quadrant.  Against the
     fp32 product of the same bf16 inputs (fp32 summation order only), bit-identical between runs, equal to an explicit
@@ -935,15 +936,16 @@ def test_wgrad_group_in_kernel_reduction(K, splits):
         A = rnd(K, lda, dtype=torch.bfloat16, seed=40 + i).to(DEV)
         B = rnd(K, ldb, dtype=torch.bfloat16, seed=50 + i).to(DEV)
         ops.append((A, B, M, N, lda, ldb))
-    tiles = sum(((M + 127) // 128) * ((N + 127) // 128) for (_, _, M, N, _, _) in ops)
-    ws = torch.full((tiles * splits * 16384,), float("nan"), device=DEV)
-    cnt = torch.zeros(tiles * 4, dtype=torch.int32, device=DEV)
-    kper = -(-(-(-K // splits)) // 64) * 64
+    tiles, nws, ncnt = hip.wgrad_group_sizes([(M, N) for (_, _, M, N, _, _) in ops], splits, config)
+    ws = torch.full((nws,), float("nan"), device=DEV)
+    cnt = torch.zeros(ncnt, dtype=torch.int32, device=DEV)
+    kq = 128 if config else 64
+    kper = -(-(-(-K // splits)) // kq) * kq
     outs = []
     for rep in range(3):
         Cs = [torch.full((M, N + 8), 7.0, device=DEV) for (_, _, M, N, _, _) in ops]      # ldc = N + 8: the pad columns stay 7
         probs = [(A, B, C_, M, N, lda, ldb, N + 8) for (A, B, M, N, lda, ldb), C_ in zip(ops, Cs)]
-        hip.wgrad_group(probs, K, splits, ws, cnt, accumulate=False)
+        hip.wgrad_group(probs, K, splits, ws, cnt, accumulate=False, config=config)
         assert int(cnt.abs().sum()) == 0
         outs.append([c.clone() for c in Cs])
         for (A, B, M, N, lda, ldb), C_ in zip(ops, Cs):
@@ -964,29 +966,30 @@ def test_wgrad_group_in_kernel_reduction(K, splits):
     # accumulate = 1 adds to what is there
     Cs = [torch.ones(M, N + 8, device=DEV) for (_, _, M, N, _, _) in ops]
     probs = [(A, B, C_, M, N, lda, ldb, N + 8) for (A, B, M, N, lda, ldb), C_ in zip(ops, Cs)]
-    hip.wgrad_group(probs, K, splits, ws, cnt, accumulate=True)
+    hip.wgrad_group(probs, K, splits, ws, cnt, accumulate=True, config=config)
     for C_, o, (_, _, M, N, _, _) in zip(Cs, outs[0], ops):
         scale = o[:, :N].abs().max().item()
         assert (C_[:, :N] - 1.0 - o[:, :N]).abs().max().item() <= 1e-6 * scale
         assert (C_[:, N:] == 1.0).all()
 
 
-def test_wgrad_group_repeated_launches_stay_bit_equal():
-    """Race screen at the training shapes: the four weight gradients of a GPT-2-base block (432 tiles x 2 K halves, every
-    quadrant reduced by whichever wave arrives last) launched 40 times back to back -- every result bit-equal to the first."""
+@pytest.mark.parametrize("config", [0, 1])
+def test_wgrad_group_repeated_launches_stay_bit_equal(config):
+    """Race screen at the training shapes: the four weight gradients of a GPT-2-base block (432 / 108 tiles x 2 K halves, every
+    wave tile reduced by whichever wave arrives last) launched 40 times back to back -- every result bit-equal to the first."""
     K, D = 15104, 768
     g = torch.Generator(device=DEV).manual_seed(3)
     mk = lambda n: (torch.randn(K, n, device=DEV, generator=g) * 0.5).to(torch.bfloat16)
     m2, du, gact, dy, ctx, dy2, a1, dqkv = mk(D), mk(4 * D), mk(4 * D), mk(D), mk(D), mk(D), mk(D), mk(3 * D)
     shapes = [(m2, du, D, 4 * D), (gact, dy, 4 * D, D), (ctx, dy2, D, D), (a1, dqkv, D, 3 * D)]
-    tiles = sum((M // 128) * (N // 128) for (_, _, M, N) in shapes)
-    assert tiles == 432
-    ws = torch.empty(tiles * 2 * 16384, device=DEV)
-    cnt = torch.zeros(tiles * 4, dtype=torch.int32, device=DEV)
+    tiles, nws, ncnt = hip.wgrad_group_sizes([(M, N) for (_, _, M, N) in shapes], 2, config)
+    assert tiles == (108 if config else 432)
+    ws = torch.empty(nws, device=DEV)
+    cnt = torch.zeros(ncnt, dtype=torch.int32, device=DEV)
     first = None
     for it in range(40):
         Cs = [torch.empty(M, N, device=DEV) for (_, _, M, N) in shapes]
-        hip.wgrad_group([(A, B, C_, M, N) for (A, B, M, N), C_ in zip(shapes, Cs)], K, 2, ws, cnt)
+        hip.wgrad_group([(A, B, C_, M, N) for (A, B, M, N), C_ in zip(shapes, Cs)], K, 2, ws, cnt, config=config)
         if first is None:
             first = Cs
             for (A, B, M, N), C_ in zip(shapes, Cs):

@@ -29,11 +29,12 @@ def baseline():
         hip.slab_sum(slabs, s, M * N, C_, M * N, accumulate=False)
 
 
-def grouped(S):
-    ws = torch.empty(tiles * S * 16384, device=DEV)
-    cnt = torch.zeros(tiles * 4, dtype=torch.int32, device=DEV)
+def grouped(S, config=0):
+    _, nws, ncnt = hip.wgrad_group_sizes([(M, N) for (_, _, M, N) in shapes], S, config)
+    ws = torch.empty(nws, device=DEV)
+    cnt = torch.zeros(ncnt, dtype=torch.int32, device=DEV)
     probs = [(A, B, C_, M, N) for (A, B, M, N), C_ in zip(shapes, Cs)]
-    return lambda: hip.wgrad_group(probs, K, S, ws, cnt)
+    return lambda: hip.wgrad_group(probs, K, S, ws, cnt, config=config)
 
 
 def timeit(fn, cold, iters=12):
@@ -56,3 +57,8 @@ for cold in (False, True):
     for S in [int(x) for x in os.environ.get("SPLITS", "1,2,3").split(",")]:
         t = timeit(grouped(S), cold)
         print("%-5s grouped launch, %d K split(s), %4d workgroups %7.1f us  %6.0f TFLOP/s" % ("cold" if cold else "warm", S, tiles * S, t, flops / t / 1e6))
+    if not os.environ.get("MMTG_WGRAD_FENCE"):
+        for S in [int(x) for x in os.environ.get("SPLITS8", "1,2,3").split(",")]:
+            t8 = hip.wgrad_group_sizes([(M, N) for (_, _, M, N) in shapes], S, 1)[0]
+            t = timeit(grouped(S, 1), cold)
+            print("%-5s grouped eight-phase 256x256, %d K split(s), %4d workgroups %7.1f us  %6.0f TFLOP/s" % ("cold" if cold else "warm", S, t8 * S, t, flops / t / 1e6))

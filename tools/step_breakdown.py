@@ -60,7 +60,7 @@ def wrap(name, fn):
 skip = {"lib", "lib_path", "exported_symbols", "dt", "torch_dtype", "drop_thresh", "prof_enable", "prof_read", "gemm_trace"}
 for name in dir(hip):
     fn = getattr(hip, name)
-    if callable(fn) and not name.startswith("_") and name not in skip and getattr(fn, "__module__", "") == hip.__name__:
+    if callable(fn) and not isinstance(fn, type) and not name.startswith("_") and name not in skip and getattr(fn, "__module__", "") == hip.__name__:
         setattr(hip, name, wrap(name, fn))
 
 t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
