@@ -785,6 +785,10 @@ class Engine:
         model; parameter gradients are ACCUMULATED into the flat fp32 buffer."""
         a, sh = self.act, self.sh
         self.ensure_grad()
+        if self._lazy is not None and not self.wgrad_overwrite:
+            # (a backward that accumulates after a zero_grad(shape_key) that relied on overwrites: zero what it skipped)
+            self.grad.zero_()
+            self._lazy = None
         B, T, M, L = a["B"], a["T"], a["M"], a["L"]
         S, E, H, D, P = sh.S, sh.E, sh.H, sh.D, sh.P
         pe, pa, pr = a["pdrop"]
@@ -803,10 +807,6 @@ class Engine:
         # dropout-masked gradient entering the previous residual branch and that branch's bias
         # gradient (column sum) -- see mmtg_layernorm_bwd.
         lnws = self.buf("ln_bwd_ws", (hip.lib().mmtg_layernorm_bwd_ws(M, max(D, H)),), torch.float32)
-        if self._lazy is not None and not self.wgrad_overwrite:
-            # (a backward that accumulates after a zero_grad(shape_key) that relied on overwrites: zero what it skipped)
-            self.grad.zero_()
-            self._lazy = None
         dx = self.buf("d_resid_a", (M, D))
         dx2 = self.buf("d_resid_b", (M, D))
         # One grouped launch per block for its four weight gradients (mmtg_wgrad_group): the mlp.c_proj product's dy must then
