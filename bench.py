@@ -172,7 +172,7 @@ def bench_decode(args, world, rank, dev, steps, warmup, with_cpu=True):
         pr = hip.prof_read()
         print({k: (v["launches"], round(v["ms"], 2)) for k, v in pr.items() if v["launches"]})
         return None
-    dec = GreedyDecoder(model, max_batch=B, max_len=Ln)
+    dec = GreedyDecoder(model, max_batch=B, max_len=Ln, use_graph=not getattr(args, "decode_eager", False))
     for _ in range(max(1, warmup)):
         ids = dec.generate(batch, Ln, temperature=1.1, repitition_penalty=1.5)
     out_ids = [None]
@@ -240,8 +240,21 @@ def decode_roofline(args, model, batch, B, Ln, dec, step_us_events):
     tot_ms = sum(v["ms"] for v in pr.values())
     step_us = step_us_events
     ach = alg / max(step_us, 1e-9) / 1e3            # GB/s
+    traffic, tsrc = None, None
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_decode_pmc_traffic.json")), reverse=True):
+        try:
+            with open(f) as fh:
+                m = json.load(fh)
+        except Exception:
+            continue
+        if m.get("kernel_source_sha") == hip.source_sha() and B == 256 and args.dtype == "bf16":
+            traffic, tsrc = m["hbm_bytes_per_token_step"], os.path.relpath(f, ROOT)
+            break
     return {"bound": "hbm", "kernel": dec.kernel_name(), "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s",
-            "frac": round(ach / 8000.0, 4), "traffic": None,
+            "frac": round(ach / 8000.0, 4), "traffic": traffic,
+            "traffic_source": (tsrc + " (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE over every kernel of the token step)") if tsrc else
+                              "none: no profiles/r*_decode_pmc_traffic.json was taken on kernel sources sha %s" % hip.source_sha()[:12],
             "algorithmic_bytes_per_token_step": int(alg), "weights_bytes": int(w_bytes), "kv_bytes_mean": int(kv_bytes),
             "us_per_token_step_hip_events": round(step_us, 2),
             "eager_kernel_us_per_token_step": round(1e3 * tot_ms / steps_per_seq, 2),
@@ -475,6 +488,7 @@ def main():
                     help="decode: batched greedy generation (BASELINE configs[3]: batch 256, max_len 128)")
     ap.add_argument("--decode-batch", type=int, default=256)
     ap.add_argument("--decode-len", type=int, default=128)
+    ap.add_argument("--decode-eager", action="store_true", help="decode without graph capture (counter-collection passes: every dispatch visible)")
     ap.add_argument("--dry-launch", action="store_true",
                     help="launch contract only (no GPU): ranks rendezvous over gloo, rank 0 prints one JSON line")
     ap.add_argument("--no-f32", action="store_true", help="skip the f32 (parity-gate mode) object of the default line")

@@ -163,7 +163,9 @@ __device__ __forceinline__ int wg_locate(const WgArgs& a, int& t, int& split, in
     return pi;
 }
 
-template <bool FENCE>
+// ABLATE (timing only, wrong results; MMTG_WGRAD_ABLATE=1|2): 1 = every fragment by ONE ds_read_b128 instead of two
+// ds_read_b64_tr_b16 (what an 8-row register transpose of plain reads would issue); 2 = no LDS-DMA fills after the first tile.
+template <bool FENCE, int ABLATE = 0>
 __global__ __launch_bounds__(256, 4) void wgrad_group_kernel(WgArgs a) {
     constexpr int TBM = 128, TBN = 128, NW = 4, TM = 4, TN = 4, BK = 64;
     constexpr int NB = TBM / 8 / NW;
@@ -202,6 +204,7 @@ __global__ __launch_bounds__(256, 4) void wgrad_group_kernel(WgArgs a) {
         if (kt) __builtin_amdgcn_s_barrier();      // every wave is done reading the previous tile
         const bool full = kt < nk_full;
         const int krem = klen - kt * BK;
+        if (ABLATE != 2 || kt == 0) {
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int o = full ? va[i] : dma_voff<true, TBM>(lda, m0, M, krem, wave + NW * i, lane);
@@ -212,6 +215,7 @@ __global__ __launch_bounds__(256, 4) void wgrad_group_kernel(WgArgs a) {
             const int o = full ? vb[i] : dma_voff<true, TBN>(ldb, n0, N, krem, wave + NW * i, lane);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, LDS_PTR(void, smem + TA + (wave + NW * i) * 1024), 16, o, sb, 0, 0);
         }
+        }
         sa += stepa;
         sb += stepb;
         wait_vmcnt<0>();
@@ -220,9 +224,15 @@ __global__ __launch_bounds__(256, 4) void wgrad_group_kernel(WgArgs a) {
         for (int kk = 0; kk < 2; ++kk) {
             bf16x8 fa[TM], fb[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = tr_read_pair(smem, oa[i] + kk * 32 * 2 * TBM, oa[i] + kk * 32 * 2 * TBM + 4 * 2 * TBM);
+            for (int i = 0; i < TM; ++i) {
+                if constexpr (ABLATE == 1) fa[i] = *reinterpret_cast<const bf16x8*>(smem + ((oa[i] + kk * 8192) & ~15));
+                else fa[i] = tr_read_pair(smem, oa[i] + kk * 32 * 2 * TBM, oa[i] + kk * 32 * 2 * TBM + 4 * 2 * TBM);
+            }
 #pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = tr_read_pair(smem + TA, ob[j] + kk * 32 * 2 * TBN, ob[j] + kk * 32 * 2 * TBN + 4 * 2 * TBN);
+            for (int j = 0; j < TN; ++j) {
+                if constexpr (ABLATE == 1) fb[j] = *reinterpret_cast<const bf16x8*>(smem + TA + ((ob[j] + kk * 8192) & ~15));
+                else fb[j] = tr_read_pair(smem + TA, ob[j] + kk * 32 * 2 * TBN, ob[j] + kk * 32 * 2 * TBN + 4 * 2 * TBN);
+            }
             // (swapped operands: a lane then holds 4 consecutive columns of row l15 -- row-contiguous stores)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -420,7 +430,17 @@ extern "C" int mmtg_wgrad_group(int config, int n, const mmtg_wgrad_problem* pro
             MMTG_FAIL(MMTG_ERR_HIP, "wgrad_group: cannot raise dynamic LDS to %zu bytes", shm);
         attr_done = true;
     }
-    if (fence) hipLaunchKernelGGL(wgrad_group_kernel<true>, dim3(tiles * splits), dim3(256), shm, s, a);
+    static const int ablate = getenv("MMTG_WGRAD_ABLATE") ? atoi(getenv("MMTG_WGRAD_ABLATE")) : 0;
+    if (ablate) {
+        static bool abl_done = false;
+        if (!abl_done) {
+            hipFuncSetAttribute((const void*)wgrad_group_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+            hipFuncSetAttribute((const void*)wgrad_group_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+            abl_done = true;
+        }
+        if (ablate == 1) hipLaunchKernelGGL((wgrad_group_kernel<false, 1>), dim3(tiles * splits), dim3(256), shm, s, a);
+        else hipLaunchKernelGGL((wgrad_group_kernel<false, 2>), dim3(tiles * splits), dim3(256), shm, s, a);
+    } else if (fence) hipLaunchKernelGGL(wgrad_group_kernel<true>, dim3(tiles * splits), dim3(256), shm, s, a);
     else hipLaunchKernelGGL(wgrad_group_kernel<false>, dim3(tiles * splits), dim3(256), shm, s, a);
     MMTG_LAUNCH_CHECK("wgrad_group");
     return MMTG_OK;
