@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MMTG_ABI_VERSION 2
+#define MMTG_ABI_VERSION 3
 
 /* The library is built with -fvisibility=hidden: only the entry points below are exported. */
 #define MMTG_API __attribute__((visibility("default")))
@@ -354,13 +354,16 @@ MMTG_API int mmtg_decode_attn(int dtype, const void* qkv, void* kcache, void* vc
 MMTG_API int mmtg_decode_attn_split(int dtype, const float* part, int splits, const float* bias, void* kcache, void* vcache,
                            const int* keep, long ldkeep, const int* pos_ptr, void* out, int B, int nH, int dh, int Tmax,
                            void* stream);
+/* pos_next (optional, must not alias pos_ptr): receives *pos_ptr + 1 -- the decoder keeps the position in a PAIR of slots
+ * and alternates them step by step (every kernel of a step reads one slot, this last kernel writes the other), which removes
+ * the one-thread mmtg_decode_advance launch from the captured step.                                                        */
 MMTG_API int mmtg_decode_select(const float* logits, long ldl, int V, long long* seq, long ldseq, const int* pos_ptr,
-                       int P, int sent, float temperature, float rep_penalty, int B, void* stream);
+                       int P, int sent, float temperature, float rep_penalty, int B, int* pos_next, void* stream);
 /* decode_select with the stochastic selection above; the draw of position pos uses uniforms[pos * ldu + b]
  * (a [positions, ldu] device array filled before the graph is replayed).                                    */
 MMTG_API int mmtg_decode_sample(const float* logits, long ldl, int V, long long* seq, long ldseq, const int* pos_ptr,
                        int P, int sent, float temperature, float rep_penalty, int top_k, float top_p,
-                       const float* uniforms, long ldu, int B, void* stream);
+                       const float* uniforms, long ldu, int B, int* pos_next, void* stream);
 MMTG_API int mmtg_decode_advance(int* pos_ptr, void* stream);
 
 #ifdef __cplusplus

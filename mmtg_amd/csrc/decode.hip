@@ -22,21 +22,47 @@ __device__ __forceinline__ void count_ids(unsigned* cnt, int V, const long long*
     __syncthreads();
 }
 
-// this thread's share of the processed-logit arg-max (lowest index wins ties)
+// one logit through the reference's processor (generate.py:127-136), folded into the running arg-max (lowest index wins ties)
+__device__ __forceinline__ void scan_one(float x, int v, const unsigned* cnt, float temperature, float rep_penalty, float& best, int& besti) {
+    if (v != 0 && v != 102) {
+        const int c = (cnt[v >> 1] >> (16 * (v & 1))) & 0xFFFF;
+        for (int i = 0; i < c; ++i) x = x / rep_penalty;
+    }
+    x = x / temperature;
+    if (v == 1 || v == 2 || v == 100 || v == 102) x = -INFINITY;
+    if (x > best || (x == best && v < besti)) { best = x; besti = v; }
+}
+// this thread's share of the processed-logit arg-max.  16-byte aligned rows are read as float4 with all of a pass's loads
+// (up to 16 per thread = 16 K logits per block) requested before the first is used: one memory round trip per row instead of a
+// dependent 4-byte load per 256 logits (round 3: 21.5 -> see profiles/ us for 256 rows of V = 13317).
 __device__ __forceinline__ void scan_row(const float* row, int V, const unsigned* cnt, float temperature, float rep_penalty,
                                          int tid, float& best, int& besti) {
     best = -INFINITY;
     besti = 0x7fffffff;
-    for (int v = tid; v < V; v += 256) {
-        float x = row[v];
-        if (v != 0 && v != 102) {
-            const int c = (cnt[v >> 1] >> (16 * (v & 1))) & 0xFFFF;
-            for (int i = 0; i < c; ++i) x = x / rep_penalty;
+    int done = 0;
+    if ((reinterpret_cast<uintptr_t>(row) & 15) == 0) {
+        constexpr int UN = 16;
+        const int nvec = V >> 2;
+        const f32x4* row4 = reinterpret_cast<const f32x4*>(row);
+        for (int base = 0; base < nvec; base += 256 * UN) {
+            f32x4 r[UN];
+#pragma unroll
+            for (int i = 0; i < UN; ++i) {
+                const int idx = base + i * 256 + tid;
+                r[i] = idx < nvec ? row4[idx] : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int i = 0; i < UN; ++i) {
+                const int idx = base + i * 256 + tid;
+                if (idx < nvec) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) scan_one(r[i][e], 4 * idx + e, cnt, temperature, rep_penalty, best, besti);
+                }
+            }
         }
-        x = x / temperature;
-        if (v == 1 || v == 2 || v == 100 || v == 102) x = -INFINITY;
-        if (x > best || (x == best && v < besti)) { best = x; besti = v; }
+        done = nvec << 2;
     }
+    for (int v = done + tid; v < V; v += 256) scan_one(row[v], v, cnt, temperature, rep_penalty, best, besti);
 }
 
 __global__ __launch_bounds__(256) void logits_argmax_kernel(const float* __restrict__ logits, long ldl, int V,
@@ -351,48 +377,100 @@ __global__ __launch_bounds__(256) void decode_embed_add_kernel(const T* __restri
 // One wave per (b, head): append this token's K/V to the cache, then attend over keys 0..pos.
 // Cache layout [B, nH, Tmax, 64].  Both passes over the cache use 16-byte vectors: a key's 64 channels are spread over
 // OCT = 8 (bf16) / 16 (f32) adjacent lanes, so one wave-instruction reads 64 / OCT whole cache rows -- 1 KB, fully
-// coalesced -- instead of one row per lane (scores) or one row per iteration (values): 18 dependent loads for a
-// 143-key prefix instead of 143.  Scores: partial dot products folded across the OCT lanes; values: each lane
-// accumulates its channel octet over its keys, the key groups are folded at the end.  Fixed summation order.
+// coalesced.  Scores: partial dot products folded across the OCT lanes; values: each lane accumulates its channel octet
+// over its keys, the key groups are folded at the end.  Fixed summation order (ascending key per lane).
+// Round 3: the K AND V rows of the first UN0 * KPI keys are requested at the very top, before the token's own q / k / v are
+// even assembled from the c_attn slabs -- they depend on nothing this kernel computes -- so a step with a short prefix costs one
+// memory round trip instead of three dependent ones (slabs -> scores -> values).  Branch-free: rows at or past `pos` are
+// requested from the last valid row and replaced afterwards (key == pos: the token's own row, held in LDS exactly as stored).
 template <typename T>
 __global__ __launch_bounds__(64) void decode_attn_kernel(const T* __restrict__ qkv, T* __restrict__ kc, T* __restrict__ vc,
         const int* __restrict__ keep, long ldkeep, const int* __restrict__ pos_ptr, T* __restrict__ out,
         int nH, int Tmax, const float* __restrict__ part, int splits, long slab, const float* __restrict__ bias) {
     typedef typename Vec16<T>::type V;
     constexpr int EPL = Vec16<T>::N, OCT = 64 / EPL, KPI = 64 / OCT;      // elements per lane, lanes per key, keys per instruction
+    constexpr int UN = 16, UN0 = 12;
     __shared__ float sp[1024];
+    __shared__ int skeep[1024];
     __shared__ float sq[64];
+    __shared__ __attribute__((aligned(16))) T sk[64];
+    __shared__ __attribute__((aligned(16))) T sv[64];
     const int h = blockIdx.x, b = blockIdx.y, lane = threadIdx.x, pos = *pos_ptr;
     const int D = nH * 64;
     const T* row = qkv + (long)b * 3 * D + h * 64;
     T* kbase = kc + (((long)b * nH + h) * Tmax) * 64;
     T* vbase = vc + (((long)b * nH + h) * Tmax) * 64;
-    if (part) {
-        // the c_attn product arrives as split-K slabs (MMTG_EPI_SPLIT): sum them in order, add the bias
-        // and round to the storage type exactly as mmtg_splitk_finish would (saves that launch)
-        const float* pr = part + (long)b * 3 * D + h * 64 + lane;
-        float q = 0.f, k = 0.f, v = 0.f;
-        for (int s_ = 0; s_ < splits; ++s_) { q += pr[s_ * slab]; k += pr[s_ * slab + D]; v += pr[s_ * slab + 2 * D]; }
-        q += bias[h * 64 + lane]; k += bias[D + h * 64 + lane]; v += bias[2 * D + h * 64 + lane];
-        sq[lane] = (float)(T)q * 0.125f;
-        kbase[(long)pos * 64 + lane] = (T)k;
-        vbase[(long)pos * 64 + lane] = (T)v;
-    } else {
-        sq[lane] = (float)row[lane] * 0.125f;
-        kbase[(long)pos * 64 + lane] = row[D + lane];
-        vbase[(long)pos * 64 + lane] = row[2 * D + lane];
-    }
-    __syncthreads();
     const int nkeys = pos + 1;
     const int oc = lane % OCT, kg = lane / OCT;
+    const int last = pos > 0 ? pos - 1 : 0;
+    V kv0[UN0], vv0[UN0];
+#pragma unroll
+    for (int u = 0; u < UN0; ++u) {
+        const int key = u * KPI + kg, kr = key < pos ? key : last;
+        kv0[u] = *reinterpret_cast<const V*>(kbase + (long)kr * 64 + oc * EPL);
+        vv0[u] = *reinterpret_cast<const V*>(vbase + (long)kr * 64 + oc * EPL);
+    }
+    // the key-padding flags of the whole prefix in one coalesced pass, into LDS (round 3: the score loop used to read keep[]
+    // from global memory key group by key group -- up to 16 DEPENDENT 4-byte loads, each a full memory round trip)
+    // (the first 256 flags as four independent loads, stored after the slab sums; longer prefixes: a plain loop)
+    int kp[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) kp[i] = keep[(long)b * ldkeep + min(lane + 64 * i, pos)];
+    asm volatile("" ::: "memory");      // compiler barrier: the requests above are ISSUED here (nothing waits for them yet)
+    if (part) {
+        // the c_attn product arrives as split-K slabs (MMTG_EPI_SPLIT): sum them in order, add the bias
+        // and round to the storage type exactly as mmtg_splitk_finish would (saves that launch); up to four slabs are
+        // requested together (one round trip), more in a plain loop
+        const float* pr = part + (long)b * 3 * D + h * 64 + lane;
+        float q = 0.f, k = 0.f, v = 0.f;
+        const float bq = bias[h * 64 + lane], bk = bias[D + h * 64 + lane], bv = bias[2 * D + h * 64 + lane];
+        float pq[4], pk[4], pv[4];
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) {
+            const long o = (long)(s_ < splits ? s_ : 0) * slab;
+            pq[s_] = pr[o]; pk[s_] = pr[o + D]; pv[s_] = pr[o + 2 * D];
+        }
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_)
+            if (s_ < splits) { q += pq[s_]; k += pk[s_]; v += pv[s_]; }
+        for (int s_ = 4; s_ < splits; ++s_) { q += pr[s_ * slab]; k += pr[s_ * slab + D]; v += pr[s_ * slab + 2 * D]; }
+        q += bq; k += bk; v += bv;
+        sq[lane] = (float)(T)q * 0.125f;
+        sk[lane] = (T)k;
+        sv[lane] = (T)v;
+    } else {
+        sq[lane] = (float)row[lane] * 0.125f;
+        sk[lane] = row[D + lane];
+        sv[lane] = row[2 * D + lane];
+    }
+    kbase[(long)pos * 64 + lane] = sk[lane];
+    vbase[(long)pos * 64 + lane] = sv[lane];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) skeep[lane + 64 * i] = kp[i];
+    for (int key = lane + 256; key < nkeys; key += 64) skeep[key] = keep[(long)b * ldkeep + key];
+    __syncthreads();
     float qv[EPL];
 #pragma unroll
     for (int e = 0; e < EPL; ++e) qv[e] = sq[oc * EPL + e];
-    // ---- scores: UN independent 16-byte loads per lane are requested before the first is used (a wave keeps up to
-    //      UN KB of the cache in flight: the pass is bound by HBM latency, not bandwidth, at 12 waves per CU)
-    constexpr int UN = 16;
+    const V knew = *reinterpret_cast<const V*>(sk + oc * EPL), vnew = *reinterpret_cast<const V*>(sv + oc * EPL);
+#pragma unroll
+    for (int u = 0; u < UN0; ++u) {
+        const int key = u * KPI + kg;
+        const bool isnew = key == pos;
+        float a = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            a += qv[e] * (float)(isnew ? knew[e] : kv0[u][e]);
+            vv0[u][e] = isnew ? vnew[e] : vv0[u][e];
+        }
+#pragma unroll
+        for (int o = 1; o < OCT; o <<= 1) a += __shfl_xor(a, o, 64);
+        if (oc == 0 && key < nkeys) sp[key] = skeep[key] ? a : -INFINITY;
+    }
+    // ---- scores of the later chunks: UN independent 16-byte loads per lane are requested before the first is used
+    //      (the token's own row was stored above and is published by the barrier: re-read from the cache like any other)
 #pragma unroll 1
-    for (int k0 = 0; k0 < nkeys; k0 += UN * KPI) {
+    for (int k0 = UN0 * KPI; k0 < nkeys; k0 += UN * KPI) {
         V kv[UN];
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
@@ -407,7 +485,7 @@ __global__ __launch_bounds__(64) void decode_attn_kernel(const T* __restrict__ q
             for (int e = 0; e < EPL; ++e) a += qv[e] * (float)kv[u][e];
 #pragma unroll
             for (int o = 1; o < OCT; o <<= 1) a += __shfl_xor(a, o, 64);
-            if (oc == 0 && key < nkeys) sp[key] = keep[(long)b * ldkeep + key] ? a : -INFINITY;
+            if (oc == 0 && key < nkeys) sp[key] = skeep[key] ? a : -INFINITY;
         }
     }
     __syncthreads();
@@ -424,12 +502,19 @@ __global__ __launch_bounds__(64) void decode_attn_kernel(const T* __restrict__ q
     }
     sum = wave_sum(sum);
     __syncthreads();
-    // ---- values
+    // ---- values: the first chunk from the rows already in registers, later chunks from the cache
     float acc[EPL];
 #pragma unroll
     for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int u = 0; u < UN0; ++u) {
+        const int key = u * KPI + kg;
+        const float pp = key < nkeys ? sp[key] : 0.f;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) acc[e] += pp * (float)vv0[u][e];
+    }
 #pragma unroll 1
-    for (int k0 = 0; k0 < nkeys; k0 += UN * KPI) {
+    for (int k0 = UN0 * KPI; k0 < nkeys; k0 += UN * KPI) {
         V vv[UN];
         float pp[UN];
 #pragma unroll
@@ -460,11 +545,14 @@ __global__ __launch_bounds__(64) void decode_attn_kernel(const T* __restrict__ q
 __global__ __launch_bounds__(256) void decode_select_kernel(const float* __restrict__ logits, long ldl, int V,
         long long* __restrict__ seq, long ldseq, const int* __restrict__ pos_ptr, int P, int sent,
         float temperature, float rep_penalty, int have_logits, int top_k, float top_p,
-        const float* __restrict__ uniforms, long ldu) {
+        const float* __restrict__ uniforms, long ldu, int* __restrict__ pos_next) {
     extern __shared__ unsigned cnt[];
     __shared__ float sval[4];
     __shared__ int sidx[4];
     const int b = blockIdx.x, tid = threadIdx.x, pos = *pos_ptr;
+    // the step's last kernel also publishes the next position -- into the OTHER slot of the decoder's position pair (every
+    // kernel of this step reads *pos_ptr; nobody reads *pos_next before the next step), which replaces a one-thread launch
+    if (pos_next && b == 0 && tid == 0) *pos_next = pos + 1;
     const int j = pos + 1 - P;                 // lyric index of the token to append
     if (j < 1) return;                         // still inside the prompt / the initial [#START#]
     long long* gen = seq + (long)b * ldseq + P;
@@ -572,24 +660,25 @@ extern "C" int mmtg_decode_attn_split(int dtype, const float* part, int splits, 
 
 static int decode_select_launch(const float* logits, long ldl, int V, long long* seq, long ldseq, const int* pos_ptr,
                                 int P, int sent, float temperature, float rep_penalty, int top_k, float top_p,
-                                const float* uniforms, long ldu, int B, void* stream);
+                                const float* uniforms, long ldu, int B, int* pos_next, void* stream);
 
 extern "C" int mmtg_decode_select(const float* logits, long ldl, int V, long long* seq, long ldseq, const int* pos_ptr,
-                                  int P, int sent, float temperature, float rep_penalty, int B, void* stream) {
-    return decode_select_launch(logits, ldl, V, seq, ldseq, pos_ptr, P, sent, temperature, rep_penalty, 1, 0.f, nullptr, 0, B, stream);
+                                  int P, int sent, float temperature, float rep_penalty, int B, int* pos_next, void* stream) {
+    return decode_select_launch(logits, ldl, V, seq, ldseq, pos_ptr, P, sent, temperature, rep_penalty, 1, 0.f, nullptr, 0, B, pos_next, stream);
 }
 
 extern "C" int mmtg_decode_sample(const float* logits, long ldl, int V, long long* seq, long ldseq, const int* pos_ptr,
                                   int P, int sent, float temperature, float rep_penalty, int top_k, float top_p,
-                                  const float* uniforms, long ldu, int B, void* stream) {
+                                  const float* uniforms, long ldu, int B, int* pos_next, void* stream) {
     MMTG_REQUIRE(uniforms && ldu >= B && top_k >= 0 && top_p >= 0.f, "decode_sample: uniforms [positions, ldu >= B], top_k >= 0, top_p >= 0");
-    return decode_select_launch(logits, ldl, V, seq, ldseq, pos_ptr, P, sent, temperature, rep_penalty, top_k, top_p, uniforms, ldu, B, stream);
+    return decode_select_launch(logits, ldl, V, seq, ldseq, pos_ptr, P, sent, temperature, rep_penalty, top_k, top_p, uniforms, ldu, B, pos_next, stream);
 }
 
 static int decode_select_launch(const float* logits, long ldl, int V, long long* seq, long ldseq, const int* pos_ptr,
                                 int P, int sent, float temperature, float rep_penalty, int top_k, float top_p,
-                                const float* uniforms, long ldu, int B, void* stream) {
+                                const float* uniforms, long ldu, int B, int* pos_next, void* stream) {
     MMTG_REQUIRE(seq && pos_ptr && B > 0 && sent > 1, "decode_select: bad args");
+    MMTG_REQUIRE(pos_next != pos_ptr, "decode_select: pos_next must not alias pos_ptr (blocks read the position while block 0 writes the next)");
     MMTG_REQUIRE(!logits || (V > 0 && ldl >= V && temperature > 0.f && rep_penalty > 0.f), "decode_select: bad logits args");
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(MMTG_PROF_DECODE, s, 4.0 * B * V, 4.0 * B * V);
@@ -603,7 +692,7 @@ static int decode_select_launch(const float* logits, long ldl, int V, long long*
         attr_done = true;
     }
     hipLaunchKernelGGL(decode_select_kernel, dim3(B), dim3(256), shm, s, logits, ldl, V, seq, ldseq,
-                       pos_ptr, P, sent, temperature, rep_penalty, logits != nullptr, top_k, top_p, logits ? uniforms : nullptr, ldu);
+                       pos_ptr, P, sent, temperature, rep_penalty, logits != nullptr, top_k, top_p, logits ? uniforms : nullptr, ldu, pos_next);
     MMTG_LAUNCH_CHECK("decode_select");
     return MMTG_OK;
 }

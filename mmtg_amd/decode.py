@@ -51,7 +51,9 @@ class GreedyDecoder:
         self.lanes = lanes
         if _parent is None:
             self.seq = torch.zeros(B, self.Tmax, dtype=torch.long, device=dev)
-            self.pos_all = torch.zeros(lanes, dtype=torch.int32, device=dev)
+            # the position lives in a PAIR of slots per lane: the kernels of step k read slot k % 2, the step's last kernel
+            # (decode_select) writes k + 1 into the other one -- no separate "advance" launch, two captured graphs per setting
+            self.pos_all = torch.zeros(2, lanes, dtype=torch.int32, device=dev)
             self.keep = torch.zeros(B, self.Tmax, dtype=torch.int32, device=dev)
             self.types = torch.zeros(B, dtype=torch.long, device=dev)
             self.tpw_type = torch.zeros(B, sh.P, dtype=torch.long, device=dev)
@@ -59,7 +61,7 @@ class GreedyDecoder:
             self.c = torch.zeros(B * sh.S, E, dtype=tdt, device=dev)
             self.kc = torch.zeros(sh.L, B, sh.nH, self.Tmax, 64, dtype=tdt, device=dev)
             self.vc = torch.zeros_like(self.kc)
-            self.pos = self.pos_all[0:1]
+            self.pos_pair = (self.pos_all[0, 0:1], self.pos_all[1, 0:1])
         else:       # a lane: row block [_lane*B, (_lane+1)*B) of the parent's state, private scratch
             lo, hi = _lane * B, (_lane + 1) * B
             self.seq, self.keep, self.types = _parent.seq[lo:hi], _parent.keep[lo:hi], _parent.types[lo:hi]
@@ -67,7 +69,7 @@ class GreedyDecoder:
             self.c = _parent.c[lo * sh.S:hi * sh.S]
             self.kc = [_parent.kc[l, lo:hi] for l in range(sh.L)]
             self.vc = [_parent.vc[l, lo:hi] for l in range(sh.L)]
-            self.pos = _parent.pos_all[_lane:_lane + 1]
+            self.pos_pair = (_parent.pos_all[0, _lane:_lane + 1], _parent.pos_all[1, _lane:_lane + 1])
         self.splits = tuple(int(x) for x in os.environ.get("MMTG_DECODE_SPLITS", "2,4,1,8").split(","))
         # (measured at batch 256, us per token step: 2,3,2,6 -> 1020; 4,6,3,12 -> 1248; 1,1,1,2 -> 1183; unsplit 1264;
         #  with the one-slice c_fc + fused GELU: 2,3,1,8 -> 940, 2,3,1,6 -> 943, 1,3,1,8 -> 963, 2,3,1,12 -> 1003)
@@ -88,6 +90,7 @@ class GreedyDecoder:
             if self.fast:
                 slab = max(self.splits[0] * 3 * D, self.splits[1] * D, self.splits[2] * 4 * D, self.splits[3] * D)
                 self.part = torch.empty(slab * B, dtype=torch.float32, device=dev)
+        self.pos, self.pos_next = self.pos_pair
         self.uniforms = None
         self.graphs = {}
         self.params = None
@@ -98,7 +101,8 @@ class GreedyDecoder:
         self.eng._fwd(x, wkey, out, self.B, "conv1d", **kw)
 
     # ------------------------------------------------------------------ one token
-    def _step(self, with_head):
+    def _step(self, with_head, parity=0):
+        self.pos, self.pos_next = self.pos_pair[parity], self.pos_pair[1 - parity]
         if self.children:
             # fork: lane 0 stays on the current stream, the others run on side streams; join before the step ends
             cur = torch.cuda.current_stream()
@@ -107,10 +111,10 @@ class GreedyDecoder:
             for i, ch in enumerate(self.children):
                 ch.params = self.params
                 if i == 0:
-                    ch._step(with_head)
+                    ch._step(with_head, parity)
                 else:
                     with torch.cuda.stream(self.side[i - 1]):
-                        ch._step(with_head)
+                        ch._step(with_head, parity)
             for st in self.side:
                 cur.wait_stream(st)
             return
@@ -135,13 +139,13 @@ class GreedyDecoder:
             Vp = eng.layout.Vpad
             hip.gemm(self.a, eng.Wp("wte"), self.logits, B, Vp, D, transB=True, ldb=D, out_f32=True)
             if top_k == 1 and top_p == 0.0:
-                hip.decode_select(self.logits, Vp, min(sh.V, 13317), self.seq, self.pos, sh.P, sent, temperature, rep, B)
+                hip.decode_select(self.logits, Vp, min(sh.V, 13317), self.seq, self.pos, sh.P, sent, temperature, rep, B,
+                                  pos_next=self.pos_next)
             else:        # stochastic: the draw of each position reads its row of the pre-filled uniforms
                 hip.decode_sample(self.logits, Vp, min(sh.V, 13317), self.seq, self.pos, sh.P, sent, temperature, rep,
-                                  top_k, top_p, self.uniforms, B)
+                                  top_k, top_p, self.uniforms, B, pos_next=self.pos_next)
         else:
-            hip.decode_select(None, 0, 0, self.seq, self.pos, sh.P, sent, temperature, rep, B)
-        hip.decode_advance(self.pos)
+            hip.decode_select(None, 0, 0, self.seq, self.pos, sh.P, sent, temperature, rep, B, pos_next=self.pos_next)
 
     def _layers_plain(self, hcur, hnext, with_head):
         """One GPT-2 block per layer with the training-side kernels (fp32 parity mode)."""
@@ -206,21 +210,21 @@ class GreedyDecoder:
             self._split(self.g, p + "mlp.c_proj.weight", hcur, s2, eng.P(p + "mlp.c_proj.bias"),
                         epi=hip.EPI_RESID, aux=hnext, ldaux=D, **ln)
 
-    def _run_step(self, with_head):
+    def _run_step(self, with_head, parity):
         if not self.use_graph:
-            self._step(with_head)
+            self._step(with_head, parity)
             return
-        key = (with_head, self.params)
+        key = (with_head, parity, self.params)
         g = self.graphs.get(key)
         if g is None:
             # warm-up outside capture (lazy LDS-attribute / module loading), then rewind the position
             saved = (self.pos_all.clone(), self.seq.clone(), self.keep.clone())
-            self._step(with_head)
+            self._step(with_head, parity)
             torch.cuda.synchronize()
             self.pos_all.copy_(saved[0]); self.seq.copy_(saved[1]); self.keep.copy_(saved[2])
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                self._step(with_head)
+                self._step(with_head, parity)
             self.graphs[key] = g
             self.pos_all.copy_(saved[0]); self.seq.copy_(saved[1]); self.keep.copy_(saved[2])
         g.replay()
@@ -278,7 +282,7 @@ class GreedyDecoder:
             for pos in range(n_steps):
                 j = pos + 1 - sh.P                                  # lyric index appended after this step
                 forced = j < 1 or (j > 1 and (j + 1) % (sh.msl + 2) in (0, 1))
-                self._run_step(with_head=not forced)
+                self._run_step(with_head=not forced, parity=pos & 1)
         finally:
             self.use_graph = saved_mode
         return self.seq[:, sh.P:sh.P + 1 + length].clone()

@@ -13,7 +13,7 @@ import os
 import torch
 
 F32, BF16 = 0, 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 EPI_NONE, EPI_GELU, EPI_TANH, EPI_RESID, EPI_DGELU, EPI_DTANH, EPI_ATOMIC, EPI_ROWDOT = range(8)
 GEMM_NO_TR, GEMM_REGSTAGE, GEMM_SKINNY, GEMM_NO_SKINNY, GEMM_WIDE, GEMM_NO_WIDE = 1, 2, 4, 8, 16, 32
 GEMM_PERSIST, GEMM_NO_PERSIST, GEMM_ROW_ORDER, GEMM_OCC4, GEMM_NO_OCC4, GEMM_COL_BLOCK, GEMM_P256, GEMM_NO_P8, GEMM_P8 = 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384
@@ -73,8 +73,8 @@ _SIGS = {
     "mmtg_decode_attn": ([_i, _vp, _vp, _vp, _vp, _l, _vp, _vp, _i, _i, _i, _i, _vp], _i),
     "mmtg_decode_attn_split": ([_i, _vp, _i, _vp, _vp, _vp, _vp, _l, _vp, _vp, _i, _i, _i, _i, _vp], _i),
     "mmtg_logits_process_sample": ([_vp, _l, _i, _vp, _l, _vp, _f, _f, _i, _f, _vp, _vp, _vp, _i, _vp], _i),
-    "mmtg_decode_sample": ([_vp, _l, _i, _vp, _l, _vp, _i, _i, _f, _f, _i, _f, _vp, _l, _i, _vp], _i),
-    "mmtg_decode_select": ([_vp, _l, _i, _vp, _l, _vp, _i, _i, _f, _f, _i, _vp], _i),
+    "mmtg_decode_sample": ([_vp, _l, _i, _vp, _l, _vp, _i, _i, _f, _f, _i, _f, _vp, _l, _i, _vp, _vp], _i),
+    "mmtg_decode_select": ([_vp, _l, _i, _vp, _l, _vp, _i, _i, _f, _f, _i, _vp, _vp], _i),
     "mmtg_decode_advance": ([_vp, _vp], _i),
 }
 
@@ -452,15 +452,15 @@ def decode_attn_split(part, splits, bias, kcache, vcache, keep, pos, out, B, nH,
                                         _p(pos), _p(out), B, nH, dh, Tmax, _stream()), "decode_attn_split")
 
 
-def decode_select(logits, ldl, V, seq, pos, P, sent, temperature, rep_penalty, B):
+def decode_select(logits, ldl, V, seq, pos, P, sent, temperature, rep_penalty, B, pos_next=None):
     _check(lib().mmtg_decode_select(_p(logits), ldl, V, _p(seq), seq.stride(0), _p(pos), P, sent, float(temperature),
-                                    float(rep_penalty), B, _stream()), "decode_select")
+                                    float(rep_penalty), B, _p(pos_next), _stream()), "decode_select")
 
 
-def decode_sample(logits, ldl, V, seq, pos, P, sent, temperature, rep_penalty, top_k, top_p, uniforms, B):
+def decode_sample(logits, ldl, V, seq, pos, P, sent, temperature, rep_penalty, top_k, top_p, uniforms, B, pos_next=None):
     _check(lib().mmtg_decode_sample(_p(logits), ldl, V, _p(seq), seq.stride(0), _p(pos), P, sent, float(temperature),
-                                    float(rep_penalty), int(top_k), float(top_p), _p(uniforms), uniforms.stride(0), B, _stream()),
-           "decode_sample")
+                                    float(rep_penalty), int(top_k), float(top_p), _p(uniforms), uniforms.stride(0), B, _p(pos_next),
+                                    _stream()), "decode_sample")
 
 
 def decode_advance(pos):
