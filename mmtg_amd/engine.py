@@ -205,6 +205,8 @@ _WTE_T = _os.environ.get("MMTG_NO_WTE_T") is None      # [D, Vpad] copy of wte f
 _P8T = _os.environ.get("MMTG_GEMM_P8T", "0") != "0"      # eight-phase K-strided kernel for the slab weight gradients (opt-in: measured slower in situ)
 _WGRAD_GROUP = _os.environ.get("MMTG_WGRAD_GROUP", "1") != "0"   # one grouped launch per GPT-2 block for its four weight gradients (A/B switch)
 _WGRAD_GROUP_SPLITS = int(_os.environ.get("MMTG_WGRAD_GROUP_SPLITS", "0"))    # 0 = the one-round rule below
+_LMHEAD_GROUP = _os.environ.get("MMTG_LMHEAD_GROUP", "1") != "0"      # the tied embedding's weight gradient through the grouped kernel (A/B switch)
+_LMHEAD_GROUP_SPLITS = int(_os.environ.get("MMTG_LMHEAD_GROUP_SPLITS", "0"))
 _WGRAD_GROUP_CFG = int(_os.environ.get("MMTG_WGRAD_GROUP_CFG", "0"))          # 0: 128x128 tiles, four workgroups per CU; 1: 256x256 eight-phase
 
 
@@ -801,8 +803,22 @@ class Engine:
         else:
             hip.gemm(dlogits, self.Wp("wte"), dhf, M, D, Vp, transB=False, ldb=D)
         # (Vpad rows: the pad columns of dlogits are zero, so the pad rows of the pack receive +0)
-        hip.gemm(dlogits, a["hf"], self.Gp("wte"), Vp, D, M, transA=True, transB=False, lda=Vp, ldb=D, ldc=D,
-                 epi=hip.EPI_ATOMIC, splits=_wgrad_splits(Vp, D, M, self.dtype == hip.BF16))
+        if _WGRAD_GROUP and _LMHEAD_GROUP and self.dtype == hip.BF16 and M >= 256 and D % 8 == 0 and Vp % 8 == 0:
+            # the tied embedding's gradient through the grouped kernel too: no fp32 atomics (bit-reproducible), and the
+            # gradient is WRITTEN, so the lazy zero_grad can skip its 41 MB (the type-embedding rows are added later)
+            tiles = hip.wgrad_group_sizes(((Vp, D),), 1, 0)[0]
+            hs = _LMHEAD_GROUP_SPLITS or _group_splits(tiles, M)
+            _, nws, ncnt = hip.wgrad_group_sizes(((Vp, D),), hs, 0)
+            hws = self.buf("wgrad_group_ws", (nws,), torch.float32) if hs > 1 else None
+            hcnt = self.ws.get(("wgrad_group_cnt", torch.int32))
+            if hcnt is None or hcnt.numel() < ncnt:
+                hcnt = self.ws[("wgrad_group_cnt", torch.int32)] = torch.zeros(ncnt, device=self.dev, dtype=torch.int32)
+            hip.wgrad_group([(dlogits, a["hf"], self.Gp("wte"), Vp, D, Vp, D, D)], M, hs, hws, hcnt, accumulate=not self.wgrad_overwrite)
+            if self.wgrad_overwrite and self._ow_rec is not None:
+                self._ow_rec[1].append((self.layout.pack_range["wte"][0], Vp * D))
+        else:
+            hip.gemm(dlogits, a["hf"], self.Gp("wte"), Vp, D, M, transA=True, transB=False, lda=Vp, ldb=D, ldc=D,
+                     epi=hip.EPI_ATOMIC, splits=_wgrad_splits(Vp, D, M, self.dtype == hip.BF16))
         # Every LayerNorm backward on the residual stream also emits, in the same pass, the
         # dropout-masked gradient entering the previous residual branch and that branch's bias
         # gradient (column sum) -- see mmtg_layernorm_bwd.
