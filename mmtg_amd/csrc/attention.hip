@@ -554,8 +554,18 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(const T* __restrict__
 // probability round((1 - p) 2^12) / 2^12 -- about 2 vector instructions per decision instead of a 32-bit hash each,
 // and the three kernels (forward, dK/dV, dQ) rebuild identical matrices.  (The tiled kernels hash per element; a model
 // uses one family throughout.)
-constexpr int SM_MAXT = 256;
+constexpr int SM_MAXT = 512;      // whole-head kernels: MT = 256 (8 waves, two workgroups per CU) or 512 (16 waves, one per CU; round 3)
 constexpr float LOG2E = 1.4426950408889634f;
+
+// Keep-bit matrix addressing.  MT = 256: dense, 8 words per query row.  MT = 512: only the words at or below the diagonal are
+// stored, row-major (band k = rows 32 k .. 32 k + 31 has k + 1 words per row: 17 KB instead of 32 KB -- K / V images of 2 x 64 KB
+// leave no room for the dense matrix).  Rows of a band are (k + 1) words apart; a read one word past a row's last word lands in
+// the next row (or the two pad words at the end) and is only ever combined with probabilities that are already zero.
+template <int MT> __device__ __forceinline__ int mask_row_base(int row) {
+    if constexpr (MT == 256) return row * 8;
+    else { const int k = row >> 5; return 16 * k * (k + 1) + (row - 32 * k) * (k + 1); }
+}
+template <int MT> constexpr int mask_words() { return MT == 256 ? 256 * 8 : 16 * 16 * 17 + 2; }
 
 __device__ __forceinline__ bf16x8 ld_row(const char* img, int row, int ks, int g) {
     return *reinterpret_cast<const bf16x8*>(img + off_ks<bf16>(row, ks * 4 + g));
@@ -566,32 +576,34 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t rows_rsrc(const bf16* p, long 
 // One chunk (64 rows) of both images = two requests per wave.  Chunk indices beyond the tensor's last chunk re-target
 // an existing chunk (same source, same destination -- harmless), so the number of requests is a compile-time constant
 // and the compiler's own waits for the few plain loads stay counted ones.
-template <int NW = 8>
+// (a chunk = MT / 4 rows = MT / 32 one-KB blocks per image: 64 rows for MT = 256, 128 for MT = 512; NW waves share them)
+template <int NW = 8, int MT = 256>
 __device__ __forceinline__ void dma_issue_chunk(char* imgA, __amdgpu_buffer_rsrc_t ra, long lda, char* imgB, __amdgpu_buffer_rsrc_t rb,
                                                 long ldb, int c4, int nchunk, int wave, int lane) {
     const int c = c4 < nchunk ? c4 : c4 % nchunk;
 #pragma unroll
-    for (int i = 0; i < 8 / NW; ++i) {
-        const int blk = 8 * c + wave + NW * i, row = blk * 8 + (lane >> 3);
+    for (int i = 0; i < (MT / 32) / NW; ++i) {
+        const int blk = (MT / 32) * c + wave + NW * i, row = blk * 8 + (lane >> 3);
         const int ch = (lane & 7) ^ vswz(row);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, LDS_PTR(void, imgA + blk * 1024), 16, (int)(((long)row * lda + ch * 8) * 2), 0, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, LDS_PTR(void, imgB + blk * 1024), 16, (int)(((long)row * ldb + ch * 8) * 2), 0, 0, 0);
     }
 }
 // 256 dwords (one per row), element i at src[i * stride]; wave w brings rows 64 (w & 3) .. (waves 4-7 repeat 0-3)
+template <int MT = 256>
 __device__ __forceinline__ void dma_issue_scalars(void* dst, const void* src, int stride, int nvalid, int wave, int lane) {
     const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(src), 0, (int)(((long)(nvalid - 1) * stride + 1) * 4), 0x00020000);
-    const int i = 64 * (wave & 3) + lane;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, LDS_PTR(void, (char*)dst + 256 * (wave & 3)), 4, i * stride * 4, 0, 0, 0);
+    const int ws = wave % (MT / 64), i = 64 * ws + lane;        // MT dwords, one per row; the upper waves repeat the lower ones
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, LDS_PTR(void, (char*)dst + 256 * ws), 4, i * stride * 4, 0, 0, 0);
 }
 // Streaming schedule shared by the three kernels: chunks 0 and 1 are requested in the prologue, chunk c + 2 right
 // after the barrier that publishes chunk c.  Before that barrier a wave waits until only its two youngest requests
 // (chunk c + 1) are outstanding -- or none, for the last of the four.
-template <int NW = 8>
+template <int NW = 8, int MT = 256>
 __device__ __forceinline__ void dma_wait_chunk(int c) {
     if (c >= 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (NW == 8) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if ((MT / 32) / NW == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");       // one block per image and chunk per wave
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                              // two (the half-wave dK / dV builds)
 }
 // workgroup barrier WITHOUT the release fence of __syncthreads(): the fence would drain every outstanding LDS-DMA
 // request (vmcnt(0)) and serialise the streamed chunks; LDS stores of this wave are drained explicitly
@@ -601,23 +613,23 @@ __device__ __forceinline__ void raw_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // Only words at or below the diagonal of rows < Tn are ever read (a word is one work item: compacted index i ->
 // row-major enumeration of the pairs (row, w <= row / 32), 4 x 32 rows + 8 ... per 32-row band).
 constexpr int MASK_BITS = 12;          // keep probability in units of 2^-12
-template <int NTHR = 512>
+template <int NTHR = 512, int MT = 256>
 __device__ __forceinline__ void gen_keep_mask(uint32_t* sMask, uint32_t bh, int Tn, uint32_t seed, uint32_t keepq, int tid) {
     // band k (rows 32 k .. 32 k + 31) has k + 1 words per row: items before band k = 32 * k (k + 1) / 2
     const int nband = (Tn + 31) >> 5, total = 16 * nband * (nband + 1);
 #pragma unroll 1
     for (int i = tid; i < total; i += NTHR) {
         int k = 0;
-        while (16 * (k + 1) * (k + 2) <= i) ++k;             // at most 8 steps
+        while (16 * (k + 1) * (k + 2) <= i) ++k;             // at most MT / 32 steps
         const int j = i - 16 * k * (k + 1), row = 32 * k + j / (k + 1), w = j % (k + 1);
-        uint32_t x = hash_u32(seed, (bh * (uint32_t)Tn + (uint32_t)row) * 8u + (uint32_t)w) | 1u;
+        uint32_t x = hash_u32(seed, (bh * (uint32_t)Tn + (uint32_t)row) * (uint32_t)(MT / 32) + (uint32_t)w) | 1u;
         uint32_t acc = 0;
 #pragma unroll
         for (int bit = 0; bit < MASK_BITS; ++bit) {
             x ^= x << 13; x ^= x >> 17; x ^= x << 5;
             acc = ((keepq >> bit) & 1u) ? (acc | x) : (acc & x);
         }
-        sMask[row * 8 + w] = acc;
+        sMask[mask_row_base<MT>(row) + w] = acc;
     }
 }
 // float p kept (bit 1) or zeroed (bit 0); `w` holds the bit at position `pos`
@@ -632,7 +644,7 @@ struct FwdTile {
     float m, l;       // running maximum (in log2 units: s * log2 e) and sum
 };
 
-template <bool DROP>
+template <bool DROP, int MT = 256>
 __device__ __forceinline__ void fwd_small_chunk(FwdTile& st, const char* sK, const char* sV, const float* sBias, const uint32_t* sMask,
                                                 const bf16x8 (&qf)[2], int t, int j0, int lane) {
     const int g = lane >> 4, l15 = lane & 15;
@@ -668,9 +680,15 @@ __device__ __forceinline__ void fwd_small_chunk(FwdTile& st, const char* sK, con
     float rs = 0.f;
     uint32_t w0 = 0, w1 = 0;
     if constexpr (DROP) {       // this query row's keep bits of the chunk's 64 keys, pre-shifted to the lane's 4 g
-        const u32x2 w = *reinterpret_cast<const u32x2*>(sMask + qi * 8 + (j0 >> 5));
-        w0 = w[0] >> (4 * g);
-        w1 = w[1] >> (4 * g);
+        if constexpr (MT == 256) {
+            const u32x2 w = *reinterpret_cast<const u32x2*>(sMask + qi * 8 + (j0 >> 5));
+            w0 = w[0] >> (4 * g);
+            w1 = w[1] >> (4 * g);
+        } else {
+            const uint32_t* wp = sMask + mask_row_base<MT>(qi) + (j0 >> 5);
+            w0 = wp[0] >> (4 * g);
+            w1 = wp[1] >> (4 * g);
+        }
     }
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
@@ -718,19 +736,20 @@ __device__ __forceinline__ void fwd_small_store(const FwdTile& st, int t, int la
     }
 }
 
-template <bool DROP>
-__global__ __launch_bounds__(512, 4) void attn_fwd_small_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keep,
+template <bool DROP, int MT = 256>
+__global__ __launch_bounds__(2 * MT, 4) void attn_fwd_small_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keep,
         bf16* __restrict__ out, float* __restrict__ lse, int Tn, int nH,
         uint32_t keep16, uint32_t drop_seed, float inv_keep, unsigned long long* __restrict__ trace) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned long long ts[6] = {0, 0, 0, 0, 0, 0};
     if (trace) ts[0] = __builtin_amdgcn_s_memrealtime();
-    const int nchunk = (Tn + 63) >> 6, rows_pad = nchunk << 6;
+    constexpr int NW = MT / 32, CROWS = MT / 4;
+    const int nchunk = (Tn + CROWS - 1) / CROWS, rows_pad = nchunk * CROWS;
     char* sK = smem;
     char* sV = sK + rows_pad * 128;
-    int* sKeep = reinterpret_cast<int*>(sV + rows_pad * 128);            // [256] flags
-    float* sBias = reinterpret_cast<float*>(sKeep + 256);               // [256] 0 / -inf
-    uint32_t* sMask = reinterpret_cast<uint32_t*>(sBias + 256 + 256);   // [256][8] keep bits (after one spare [256])
+    int* sKeep = reinterpret_cast<int*>(sV + rows_pad * 128);            // [MT] flags
+    float* sBias = reinterpret_cast<float*>(sKeep + MT);                // [MT] 0 / -inf
+    uint32_t* sMask = reinterpret_cast<uint32_t*>(sBias + MT + MT);     // keep bits (after one spare [MT])
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = blockIdx.x % nH, b = blockIdx.x / nH;
@@ -753,11 +772,11 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_small_kernel(const bf16* __re
         }
     }
     const __amdgpu_buffer_rsrc_t rk = rows_rsrc(base + D, ld, Tn), rv = rows_rsrc(base + 2 * D, ld, Tn);
-    dma_issue_scalars(sKeep, keep + (long)b * Tn, 1, Tn, wave, lane);
-    dma_issue_chunk(sK, rk, ld, sV, rv, ld, 0, nchunk, wave, lane);
-    dma_issue_chunk(sK, rk, ld, sV, rv, ld, 1, nchunk, wave, lane);
+    dma_issue_scalars<MT>(sKeep, keep + (long)b * Tn, 1, Tn, wave, lane);
+    dma_issue_chunk<NW, MT>(sK, rk, ld, sV, rv, ld, 0, nchunk, wave, lane);
+    dma_issue_chunk<NW, MT>(sK, rk, ld, sV, rv, ld, 1, nchunk, wave, lane);
     if (trace) ts[1] = __builtin_amdgcn_s_memrealtime();
-    if constexpr (DROP) gen_keep_mask(sMask, (uint32_t)(b * nH + h), Tn, drop_seed, keep16, tid);
+    if constexpr (DROP) gen_keep_mask<2 * MT, MT>(sMask, (uint32_t)(b * nH + h), Tn, drop_seed, keep16, tid);
     // 1/sqrt(64) pre-scale of the queries (exact in bf16); also the first use of the plain loads (a counted wait here)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
@@ -774,16 +793,17 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_small_kernel(const bf16* __re
     // the longer tile (B) consumes the key chunks as they land; the shorter one (A) runs afterwards on resident data
 #pragma unroll 1
     for (int jb = 0; jb < nchunk; ++jb) {
-        dma_wait_chunk(jb);
+        dma_wait_chunk<NW, MT>(jb);
         raw_barrier();
-        if (jb < 2) dma_issue_chunk(sK, rk, ld, sV, rv, ld, jb + 2, nchunk, wave, lane);
+        if (jb < 2) dma_issue_chunk<NW, MT>(sK, rk, ld, sV, rv, ld, jb + 2, nchunk, wave, lane);
         if (jb == 0) {
-            if (tid < 256) sBias[tid] = sKeep[tid] != 0 ? 0.f : -INFINITY;       // key-padding flags -> additive bias
+            if (tid < MT) sBias[tid] = sKeep[tid] != 0 ? 0.f : -INFINITY;        // key-padding flags -> additive bias
             raw_barrier();
             if (trace) ts[2] = __builtin_amdgcn_s_memrealtime();
         }
-        const int j0 = jb * 64;
-        if (work && j0 <= 16 * tB + 15) fwd_small_chunk<DROP>(st, sK, sV, sBias, sMask, qfB, tB, j0, lane);
+#pragma unroll 1
+        for (int j0 = jb * CROWS; j0 < (jb + 1) * CROWS; j0 += 64)
+            if (work && j0 <= 16 * tB + 15) fwd_small_chunk<DROP, MT>(st, sK, sV, sBias, sMask, qfB, tB, j0, lane);
     }
     if (trace) ts[3] = __builtin_amdgcn_s_memrealtime();
     if (work) fwd_small_store(st, tB, lane, b, h, Tn, nH, inv_keep, out, lse);
@@ -794,12 +814,12 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_small_kernel(const bf16* __re
         st.m = -INFINITY;
         st.l = 0.f;
 #pragma unroll 1
-        for (int j0 = 0; j0 <= 16 * tA + 15; j0 += 64) fwd_small_chunk<DROP>(st, sK, sV, sBias, sMask, qfA, tA, j0, lane);
+        for (int j0 = 0; j0 <= 16 * tA + 15; j0 += 64) fwd_small_chunk<DROP, MT>(st, sK, sV, sBias, sMask, qfA, tA, j0, lane);
         fwd_small_store(st, tA, lane, b, h, Tn, nH, inv_keep, out, lse);
     }
     if (trace && lane == 0) {
         ts[5] = __builtin_amdgcn_s_memrealtime();
-        unsigned long long* r = trace + ((long)blockIdx.x * 8 + wave) * 8;
+        unsigned long long* r = trace + ((long)blockIdx.x * NW + wave) * 8;
         r[0] = ts[0]; r[1] = ts[1]; r[2] = ts[2]; r[3] = ts[3]; r[4] = ts[4]; r[5] = ts[5];
         r[6] = __builtin_amdgcn_s_getreg((4 << 11) | 20);    // XCC_ID
         r[7] = 1;
@@ -810,7 +830,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_small_kernel(const bf16* __re
 struct BwdKeys {
     f32x4 dk[4], dv[4];
 };
-template <bool DROP>
+template <bool DROP, int MT = 256>
 __device__ __forceinline__ void bwd_small_keys_block(BwdKeys& st, const char* sQ, const char* sO, const float* sLse, const float* sDel,
                                                      const uint32_t* sMask, const bf16x8 (&kf)[2], const bf16x8 (&vf)[2],
                                                      int t, int q0, int lane, float ik_scale) {
@@ -840,7 +860,7 @@ __device__ __forceinline__ void bwd_small_keys_block(BwdKeys& st, const char* sQ
                 const float p = __builtin_amdgcn_exp2f(x);
                 float dp = dp_acc[r];
                 if constexpr (DROP) {
-                    const uint32_t w = sMask[(qr + r) * 8 + (key >> 5)];
+                    const uint32_t w = sMask[mask_row_base<MT>(qr + r) + (key >> 5)];
                     dp = mask_keep(dp, w, key & 31);
                     pT[qs][r] = mask_keep(p, w, key & 31);                     // (x 1/(1-p) at the end, on dV)
                 } else {
@@ -923,20 +943,21 @@ __device__ __forceinline__ void bwd_small_bias_flush(const f32x4 (&bk)[4], const
 
 // NW waves per workgroup: 8 (two workgroups = 16 waves per CU, <= 128 VGPRs) or 4 (two workgroups = 8 waves per CU, up to
 // 256 VGPRs, every wave owns two tile pairs)
-template <bool DROP, int NW>
-__global__ __launch_bounds__(64 * NW, NW / 2) void attn_bwd_small_kv_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keep,
+template <bool DROP, int NW, int MT = 256>
+__global__ __launch_bounds__(64 * NW, (NW / (MT == 256 ? 2 : 4))) void attn_bwd_small_kv_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keep,
         const bf16* __restrict__ d_out, const float* __restrict__ lse, const float* __restrict__ delta,
         bf16* __restrict__ dqkv, float* __restrict__ dbias, int bias_rows, int Tn, int nH,
         uint32_t keep16, uint32_t drop_seed, float inv_keep) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int nchunk = (Tn + 63) >> 6, rows_pad = nchunk << 6;
+    constexpr int CROWS = MT / 4, PPW = (MT / 32) / NW;            // rows per DMA chunk; tile pairs per wave
+    const int nchunk = (Tn + CROWS - 1) / CROWS, rows_pad = nchunk * CROWS;
     char* sQ = smem;
     char* sO = sQ + rows_pad * 128;
-    float* sLse = reinterpret_cast<float*>(sO + rows_pad * 128);    // [256]
-    float* sDel = sLse + 256;                                       // [256]
-    int* sKeep = reinterpret_cast<int*>(sDel + 256);                // [256]
-    float* sB = reinterpret_cast<float*>(sKeep + 256);              // [2][64] column sums of dK, dV (in a [256] slot)
-    uint32_t* sMask = reinterpret_cast<uint32_t*>(sB + 256);        // [256][8] keep bits
+    float* sLse = reinterpret_cast<float*>(sO + rows_pad * 128);    // [MT]
+    float* sDel = sLse + MT;                                        // [MT]
+    int* sKeep = reinterpret_cast<int*>(sDel + MT);                 // [MT]
+    float* sB = reinterpret_cast<float*>(sKeep + MT);               // [2][64] column sums of dK, dV (in a [MT] slot)
+    uint32_t* sMask = reinterpret_cast<uint32_t*>(sB + MT);         // keep bits
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = blockIdx.x % nH, b = blockIdx.x / nH;
@@ -962,19 +983,19 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void attn_bwd_small_kv_kernel(cons
     if (wave < npair) load_frags(wave);
     else { kf[0] = kf[1] = vf[0] = vf[1] = zero16<bf16>(); }
     const __amdgpu_buffer_rsrc_t rq = rows_rsrc(base, ld, Tn), ro = rows_rsrc(dob, D, Tn);
-    dma_issue_scalars(sKeep, keep + (long)b * Tn, 1, Tn, wave, lane);
-    dma_issue_scalars(sLse, lse + ((long)b * nH + h) * Tn, 1, Tn, wave, lane);
-    dma_issue_scalars(sDel, delta + (long)b * Tn * nH + h, nH, Tn, wave, lane);
-    dma_issue_chunk<NW>(sQ, rq, ld, sO, ro, D, 0, nchunk, wave, lane);
-    dma_issue_chunk<NW>(sQ, rq, ld, sO, ro, D, 1, nchunk, wave, lane);
-    if constexpr (DROP) gen_keep_mask<64 * NW>(sMask, (uint32_t)(b * nH + h), Tn, drop_seed, keep16, tid);
+    dma_issue_scalars<MT>(sKeep, keep + (long)b * Tn, 1, Tn, wave, lane);
+    dma_issue_scalars<MT>(sLse, lse + ((long)b * nH + h) * Tn, 1, Tn, wave, lane);
+    dma_issue_scalars<MT>(sDel, delta + (long)b * Tn * nH + h, nH, Tn, wave, lane);
+    dma_issue_chunk<NW, MT>(sQ, rq, ld, sO, ro, D, 0, nchunk, wave, lane);
+    dma_issue_chunk<NW, MT>(sQ, rq, ld, sO, ro, D, 1, nchunk, wave, lane);
+    if constexpr (DROP) gen_keep_mask<64 * NW, MT>(sMask, (uint32_t)(b * nH + h), Tn, drop_seed, keep16, tid);
     // first use of the plain loads: a counted wait here instead of a full drain inside the loop
     asm volatile("" :: "v"(kf[0]), "v"(kf[1]), "v"(vf[0]), "v"(vf[1]));
     BwdKeys st;
 #pragma unroll
     for (int i = 0; i < 4; ++i) st.dk[i] = st.dv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     // (the 4-wave build has the registers to carry the bias sums over its four tiles: 32 more; the 8-wave build reduces per tile)
-    constexpr bool BACC = NW == 4;
+    constexpr bool BACC = PPW == 2;
     f32x4 bk[4], bv[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) bk[i] = bv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -987,22 +1008,22 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void attn_bwd_small_kv_kernel(cons
         const bool work = wave < npair;
 #pragma unroll 1
         for (int c = 0; c < nchunk; ++c) {
-            dma_wait_chunk<NW>(c);
+            dma_wait_chunk<NW, MT>(c);
             raw_barrier();
-            if (c < 2) dma_issue_chunk<NW>(sQ, rq, ld, sO, ro, D, c + 2, nchunk, wave, lane);
+            if (c < 2) dma_issue_chunk<NW, MT>(sQ, rq, ld, sO, ro, D, c + 2, nchunk, wave, lane);
             if (c == 0) {
                 if (tid < 128) sB[tid] = 0.f;
-                for (int i = tid; i < 256; i += 64 * NW) { sLse[i] *= LOG2E; sDel[i] *= 0.125f; }
+                for (int i = tid; i < MT; i += 64 * NW) { sLse[i] *= LOG2E; sDel[i] *= 0.125f; }
                 raw_barrier();
             }
 #pragma unroll 1
-            for (int qb = 2 * c; qb < 2 * c + 2 && qb < nqb; ++qb)
+            for (int qb = c * (CROWS / 32); qb < (c + 1) * (CROWS / 32) && qb < nqb; ++qb)
                 if (work && qb >= ((16 * tA) >> 5))
-                    bwd_small_keys_block<DROP>(st, sQ, sO, sLse, sDel, sMask, kf, vf, tA, 32 * qb, lane, ik_scale);
+                    bwd_small_keys_block<DROP, MT>(st, sQ, sO, sLse, sDel, sMask, kf, vf, tA, 32 * qb, lane, ik_scale);
         }
     }
 #pragma unroll 1
-    for (int pi = 0; pi < 8 / NW; ++pi) {
+    for (int pi = 0; pi < PPW; ++pi) {
         const int p = wave + NW * pi;
         if (p >= npair) break;
         const int tA = p, tB = ntile - 1 - p;
@@ -1012,17 +1033,17 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void attn_bwd_small_kv_kernel(cons
             for (int i = 0; i < 4; ++i) st.dk[i] = st.dv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
             for (int qb = (16 * tA) >> 5; qb < nqb; ++qb)
-                bwd_small_keys_block<DROP>(st, sQ, sO, sLse, sDel, sMask, kf, vf, tA, 32 * qb, lane, ik_scale);
+                bwd_small_keys_block<DROP, MT>(st, sQ, sO, sLse, sDel, sMask, kf, vf, tA, 32 * qb, lane, ik_scale);
         }
         if (tA != tB) load_frags(tB);
-        bwd_small_keys_store<BACC>(st, tA, lane, b, h, Tn, nH, inv_keep, sKeep[(16 * tA + l15) & 255] != 0, dqkv, sBp, bk, bv);
+        bwd_small_keys_store<BACC>(st, tA, lane, b, h, Tn, nH, inv_keep, sKeep[(16 * tA + l15) & (MT - 1)] != 0, dqkv, sBp, bk, bv);
         if (tA != tB) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) st.dk[i] = st.dv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
             for (int qb = (16 * tB) >> 5; qb < nqb; ++qb)
-                bwd_small_keys_block<DROP>(st, sQ, sO, sLse, sDel, sMask, kf, vf, tB, 32 * qb, lane, ik_scale);
-            bwd_small_keys_store<BACC>(st, tB, lane, b, h, Tn, nH, inv_keep, sKeep[(16 * tB + l15) & 255] != 0, dqkv, sBp, bk, bv);
+                bwd_small_keys_block<DROP, MT>(st, sQ, sO, sLse, sDel, sMask, kf, vf, tB, 32 * qb, lane, ik_scale);
+            bwd_small_keys_store<BACC>(st, tB, lane, b, h, Tn, nH, inv_keep, sKeep[(16 * tB + l15) & (MT - 1)] != 0, dqkv, sBp, bk, bv);
         }
     }
     if (dbias) {
@@ -1039,7 +1060,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void attn_bwd_small_kv_kernel(cons
 }
 
 // ---- backward, dQ kernel: the 16 queries of tile t (Q, dO fragments in registers), one 32-key block
-template <bool DROP>
+template <bool DROP, int MT = 256>
 __device__ __forceinline__ void bwd_small_queries_block(f32x4 (&dq)[4], const char* sK, const char* sV, const float* sBias,
                                                         const uint32_t* sMask, const bf16x8 (&qf)[2], const bf16x8 (&of)[2],
                                                         float lse2_q, float dels_q, int t, int j0, int lane, float ik_scale) {
@@ -1048,7 +1069,7 @@ __device__ __forceinline__ void bwd_small_queries_block(f32x4 (&dq)[4], const ch
     const float c1 = 0.125f * LOG2E;
     f32x4 dsT[2];
     uint32_t wq = 0;
-    if constexpr (DROP) wq = sMask[qi * 8 + (j0 >> 5)] >> (4 * g);      // this query row's keep bits of the block's 32 keys
+    if constexpr (DROP) wq = sMask[mask_row_base<MT>(qi) + (j0 >> 5)] >> (4 * g);      // this query row's keep bits of the block's 32 keys
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
         dsT[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1112,19 +1133,20 @@ __device__ __forceinline__ void bwd_small_bias_flush_q(const f32x4 (&bq)[4], flo
         }
 }
 
-template <bool DROP>
-__global__ __launch_bounds__(512, 4) void attn_bwd_small_q_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keep,
+template <bool DROP, int MT = 256>
+__global__ __launch_bounds__(2 * MT, 4) void attn_bwd_small_q_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keep,
         const bf16* __restrict__ d_out, const float* __restrict__ lse, const float* __restrict__ delta,
         bf16* __restrict__ dqkv, float* __restrict__ dbias, int bias_rows, int Tn, int nH,
         uint32_t keep16, uint32_t drop_seed, float inv_keep) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int nchunk = (Tn + 63) >> 6, rows_pad = nchunk << 6;
+    constexpr int NW = MT / 32, CROWS = MT / 4;
+    const int nchunk = (Tn + CROWS - 1) / CROWS, rows_pad = nchunk * CROWS;
     char* sK = smem;
     char* sV = sK + rows_pad * 128;
-    int* sKeep = reinterpret_cast<int*>(sV + rows_pad * 128);      // [256]
-    float* sBias = reinterpret_cast<float*>(sKeep + 256);          // [256]
-    float* sB = sBias + 256;                                        // [64] column sums of dQ (in a [256] slot)
-    uint32_t* sMask = reinterpret_cast<uint32_t*>(sB + 512);        // [256][8] keep bits
+    int* sKeep = reinterpret_cast<int*>(sV + rows_pad * 128);      // [MT]
+    float* sBias = reinterpret_cast<float*>(sKeep + MT);           // [MT]
+    float* sB = sBias + MT;                                         // [64] column sums of dQ (in two [MT] slots)
+    uint32_t* sMask = reinterpret_cast<uint32_t*>(sB + 2 * MT);     // keep bits
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = blockIdx.x % nH, b = blockIdx.x / nH;
@@ -1154,10 +1176,10 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_small_q_kernel(const bf16* __
     if (work && qa < Tn) { lseA = lse[((long)b * nH + h) * Tn + qa]; delA = delta[((long)b * Tn + qa) * nH + h]; }
     if (work && qb_ < Tn) { lseB = lse[((long)b * nH + h) * Tn + qb_]; delB = delta[((long)b * Tn + qb_) * nH + h]; }
     const __amdgpu_buffer_rsrc_t rk = rows_rsrc(base + D, ld, Tn), rv = rows_rsrc(base + 2 * D, ld, Tn);
-    dma_issue_scalars(sKeep, keep + (long)b * Tn, 1, Tn, wave, lane);
-    dma_issue_chunk(sK, rk, ld, sV, rv, ld, 0, nchunk, wave, lane);
-    dma_issue_chunk(sK, rk, ld, sV, rv, ld, 1, nchunk, wave, lane);
-    if constexpr (DROP) gen_keep_mask(sMask, (uint32_t)(b * nH + h), Tn, drop_seed, keep16, tid);
+    dma_issue_scalars<MT>(sKeep, keep + (long)b * Tn, 1, Tn, wave, lane);
+    dma_issue_chunk<NW, MT>(sK, rk, ld, sV, rv, ld, 0, nchunk, wave, lane);
+    dma_issue_chunk<NW, MT>(sK, rk, ld, sV, rv, ld, 1, nchunk, wave, lane);
+    if constexpr (DROP) gen_keep_mask<2 * MT, MT>(sMask, (uint32_t)(b * nH + h), Tn, drop_seed, keep16, tid);
     // first use of the plain loads: a counted wait here instead of a full drain inside the loop
     asm volatile("" :: "v"(qfA[0]), "v"(qfA[1]), "v"(ofA[0]), "v"(ofA[1]), "v"(qfB[0]), "v"(qfB[1]), "v"(ofB[0]), "v"(ofB[1]));
     lseA *= LOG2E; lseB *= LOG2E; delA *= 0.125f; delB *= 0.125f;
@@ -1168,18 +1190,18 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_small_q_kernel(const bf16* __
     // tile B (high queries) consumes the key chunks as they land; tile A (a short range) runs afterwards
 #pragma unroll 1
     for (int c = 0; c < nchunk; ++c) {
-        dma_wait_chunk(c);
+        dma_wait_chunk<NW, MT>(c);
         raw_barrier();
-        if (c < 2) dma_issue_chunk(sK, rk, ld, sV, rv, ld, c + 2, nchunk, wave, lane);
+        if (c < 2) dma_issue_chunk<NW, MT>(sK, rk, ld, sV, rv, ld, c + 2, nchunk, wave, lane);
         if (c == 0) {
             if (tid < 64) sB[tid] = 0.f;
-            if (tid < 256) sBias[tid] = sKeep[tid] != 0 ? 0.f : -INFINITY;
+            if (tid < MT) sBias[tid] = sKeep[tid] != 0 ? 0.f : -INFINITY;
             raw_barrier();
         }
 #pragma unroll 1
-        for (int kb = 2 * c; kb < 2 * c + 2; ++kb)
+        for (int kb = c * (CROWS / 32); kb < (c + 1) * (CROWS / 32); ++kb)
             if (work && 32 * kb <= 16 * tB + 15)
-                bwd_small_queries_block<DROP>(dq, sK, sV, sBias, sMask, qfB, ofB, lseB, delB, tB, 32 * kb, lane, ik_scale);
+                bwd_small_queries_block<DROP, MT>(dq, sK, sV, sBias, sMask, qfB, ofB, lseB, delB, tB, 32 * kb, lane, ik_scale);
     }
     f32x4 bq[4];
 #pragma unroll
@@ -1191,7 +1213,7 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_small_q_kernel(const bf16* __
             for (int i = 0; i < 4; ++i) dq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
             for (int j0 = 0; j0 <= 16 * tA + 15; j0 += 32)
-                bwd_small_queries_block<DROP>(dq, sK, sV, sBias, sMask, qfA, ofA, lseA, delA, tA, j0, lane, ik_scale);
+                bwd_small_queries_block<DROP, MT>(dq, sK, sV, sBias, sMask, qfA, ofA, lseA, delA, tA, j0, lane, ik_scale);
             bwd_small_queries_store(dq, tA, lane, b, h, Tn, nH, dqkv, sBp, bq);
         }
     }
@@ -1206,8 +1228,11 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_small_q_kernel(const bf16* __
     }
 }
 
-// two images + four [256]-dword scalar slots + the keep-bit matrix
-inline size_t small_smem(int T) { const int rp = ((T + 63) >> 6) << 6; return (size_t)rp * 256 + 4 * 256 * 4 + 256 * 8 * 4; }
+// two images + four [MT]-dword scalar slots + the keep-bit matrix
+template <int MT = 256> inline size_t small_smem(int T) {
+    const int cr = MT / 4, rp = ((T + cr - 1) / cr) * cr;
+    return (size_t)rp * 256 + 4 * MT * 4 + (size_t)mask_words<MT>() * 4;
+}
 // keep probability of the whole-head kernels' dropout in units of 2^-12 and the matching scale
 inline unsigned small_keep16(unsigned thresh32) { return 4096u - ((thresh32 + 0x80000u) >> 20); }
 inline float small_inv_keep(unsigned keepq) { return (float)(4096.0 / (double)keepq); }
@@ -1245,23 +1270,27 @@ extern "C" int mmtg_attn_fwd(int dtype, const void* qkv, const int* keep, void* 
     dim3 grid(cdiv(T, 64), nH, B), block(256);
     const float ik = inv_keep_of(drop_thresh);
     static const bool legacy = getenv("MMTG_ATTN_TILED") != nullptr;      // A/B switch: the tiled kernel for every T
-    if (dtype == MMTG_BF16 && T <= SM_MAXT && !legacy) {
+    static const bool no512 = getenv("MMTG_ATTN_NO512") != nullptr;     // A/B switch: the tiled kernels for 256 < T <= 512 (round 2)
+    if (dtype == MMTG_BF16 && T <= (no512 ? 256 : SM_MAXT) && !legacy) {
         static bool attr_set = false;
         if (!attr_set) {
-            if (hipFuncSetAttribute((const void*)attn_fwd_small_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)small_smem(SM_MAXT)) != hipSuccess ||
-                hipFuncSetAttribute((const void*)attn_fwd_small_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)small_smem(SM_MAXT)) != hipSuccess)
+            if (hipFuncSetAttribute((const void*)attn_fwd_small_kernel<false, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_smem<256>(256)) != hipSuccess ||
+                hipFuncSetAttribute((const void*)attn_fwd_small_kernel<true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_smem<256>(256)) != hipSuccess ||
+                hipFuncSetAttribute((const void*)attn_fwd_small_kernel<false, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_smem<512>(512)) != hipSuccess ||
+                hipFuncSetAttribute((const void*)attn_fwd_small_kernel<true, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_smem<512>(512)) != hipSuccess)
                 MMTG_FAIL(MMTG_ERR_HIP, "attn_fwd: cannot raise dynamic LDS");
             attr_set = true;
         }
         const unsigned k16 = small_keep16(drop_thresh);
-        if (k16 < 4096u)
-            hipLaunchKernelGGL(attn_fwd_small_kernel<true>, dim3(B * nH), dim3(512), small_smem(T), s, (const bf16*)qkv, keep,
-                               (bf16*)out, lse, T, nH, k16, drop_seed, small_inv_keep(k16), g_attn_trace);
-        else
-            hipLaunchKernelGGL(attn_fwd_small_kernel<false>, dim3(B * nH), dim3(512), small_smem(T), s, (const bf16*)qkv, keep,
-                               (bf16*)out, lse, T, nH, 0u, drop_seed, 1.0f, g_attn_trace);
+        const bool drop = k16 < 4096u;
+        const unsigned kq = drop ? k16 : 0u;
+        const float ikq = drop ? small_inv_keep(k16) : 1.0f;
+        // one workgroup per (batch row, head): 8 waves and two workgroups per CU up to T = 256, 16 waves and one per CU up to 512
+#define FWD_SMALL(DROP_, MT_) hipLaunchKernelGGL((attn_fwd_small_kernel<DROP_, MT_>), dim3(B * nH), dim3(2 * MT_), small_smem<MT_>(T), s, \
+                                                 (const bf16*)qkv, keep, (bf16*)out, lse, T, nH, kq, drop_seed, ikq, g_attn_trace)
+        if (T <= 256) { if (drop) FWD_SMALL(true, 256); else FWD_SMALL(false, 256); }
+        else { if (drop) FWD_SMALL(true, 512); else FWD_SMALL(false, 512); }
+#undef FWD_SMALL
         MMTG_LAUNCH_CHECK("attn_fwd");
         return MMTG_OK;
     }
@@ -1292,6 +1321,7 @@ extern "C" int mmtg_attn_bwd(int dtype, const void* qkv, const int* keep, const 
     float* const bias_dst = dbias && dbias_ws ? dbias_ws : dbias;
     const int bias_rows = dbias && dbias_ws ? 1 : 0;
     static bool attr_set[2] = {false, false};
+    bool small_path = false;
     static const int ablate = getenv("MMTG_ATTN_ABLATE") ? atoi(getenv("MMTG_ATTN_ABLATE")) : 0;   // timing experiments only
     if (dtype == MMTG_F32) {
         const int KB = 4 * AT<float>::KPW;
@@ -1306,42 +1336,47 @@ extern "C" int mmtg_attn_bwd(int dtype, const void* qkv, const int* keep, const 
         if (nkb > 1) { if (hipMemsetAsync(dq32, 0, rows * D * sizeof(float), s) != hipSuccess) MMTG_FAIL(MMTG_ERR_HIP, "attn_bwd: memset failed"); }
         hipLaunchKernelGGL((attn_bwd_kernel<float, 4>), dim3(nkb, nH, B), dim3(256), shm, s, (const float*)qkv, keep, (const float*)dout, lse, delta, dq32, (float*)dqkv, bias_dst, bias_rows, T, nH, nkb == 1, drop_thresh, drop_seed, ik, ablate);
         if (nkb > 1) hipLaunchKernelGGL(attn_dq_finish_kernel<float>, dim3(2048), dim3(256), 0, s, dq32, (float*)dqkv, rows, D);
-    } else if (dtype == MMTG_BF16 && T <= SM_MAXT && !getenv("MMTG_ATTN_TILED")) {
+    } else if (dtype == MMTG_BF16 && T <= (getenv("MMTG_ATTN_NO512") ? 256 : SM_MAXT) && !getenv("MMTG_ATTN_TILED")) {
+        small_path = true;
         static bool attr_small = false;
         if (!attr_small) {
-            const int shm = (int)small_smem(SM_MAXT);
-            if (hipFuncSetAttribute((const void*)attn_bwd_small_kv_kernel<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, shm) != hipSuccess ||
-                hipFuncSetAttribute((const void*)attn_bwd_small_kv_kernel<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, shm) != hipSuccess ||
-                hipFuncSetAttribute((const void*)attn_bwd_small_kv_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, shm) != hipSuccess ||
-                hipFuncSetAttribute((const void*)attn_bwd_small_kv_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, shm) != hipSuccess ||
-                hipFuncSetAttribute((const void*)attn_bwd_small_q_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, shm) != hipSuccess ||
-                hipFuncSetAttribute((const void*)attn_bwd_small_q_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, shm) != hipSuccess)
-                MMTG_FAIL(MMTG_ERR_HIP, "attn_bwd: cannot raise dynamic LDS");
+            const int shm2 = (int)small_smem<256>(256), shm5 = (int)small_smem<512>(512);
+            bool ok = true;
+#define SET_LDS(K_, B_) ok = ok && hipFuncSetAttribute((const void*)K_, hipFuncAttributeMaxDynamicSharedMemorySize, B_) == hipSuccess
+            SET_LDS((attn_bwd_small_kv_kernel<false, 8, 256>), shm2); SET_LDS((attn_bwd_small_kv_kernel<true, 8, 256>), shm2);
+            SET_LDS((attn_bwd_small_kv_kernel<false, 4, 256>), shm2); SET_LDS((attn_bwd_small_kv_kernel<true, 4, 256>), shm2);
+            SET_LDS((attn_bwd_small_q_kernel<false, 256>), shm2); SET_LDS((attn_bwd_small_q_kernel<true, 256>), shm2);
+            SET_LDS((attn_bwd_small_kv_kernel<false, 16, 512>), shm5); SET_LDS((attn_bwd_small_kv_kernel<true, 16, 512>), shm5);
+            SET_LDS((attn_bwd_small_kv_kernel<false, 8, 512>), shm5); SET_LDS((attn_bwd_small_kv_kernel<true, 8, 512>), shm5);
+            SET_LDS((attn_bwd_small_q_kernel<false, 512>), shm5); SET_LDS((attn_bwd_small_q_kernel<true, 512>), shm5);
+#undef SET_LDS
+            if (!ok) MMTG_FAIL(MMTG_ERR_HIP, "attn_bwd: cannot raise dynamic LDS");
             attr_small = true;
         }
         if (!delta_ready) hipLaunchKernelGGL(attn_delta_kernel<bf16>, dim3(cdiv(rows * nH, 4)), dim3(256), 0, s, (const bf16*)out, (const bf16*)dout, delta, T, nH, rows);
         const unsigned th16 = small_keep16(drop_thresh);
-        const float ik16 = small_inv_keep(th16);
-        const size_t shm = small_smem(T);
-        // dK/dV kernel: with dropout the 4-wave build (160 VGPRs, no spills, each wave two tile pairs) wins (117 vs 135 us for
-        // backward + delta in isolation); without, the 8-wave build does (106 vs 111).  MMTG_ATTN_KV_NW=4|8 forces one.
+        const bool drop = th16 < 4096u;
+        const unsigned kq = drop ? th16 : 0u;
+        const float ik16 = drop ? small_inv_keep(th16) : 1.0f;
+        // dK/dV kernel: with dropout the half-wave build (every wave two tile pairs, up to 256 VGPRs, no spills) wins at T <= 256
+        // (117 vs 135 us for backward + delta in isolation); without, the full-wave build does (106 vs 111).
+        // MMTG_ATTN_KV_NW=4|8 (T <= 256) / 8|16 (T <= 512) forces one.
         static const int kv_nw = getenv("MMTG_ATTN_KV_NW") ? atoi(getenv("MMTG_ATTN_KV_NW")) : 0;
-        const bool kv4 = kv_nw ? kv_nw == 4 : th16 < 4096u;
-        if (th16 < 4096u) {
-            if (kv4) hipLaunchKernelGGL((attn_bwd_small_kv_kernel<true, 4>), dim3(B * nH), dim3(256), shm, s, (const bf16*)qkv, keep, (const bf16*)dout, lse,
-                               delta, (bf16*)dqkv, bias_dst, bias_rows, T, nH, th16, drop_seed, ik16);
-            else hipLaunchKernelGGL((attn_bwd_small_kv_kernel<true, 8>), dim3(B * nH), dim3(512), shm, s, (const bf16*)qkv, keep, (const bf16*)dout, lse,
-                               delta, (bf16*)dqkv, bias_dst, bias_rows, T, nH, th16, drop_seed, ik16);
-            hipLaunchKernelGGL(attn_bwd_small_q_kernel<true>, dim3(B * nH), dim3(512), shm, s, (const bf16*)qkv, keep, (const bf16*)dout, lse,
-                               delta, (bf16*)dqkv, bias_dst, bias_rows, T, nH, th16, drop_seed, ik16);
+#define KV_SMALL(DROP_, NW_, MT_) hipLaunchKernelGGL((attn_bwd_small_kv_kernel<DROP_, NW_, MT_>), dim3(B * nH), dim3(64 * NW_), small_smem<MT_>(T), s, \
+                                   (const bf16*)qkv, keep, (const bf16*)dout, lse, delta, (bf16*)dqkv, bias_dst, bias_rows, T, nH, kq, drop_seed, ik16)
+#define Q_SMALL(DROP_, MT_) hipLaunchKernelGGL((attn_bwd_small_q_kernel<DROP_, MT_>), dim3(B * nH), dim3(2 * MT_), small_smem<MT_>(T), s, \
+                                   (const bf16*)qkv, keep, (const bf16*)dout, lse, delta, (bf16*)dqkv, bias_dst, bias_rows, T, nH, kq, drop_seed, ik16)
+        if (T <= 256) {
+            const bool half = kv_nw ? kv_nw == 4 : drop;
+            if (drop) { if (half) KV_SMALL(true, 4, 256); else KV_SMALL(true, 8, 256); Q_SMALL(true, 256); }
+            else { if (half) KV_SMALL(false, 4, 256); else KV_SMALL(false, 8, 256); Q_SMALL(false, 256); }
         } else {
-            if (kv4) hipLaunchKernelGGL((attn_bwd_small_kv_kernel<false, 4>), dim3(B * nH), dim3(256), shm, s, (const bf16*)qkv, keep, (const bf16*)dout, lse,
-                               delta, (bf16*)dqkv, bias_dst, bias_rows, T, nH, 0u, drop_seed, 1.0f);
-            else hipLaunchKernelGGL((attn_bwd_small_kv_kernel<false, 8>), dim3(B * nH), dim3(512), shm, s, (const bf16*)qkv, keep, (const bf16*)dout, lse,
-                               delta, (bf16*)dqkv, bias_dst, bias_rows, T, nH, 0u, drop_seed, 1.0f);
-            hipLaunchKernelGGL(attn_bwd_small_q_kernel<false>, dim3(B * nH), dim3(512), shm, s, (const bf16*)qkv, keep, (const bf16*)dout, lse,
-                               delta, (bf16*)dqkv, bias_dst, bias_rows, T, nH, 0u, drop_seed, 1.0f);
+            const bool half = kv_nw ? kv_nw == 8 : drop;
+            if (drop) { if (half) KV_SMALL(true, 8, 512); else KV_SMALL(true, 16, 512); Q_SMALL(true, 512); }
+            else { if (half) KV_SMALL(false, 8, 512); else KV_SMALL(false, 16, 512); Q_SMALL(false, 512); }
         }
+#undef KV_SMALL
+#undef Q_SMALL
     } else if (dtype == MMTG_BF16) {
         const int KB = 4 * AT<bf16>::KPW;
         const int nkb = cdiv(T, KB);
@@ -1358,7 +1393,8 @@ extern "C" int mmtg_attn_bwd(int dtype, const void* qkv, const int* keep, const 
     } else MMTG_FAIL(MMTG_ERR_BAD_ARG, "attn_bwd: bad dtype");
     MMTG_LAUNCH_CHECK("attn_bwd");
     // several key blocks per head: dQ went through the fp32 atomics + finish pass; sum its columns here
-    const int nkb_ = cdiv(T, dtype == MMTG_F32 ? 4 * AT<float>::KPW : 4 * AT<bf16>::KPW);
+    // (the whole-head kernels write ONE partial bias row per batch row and leave nothing to the dQ column pass)
+    const int nkb_ = small_path ? 1 : cdiv(T, dtype == MMTG_F32 ? 4 * AT<float>::KPW : 4 * AT<bf16>::KPW);
     if (bias_rows) {
         int rc = mmtg_colsum(MMTG_F32, dbias_ws, 3L * D, B * nkb_, 3 * D, dbias, stream);
         if (rc) return rc;

@@ -494,7 +494,7 @@ def ref_attention(qkv, keep, nH):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("T", [236, 104, 64, 300, 1, 17, 1024, 256, 240, 33])
+@pytest.mark.parametrize("T", [236, 104, 64, 300, 1, 17, 1024, 256, 240, 33, 257, 384, 512, 497])
 def test_attention(dtype, T):
     B, nH, dh = 2, 3, 64
     D = nH * dh
@@ -533,21 +533,28 @@ def test_attention(dtype, T):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_attention_dropout_consistency(dtype):
+@pytest.mark.parametrize("T", [64, 200, 320, 512])
+def test_attention_dropout_consistency(dtype, T):
     """Forward/backward share one counter-based mask: check against an fp32
-    reference that uses the mask recovered from a probe run (V = identity rows)."""
-    B, nH, dh, T = 1, 1, 64, 64
+    reference that uses the mask recovered from probe runs (V = identity rows, 64 keys per run).  T = 64 / 200: the
+    whole-head kernels of up to 256 positions (bf16), 320 / 512: their 16-wave form with the compact keep-bit matrix;
+    fp32 and T > 512: the tiled kernels' per-element hash."""
+    B, nH, dh = 1, 1, 64
     D = nH * dh
     p = 0.3
     qkv = rnd(B, T, 3 * D, dtype=dtype, seed=5, scale=0.5)
     keep = torch.ones(B, T, dtype=torch.int32)
-    probe = qkv.clone()
-    probe[..., :2 * D] = 0                       # uniform attention: P = 1/(t+1)
-    probe[..., 2 * D:] = torch.eye(T, dh)        # V = I  -> out[t, j] = mask[t, j] * P / (1-p)
     out = torch.empty(B, T, D, device=DEV, dtype=dtype)
     lse = torch.empty(B, nH, T, device=DEV)
-    hip.attn_fwd(probe.to(DEV), keep.to(DEV), out, lse, B, T, nH, dh, drop_p=p, drop_seed=11)
-    mask = (out[0].float().cpu() != 0).float()
+    mask = torch.zeros(T, T)
+    for c0 in range(0, T, dh):
+        probe = qkv.clone()
+        probe[..., :2 * D] = 0                       # uniform attention: P = 1/(t+1)
+        probe[..., 2 * D:] = 0
+        n = min(dh, T - c0)
+        probe[0, c0:c0 + n, 2 * D:2 * D + n] = torch.eye(n).to(dtype)     # V rows c0.. = unit vectors -> out[t, j] = mask[t, c0 + j] P / (1-p)
+        hip.attn_fwd(probe.to(DEV), keep.to(DEV), out, lse, B, T, nH, dh, drop_p=p, drop_seed=11)
+        mask[:, c0:c0 + n] = (out[0, :, :n].float().cpu() != 0).float()
     tri = torch.tril(torch.ones(T, T))
     frac = float((mask * tri).sum() / tri.sum())
     assert 0.6 < frac < 0.8, frac
