@@ -402,7 +402,7 @@ __global__ __launch_bounds__(256, LN_BWD_WAVES) void ln_bwd2_kernel(const T* __r
 // accumulators + operands fit 128 VGPRs and FOUR waves per SIMD keep twice the bytes in flight.  Same
 // next-row prefetch, partial-row workspace and finalize kernel as v2.
 template <int A, int B>
-__global__ __launch_bounds__(256, (8 * A + 4 * B <= 8 ? 4 : 3)) void ln_bwd3_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x,
+__global__ __launch_bounds__(256, (8 * A + 4 * B <= 8 ? 4 : 8 * A + 4 * B <= 12 ? 3 : 2)) void ln_bwd3_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x,
                                                          const float* __restrict__ gamma, const float* __restrict__ mean,
                                                          const float* __restrict__ rstd, const bf16* __restrict__ dres,
                                                          bf16* __restrict__ dx, bf16* __restrict__ dxm, float* __restrict__ ws,
@@ -739,21 +739,25 @@ extern "C" int mmtg_layernorm_bwd(int dtype, const void* dy, const void* x, cons
     const bool vec = !v1 && cols % epc == 0 && MMTG_ALIGNED16(dy) && MMTG_ALIGNED16(x) && MMTG_ALIGNED16(dx) &&
                      (!dres || MMTG_ALIGNED16(dres)) && (!dx_masked || MMTG_ALIGNED16(dx_masked)) && MMTG_ALIGNED16(gamma);
     static const bool v2only = getenv("MMTG_LN_V2") != nullptr;  // A/B switch: half-wave-per-row kernel for bf16 too
-    if (vec && !v2only && dtype == MMTG_BF16 && (cols == 512 || cols == 768)) {     // (1024: 16 columns per lane spill at 168 VGPRs)
-        // full wave per row, four resident 4-wave blocks per CU
-        static int cap3 = 0;
+    static const bool no1024 = getenv("MMTG_LN_NO1024") != nullptr;   // A/B switch: 1024 columns on the half-wave kernel (round 2)
+    if (vec && !v2only && dtype == MMTG_BF16 && (cols == 512 || cols == 768 || (cols == 1024 && !no1024))) {
+        // full wave per row; four / three resident 4-wave blocks per CU at 512 / 768 columns; at 1024 (16 columns per lane: the 3 x 16
+        // column accumulators need ~200 VGPRs) two blocks per CU without spills instead of three with them (round 3)
+        static int cap3 = 0, cus_ = 0;
         if (!cap3) {
             int dev = 0, cus = 0;
             if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+            cus_ = cus;
             cap3 = getenv("MMTG_LN_CAP") ? atoi(getenv("MMTG_LN_CAP")) : 3 * cus;
         }
-        if (nb > cap3) nb = cap3;
+        const int capx = cols == 1024 && !getenv("MMTG_LN_CAP") ? 2 * cus_ : cap3;
+        if (nb > capx) nb = capx;
         const int sweeps = cdiv(cdiv(rows, 4), nb);
         nb = cdiv(cdiv(rows, 4), sweeps);
         dim3 grid(nb), block(256);
 #define LN3(A_, B_) hipLaunchKernelGGL((ln_bwd3_kernel<A_, B_>), grid, block, 0, s, (const bf16*)dy, (const bf16*)x, gamma, mean, rstd, \
                                        (const bf16*)dres, (bf16*)dx, (bf16*)dx_masked, ws, rows, want, drop_thresh, drop_seed, ik)
-        if (cols == 512) LN3(1, 0); else LN3(1, 1);
+        if (cols == 512) LN3(1, 0); else if (cols == 768) LN3(1, 1); else LN3(2, 0);
 #undef LN3
     } else if (vec) {
         // half-wave per row: a block covers 8 rows per sweep; equal sweeps per wave, <= the v1 block count
