@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MMTG_ABI_VERSION 3
+#define MMTG_ABI_VERSION 4
 
 /* The library is built with -fvisibility=hidden: only the entry points below are exported. */
 #define MMTG_API __attribute__((visibility("default")))
@@ -345,8 +345,30 @@ MMTG_API int mmtg_decode_embed(int dtype, const void* table, const long long* se
                       const int* pos_ptr, const long long* tpw_type, const long long* tpw_mask,
                       long long* type_out, int* keep, long ldkeep, int B, int P, int S, int E, int two_sents,
                       int V, int sent, int max_sent_num, void* stream);
+/* stats (optional, f32 [B][32][2]): the LayerNorm statistics (sum, sum of squares) of every row of h as stored, in partial 0
+ * (partials 1..31 zeroed) -- the input of the first LN-fold product of the fused decode step (mmtg_decode_gemm).          */
 MMTG_API int mmtg_decode_embed_add(int dtype, const void* g, const void* wpe, const void* wte, const long long* type_ids,
-                          const int* pos_ptr, void* h, int B, int D, void* stream);
+                          const int* pos_ptr, void* h, int B, int D, float* stats, void* stream);
+/* Round 3: the decode step's batch-sized products with the row-wise glue fused in (bf16; A [M, lda], W [N, ldw] K-contiguous;
+ * 64 x 64 tiles; replaces the products + mmtg_splitk_finish launches behind generate.py:124's per-token model call):
+ *   mode 0 "LN-fold"        C = act( rstd_m (A W^T - mu_m colsum_n) + bias_n ), act in {MMTG_EPI_NONE, MMTG_EPI_GELU}; C bf16
+ *                           [M, ldc] or fp32 (out_f32).  W = the gamma-folded weight copy, colsum / bias = its column sums and
+ *                           folded bias (mmtg_ln_fold_weights); mu_m / rstd_m from stats_in.
+ *   mode 1 "LN-fold slabs"  split-K: C = fp32 [splits][M][ldc], slab s = rstd_m (A_s W_s^T) - [s == 0] rstd_m mu_m colsum_n
+ *                           (the bias is left to the consumer, mmtg_decode_attn_split).
+ *   mode 2 "reduce"         split-K reduced IN the kernel by the last-arriving wave of every 32 x 32 wave tile (partials in
+ *                           `ws`: >= tiles * splits * 4096 floats; `counters`: >= 4 * tiles, zero on entry and on return):
+ *                           C (bf16) = sum_s partial_s + bias + resid, and stats_out[m][n / 32] = (sum, sum of squares) of the
+ *                           stored row segment -- the LayerNorm statistics of the new residual stream as 32-column partials.
+ * stats_in / stats_out: f32 [M][32][2] (N <= 1024 in mode 2); np_in = partials to add (1 after mmtg_decode_embed_add, N / 32 after a mode-2 product).  */
+MMTG_API int mmtg_decode_gemm(int mode, int M, int N, int K, const void* A, long lda, const void* W, long ldw, void* C, long ldc,
+                     const float* bias, const float* colsum, const float* stats_in, int np_in, float eps, int act, int out_f32,
+                     const void* resid, long ldr, float* stats_out, int splits, float* ws, long ws_floats, unsigned* counters,
+                     long n_counters, void* stream);
+/* Wf[n, k] = gamma[k] W[n, k] (bf16), colsum[n] = sum_k Wf[n, k], bias_f[n] = bias[n] + sum_k beta[k] W[n, k]: the operands of the
+ * LN-fold products, LN(x) W^T + b = rstd (x Wf^T - mu colsum) + bias_f.  W: [N, ldw] bf16 K-contiguous; bias may be null.   */
+MMTG_API int mmtg_ln_fold_weights(const void* W, long ldw, const float* gamma, const float* beta, const float* bias, void* Wf,
+                         float* colsum, float* bias_f, int N, int K, void* stream);
 MMTG_API int mmtg_decode_attn(int dtype, const void* qkv, void* kcache, void* vcache, const int* keep, long ldkeep,
                      const int* pos_ptr, void* out, int B, int nH, int dh, int Tmax, void* stream);
 /* the same, taking the c_attn product as MMTG_EPI_SPLIT slabs (part: f32 [splits][B][3*D]) plus its bias:

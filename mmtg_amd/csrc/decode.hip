@@ -5,7 +5,7 @@
 // every lane applies that many sequential fp32 divisions to its own slots -- bit-for-bit the
 // reference's arithmetic, in O(V + n) instead of the O(V n) scan of the first version (which made
 // this kernel 9 % of a decode step: 122 us at 220 generated tokens).
-#include "common.h"
+#include "gemm_common.h"
 
 namespace {
 
@@ -364,14 +364,283 @@ __global__ __launch_bounds__(256) void decode_embed_kernel(const T* __restrict__
     }
 }
 
+
+// =====================================================================================
+// Round 3: the decode step's batch-sized products with the row-wise glue fused in (5 graph nodes per GPT-2 block instead of 7).
+//
+// Until now every split-K product of the step was followed by a "finish" launch (sum the slabs, bias, residual, and the LayerNorm
+// of the NEXT product's input).  A graph node costs ~4 us whatever it does, so the finish kernels were 24 x 5.2 us
+// of a 758 us step.  They are gone:
+//   * mode 2 ("reduce"): a split-K product whose K slices are reduced IN the kernel -- every split stores its raw fp32 partial
+//     wave tile into slot (tile, split) of a workspace with agent-scope stores, bumps the wave tile's arrival counter, and the
+//     wave that arrives last adds the partials in split order (its own from registers), adds bias and residual, rounds and stores
+//     the bf16 row segment AND the (sum, sum of squares) of what it stored for each of its rows -- the LayerNorm statistics of
+//     the new residual stream, as 32-column partials (the mechanism of mmtg_wgrad_group, csrc/wgrad.hip);
+//   * modes 0 / 1 ("LN-fold"): the product that consumes a LayerNorm takes the UN-normalised rows and applies the LayerNorm
+//     algebraically: LN(x) W = rstd (x W' - mu c) + b' with W' = gamma (.) W (a bf16 copy, mmtg_ln_fold_weights), c_n = sum_k
+//     W'_kn, b' = b + beta W; mu / rstd come from the statistics partials.  Decode has no backward: nothing else needs LN(x).
+// Tile = 64 x 64 per 256-thread workgroup (2 x 2 waves of 32 x 32), K-contiguous operands, 4-deep LDS-DMA ring, counted vmcnt
+// (the main loop of gemm_dma_kernel<false, false, 64, 64, 2, 2, 4>, gemm.hip).
+constexpr int DG_NP = 32;     // statistics partials per row the buffers are sized for (n_embd <= 1024: one per 32 columns)
+
+// Partial tiles cross XCDs: their stores and loads carry the agent-scope bit (sc1: write through / always miss; cache-policy
+// operand 16 of the raw buffer builtins) instead of an L2-wide write-back + invalidate per wave (csrc/wgrad.hip).  Compiler-visible
+// loads: every other split's pieces are requested back to back and waited for once.
+__device__ __forceinline__ void dg_st4_agent(__amdgpu_buffer_rsrc_t r, int byte_off, const f32x4& v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, byte_off, 0, 16);
+}
+__device__ __forceinline__ f32x4 dg_ld4_agent(__amdgpu_buffer_rsrc_t r, int byte_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 16));
+}
+
+struct DgArgs {
+    const bf16* A; const bf16* W; void* C;
+    long lda, ldw, ldc, ldr;
+    int M, N, K, kper, splits, ntiles, tiles_n;
+    int bytesA, bytesW;
+    const float* bias; const float* colsum; const float* stats_in; int np_in; float eps; float inv_k;
+    int act, out_f32;
+    const bf16* resid; float* stats_out; int np_out;
+    float* ws; unsigned* cnt; int ws_bytes;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void decode_gemm_kernel(DgArgs p) {
+    constexpr int TB = 64, NW = 4, NBUF = 4, BK = 64, NB = 2;
+    constexpr int TA = TB * 128, STAGE = 2 * TA;
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // NBUF stages | row statistics
+    float* const smu = reinterpret_cast<float*>(smem + NBUF * STAGE);
+    float* const srs = smu + TB;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, l15 = lane & 15;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int bid = blockIdx.x;
+    const int split = bid / p.ntiles, t = bid - split * p.ntiles;
+    const int m0 = (t / p.tiles_n) * TB, n0 = (t % p.tiles_n) * TB;
+    const int kbeg = split * p.kper;
+    const int klen = max(0, min(p.K, kbeg + p.kper) - kbeg);
+    const int nk = (klen + BK - 1) / BK, nk_full = klen / BK;
+    // LN-fold: this tile's 64 rows of statistics partials are requested now and reduced after the K loop
+    float s1 = 0.f, s2 = 0.f;
+    f32x4 sp[MODE == 2 ? 1 : DG_NP / 2];
+    if constexpr (MODE != 2) {
+        if (tid < TB) {
+            const int m = min(m0 + tid, p.M - 1);
+            const f32x4* src = reinterpret_cast<const f32x4*>(p.stats_in + (long)m * DG_NP * 2);
+#pragma unroll
+            for (int i = 0; i < DG_NP / 2; ++i) sp[i] = i * 2 < p.np_in ? src[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.A), 0, p.bytesA, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.W), 0, p.bytesW, 0x00020000);
+    int sa = (int)(((long)m0 * p.lda + kbeg) * 2), sb = (int)(((long)n0 * p.ldw + kbeg) * 2);
+    int va[NB], vb[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        va[i] = dma_voff<false, TB>(p.lda, m0, p.M, BK, wave + NW * i, lane);
+        vb[i] = dma_voff<false, TB>(p.ldw, n0, p.N, BK, wave + NW * i, lane);
+    }
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#define DG_ISSUE(tt)                                                                                                   \
+    do {                                                                                                               \
+        char* st_ = smem + ((tt) % NBUF) * STAGE;                                                                      \
+        const bool full_ = (tt) < nk_full, live_ = (tt) < nk;                                                          \
+        const int krem_ = klen - (tt) * BK;                                                                            \
+        _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                                               \
+            const int oa_ = !live_ ? OOB : full_ ? va[i] : dma_voff<false, TB>(p.lda, m0, p.M, krem_, wave + NW * i, lane); \
+            const int ob_ = !live_ ? OOB : full_ ? vb[i] : dma_voff<false, TB>(p.ldw, n0, p.N, krem_, wave + NW * i, lane); \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, LDS_PTR(void, st_ + (wave + NW * i) * 1024), 16, oa_, live_ ? sa : 0, 0, 0); \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, LDS_PTR(void, st_ + TA + (wave + NW * i) * 1024), 16, ob_, live_ ? sb : 0, 0, 0); \
+        }                                                                                                              \
+        sa += BK * 2;                                                                                                  \
+        sb += BK * 2;                                                                                                  \
+    } while (0)
+#pragma unroll
+    for (int t0 = 0; t0 < NBUF - 1; ++t0) DG_ISSUE(t0);
+    for (int kt = 0; kt < nk; ++kt) {
+        wait_vmcnt<(NBUF - 2) * 2 * NB>();         // my part of tile kt has landed (two younger tiles may be in flight)
+        __builtin_amdgcn_s_barrier();              // ... and everyone's; every wave is done reading tile kt - 1
+        DG_ISSUE(kt + NBUF - 1);
+        const char* tA = smem + (kt % NBUF) * STAGE;
+        const char* tB = tA + TA;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                fa[i] = ld_frag_kc<bf16>(tA, wm * 32 + i * 16 + l15, kk, g);
+                fb[i] = ld_frag_kc<bf16>(tB, wn * 32 + i * 16 + l15, kk, g);
+            }
+            // (swapped operands: a lane holds 4 consecutive columns of row l15)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) mma16(fb[j], fa[i], acc[i][j]);
+        }
+    }
+#undef DG_ISSUE
+    wait_vmcnt<0>();                               // the zero-fill tail requests
+    const int mw0 = m0 + wm * 32, nw0 = n0 + wn * 32;
+    if constexpr (MODE != 2) {
+        // ---- LN-fold epilogue
+        if (tid < TB) {
+#pragma unroll
+            for (int i = 0; i < DG_NP / 2; ++i) { s1 += sp[i][0] + sp[i][2]; s2 += sp[i][1] + sp[i][3]; }
+            const float mu = s1 * p.inv_k;
+            const float var = fmaxf(s2 * p.inv_k - mu * mu, 0.f);
+            smu[tid] = mu;
+            srs[tid] = rsqrtf(var + p.eps);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int rl = wm * 32 + i * 16 + l15, m = m0 + rl;
+            const float mu = smu[rl], rs = srs[rl];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = nw0 + j * 16 + 4 * g;
+                if (m >= p.M || n >= p.N) continue;
+                const f32x4 c4 = *reinterpret_cast<const f32x4*>(p.colsum + n);
+                f32x4 v;
+                if constexpr (MODE == 1) {
+                    // slab `split` of the consumer's fp32 input: the mean term rides on slab 0, the bias is the consumer's
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = rs * acc[i][j][r] - (split == 0 ? rs * mu * c4[r] : 0.f);
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + ((long)split * p.M + m) * p.ldc + n) = v;
+                } else {
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        v[r] = rs * (acc[i][j][r] - mu * c4[r]) + b4[r];
+                        if (p.act == MMTG_EPI_GELU) v[r] = gelu_new_t<bf16>(v[r]);
+                    }
+                    if (p.out_f32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n) = v;
+                    else {
+                        const bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                        *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(p.C) + (long)m * p.ldc + n) = o;
+                    }
+                }
+            }
+        }
+    } else {
+        // ---- split-K reduced by the last-arriving wave (csrc/wgrad.hip), + bias + residual + row statistics
+        const int S = p.splits;
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(p.ws, 0, p.ws_bytes, 0x00020000);
+        const int slot0 = (t * S * (TB * TB) + wave * 1024 + lane * 4) * 4;        // byte offset of my lane in slot (t, 0)
+        if (S > 1) {
+            const int mine = slot0 + split * (TB * TB * 4);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) dg_st4_agent(rw, mine + (i * 2 + j) * 1024, acc[i][j]);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every write-through store has been acknowledged
+            unsigned* const cnt = p.cnt + (long)t * NW + wave;
+            unsigned old = 0;
+            if (lane == 0) old = atomicAdd(cnt, 1u);
+            old = __builtin_amdgcn_readfirstlane(old);
+            if (old != (unsigned)(S - 1)) return;
+            if (lane == 0) *cnt = 0u;
+        }
+        // every split's partial (my own slot included: statically indexed registers, no scratch), all requested back to back:
+        // one memory round trip for the whole reduction
+        f32x4 prt[8][4];
+#pragma unroll
+        for (int s_ = 0; s_ < 8; ++s_) {
+            const int se = s_ < S ? s_ : split;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) prt[s_][q] = S > 1 ? dg_ld4_agent(rw, slot0 + se * (TB * TB * 4) + q * 1024) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = mw0 + i * 16 + l15;
+            float r1 = 0.f, r2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = nw0 + j * 16 + 4 * g;
+                f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s_ = 0; s_ < 8; ++s_) {                  // split order; mine from registers
+                    const f32x4 v = s_ == split ? acc[i][j] : prt[s_][i * 2 + j];
+                    if (s_ < S) sum += v;
+                }
+                if (m < p.M && n < p.N) {
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + n);
+                    const bf16x4 x4 = *reinterpret_cast<const bf16x4*>(p.resid + (long)m * p.ldr + n);
+                    bf16x4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        o[r] = (bf16)(sum[r] + b4[r] + (float)x4[r]);
+                        const float f = (float)o[r];
+                        r1 += f;
+                        r2 += f * f;
+                    }
+                    *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(p.C) + (long)m * p.ldc + n) = o;
+                }
+            }
+            // the row's 32 columns of this wave tile live in the four lane groups g: fold them
+            r1 += __shfl_xor(r1, 16, 64); r2 += __shfl_xor(r2, 16, 64);
+            r1 += __shfl_xor(r1, 32, 64); r2 += __shfl_xor(r2, 32, 64);
+            if (g == 0 && m < p.M && nw0 < p.N) {
+                float* dst = p.stats_out + ((long)m * DG_NP + (nw0 >> 5)) * 2;
+                dst[0] = r1;
+                dst[1] = r2;
+            }
+        }
+    }
+}
+
+// W'[n, k] = gamma[k] W[n, k] (bf16), c[n] = sum_k W'[n, k] (of the ROUNDED values: what the product will multiply),
+// bf[n] = bias[n] + sum_k beta[k] W[n, k]: one wave per output row
+__global__ __launch_bounds__(256) void ln_fold_kernel(const bf16* __restrict__ W, long ldw, const float* __restrict__ gamma,
+        const float* __restrict__ beta, const float* __restrict__ bias, bf16* __restrict__ Wf, float* __restrict__ c,
+        float* __restrict__ bf, int N, int K) {
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (n >= N) return;
+    float sc = 0.f, sb = 0.f;
+    for (int k = lane * 8; k < K; k += 512) {
+        const bf16x8 w = *reinterpret_cast<const bf16x8*>(W + (long)n * ldw + k);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            o[e] = (bf16)(gamma[k + e] * (float)w[e]);
+            sc += (float)o[e];
+            sb += beta[k + e] * (float)w[e];
+        }
+        *reinterpret_cast<bf16x8*>(Wf + (long)n * ldw + k) = o;
+    }
+    sc = wave_sum(sc);
+    sb = wave_sum(sb);
+    if (lane == 0) { c[n] = sc; bf[n] = (bias ? bias[n] : 0.f) + sb; }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void decode_embed_add_kernel(const T* __restrict__ g, const T* __restrict__ wpe,
         const T* __restrict__ wte, const long long* __restrict__ type_ids, const int* __restrict__ pos_ptr,
-        T* __restrict__ h, int D) {
+        T* __restrict__ h, int D, float* __restrict__ stats) {
+    __shared__ float red[8];
     const int b = blockIdx.x, pos = *pos_ptr;
     const long long ty = type_ids[b];
-    for (int d = threadIdx.x; d < D; d += 256)
-        h[(long)b * D + d] = (T)((float)g[(long)b * D + d] + (float)wpe[(long)pos * D + d] + (float)wte[ty * D + d]);
+    float s1 = 0.f, s2 = 0.f;
+    for (int d = threadIdx.x; d < D; d += 256) {
+        const T o = (T)((float)g[(long)b * D + d] + (float)wpe[(long)pos * D + d] + (float)wte[ty * D + d]);
+        h[(long)b * D + d] = o;
+        s1 += (float)o;
+        s2 += (float)o * (float)o;
+    }
+    if (stats) {        // LayerNorm statistics of the row as stored (fused decode path): partial 0 carries all of it
+        s1 = wave_sum(s1);
+        s2 = wave_sum(s2);
+        if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = s1; red[4 + (threadIdx.x >> 6)] = s2; }
+        __syncthreads();
+        float* dst = stats + (long)b * DG_NP * 2;
+        if (threadIdx.x == 0) { dst[0] = red[0] + red[1] + red[2] + red[3]; dst[1] = red[4] + red[5] + red[6] + red[7]; }
+        else if (threadIdx.x < DG_NP * 2 && threadIdx.x >= 2) dst[threadIdx.x] = 0.f;
+    }
 }
 
 // One wave per (b, head): append this token's K/V to the cache, then attend over keys 0..pos.
@@ -609,14 +878,14 @@ extern "C" int mmtg_decode_embed(int dtype, const void* table, const long long* 
 }
 
 extern "C" int mmtg_decode_embed_add(int dtype, const void* g, const void* wpe, const void* wte, const long long* type_ids,
-                                     const int* pos_ptr, void* h, int B, int D, void* stream) {
+                                     const int* pos_ptr, void* h, int B, int D, float* stats, void* stream) {
     MMTG_REQUIRE(g && wpe && wte && type_ids && pos_ptr && h && B > 0 && D > 0, "decode_embed_add: bad args");
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(MMTG_PROF_DECODE, s, 2.0 * B * D, (dtype == MMTG_F32 ? 16.0 : 8.0) * B * D);
     if (dtype == MMTG_F32)
-        hipLaunchKernelGGL(decode_embed_add_kernel<float>, dim3(B), dim3(256), 0, s, (const float*)g, (const float*)wpe, (const float*)wte, type_ids, pos_ptr, (float*)h, D);
+        hipLaunchKernelGGL(decode_embed_add_kernel<float>, dim3(B), dim3(256), 0, s, (const float*)g, (const float*)wpe, (const float*)wte, type_ids, pos_ptr, (float*)h, D, stats);
     else if (dtype == MMTG_BF16)
-        hipLaunchKernelGGL(decode_embed_add_kernel<bf16>, dim3(B), dim3(256), 0, s, (const bf16*)g, (const bf16*)wpe, (const bf16*)wte, type_ids, pos_ptr, (bf16*)h, D);
+        hipLaunchKernelGGL(decode_embed_add_kernel<bf16>, dim3(B), dim3(256), 0, s, (const bf16*)g, (const bf16*)wpe, (const bf16*)wte, type_ids, pos_ptr, (bf16*)h, D, stats);
     else MMTG_FAIL(MMTG_ERR_BAD_ARG, "decode_embed_add: bad dtype");
     MMTG_LAUNCH_CHECK("decode_embed_add");
     return MMTG_OK;
@@ -701,5 +970,72 @@ extern "C" int mmtg_decode_advance(int* pos_ptr, void* stream) {
     MMTG_REQUIRE(pos_ptr, "decode_advance: null pointer");
     hipLaunchKernelGGL(decode_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, pos_ptr);
     MMTG_LAUNCH_CHECK("decode_advance");
+    return MMTG_OK;
+}
+
+extern "C" int mmtg_ln_fold_weights(const void* W, long ldw, const float* gamma, const float* beta, const float* bias, void* Wf,
+                                    float* colsum, float* bias_f, int N, int K, void* stream) {
+    MMTG_REQUIRE(W && gamma && beta && Wf && colsum && bias_f && N > 0 && K > 0 && K % 8 == 0 && ldw % 8 == 0 && ldw >= K,
+                 "ln_fold_weights: bad arguments (K, ldw multiples of 8)");
+    MMTG_REQUIRE(MMTG_ALIGNED16(W) && MMTG_ALIGNED16(Wf), "ln_fold_weights: 16-byte alignment");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(MMTG_PROF_MISC, s, 3.0 * N * (double)K, 4.0 * N * (double)K);
+    hipLaunchKernelGGL(ln_fold_kernel, dim3(cdiv(N, 4)), dim3(256), 0, s, (const bf16*)W, ldw, gamma, beta, bias, (bf16*)Wf, colsum, bias_f, N, K);
+    MMTG_LAUNCH_CHECK("ln_fold_weights");
+    return MMTG_OK;
+}
+
+extern "C" int mmtg_decode_gemm(int mode, int M, int N, int K, const void* A, long lda, const void* W, long ldw, void* C, long ldc,
+                                const float* bias, const float* colsum, const float* stats_in, int np_in, float eps, int act,
+                                int out_f32, const void* resid, long ldr, float* stats_out, int splits, float* ws, long ws_floats,
+                                unsigned* counters, long n_counters, void* stream) {
+    MMTG_REQUIRE(mode >= 0 && mode <= 2, "decode_gemm: mode 0 (LN-fold), 1 (LN-fold slabs) or 2 (in-kernel split-K reduce)");
+    MMTG_REQUIRE(M > 0 && N > 0 && K > 0 && A && W && C, "decode_gemm: bad arguments");
+    MMTG_REQUIRE(K % 8 == 0 && lda % 8 == 0 && ldw % 8 == 0 && N % 4 == 0 && ldc % 4 == 0, "decode_gemm: K, lda, ldw multiples of 8; N, ldc of 4");
+    MMTG_REQUIRE(MMTG_ALIGNED16(A) && MMTG_ALIGNED16(W) && MMTG_ALIGNED16(C), "decode_gemm: 16-byte alignment");
+    if (splits < 1) splits = 1;
+    DgArgs a;
+    memset(&a, 0, sizeof(a));
+    a.A = (const bf16*)A; a.W = (const bf16*)W; a.C = C; a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr;
+    a.M = M; a.N = N; a.K = K;
+    a.kper = cdiv(cdiv(K, splits), 64) * 64;
+    a.splits = cdiv(K, a.kper);
+    a.tiles_n = cdiv(N, 64);
+    a.ntiles = cdiv(M, 64) * a.tiles_n;
+    const long bytesA = ((long)(M - 1) * lda + K) * 2, bytesW = ((long)(N - 1) * ldw + K) * 2;
+    MMTG_REQUIRE(bytesA < 0x7FFFFF00L && bytesW < 0x7FFFFF00L, "decode_gemm: operands must stay below 2 GiB");
+    a.bytesA = (int)bytesA; a.bytesW = (int)bytesW;
+    a.bias = bias; a.colsum = colsum; a.stats_in = stats_in; a.np_in = np_in; a.eps = eps; a.inv_k = 1.0f / (float)K;
+    a.act = act; a.out_f32 = out_f32; a.resid = (const bf16*)resid; a.stats_out = stats_out; a.ws = ws; a.cnt = counters;
+    a.ws_bytes = (int)(ws_floats < (1L << 29) ? ws_floats * 4 : 0x7FFFFFF0L);
+    if (mode != 2) {
+        MMTG_REQUIRE(colsum && stats_in && np_in >= 1 && np_in <= DG_NP && MMTG_ALIGNED16(stats_in) && MMTG_ALIGNED16(colsum),
+                     "decode_gemm: LN-fold needs the weight column sums and the row statistics ([M][%d][2] floats, np_in partials)", DG_NP);
+        MMTG_REQUIRE(mode == 1 || (bias && MMTG_ALIGNED16(bias) && a.splits == 1), "decode_gemm: mode 0 is a single K slice with the folded bias");
+        MMTG_REQUIRE(mode == 0 || out_f32 == 1, "decode_gemm: mode 1 writes fp32 slabs [splits][M][ldc]");
+        MMTG_REQUIRE(act == MMTG_EPI_NONE || act == MMTG_EPI_GELU, "decode_gemm: activation NONE or GELU");
+    } else {
+        MMTG_REQUIRE(bias && resid && stats_out && N % 32 == 0 && N / 32 <= DG_NP && ldr % 4 == 0 && MMTG_ALIGNED16(bias),
+                     "decode_gemm: the reduce mode needs bias, residual and the statistics output; N a multiple of 32, at most %d", 32 * DG_NP);
+        MMTG_REQUIRE(a.splits <= 8, "decode_gemm: at most 8 K splits in the reduce mode");
+        MMTG_REQUIRE(a.splits == 1 || (ws && counters && ws_floats >= (long)a.ntiles * a.splits * 4096 && n_counters >= (long)a.ntiles * 4),
+                     "decode_gemm: split products need %ld workspace floats and %ld zeroed counters", (long)a.ntiles * a.splits * 4096, (long)a.ntiles * 4);
+    }
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(MMTG_PROF_GEMM_BF16, s, 2.0 * M * N * (double)K, 2.0 * ((double)M * K + (double)N * K) + (out_f32 ? 4.0 : 2.0) * (double)M * N);
+    const size_t shm = 4 * 2 * 64 * 128 + 2 * 64 * 4;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)decode_gemm_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess ||
+            hipFuncSetAttribute((const void*)decode_gemm_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess ||
+            hipFuncSetAttribute((const void*)decode_gemm_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
+            MMTG_FAIL(MMTG_ERR_HIP, "decode_gemm: cannot raise dynamic LDS");
+        attr_done = true;
+    }
+    const dim3 grid(a.ntiles * a.splits), block(256);
+    if (mode == 0) hipLaunchKernelGGL(decode_gemm_kernel<0>, grid, block, shm, s, a);
+    else if (mode == 1) hipLaunchKernelGGL(decode_gemm_kernel<1>, grid, block, shm, s, a);
+    else hipLaunchKernelGGL(decode_gemm_kernel<2>, grid, block, shm, s, a);
+    MMTG_LAUNCH_CHECK("decode_gemm");
     return MMTG_OK;
 }

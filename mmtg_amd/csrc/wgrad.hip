@@ -434,8 +434,8 @@ extern "C" int mmtg_wgrad_group(int config, int n, const mmtg_wgrad_problem* pro
     if (ablate) {
         static bool abl_done = false;
         if (!abl_done) {
-            hipFuncSetAttribute((const void*)wgrad_group_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-            hipFuncSetAttribute((const void*)wgrad_group_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+            (void)hipFuncSetAttribute((const void*)wgrad_group_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+            (void)hipFuncSetAttribute((const void*)wgrad_group_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
             abl_done = true;
         }
         if (ablate == 1) hipLaunchKernelGGL((wgrad_group_kernel<false, 1>), dim3(tiles * splits), dim3(256), shm, s, a);

@@ -90,6 +90,24 @@ class GreedyDecoder:
             if self.fast:
                 slab = max(self.splits[0] * 3 * D, self.splits[1] * D, self.splits[2] * 4 * D, self.splits[3] * D)
                 self.part = torch.empty(slab * B, dtype=torch.float32, device=dev)
+            # Round 3, fused step (5 graph nodes per block instead of 7): split-K products reduced in the kernel by the last-arriving
+            # wave (+ bias + residual + LayerNorm statistics), LayerNorms applied algebraically in the consuming products
+            # (mmtg_decode_gemm).  MMTG_DECODE_FUSED=0 keeps the round-2 products + finish launches.
+            self.fused = (self.fast and os.environ.get("MMTG_DECODE_FUSED", "1") != "0" and D % 64 == 0 and D // 32 <= hip.DG_NP
+                          and self.eng.layout.Vpad % 4 == 0)
+            if self.fused:
+                L, Vp = sh.L, self.eng.layout.Vpad
+                bf = lambda *s_: torch.empty(*s_, dtype=torch.bfloat16, device=dev)
+                f32 = lambda *s_: torch.empty(*s_, dtype=torch.float32, device=dev)
+                self.fq = [(bf(3 * D, D), f32(3 * D), f32(3 * D)) for _ in range(L)]          # gamma-folded c_attn copy, column sums, folded bias
+                self.ffc = [(bf(4 * D, D), f32(4 * D), f32(4 * D)) for _ in range(L)]
+                self.fh = (bf(Vp, D), f32(Vp), f32(Vp))
+                self.st = (torch.zeros(B, hip.DG_NP, 2, dtype=torch.float32, device=dev),
+                           torch.zeros(B, hip.DG_NP, 2, dtype=torch.float32, device=dev))
+                tiles = -(-B // 64) * (D // 64)
+                self.rws = f32(tiles * max(self.splits[1], self.splits[3]) * 4096)
+                self.rcnt = torch.zeros(tiles * 4, dtype=torch.int32, device=dev)
+                self.folds_for = None
         self.pos, self.pos_next = self.pos_pair
         self.uniforms = None
         self.graphs = {}
@@ -129,15 +147,20 @@ class GreedyDecoder:
         eng._fwd(self.x, "decoder.projector_layer1.weight", self.h1, B, "linear",
                  bias=eng.P("decoder.projector_layer1.bias"), epi=hip.EPI_TANH)
         eng._fwd(self.h1, "decoder.projector_layer2.weight", self.h, B, "linear", bias=eng.P("decoder.projector_layer2.bias"))
-        hip.decode_embed_add(self.h, eng.W(pre + "wpe.weight"), eng.W(pre + "wte.weight"), self.types, self.pos, self.h, B, D)
+        fused = getattr(self, "fused", False)
+        hip.decode_embed_add(self.h, eng.W(pre + "wpe.weight"), eng.W(pre + "wte.weight"), self.types, self.pos, self.h, B, D,
+                             stats=self.st[0] if fused else None)
         hcur, hnext = self.h, self.h2
-        if self.fast:
+        if fused:
+            self._layers_fused(hcur, hnext, with_head)
+        elif self.fast:
             self._layers_split(hcur, hnext, with_head)
         else:
             self._layers_plain(hcur, hnext, with_head)
         if with_head:
             Vp = eng.layout.Vpad
-            hip.gemm(self.a, eng.Wp("wte"), self.logits, B, Vp, D, transB=True, ldb=D, out_f32=True)
+            if not fused:
+                hip.gemm(self.a, eng.Wp("wte"), self.logits, B, Vp, D, transB=True, ldb=D, out_f32=True)
             if top_k == 1 and top_p == 0.0:
                 hip.decode_select(self.logits, Vp, min(sh.V, 13317), self.seq, self.pos, sh.P, sent, temperature, rep, B,
                                   pos_next=self.pos_next)
@@ -210,6 +233,54 @@ class GreedyDecoder:
             self._split(self.g, p + "mlp.c_proj.weight", hcur, s2, eng.P(p + "mlp.c_proj.bias"),
                         epi=hip.EPI_RESID, aux=hnext, ldaux=D, **ln)
 
+    def _refresh_folds(self):
+        """gamma-folded weight copies, their column sums and folded biases for the LN-fold products (once per generation: the
+        weights may have been stepped)."""
+        eng, sh = self.eng, self.eng.sh
+        D = sh.D
+        pre = "decoder.gpt2.transformer."
+        for l in range(sh.L):
+            p = f"{pre}h.{l}."
+            wf, c, b = self.fq[l]
+            hip.ln_fold_weights(eng.Wt(p + "attn.c_attn.weight"), eng.P(p + "ln_1.weight"), eng.P(p + "ln_1.bias"),
+                                eng.P(p + "attn.c_attn.bias"), wf, c, b, 3 * D, D)
+            wf, c, b = self.ffc[l]
+            hip.ln_fold_weights(eng.Wt(p + "mlp.c_fc.weight"), eng.P(p + "ln_2.weight"), eng.P(p + "ln_2.bias"),
+                                eng.P(p + "mlp.c_fc.bias"), wf, c, b, 4 * D, D)
+        wf, c, b = self.fh
+        hip.ln_fold_weights(eng.Wp("wte"), eng.P(pre + "ln_f.weight"), eng.P(pre + "ln_f.bias"), None, wf, c, b, eng.layout.Vpad, D)
+
+    def _layers_fused(self, hcur, hnext, with_head):
+        """bf16 fused path: per block c_attn (LN-fold, split-K slabs summed by the attention kernel) -> attention -> attn c_proj
+        (split-K reduced in the kernel + bias + residual + statistics) -> c_fc (LN-fold + GELU) -> mlp c_proj (as c_proj); the
+        head is an LN-fold product writing fp32 logits.  The residual stream alternates between two buffers and so do its
+        LayerNorm statistics."""
+        eng, sh, B = self.eng, self.eng.sh, self.B
+        D = sh.D
+        pre = "decoder.gpt2.transformer."
+        sq, sp, _, s2 = self.splits
+        NP = D // 32
+        kper = -(-(-(-D // sq)) // 64) * 64          # K slices are whole 64-deep tiles: the product writes ceil(D / kper) slabs
+        nslab = -(-D // kper)
+        x, xo = hcur, hnext
+        st, sto = self.st
+        for l in range(sh.L):
+            p = f"{pre}h.{l}."
+            wf, c, bq = self.fq[l]
+            hip.decode_gemm(1, x, wf, self.part, B, 3 * D, D, colsum=c, stats_in=st, np_in=NP, eps=sh.eps, out_f32=True, splits=sq)
+            hip.decode_attn_split(self.part, nslab, bq, self.kc[l], self.vc[l], self.keep, self.pos,
+                                  self.ctx, B, sh.nH, 64, self.Tmax)
+            hip.decode_gemm(2, self.ctx, eng.Wt(p + "attn.c_proj.weight"), xo, B, D, D, bias=eng.P(p + "attn.c_proj.bias"), resid=x,
+                            stats_out=sto, splits=sp, ws=self.rws, counters=self.rcnt)
+            wf, c, bfc = self.ffc[l]
+            hip.decode_gemm(0, xo, wf, self.g, B, 4 * D, D, bias=bfc, colsum=c, stats_in=sto, np_in=NP, eps=sh.eps, act=hip.EPI_GELU)
+            hip.decode_gemm(2, self.g, eng.Wt(p + "mlp.c_proj.weight"), x, B, D, 4 * D, bias=eng.P(p + "mlp.c_proj.bias"), resid=xo,
+                            stats_out=st, splits=s2, ws=self.rws, counters=self.rcnt)
+        if with_head:
+            wf, c, bh = self.fh
+            hip.decode_gemm(0, x, wf, self.logits, B, eng.layout.Vpad, D, bias=bh, colsum=c, stats_in=st, np_in=NP, eps=sh.eps,
+                            out_f32=True)
+
     def _run_step(self, with_head, parity):
         if not self.use_graph:
             self._step(with_head, parity)
@@ -265,6 +336,9 @@ class GreedyDecoder:
                 ch.uniforms.copy_(blk)
         eng.invalidate_copies()
         self.eng.refresh_copies()
+        for d in ([self] + self.children):          # (a lane has its own folded copies: they are part of its scratch)
+            if getattr(d, "fused", False):
+                d._refresh_folds()
         a = eng.forward(batch, train_flag=False, training=False, encode_only=True)
         self.c.copy_(a["c"])
         self.seq.zero_()

@@ -13,7 +13,7 @@ import os
 import torch
 
 F32, BF16 = 0, 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 EPI_NONE, EPI_GELU, EPI_TANH, EPI_RESID, EPI_DGELU, EPI_DTANH, EPI_ATOMIC, EPI_ROWDOT = range(8)
 GEMM_NO_TR, GEMM_REGSTAGE, GEMM_SKINNY, GEMM_NO_SKINNY, GEMM_WIDE, GEMM_NO_WIDE = 1, 2, 4, 8, 16, 32
 GEMM_PERSIST, GEMM_NO_PERSIST, GEMM_ROW_ORDER, GEMM_OCC4, GEMM_NO_OCC4, GEMM_COL_BLOCK, GEMM_P256, GEMM_NO_P8, GEMM_P8 = 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384
@@ -69,7 +69,9 @@ _SIGS = {
     "mmtg_transpose_batch": ([_i, _vp, _vp, _vp, _i, _i, _i, _vp], _i),
     "mmtg_logits_process_argmax": ([_vp, _l, _i, _vp, _l, _vp, _f, _f, _vp, _i, _vp], _i),
     "mmtg_decode_embed": ([_i, _vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
-    "mmtg_decode_embed_add": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp], _i),
+    "mmtg_decode_embed_add": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp], _i),
+    "mmtg_decode_gemm": ([_i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _vp, _vp, _vp, _i, _f, _i, _i, _vp, _l, _vp, _i, _vp, _l, _vp, _l, _vp], _i),
+    "mmtg_ln_fold_weights": ([_vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp], _i),
     "mmtg_decode_attn": ([_i, _vp, _vp, _vp, _vp, _l, _vp, _vp, _i, _i, _i, _i, _vp], _i),
     "mmtg_decode_attn_split": ([_i, _vp, _i, _vp, _vp, _vp, _vp, _l, _vp, _vp, _i, _i, _i, _i, _vp], _i),
     "mmtg_logits_process_sample": ([_vp, _l, _i, _vp, _l, _vp, _f, _f, _i, _f, _vp, _vp, _vp, _i, _vp], _i),
@@ -437,9 +439,27 @@ def decode_embed(table, seq, c, x, pos, tpw_type, tpw_mask, type_out, keep, B, P
                                    max_sent_num, _stream()), "decode_embed")
 
 
-def decode_embed_add(g, wpe, wte, type_ids, pos, h, B, D):
-    _check(lib().mmtg_decode_embed_add(dt(g), _p(g), _p(wpe), _p(wte), _p(type_ids), _p(pos), _p(h), B, D, _stream()),
+def decode_embed_add(g, wpe, wte, type_ids, pos, h, B, D, stats=None):
+    _check(lib().mmtg_decode_embed_add(dt(g), _p(g), _p(wpe), _p(wte), _p(type_ids), _p(pos), _p(h), B, D, _p(stats), _stream()),
            "decode_embed_add")
+
+
+DG_NP = 32      # statistics partials per row (include/mmtg_hip.h, mmtg_decode_gemm)
+
+
+def decode_gemm(mode, A, W, C_, M, N, K, bias=None, colsum=None, stats_in=None, np_in=0, eps=1e-5, act=EPI_NONE, out_f32=False,
+                resid=None, stats_out=None, splits=1, ws=None, counters=None, lda=None, ldw=None, ldc=None, ldr=None):
+    """The fused products of the decode step (include/mmtg_hip.h, mmtg_decode_gemm)."""
+    _check(lib().mmtg_decode_gemm(int(mode), M, N, K, _p(A), K if lda is None else lda, _p(W), K if ldw is None else ldw, _p(C_),
+                                  N if ldc is None else ldc, _p(bias), _p(colsum), _p(stats_in), int(np_in), float(eps), int(act),
+                                  int(out_f32), _p(resid), N if ldr is None else ldr, _p(stats_out), int(splits), _p(ws),
+                                  0 if ws is None else ws.numel(), _p(counters), 0 if counters is None else counters.numel(),
+                                  _stream()), "decode_gemm")
+
+
+def ln_fold_weights(W, gamma, beta, bias, Wf, colsum, bias_f, N, K, ldw=None):
+    _check(lib().mmtg_ln_fold_weights(_p(W), K if ldw is None else ldw, _p(gamma), _p(beta), _p(bias), _p(Wf), _p(colsum), _p(bias_f),
+                                      N, K, _stream()), "ln_fold_weights")
 
 
 def decode_attn(qkv, kcache, vcache, keep, pos, out, B, nH, dh, Tmax):

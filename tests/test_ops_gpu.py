@@ -1009,6 +1009,81 @@ def test_wgrad_group_repeated_launches_stay_bit_equal(config):
 
 
 
+@pytest.mark.parametrize("M", [256, 200, 32])
+def test_decode_gemm_ln_fold_and_in_kernel_reduce(M):
+    """mmtg_decode_gemm + mmtg_ln_fold_weights (the fused decode step): (a) the folded operands against their definition;
+    (b) mode 0 -- LN(x) W^T + b applied algebraically from row-statistics partials -- against the explicit LayerNorm in fp32 on
+    the same bf16 operands (bf16 output rounding + the bf16 rounding of gamma (.) W), with GELU and with fp32 output; (c) mode 1
+    slabs + folded bias = mode 0; (d) mode 2: split-K reduced in the kernel + bias + residual, bit-equal between runs and
+    between split counts' own repeats, counters left zeroed, and its statistics partials = sums over the STORED bf16 rows."""
+    K, N = 768, 2304
+    NP = hip.DG_NP
+    g = torch.Generator().manual_seed(9)
+    x = (torch.randn(M, K, generator=g) * 2.0 + torch.randn(M, 1, generator=g)).to(torch.bfloat16)
+    x[:, 5] *= 20.0                                        # an outlier channel, as GPT-2's residual stream has
+    W = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16)
+    gamma, beta = 1.0 + 0.1 * torch.randn(K, generator=g), 0.1 * torch.randn(K, generator=g)
+    bias = 0.1 * torch.randn(N, generator=g)
+    xd, Wd = x.to(DEV), W.to(DEV)
+    Wf = torch.empty(N, K, dtype=torch.bfloat16, device=DEV)
+    c, bf = torch.empty(N, device=DEV), torch.empty(N, device=DEV)
+    hip.ln_fold_weights(Wd, gamma.to(DEV), beta.to(DEV), bias.to(DEV), Wf, c, bf, N, K)
+    Wf_ref = (gamma[None, :] * W.float()).to(torch.bfloat16)
+    assert torch.equal(Wf.cpu(), Wf_ref)
+    close(c, Wf_ref.float().sum(1), torch.float32, K, "colsum")
+    close(bf, bias + W.float() @ beta, torch.float32, K, "folded bias")
+    # statistics partials of x as stored (what the producing kernels emit)
+    xf = x.float()
+    st = torch.zeros(M, NP, 2)
+    st[:, :K // 32, 0] = xf.view(M, K // 32, 32).sum(2)
+    st[:, :K // 32, 1] = (xf * xf).view(M, K // 32, 32).sum(2)
+    std = st.to(DEV)
+    mu, var = xf.mean(1, keepdim=True), xf.var(1, unbiased=False, keepdim=True)
+    ln = (xf - mu) / torch.sqrt(var + 1e-5)
+    ref = (ln * gamma + beta) @ W.float().t() + bias
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    hip.decode_gemm(0, xd, Wf, out, M, N, K, bias=bf, colsum=c, stats_in=std, np_in=K // 32)
+    close(out, ref, torch.bfloat16, K, "LN-fold")
+    out32 = torch.empty(M, N, device=DEV)
+    hip.decode_gemm(0, xd, Wf, out32, M, N, K, bias=bf, colsum=c, stats_in=std, np_in=NP, out_f32=True)
+    exact = ((xf - mu) / torch.sqrt(var + 1e-5)) @ Wf_ref.float().t() + bf.cpu()        # the algebra on the folded operands
+    assert (out32.cpu() - exact).abs().max().item() <= 2e-3 * exact.abs().max().item()
+    outg = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    hip.decode_gemm(0, xd, Wf, outg, M, N, K, bias=bf, colsum=c, stats_in=std, np_in=NP, act=hip.EPI_GELU)
+    close(outg, O.gelu_new(ref), torch.bfloat16, K, "LN-fold + GELU")
+    for S in (2, 3):
+        slabs = torch.full((S, M, N), float("nan"), device=DEV)
+        hip.decode_gemm(1, xd, Wf, slabs, M, N, K, colsum=c, stats_in=std, np_in=NP, out_f32=True, splits=S)
+        assert (slabs.sum(0) + bf - out32).abs().max().item() <= 1e-3 * exact.abs().max().item()
+    # ---- mode 2
+    K2, N2 = 3072, 768
+    A = (torch.randn(M, K2, generator=g) * 0.5).to(torch.bfloat16).to(DEV)
+    W2 = (torch.randn(N2, K2, generator=g) * 0.05).to(torch.bfloat16).to(DEV)
+    b2 = (0.1 * torch.randn(N2, generator=g)).to(DEV)
+    resid = x.to(DEV)
+    ref2 = A.float() @ W2.float().t() + b2 + resid.float()
+    tiles = -(-M // 64) * (N2 // 64)
+    for S in (1, 4, 8):
+        ws = torch.full((tiles * S * 4096,), float("nan"), device=DEV)
+        cnt = torch.zeros(tiles * 4, dtype=torch.int32, device=DEV)
+        outs = []
+        for rep in range(3):
+            xo = torch.full((M, N2), 7.0, dtype=torch.bfloat16, device=DEV)
+            so = torch.full((M, NP, 2), float("nan"), device=DEV)
+            hip.decode_gemm(2, A, W2, xo, M, N2, K2, bias=b2, resid=resid, stats_out=so, splits=S, ws=ws, counters=cnt)
+            assert int(cnt.abs().sum()) == 0
+            outs.append((xo, so))
+        close(outs[0][0], ref2, torch.bfloat16, K2, "reduce S=%d" % S)
+        npo = N2 // 32
+        for xo, so in outs[1:]:
+            assert torch.equal(xo, outs[0][0]) and torch.equal(so[:, :npo], outs[0][1][:, :npo])
+        assert torch.isnan(outs[0][1][:, npo:]).all()               # partials past N / 32 are not touched
+        xs = outs[0][0].float()
+        assert (outs[0][1][:, :npo, 0] - xs.view(M, npo, 32).sum(2)).abs().max().item() <= 1e-3
+        assert (outs[0][1][:, :npo, 1] - (xs * xs).view(M, npo, 32).sum(2)).abs().max().item() <= 1e-2 * (xs * xs).view(M, npo, 32).sum(2).abs().max().item()
+
+
+
 # ------------------------------------------------------------------ generation
 def test_logits_process_argmax():
     B, V, G = 6, 500, 40
