@@ -415,23 +415,16 @@ __global__ __launch_bounds__(256, 2) void decode_gemm_kernel(DgArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, l15 = lane & 15;
     const int wm = wave >> 1, wn = wave & 1;
+    // plain item order: consecutive workgroups = consecutive column tiles of one row tile, dealt round-robin to the 8 XCDs.
+    // (An XCD-contiguous order with the row tiles of a weight panel side by side on one XCD -- the training kernels' order --
+    //  measured 789 vs 728 us per token step here: the step is latency-bound, and spreading a product's first requests over all
+    //  eight L2s matters more than fetching a 96 KB panel once.)
     const int bid = blockIdx.x;
     const int split = bid / p.ntiles, t = bid - split * p.ntiles;
     const int m0 = (t / p.tiles_n) * TB, n0 = (t % p.tiles_n) * TB;
     const int kbeg = split * p.kper;
     const int klen = max(0, min(p.K, kbeg + p.kper) - kbeg);
     const int nk = (klen + BK - 1) / BK, nk_full = klen / BK;
-    // LN-fold: this tile's 64 rows of statistics partials are requested now and reduced after the K loop
-    float s1 = 0.f, s2 = 0.f;
-    f32x4 sp[MODE == 2 ? 1 : DG_NP / 2];
-    if constexpr (MODE != 2) {
-        if (tid < TB) {
-            const int m = min(m0 + tid, p.M - 1);
-            const f32x4* src = reinterpret_cast<const f32x4*>(p.stats_in + (long)m * DG_NP * 2);
-#pragma unroll
-            for (int i = 0; i < DG_NP / 2; ++i) sp[i] = i * 2 < p.np_in ? src[i] : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-    }
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.A), 0, p.bytesA, 0x00020000);
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.W), 0, p.bytesW, 0x00020000);
     int sa = (int)(((long)m0 * p.lda + kbeg) * 2), sb = (int)(((long)n0 * p.ldw + kbeg) * 2);
@@ -462,6 +455,33 @@ __global__ __launch_bounds__(256, 2) void decode_gemm_kernel(DgArgs p) {
     } while (0)
 #pragma unroll
     for (int t0 = 0; t0 < NBUF - 1; ++t0) DG_ISSUE(t0);
+    const int mw0 = m0 + wm * 32, nw0 = n0 + wn * 32;
+    // LN-fold: mu / rstd of the tile's 64 rows from the statistics partials, and this lane's column sums / folded biases, while
+    // the first K tiles are in flight (published to the other waves by the K loop's barriers; consumed in the epilogue)
+    f32x4 c4[2], b4[2];
+    if constexpr (MODE != 2) {
+        if (tid < TB) {
+            const int m = min(m0 + tid, p.M - 1);
+            const f32x4* src = reinterpret_cast<const f32x4*>(p.stats_in + (long)m * DG_NP * 2);
+            f32x4 sp[DG_NP / 2];
+#pragma unroll
+            for (int i = 0; i < DG_NP / 2; ++i) sp[i] = i * 2 < p.np_in ? src[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < DG_NP / 2; ++i) { s1 += sp[i][0] + sp[i][2]; s2 += sp[i][1] + sp[i][3]; }
+            const float mu = s1 * p.inv_k;
+            const float var = fmaxf(s2 * p.inv_k - mu * mu, 0.f);
+            smu[tid] = mu;
+            srs[tid] = rsqrtf(var + p.eps);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // stored before this wave passes the first K-loop barrier
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = min(nw0 + j * 16 + 4 * g, p.N - 4);
+            c4[j] = *reinterpret_cast<const f32x4*>(p.colsum + n);
+            b4[j] = MODE == 0 ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
     for (int kt = 0; kt < nk; ++kt) {
         wait_vmcnt<(NBUF - 2) * 2 * NB>();         // my part of tile kt has landed (two younger tiles may be in flight)
         __builtin_amdgcn_s_barrier();              // ... and everyone's; every wave is done reading tile kt - 1
@@ -485,18 +505,9 @@ __global__ __launch_bounds__(256, 2) void decode_gemm_kernel(DgArgs p) {
     }
 #undef DG_ISSUE
     wait_vmcnt<0>();                               // the zero-fill tail requests
-    const int mw0 = m0 + wm * 32, nw0 = n0 + wn * 32;
     if constexpr (MODE != 2) {
         // ---- LN-fold epilogue
-        if (tid < TB) {
-#pragma unroll
-            for (int i = 0; i < DG_NP / 2; ++i) { s1 += sp[i][0] + sp[i][2]; s2 += sp[i][1] + sp[i][3]; }
-            const float mu = s1 * p.inv_k;
-            const float var = fmaxf(s2 * p.inv_k - mu * mu, 0.f);
-            smu[tid] = mu;
-            srs[tid] = rsqrtf(var + p.eps);
-        }
-        __syncthreads();
+        if (nk == 0) __syncthreads();              // (no K loop barrier has published smu / srs)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int rl = wm * 32 + i * 16 + l15, m = m0 + rl;
@@ -505,18 +516,16 @@ __global__ __launch_bounds__(256, 2) void decode_gemm_kernel(DgArgs p) {
             for (int j = 0; j < 2; ++j) {
                 const int n = nw0 + j * 16 + 4 * g;
                 if (m >= p.M || n >= p.N) continue;
-                const f32x4 c4 = *reinterpret_cast<const f32x4*>(p.colsum + n);
                 f32x4 v;
                 if constexpr (MODE == 1) {
                     // slab `split` of the consumer's fp32 input: the mean term rides on slab 0, the bias is the consumer's
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = rs * acc[i][j][r] - (split == 0 ? rs * mu * c4[r] : 0.f);
+                    for (int r = 0; r < 4; ++r) v[r] = rs * acc[i][j][r] - (split == 0 ? rs * mu * c4[j][r] : 0.f);
                     *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + ((long)split * p.M + m) * p.ldc + n) = v;
                 } else {
-                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + n);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        v[r] = rs * (acc[i][j][r] - mu * c4[r]) + b4[r];
+                        v[r] = rs * (acc[i][j][r] - mu * c4[j][r]) + b4[j][r];
                         if (p.act == MMTG_EPI_GELU) v[r] = gelu_new_t<bf16>(v[r]);
                     }
                     if (p.out_f32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n) = v;

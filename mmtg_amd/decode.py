@@ -70,7 +70,11 @@ class GreedyDecoder:
             self.kc = [_parent.kc[l, lo:hi] for l in range(sh.L)]
             self.vc = [_parent.vc[l, lo:hi] for l in range(sh.L)]
             self.pos_pair = (_parent.pos_all[0, _lane:_lane + 1], _parent.pos_all[1, _lane:_lane + 1])
-        self.splits = tuple(int(x) for x in os.environ.get("MMTG_DECODE_SPLITS", "2,4,1,8").split(","))
+        # (K slices of c_attn, attn c_proj, c_fc, mlp c_proj.  Fused step -- no finish launches, the reduction runs in the product's
+        #  own tail -- measured at batch 256, us per token step: 2,4,1,4 -> 714-716; 2,3,1,4 -> 715; 2,2,1,4 -> 721; 3,4,1,4 -> 720;
+        #  2,4,1,3 -> 726; 2,4,1,8 -> 728; 2,4,1,6 -> 739; 2,6,1,4 -> 746; 2,4,1,2 -> 751; 4,4,1,4 -> 755; profiles/r03_v8_*)
+        fused_ok = self.eng.dtype == hip.BF16 and not os.environ.get("MMTG_DECODE_PLAIN") and os.environ.get("MMTG_DECODE_FUSED", "1") != "0"
+        self.splits = tuple(int(x) for x in os.environ.get("MMTG_DECODE_SPLITS", "2,4,1,4" if fused_ok else "2,4,1,8").split(","))
         # (measured at batch 256, us per token step: 2,3,2,6 -> 1020; 4,6,3,12 -> 1248; 1,1,1,2 -> 1183; unsplit 1264;
         #  with the one-slice c_fc + fused GELU: 2,3,1,8 -> 940, 2,3,1,6 -> 943, 1,3,1,8 -> 963, 2,3,1,12 -> 1003)
         #  round 2, 64x64 tiles (graph-replayed per-product times, profiles/r02_decode_gemm_tiles.log): 2,4,1,8)
@@ -306,7 +310,10 @@ class GreedyDecoder:
         return how + (", %d row blocks of %d side by side" % (self.lanes, self.B // self.lanes) if self.lanes > 1 else "")
 
     def kernel_name(self):
-        return ("decode token step: split-K gemm_dma_kernel<256x32> weight streaming + decode_attn KV-cache streaming + finish kernels"
+        if getattr(self, "fused", False):
+            return ("decode token step: decode_gemm_kernel<64x64> weight streaming (split-K reduced in the kernel, LayerNorm applied "
+                    "algebraically) + decode_attn KV-cache streaming, 5 graph nodes per block")
+        return ("decode token step: split-K gemm_dma_kernel<64x64> weight streaming + decode_attn KV-cache streaming + finish kernels"
                 if self.fast else "decode token step: training-side kernels per layer")
 
     @torch.no_grad()
