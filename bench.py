@@ -249,11 +249,15 @@ def decode_roofline(args, model, batch, B, Ln, dec, step_us_events):
         except Exception:
             continue
         if m.get("kernel_source_sha") == hip.source_sha() and B == 256 and args.dtype == "bf16":
-            traffic, tsrc = m["hbm_bytes_per_token_step"], os.path.relpath(f, ROOT)
+            if m.get("step") == "unfused" and getattr(dec, "fused", False):
+                # the counter passes only run on the round-2 step (tools/gpu_pmc_decode.sh): not this step's traffic
+                traffic, tsrc = None, os.path.relpath(f, ROOT) + " holds the UNFUSED step's %d bytes per token step; the fused step's counter pass crashes in the profiler" % m["hbm_bytes_per_token_step"]
+            else:
+                traffic, tsrc = m["hbm_bytes_per_token_step"], os.path.relpath(f, ROOT)
             break
     return {"bound": "hbm", "kernel": dec.kernel_name(), "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s",
             "frac": round(ach / 8000.0, 4), "traffic": traffic,
-            "traffic_source": (tsrc + " (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE over every kernel of the token step)") if tsrc else
+            "traffic_source": (tsrc + (" (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE over every kernel of the token step)" if traffic else "")) if tsrc else
                               "none: no profiles/r*_decode_pmc_traffic.json was taken on kernel sources sha %s" % hip.source_sha()[:12],
             "algorithmic_bytes_per_token_step": int(alg), "weights_bytes": int(w_bytes), "kv_bytes_mean": int(kv_bytes),
             "us_per_token_step_hip_events": round(step_us, 2),

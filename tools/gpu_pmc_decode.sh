@@ -7,8 +7,13 @@
 mkdir -p gpurun_out/pmc_decode
 export TMPDIR=/tmp
 R=$(pwd)
+# NOTE (round 3): with the FUSED token step the counter passes die at --decode-len 128 with a host-side segfault inside the
+# profiler's launch interception (first mmtg_decode_gemm mode-2 launch; lengths <= 96, the op test of that kernel and every
+# non-counter run are fine), so the passes measure the round-2 step (MMTG_DECODE_FUSED=0: products + finish launches).  Every
+# pass runs under `timeout`: a counter pass that hangs must not hold the GPU box.
+export MMTG_DECODE_FUSED=0
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc_decode -o $c -- python3 bench.py --mode decode --steps 1 --warmup 1 --no-roofline --no-cpu-baseline --decode-eager > gpurun_out/pmc_decode/$c.log 2>&1
+  timeout 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc_decode -o $c -- python3 bench.py --mode decode --steps 1 --warmup 1 --no-roofline --no-cpu-baseline --decode-eager > gpurun_out/pmc_decode/$c.log 2>&1
 done
 python3 - <<'PY'
 import csv, glob, json, sys
@@ -35,7 +40,8 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
 gens, steps = 2, 143
 read_b = out["FETCH_SIZE"][1] * 1024 * 2 / (gens * steps)
 write_b = out["WRITE_SIZE"][1] * 1024 / (gens * steps)
-res = {"what": "decode token step, batch 256, every kernel of the step (eager launches of the graph's node list)",
+res = {"what": "decode token step, batch 256, every kernel of the ROUND-2 (unfused, MMTG_DECODE_FUSED=0) step (eager launches of the graph's node list)",
+       "step": "unfused",
        "kernel_source_sha": hip.source_sha(), "dispatches_counted": out["FETCH_SIZE"][0],
        "hbm_read_bytes_per_token_step": round(read_b), "hbm_write_bytes_per_token_step": round(write_b),
        "hbm_bytes_per_token_step": round(read_b + write_b),
