@@ -313,3 +313,19 @@ def test_bench_self_launch_reports_a_dead_rank():
     r = _run_bench(["--gpus", "2", "--dry-launch"], env={"MMTG_DRY_FAIL_RANK": "1", "MMTG_BENCH_KILL_GRACE": "2"})
     assert r.returncode != 0
     assert not [ln for ln in r.stdout.splitlines() if ln.strip()]     # no JSON line from a failed job
+
+
+def test_grouped_weight_gradient_split_rule_and_workspace_sizes():
+    """Engine-side rules of the grouped weight-gradient launch (no GPU): one round of the kernel's slots, no K slice shorter than
+    1024 tokens; workspace / counter sizes per configuration as include/mmtg_hip.h states them."""
+    from mmtg_amd.engine import _group_splits
+    base = ((768, 3072), (3072, 768), (768, 768), (768, 2304))
+    tiles, ws, cnt = hip.wgrad_group_sizes(base, 2, 0)
+    assert (tiles, ws, cnt) == (432, 432 * 2 * 16384, 432 * 4)
+    assert _group_splits(tiles, 15104) == 2                      # 864 workgroups <= 1024 slots
+    assert _group_splits(tiles, 1500) == 1                       # short batches: no slice below 1024 tokens
+    medium = ((1024, 4096), (4096, 1024), (1024, 1024), (1024, 3072))
+    assert hip.wgrad_group_sizes(medium, 1, 0)[0] == 768 and _group_splits(768, 16384) == 1
+    t8, ws8, c8 = hip.wgrad_group_sizes(base, 2, 1)
+    assert (t8, ws8, c8) == (108, 108 * 2 * 65536, 108 * 8)
+    assert _group_splits(t8, 15104, 256) == 2
