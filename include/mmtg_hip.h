@@ -72,6 +72,9 @@ enum {
 #define MMTG_GEMM_NO_OCC4 1024   /* flags: never pick it automatically (A/B measurements) */
 #define MMTG_GEMM_NO_P8 8192     /* flags: never pick the eight-phase 256x256 / 192x256 kernel (bf16, transA = 0, transB = 1, K % 128 == 0: the
                                     default for M >= 1024, N >= 256) -- A/B measurements and bit-equality tests against the older kernels */
+#define MMTG_GEMM_GELU_GRAD 32768 /* flags (round 3): MMTG_EPI_GELU stores gelu_new'(pre-activation) in aux2 instead of the pre-activation, and
+                                    MMTG_EPI_DGELU multiplies by aux as it is (C = acc * aux): the backward then needs no transcendental --
+                                    the only consumer of the saved pre-activation was gelu' (both products of a pair must carry the flag) */
 #define MMTG_GEMM_P8 16384       /* flags: eight-phase kernel also for the dGELU product (otherwise on the single-stage kernel by measurement) */
 #define MMTG_GEMM_P256 4096      /* flags: persistent pipelined kernel with 256x128 tiles, 8 waves, one workgroup per CU (bf16, transA = 0) */
 #define MMTG_GEMM_COL_BLOCK 2048 /* flags: force the column-blocked item order with blocks of two tile columns (test hook;

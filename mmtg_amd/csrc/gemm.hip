@@ -1296,6 +1296,7 @@ extern "C" int mmtg_gemm(int dtype, int transA, int transB, int M, int N, int K,
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldaux = ldaux;
     a.epi = epi; a.out_f32 = out_f32; a.use_tr = !(flags & MMTG_GEMM_NO_TR);
     a.trace = g_trace; a.trace_n = g_trace_n;
+    a.gelu_grad = (flags & MMTG_GEMM_GELU_GRAD) ? 1 : 0;
     a.dbg_flags = ((flags & MMTG_GEMM_ROW_ORDER) ? 1 : 0) | ((flags & MMTG_GEMM_COL_BLOCK) ? 16 : 0) | ((flags & MMTG_GEMM_P256) ? 32 : 0);     // bit 1 (value 2): single-stage kernel, set below
     a.tiles_n = cdiv(N, BN); a.alpha = alpha;
     // byte extents for the buffer descriptors of the LDS-DMA pipeline (offsets are 32-bit)

@@ -35,6 +35,7 @@ struct GemmArgs {
     float alpha;
     uint32_t drop_thresh; uint32_t drop_seed; float drop_inv_keep;
     int bytesA, bytesB;    // operand extents for the LDS-DMA buffer descriptors
+    int gelu_grad;         // MMTG_GEMM_GELU_GRAD: GELU stores gelu'(pre) in aux2; DGELU multiplies by aux as stored
     const int* gather;     // mmtg_gemm_gather: table row of output row m (mode 0: A rows) / of reduction index k (mode 1: B rows)
     const int* aux_rows;   // row of `aux` that output row m reads (null: row m)
 };
@@ -370,7 +371,14 @@ __device__ __forceinline__ void epi_tiles(const GemmArgs& p, f32x4 (&acc)[TM][TN
                 for (int e = 0; e < 8; ++e) a8[e] = (float)ax[((h % RING) * NQ + q) * VPA + e / Vec16<T>::N][e % Vec16<T>::N];
             }
             if constexpr (EPI == MMTG_EPI_GELU) {
-                store8<T>(reinterpret_cast<T*>(p.aux2) + (long)m * p.ldc + n, v);
+                if (p.gelu_grad) {          // the backward's only use of the pre-activation is gelu': store THAT (round 3)
+                    float gd[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) gd[e] = gelu_new_grad_t<T>(v[e]);
+                    store8<T>(reinterpret_cast<T*>(p.aux2) + (long)m * p.ldc + n, gd);
+                } else {
+                    store8<T>(reinterpret_cast<T*>(p.aux2) + (long)m * p.ldc + n, v);
+                }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = gelu_new_t<T>(v[e]);
             } else if constexpr (EPI == MMTG_EPI_TANH) {
@@ -390,7 +398,7 @@ __device__ __forceinline__ void epi_tiles(const GemmArgs& p, f32x4 (&acc)[TM][TN
             } else if constexpr (EPI == MMTG_EPI_DGELU) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    v[e] *= gelu_new_grad_t<T>(a8[e]);
+                    v[e] *= p.gelu_grad ? a8[e] : gelu_new_grad_t<T>(a8[e]);
                     if constexpr (COLSUM) cs[e] += (float)(T)v[e];      // column sums of the output as stored
                 }
             } else if constexpr (EPI == MMTG_EPI_DTANH) {

@@ -205,6 +205,10 @@ _WTE_T = _os.environ.get("MMTG_NO_WTE_T") is None      # [D, Vpad] copy of wte f
 _P8T = _os.environ.get("MMTG_GEMM_P8T", "0") != "0"      # eight-phase K-strided kernel for the slab weight gradients (opt-in: measured slower in situ)
 _WGRAD_GROUP = _os.environ.get("MMTG_WGRAD_GROUP", "1") != "0"   # one grouped launch per GPT-2 block for its four weight gradients (A/B switch)
 _WGRAD_GROUP_SPLITS = int(_os.environ.get("MMTG_WGRAD_GROUP_SPLITS", "0"))    # 0 = the one-round rule below
+# fc1's epilogue saves gelu'(pre-activation) instead of the pre-activation (MMTG_GEMM_GELU_GRAD): OPT-IN.  Same box: 15.11 -> 15.03 ms
+# per step, but the tiny, cancellation-dominated gradient of mm_atten_layer.att_matrices.3.weight moves from 1.05x to 1.18x of the
+# oracle's norm on the 2-layer golden model (every other tensor within 1 %): outside the parity suite's 10 % bound, so not the default
+_GELU_GRAD = _os.environ.get("MMTG_GELU_GRAD", "0") != "0"
 _LMHEAD_GROUP = _os.environ.get("MMTG_LMHEAD_GROUP", "1") != "0"      # the tied embedding's weight gradient through the grouped kernel (A/B switch)
 _LMHEAD_GROUP_SPLITS = int(_os.environ.get("MMTG_LMHEAD_GROUP_SPLITS", "0"))
 _WGRAD_GROUP_CFG = int(_os.environ.get("MMTG_WGRAD_GROUP_CFG", "0"))          # 0: 128x128 tiles, four workgroups per CU; 1: 256x256 eight-phase
@@ -559,7 +563,7 @@ class Engine:
             M = B * T
             if T > sh.NP:
                 raise ValueError("sequence length %d exceeds n_positions %d" % (T, sh.NP))
-        a = {"B": B, "L": L, "T": T, "M": M, "seed": seed, "pdrop": (pe, pa, pr), "train_flag": train_flag,
+        a = {"B": B, "L": L, "T": T, "M": M, "seed": seed, "pdrop": (pe, pa, pr), "train_flag": train_flag, "gelu_grad": _GELU_GRAD,
              "targets": targets, "topic_ids": topic_ids}
 
         # ---------------- encoder: topic_fc + 2 GRUs (model.py:63-81) + ln_layer1..3 (:380-382)
@@ -684,8 +688,10 @@ class Engine:
             hip.layernorm_fwd(xmid, m2, self.P(p + "ln_2.weight"), self.P(p + "ln_2.bias"), mu2, rs2, M, D, sh.eps)
             u = self.buf(f"l{l}_u", (M, 4 * D))
             gact = self.buf(f"l{l}_g", (M, 4 * D))
+            # (u: the pre-activation -- or, with MMTG_GELU_GRAD=1, gelu_new'(pre-activation): all the backward ever takes from it;
+            #  saving the derivative moves the backward's exp / rcp into this epilogue, which computes the sigmoid anyway)
             self._fwd(m2, p + "mlp.c_fc.weight", gact, M, "conv1d", bias=self.P(p + "mlp.c_fc.bias"),
-                      epi=hip.EPI_GELU, aux2=u)
+                      epi=hip.EPI_GELU, aux2=u, flags=hip.GEMM_GELU_GRAD if _GELU_GRAD else 0)
             xout = self.buf(f"resid_{l + 1}", (M, D))
             self._fwd(gact, p + "mlp.c_proj.weight", xout, M, "conv1d", bias=self.P(p + "mlp.c_proj.bias"),
                       epi=hip.EPI_RESID, aux=xmid, ldaux=D, drop_p=pr, drop_seed=s[2])
@@ -863,7 +869,8 @@ class Engine:
             #  gives the c_fc bias gradient instead of a pass over du)
             bands = self.buf("d_u_bands", ((M + 63) // 64, 4 * D), torch.float32)
             self._prefetch(m2, gact)            # while dGELU runs: the operands of the two weight gradients after it
-            self._dgrad(dy, p + "mlp.c_proj.weight", du, M, "conv1d", epi=hip.EPI_DGELU, aux=u, ldaux=4 * D, aux2=bands)
+            self._dgrad(dy, p + "mlp.c_proj.weight", du, M, "conv1d", epi=hip.EPI_DGELU, aux=u, ldaux=4 * D, aux2=bands,
+                        flags=hip.GEMM_GELU_GRAD if a["gelu_grad"] else 0)
             hip.colsum(bands, bands.shape[0], 4 * D, self.G(p + "mlp.c_fc.bias"))
             # (both consumers of du run while it is still in the Infinity Cache; the c_proj weight gradient, whose
             #  operands come from HBM either way, goes last -- it must precede the LayerNorm backward, which reuses dmask)

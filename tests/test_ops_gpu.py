@@ -327,6 +327,40 @@ def test_gemm_epilogues(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_gelu_saved_derivative_pair(dtype):
+    """MMTG_GEMM_GELU_GRAD (round 3): the fc1 epilogue stores gelu_new'(pre-activation) instead of the pre-activation and the dGELU
+    product multiplies by it as stored -- the pair gives the same forward output and the same d(pre-activation) as the
+    pre-activation-saving pair, to the rounding of the stored derivative; both routes of the bf16 kernels (default and
+    GEMM_NO_P8) agree bit for bit."""
+    M, N, K = 1200, 512, 256
+    a = rnd(M, K, dtype=dtype, seed=71).to(DEV)
+    w = rnd(N, K, dtype=dtype, seed=72, scale=0.2).to(DEV)
+    bias = rnd(N, seed=73).to(DEV)
+    dy = rnd(M, K, dtype=dtype, seed=74).to(DEV)           # product 2: d(pre) = (dy @ w2^T) * gelu'(pre), w2 [N, K]
+    pre_ref = a.float() @ w.float().t() + bias
+    xg = pre_ref.clone().requires_grad_(True)
+    O.gelu_new(xg).sum().backward()
+    gprime_ref = xg.grad
+    outs = []
+    for flags in ((0, hip.GEMM_NO_P8) if dtype == torch.bfloat16 else (0,)):
+        g_u, u = torch.empty(M, N, device=DEV, dtype=dtype), torch.empty(M, N, device=DEV, dtype=dtype)
+        hip.gemm(a, w, g_u, M, N, K, transB=True, bias=bias, epi=hip.EPI_GELU, aux2=u, flags=flags)
+        g_d, gd = torch.empty(M, N, device=DEV, dtype=dtype), torch.empty(M, N, device=DEV, dtype=dtype)
+        hip.gemm(a, w, g_d, M, N, K, transB=True, bias=bias, epi=hip.EPI_GELU, aux2=gd, flags=flags | hip.GEMM_GELU_GRAD)
+        assert torch.equal(g_u, g_d)                        # the forward output does not depend on what is saved
+        close(gd, gprime_ref, dtype, 1, "saved gelu'")
+        du_u, du_d = torch.empty(M, N, device=DEV, dtype=dtype), torch.empty(M, N, device=DEV, dtype=dtype)
+        hip.gemm(dy, w, du_u, M, N, K, transB=True, epi=hip.EPI_DGELU, aux=u, flags=flags)
+        hip.gemm(dy, w, du_d, M, N, K, transB=True, epi=hip.EPI_DGELU, aux=gd, flags=flags | hip.GEMM_GELU_GRAD)
+        ref = (dy.float() @ w.float().t()) * gprime_ref.to(DEV)
+        close(du_u, ref, dtype, K, "dGELU from the pre-activation")
+        close(du_d, ref, dtype, K, "dGELU from the saved derivative")
+        outs.append((gd, du_d))
+    for x, y in zip(outs[0], outs[-1]):
+        assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_weight_gradient_ragged_tokens(dtype):
     """X^T dY with a token count (reduction length) that is no multiple of anything."""
     Mtok, Kin, Nout = 708, 256, 384
