@@ -35,7 +35,10 @@ class GreedyDecoder:
         dev, tdt = self.eng.dev, self.eng.tdt
         B, D, H, E = self.B, sh.D, sh.H, sh.E
         # bf16: deterministic split-K products (K slices per product: c_attn, attn c_proj, c_fc, mlp c_proj)
-        self.fast = self.eng.dtype == hip.BF16 and not os.environ.get("MMTG_DECODE_PLAIN")
+        # fp32 (the parity mode): the same split-K schedule through the fp32 kernel's slab epilogue (128x128 tiles, so more
+        # K slices: 6-24 workgroups per product otherwise)
+        self.fast = not os.environ.get("MMTG_DECODE_PLAIN")
+        bf = self.eng.dtype == hip.BF16
         # Lanes (opt-in, MMTG_DECODE_LANES / lanes=): the rows of a batch never interact, so the batch can be cut into
         # `lanes` row blocks whose launch chains run side by side on their own streams (fork / join inside the captured
         # graph).  Every row goes through the same arithmetic in the same order whatever the lane count, so the ids do
@@ -74,7 +77,8 @@ class GreedyDecoder:
         #  own tail -- measured at batch 256, us per token step: 2,4,1,4 -> 714-716; 2,3,1,4 -> 715; 2,2,1,4 -> 721; 3,4,1,4 -> 720;
         #  2,4,1,3 -> 726; 2,4,1,8 -> 728; 2,4,1,6 -> 739; 2,6,1,4 -> 746; 2,4,1,2 -> 751; 4,4,1,4 -> 755; profiles/r03_v8_*)
         fused_ok = self.eng.dtype == hip.BF16 and not os.environ.get("MMTG_DECODE_PLAIN") and os.environ.get("MMTG_DECODE_FUSED", "1") != "0"
-        self.splits = tuple(int(x) for x in os.environ.get("MMTG_DECODE_SPLITS", "2,4,1,4" if fused_ok else "2,4,1,8").split(","))
+        self.splits = tuple(int(x) for x in os.environ.get(
+            "MMTG_DECODE_SPLITS", ("2,4,1,4" if fused_ok else "2,4,1,8") if bf else "8,12,8,24").split(","))
         # (measured at batch 256, us per token step: 2,3,2,6 -> 1020; 4,6,3,12 -> 1248; 1,1,1,2 -> 1183; unsplit 1264;
         #  with the one-slice c_fc + fused GELU: 2,3,1,8 -> 940, 2,3,1,6 -> 943, 1,3,1,8 -> 963, 2,3,1,12 -> 1003)
         #  round 2, 64x64 tiles (graph-replayed per-product times, profiles/r02_decode_gemm_tiles.log): 2,4,1,8)
@@ -97,7 +101,7 @@ class GreedyDecoder:
             # Round 3, fused step (5 graph nodes per block instead of 7): split-K products reduced in the kernel by the last-arriving
             # wave (+ bias + residual + LayerNorm statistics), LayerNorms applied algebraically in the consuming products
             # (mmtg_decode_gemm).  MMTG_DECODE_FUSED=0 keeps the round-2 products + finish launches.
-            self.fused = (self.fast and os.environ.get("MMTG_DECODE_FUSED", "1") != "0" and D % 64 == 0 and D // 32 <= hip.DG_NP
+            self.fused = (self.fast and bf and os.environ.get("MMTG_DECODE_FUSED", "1") != "0" and D % 64 == 0 and D // 32 <= hip.DG_NP
                           and self.eng.layout.Vpad % 4 == 0)
             if self.fused:
                 L, Vp = sh.L, self.eng.layout.Vpad
@@ -198,10 +202,20 @@ class GreedyDecoder:
         """Deterministic split-K product for the batch-sized M of a decode step: `splits` K slices store
         fp32 partial products (N/32 x splits workgroups instead of N/32), splitk_finish sums them in order
         and applies bias / activation / residual (/ the next LayerNorm)."""
-        wt = self.eng.Wt(wkey)
-        N, K = wt.shape
-        hip.gemm(x, wt, self.part, self.B, N, K, transB=True, ldb=K, ldc=N, epi=hip.EPI_SPLIT, out_f32=True, splits=splits)
-        hip.splitk_finish(self.part, splits, self.B, N, out, bias=bias, **fin)
+        self._slabs(x, wkey, splits)
+        hip.splitk_finish(self.part, splits, self.B, self.eng.W(wkey).shape[1], out, bias=bias, **fin)
+
+    def _slabs(self, x, wkey, splits):
+        """`splits` fp32 partial products of x @ W into self.part (bf16: the [out,in] weight copy through the 64x64 LDS-DMA
+        configuration; fp32: the Conv1D weight as stored through the fp32 kernel)."""
+        if self.eng.dtype == hip.BF16:
+            wt = self.eng.Wt(wkey)
+            N, K = wt.shape
+            hip.gemm(x, wt, self.part, self.B, N, K, transB=True, ldb=K, ldc=N, epi=hip.EPI_SPLIT, out_f32=True, splits=splits)
+        else:
+            w = self.eng.W(wkey)
+            K, N = w.shape
+            hip.gemm(x, w, self.part, self.B, N, K, ldb=N, ldc=N, epi=hip.EPI_SPLIT, out_f32=True, splits=splits)
 
     def _layers_split(self, hcur, hnext, with_head):
         """bf16 fast path: 4 split-K products + 4 finish kernels + attention per layer; every LayerNorm
@@ -215,8 +229,7 @@ class GreedyDecoder:
             p = f"{pre}h.{l}."
             if os.environ.get("MMTG_DECODE_ATTN_SPLIT", "1") == "1":
                 # c_attn: the attention kernel sums the split-K slabs itself (no finish launch)
-                wq = eng.Wt(p + "attn.c_attn.weight")
-                hip.gemm(self.a, wq, self.part, B, 3 * D, D, transB=True, ldb=D, ldc=3 * D, epi=hip.EPI_SPLIT, out_f32=True, splits=sq)
+                self._slabs(self.a, p + "attn.c_attn.weight", sq)
                 hip.decode_attn_split(self.part, sq, eng.P(p + "attn.c_attn.bias"), self.kc[l], self.vc[l], self.keep, self.pos,
                                       self.ctx, B, sh.nH, 64, self.Tmax)
             else:

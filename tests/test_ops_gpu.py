@@ -429,6 +429,33 @@ def test_gemm_split_k_finish(shape):
     close(g, O.gelu_new(a.float() @ w.float().t() + bias), dtype, K, "split-K + gelu")
 
 
+@pytest.mark.parametrize("shape", [(32, 768, 3072, 24), (40, 2304, 768, 8), (64, 776, 200, 3)])
+def test_gemm_split_k_slabs_fp32(shape):
+    """The fp32 kernel's slab epilogue (decode in the fp32 parity mode): Conv1D weights as stored ([in, out], NN layout),
+    K slices of whole 32-deep tiles, slices past the end store zeros; splitk_finish adds them in order."""
+    M, N, K, S = shape
+    a = rnd(M, K, seed=41).to(DEV)
+    w = rnd(K, N, seed=42, scale=0.2).to(DEV)
+    bias = rnd(N, seed=43).to(DEV)
+    res = rnd(M, N, seed=44).to(DEV)
+    part = torch.full((S, M, N), float("nan"), device=DEV, dtype=torch.float32)
+    outs = []
+    for _ in range(2):
+        hip.gemm(a, w, part, M, N, K, ldb=N, ldc=N, epi=hip.EPI_SPLIT, out_f32=True, splits=S)
+        out = torch.empty(M, N, device=DEV)
+        hip.splitk_finish(part, S, M, N, out, bias=bias, epi=hip.EPI_RESID, aux=res)
+        outs.append(out)
+    assert torch.isfinite(part).all()
+    kper = -(-(-(-K // S)) // 32) * 32
+    for s in range(S):      # every slab is the product over its own K slice
+        lo, hi = min(K, s * kper), min(K, (s + 1) * kper)
+        ref_s = a[:, lo:hi].double() @ w[lo:hi].double()
+        close(part[s], ref_s.float(), torch.float32, max(hi - lo, 1), "slab %d" % s)
+    ref = (a.double() @ w.double() + bias.double() + res.double()).float()
+    close(outs[0], ref, torch.float32, K, "fp32 split-K + finish")
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_gemm_rowdot_epilogue_is_attention_delta():
     M, N, K = 600, 192, 128
     dtype = torch.bfloat16
