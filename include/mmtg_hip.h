@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MMTG_ABI_VERSION 4
+#define MMTG_ABI_VERSION 5
 
 /* The library is built with -fvisibility=hidden: only the entry points below are exported. */
 #define MMTG_API __attribute__((visibility("default")))
@@ -243,6 +243,19 @@ MMTG_API int mmtg_gru_cell_bwd(int dtype, const float* dh, const float* save, co
 MMTG_API int mmtg_gru_cell_bwd_fused(int dtype, const void* rows, long ld_rows, const float* carry, const float* part, int splits,
                             const float* save, const void* h_prev, long ld_hp, void* dgi, long ld_dgi, void* dgh,
                             float* dh_prev, int B, int H, void* stream);
+/* The other recurrent cells MultiModalEncoder accepts (reference src/model.py:41-59: nn.RNN(nonlinearity="relu") / nn.LSTM).
+ * Pre-activations a = gi + gh ([B, G*H] rows; G = 1 / 4, LSTM gate order i|f|g|o; ld_gh = 0: one bias row for every b).
+ * LSTM: c_prev / c fp32 [B,H] (c_prev null = zeros), save [5,B,H] f32 = i, f, g, o, tanh(c);  ReLU cell: c_prev, c, save unused. */
+#define MMTG_RNN_RELU 0
+#define MMTG_RNN_LSTM 1
+MMTG_API int mmtg_rnn_cell_fwd(int dtype, int kind, const void* gi, long ld_gi, const void* gh, long ld_gh, const float* c_prev,
+                      void* h, long ld_h, float* c, float* save, int B, int H, void* stream);
+/* One BPTT step: dh_t = rows[b, :] (`dtype`, row stride ld_rows) + part (f32 [B,H], nullable: d(a_{t+1}) W_hh) -> da (`dtype`,
+ * [B, G*H] rows of stride ld_da; it is d(gi) and d(gh) at once).  LSTM: dc (f32 [B,H]) is read when dc_in != 0 (dc_{t+1} f_{t+1})
+ * and rewritten with dc_t f_t; ReLU cell: h = the step's output rows (stride ld_h).                                              */
+MMTG_API int mmtg_rnn_cell_bwd(int dtype, int kind, const void* rows, long ld_rows, const float* part, const float* save,
+                      const float* c_prev, const void* h, long ld_h, float* dc, int dc_in, void* da, long ld_da,
+                      int B, int H, void* stream);
 /* alpha attention (model.py:138-161): qkv [B*S, 3H] -> ctx [B*S, H], probs [B,heads,S,S] f32,
  * kl += mean_i KLDiv_batchmean(log P[:,:,i,:], prior_i); prior [S,S] f32.       */
 MMTG_API int mmtg_alpha_attn_fwd(int dtype, const void* qkv, const float* prior, void* ctx, float* probs,

@@ -13,20 +13,38 @@ import copy
 
 def make_model_cfgs(seq_len=5, wenlan_dim=2048, hidden=512, heads=4,
                     gpt2_path="./pretrained/GPT2_lyrics_ckpt_epoch00.ckpt",
-                    dropout=0.1):
-    """Build a ``model_cfgs`` dict with the reference's key layout."""
-    chan = {"type": "GRU", "input_dim": wenlan_dim, "hidden_dim": hidden,
-            "num_layers": 1}
+                    dropout=0.1, image_type="GRU", image_layers=1, text_type="GRU", text_layers=1):
+    """Build a ``model_cfgs`` dict with the reference's key layout.  Channel types: 'GRU' (released), 'LSTM', 'RNN'
+    (reference src/model.py:41-59)."""
+    chan = lambda t, n: {"type": t, "input_dim": wenlan_dim, "hidden_dim": hidden, "num_layers": n}
     return {
         "seq_len": seq_len,
         "topic": {"input_dim": wenlan_dim, "hidden_dim": hidden},
-        "image": dict(chan),
-        "text": dict(chan),
+        "image": chan(image_type, image_layers),
+        "text": chan(text_type, text_layers),
         "SELF_ATT": {"hidden_size": hidden, "attention_heads": heads},
         "MM_ATT": {"attention_dim": 1},
         "GPT2_PATH": gpt2_path,
         "dropout": dropout,
     }
+
+
+RNN_GATES = {"GRU": 3, "LSTM": 4, "RNN": 1}     # rows of weight_ih / weight_hh per hidden unit (torch.nn.RNNBase)
+
+
+def rnn_param_shapes(model_cfgs, ch):
+    """[(suffix, shape)] of the recurrent parameters of channel ``ch`` ('image' / 'text') in torch.nn.RNNBase naming, layer by layer."""
+    c = model_cfgs[ch]
+    if c["type"] not in RNN_GATES:
+        raise ValueError("encoder channel type %r (reference src/model.py:41-59 knows RNN, LSTM, GRU)" % (c["type"],))
+    if int(c["num_layers"]) < 1:
+        raise ValueError("num_layers must be >= 1")
+    G, H, E = RNN_GATES[c["type"]], c["hidden_dim"], c["input_dim"]
+    out = []
+    for l in range(int(c["num_layers"])):
+        out.append([("weight_ih_l%d" % l, (G * H, E if l == 0 else H)), ("weight_hh_l%d" % l, (G * H, H)),
+                    ("bias_ih_l%d" % l, (G * H,)), ("bias_hh_l%d" % l, (G * H,))])
+    return out
 
 
 #: released configuration (reference src/configs.py:14-41)

@@ -80,6 +80,61 @@ __global__ __launch_bounds__(256) void gru_cell_bwd_fused_kernel(const T* __rest
     dh_prev[i] = d * z;
 }
 
+// ------------------------------------------------------------------ LSTM / ReLU-RNN cells (the other encoder types of model.py:39-58)
+// Pre-activations a = gi + gh (gi = W_ih x_t + b_ih for all steps in one product, gh = W_hh h_{t-1} + b_hh per step).
+//   kind 1, nn.LSTM (gate order i, f, g, o):  i = s(a_i) f = s(a_f) g = tanh(a_g) o = s(a_o);  c = f c_prev + i g;  h = o tanh(c)
+//   kind 0, nn.RNN(nonlinearity="relu"):     h = max(a, 0)
+// The cell state stays fp32 ([B, H] per step); save = [5, B, H] fp32 per step: i, f, g, o, tanh(c).
+template <typename T, int KIND>
+__global__ __launch_bounds__(256) void rnn_cell_fwd_kernel(const T* __restrict__ gi, long ld_gi, const T* __restrict__ gh, long ld_gh,
+        const float* __restrict__ c_prev, T* __restrict__ h, long ld_h, float* __restrict__ c, float* __restrict__ save, int B, int H) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)B * H) return;
+    const int b = (int)(i / H), j = (int)(i % H);
+    const long o = (long)b * ld_gh + j, oi = (long)b * ld_gi + j;     // ld_gh = 0: one row for every b (step 0: gh = b_hh)
+    if constexpr (KIND == 0) {
+        h[(long)b * ld_h + j] = (T)fmaxf((float)gi[oi] + (float)gh[o], 0.f);
+    } else {
+        const float gi_ = sigmoid_f((float)gi[oi] + (float)gh[o]);
+        const float gf = sigmoid_f((float)gi[oi + H] + (float)gh[o + H]);
+        const float gg = tanhf((float)gi[oi + 2 * H] + (float)gh[o + 2 * H]);
+        const float go = sigmoid_f((float)gi[oi + 3 * H] + (float)gh[o + 3 * H]);
+        const float cn = gf * (c_prev ? c_prev[i] : 0.f) + gi_ * gg;
+        const float tc = tanhf(cn);
+        c[i] = cn;
+        h[(long)b * ld_h + j] = (T)(go * tc);
+        const long BH = (long)B * H;
+        save[i] = gi_; save[BH + i] = gf; save[2 * BH + i] = gg; save[3 * BH + i] = go; save[4 * BH + i] = tc;
+    }
+}
+
+// Backward of one step with the gradient assembly fused in (as gru_cell_bwd_fused): dh_t = rows[b, :] (gradient of the layer's
+// output row of step t: the LayerNorm path, or the layer above) + part (d(a_{t+1}) W_hh, fp32 [B, H], nullable).
+// LSTM: dc (fp32 [B, H]) carries dc_{t+1} f_{t+1} in (when dc_in != 0) and dc_t f_t out.  da: [B, G H] rows of stride ld_da.
+template <typename T, int KIND>
+__global__ __launch_bounds__(256) void rnn_cell_bwd_kernel(const T* __restrict__ rows, long ld_rows, const float* __restrict__ part,
+        const float* __restrict__ save, const float* __restrict__ c_prev, const T* __restrict__ h, long ld_h, float* __restrict__ dc,
+        int dc_in, T* __restrict__ da, long ld_da, int B, int H) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)B * H) return;
+    const int b = (int)(i / H), j = (int)(i % H);
+    float d = (float)rows[(long)b * ld_rows + j];
+    if (part) d += part[i];
+    const long oa = (long)b * ld_da + j;
+    if constexpr (KIND == 0) {
+        da[oa] = (T)((float)h[(long)b * ld_h + j] > 0.f ? d : 0.f);
+    } else {
+        const long BH = (long)B * H;
+        const float gi_ = save[i], gf = save[BH + i], gg = save[2 * BH + i], go = save[3 * BH + i], tc = save[4 * BH + i];
+        const float dct = (dc_in ? dc[i] : 0.f) + d * go * (1.f - tc * tc);
+        da[oa] = (T)(dct * gg * gi_ * (1.f - gi_));
+        da[oa + H] = (T)(dct * (c_prev ? c_prev[i] : 0.f) * gf * (1.f - gf));
+        da[oa + 2 * H] = (T)(dct * gi_ * (1.f - gg * gg));
+        da[oa + 3 * H] = (T)(d * tc * go * (1.f - go));
+        dc[i] = dct * gf;
+    }
+}
+
 // ------------------------------------------------------------------ alpha attention
 // One wave per (b, head): S <= 8 steps, dh = H/heads <= 256.  Lane owns dh/64
 // consecutive channels; QK^T dot products by wave reduction.
@@ -307,6 +362,41 @@ extern "C" int mmtg_gru_cell_bwd_fused(int dtype, const void* rows, long ld_rows
     DISPATCH(dtype, K_)
 #undef K_
     MMTG_LAUNCH_CHECK("gru_cell_bwd_fused");
+    return MMTG_OK;
+}
+
+extern "C" int mmtg_rnn_cell_fwd(int dtype, int kind, const void* gi, long ld_gi, const void* gh, long ld_gh, const float* c_prev,
+                                 void* h, long ld_h, float* c, float* save, int B, int H, void* stream) {
+    MMTG_REQUIRE(kind == MMTG_RNN_RELU || kind == MMTG_RNN_LSTM, "rnn_cell_fwd: kind %d", kind);
+    const int G = kind == MMTG_RNN_LSTM ? 4 : 1;
+    MMTG_REQUIRE(gi && gh && h && B > 0 && H > 0 && (ld_gh == 0 || ld_gh >= (long)G * H) && ld_gi >= (long)G * H && ld_h >= H, "rnn_cell_fwd: bad args");
+    MMTG_REQUIRE(kind != MMTG_RNN_LSTM || (c && save), "rnn_cell_fwd: the LSTM cell needs its state and save buffers");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(MMTG_PROF_ENCODER, s, 8.0 * G * B * H, 12.0 * G * B * H);
+    dim3 grid(cdiv((long)B * H, 256)), block(256);
+#define K_(T) do { if (kind == MMTG_RNN_LSTM) hipLaunchKernelGGL((rnn_cell_fwd_kernel<T, 1>), grid, block, 0, s, (const T*)gi, ld_gi, (const T*)gh, ld_gh, c_prev, (T*)h, ld_h, c, save, B, H); \
+                   else hipLaunchKernelGGL((rnn_cell_fwd_kernel<T, 0>), grid, block, 0, s, (const T*)gi, ld_gi, (const T*)gh, ld_gh, c_prev, (T*)h, ld_h, c, save, B, H); } while (0)
+    DISPATCH(dtype, K_)
+#undef K_
+    MMTG_LAUNCH_CHECK("rnn_cell_fwd");
+    return MMTG_OK;
+}
+
+extern "C" int mmtg_rnn_cell_bwd(int dtype, int kind, const void* rows, long ld_rows, const float* part, const float* save,
+                                 const float* c_prev, const void* h, long ld_h, float* dc, int dc_in, void* da, long ld_da,
+                                 int B, int H, void* stream) {
+    MMTG_REQUIRE(kind == MMTG_RNN_RELU || kind == MMTG_RNN_LSTM, "rnn_cell_bwd: kind %d", kind);
+    const int G = kind == MMTG_RNN_LSTM ? 4 : 1;
+    MMTG_REQUIRE(rows && da && B > 0 && H > 0 && ld_rows >= H && ld_da >= (long)G * H, "rnn_cell_bwd: bad args");
+    MMTG_REQUIRE(kind == MMTG_RNN_LSTM ? (save && dc) : (h && ld_h >= H), "rnn_cell_bwd: LSTM needs save + dc, the ReLU cell its output h");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(MMTG_PROF_ENCODER, s, 10.0 * G * B * H, 14.0 * G * B * H);
+    dim3 grid(cdiv((long)B * H, 256)), block(256);
+#define K_(T) do { if (kind == MMTG_RNN_LSTM) hipLaunchKernelGGL((rnn_cell_bwd_kernel<T, 1>), grid, block, 0, s, (const T*)rows, ld_rows, part, save, c_prev, (const T*)h, ld_h, dc, dc_in, (T*)da, ld_da, B, H); \
+                   else hipLaunchKernelGGL((rnn_cell_bwd_kernel<T, 0>), grid, block, 0, s, (const T*)rows, ld_rows, part, save, c_prev, (const T*)h, ld_h, dc, dc_in, (T*)da, ld_da, B, H); } while (0)
+    DISPATCH(dtype, K_)
+#undef K_
+    MMTG_LAUNCH_CHECK("rnn_cell_bwd");
     return MMTG_OK;
 }
 

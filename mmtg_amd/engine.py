@@ -23,6 +23,7 @@ import numpy as np
 import torch
 
 from . import hip
+from .configs import rnn_param_shapes
 
 ALIGN = 64  # elements; keeps every pack 16-byte aligned in both f32 and bf16
 
@@ -77,9 +78,9 @@ class ParamLayout:
             packs.append((f"ln_layer{i}.bias", [(f"ln_layer{i}.bias", (H,))], 0))
         for ch in ("text", "image"):
             r = f"encoder.rnns_{ch}."
-            for nm, shp in (("weight_ih_l0", (3 * H, E)), ("weight_hh_l0", (3 * H, H)),
-                            ("bias_ih_l0", (3 * H,)), ("bias_hh_l0", (3 * H,))):
-                packs.append((r + nm, [(r + nm, shp)], 0))
+            for layer in reversed(rnn_param_shapes(model_cfgs, ch)):     # the top layer's gradients are ready first
+                for nm, shp in layer:
+                    packs.append((r + nm, [(r + nm, shp)], 0))
         packs.append(("encoder.topic_fc.weight", [("encoder.topic_fc.weight", (H, E))], 0))
         packs.append(("encoder.topic_fc.bias", [("encoder.topic_fc.bias", (H,))], 0))
 
@@ -140,6 +141,13 @@ class Shapes:
         self.NP = gpt2_cfg["n_positions"]
         self.eps = gpt2_cfg.get("layer_norm_epsilon", 1e-5)
         self.pdrop = (gpt2_cfg.get("embd_pdrop", 0.1), gpt2_cfg.get("attn_pdrop", 0.1), gpt2_cfg.get("resid_pdrop", 0.1))
+        # encoder channels (model.py:39-59): cell type, layers; dropout between the layers of a channel in training (nn.RNNBase)
+        self.rnn = {ch: (model_cfgs[ch]["type"], int(model_cfgs[ch]["num_layers"])) for ch in ("image", "text")}
+        self.rnn_pdrop = float(model_cfgs.get("dropout", 0.0))
+        for ch in ("image", "text"):
+            rnn_param_shapes(model_cfgs, ch)         # validates type / num_layers
+            if model_cfgs[ch]["input_dim"] != self.E or model_cfgs[ch]["hidden_dim"] != self.H:
+                raise ValueError("The hidden dim of topic, image and text must be equal (model.py:36); this engine also takes one input dim")
         if self.D % self.nH or self.D // self.nH != 64:
             raise ValueError("the attention kernels are built for head dim 64 (n_embd=%d, n_head=%d)" % (self.D, self.nH))
         if model_cfgs["MM_ATT"]["attention_dim"] != 1:
@@ -535,6 +543,56 @@ class Engine:
         hip.cast_f32_to(t, out, t.numel())
         return out
 
+    def _rnn_fwd(self, ch, x, B, training, seed, site):
+        """One encoder channel (model.py:39-59, 78-79): `num_layers` stacked GRU / LSTM / ReLU-RNN layers over the S steps, h0 = 0,
+        rows b*S+t.  Per layer: W_ih x + b_ih for all steps in ONE product, then per step the recurrent product W_hh h_{t-1} + b_hh
+        and the cell kernel; between layers nn.RNNBase's dropout (training only; counter-hash mask, regenerated in the backward).
+        Returns the per-layer activation records the backward needs."""
+        sh = self.sh
+        S, H = sh.S, sh.H
+        kind, NL = sh.rnn[ch]
+        G = hip.RNN_GATES[kind]
+        r = f"encoder.rnns_{ch}."
+        gh = self.buf("gh%d" % G, (B, G * H))
+        layers, inp = [], x
+        for l in range(NL):
+            sfx = "_l%d" % l
+            tag = ch if l == 0 else "%s%d" % (ch, l)
+            gi = self.buf("gi_" + tag, (B * S, G * H))
+            self._fwd(inp, r + "weight_ih" + sfx, gi, B * S, "linear", bias=self.P(r + "bias_ih" + sfx))
+            h_all = self.buf("h_" + tag, (B * S, H))
+            rec = {"inp": inp, "gi": gi, "h": h_all, "drop": None}
+            if kind == "GRU":
+                save = rec["save"] = self.buf("gru_save_" + tag, (S, 4, B, H), torch.float32)
+                for t in range(S):
+                    if t == 0:      # h_prev = 0: the recurrent product is b_hh itself (one row, stride 0), no launch
+                        hip.gru_cell_fwd(gi[t:], self.W(r + "bias_hh" + sfx), None, h_all[t:], save[t], B, H,
+                                         ld_gi=S * 3 * H, ld_hp=S * H, ld_h=S * H, ld_gh=0)
+                        continue
+                    self._fwd(h_all[t - 1:], r + "weight_hh" + sfx, gh, B, "linear", bias=self.P(r + "bias_hh" + sfx), lda=S * H)
+                    hip.gru_cell_fwd(gi[t:], gh, h_all[t - 1:], h_all[t:], save[t], B, H,
+                                     ld_gi=S * 3 * H, ld_hp=S * H, ld_h=S * H)
+            else:
+                lstm = kind == "LSTM"
+                code = hip.RNN_LSTM if lstm else hip.RNN_RELU
+                save = rec["save"] = self.buf("lstm_save_" + tag, (S, 5, B, H), torch.float32) if lstm else None
+                c_all = rec["c"] = self.buf("lstm_c_" + tag, (S, B, H), torch.float32) if lstm else None
+                for t in range(S):
+                    if t == 0:
+                        g_t, ld_gh = self.W(r + "bias_hh" + sfx), 0
+                    else:
+                        self._fwd(h_all[t - 1:], r + "weight_hh" + sfx, gh, B, "linear", bias=self.P(r + "bias_hh" + sfx), lda=S * H)
+                        g_t, ld_gh = gh, None
+                    hip.rnn_cell_fwd(code, gi[t:], g_t, c_all[t - 1] if lstm and t else None, h_all[t:], c_all[t] if lstm else None,
+                                     save[t] if lstm else None, B, H, ld_gi=S * G * H, ld_h=S * H, ld_gh=ld_gh)
+            layers.append(rec)
+            inp = h_all
+            if l + 1 < NL and training and sh.rnn_pdrop > 0.0:
+                rec["drop"] = mix_seed(seed, 0x1000 + 64 * site + l)
+                inp = self.buf("hd_" + tag, (B * S, H))
+                hip.dropout_apply(h_all, inp, B * S * H, sh.rnn_pdrop, rec["drop"])
+        return layers
+
     def forward(self, batch, train_flag=True, training=False, per_row_infer=True, need_logits=True, logits_f32=True,
                 encode_only=False):
         """MMTG.forward (model.py:356-400).  Returns dict(logits_pad [M,Vpad] f32, B, T, ...);
@@ -576,32 +634,20 @@ class Engine:
         st = {}
         st["ln1"] = (self.buf("ln1_mu", (B,), torch.float32), self.buf("ln1_rs", (B,), torch.float32))
         hip.layernorm_fwd(t_raw, t_ln, self.P("ln_layer1.weight"), self.P("ln_layer1.bias"), *st["ln1"], B, H)
-        gh = self.buf("gh", (B, 3 * H))
         enc = {}
-        for ch, x, lnk in (("image", xi, "ln_layer2"), ("text", xr, "ln_layer3")):
-            r = f"encoder.rnns_{ch}."
-            gi = self.buf("gi_" + ch, (B * S, 3 * H))
-            self._fwd(x, r + "weight_ih_l0", gi, B * S, "linear", bias=self.P(r + "bias_ih_l0"))
-            h_all = self.buf("h_" + ch, (B * S, H))
-            save = self.buf("gru_save_" + ch, (S, 4, B, H), torch.float32)
-            for t in range(S):
-                if t == 0:      # h_prev = 0: the recurrent product is b_hh itself (one row, stride 0), no launch
-                    hip.gru_cell_fwd(gi[t:], self.W(r + "bias_hh_l0"), None, h_all[t:], save[t], B, H,
-                                     ld_gi=S * 3 * H, ld_hp=S * H, ld_h=S * H, ld_gh=0)
-                    continue
-                self._fwd(h_all[t - 1:], r + "weight_hh_l0", gh, B, "linear", bias=self.P(r + "bias_hh_l0"), lda=S * H)
-                hip.gru_cell_fwd(gi[t:], gh, h_all[t - 1:], h_all[t:], save[t], B, H,
-                                 ld_gi=S * 3 * H, ld_hp=S * H, ld_h=S * H)
+        for ch, x, lnk, site in (("image", xi, "ln_layer2", 0), ("text", xr, "ln_layer3", 1)):
+            layers = self._rnn_fwd(ch, x, B, training, seed, site)
+            h_all = layers[-1]["h"]
             h_ln = self.buf("hln_" + ch, (B * S, H))
             st[lnk] = (self.buf(lnk + "_mu", (B * S,), torch.float32), self.buf(lnk + "_rs", (B * S,), torch.float32))
             hip.layernorm_fwd(h_all, h_ln, self.P(lnk + ".weight"), self.P(lnk + ".bias"), *st[lnk], B * S, H)
-            enc[ch] = (x, gi, h_all, save, h_ln)
+            enc[ch] = (layers, h_ln)
 
         # ---------------- alpha attention (model.py:133-161) on batch-first rows b*S+i
         kl = self.buf("kl", (1,), torch.float32, zero=True)
         alpha = {}
         for mod, ch in (("img", "image"), ("text", "text")):
-            h_ln = enc[ch][4]
+            h_ln = enc[ch][1]
             qkv = self.buf("aqkv_" + mod, (B * S, 3 * H))
             hip.gemm(h_ln, self.Wp(mod + "_qkv_w"), qkv, B * S, 3 * H, H, transB=True, ldb=H, bias=self.Pp(mod + "_qkv_b"))
             ctx = self.buf("actx_" + mod, (B * S, H))
@@ -963,7 +1009,8 @@ class Engine:
         tmp32 = self.buf("d_tmp32", (B, H), torch.float32)
         for mod, ch, lnk, dctx_a in (("text", "text", "ln_layer3", dct), ("img", "image", "ln_layer2", dci)):
             qkv_a, ctx_a, probs = a["alpha"][mod]
-            x_in, gi, h_all, save, h_ln = a["enc"][ch]
+            layers, h_ln = a["enc"][ch]
+            h_all = layers[-1]["h"]
             dqkv_a = self.buf("d_aqkv", (B * S, 3 * H))
             hip.alpha_attn_bwd(qkv_a, self.prior, probs, dctx_a, dkl, dqkv_a, B, S, H, sh.heads)
             dhln = self.buf("d_hln", (B * S, H))
@@ -975,35 +1022,7 @@ class Engine:
             dh_all = self.buf("d_hall", (B * S, H))
             hip.layernorm_bwd(dhln, h_all, self.P(lnk + ".weight"), *a["st"][lnk], None, dh_all,
                               self.G(lnk + ".weight"), self.G(lnk + ".bias"), B * S, H, ws=lnws)
-            # BPTT over the S steps (rows b*S+t)
-            r = f"encoder.rnns_{ch}."
-            dgi = self.buf("d_gi", (B * S, 3 * H))
-            # every step's d(gh) is kept (time-major) so that the recurrent weight / bias gradients are ONE
-            # product and ONE column sum after the loop instead of one per step
-            dgh_tm = self.buf("d_gh_tm", (S, B, 3 * H))
-            bf = self.dtype == hip.BF16
-            ks = 6 if bf and (3 * H) % (6 * 64) == 0 else 0      # split-K slabs of the carry product (bf16 kernels only)
-            part = self.buf("d_hp_slabs", (max(ks, 1), B, H), torch.float32)
-            for t in range(S - 1, -1, -1):
-                # total gradient wrt h_t = LN path (row b*S+t) + carry dh_{t+1} z_{t+1} + d(gh_{t+1}) W_hh, assembled in the cell kernel
-                last = t == S - 1
-                dgh = dgh_tm[t]
-                hip.gru_cell_bwd_fused(dh_all[t:], S * H, None if last else dhp32, None if last else (part if ks else tmp32),
-                                       0 if last else (ks or 1), save[t], None if t == 0 else h_all[t - 1:], dgi[t:], dgh, dhp32,
-                                       B, H, ld_hp=S * H, ld_dgi=S * 3 * H)
-                if t > 0:
-                    if ks:
-                        hip.gemm(dgh, self.W(r + "weight_hh_l0"), part, B, H, 3 * H, transB=False, ldb=H,
-                                 epi=hip.EPI_SPLIT, out_f32=True, splits=ks)
-                    else:
-                        hip.gemm(dgh, self.W(r + "weight_hh_l0"), tmp32, B, H, 3 * H, transB=False, ldb=H, out_f32=True)
-            hip.colsum(dgh_tm, S * B, 3 * H, self.G(r + "bias_hh_l0"))
-            if S > 1:
-                hprev_tm = self.buf("h_prev_tm", (S - 1, B, H))
-                hprev_tm.copy_(h_all.view(B, S, H)[:, :S - 1].transpose(0, 1))     # data movement only
-                hip.gemm(dgh_tm[1:], hprev_tm, self.G(r + "weight_hh_l0"), 3 * H, H, (S - 1) * B, transA=True, transB=False,
-                         lda=3 * H, ldb=H, ldc=H, epi=hip.EPI_ATOMIC, splits=1)
-            self._wgrad(x_in, dgi, r + "weight_ih_l0", r + "bias_ih_l0", B * S, "linear")
+            self._rnn_bwd(ch, layers, dh_all, B, dhp32, tmp32)
         # ---- topic channel
         dt_ln = self.buf("d_tln", (B, H))
         hip.cast_f32_to(dtopic, dt_ln, B * H)
@@ -1013,6 +1032,70 @@ class Engine:
         self._wgrad(a["xt"], dt_raw, "encoder.topic_fc.weight", "encoder.topic_fc.bias", B, "linear")
         self._ready("encoder.topic_fc.bias")
         self._lazy = None
+
+    def _rnn_bwd(self, ch, layers, dh_all, B, dhp32, tmp32):
+        """BPTT of one encoder channel (rows b*S+t), top layer first.  dh_all [B*S, H]: gradient of the top layer's outputs."""
+        sh = self.sh
+        S, H = sh.S, sh.H
+        kind, NL = sh.rnn[ch]
+        G = hip.RNN_GATES[kind]
+        r = f"encoder.rnns_{ch}."
+        bf = self.dtype == hip.BF16
+        for l in range(NL - 1, -1, -1):
+            sfx = "_l%d" % l
+            rec = layers[l]
+            h_all, save = rec["h"], rec["save"]
+            dgi = self.buf("d_gi%d" % G, (B * S, G * H))
+            if kind == "GRU":
+                # every step's d(gh) is kept (time-major) so that the recurrent weight / bias gradients are ONE
+                # product and ONE column sum after the loop instead of one per step
+                dgh_tm = self.buf("d_gh_tm", (S, B, 3 * H))
+                ks = 6 if bf and (3 * H) % (6 * 64) == 0 else 0      # split-K slabs of the carry product (bf16 kernels only)
+                part = self.buf("d_hp_slabs", (max(ks, 1), B, H), torch.float32)
+                for t in range(S - 1, -1, -1):
+                    # total gradient wrt h_t = rows b*S+t of dh_all + carry dh_{t+1} z_{t+1} + d(gh_{t+1}) W_hh, assembled in the cell kernel
+                    last = t == S - 1
+                    dgh = dgh_tm[t]
+                    hip.gru_cell_bwd_fused(dh_all[t:], S * H, None if last else dhp32, None if last else (part if ks else tmp32),
+                                           0 if last else (ks or 1), save[t], None if t == 0 else h_all[t - 1:], dgi[t:], dgh, dhp32,
+                                           B, H, ld_hp=S * H, ld_dgi=S * 3 * H)
+                    if t > 0:
+                        if ks:
+                            hip.gemm(dgh, self.W(r + "weight_hh" + sfx), part, B, H, 3 * H, transB=False, ldb=H,
+                                     epi=hip.EPI_SPLIT, out_f32=True, splits=ks)
+                        else:
+                            hip.gemm(dgh, self.W(r + "weight_hh" + sfx), tmp32, B, H, 3 * H, transB=False, ldb=H, out_f32=True)
+                hip.colsum(dgh_tm, S * B, 3 * H, self.G(r + "bias_hh" + sfx))
+                drec_tm = dgh_tm[1:]
+            else:
+                # LSTM / ReLU cell: d(gi) = d(gh) = d(pre-activation), one tensor
+                lstm = kind == "LSTM"
+                code = hip.RNN_LSTM if lstm else hip.RNN_RELU
+                dc = self.buf("d_c32", (B, H), torch.float32) if lstm else None
+                for t in range(S - 1, -1, -1):
+                    last = t == S - 1
+                    hip.rnn_cell_bwd(code, dh_all[t:], S * H, None if last else tmp32, save[t] if lstm else None,
+                                     rec["c"][t - 1] if lstm and t else None, h_all[t:], S * H, dc, not last, dgi[t:], S * G * H, B, H)
+                    if t > 0:
+                        hip.gemm(dgi[t:], self.W(r + "weight_hh" + sfx), tmp32, B, H, G * H, transB=False, lda=S * G * H, ldb=H,
+                                 out_f32=True)
+                hip.colsum(dgi, B * S, G * H, self.G(r + "bias_hh" + sfx))
+                drec_tm = None
+                if S > 1:
+                    drec_tm = self.buf("d_a_tm%d" % G, (S - 1, B, G * H))
+                    drec_tm.copy_(dgi.view(B, S, G * H)[:, 1:].transpose(0, 1))     # data movement only
+            if S > 1:
+                hprev_tm = self.buf("h_prev_tm", (S - 1, B, H))
+                hprev_tm.copy_(h_all.view(B, S, H)[:, :S - 1].transpose(0, 1))     # data movement only
+                hip.gemm(drec_tm, hprev_tm, self.G(r + "weight_hh" + sfx), G * H, H, (S - 1) * B, transA=True, transB=False,
+                         lda=G * H, ldb=H, ldc=H, epi=hip.EPI_ATOMIC, splits=1)
+            self._wgrad(rec["inp"], dgi, r + "weight_ih" + sfx, r + "bias_ih" + sfx, B * S, "linear")
+            if l > 0:
+                # gradient of the layer below's outputs: d(gi) W_ih, through the same dropout mask as the forward
+                dh_all = self.buf("d_hx%d" % (l & 1), (B * S, H))
+                hip.gemm(dgi, self.W(r + "weight_ih" + sfx), dh_all, B * S, H, G * H, transB=False, ldb=H)
+                if layers[l - 1]["drop"] is not None:
+                    hip.dropout_apply(dh_all, dh_all, B * S * H, sh.rnn_pdrop, layers[l - 1]["drop"])
 
     # ---------------------------------------------------------------- optimizer (train.py:194-197)
     def grad_norm_sq(self):

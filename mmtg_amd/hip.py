@@ -13,7 +13,7 @@ import os
 import torch
 
 F32, BF16 = 0, 1
-ABI_VERSION = 4
+ABI_VERSION = 5
 EPI_NONE, EPI_GELU, EPI_TANH, EPI_RESID, EPI_DGELU, EPI_DTANH, EPI_ATOMIC, EPI_ROWDOT = range(8)
 GEMM_NO_TR, GEMM_REGSTAGE, GEMM_SKINNY, GEMM_NO_SKINNY, GEMM_WIDE, GEMM_NO_WIDE = 1, 2, 4, 8, 16, 32
 GEMM_PERSIST, GEMM_NO_PERSIST, GEMM_ROW_ORDER, GEMM_OCC4, GEMM_NO_OCC4, GEMM_COL_BLOCK, GEMM_P256, GEMM_NO_P8, GEMM_P8 = 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384
@@ -52,6 +52,8 @@ _SIGS = {
     "mmtg_loss_bwd": ([_i, _i, _vp, _l, _i, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _i, _vp, _l, _i, _vp], _i),
     "mmtg_gru_cell_fwd": ([_i, _vp, _l, _vp, _l, _vp, _l, _vp, _l, _vp, _i, _i, _vp], _i),
     "mmtg_gru_cell_bwd_fused": ([_i, _vp, _l, _vp, _vp, _i, _vp, _vp, _l, _vp, _l, _vp, _vp, _i, _i, _vp], _i),
+    "mmtg_rnn_cell_fwd": ([_i, _i, _vp, _l, _vp, _l, _vp, _vp, _l, _vp, _vp, _i, _i, _vp], _i),
+    "mmtg_rnn_cell_bwd": ([_i, _i, _vp, _l, _vp, _vp, _vp, _vp, _l, _vp, _i, _vp, _l, _i, _i, _vp], _i),
     "mmtg_gru_cell_bwd": ([_i, _vp, _vp, _vp, _l, _vp, _l, _vp, _vp, _i, _i, _vp], _i),
     "mmtg_alpha_attn_fwd": ([_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp], _i),
     "mmtg_alpha_attn_bwd": ([_i, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _vp], _i),
@@ -327,6 +329,22 @@ def gru_cell_bwd(dh, save, h_prev, dgi, dgh, dh_prev, B, H, ld_hp=None, ld_dgi=N
     _check(lib().mmtg_gru_cell_bwd(dt(dgi), _p(dh), _p(save), _p(h_prev), H if ld_hp is None else ld_hp, _p(dgi),
                                    3 * H if ld_dgi is None else ld_dgi, _p(dgh), _p(dh_prev), B, H, _stream()),
            "gru_cell_bwd")
+
+
+RNN_RELU, RNN_LSTM = 0, 1
+RNN_GATES = {"GRU": 3, "LSTM": 4, "RNN": 1}
+
+
+def rnn_cell_fwd(kind, gi, gh, c_prev, h, c, save, B, H, ld_gi, ld_h, ld_gh=None):
+    """ReLU-RNN / LSTM cell of one step (reference model.py:41-59 encoder types)."""
+    G = 4 if kind == RNN_LSTM else 1
+    _check(lib().mmtg_rnn_cell_fwd(dt(gi), kind, _p(gi), ld_gi, _p(gh), G * H if ld_gh is None else ld_gh, _p(c_prev), _p(h), ld_h,
+                                   _p(c), _p(save), B, H, _stream()), "rnn_cell_fwd")
+
+
+def rnn_cell_bwd(kind, rows, ld_rows, part, save, c_prev, h, ld_h, dc, dc_in, da, ld_da, B, H):
+    _check(lib().mmtg_rnn_cell_bwd(dt(da), kind, _p(rows), ld_rows, _p(part), _p(save), _p(c_prev), _p(h), ld_h, _p(dc), int(dc_in),
+                                   _p(da), ld_da, B, H, _stream()), "rnn_cell_bwd")
 
 
 def alpha_attn_fwd(qkv, prior, ctx, probs, kl, B, S, H, heads):

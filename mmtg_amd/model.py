@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from . import hip
-from .configs import GPT2_BASE, GPT2_PDROP
+from .configs import GPT2_BASE, GPT2_PDROP, rnn_param_shapes
 from .engine import Engine, ParamLayout, Shapes
 
 
@@ -157,9 +157,8 @@ class MMTG(nn.Module):
         self.data_config = data_config
         self.vocab_size = vocab_size
         self.train_flag = train_flag
-        for ch in ("image", "text"):
-            if model_cfgs[ch]["type"] != "GRU" or model_cfgs[ch]["num_layers"] != 1:
-                raise NotImplementedError("only the released encoder (1-layer GRU channels) is built")
+        for ch in ("image", "text"):         # reference model.py:41-59: RNN(relu) / LSTM / GRU, num_layers >= 1
+            rnn_param_shapes(model_cfgs, ch)
         assert model_cfgs["topic"]["hidden_dim"] == model_cfgs["image"]["hidden_dim"] == model_cfgs["text"]["hidden_dim"], \
             "The hidden dim of topic, image and text must be equal."
         compute_dtype = compute_dtype or os.environ.get("MMTG_DTYPE", "bf16")

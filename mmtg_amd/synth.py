@@ -16,6 +16,8 @@ from __future__ import annotations
 
 import numpy as np
 
+from .configs import rnn_param_shapes
+
 PAD, START, EOS, UNK, CLS, SEP, MASK = 0, 1, 2, 100, 101, 102, 103
 FIRST_WORD_ID = 104
 
@@ -35,10 +37,8 @@ def param_spec(model_cfgs, gpt2_cfg):
     spec = [("encoder.topic_fc.weight", (H, E), "w"),
             ("encoder.topic_fc.bias", (H,), "b")]
     for ch in ("image", "text"):
-        spec += [(f"encoder.rnns_{ch}.weight_ih_l0", (3 * H, E), "w"),
-                 (f"encoder.rnns_{ch}.weight_hh_l0", (3 * H, H), "w"),
-                 (f"encoder.rnns_{ch}.bias_ih_l0", (3 * H,), "b"),
-                 (f"encoder.rnns_{ch}.bias_hh_l0", (3 * H,), "b")]
+        for layer in rnn_param_shapes(model_cfgs, ch):
+            spec += [(f"encoder.rnns_{ch}.{nm}", shp, "w" if nm.startswith("weight") else "b") for nm, shp in layer]
     for i in (1, 2, 3):
         spec += [(f"ln_layer{i}.weight", (H,), "g"), (f"ln_layer{i}.bias", (H,), "b")]
     for mod in ("img", "text"):

@@ -100,21 +100,66 @@ def gru_forward(x, w_ih, w_hh, b_ih, b_hh):
     return torch.stack(outs, 0)
 
 
+def lstm_forward(x, w_ih, w_hh, b_ih, b_hh):
+    """One nn.LSTM layer, h0 = c0 = 0 (model.py:46-47 / 55-56; gate order i,f,g,o:
+    c' = f*c + i*g, h' = o*tanh(c'))."""
+    S, B, _ = x.shape
+    Hh = w_hh.shape[1]
+    h = x.new_zeros(B, Hh)
+    c = x.new_zeros(B, Hh)
+    gi_all = x @ w_ih.t() + b_ih
+    outs = []
+    for t in range(S):
+        a_i, a_f, a_g, a_o = (gi_all[t] + h @ w_hh.t() + b_hh).chunk(4, -1)
+        c = torch.sigmoid(a_f) * c + torch.sigmoid(a_i) * torch.tanh(a_g)
+        h = torch.sigmoid(a_o) * torch.tanh(c)
+        outs.append(h)
+    return torch.stack(outs, 0)
+
+
+def rnn_relu_forward(x, w_ih, w_hh, b_ih, b_hh):
+    """One nn.RNN(nonlinearity="relu") layer, h0 = 0 (model.py:42-43 / 52-53)."""
+    S, B, _ = x.shape
+    h = x.new_zeros(B, w_hh.shape[1])
+    gi_all = x @ w_ih.t() + b_ih
+    outs = []
+    for t in range(S):
+        h = torch.relu(gi_all[t] + h @ w_hh.t() + b_hh)
+        outs.append(h)
+    return torch.stack(outs, 0)
+
+
+_RNN_LAYER = {"GRU": gru_forward, "LSTM": lstm_forward, "RNN": rnn_relu_forward}
+
+
+def rnn_stack_forward(w, prefix, x, masks=None):
+    """The channel's nn.RNNBase stack (model.py:41-59): type and depth are read off the state dict (rows of weight_ih_l0
+    per hidden unit = gates: 3 GRU, 4 LSTM, 1 RNN; layers = weight_ih_l* present).  Eval semantics by default; masks[l]
+    ([S,B,H], already scaled by 1/keep) is nn.RNNBase's training-mode dropout on the output of layer l (all but the last)."""
+    gates = w[prefix + "weight_ih_l0"].shape[0] // w[prefix + "weight_hh_l0"].shape[1]
+    layer = _RNN_LAYER[{3: "GRU", 4: "LSTM", 1: "RNN"}[gates]]
+    l = 0
+    while prefix + "weight_ih_l%d" % l in w:
+        x = layer(x, *(w[prefix + n + "_l%d" % l] for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")))
+        l += 1
+        if masks is not None and prefix + "weight_ih_l%d" % l in w:
+            x = x * masks[l - 1]
+    return x
+
+
 def layer_norm(x, g, b, eps=1e-5):
     mu = x.mean(-1, keepdim=True)
     var = ((x - mu) ** 2).mean(-1, keepdim=True)
     return (x - mu) / torch.sqrt(var + eps) * g + b
 
 
-def encoder_forward(w, topic_emb, img, txt):
+def encoder_forward(w, topic_emb, img, txt, rnn_masks=None):
     """MultiModalEncoder.forward (model.py:63-81) then ln_layer1..3
     (model.py:380-382).  img/txt are [S,B,E]."""
     p = "encoder."
     topic = (topic_emb @ w[p + "topic_fc.weight"].t() + w[p + "topic_fc.bias"]).unsqueeze(0)
-    oi = gru_forward(img, *(w[p + "rnns_image." + n] for n in
-                            ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0")))
-    ot = gru_forward(txt, *(w[p + "rnns_text." + n] for n in
-                            ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0")))
+    oi = rnn_stack_forward(w, p + "rnns_image.", img, None if rnn_masks is None else rnn_masks["image"])
+    ot = rnn_stack_forward(w, p + "rnns_text.", txt, None if rnn_masks is None else rnn_masks["text"])
     raw = (topic, oi, ot)
     normed = (layer_norm(topic, w["ln_layer1.weight"], w["ln_layer1.bias"]),
               layer_norm(oi, w["ln_layer2.weight"], w["ln_layer2.bias"]),
@@ -257,12 +302,12 @@ def inference_type_ids_and_mask(sh, input_ids, tpw_type_ids, tpw_att_mask, per_r
             torch.cat([tpw_att_mask.long(), mask], 1))
 
 
-def mmtg_forward(w, sh, table, batch, train_flag=True, collect=None, per_row_infer=False):
+def mmtg_forward(w, sh, table, batch, train_flag=True, collect=None, per_row_infer=False, rnn_masks=None):
     """MMTG.forward (model.py:356-400) -> (lm_loss, kl, logits[B,T,V])."""
     topic_emb = batch["topic_emb"].float()
     img = batch["img_embs"].float().transpose(0, 1)
     txt = batch["r_embs"].float().transpose(0, 1)
-    raw, (tn, im, tx) = encoder_forward(w, topic_emb, img, txt)
+    raw, (tn, im, tx) = encoder_forward(w, topic_emb, img, txt, rnn_masks)
     priors = gaussian_priors(sh.S)
     ia, ikl = alpha_attention(w, "img_inner_atten_layer", im.transpose(0, 1), sh.heads, priors)
     ta, tkl = alpha_attention(w, "text_inner_atten_layer", tx.transpose(0, 1), sh.heads, priors)

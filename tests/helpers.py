@@ -15,7 +15,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 def load_case(name):
     fx = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
     meta = json.loads(str(fx["meta"]))
-    mcfg = make_model_cfgs(seq_len=meta["S"])
+    mcfg = make_model_cfgs(seq_len=meta["S"], **meta.get("enc", {}))      # "enc": encoder types / depths of the variant fixtures
     gcfg = meta["gpt2_cfg"]
     dcfg = data_config(seq_len=meta["S"])
     weights = synth.make_weights(mcfg, gcfg, seed=meta["weight_seed"])

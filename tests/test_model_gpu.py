@@ -24,6 +24,9 @@ from oracle import mmtg_oracle as O  # noqa: E402
 DEV = "cuda"
 
 
+CASES = ["tiny_s5", "tiny_s2", "tiny_lstm2_rnn2", "tiny_gru2_lstm1"]     # the last two: LSTM / ReLU-RNN / multi-layer encoder channels
+
+
 def build(case, dtype, train_flag=True):
     fx, meta, mcfg, gcfg, dcfg, weights, table, batch = load_case(case)
     model = MMTG(mcfg, dcfg, meta["V"], train_flag=False, gpt2_config=gcfg, token_table=table, compute_dtype=dtype)
@@ -34,7 +37,7 @@ def build(case, dtype, train_flag=True):
     return fx, meta, mcfg, gcfg, dcfg, weights, table, batch, model
 
 
-@pytest.mark.parametrize("case", ["tiny_s5", "tiny_s2"])
+@pytest.mark.parametrize("case", CASES)
 def test_forward_f32_vs_golden(case):
     fx, meta, mcfg, gcfg, dcfg, weights, table, batch, model = build(case, "f32")
     with torch.no_grad():
@@ -61,15 +64,16 @@ def test_forward_f32_vs_golden(case):
 
     chk("enc_topic", a["t_raw"].view(1, B, -1), fx["int_enc_topic"])
     chk("ln_topic", a["t_ln"].view(1, B, -1), fx["int_ln_topic"])
-    chk("enc_image", a["enc"]["image"][2].view(B, S, -1).transpose(0, 1), fx["int_enc_image"])
-    chk("ln_text", a["enc"]["text"][4].view(B, S, -1).transpose(0, 1), fx["int_ln_text"])
+    chk("enc_image", a["enc"]["image"][0][-1]["h"].view(B, S, -1).transpose(0, 1), fx["int_enc_image"])
+    chk("enc_text", a["enc"]["text"][0][-1]["h"].view(B, S, -1).transpose(0, 1), fx["int_enc_text"])
+    chk("ln_text", a["enc"]["text"][1].view(B, S, -1).transpose(0, 1), fx["int_ln_text"])
     chk("img_inner", a["alpha"]["img"][1].view(B, S, -1), fx["int_img_inner"])
     chk("mm_out", a["c"].view(B, S, -1).transpose(0, 1), fx["int_mm_out"])
     chk("block0", a["layers"][1][0].view(B, T, -1)[:, ::ts], fx["int_block0"])
     chk("ln_f", a["hf"].view(B, T, -1)[:, ::ts], fx["int_ln_f"])
 
 
-@pytest.mark.parametrize("case", ["tiny_s5", "tiny_s2"])
+@pytest.mark.parametrize("case", CASES)
 def test_dropin_backward_f32_vs_golden(case):
     """reference loop train.py:188-194: forward, MyLoss, total.backward(), clip."""
     fx, meta, mcfg, gcfg, dcfg, weights, table, batch, model = build(case, "f32")
@@ -108,7 +112,7 @@ def test_dropin_backward_f32_vs_golden(case):
     assert sd["ln_layer1.weight"].grad is None
 
 
-@pytest.mark.parametrize("case", ["tiny_s5", "tiny_s2"])
+@pytest.mark.parametrize("case", CASES)
 def test_fused_train_step_f32_vs_golden(case):
     fx, meta, mcfg, gcfg, dcfg, weights, table, batch, model = build(case, "f32")
     hp = json.loads(str(fx["train_hparams"]))
@@ -147,7 +151,7 @@ def test_full_shape_f32_spot_checks():
         assert abs(got - float(fx[f"myloss_stage{stage}"])) < 2e-4 * max(1, abs(float(fx[f"myloss_stage{stage}"])))
 
 
-@pytest.mark.parametrize("case", ["tiny_s5", "tiny_s2"])
+@pytest.mark.parametrize("case", CASES)
 def test_bf16_vs_oracle(case):
     fx, meta, mcfg, gcfg, dcfg, weights, table, batch, model = build(case, "bf16")
     hp = json.loads(str(fx["train_hparams"]))
@@ -155,7 +159,9 @@ def test_bf16_vs_oracle(case):
     lm, kl, logits = model(tb)
     ref = torch.from_numpy(fx["logits"])
     err = (logits.detach().cpu() - ref).abs()
-    assert float(err.max()) < 0.12 and float(err.mean()) < 0.02, (float(err.max()), float(err.mean()))
+    # bf16 bound: 0.12 abs (0.02 mean) at |logit| ~ 8, scaled with the fixture's logit range (the variant fixtures reach 10.4)
+    rel = max(1.0, float(ref.abs().max()) / 8.0)
+    assert float(err.max()) < 0.12 * rel and float(err.mean()) < 0.02 * rel, (float(err.max()), float(err.mean()), rel)
     assert abs(kl.item() - float(fx["kl"])) < 3e-2 * abs(float(fx["kl"]))
     loss = MyLoss(dcfg, mcfg)(logits, tb["targets"], tb["rating"], hp["stage"])
     (loss + hp["alpha"] * kl).backward()
@@ -178,14 +184,14 @@ def test_bf16_vs_oracle(case):
 
 
 @pytest.mark.parametrize("route", ["cached", "rerun"])
-@pytest.mark.parametrize("length,row", [(30, 0), (30, 1), (220, 0)])
-def test_greedy_decode_bit_exact(length, row, route, monkeypatch):
+@pytest.mark.parametrize("length,row,case", [(30, 0, "tiny_s5"), (30, 1, "tiny_s5"), (220, 0, "tiny_s5"), (30, 0, "tiny_lstm2_rnn2")])
+def test_greedy_decode_bit_exact(length, row, case, route, monkeypatch):
     """The drop-in sample_sequence against the reference's own id lists, on both of its routes: the KV-cached graph-replayed
     decoder (the default for the reference's call) and the reference-shaped loop that re-runs the prefix (MMTG_SAMPLE_RERUN)."""
     from mmtg_amd import generate as G
     if route == "rerun":
         monkeypatch.setenv("MMTG_SAMPLE_RERUN", "1")
-    fx, meta, mcfg, gcfg, dcfg, weights, table, batch, model = build("tiny_s5", "f32", train_flag=False)
+    fx, meta, mcfg, gcfg, dcfg, weights, table, batch, model = build(case, "f32", train_flag=False)
     probe = {"targets": np.asarray([1])}
     assert (G._cached_decoder(model, probe, length) is not None) == (route == "cached")
     dp = json.loads(str(fx["decode_params"]))
@@ -777,3 +783,52 @@ def test_scaled_stress_config_full_size_properties():
     l32 = float(MMTGTrainer(m32, lr=1e-4, alpha=0.2).step(batch, stage=3)["loss"])
     assert abs(losses[0] - l32) <= 3e-3 * abs(l32), (losses[0], l32)
     _report("scaled_stress_full_size", additivity_cos=cos, additivity_rel=rel, loss_bf16=losses[0], loss_f32=l32, losses=losses)
+
+
+def test_rnn_interlayer_dropout_training_mode_vs_oracle():
+    """nn.RNNBase's dropout between the layers of an encoder channel (model.py:43-59 pass dropout=model_cfgs['dropout']; training
+    mode only).  The engine's counter-hash masks are read back (the same kernel on a tensor of ones) and handed to the oracle, so the
+    training-mode forward AND backward are compared against autograd through identical masks: the backward must regenerate the
+    forward's mask at the right place."""
+    fx, meta, mcfg, gcfg, dcfg, weights, table, batch, model = build("tiny_lstm2_rnn2", "f32")
+    from mmtg_amd import hip
+    assert mcfg["dropout"] > 0
+    tb = batch_to_torch(batch, DEV)
+    eng = model.engine()
+    B, S, H = meta["B"], meta["S"], mcfg["topic"]["hidden_dim"]
+    hp = json.loads(str(fx["train_hparams"]))
+
+    def run(training):
+        eng.zero_grad()
+        eng.drop_seed = 31337
+        eng.forward(tb, train_flag=True, training=training, logits_f32=False)
+        sc = eng.loss(tb["rating"], hp["stage"], batch_den=B)
+        dl = eng.loss_backward(1.0)
+        eng.backward(dl, dkl=hp["alpha"])
+        return float(sc[0].item()), float(eng.act["kl"].item())
+
+    l_eval, _ = run(False)
+    l_train, kl_train = run(True)
+    assert abs(l_train - l_eval) > 1e-4          # the masks are active (GPT-2's own dropouts are 0 in the fixture)
+    masks = {}
+    for ch in ("image", "text"):
+        layers = eng.act["enc"][ch][0]
+        assert layers[0]["drop"] is not None and layers[-1]["drop"] is None
+        ones, m = torch.ones(B * S, H, device=DEV), torch.empty(B * S, H, device=DEV)
+        hip.dropout_apply(ones, m, B * S * H, mcfg["dropout"], layers[0]["drop"])
+        keep = float((m != 0).float().mean())
+        assert abs(keep - (1 - mcfg["dropout"])) < 0.05
+        masks[ch] = [m.view(B, S, H).transpose(0, 1).cpu()]
+    sh = O.Shapes(mcfg, dcfg, gcfg)
+    w = O.weights_to_torch(weights, True)
+    cb = batch_to_torch(batch)
+    _, okl, ologits = O.mmtg_forward(w, sh, torch.from_numpy(table), cb, True, rnn_masks=masks)
+    oloss = O.my_loss(ologits, cb["targets"], cb["rating"], hp["stage"], sh.P)
+    (oloss + hp["alpha"] * okl).backward()
+    assert abs(l_train - oloss.item()) < 1e-4 * abs(oloss.item())
+    assert abs(kl_train - okl.item()) < 1e-4 * abs(okl.item())
+    total = float(torch.sqrt(sum((t.grad.double() ** 2).sum() for t in {id(t): t for t in w.values()}.values())))
+    for k in (k for k in w if k.startswith("encoder.")):
+        g, r = eng.G(k).float().cpu().flatten(), w[k].grad.flatten()
+        scale = max(float(r.abs().max()), float(r.norm()) / np.sqrt(r.numel()), 1e-7 * total)
+        assert float((g - r).abs().max()) < 5e-3 * scale, (k, float((g - r).abs().max()), scale)

@@ -1303,3 +1303,46 @@ def test_gemm_gather_forward_and_weight_gradient():
     hip.gemm_gather(1, dA, table, got_s, H, E, Kt, rk, Vt, lda=H, ldb=E, ldc=E, epi=hip.EPI_SPLIT, splits=splits)
     assert torch.equal(got_s, ref_s)
     close(got_s.sum(0), dA.float().t() @ xk.float(), dtype, Kt, "gather weight gradient")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("kind", ["LSTM", "RNN"])
+def test_rnn_cells_fwd_bwd_vs_torch(kind, dtype):
+    """mmtg_rnn_cell_fwd / _bwd (the LSTM and ReLU-RNN encoder cells of model.py:41-59) over a short sequence in the engine's
+    row layout (rows b*S+t) against torch autograd on the same fp32 pre-activations."""
+    B, S, H = 6, 3, 64
+    G = 4 if kind == "LSTM" else 1
+    code = hip.RNN_LSTM if kind == "LSTM" else hip.RNN_RELU
+    gi = rnd(B * S, G * H, dtype=dtype, seed=61).to(DEV)
+    gh = rnd(S, B, G * H, dtype=dtype, seed=62).to(DEV)
+    dh = rnd(B * S, H, dtype=dtype, seed=63).to(DEV)
+    part = rnd(S, B, H, seed=64).to(DEV)              # stands for d(a_{t+1}) W_hh
+    h = torch.zeros(B * S, H, device=DEV, dtype=dtype)
+    c = torch.zeros(S, B, H, device=DEV)
+    save = torch.zeros(S, 5, B, H, device=DEV)
+    for t in range(S):
+        hip.rnn_cell_fwd(code, gi[t:], gh[t], c[t - 1] if t else None, h[t:], c[t], save[t], B, H, ld_gi=S * G * H, ld_h=S * H)
+    # torch reference on the same pre-activations (a = gi + gh per step)
+    a = (gi.float().view(B, S, G * H).transpose(0, 1) + gh.float()).detach().requires_grad_(True)      # [S, B, G H]
+    hs, cp = [], torch.zeros(B, H, device=DEV)
+    for t in range(S):
+        if kind == "LSTM":
+            ai, af, ag, ao = a[t].chunk(4, -1)
+            cp = torch.sigmoid(af) * cp + torch.sigmoid(ai) * torch.tanh(ag)
+            hs.append(torch.sigmoid(ao) * torch.tanh(cp))
+        else:
+            hs.append(torch.relu(a[t]))
+    href = torch.stack(hs, 1).reshape(B * S, H)
+    close(h, href, dtype, 4, kind + " forward")
+    # backward: every step's dh = rows + part (no recurrence through h here: part plays its role), the cell state carries
+    da = torch.zeros(B * S, G * H, device=DEV, dtype=dtype)
+    dc = torch.zeros(B, H, device=DEV)
+    for t in range(S - 1, -1, -1):
+        last = t == S - 1
+        hip.rnn_cell_bwd(code, dh[t:], S * H, None if last else part[t], save[t] if kind == "LSTM" else None,
+                         c[t - 1] if kind == "LSTM" and t else None, h[t:], S * H, dc if kind == "LSTM" else None, not last,
+                         da[t:], S * G * H, B, H)
+    up = dh.float().view(B, S, H).clone()
+    up[:, :S - 1] += part[:S - 1].transpose(0, 1)
+    (href.view(B, S, H) * up).sum().backward()
+    close(da.view(B, S, G * H).transpose(0, 1), a.grad, dtype, 8, kind + " backward")

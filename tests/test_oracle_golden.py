@@ -22,7 +22,10 @@ def _setup(name, requires_grad=False):
     return fx, meta, sh, w, torch.from_numpy(table), batch_to_torch(batch)
 
 
-@pytest.mark.parametrize("case", ["tiny_s5", "tiny_s2"])
+CASES = ["tiny_s5", "tiny_s2", "tiny_lstm2_rnn2", "tiny_gru2_lstm1"]     # the last two: encoder types / depths of model.py:41-59
+
+
+@pytest.mark.parametrize("case", CASES)
 def test_forward_and_intermediates(case):
     fx, meta, sh, w, table, batch = _setup(case)
     col = {}
@@ -44,7 +47,7 @@ def test_forward_and_intermediates(case):
         assert abs(got - ref) <= 2e-5 * max(1.0, abs(ref)), (stage, got, ref)
 
 
-@pytest.mark.parametrize("case", ["tiny_s5", "tiny_s2"])
+@pytest.mark.parametrize("case", CASES)
 def test_grads_and_one_step(case):
     fx, meta, sh, w, table, batch = _setup(case, requires_grad=True)
     hp = json.loads(str(fx["train_hparams"]))
@@ -134,9 +137,9 @@ def test_filtering_kats():
         np.testing.assert_array_equal(out.numpy(), fx["out"][i])
 
 
-@pytest.mark.parametrize("length,row", [(30, 0), (30, 1), (220, 0)])
-def test_greedy_decode_ids(length, row):
-    fx, meta, sh, w, table, batch = _setup("tiny_s5")
+@pytest.mark.parametrize("length,row,case", [(30, 0, "tiny_s5"), (30, 1, "tiny_s5"), (220, 0, "tiny_s5"), (30, 0, "tiny_lstm2_rnn2")])
+def test_greedy_decode_ids(length, row, case):
+    fx, meta, sh, w, table, batch = _setup(case)
     dp = json.loads(str(fx["decode_params"]))
     start = {k: v[row].numpy() for k, v in batch.items() if k != "rating"}
     start["targets"] = np.asarray([1])

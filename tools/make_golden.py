@@ -170,8 +170,8 @@ def greedy_margins(raw, temperature, penalty, length, sent_slot=22):
 
 
 def case_model(name, out_dir, S, n_layer, V, B, seed, full_logits=True,
-               with_grads=True, with_decode=True, decode_rows=(0, 1), store_rawlogits=True):
-    mcfg = make_model_cfgs(seq_len=S)
+               with_grads=True, with_decode=True, decode_rows=(0, 1), store_rawlogits=True, enc=None, decode_lengths=None):
+    mcfg = make_model_cfgs(seq_len=S, **(enc or {}))
     gcfg = gpt2_config(n_layer=n_layer, vocab_size=V, n_positions=256 if n_layer <= 2 else 1024,
                        embd_pdrop=0.0, attn_pdrop=0.0, resid_pdrop=0.0)
     table = synth.make_token_table(V, seed=seed + 1)
@@ -188,7 +188,7 @@ def case_model(name, out_dir, S, n_layer, V, B, seed, full_logits=True,
     fx = {"meta": json.dumps({
         "S": S, "n_layer": n_layer, "V": V, "B": B, "weight_seed": seed,
         "table_seed": seed + 1, "batch_seed": seed + 2,
-        "torch": torch.__version__, "gpt2_cfg": gcfg, "ratings": batch_np["rating"].tolist(),
+        "torch": torch.__version__, "gpt2_cfg": gcfg, "ratings": batch_np["rating"].tolist(), "enc": enc or {},
         "source": "reference src/model.py + src/loss.py executed on CPU fp32"})}
 
     # ---- intermediates via forward hooks ---------------------------------
@@ -295,7 +295,7 @@ def case_model(name, out_dir, S, n_layer, V, B, seed, full_logits=True,
 
         model.forward = rec_forward
         keys = [k for k in batch_np if k != "rating"]
-        for length in (30, 220 if S == 5 else 2 * S * 22):
+        for length in decode_lengths or (30, 220 if S == 5 else 2 * S * 22):
             for row in decode_rows:
                 rec.clear()
                 start = {k: np.asarray(batch_np[k][row]) for k in keys}
@@ -449,12 +449,22 @@ def case_postprocess(out_dir, golden_dir):
     print("wrote", path, [o[:24] for o in outs])
 
 
+def case_variants(out_dir):
+    """The encoder types / depths MultiModalEncoder accepts besides the released 1-layer GRUs (src/model.py:41-59): the reference's
+    own nn.LSTM / nn.RNN(relu) / multi-layer nn.GRU executed on the same synthetic recipe (eval mode: no inter-layer dropout)."""
+    case_model("tiny_lstm2_rnn2", out_dir, S=5, n_layer=2, V=160, B=3, seed=400, decode_rows=(0,), decode_lengths=(30,),
+               enc=dict(image_type="LSTM", image_layers=2, text_type="RNN", text_layers=2))
+    case_model("tiny_gru2_lstm1", out_dir, S=2, n_layer=2, V=160, B=4, seed=500, with_decode=False,
+               enc=dict(image_type="GRU", image_layers=2, text_type="LSTM", text_layers=1))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
     ap.add_argument("--skip-full", action="store_true")
     ap.add_argument("--only-dataset", action="store_true", help="regenerate tests/golden/dataset.npz only")
     ap.add_argument("--only-postprocess", action="store_true", help="regenerate tests/golden/postprocess.npz only")
+    ap.add_argument("--only-variants", action="store_true", help="(re)generate the encoder-variant fixtures only")
     args = ap.parse_args()
     out_dir = os.path.abspath(args.out)
     os.makedirs(out_dir, exist_ok=True)
@@ -463,6 +473,9 @@ def main():
     if args.only_postprocess:
         case_postprocess(out_dir, os.path.join(REPO, "tests", "golden"))
         return
+    if args.only_variants:
+        case_variants(out_dir)
+        return
     case_dataset(out_dir)
     if args.only_dataset:
         return
@@ -470,6 +483,7 @@ def main():
     case_filtering(out_dir, gen)
     case_model("tiny_s2", out_dir, S=2, n_layer=2, V=160, B=4, seed=200, with_decode=False)
     case_postprocess(out_dir, out_dir)
+    case_variants(out_dir)
     if not args.skip_full:
         # (full size: sampled logits + top-5 + LSE, sampled gradients / gradient norms / parameters after one step,
         #  and one greedy sample_sequence run of 30 and of 220 positions with its per-call top-2 margins)
