@@ -219,6 +219,8 @@ _WGRAD_GROUP_SPLITS = int(_os.environ.get("MMTG_WGRAD_GROUP_SPLITS", "0"))    # 
 _GELU_GRAD = _os.environ.get("MMTG_GELU_GRAD", "0") != "0"
 _LMHEAD_GROUP = _os.environ.get("MMTG_LMHEAD_GROUP", "1") != "0"      # the tied embedding's weight gradient through the grouped kernel (A/B switch)
 _LMHEAD_GROUP_SPLITS = int(_os.environ.get("MMTG_LMHEAD_GROUP_SPLITS", "0"))
+# the grouped weight-gradient launches on a SIDE stream, one block behind the dgrad chain (MMTG_WGRAD_STREAM; see Engine.backward)
+_WGRAD_STREAM = _os.environ.get("MMTG_WGRAD_STREAM", "0") != "0"
 _WGRAD_GROUP_CFG = int(_os.environ.get("MMTG_WGRAD_GROUP_CFG", "0"))          # 0: 128x128 tiles, four workgroups per CU; 1: 256x256 eight-phase
 
 
@@ -830,6 +832,18 @@ class Engine:
         for t in tensors:
             hip.prefetch(t, self._pf_sink, _PREFETCH, stream=self._pf_stream)
 
+    def _side_stream(self):
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.dev)
+            self._events = {}
+        return self._side
+
+    def _event(self, i):
+        ev = self._events.get(i)
+        if ev is None:
+            ev = self._events[i] = torch.cuda.Event()
+        return ev
+
     def _ready(self, pack):
         if self.bucket_hook is not None:
             self.bucket_hook(pack)
@@ -865,7 +879,13 @@ class Engine:
             hcnt = self.ws.get(("wgrad_group_cnt", torch.int32))
             if hcnt is None or hcnt.numel() < ncnt:
                 hcnt = self.ws[("wgrad_group_cnt", torch.int32)] = torch.zeros(ncnt, device=self.dev, dtype=torch.int32)
-            hip.wgrad_group([(dlogits, a["hf"], self.Gp("wte"), Vp, D, Vp, D, D)], M, hs, hws, hcnt, accumulate=not self.wgrad_overwrite)
+            side = self._side_stream() if (_WGRAD_STREAM and pr > 0) else None
+            if side is not None:        # beside the LM head's dgrad, ln_f and the last block's chain (reads dlogits / hf only)
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    hip.wgrad_group([(dlogits, a["hf"], self.Gp("wte"), Vp, D, Vp, D, D)], M, hs, hws, hcnt, accumulate=not self.wgrad_overwrite)
+            else:
+                hip.wgrad_group([(dlogits, a["hf"], self.Gp("wte"), Vp, D, Vp, D, D)], M, hs, hws, hcnt, accumulate=not self.wgrad_overwrite)
             if self.wgrad_overwrite and self._ow_rec is not None:
                 self._ow_rec[1].append((self.layout.pack_range["wte"][0], Vp * D))
         else:
@@ -896,19 +916,31 @@ class Engine:
         lastp = f"{pre}h.{sh.L - 1}."
         hip.layernorm_bwd(dhf, a["x_last"], self.P(pre + "ln_f.weight"), a["muf"], a["rsf"], None, dx,
                           self.G(pre + "ln_f.weight"), self.G(pre + "ln_f.bias"), M, D,
-                          dx_masked=dmask, drop_p=pr, drop_seed=a["layers"][sh.L - 1][13][2],
+                          dx_masked=(self.buf("d_masked_1", (M, D)) if (group and _WGRAD_STREAM and pr > 0 and (sh.L - 1) & 1) else dmask), drop_p=pr, drop_seed=a["layers"][sh.L - 1][13][2],
                           dcolsum=self.G(lastp + "mlp.c_proj.bias"), ws=lnws)
         self._ready("ln_f.b")
         du = self.buf("d_u", (M, 4 * D))
         dm = self.buf("d_m", (M, D))
         dctx = self.buf("d_ctx", (M, D))
         dqkv = self.buf("d_qkv", (M, 3 * D))
+        # MMTG_WGRAD_STREAM: block l's grouped weight gradients run on a side stream while the main stream already walks block
+        # l - 1 -- the operands the chain produces (du, the two masked residual gradients, dqkv) then live in two buffer sets that
+        # alternate block by block, and the main stream waits for block l + 1's launch before it rewrites that block's set.
+        stream_mode = group and _WGRAD_STREAM and pr > 0
+        if stream_mode:
+            side = self._side_stream()
+            odd = (self.buf("d_u_1", (M, 4 * D)), self.buf("d_masked_1", (M, D)), self.buf("d_masked_b_1", (M, D)),
+                   self.buf("d_qkv_1", (M, 3 * D)))
+            sets = ((du, dmask, dmask_b, dqkv), odd)
+            wdone = {}
         da = self.buf("d_a", (M, D))
         delta = self.buf("attn_delta", (M, sh.nH), torch.float32)
         dq32 = self.buf("attn_dq32", (M, D), torch.float32)
         for l in range(sh.L - 1, -1, -1):
             p = f"{pre}h.{l}."
             (xin, mu1, rs1, a1, qkv, ctx, lse, xmid, mu2, rs2, m2, u, gact, s) = a["layers"][l]
+            if stream_mode:
+                du, dmask, dmask_b, dqkv = sets[l & 1]
             # x_out = x_mid + drop(gact W2 + b2): dy = dx * mask (already produced, with its bias gradient)
             dy = dmask if pr > 0 else dx
             # (the dGELU epilogue also emits the column sums of du per 64-row band: a [M/64, 4D] reduction
@@ -954,20 +986,39 @@ class Engine:
                 keys = (p + "mlp.c_fc.weight", p + "mlp.c_proj.weight", p + "attn.c_proj.weight", p + "attn.c_attn.weight")
                 probs = [(m2, du, self.G(keys[0]), D, 4 * D), (gact, dy_fc2, self.G(keys[1]), 4 * D, D),
                          (ctx, dy, self.G(keys[2]), D, D), (a1, dqkv, self.G(keys[3]), D, 3 * D)]
-                hip.wgrad_group(probs, M, gsplits, gws, gcnt, accumulate=not self.wgrad_overwrite, config=gcfg)
+                if stream_mode:
+                    side.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(side):
+                        hip.wgrad_group(probs, M, gsplits, gws, gcnt, accumulate=not self.wgrad_overwrite, config=gcfg)
+                        wdone[l] = self._event(l)
+                        wdone[l].record(side)
+                else:
+                    hip.wgrad_group(probs, M, gsplits, gws, gcnt, accumulate=not self.wgrad_overwrite, config=gcfg)
                 if self.wgrad_overwrite and self._ow_rec is not None:
                     self._ow_rec[1].extend((self.layout.entries[k][0], self.layout.entries[k][2]) for k in keys)
             else:
                 self._wgrad(a1, dqkv, p + "attn.c_attn.weight", None, M, "conv1d")
+            if stream_mode and (l + 1) in wdone:
+                # block l + 1's weight gradients have read the set this LayerNorm backward starts to rewrite; its gradients are
+                # final only now (the data-parallel bucket hook must not see them earlier)
+                torch.cuda.current_stream().wait_event(wdone.pop(l + 1))
+                self._ready(f"{pre}h.{l + 1}.ln_1.bias")
             if l > 0:
                 hip.layernorm_bwd(da, xin, self.P(p + "ln_1.weight"), mu1, rs1, dx2, dx,
                                   self.G(p + "ln_1.weight"), self.G(p + "ln_1.bias"), M, D,
-                                  dx_masked=dmask, drop_p=pr, drop_seed=a["layers"][l - 1][13][2],
+                                  dx_masked=(sets[(l - 1) & 1][1] if stream_mode else dmask), drop_p=pr, drop_seed=a["layers"][l - 1][13][2],
                                   dcolsum=self.G(f"{pre}h.{l - 1}.mlp.c_proj.bias"), ws=lnws)
             else:
                 hip.layernorm_bwd(da, xin, self.P(p + "ln_1.weight"), mu1, rs1, dx2, dx,
                                   self.G(p + "ln_1.weight"), self.G(p + "ln_1.bias"), M, D, ws=lnws)
-            self._ready(p + "ln_1.bias")
+            if not stream_mode:
+                self._ready(p + "ln_1.bias")
+        if stream_mode:
+            torch.cuda.current_stream().wait_stream(side)        # block 0's launch (and the tied embedding's, long done)
+            for l_ in sorted(wdone, reverse=True):
+                self._ready(f"{pre}h.{l_}.ln_1.bias")
+        elif _WGRAD_STREAM and pr > 0 and getattr(self, "_side", None) is not None:
+            torch.cuda.current_stream().wait_stream(self._side)  # (only the tied embedding's gradient ran on the side stream)
         # ---- GPT-2 input embedding: h0 = drop(g + wpe + wte[type])
         hip.embed_add_bwd(dx, a["type_ids"], self.G(pre + "wpe.weight"), self.G(pre + "wte.weight"), M, T, D,
                           min(32, sh.V), drop_p=pe, drop_seed=a["seed"])

@@ -48,3 +48,6 @@ for trial in range(int(os.environ.get("TRIALS", "8"))):
     print("trial", trial, "differing tensors:", len(bad), "of which GPT-2 block matrices:", len(mats))
     for x in mats:
         print("   ", x)
+    if os.environ.get("NAMES") and trial == 0:
+        for x in bad:
+            print("    differs:", x[0], "max|d| %.3g of %.3g, %d / %d elements" % x[1:])
