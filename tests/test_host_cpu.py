@@ -29,8 +29,11 @@ def tiny_model(S=5, L=2, V=160):
     return MMTG(mcfg, data_config(seq_len=S), V, gpt2_config=gcfg), mcfg, gcfg
 
 
-def test_state_dict_keys_match_reference():
-    fx, meta, mcfg, gcfg, dcfg, weights, table, batch = load_case("tiny_s5")
+@pytest.mark.parametrize("case", ["tiny_s5", "tiny_lstm2_rnn2", "tiny_gru2_lstm1"])
+def test_state_dict_keys_match_reference(case):
+    """named_parameters() of the reference (recorded in the fixtures) = this model's state dict, also for the LSTM / ReLU-RNN /
+    multi-layer encoder channels of model.py:41-59 (torch.nn.RNNBase names: weight_ih_l{k}, weight_hh_l{k}, bias_*_l{k})."""
+    fx, meta, mcfg, gcfg, dcfg, weights, table, batch = load_case(case)
     model = MMTG(mcfg, dcfg, meta["V"], gpt2_config=gcfg)
     ref_keys = sorted(str(k) for k in fx["grad_keys"])       # named_parameters() of the reference
     sd = model.state_dict()
@@ -40,6 +43,22 @@ def test_state_dict_keys_match_reference():
         assert tuple(sd[k].shape) == v.shape, k
     n = sum(p.numel() for p in model.parameters())
     assert n == sum(v.size for k, v in weights.items() if k != "decoder.gpt2.lm_head.weight")
+
+
+def test_encoder_variants_layout_and_validation():
+    """Channel type / depth are validated like the reference's constructor would fail (unknown type: no rnns_* attribute); the
+    flat layout orders a channel's layers top first (gradient-ready order) and torch's own modules agree on names and shapes."""
+    mcfg = make_model_cfgs(seq_len=3, image_type="LSTM", image_layers=3, text_type="RNN", text_layers=2)
+    lay = ParamLayout(mcfg, gpt2_config(n_layer=1, vocab_size=160, n_positions=128))
+    for ch, mod in (("image", torch.nn.LSTM(2048, 512, num_layers=3)), ("text", torch.nn.RNN(2048, 512, num_layers=2, nonlinearity="relu"))):
+        for k, v in mod.state_dict().items():
+            assert lay.entries["encoder.rnns_%s.%s" % (ch, k)][1] == tuple(v.shape), (ch, k)
+    img = [k for k in lay.keys if k.startswith("encoder.rnns_image.weight_ih")]
+    assert img == ["encoder.rnns_image.weight_ih_l2", "encoder.rnns_image.weight_ih_l1", "encoder.rnns_image.weight_ih_l0"]
+    with pytest.raises(ValueError):
+        ParamLayout(make_model_cfgs(image_type="Transformer"), gpt2_config(n_layer=1))
+    with pytest.raises(ValueError):
+        ParamLayout(make_model_cfgs(text_layers=0), gpt2_config(n_layer=1))
 
 
 def test_full_model_parameter_count():
