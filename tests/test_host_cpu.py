@@ -23,8 +23,8 @@ from mmtg_amd.trainer import curriculum_filter, linear_schedule
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def tiny_model(S=5, L=2, V=160):
-    mcfg = make_model_cfgs(seq_len=S)
+def tiny_model(S=5, L=2, V=160, **enc):
+    mcfg = make_model_cfgs(seq_len=S, **enc)
     gcfg = gpt2_config(n_layer=L, vocab_size=V, n_positions=256)
     return MMTG(mcfg, data_config(seq_len=S), V, gpt2_config=gcfg), mcfg, gcfg
 
@@ -74,10 +74,13 @@ def test_full_model_parameter_count():
     assert bk[0][0] == 0 and bk[-1][1] == lay.total and all(a[1] == b[0] for a, b in zip(bk, bk[1:]))
 
 
-def test_load_state_dict_variants_and_roundtrip(tmp_path):
-    model, mcfg, gcfg = tiny_model()
+@pytest.mark.parametrize("enc", [{}, dict(image_type="LSTM", image_layers=2, text_type="RNN", text_layers=2)])
+def test_load_state_dict_variants_and_roundtrip(tmp_path, enc):
+    model, mcfg, gcfg = tiny_model(**enc)
     sd = {k: v.clone() for k, v in model.state_dict().items()}
-    other, _, _ = tiny_model()
+    if enc:
+        assert sd["encoder.rnns_image.weight_ih_l1"].shape == (2048, 512) and sd["encoder.rnns_text.weight_hh_l1"].shape == (512, 512)
+    other, _, _ = tiny_model(**enc)
     wrapped = {"module." + k: v for k, v in sd.items()}                      # saved from nn.DataParallel
     wrapped["module.decoder.gpt2.transformer.h.0.attn.bias"] = torch.ones(1, 1, 4, 4, dtype=torch.uint8)
     wrapped["module.decoder.gpt2.transformer.h.0.attn.masked_bias"] = torch.tensor(-1e4)
@@ -85,7 +88,7 @@ def test_load_state_dict_variants_and_roundtrip(tmp_path):
     for k, v in other.state_dict().items():
         assert torch.equal(v, sd[k]), k
     torch.save({"model": other.state_dict(), "args": None, "model_cfgs": mcfg}, tmp_path / "ckpt.pth")
-    third, _, _ = tiny_model()
+    third, _, _ = tiny_model(**enc)
     third.load_state_dict(torch.load(tmp_path / "ckpt.pth")["model"])
     assert all(torch.equal(third.state_dict()[k], sd[k]) for k in sd)
     legacy = other.legacy_state_dict()
