@@ -376,11 +376,15 @@ MMTG_API int mmtg_decode_embed_add(int dtype, const void* g, const void* wpe, co
  *                           `ws`: >= tiles * splits * 4096 floats; `counters`: >= 4 * tiles, zero on entry and on return):
  *                           C (bf16) = sum_s partial_s + bias + resid, and stats_out[m][n / 32] = (sum, sum of squares) of the
  *                           stored row segment -- the LayerNorm statistics of the new residual stream as 32-column partials.
+ *                           With type_ids != null the residual is the GPT-2 input embedding instead of a tensor:
+ *                           emb_pos[*pos_ptr][n] + emb_type[type_ids[m]][n] (rows of stride ldr; resid = null) -- projector_layer2
+ *                           and model.py:282-288's position / token-type embedding add in one launch.
  * stats_in / stats_out: f32 [M][32][2] (N <= 1024 in mode 2); np_in = partials to add (1 after mmtg_decode_embed_add, N / 32 after a mode-2 product).  */
 MMTG_API int mmtg_decode_gemm(int mode, int M, int N, int K, const void* A, long lda, const void* W, long ldw, void* C, long ldc,
                      const float* bias, const float* colsum, const float* stats_in, int np_in, float eps, int act, int out_f32,
                      const void* resid, long ldr, float* stats_out, int splits, float* ws, long ws_floats, unsigned* counters,
-                     long n_counters, void* stream);
+                     long n_counters, const void* emb_pos, const void* emb_type, const long long* type_ids, const int* pos_ptr,
+                     void* stream);
 /* Wf[n, k] = gamma[k] W[n, k] (bf16), colsum[n] = sum_k Wf[n, k], bias_f[n] = bias[n] + sum_k beta[k] W[n, k]: the operands of the
  * LN-fold products, LN(x) W^T + b = rstd (x Wf^T - mu colsum) + bias_f.  W: [N, ldw] bf16 K-contiguous; bias may be null.   */
 MMTG_API int mmtg_ln_fold_weights(const void* W, long ldw, const float* gamma, const float* beta, const float* bias, void* Wf,

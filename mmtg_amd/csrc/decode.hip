@@ -402,6 +402,8 @@ struct DgArgs {
     int act, out_f32;
     const bf16* resid; float* stats_out; int np_out;
     float* ws; unsigned* cnt; int ws_bytes;
+    // mode 2, residual = wpe[*pos_ptr] + wte[type_ids[m]] instead of a tensor (the GPT-2 input embedding added in the projector's epilogue)
+    const bf16* emb_pos; const bf16* emb_type; const long long* type_ids; const int* pos_ptr;
 };
 
 template <int MODE>
@@ -579,11 +581,21 @@ __global__ __launch_bounds__(256, 2) void decode_gemm_kernel(DgArgs p) {
                 }
                 if (m < p.M && n < p.N) {
                     const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + n);
-                    const bf16x4 x4 = *reinterpret_cast<const bf16x4*>(p.resid + (long)m * p.ldr + n);
+                    float xr[4];
+                    if (p.type_ids) {
+                        const bf16x4 e0 = *reinterpret_cast<const bf16x4*>(p.emb_pos + (long)*p.pos_ptr * p.ldr + n);
+                        const bf16x4 e1 = *reinterpret_cast<const bf16x4*>(p.emb_type + p.type_ids[m] * p.ldr + n);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) xr[r] = (float)e0[r] + (float)e1[r];
+                    } else {
+                        const bf16x4 x4 = *reinterpret_cast<const bf16x4*>(p.resid + (long)m * p.ldr + n);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) xr[r] = (float)x4[r];
+                    }
                     bf16x4 o;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        o[r] = (bf16)(sum[r] + b4[r] + (float)x4[r]);
+                        o[r] = (bf16)(sum[r] + b4[r] + xr[r]);
                         const float f = (float)o[r];
                         r1 += f;
                         r2 += f * f;
@@ -997,7 +1009,8 @@ extern "C" int mmtg_ln_fold_weights(const void* W, long ldw, const float* gamma,
 extern "C" int mmtg_decode_gemm(int mode, int M, int N, int K, const void* A, long lda, const void* W, long ldw, void* C, long ldc,
                                 const float* bias, const float* colsum, const float* stats_in, int np_in, float eps, int act,
                                 int out_f32, const void* resid, long ldr, float* stats_out, int splits, float* ws, long ws_floats,
-                                unsigned* counters, long n_counters, void* stream) {
+                                unsigned* counters, long n_counters, const void* emb_pos, const void* emb_type,
+                                const long long* type_ids, const int* pos_ptr, void* stream) {
     MMTG_REQUIRE(mode >= 0 && mode <= 2, "decode_gemm: mode 0 (LN-fold), 1 (LN-fold slabs) or 2 (in-kernel split-K reduce)");
     MMTG_REQUIRE(M > 0 && N > 0 && K > 0 && A && W && C, "decode_gemm: bad arguments");
     MMTG_REQUIRE(K % 8 == 0 && lda % 8 == 0 && ldw % 8 == 0 && N % 4 == 0 && ldc % 4 == 0, "decode_gemm: K, lda, ldw multiples of 8; N, ldc of 4");
@@ -1024,7 +1037,9 @@ extern "C" int mmtg_decode_gemm(int mode, int M, int N, int K, const void* A, lo
         MMTG_REQUIRE(mode == 0 || out_f32 == 1, "decode_gemm: mode 1 writes fp32 slabs [splits][M][ldc]");
         MMTG_REQUIRE(act == MMTG_EPI_NONE || act == MMTG_EPI_GELU, "decode_gemm: activation NONE or GELU");
     } else {
-        MMTG_REQUIRE(bias && resid && stats_out && N % 32 == 0 && N / 32 <= DG_NP && ldr % 4 == 0 && MMTG_ALIGNED16(bias),
+        MMTG_REQUIRE(!type_ids || (emb_pos && emb_type && pos_ptr && !resid), "decode_gemm: the embedding residual takes wpe, wte, type ids and the position (and no resid)");
+        a.emb_pos = (const bf16*)emb_pos; a.emb_type = (const bf16*)emb_type; a.type_ids = type_ids; a.pos_ptr = pos_ptr;
+        MMTG_REQUIRE(bias && (resid || type_ids) && stats_out && N % 32 == 0 && N / 32 <= DG_NP && ldr % 4 == 0 && MMTG_ALIGNED16(bias),
                      "decode_gemm: the reduce mode needs bias, residual and the statistics output; N a multiple of 32, at most %d", 32 * DG_NP);
         MMTG_REQUIRE(a.splits <= 8, "decode_gemm: at most 8 K splits in the reduce mode");
         MMTG_REQUIRE(a.splits == 1 || (ws && counters && ws_floats >= (long)a.ntiles * a.splits * 4096 && n_counters >= (long)a.ntiles * 4),

@@ -116,6 +116,8 @@ class GreedyDecoder:
                 self.rws = f32(tiles * max(self.splits[1], self.splits[3]) * 4096)
                 self.rcnt = torch.zeros(tiles * 4, dtype=torch.int32, device=dev)
                 self.folds_for = None
+                # (MMTG_DECODE_EMBED_IN_PROJ=0: projector_layer2 and the embedding add as two launches, the round-3 v8 step)
+                self.embed_in_proj = os.environ.get("MMTG_DECODE_EMBED_IN_PROJ", "1") != "0" and H % 8 == 0
         self.pos, self.pos_next = self.pos_pair
         self.uniforms = None
         self.graphs = {}
@@ -154,10 +156,16 @@ class GreedyDecoder:
                          sh.max_seq_length // sent + 1)
         eng._fwd(self.x, "decoder.projector_layer1.weight", self.h1, B, "linear",
                  bias=eng.P("decoder.projector_layer1.bias"), epi=hip.EPI_TANH)
-        eng._fwd(self.h1, "decoder.projector_layer2.weight", self.h, B, "linear", bias=eng.P("decoder.projector_layer2.bias"))
         fused = getattr(self, "fused", False)
-        hip.decode_embed_add(self.h, eng.W(pre + "wpe.weight"), eng.W(pre + "wte.weight"), self.types, self.pos, self.h, B, D,
-                             stats=self.st[0] if fused else None)
+        if fused and self.embed_in_proj:
+            # projector_layer2 + the GPT-2 input embedding (wpe[pos] + wte[type]) + the first LayerNorm statistics in one launch
+            w2 = eng.W("decoder.projector_layer2.weight")
+            hip.decode_gemm(2, self.h1, w2, self.h, B, D, H, bias=eng.P("decoder.projector_layer2.bias"), stats_out=self.st[0],
+                            emb_pos=eng.W(pre + "wpe.weight"), emb_type=eng.W(pre + "wte.weight"), type_ids=self.types, pos=self.pos, ldr=D)
+        else:
+            eng._fwd(self.h1, "decoder.projector_layer2.weight", self.h, B, "linear", bias=eng.P("decoder.projector_layer2.bias"))
+            hip.decode_embed_add(self.h, eng.W(pre + "wpe.weight"), eng.W(pre + "wte.weight"), self.types, self.pos, self.h, B, D,
+                                 stats=self.st[0] if fused else None)
         hcur, hnext = self.h, self.h2
         if fused:
             self._layers_fused(hcur, hnext, with_head)

@@ -73,7 +73,8 @@ _SIGS = {
     "mmtg_logits_process_argmax": ([_vp, _l, _i, _vp, _l, _vp, _f, _f, _vp, _i, _vp], _i),
     "mmtg_decode_embed": ([_i, _vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
     "mmtg_decode_embed_add": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp], _i),
-    "mmtg_decode_gemm": ([_i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _vp, _vp, _vp, _i, _f, _i, _i, _vp, _l, _vp, _i, _vp, _l, _vp, _l, _vp], _i),
+    "mmtg_decode_gemm": ([_i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _vp, _vp, _vp, _i, _f, _i, _i, _vp, _l, _vp, _i, _vp, _l, _vp, _l,
+                          _vp, _vp, _vp, _vp, _vp], _i),
     "mmtg_ln_fold_weights": ([_vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp], _i),
     "mmtg_decode_attn": ([_i, _vp, _vp, _vp, _vp, _l, _vp, _vp, _i, _i, _i, _i, _vp], _i),
     "mmtg_decode_attn_split": ([_i, _vp, _i, _vp, _vp, _vp, _vp, _l, _vp, _vp, _i, _i, _i, _i, _vp], _i),
@@ -467,13 +468,14 @@ DG_NP = 32      # statistics partials per row (include/mmtg_hip.h, mmtg_decode_g
 
 
 def decode_gemm(mode, A, W, C_, M, N, K, bias=None, colsum=None, stats_in=None, np_in=0, eps=1e-5, act=EPI_NONE, out_f32=False,
-                resid=None, stats_out=None, splits=1, ws=None, counters=None, lda=None, ldw=None, ldc=None, ldr=None):
+                resid=None, stats_out=None, splits=1, ws=None, counters=None, lda=None, ldw=None, ldc=None, ldr=None,
+                emb_pos=None, emb_type=None, type_ids=None, pos=None):
     """The fused products of the decode step (include/mmtg_hip.h, mmtg_decode_gemm)."""
     _check(lib().mmtg_decode_gemm(int(mode), M, N, K, _p(A), K if lda is None else lda, _p(W), K if ldw is None else ldw, _p(C_),
                                   N if ldc is None else ldc, _p(bias), _p(colsum), _p(stats_in), int(np_in), float(eps), int(act),
                                   int(out_f32), _p(resid), N if ldr is None else ldr, _p(stats_out), int(splits), _p(ws),
                                   0 if ws is None else ws.numel(), _p(counters), 0 if counters is None else counters.numel(),
-                                  _stream()), "decode_gemm")
+                                  _p(emb_pos), _p(emb_type), _p(type_ids), _p(pos), _stream()), "decode_gemm")
 
 
 def ln_fold_weights(W, gamma, beta, bias, Wf, colsum, bias_f, N, K, ldw=None):
