@@ -122,17 +122,17 @@ __global__ __launch_bounds__(256) void row_lse_kernel(const LT* __restrict__ log
 }
 
 // single block: per-sample CE, rating-conditioned loss, coefficients, both scalars
-__global__ __launch_bounds__(256) void sample_loss_kernel(const float* __restrict__ nll,
+__global__ __launch_bounds__(1024) void sample_loss_kernel(const float* __restrict__ nll,
         const long long* __restrict__ ratings, int stage, int B, int P, int L, float batch_den,
         float* __restrict__ sample_ce, float* __restrict__ coef, float* __restrict__ scalars) {
-    __shared__ float sh[4];
+    __shared__ float sh[32];
     const int Tt = P + L;
     const int ntok = Tt - 1 - P;  // rows P .. T-2  (loss.py:62-63)
     float my = 0.f, lm = 0.f;
     // (round 3: one wave per sample, the token sum spread over its lanes -- the one-thread-per-sample loop walked 235 dependent
-    //  global loads per sample: 37 us of a 131 us loss forward)
+    //  global loads per sample: 37 us of a 131 us loss forward; sixteen waves: every wave's samples are one load latency apart)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int b = wave; b < B; b += 4) {
+    for (int b = wave; b < B; b += 16) {
         float ce = 0.f, all = 0.f;
         for (int t = lane; t < Tt - 1; t += 64) {
             const float n = nll[(long)b * Tt + t];
@@ -157,9 +157,11 @@ __global__ __launch_bounds__(256) void sample_loss_kernel(const float* __restric
         coef[b] = cf / (ntok * batch_den);
         my += lb;
     }
-    my = block_sum(my, sh);
-    lm = block_sum(lm, sh);
+    if (lane == 0) { sh[wave] = my; sh[16 + wave] = lm; }
+    __syncthreads();
     if (threadIdx.x == 0) {
+        my = lm = 0.f;
+        for (int w = 0; w < 16; ++w) { my += sh[w]; lm += sh[16 + w]; }       // fixed order
         scalars[0] = my / batch_den;
         scalars[1] = lm / ((float)B * (Tt - 1));
     }
@@ -239,7 +241,7 @@ extern "C" int mmtg_loss_fwd(int logits_dtype, const void* logits, long ldl, int
         hipLaunchKernelGGL(row_lse_kernel<float>, dim3((unsigned)M), dim3(256), 0, s, (const float*)logits, ldl, V, topic_ids, targets, label_zero, P, L, nll, lse);
     else
         hipLaunchKernelGGL(row_lse_kernel<bf16>, dim3((unsigned)M), dim3(256), 0, s, (const bf16*)logits, ldl, V, topic_ids, targets, label_zero, P, L, nll, lse);
-    hipLaunchKernelGGL(sample_loss_kernel, dim3(1), dim3(256), 0, s, nll, ratings, stage, B, P, L, batch_den, sample_ce, coef, scalars);
+    hipLaunchKernelGGL(sample_loss_kernel, dim3(1), dim3(1024), 0, s, nll, ratings, stage, B, P, L, batch_den, sample_ce, coef, scalars);
     MMTG_LAUNCH_CHECK("loss_fwd");
     return MMTG_OK;
 }
