@@ -832,3 +832,39 @@ def test_rnn_interlayer_dropout_training_mode_vs_oracle():
         g, r = eng.G(k).float().cpu().flatten(), w[k].grad.flatten()
         scale = max(float(r.abs().max()), float(r.norm()) / np.sqrt(r.numel()), 1e-7 * total)
         assert float((g - r).abs().max()) < 5e-3 * scale, (k, float((g - r).abs().max()), scale)
+
+
+def test_weight_gradients_on_a_side_stream_match_the_default_order(monkeypatch):
+    """MMTG_WGRAD_STREAM (opt-in): block l's grouped weight-gradient launch runs on a side stream while the main stream walks
+    block l - 1, its operands double-buffered block by block.  Same kernels, same summation order: the block matrices must be
+    BIT-equal to the default schedule's, everything else equal up to the fp32-atomic column sums (3-layer model so that both
+    buffer sets and the wait before a set is rewritten are exercised; dropout on -- the side-stream path needs the masked copies)."""
+    import mmtg_amd.engine as E
+    from mmtg_amd import synth
+    from mmtg_amd.configs import data_config, gpt2_config, make_model_cfgs
+    S, V = 5, 160
+    mcfg, dcfg = make_model_cfgs(seq_len=S), data_config(seq_len=S)
+    gcfg = gpt2_config(n_layer=3, vocab_size=V, n_positions=256, embd_pdrop=0.1, attn_pdrop=0.1, resid_pdrop=0.1)
+    weights = synth.make_weights(mcfg, gcfg, seed=100)
+    nb = synth.make_batch(6, mcfg, dcfg, V, seed=7)
+    tb = {k: torch.from_numpy(np.asarray(v)).to(DEV) for k, v in nb.items()}
+    grads = []
+    for stream in (False, True):
+        monkeypatch.setattr(E, "_WGRAD_STREAM", stream)
+        model = MMTG(mcfg, dcfg, V, train_flag=True, gpt2_config=gcfg, token_table=synth.make_token_table(V, seed=101), compute_dtype="bf16")
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})
+        model.to(DEV).train()
+        tr = MMTGTrainer(model, lr=0.0, alpha=0.2)
+        for _ in range(2):              # the second step runs on the lazily zeroed buffer
+            tr.eng.drop_seed = 4242
+            tr.step(tb, stage=3)
+        torch.cuda.synchronize()
+        assert (getattr(tr.eng, "_side", None) is not None) == stream
+        grads.append((tr.eng.grad.clone(), model.layout))
+    (g0, lay), (g1, _) = grads
+    for k, (off, shape, n) in lay.entries.items():
+        a, b = g0[off:off + n], g1[off:off + n]
+        if ".h." in k and k.endswith(".weight") and ".ln_" not in k:        # the grouped launch's outputs
+            assert torch.equal(a, b), k
+        else:
+            assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(a.abs().max())), k
