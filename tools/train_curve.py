@@ -13,7 +13,12 @@ from mmtg_amd.trainer import MMTGTrainer
 S, V, B = 5, 13317, 64
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 120
 every = max(10, steps // 12)
-mcfg, dcfg = make_model_cfgs(seq_len=S), data_config(seq_len=S)
+# ENC="LSTM,2,RNN,2": image type / layers, text type / layers (the encoder channel variants of model.py:41-59; default: released GRUs)
+enc = {}
+if os.environ.get("ENC"):
+    it, il, tt, tl = os.environ["ENC"].split(",")
+    enc = dict(image_type=it, image_layers=int(il), text_type=tt, text_layers=int(tl))
+mcfg, dcfg = make_model_cfgs(seq_len=S, **enc), data_config(seq_len=S)
 gcfg = gpt2_config(n_layer=12, vocab_size=V)
 model = MMTG(mcfg, dcfg, V, train_flag=True, gpt2_config=gcfg, compute_dtype="bf16", token_table=synth.make_token_table(V, seed=2))
 model.reset_parameters(seed=0)
