@@ -914,9 +914,11 @@ class Engine:
             if gcnt is None or gcnt.numel() < ncnt:      # zero once: every launch leaves the counters zeroed
                 gcnt = self.ws[("wgrad_group_cnt", torch.int32)] = torch.zeros(ncnt, device=self.dev, dtype=torch.int32)
         lastp = f"{pre}h.{sh.L - 1}."
+        # (MMTG_WGRAD_STREAM: the top block's masked gradient goes into the buffer set of that block's parity, see below)
+        dmask_top = self.buf("d_masked_1", (M, D)) if (group and _WGRAD_STREAM and pr > 0 and (sh.L - 1) & 1) else dmask
         hip.layernorm_bwd(dhf, a["x_last"], self.P(pre + "ln_f.weight"), a["muf"], a["rsf"], None, dx,
                           self.G(pre + "ln_f.weight"), self.G(pre + "ln_f.bias"), M, D,
-                          dx_masked=(self.buf("d_masked_1", (M, D)) if (group and _WGRAD_STREAM and pr > 0 and (sh.L - 1) & 1) else dmask), drop_p=pr, drop_seed=a["layers"][sh.L - 1][13][2],
+                          dx_masked=dmask_top, drop_p=pr, drop_seed=a["layers"][sh.L - 1][13][2],
                           dcolsum=self.G(lastp + "mlp.c_proj.bias"), ws=lnws)
         self._ready("ln_f.b")
         du = self.buf("d_u", (M, 4 * D))
