@@ -107,8 +107,10 @@ def test_device_loader_feeds_the_trainer(tmp_path):
     assert seen == 3
 
 
-def test_checkpoint_resume_continues_the_run(tmp_path):
-    """save_checkpoint after two steps, two more steps; a fresh model + trainer restored from the file and run
+@pytest.mark.parametrize("enc", [{}, dict(image_type="LSTM", image_layers=2, text_type="GRU", text_layers=2)])
+def test_checkpoint_resume_continues_the_run(tmp_path, enc):
+    """(second case: 2-layer LSTM / GRU encoder channels -- the inter-layer dropout counter and the extra layers' moments travel too)
+    save_checkpoint after two steps, two more steps; a fresh model + trainer restored from the file and run
     on the same two batches lands on the same parameters: the optimizer moments, AdamW step, scheduler position
     and dropout counter all travel (dropout ON, warm-up schedule).  Tolerance: 2e-5 relative on the flat fp32
     parameter vector (the few fp32-atomic reductions left -- embeddings, LM-head weight gradient -- are not
@@ -119,7 +121,7 @@ def test_checkpoint_resume_continues_the_run(tmp_path):
     from mmtg_amd.configs import data_config, gpt2_config, make_model_cfgs
     from mmtg_amd.trainer import MMTGTrainer, load_checkpoint, save_checkpoint
     S, V = 5, 300
-    mcfg, dcfg = make_model_cfgs(seq_len=S), data_config(seq_len=S)
+    mcfg, dcfg = make_model_cfgs(seq_len=S, **enc), data_config(seq_len=S)
     gcfg = gpt2_config(n_layer=2, vocab_size=V, n_positions=256)
     table = synth.make_token_table(V, seed=2)
     batches = [{k: torch.from_numpy(np.asarray(v)).cuda() for k, v in synth.make_batch(6, mcfg, dcfg, V, seed=30 + i).items()}
