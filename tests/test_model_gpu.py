@@ -868,3 +868,52 @@ def test_weight_gradients_on_a_side_stream_match_the_default_order(monkeypatch):
             assert torch.equal(a, b), k
         else:
             assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(a.abs().max())), k
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_non_released_encoder_sizes_and_types_vs_oracle(dtype):
+    """Encoder sizes the released checkpoint does not use, with the reference's other channel types: 1024-d input embeddings,
+    hidden 256, 2 attention heads, S = 3 steps, a 1-layer LSTM image channel and a 3-layer ReLU-RNN text channel -- HIP engine vs
+    the CPU oracle (pinned to the reference by the golden fixtures) on identical seeded weights and batch.
+    f32: logits <= 1e-3, loss / KL 1e-4 rel, gradients <= 2e-3 of each tensor's max; bf16: gradient cosine >= 0.99."""
+    from mmtg_amd import synth
+    from mmtg_amd.configs import data_config, gpt2_config, make_model_cfgs
+    S, V, B, E = 3, 200, 5, 1024
+    mcfg = make_model_cfgs(seq_len=S, wenlan_dim=E, hidden=256, heads=2, dropout=0.0,
+                           image_type="LSTM", image_layers=1, text_type="RNN", text_layers=3)
+    dcfg = data_config(seq_len=S, wenlan_emb_size=E)
+    gcfg = gpt2_config(n_layer=2, vocab_size=V, n_positions=256, embd_pdrop=0.0, attn_pdrop=0.0, resid_pdrop=0.0)
+    weights = synth.make_weights(mcfg, gcfg, seed=21)
+    table = synth.make_token_table(V, emb=E, seed=22)
+    nb = synth.make_batch(B, mcfg, dcfg, V, seed=23)
+    model = MMTG(mcfg, dcfg, V, train_flag=True, gpt2_config=gcfg, token_table=table, compute_dtype=dtype)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})
+    model.to(DEV)
+    model.eval()
+    tb = {k: torch.from_numpy(np.asarray(v)).to(DEV) for k, v in nb.items()}
+    lm, kl, logits = model(tb)
+    loss = MyLoss(dcfg, mcfg)(logits, tb["targets"], tb["rating"], 2)
+    (loss + 0.2 * kl).backward()
+    sh = O.Shapes(mcfg, dcfg, gcfg)
+    w = O.weights_to_torch(weights, True)
+    cb = {k: torch.from_numpy(np.asarray(v)) for k, v in nb.items()}
+    _, okl, ologits = O.mmtg_forward(w, sh, torch.from_numpy(table), cb, True)
+    oloss = O.my_loss(ologits, cb["targets"], cb["rating"], 2, sh.P)
+    (oloss + 0.2 * okl).backward()
+    f32 = dtype == "f32"
+    err = (logits.detach().float().cpu() - ologits.detach()).abs()
+    top = float(ologits.detach().abs().max())
+    assert float(err.max()) < (1e-3 if f32 else 0.025 * top), (float(err.max()), top)
+    rel = 1e-4 if f32 else 3e-2
+    assert abs(loss.item() - oloss.item()) <= rel * max(1.0, abs(oloss.item()))
+    assert abs(kl.item() - okl.item()) <= rel * max(1.0, abs(okl.item()))
+    total = float(torch.sqrt(sum((t.grad.double() ** 2).sum() for t in {id(t): t for t in w.values()}.values())))
+    for k, p in model.named_parameters():
+        g, r = p.grad.float().cpu(), w[k].grad
+        if float(r.norm()) < 1e-5 * total:
+            continue
+        if f32:
+            assert float((g - r).abs().max()) <= 2e-3 * float(r.abs().max()) + 1e-7, k
+        else:
+            cos = float(torch.dot(g.flatten(), r.flatten()) / (g.norm() * r.norm() + 1e-30))
+            assert cos > 0.99, (k, cos)
