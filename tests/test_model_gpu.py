@@ -917,3 +917,40 @@ def test_non_released_encoder_sizes_and_types_vs_oracle(dtype):
         else:
             cos = float(torch.dot(g.flatten(), r.flatten()) / (g.norm() * r.norm() + 1e-30))
             assert cos > 0.99, (k, cos)
+
+
+@pytest.mark.parametrize("enc", [{}, dict(image_type="LSTM", image_layers=2, text_type="RNN", text_layers=1)])
+def test_single_experience_step_vs_oracle(enc):
+    """Edge of the recurrent channels: S = 1 (no recurrent product at all: every step-0 cell takes b_hh alone, the W_hh gradients are
+    exactly zero, the Gaussian prior is the 1 x 1 identity so both KL terms vanish).  f32 engine vs the oracle."""
+    from mmtg_amd import synth
+    from mmtg_amd.configs import data_config, gpt2_config, make_model_cfgs
+    S, V, B = 1, 160, 2
+    mcfg = make_model_cfgs(seq_len=S, dropout=0.0, **enc)
+    dcfg = data_config(seq_len=S)
+    gcfg = gpt2_config(n_layer=2, vocab_size=V, n_positions=256, embd_pdrop=0.0, attn_pdrop=0.0, resid_pdrop=0.0)
+    weights = synth.make_weights(mcfg, gcfg, seed=31)
+    table = synth.make_token_table(V, seed=32)
+    nb = synth.make_batch(B, mcfg, dcfg, V, seed=33)
+    model = MMTG(mcfg, dcfg, V, train_flag=True, gpt2_config=gcfg, token_table=table, compute_dtype="f32")
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})
+    model.to(DEV)
+    model.eval()
+    tb = {k: torch.from_numpy(np.asarray(v)).to(DEV) for k, v in nb.items()}
+    lm, kl, logits = model(tb)
+    loss = MyLoss(dcfg, mcfg)(logits, tb["targets"], tb["rating"], 2)
+    (loss + 0.2 * kl).backward()
+    sh = O.Shapes(mcfg, dcfg, gcfg)
+    w = O.weights_to_torch(weights, True)
+    cb = {k: torch.from_numpy(np.asarray(v)) for k, v in nb.items()}
+    _, okl, ologits = O.mmtg_forward(w, sh, torch.from_numpy(table), cb, True)
+    oloss = O.my_loss(ologits, cb["targets"], cb["rating"], 2, sh.P)
+    (oloss + 0.2 * okl).backward()
+    assert float((logits.detach().cpu() - ologits.detach()).abs().max()) < 1e-3
+    assert abs(loss.item() - oloss.item()) < 1e-4 * abs(oloss.item()) and abs(kl.item()) < 1e-6 and abs(okl.item()) < 1e-6
+    total = float(torch.sqrt(sum((t.grad.double() ** 2).sum() for t in {id(t): t for t in w.values()}.values())))
+    for k, p in model.named_parameters():
+        r = w[k].grad
+        assert float((p.grad.cpu() - r).abs().max()) <= 2e-3 * float(r.abs().max()) + 1e-8 * total, k
+        if "weight_hh" in k:
+            assert float(p.grad.abs().max()) == 0.0 and float(r.abs().max()) == 0.0, k
