@@ -1257,6 +1257,12 @@ extern "C" int mmtg_attn_trace(void* buf) {
     return MMTG_OK;
 }
 
+// A/B route switches, read ONCE per process and shared by the forward and the backward: the two passes must pick the same
+// kernel family (whole-head and tiled kernels draw different dropout-mask families), so a switch flipped mid-process cannot
+// pair a forward of one family with a backward of the other.
+static bool attn_route_tiled() { static const bool v = getenv("MMTG_ATTN_TILED") != nullptr; return v; }     // tiled kernels for every T
+static bool attn_route_no512() { static const bool v = getenv("MMTG_ATTN_NO512") != nullptr; return v; }     // tiled kernels for 256 < T <= 512 (round 2)
+
 extern "C" int mmtg_attn_fwd(int dtype, const void* qkv, const int* keep, void* out, float* lse,
                              int B, int T, int nH, int dh, unsigned drop_thresh, unsigned drop_seed, void* stream) {
     MMTG_REQUIRE(dh == DH, "attn_fwd: head dim %d unsupported (built for 64)", dh);
@@ -1269,8 +1275,7 @@ extern "C" int mmtg_attn_fwd(int dtype, const void* qkv, const int* keep, void* 
     ProfScope prof(MMTG_PROF_ATTN_FWD, s, 2.0 * B * nH * (double)T * T * dh, esz * 4.0 * B * T * nH * dh);
     dim3 grid(cdiv(T, 64), nH, B), block(256);
     const float ik = inv_keep_of(drop_thresh);
-    static const bool legacy = getenv("MMTG_ATTN_TILED") != nullptr;      // A/B switch: the tiled kernel for every T
-    static const bool no512 = getenv("MMTG_ATTN_NO512") != nullptr;     // A/B switch: the tiled kernels for 256 < T <= 512 (round 2)
+    const bool legacy = attn_route_tiled(), no512 = attn_route_no512();
     if (dtype == MMTG_BF16 && T <= (no512 ? 256 : SM_MAXT) && !legacy) {
         static bool attr_set = false;
         if (!attr_set) {
@@ -1336,7 +1341,7 @@ extern "C" int mmtg_attn_bwd(int dtype, const void* qkv, const int* keep, const 
         if (nkb > 1) { if (hipMemsetAsync(dq32, 0, rows * D * sizeof(float), s) != hipSuccess) MMTG_FAIL(MMTG_ERR_HIP, "attn_bwd: memset failed"); }
         hipLaunchKernelGGL((attn_bwd_kernel<float, 4>), dim3(nkb, nH, B), dim3(256), shm, s, (const float*)qkv, keep, (const float*)dout, lse, delta, dq32, (float*)dqkv, bias_dst, bias_rows, T, nH, nkb == 1, drop_thresh, drop_seed, ik, ablate);
         if (nkb > 1) hipLaunchKernelGGL(attn_dq_finish_kernel<float>, dim3(2048), dim3(256), 0, s, dq32, (float*)dqkv, rows, D);
-    } else if (dtype == MMTG_BF16 && T <= (getenv("MMTG_ATTN_NO512") ? 256 : SM_MAXT) && !getenv("MMTG_ATTN_TILED")) {
+    } else if (dtype == MMTG_BF16 && T <= (attn_route_no512() ? 256 : SM_MAXT) && !attn_route_tiled()) {
         small_path = true;
         static bool attr_small = false;
         if (!attr_small) {

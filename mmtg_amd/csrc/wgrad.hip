@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256, 4) void wgrad_group_kernel(WgArgs a) {
 // LDS fill bytes per FLOP of the 128x128 kernel (the fill path bounds that one: four workgroups pull 4 x 32 KB per K step
 // through the CU's 52 B/clk L2 port).  As a per-product kernel it lost (gemm.hip: 7-24 slabs per product, a 256 KB slab
 // store and a cold prologue exposed per 17-34 K tiles); grouped, a workgroup runs 118 K tiles and 108 tiles x 2 K halves =
-// 216 workgroups fill 84 % of the CUs in one round.  Rows of K past the end are zero-filled by the buffer descriptor.
+// 216 workgroups fill 84 % of the CUs in one round.  Rows of K past the end of a slice are requested out of range per lane (zeros).
 __device__ __forceinline__ void g8_issue(__amdgpu_buffer_rsrc_t r, char* d0, char* d1, int v0, int v1, int soff) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, LDS_PTR(void, d0), 16, v0, soff, 0, 0);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, LDS_PTR(void, d1), 16, v1, soff, 0, 0);
@@ -305,10 +305,14 @@ __global__ __launch_bounds__(512, 1) void wgrad_group_p8_kernel(WgArgs a) {
     const int vA10 = g8_voff<8>(lda, m0, M, 1, wave, lane), vA11 = g8_voff<8>(lda, m0, M, 1, wave + 8, lane);
     const int vB00 = g8_voff<4>(ldb, n0, N, 0, wave, lane), vB01 = g8_voff<4>(ldb, n0, N, 0, wave + 8, lane);
     const int vB10 = g8_voff<4>(ldb, n0, N, 1, wave, lane), vB11 = g8_voff<4>(ldb, n0, N, 1, wave + 8, lane);
-#define G8_A0(t_) g8_issue(ra, smem + ((t_) & 1) * STAGE + lA00, smem + ((t_) & 1) * STAGE + lA01, (t_) < nk ? vA00 : OOB, (t_) < nk ? vA01 : OOB, sa0 + (t_) * stepa)
-#define G8_A1(t_) g8_issue(ra, smem + ((t_) & 1) * STAGE + lA10, smem + ((t_) & 1) * STAGE + lA11, (t_) < nk ? vA10 : OOB, (t_) < nk ? vA11 : OOB, sa0 + (t_) * stepa)
-#define G8_B0(t_) g8_issue(rb, smem + ((t_) & 1) * STAGE + lB00, smem + ((t_) & 1) * STAGE + lB01, (t_) < nk ? vB00 : OOB, (t_) < nk ? vB01 : OOB, sb0 + (t_) * stepb)
-#define G8_B1(t_) g8_issue(rb, smem + ((t_) & 1) * STAGE + lB10, smem + ((t_) & 1) * STAGE + lB11, (t_) < nk ? vB10 : OOB, (t_) < nk ? vB11 : OOB, sb0 + (t_) * stepb)
+    // k-row (inside a K tile) of this lane in its two DMA blocks: rows at or past the end of the K slice are requested out of
+    // range PER LANE (the row offset of a K tile travels in the scalar offset, which the descriptor's bounds check may not
+    // cover -- a ragged last slice must not depend on it)
+    const int kl0 = wave * 4 + (lane >> 4), kl1 = kl0 + 32;
+#define G8_A0(t_) g8_issue(ra, smem + ((t_) & 1) * STAGE + lA00, smem + ((t_) & 1) * STAGE + lA01, (t_) * 64 + kl0 < klen ? vA00 : OOB, (t_) * 64 + kl1 < klen ? vA01 : OOB, sa0 + (t_) * stepa)
+#define G8_A1(t_) g8_issue(ra, smem + ((t_) & 1) * STAGE + lA10, smem + ((t_) & 1) * STAGE + lA11, (t_) * 64 + kl0 < klen ? vA10 : OOB, (t_) * 64 + kl1 < klen ? vA11 : OOB, sa0 + (t_) * stepa)
+#define G8_B0(t_) g8_issue(rb, smem + ((t_) & 1) * STAGE + lB00, smem + ((t_) & 1) * STAGE + lB01, (t_) * 64 + kl0 < klen ? vB00 : OOB, (t_) * 64 + kl1 < klen ? vB01 : OOB, sb0 + (t_) * stepb)
+#define G8_B1(t_) g8_issue(rb, smem + ((t_) & 1) * STAGE + lB10, smem + ((t_) & 1) * STAGE + lB11, (t_) * 64 + kl0 < klen ? vB10 : OOB, (t_) * 64 + kl1 < klen ? vB11 : OOB, sb0 + (t_) * stepb)
     int oa[4], ob[2];
     ks_offsets<128, 4>(wr * 64, lane, oa);
     ks_offsets<128, 2>(wc * 32, lane, ob);

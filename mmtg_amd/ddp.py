@@ -20,8 +20,31 @@ GPUs are visible).
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
+
+# The CU reservation is a process-global setting of the GEMM library; reducers come and go (a trainer rebuilt after a
+# checkpoint resume, a test that builds several), so it is reference-counted here: the first live reducer sets it, the last
+# one to close gives the CUs back -- a stale reducer collected late cannot clear a live one's reservation.
+_budget_users = 0
+
+
+def _budget_acquire():
+    global _budget_users
+    from . import hip
+    if _budget_users == 0:
+        hip.gemm_cu_budget(int(os.environ.get("MMTG_DDP_GEMM_CUS", "-32")))
+    _budget_users += 1
+
+
+def _budget_release():
+    global _budget_users
+    from . import hip
+    _budget_users = max(0, _budget_users - 1)
+    if _budget_users == 0:
+        hip.gemm_cu_budget(0)
 
 
 class GradReducer:
@@ -31,16 +54,16 @@ class GradReducer:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.layout = layout
         # MMTG_FORCE_DDP: run the collectives even at world size 1 (single-GPU self-test of the RCCL path)
-        self.force = dist.is_initialized() and bool(__import__("os").environ.get("MMTG_FORCE_DDP"))
+        self.force = dist.is_initialized() and bool(os.environ.get("MMTG_FORCE_DDP"))
         self.buckets = layout.buckets(int(bucket_mb * 1024 * 1024 / 4))
         self._budget_set = False
         if self.world > 1 and torch.cuda.is_available():
             # the RCCL kernels run beside the backward and hold their CUs for the whole collective; a workgroup of the
             # eight-phase GEMM kernel needs a CU to itself, so its tile rule must not plan on all 256 (MMTG_DDP_GEMM_CUS:
             # > 0 = CUs it may count on, < 0 = CUs to leave to the collectives; default 32 left).  GPU runs only: on CPU
-            # tensors (gloo tests) there is no library to tell.  The setting is process-global; close() restores it.
-            from . import hip
-            hip.gemm_cu_budget(int(__import__("os").environ.get("MMTG_DDP_GEMM_CUS", "-32")))
+            # tensors (gloo tests) there is no library to tell.  The setting is process-global and reference-counted
+            # (_budget_acquire / _budget_release): close() of the LAST live reducer restores it.
+            _budget_acquire()
             self._budget_set = True
         self.pack_end = {name: o + n for name, (o, n) in layout.pack_range.items()}
         self.reset()
@@ -48,9 +71,8 @@ class GradReducer:
     def close(self):
         """Give the CUs reserved for the collectives back to the GEMM tile rule (decode / inference in the same process)."""
         if self._budget_set:
-            from . import hip
-            hip.gemm_cu_budget(0)
             self._budget_set = False
+            _budget_release()
 
     def __del__(self):
         try:

@@ -339,12 +339,15 @@ class GreedyDecoder:
 
     @torch.no_grad()
     def generate(self, batch, length, temperature=1.0, repitition_penalty=1.0, top_k=1, top_p=0.0, generator=None,
-                 use_graph=None):
+                 use_graph=None, teacher=None, tap=None):
         """batch: dict with topic_ids/tpw_* [B,P], topic_emb, img_embs, r_embs (no targets needed).
         Runs `length` iterations of the reference loop and returns the lyric ids
         [B, 1 + length] (column 0 is the initial [#START#]).  top_k = 1, top_p = 0 is the greedy setting;
         anything else samples on the device (generate.py:137-141): one uniform per row and position is drawn
-        from `generator` (a CUDA torch.Generator; default: the global one) before the steps are replayed."""
+        from `generator` (a CUDA torch.Generator; default: the global one) before the steps are replayed.
+        Parity hooks (tests/test_decode_gpu.py): `teacher` [B, 1 + length] long -- after every step the token the step
+        appended is replaced by teacher[:, j] wherever that is >= 0 (teacher forcing on a reference id list; the step's own
+        pick is handed to `tap` first); `tap(j, with_head, picked [B], logits [B, Vpad] or None)` is called after every step."""
         eng, sh = self.eng, self.eng.sh
         B = batch["img_embs"].shape[0]
         if B != self.B:
@@ -385,6 +388,11 @@ class GreedyDecoder:
                 j = pos + 1 - sh.P                                  # lyric index appended after this step
                 forced = j < 1 or (j > 1 and (j + 1) % (sh.msl + 2) in (0, 1))
                 self._run_step(with_head=not forced, parity=pos & 1)
+                if tap is not None:
+                    tap(j, not forced, self.seq[:, pos + 1].clone(), self.logits if not forced and not self.children else None)
+                if teacher is not None and 0 <= j <= length:
+                    col = teacher[:, j].to(eng.dev)
+                    self.seq[:, pos + 1] = torch.where(col >= 0, col, self.seq[:, pos + 1])
         finally:
             self.use_graph = saved_mode
         return self.seq[:, sh.P:sh.P + 1 + length].clone()

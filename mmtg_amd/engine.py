@@ -875,7 +875,9 @@ class Engine:
             tiles = hip.wgrad_group_sizes(((Vp, D),), 1, 0)[0]
             hs = _LMHEAD_GROUP_SPLITS or _group_splits(tiles, M)
             _, nws, ncnt = hip.wgrad_group_sizes(((Vp, D),), hs, 0)
-            hws = self.buf("wgrad_group_ws", (nws,), torch.float32) if hs > 1 else None
+            # (a workspace of its own: under MMTG_WGRAD_STREAM this launch may still be pending on the side stream when the
+            #  block launches size theirs -- a shared name could reallocate, i.e. free, the buffer under it)
+            hws = self.buf("wgrad_group_ws_head", (nws,), torch.float32) if hs > 1 else None
             hcnt = self.ws.get(("wgrad_group_cnt", torch.int32))
             if hcnt is None or hcnt.numel() < ncnt:
                 hcnt = self.ws[("wgrad_group_cnt", torch.int32)] = torch.zeros(ncnt, device=self.dev, dtype=torch.int32)

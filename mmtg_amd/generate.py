@@ -55,6 +55,10 @@ def _cached_decoder(model, start_input, length):
     m = getattr(model, "module", model)
     if not isinstance(m, MMTG) or m.train_flag or not m._flat.is_cuda or os.environ.get("MMTG_SAMPLE_RERUN"):
         return None
+    if m.training:
+        # a model left in train() mode: the prefix re-run loop follows the module mode (dropout, torch.multinomial draws);
+        # the cached decoder never applies dropout and draws from its own uniform stream, so it only serves eval() models
+        return None
     t = np.asarray(start_input["targets"]).reshape(-1)
     sh = m.shapes
     if t.shape[0] != 1 or int(t[0]) != 1 or length < 1 or sh.P + length + 1 > sh.NP:

@@ -1,5 +1,9 @@
 """Fused training step: the hot loop of the reference's src/train.py:177-200 as one
-host-sync-free sequence of HIP kernel launches.
+sequence of HIP kernel launches without host synchronisation (losses, the clip coefficient and the
+global row count stay on the device).  The one exception is the in-trainer curriculum filter of
+stages 1 / 2 on DEVICE ratings, which reads the selection back once per step; hand the ratings
+over on the host as well (``batch["rating_host"]``) or filter in the loader (``DeviceLoader``)
+and the step is sync-free in every stage.
 
     filter rows by curriculum stage  -> forward -> MyLoss (+ alpha * KL) -> backward
     -> bucketed RCCL all-reduce (overlapped) -> clip_grad_norm_(1.0) + AdamW + LR schedule
@@ -100,8 +104,14 @@ class MMTGTrainer:
         exact behaviour would be a host read of the all-reduced count every step."""
         eng = self.eng
         if filter_rows and stage in (1, 2):
-            idx = curriculum_filter(batch["rating"], stage)
-            batch = {k: v[idx.to(v.device)] for k, v in batch.items()}
+            # The selected row COUNT shapes every launch of the step, so the host has to know it: computed from a host copy
+            # of the ratings when the batch carries one ("rating_host", a CPU tensor -- the loader has the ratings on the
+            # host anyway; DeviceLoader goes further and filters before the copy) this costs no device synchronisation;
+            # from device ratings alone it costs ONE device -> host read per step in stages 1 / 2 (torch.where).
+            idx = curriculum_filter(batch["rating_host"] if "rating_host" in batch else batch["rating"], stage)
+            batch = {k: v[idx.to(v.device, non_blocking=True)] for k, v in batch.items() if k != "rating_host"}
+        elif "rating_host" in batch:
+            batch = {k: v for k, v in batch.items() if k != "rating_host"}
         n_local = int(batch["rating"].shape[0]) if "rating" in batch else int(batch["targets"].shape[0])
         red = self.reducer if (self.reducer is not None and self.reducer.active) else None
         if n_local == 0 and (red is None or red.world == 1):

@@ -231,6 +231,34 @@ def test_trainer_edge_cases_empty_stage_and_single_row():
     assert torch.isfinite(model.engine().master).all()
 
 
+def test_trainer_stage_filter_from_host_ratings_is_the_same_step():
+    """train.py:178-186 inside the trainer without a device -> host read: with the ratings also handed over on the host
+    (batch["rating_host"]) the selection is computed there; rows, order and the resulting parameters equal the step that
+    filters on the device ratings."""
+    import numpy as np
+    from mmtg_amd import MMTG, synth
+    from mmtg_amd.configs import data_config, gpt2_config, make_model_cfgs
+    from mmtg_amd.trainer import MMTGTrainer
+    S, V = 5, 300
+    mcfg, dcfg = make_model_cfgs(seq_len=S), data_config(seq_len=S)
+    gcfg = gpt2_config(n_layer=2, vocab_size=V, n_positions=256, embd_pdrop=0.0, attn_pdrop=0.0, resid_pdrop=0.0)
+    masters = []
+    for host in (False, True):
+        model = MMTG(mcfg, dcfg, V, train_flag=True, gpt2_config=gcfg, token_table=synth.make_token_table(V, seed=2), compute_dtype="f32")
+        model.reset_parameters(seed=1)
+        model.to("cuda")
+        tr = MMTGTrainer(model, lr=1e-4, alpha=0.2)
+        b = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in synth.make_batch(6, mcfg, dcfg, V, seed=9).items()}
+        b["rating"] = torch.tensor([5, 3, 1, 3, 2, 4], device="cuda")
+        if host:
+            b["rating_host"] = b["rating"].cpu()
+        for stage in (1, 2):
+            out = tr.step(b, stage=stage)
+            assert out is not None and model.engine().act["B"] == (2 if stage == 1 else 4)
+        masters.append(model.engine().master.clone())
+    assert torch.equal(masters[0], masters[1])
+
+
 def test_full_size_batched_decode_rules():
     """BASELINE configs[3] shape: full 12-layer model, batch 256, 128 positions, bf16 fast path with the hipGraph --
     greedy and top-k/top-p sampling both obey the generation rules on every row (forced cadence, banned ids, sticky
@@ -325,17 +353,110 @@ def test_fused_decode_step_matches_the_unfused_one(monkeypatch):
         monkeypatch.setenv("MMTG_DECODE_FUSED", fused)
         dec = GreedyDecoder(model, max_batch=3, use_graph=False)
         assert getattr(dec, "fused", False) == (fused == "1")
-        ids = dec.generate(tb, 40, temperature=1.1, repitition_penalty=1.5)
+        first = []
+
+        def tap(j, with_head, picked, logits, first=first, V=dec.eng.sh.V):
+            if with_head and not first:
+                first.append(logits[:, :V].float().cpu().clone())
+
+        ids = dec.generate(tb, 40, temperature=1.1, repitition_penalty=1.5, tap=tap)
         ids2 = dec.generate(tb, 40, temperature=1.1, repitition_penalty=1.5)
         assert torch.equal(ids, ids2)
-        # logits of the LAST model call (the decoder's buffer still holds them)
-        outs[fused] = (ids.cpu().numpy(), dec.logits[:, :dec.eng.sh.V].float().cpu().clone())
+        # logits of the first and of the LAST model call (the decoder's buffer still holds the latter)
+        outs[fused] = (ids.cpu().numpy(), dec.logits[:, :dec.eng.sh.V].float().cpu().clone(), first[0])
     ids_f, ids_u = outs["1"][0], outs["0"][0]
     for ids in (ids_f, ids_u):
         free = [j for j in range(1, 41) if (j + 1) % 22 not in (0, 1)]
         assert not np.isin(ids[:, free], [1, 2, 100, 102]).any()
-    # first generated token: same prefix for both decoders -> their logits are comparable
+    # the FIRST model call always shares its prefix (prompt + [#START#]): its logits are compared unconditionally, for every row
+    lf, lu = outs["1"][2], outs["0"][2]
+    assert lf.shape == lu.shape and lf.shape[0] == 3
+    assert float((lf - lu).abs().max()) < 0.12 * max(1.0, float(lu.abs().max()) / 8.0)
+    # and the last call's wherever the two decoders still agree on the whole prefix
     same_prefix = (ids_f == ids_u).all(axis=1)
     if same_prefix.any():
         lf, lu = outs["1"][1][same_prefix], outs["0"][1][same_prefix]
         assert float((lf - lu).abs().max()) < 0.12 * max(1.0, float(lu.abs().max()) / 8.0)
+
+
+def _report(name, **kv):
+    import os
+    path = os.environ.get("MMTG_TEST_REPORT")
+    if path:
+        with open(path, "a") as f:
+            f.write(json.dumps(dict(test=name, **{k: (float(v) if isinstance(v, (np.floating, float)) else v) for k, v in kv.items()})) + "\n")
+
+
+@pytest.mark.parametrize("case,bound", [("tiny_s5", 0.12), ("full_12l", 0.15)])
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_bf16_fused_decoder_teacher_forced_on_the_reference_ids(case, bound, use_graph):
+    """The BENCHMARKED decode path -- the bf16 fused, KV-cached, graph-replayed GreedyDecoder -- against the reference's own
+    sample_sequence run (generate.py:117-142): row 0 is teacher-forced on the reference's 220-position greedy id list, and at
+    every model call (a) the decoder's raw fp32 logits are compared with the logits the reference's model produced at that call
+    (tiny_s5: all V of them; full_12l: the reference's top-8 ids) under the bf16-mode bound, (b) the token the device-side
+    processing + arg-max picked equals the reference's wherever the reference's top-2 margin of the PROCESSED logits exceeds
+    twice that bound over the temperature.  The decoder-side twin of test_greedy_ids_vs_golden_at_reduced_precision, which goes
+    through model.forward and never touches the decode kernels."""
+    fx, meta, mcfg, gcfg, dcfg, weights, table, batch = load_case(case)
+    model = MMTG(mcfg, dcfg, meta["V"], train_flag=False, gpt2_config=gcfg, token_table=table, compute_dtype="bf16")
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})
+    model.to(DEV).eval()
+    tb = {k: v for k, v in batch_to_torch(batch, DEV).items() if k not in ("rating", "targets")}
+    B = tb["img_embs"].shape[0]
+    key = "greedy_len220_row0"
+    ids = fx[key].tolist()                       # [1, t1, ...]: what sample_sequence returned (lags the last append)
+    length = len(ids) - 1
+    dec = GreedyDecoder(model, max_batch=B, use_graph=use_graph)
+    assert dec.fused, "the bf16 decoder must take the fused token step (the benchmarked path)"
+    teacher = torch.full((B, 1 + length), -1, dtype=torch.long)
+    teacher[0, :len(ids)] = torch.tensor(ids)
+    V = meta["V"]
+    raw = fx[key + "_rawlogits"] if key + "_rawlogits" in fx.files else None
+    calls = [i for i in range(220) if not (i > 0 and (i + 2) % 22 in (0, 1))]
+    if raw is not None:
+        from oracle import mmtg_oracle as O
+    rec = []
+
+    def tap(j, with_head, picked, logits):
+        if with_head:
+            rec.append((j, int(picked[0]), logits[0, :V].float().cpu().clone()))
+
+    dec.generate(tb, length, temperature=1.1, repitition_penalty=1.5, teacher=teacher, tap=tap)
+    n = ok = 0
+    err_max, worst_missed, first_div = 0.0, 0.0, None
+    for c, (j, picked, lg) in enumerate(rec):
+        i = j - 1                                  # call index i consumed ids[i] and appends ids[i + 1]
+        assert calls[c] == i
+        if raw is not None:
+            ref = torch.from_numpy(raw[c])
+            scale = max(1.0, float(ref.abs().max()) / 8.0)
+            e = float((lg - ref).abs().max())
+            assert e < bound * scale, (c, e)
+            pl = O.process_logits(ref, torch.tensor(ids[:i + 1]), 1.1, 1.5)
+            top = torch.topk(pl, 2).values
+            chosen, margin = int(torch.argmax(pl)), float(top[0] - top[1])
+        else:
+            t8 = fx[key + "_top8"][c].astype(np.int64)
+            e = float(np.abs(lg.numpy()[t8] - fx[key + "_top8_val"][c]).max())
+            assert e < bound, (c, e)
+            chosen, margin = int(fx[key + "_chosen"][c]), float(fx[key + "_margin"][c])
+        err_max = max(err_max, e)
+        if ids[i] == 0:
+            assert picked == 0                     # sticky PAD (generate.py:137-138): no arg-max taken
+            continue
+        if i + 1 < len(ids):
+            assert chosen == ids[i + 1]            # the fixture is self-consistent
+        n += 1
+        if picked == chosen:
+            ok += 1
+        else:
+            worst_missed = max(worst_missed, margin)
+            if first_div is None:
+                first_div = (c, margin)
+    _report("decoder_teacher_forced_%s_bf16_fused_%s" % (case, "graph" if use_graph else "eager"), calls=n, agree=ok,
+            logit_err_max=err_max, worst_missed_margin=worst_missed,
+            first_divergence_call=None if first_div is None else first_div[0],
+            first_divergence_margin=None if first_div is None else first_div[1])
+    assert n >= 120
+    assert worst_missed <= 2 * bound / 1.1, (worst_missed, first_div)
+    assert ok >= 0.6 * n

@@ -593,7 +593,7 @@ def test_full_12l_gradients_vs_golden(dtype):
     assert abs(gn - ref_gn) < (2e-3 if f32 else 2e-2) * ref_gn, (gn, ref_gn)
     sd = dict(model.named_parameters())
     fam = {}
-    worst, worst_norm = 0.0, 0.0
+    worst, worst_norm, worst_norm_key, worst_key = 0.0, 0.0, None, None
     for k in (str(k) for k in fx["grad_keys"]):
         if k == "decoder.gpt2.lm_head.weight":
             continue
@@ -603,12 +603,14 @@ def test_full_12l_gradients_vs_golden(dtype):
         gnorm_ref = float(fx["gnorm_" + k])          # norm of the tensor as AdamW sees it (after clip_grad_norm_)
         gnorm = float(g.float().norm().item())
         if gnorm_ref > 1e-5:
-            worst_norm = max(worst_norm, abs(gnorm - gnorm_ref) / gnorm_ref)
+            if abs(gnorm - gnorm_ref) / gnorm_ref > worst_norm:
+                worst_norm, worst_norm_key = abs(gnorm - gnorm_ref) / gnorm_ref, k
             assert abs(gnorm - gnorm_ref) < (2e-3 if f32 else 0.12) * gnorm_ref, (k, gnorm, gnorm_ref)
         if f32:
             scale = max(float(np.abs(ref).max()), gnorm_ref / np.sqrt(g.numel()), 1e-7)
             e = float(np.abs(got - ref).max()) / scale
-            worst = max(worst, e)
+            if e > worst:
+                worst, worst_key = e, k
             assert e < 5e-3, (k, e, scale)
         family = k.split(".")[-2] + "." + k.split(".")[-1] if ".h." in k else k
         a, b = fam.setdefault(family, ([], []))
@@ -623,7 +625,8 @@ def test_full_12l_gradients_vs_golden(dtype):
         cos_min = min(cos_min, cos)
         assert cos > (0.99999 if f32 else 0.98), (family, cos)
     _report("full_12l_gradients_" + dtype, grad_norm=gn, grad_norm_ref=ref_gn, worst_sample_err_of_scale=worst,
-            worst_tensor_norm_rel=worst_norm, min_family_cosine=cos_min)
+            worst_tensor_norm_rel=worst_norm, worst_tensor_norm_key=worst_norm_key, worst_sample_err_key=worst_key,
+            min_family_cosine=cos_min)
 
 
 def test_full_12l_fused_step_f32_vs_golden():

@@ -1042,6 +1042,28 @@ def test_wgrad_group_in_kernel_reduction(K, splits, config):
 
 
 @pytest.mark.parametrize("config", [0, 1])
+@pytest.mark.parametrize("K,splits", [(1000, 3), (200, 1), (4744, 2)])
+def test_wgrad_group_ragged_k_never_reads_past_the_operands(K, splits, config):
+    """A ragged last K slice with NaN-filled memory DIRECTLY behind both operands (same allocation, so the addresses are
+    mapped): rows at or past K must be requested out of range per lane -- a kernel that relied on the buffer descriptor's
+    range check for the K-tile offset it carries in the scalar offset would add NaNs to the gradient."""
+    M, N = 384, 256
+    bufA = torch.full((K + 256, M), float("nan"), dtype=torch.bfloat16, device=DEV)
+    bufB = torch.full((K + 256, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    bufA[:K] = rnd(K, M, dtype=torch.bfloat16, seed=3).to(DEV)
+    bufB[:K] = rnd(K, N, dtype=torch.bfloat16, seed=4).to(DEV)
+    A, B = bufA[:K], bufB[:K]
+    tiles, nws, ncnt = hip.wgrad_group_sizes([(M, N)], splits, config)
+    ws = torch.zeros(nws, device=DEV)
+    cnt = torch.zeros(ncnt, dtype=torch.int32, device=DEV)
+    C_ = torch.zeros(M, N, device=DEV)
+    hip.wgrad_group([(A, B, C_, M, N, M, N, N)], K, splits, ws, cnt, accumulate=False, config=config)
+    ref = A.float().t() @ B.float()
+    assert torch.isfinite(C_).all()
+    assert (C_ - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("config", [0, 1])
 def test_wgrad_group_repeated_launches_stay_bit_equal(config):
     """Race screen at the training shapes: the four weight gradients of a GPT-2-base block (432 / 108 tiles x 2 K halves, every
     wave tile reduced by whichever wave arrives last) launched 40 times back to back -- every result bit-equal to the first."""

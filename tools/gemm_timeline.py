@@ -38,8 +38,10 @@ C = torch.zeros(M, N, device=dev, dtype=torch.float32 if atomic else dt)
 kw = {}
 if epi == hip.EPI_GELU:
     kw["aux2"] = torch.empty(M, N, device=dev, dtype=dt)
-if epi in (hip.EPI_RESID, hip.EPI_DGELU):
+if epi in (hip.EPI_RESID, hip.EPI_DGELU, hip.EPI_ROWDOT):
     kw["aux"] = t(M, N)
+if epi == hip.EPI_ROWDOT:
+    kw["aux2"] = torch.empty(M, N // 64, device=dev, dtype=torch.float32)
 bias = None if epi in (hip.EPI_ATOMIC, hip.EPI_DGELU) else torch.zeros(N, device=dev)
 
 
@@ -52,6 +54,9 @@ for _ in range(3):
 torch.cuda.synchronize()
 nwg = 1 << 16
 buf = torch.zeros(nwg, 6, device=dev, dtype=torch.int64)
+if os.environ.get("COLD"):   # operands behind a 1 GiB fill: HBM-cold, as inside the training step
+    torch.empty(1 << 28, device=dev, dtype=torch.float32).fill_(1.0)
+    torch.cuda.synchronize()
 hip.gemm_trace(buf)
 run()
 torch.cuda.synchronize()
