@@ -249,6 +249,14 @@ def decode_roofline(args, model, batch, B, Ln, dec, step_us_events):
         except Exception:
             continue
         if m.get("kernel_source_sha") == hip.source_sha() and B == 256 and args.dtype == "bf16":
+            if m.get("step") == "fused" and getattr(dec, "fused", False):
+                # counter pass of the fused step, taken at the generation length the file names (the KV-cache share scales with it)
+                traffic = m["hbm_bytes_per_token_step"]
+                tsrc = os.path.relpath(f, ROOT) + (" [FUSED step at --decode-len %d: %d bytes per token step against %d algorithmic at that length]"
+                                                   % (m["decode_len"], m["hbm_bytes_per_token_step"], m["algorithmic_bytes_per_token_step_at_this_length"]))
+                break
+            if m.get("step") == "fused":
+                continue
             if m.get("step") == "unfused" and getattr(dec, "fused", False):
                 # the counter passes only run on the round-2 step (tools/gpu_pmc_decode.sh): not this step's traffic
                 traffic, tsrc = None, os.path.relpath(f, ROOT) + " holds the UNFUSED step's %d bytes per token step; the fused step's counter pass crashes in the profiler" % m["hbm_bytes_per_token_step"]
@@ -384,6 +392,54 @@ def f32_object(args, dev, mcfg, dcfg, gcfg, V, steps=5, warmup=2):
     return out
 
 
+def medium_object(args, dev, steps=5, warmup=3):
+    """BASELINE configs[4]'s single-GPU body under the driver's clock: GPT-2-medium 24L/1024/16H, S = 8, T = 512, 32 rows, rating
+    skew K = 32 with the stage-2 filter inside the step (ratings handed over on the host as well: no device read-back).  A bounded
+    run (3 warm-up + 5 timed steps, then 5 instrumented ones for the GEMM family's rate), outside the bf16 line's timed region."""
+    from mmtg_amd import MMTG, hip, synth
+    from mmtg_amd.configs import data_config, gpt2_config, make_model_cfgs
+    from mmtg_amd.trainer import MMTGTrainer
+    V, S, msl, skew, B = 13317, 8, 29, 32.0, 32
+    mcfg = make_model_cfgs(seq_len=S)
+    dcfg = data_config(seq_len=S, max_sent_length=msl)
+    gcfg = gpt2_config(n_layer=24, n_embd=1024, n_head=16, n_positions=512, n_ctx=512, vocab_size=V)
+    model = MMTG(mcfg, dcfg, V, train_flag=True, gpt2_config=gcfg, compute_dtype="bf16", token_table=synth.make_token_table(V, seed=2))
+    model.reset_parameters(seed=0)
+    model.to(dev).train()
+    trainer = MMTGTrainer(model, lr=1e-5, alpha=0.2, warmup_steps=10, total_steps=100000)
+    batches = []
+    for i in range(2):
+        nb = synth.make_batch(B, mcfg, dcfg, V, seed=i, low_to_high=skew)
+        nb["rating"] = np.where(np.asarray(nb["rating"]) == 3, 2, nb["rating"])
+        b = {k: torch.from_numpy(np.asarray(v)).to(dev) for k, v in nb.items()}
+        b["rating_host"] = torch.from_numpy(np.asarray(nb["rating"]))
+        batches.append(b)
+    T = dcfg.topic_prompt_length + batches[0]["targets"].shape[1]
+
+    def run(n):
+        for i in range(n):
+            trainer.step(batches[i % 2], stage=2)
+
+    run(warmup)
+    el = _timed(lambda: run(steps), 1, dev)
+    hip.prof_enable(True)
+    _timed(lambda: run(steps), 1, dev)
+    hip.prof_enable(False)
+    prof = hip.prof_read()
+    g = prof["gemm_bf16"]
+    ach = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
+    out = {"metric": "train tokens/sec, scaled stress config (GPT-2-medium decoder, 8 experience steps), one GPU of the 8",
+           "value": round(B * T * steps / el, 1), "unit": "tokens/s", "ms_per_step": round(1e3 * el / steps, 3), "steps": steps,
+           "warmup": warmup, "rows": B, "seq_len": T, "dtype": "bf16",
+           "roofline": {"bound": "mfma", "kernel": "bf16 GEMM family", "achieved": round(ach, 2), "peak": 2500.0, "unit": "TFLOP/s",
+                        "frac": round(ach / 2500.0, 4),
+                        "per_category_ms_per_step": {k: round(v["ms"] / steps, 3) for k, v in prof.items() if v["launches"]}},
+           "params_finite": bool(torch.isfinite(model._flat).all().item())}
+    del trainer, model
+    torch.cuda.empty_cache()
+    return out
+
+
 _JSON_FD = None
 
 
@@ -497,6 +553,7 @@ def main():
     ap.add_argument("--dry-launch", action="store_true",
                     help="launch contract only (no GPU): ranks rendezvous over gloo, rank 0 prints one JSON line")
     ap.add_argument("--no-f32", action="store_true", help="skip the f32 (parity-gate mode) object of the default line")
+    ap.add_argument("--no-medium", action="store_true", help="skip the configs[4] (GPT-2-medium, T = 512) object of the default line")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -563,6 +620,8 @@ def main():
         if skew is not None:        # the stage-2 filter is part of the step; keep every row in (ratings 1-2 / 4-5)
             nb["rating"] = np.where(np.asarray(nb["rating"]) == 3, 2, nb["rating"])
         batches.append({k: torch.from_numpy(np.asarray(v)).to(dev) for k, v in nb.items()})
+        if skew is not None:        # ratings on the host too: the in-step filter then needs no device read-back
+            batches[-1]["rating_host"] = torch.from_numpy(np.asarray(nb["rating"]))
     T = dcfg.topic_prompt_length + batches[0]["targets"].shape[1]
 
     # did-work evidence, outside the timed region: MyLoss of a held-out probe batch (eval mode, no dropout) before the
@@ -637,12 +696,22 @@ def main():
         conditioning = conditioning_probe(model, batches[0])
     ddp_info = None
     if ddp:
+        # exposed exchange time: a few more steps with HIP events around the reducer's finish() (outside the timed region)
+        trainer.measure_finish = True
+        run(max(3, min(args.steps, 10)))
+        finish_wait = trainer.finish_wait_ms()
+        trainer.measure_finish = False
+        from mmtg_amd.ddp import cu_budget_setting
         ddp_info = {"rccl_world": dist.get_world_size(), "backend": dist.get_backend(),
+                    "cu_budget": cu_budget_setting() if world > 1 else 0,
+                    "finish_wait_ms_per_step": None if finish_wait is None else round(finish_wait, 3),
                     "buckets": len(trainer.reducer.buckets), "bucket_mb": args.bucket_mb,
                     "gradient_bytes": int(trainer.eng.layout.total * 4),
                     "allreduce_ms_per_step_isolated": round(allreduce_probe(trainer, max(3, min(args.steps, 10)), world, dev), 3),
                     "note": "allreduce_ms_per_step_isolated = the step's bucketed SUM all-reduces (+ the row count) alone, nothing to "
-                            "overlap with; inside the step they run on RCCL's stream beside the backward"}
+                            "overlap with; inside the step they run on RCCL's stream beside the backward; finish_wait_ms_per_step = how "
+                            "long the compute stream waited for them after the backward (HIP events around GradReducer.finish, this rank): "
+                            "the exposed part of the exchange; cu_budget = CUs the GEMM tile rule leaves to (< 0) the RCCL kernels"}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == "base":
@@ -660,6 +729,12 @@ def main():
         trainer = model = None
         torch.cuda.empty_cache()
         f32 = f32_object(args, dev, mcfg, dcfg, gcfg, V)
+    medium = None
+    if (rank == 0 and world == 1 and not ddp and not args.no_medium and not args.no_decode and args.config == "base" and args.layers == 12
+            and args.dtype == "bf16"):
+        trainer = model = None
+        torch.cuda.empty_cache()
+        medium = medium_object(args, dev)
 
     if rank == 0:
         if args.config == "medium":
@@ -689,6 +764,8 @@ def main():
             out["decode"] = decode
         if f32 is not None:
             out["f32"] = f32
+        if medium is not None:
+            out["medium"] = medium
         _emit(out)
     if dist.is_initialized():
         dist.destroy_process_group()

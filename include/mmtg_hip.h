@@ -76,6 +76,7 @@ enum {
                                     MMTG_EPI_DGELU multiplies by aux as it is (C = acc * aux): the backward then needs no transcendental --
                                     the only consumer of the saved pre-activation was gelu' (both products of a pair must carry the flag) */
 #define MMTG_GEMM_P8 16384       /* flags: eight-phase kernel also for the dGELU product (otherwise on the single-stage kernel by measurement) */
+#define MMTG_GEMM_P8_288 65536   /* flags (round 4): force the eight-phase kernel's 288-row tiles where it applies (the tile rule picks them by cost; tests / A-B) */
 #define MMTG_GEMM_P256 4096      /* flags: persistent pipelined kernel with 256x128 tiles, 8 waves, one workgroup per CU (bf16, transA = 0) */
 #define MMTG_GEMM_COL_BLOCK 2048 /* flags: force the column-blocked item order with blocks of two tile columns (test hook;
                                     automatic when the weights do not stay in an XCD's L2 over several sweeps) */
@@ -134,6 +135,10 @@ MMTG_API int mmtg_gemm_trace(void* buf, int max_wgs);
  * < 0 = all but that many.  A rule input only -- results never depend on it.  mmtg_amd.ddp reserves CUs for the RCCL kernels
  * that run beside the backward (replaces nothing in the reference: its nn.DataParallel, train.py:112-114, serialises). */
 MMTG_API int mmtg_gemm_cu_budget(int cus);
+/* Measurement hook (tools/ddp_contention.py; never on the product path): `workgroups` 256-thread workgroups that each hold
+ * `lds_bytes` of LDS (163840 = a whole CU) and sleep for `usec` microseconds -- a stand-in for a collective's ring kernels holding
+ * their CUs beside the backward, so that the CU reservation above can be priced on one GPU. */
+MMTG_API int mmtg_debug_occupy(int workgroups, int lds_bytes, double usec, void* stream);
 
 /* Second half of a MMTG_EPI_SPLIT product: out[m, :] = epi(sum_s part[s][m][:] + bias) in the storage type
  * (slabs summed in index order -> deterministic); epi in {NONE, GELU, TANH, RESID (+ aux)}.  With ln_out the

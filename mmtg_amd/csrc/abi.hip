@@ -85,3 +85,30 @@ extern "C" int mmtg_prof_read(int* launches, double* ms, double* flops, double* 
     g_recs.clear();
     return MMTG_OK;
 }
+
+// ---------------------------------------------------------------- measurement hook: hold CUs
+// `workgroups` 256-thread workgroups that each declare `lds_bytes` of LDS (163840 = a whole CU: nothing else fits beside it) and
+// sleep until `usec` microseconds have passed on the 100 MHz wall counter -- the shape of a collective's ring kernels, which hold
+// their CUs for the whole exchange.  tools/ddp_contention.py runs the training step beside it to price the CU reservation of
+// mmtg_amd.ddp on ONE GPU.  Never launched by the product path.
+namespace {
+__global__ __launch_bounds__(256) void occupy_kernel(unsigned long long ticks, int touch) {
+    extern __shared__ char occ_lds[];
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+    if (touch) occ_lds[threadIdx.x] = 0;          // keeps the LDS allocation live
+}
+}  // namespace
+
+extern "C" int mmtg_debug_occupy(int workgroups, int lds_bytes, double usec, void* stream) {
+    MMTG_REQUIRE(workgroups >= 1 && workgroups <= 4096 && lds_bytes >= 0 && lds_bytes <= 163840 && usec >= 0 && usec <= 5e6,
+                 "debug_occupy: 1..4096 workgroups, <= 163840 B of LDS, <= 5 s");
+    static int attr_bytes = -1;
+    if (lds_bytes > attr_bytes) {
+        if (hipFuncSetAttribute((const void*)occupy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
+            MMTG_FAIL(MMTG_ERR_HIP, "debug_occupy: cannot raise the LDS limit to %d", lds_bytes);
+        attr_bytes = lds_bytes;
+    }
+    hipLaunchKernelGGL(occupy_kernel, dim3(workgroups), dim3(256), lds_bytes, (hipStream_t)stream, (unsigned long long)(usec * 100.0), 0);
+    return mmtg_check_launch("debug_occupy");
+}

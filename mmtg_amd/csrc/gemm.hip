@@ -737,8 +737,8 @@ __device__ __forceinline__ void p8_issue1(__amdgpu_buffer_rsrc_t r, char* d0, in
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, LDS_PTR(void, d0), 16, v0, soff, 0, 0);
 }
 
-template <int AH, int BH, int NA, int TMW>
-__device__ __forceinline__ void p8_mfma(const bf16x8 (&fa)[4][2], const bf16x8 (&fb)[2][2], f32x4 (&acc)[TMW][4]) {
+template <int AH, int BH, int NA, int TMW, int FAN>
+__device__ __forceinline__ void p8_mfma(const bf16x8 (&fa)[FAN][2], const bf16x8 (&fb)[2][2], f32x4 (&acc)[TMW][4]) {
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
@@ -775,7 +775,7 @@ __device__ __forceinline__ int p8_ks_voff(long ld, int col0, int ncols, int h, i
 template <int TBM, bool KS = false>
 __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(GemmArgs p) {
     typedef bf16 T;
-    static_assert(TBM == 256 || (TBM == 192 && !KS), "row tiles of 256 or (K-contiguous operands) 192");
+    static_assert(TBM == 256 || ((TBM == 192 || TBM == 288) && !KS), "row tiles of 256 or (K-contiguous operands) 192 / 288");
     constexpr int WTM = TBM / 2, TMW = WTM / 16, NA1 = TMW - 4;       // wave rows, 16-row tiles per wave, tiles in a1
     constexpr int NBG = TBM / 16;                                     // DMA blocks (8 rows) per wave-row group
     constexpr int TA = TBM * 128, STAGE = TA + 256 * 128;             // bytes: A tile | B tile, 128-byte rows (64 k)
@@ -785,7 +785,7 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(GemmArgs p) {
     const int g = lane >> 4, l15 = lane & 15;
     const int wr = wave >> 2, wc = wave & 3;
     const bool tr = p.trace != nullptr;                     // diagnostic timeline (mmtg_gemm_trace)
-    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, tc1 = 0, tc2 = 0;      // wall stamps (100 MHz) + shader-clock stamps around the K loop
     if (tr) ts0 = __builtin_amdgcn_s_memrealtime();
     int m0, n0, split;
     tile_origin(p, blockIdx.x, gridDim.x, m0, n0, split, TBM, 256);
@@ -802,15 +802,22 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(GemmArgs p) {
     // block 8 + w % 4).  Half tile b0 = columns 64 wc' + [0, 32) -> blocks 8 (i >> 2) + (i & 3), i = w, w + 8; b1 = those + 4.
     // K-strided operands: half tile h is the 16 KB image at h * 16 KB, a block is 4 k-rows x 256 B -> blocks w and w + 8.
     int lA00, lA01, lA10, lA11, lB00, lB01, lB10, lB11, vA00, vA01, vA10, vA11, vB00, vB01, vB10, vB11;
+    int lA12 = 0, vA12 = OOB;
     if constexpr (!KS) {
         const int bA0 = wave, bA1 = bA0 + NBG;
-        const int bA2 = TBM == 256 ? 8 + wave : (wave >> 2) * NBG + 8 + (wave & 3), bA3 = NBG + 8 + wave;      // bA3: 256 rows only
+        const int bA2 = TBM != 192 ? 8 + wave : (wave >> 2) * NBG + 8 + (wave & 3), bA3 = NBG + 8 + wave;      // bA3: 256 / 288 rows only
+        // 288 rows (round 4): a1 = 80 rows of each wave-row group = 10 blocks per group; the last two of each group go to waves 0-3
+        // as a THIRD request (the count of A1 requests enters no counted wait: only B0 / A0 / B1 of the tile after next are in
+        // flight behind vmcnt(6), and the prologue's wait covers A1(0) however many requests it was)
+        const int bA4 = wave < 2 ? 16 + wave : NBG + 16 + ((wave - 2) & 1);
+        lA12 = bA4 * 1024;
+        vA12 = (TBM == 288 && wave < 4) ? dma_voff<false, TBM>(p.lda, m0, p.M, 64, bA4, lane) : OOB;
         const int bB = 8 * (wave >> 2) + (wave & 3);
         lA00 = bA0 * 1024; lA01 = bA1 * 1024; lA10 = bA2 * 1024; lA11 = bA3 * 1024;
         lB00 = TA + bB * 1024; lB01 = TA + (bB + 16) * 1024; lB10 = TA + (bB + 4) * 1024; lB11 = TA + (bB + 20) * 1024;
         vA00 = dma_voff<false, TBM>(p.lda, m0, p.M, 64, bA0, lane); vA01 = dma_voff<false, TBM>(p.lda, m0, p.M, 64, bA1, lane);
         vA10 = dma_voff<false, TBM>(p.lda, m0, p.M, 64, bA2, lane);
-        vA11 = TBM == 256 ? dma_voff<false, TBM>(p.lda, m0, p.M, 64, bA3, lane) : OOB;
+        vA11 = TBM != 192 ? dma_voff<false, TBM>(p.lda, m0, p.M, 64, bA3, lane) : OOB;
         vB00 = dma_voff<false, 256>(p.ldb, n0, p.N, 64, bB, lane); vB01 = dma_voff<false, 256>(p.ldb, n0, p.N, 64, bB + 16, lane);
         vB10 = dma_voff<false, 256>(p.ldb, n0, p.N, 64, bB + 4, lane); vB11 = dma_voff<false, 256>(p.ldb, n0, p.N, 64, bB + 20, lane);
     } else {
@@ -825,10 +832,13 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(GemmArgs p) {
 #define P8_A0(t) p8_issue(ra, smem + ((t) & 1) * STAGE + lA00, smem + ((t) & 1) * STAGE + lA01, (t) < nk ? vA00 : OOB, (t) < nk ? vA01 : OOB, sa0 + (t) * stepa)
 #define P8_A1(t)                                                                                                                       \
     do {                                                                                                                               \
-        if constexpr (TBM == 256)                                                                                                      \
+        if constexpr (TBM != 192)                                                                                                      \
             p8_issue(ra, smem + ((t) & 1) * STAGE + lA10, smem + ((t) & 1) * STAGE + lA11, (t) < nk ? vA10 : OOB, (t) < nk ? vA11 : OOB, sa0 + (t) * stepa); \
         else                                                                                                                           \
             p8_issue1(ra, smem + ((t) & 1) * STAGE + lA10, (t) < nk ? vA10 : OOB, sa0 + (t) * stepa);                                  \
+        if constexpr (TBM == 288) {                                                                                                    \
+            if (wave < 4 && (t) < nk) p8_issue1(ra, smem + ((t) & 1) * STAGE + lA12, vA12, sa0 + (t) * stepa);                         \
+        }                                                                                                                              \
     } while (0)
 #define P8_B0(t) p8_issue(rb, smem + ((t) & 1) * STAGE + lB00, smem + ((t) & 1) * STAGE + lB01, (t) < nk ? vB00 : OOB, (t) < nk ? vB01 : OOB, sb0 + (t) * stepb)
 #define P8_B1(t) p8_issue(rb, smem + ((t) & 1) * STAGE + lB10, smem + ((t) & 1) * STAGE + lB11, (t) < nk ? vB10 : OOB, (t) < nk ? vB11 : OOB, sb0 + (t) * stepb)
@@ -861,10 +871,10 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(GemmArgs p) {
     P8_B0(1); P8_A0(1); P8_B1(1);
     wait_vmcnt<6>();                       // K tile 0 has landed (mine; the barrier makes it everyone's)
     asm volatile("s_barrier" ::: "memory");
-    if (tr) ts1 = __builtin_amdgcn_s_memrealtime();
+    if (tr) { ts1 = __builtin_amdgcn_s_memrealtime(); tc1 = __builtin_amdgcn_s_memtime(); }
     if (wr == 1) asm volatile("s_barrier" ::: "memory");          // the second wave group runs one barrier behind the first
 
-    bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
+    bf16x8 fa[NA1 > 4 ? NA1 : 4][2], fb0[2][2], fb1[2][2];
 #define P8_RD_A(ST, AH, NA)                                                                                \
     _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int i = 0; i < (NA); ++i) {     \
         if constexpr (!KS) fa[i][kk] = p8_ld(smem + (ST) * STAGE + oa[kk] + ((AH) * 64 + i * 16) * 128);    \
@@ -908,18 +918,20 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(GemmArgs p) {
 #undef P8_B0
 #undef P8_B1
     wait_vmcnt<0>();                                     // the zero-fill tail loads
-    if (tr) ts2 = __builtin_amdgcn_s_memrealtime();
+    if (tr) { ts2 = __builtin_amdgcn_s_memrealtime(); tc2 = __builtin_amdgcn_s_memtime(); }
     if (wr == 0) asm volatile("s_barrier" ::: "memory");           // re-join the two groups
     asm volatile("s_barrier" ::: "memory");                        // every wave is done with the stages: they become epilogue scratch
     if constexpr (KS) p.C = reinterpret_cast<char*>(p.C) + (long)split * p.split_stride;     // MMTG_EPI_SPLIT slab
     // (aux vectors two bands ahead; the 256-row configuration -- 128-row wave tiles -- also carries the dGELU column sums)
-    gemm_epilogue<T, false, TMW, 4, (TBM == 256 ? 2 : -2)>(p, acc, m0 + wr * WTM, n0 + wc * 64, g, l15, smem + wave * epi_scratch_bytes<TMW, 4>(), lane);
+    gemm_epilogue<T, false, TMW, 4, (TBM == 256 ? 2 : TBM == 288 ? -1 : -2)>(p, acc, m0 + wr * WTM, n0 + wc * 64, g, l15, smem + wave * epi_scratch_bytes<TMW, 4>(), lane);
     if (tr && wave == 0 && (int)blockIdx.x < p.trace_n) {
         wait_vmcnt<0>();                       // the output stores are part of the epilogue's time
         const unsigned long long ts3 = __builtin_amdgcn_s_memrealtime();
         if (lane == 0) {
             unsigned long long* r = p.trace + 6 * (size_t)blockIdx.x;
-            r[0] = ts0; r[1] = ts1; r[2] = ts2; r[3] = ts3; r[4] = (unsigned long long)nk;
+            // r[4]: K tiles in the low 20 bits, shader cycles of the K loop above them (in-loop clock = cycles / wall: the chip
+            // lowers its clock under MFMA load, MI355X_MICROARCH.md "DVFS give-back" item 6)
+            r[0] = ts0; r[1] = ts1; r[2] = ts2; r[3] = ts3; r[4] = (unsigned long long)nk | ((tc2 - tc1) << 20);
             r[5] = ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 4);
         }
     }
@@ -1081,7 +1093,7 @@ int launch_p8(const GemmArgs& a, int splits, hipStream_t stream) {
     static bool attr_done = false;
     const size_t shm = 2 * (TBM + 256) * 128;
     if (!attr_done) {
-        int rc = set_lds(gemm_p8_kernel<TBM, KS>, shm, 512, KS ? "eight-phase 256x256 K-strided" : TBM == 256 ? "eight-phase 256x256" : "eight-phase 192x256");
+        int rc = set_lds(gemm_p8_kernel<TBM, KS>, shm, 512, KS ? "eight-phase 256x256 K-strided" : TBM == 256 ? "eight-phase 256x256" : TBM == 288 ? "eight-phase 288x256" : "eight-phase 192x256");
         if (rc) return rc;
         attr_done = true;
     }
@@ -1391,10 +1403,19 @@ extern "C" int mmtg_gemm(int dtype, int transA, int transB, int M, int N, int K,
         } else if (p8 && nt_big && K % 128 == 0 && (epi != MMTG_EPI_DGELU || p8 >= 2 || (flags & MMTG_GEMM_P8))) {
             // (dGELU keeps the single-stage kernel: with the saved pre-activation read in its exposed epilogue the eight-phase
             //  kernel measured 115.7 vs 112.5 us inside the training step; MMTG_GEMM_P8=2 or the MMTG_GEMM_P8 flag routes it here too -- bit-equal)
-            const long t256 = (long)cdiv(M, 256) * cdiv(N, 256), t192 = (long)cdiv(M, 192) * cdiv(N, 256);
+            const long t256 = (long)cdiv(M, 256) * cdiv(N, 256), t192 = (long)cdiv(M, 192) * cdiv(N, 256), t288 = (long)cdiv(M, 288) * cdiv(N, 256);
             const long ncu = p8_cus();
-            const double c256 = (double)cdiv(t256, ncu), c192 = 0.75 * (double)cdiv(t192, ncu);
-            int rows = c192 < 0.95 * c256 ? 192 : 256;
+            // Row tile from a measured cost model (in-kernel timelines, profiles/r04_*): a round of tiles costs a fixed ~5.6 us
+            // (first K tile landing + epilogue + drain) plus K/64 K-tile steps of 1.41 us x rows / 256 with every CU in the loop
+            // (the chip's power-limited MFMA rate, ~1450 TFLOP/s, whatever the tile) but never below the phase protocol's 1.15 us.
+            // 288-row tiles (round 4) turn N = 2304 at M = 15104 from 3 rounds into 2 (477 tiles) and the LM head from 13 into 11.
+            static const int p8_288 = getenv("MMTG_GEMM_P8_288") ? atoi(getenv("MMTG_GEMM_P8_288")) : 1;
+            const double nkt = (double)K / 64.0;
+            auto cost = [&](long tiles, double r) { const double tk = 1.41 * r / 256.0; return (double)cdiv(tiles, ncu) * (5.6 + nkt * (tk < 1.15 ? 1.15 : tk)); };
+            const double c192 = cost(t192, 192), c256 = cost(t256, 256), c288 = cost(t288, 288);
+            int rows = c192 < 0.97 * c256 ? 192 : 256;
+            if (p8_288 && c288 < 0.95 * (rows == 192 ? c192 : c256)) rows = 288;
+            if (flags & MMTG_GEMM_P8_288) rows = 288;
             if (p8_rows_env) rows = p8_rows_env;
             if (epi == MMTG_EPI_DGELU && aux2) rows = 256;      // the fused column sums need 64-row-aligned wave tiles
             // Persistent form (more than one round of tiles): OPT-IN, MMTG_GEMM_P8_PERSIST=1 or flags P8 | PERSIST.  Bit-equal, and
@@ -1403,10 +1424,11 @@ extern "C" int mmtg_gemm(int dtype, int transA, int transB, int M, int N, int K,
             // next workgroup of that CU is already fetching its first tiles; a persistent one has them in its own vmcnt queue in
             // front of the next item's tiles, and every CU writes its 128-256 KB at the same moment.
             static const int p8_persist = getenv("MMTG_GEMM_P8_PERSIST") ? atoi(getenv("MMTG_GEMM_P8_PERSIST")) : 0;
-            const long tiles = rows == 192 ? t192 : t256;
+            const long tiles = rows == 192 ? t192 : rows == 288 ? t288 : t256;
             const bool want_persist = p8_persist || ((flags & MMTG_GEMM_P8) && (flags & MMTG_GEMM_PERSIST));
+            if (want_persist && rows == 288) rows = 256;      // (no persistent 288-row instantiation)
             if (want_persist && tiles > num_cus() && num_cus() % 8 == 0) rc = rows == 192 ? launch_p8p<192>(a, s) : launch_p8p<256>(a, s);
-            else rc = rows == 192 ? launch_p8<192>(a, 1, s) : launch_p8<256>(a, 1, s);
+            else rc = rows == 192 ? launch_p8<192>(a, 1, s) : rows == 288 ? launch_p8<288>(a, 1, s) : launch_p8<256>(a, 1, s);
             if (rc) return rc;
             MMTG_LAUNCH_CHECK("gemm");
             return MMTG_OK;

@@ -31,11 +31,16 @@ import torch.distributed as dist
 _budget_users = 0
 
 
+def cu_budget_setting():
+    """The CU reservation a data-parallel run asks the GEMM tile rule for (MMTG_DDP_GEMM_CUS; < 0: CUs left to RCCL)."""
+    return int(os.environ.get("MMTG_DDP_GEMM_CUS", "-32"))
+
+
 def _budget_acquire():
     global _budget_users
     from . import hip
     if _budget_users == 0:
-        hip.gemm_cu_budget(int(os.environ.get("MMTG_DDP_GEMM_CUS", "-32")))
+        hip.gemm_cu_budget(cu_budget_setting())
     _budget_users += 1
 
 

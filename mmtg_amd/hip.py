@@ -18,6 +18,7 @@ EPI_NONE, EPI_GELU, EPI_TANH, EPI_RESID, EPI_DGELU, EPI_DTANH, EPI_ATOMIC, EPI_R
 GEMM_NO_TR, GEMM_REGSTAGE, GEMM_SKINNY, GEMM_NO_SKINNY, GEMM_WIDE, GEMM_NO_WIDE = 1, 2, 4, 8, 16, 32
 GEMM_PERSIST, GEMM_NO_PERSIST, GEMM_ROW_ORDER, GEMM_OCC4, GEMM_NO_OCC4, GEMM_COL_BLOCK, GEMM_P256, GEMM_NO_P8, GEMM_P8 = 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384
 GEMM_GELU_GRAD = 32768
+GEMM_P8_288 = 65536
 PROF_CATS = ["gemm_bf16", "gemm_f32", "attn_fwd", "attn_bwd", "layernorm", "embed", "loss",
              "optim", "encoder", "decode", "misc"]
 
@@ -33,6 +34,7 @@ _SIGS = {
     "mmtg_prof_read": ([_vp, _vp, _vp, _vp], _i),
     "mmtg_gemm_trace": ([_vp, _i], _i),
     "mmtg_gemm_cu_budget": ([_i], _i),
+    "mmtg_debug_occupy": ([_i, _i, C.c_double, _vp], _i),
     "mmtg_gemm": ([_i, _i, _i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _vp, _i, _vp, _l, _vp, _i, _f, _i, _u, _u, _i, _vp], _i),
     "mmtg_gemm_gather": ([_i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _vp, _i, _vp, _i, _vp, _l, _vp, _i, _vp], _i),
     "mmtg_splitk_finish": ([_i, _vp, _i, _i, _i, _l, _vp, _i, _vp, _l, _vp, _l, _vp, _vp, _vp, _f, _vp], _i),
@@ -181,6 +183,12 @@ def zero_ranges(base, desc, n):
 def gemm_cu_budget(cus):
     """CUs the eight-phase kernel's tile rule may count on (0 = all, > 0 = that many, < 0 = all but that many)."""
     _check(lib().mmtg_gemm_cu_budget(int(cus)), "gemm_cu_budget")
+
+
+def debug_occupy(workgroups, usec, lds_bytes=163840, stream=None):
+    """Measurement hook: hold `workgroups` CU-sized slots (lds_bytes of LDS each) for `usec` microseconds on `stream`."""
+    st = _stream() if stream is None else stream.cuda_stream
+    _check(lib().mmtg_debug_occupy(int(workgroups), int(lds_bytes), float(usec), st), "debug_occupy")
 
 
 def gemm_trace(buf=None):

@@ -54,6 +54,7 @@ class MMTGTrainer:
         self.lm_weight = lm_weight
         self.reducer = GradReducer(self.eng.layout, bucket_mb) if distributed else None
         self._count = None
+        self.measure_finish, self.finish_events = False, []
         if self.reducer is not None:
             self.eng.bucket_hook = lambda pack: self.reducer.on_pack_ready(self.eng.grad, pack)
 
@@ -138,10 +139,25 @@ class MMTGTrainer:
                 eng._ow_rec = None
             out = {"loss": sc[0], "lm_loss": sc[1], "kl": eng.act["kl"][0]}
         if red is not None:
-            red.finish(eng.grad)
+            if self.measure_finish:     # exposed exchange time: how long the compute stream sits in finish() (bench.py --gpus N)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                red.finish(eng.grad)
+                e1.record()
+                self.finish_events.append((e0, e1))
+            else:
+                red.finish(eng.grad)
         eng.adamw_step(self.current_lr(), self.max_norm, self.betas, self.eps, self.wd, count=self._count)
         self.sched_step += 1
         return out
+
+    def finish_wait_ms(self):
+        """Mean time per step the compute stream waited in the reducer's finish() -- the part of the gradient exchange the
+        backward did NOT hide -- over the steps taken with ``measure_finish`` on (synchronises; clears the record)."""
+        torch.cuda.synchronize()
+        ms = [a.elapsed_time(b) for a, b in self.finish_events]
+        self.finish_events = []
+        return sum(ms) / len(ms) if ms else None
 
     def grad_norm(self):
         """Global gradient norm of the last step as clip_grad_norm_ saw it (device scalar): the flat buffer holds row

@@ -202,9 +202,10 @@ def test_gemm_eight_phase_kernel_matches_older_kernels(shape):
 
     old = run(hip.GEMM_NO_P8)
     close(old[1], a.float().cpu() @ w.float().cpu().t(), dtype, K, "older kernels vs fp32")
-    for rep in range(4):
-        # default routing; the dGELU product on the eight-phase kernel too (twice); the persistent form (opt-in)
-        new = run((0, hip.GEMM_P8, hip.GEMM_P8, hip.GEMM_P8 | hip.GEMM_PERSIST)[rep])
+    for rep in range(6):
+        # default routing; the dGELU product on the eight-phase kernel too (twice); the persistent form (opt-in); 288-row tiles
+        # (round 4; twice -- the dGELU product with column sums keeps its 256-row tiles there)
+        new = run((0, hip.GEMM_P8, hip.GEMM_P8, hip.GEMM_P8 | hip.GEMM_PERSIST, hip.GEMM_P8_288, hip.GEMM_P8_288)[rep])
         for i, (x, y) in enumerate(zip(old, new)):
             assert torch.equal(x, y), (shape, rep, i)
 

@@ -66,7 +66,8 @@ r = r[r[:, 3] != 0]
 t0 = r[:, 0].min()
 us = lambda x: x * 0.01   # 100 MHz ticks -> us
 start, first, loop_end, end = (us(r[:, i] - t0) for i in range(4))
-nk = r[:, 4]
+nk = r[:, 4] & 0xFFFFF
+loop_cycles = r[:, 4] >> 20          # eight-phase kernel only: shader-clock cycles of the K loop
 xcc = (r[:, 5] >> 32) & 0xF
 hw = r[:, 5] & 0xFFFFFFFF
 cu = (hw >> 8) & 0xF
@@ -83,6 +84,14 @@ dist("entry -> first K tile landed", first - start)
 dist("K loop (per workgroup)", loop_end - first)
 dist("K loop per K tile", (loop_end - first) / np.maximum(nk, 1))
 dist("epilogue + store drain", end - loop_end)
+if loop_cycles.max() > 0:
+    ghz = loop_cycles / np.maximum((loop_end - first) * 1e3, 1e-9)     # cycles / ns
+    q = np.percentile(ghz, [0, 10, 50, 90, 100])
+    print("  %-34s min %7.3f  p10 %7.3f  p50 %7.3f  p90 %7.3f  max %7.3f GHz" % (("shader clock inside the K loop",) + tuple(q)))
+    # MFMA-issue share of the loop: 16x16x32 bf16 = 16 cycles each on a SIMD's matrix pipe, two waves per SIMD
+    rows = 256 if int(os.environ.get("MMTG_GEMM_P8_ROWS", "0") or 0) == 0 else int(os.environ["MMTG_GEMM_P8_ROWS"])
+    print("  %-34s %.1f %% (at %d-row tiles: %d MFMAs of 16 cycles per wave and K tile, two waves per SIMD)" % (
+        "matrix-pipe cycles / loop cycles", 100.0 * np.median(nk * (rows // 2 // 16) * 8 * 2 * 16 / np.maximum(loop_cycles, 1)), rows, (rows // 2 // 16) * 8))
 dist("workgroup lifetime", end - start)
 # scheduling: start-time histogram in 2 us bins
 span = end.max()
