@@ -404,13 +404,24 @@ struct DgArgs {
     float* ws; unsigned* cnt; int ws_bytes;
     // mode 2, residual = wpe[*pos_ptr] + wte[type_ids[m]] instead of a tensor (the GPT-2 input embedding added in the projector's epilogue)
     const bf16* emb_pos; const bf16* emb_type; const long long* type_ids; const int* pos_ptr;
+    int bytesC, bytesR;        // extents of C (all slabs) and of the residual: buffer descriptors of the coherent (persistent) form
 };
 
-template <int MODE>
-__global__ __launch_bounds__(256, 2) void decode_gemm_kernel(DgArgs p) {
-    constexpr int TB = 64, NW = 4, NBUF = 4, BK = 64, NB = 2;
+// Agent-scope (sc1: write-through store / L1-bypassing load, cache-policy operand 16) accessors of the persistent token step: a
+// tensor written in one stage is read by OTHER workgroups -- other CUs, other XCDs -- in the next, with only a grid barrier in
+// between, so EVERY store and EVERY load of such a tensor carries the scope bit (MI355X_MICROARCH.md, valid hand-off forms).
+__device__ __forceinline__ void dg_st2_agent(__amdgpu_buffer_rsrc_t r, int byte_off, u32x2 v) { __builtin_amdgcn_raw_buffer_store_b64(v, r, byte_off, 0, 16); }
+__device__ __forceinline__ uint32_t dg_ld1_agent(__amdgpu_buffer_rsrc_t r, int byte_off) { return __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 16); }
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t dg_rsrc(const void* p, int bytes) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000); }
+
+// One 64 x 64 output tile (x one K slice) = work item `bid`.  COH = false: the stand-alone launches (one item per workgroup).
+// COH = true: the persistent token step (decode_persist_kernel) -- activations, statistics and slabs move through agent-scope
+// accesses; the caller puts a workgroup barrier between two items (LDS ring / statistics reuse).
+template <int MODE, bool COH, int NBUF, int MAXS = 8>
+__device__ __forceinline__ void dg_tile(const DgArgs& p, const int bid, char* smem) {
+    constexpr int TB = 64, NW = 4, BK = 64, NB = 2;
     constexpr int TA = TB * 128, STAGE = 2 * TA;
-    extern __shared__ __attribute__((aligned(16))) char smem[];      // NBUF stages | row statistics
+    constexpr int AUXA = COH ? 16 : 0;                                // cache policy of the activation operand's LDS-DMA
     float* const smu = reinterpret_cast<float*>(smem + NBUF * STAGE);
     float* const srs = smu + TB;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -421,7 +432,6 @@ __global__ __launch_bounds__(256, 2) void decode_gemm_kernel(DgArgs p) {
     // (An XCD-contiguous order with the row tiles of a weight panel side by side on one XCD -- the training kernels' order --
     //  measured 789 vs 728 us per token step here: the step is latency-bound, and spreading a product's first requests over all
     //  eight L2s matters more than fetching a 96 KB panel once.)
-    const int bid = blockIdx.x;
     const int split = bid / p.ntiles, t = bid - split * p.ntiles;
     const int m0 = (t / p.tiles_n) * TB, n0 = (t % p.tiles_n) * TB;
     const int kbeg = split * p.kper;
@@ -449,7 +459,7 @@ __global__ __launch_bounds__(256, 2) void decode_gemm_kernel(DgArgs p) {
         _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                                               \
             const int oa_ = !live_ ? OOB : full_ ? va[i] : dma_voff<false, TB>(p.lda, m0, p.M, krem_, wave + NW * i, lane); \
             const int ob_ = !live_ ? OOB : full_ ? vb[i] : dma_voff<false, TB>(p.ldw, n0, p.N, krem_, wave + NW * i, lane); \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, LDS_PTR(void, st_ + (wave + NW * i) * 1024), 16, oa_, live_ ? sa : 0, 0, 0); \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, LDS_PTR(void, st_ + (wave + NW * i) * 1024), 16, oa_, live_ ? sa : 0, 0, AUXA); \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, LDS_PTR(void, st_ + TA + (wave + NW * i) * 1024), 16, ob_, live_ ? sb : 0, 0, 0); \
         }                                                                                                              \
         sa += BK * 2;                                                                                                  \
@@ -466,8 +476,14 @@ __global__ __launch_bounds__(256, 2) void decode_gemm_kernel(DgArgs p) {
             const int m = min(m0 + tid, p.M - 1);
             const f32x4* src = reinterpret_cast<const f32x4*>(p.stats_in + (long)m * DG_NP * 2);
             f32x4 sp[DG_NP / 2];
+            if constexpr (COH) {
+                const __amdgpu_buffer_rsrc_t rs = dg_rsrc(p.stats_in, p.M * DG_NP * 2 * 4);
 #pragma unroll
-            for (int i = 0; i < DG_NP / 2; ++i) sp[i] = i * 2 < p.np_in ? src[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int i = 0; i < DG_NP / 2; ++i) sp[i] = i * 2 < p.np_in ? dg_ld4_agent(rs, (m * DG_NP * 2 + 4 * i) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            } else {
+#pragma unroll
+                for (int i = 0; i < DG_NP / 2; ++i) sp[i] = i * 2 < p.np_in ? src[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int i = 0; i < DG_NP / 2; ++i) { s1 += sp[i][0] + sp[i][2]; s2 += sp[i][1] + sp[i][3]; }
@@ -523,17 +539,21 @@ __global__ __launch_bounds__(256, 2) void decode_gemm_kernel(DgArgs p) {
                     // slab `split` of the consumer's fp32 input: the mean term rides on slab 0, the bias is the consumer's
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = rs * acc[i][j][r] - (split == 0 ? rs * mu * c4[j][r] : 0.f);
-                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + ((long)split * p.M + m) * p.ldc + n) = v;
+                    if constexpr (COH) dg_st4_agent(dg_rsrc(p.C, p.bytesC), (int)((((long)split * p.M + m) * p.ldc + n) * 4), v);
+                    else *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + ((long)split * p.M + m) * p.ldc + n) = v;
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         v[r] = rs * (acc[i][j][r] - mu * c4[j][r]) + b4[j][r];
                         if (p.act == MMTG_EPI_GELU) v[r] = gelu_new_t<bf16>(v[r]);
                     }
-                    if (p.out_f32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n) = v;
-                    else {
+                    if (p.out_f32) {
+                        if constexpr (COH) dg_st4_agent(dg_rsrc(p.C, p.bytesC), (int)(((long)m * p.ldc + n) * 4), v);
+                        else *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n) = v;
+                    } else {
                         const bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-                        *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(p.C) + (long)m * p.ldc + n) = o;
+                        if constexpr (COH) dg_st2_agent(dg_rsrc(p.C, p.bytesC), (int)(((long)m * p.ldc + n) * 2), __builtin_bit_cast(u32x2, o));
+                        else *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(p.C) + (long)m * p.ldc + n) = o;
                     }
                 }
             }
@@ -555,13 +575,14 @@ __global__ __launch_bounds__(256, 2) void decode_gemm_kernel(DgArgs p) {
             if (lane == 0) old = atomicAdd(cnt, 1u);
             old = __builtin_amdgcn_readfirstlane(old);
             if (old != (unsigned)(S - 1)) return;
-            if (lane == 0) *cnt = 0u;
+            // (re-armed for the next product: an agent-scope store in the persistent form, where no kernel boundary flushes it)
+            if (lane == 0) { if constexpr (COH) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *cnt = 0u; }
         }
         // every split's partial (my own slot included: statically indexed registers, no scratch), all requested back to back:
         // one memory round trip for the whole reduction
-        f32x4 prt[8][4];
+        f32x4 prt[MAXS][4];        // (MAXS = most K splits the instantiation serves: 8 stand-alone, 4 in the register-capped persistent kernel)
 #pragma unroll
-        for (int s_ = 0; s_ < 8; ++s_) {
+        for (int s_ = 0; s_ < MAXS; ++s_) {
             const int se = s_ < S ? s_ : split;
 #pragma unroll
             for (int q = 0; q < 4; ++q) prt[s_][q] = S > 1 ? dg_ld4_agent(rw, slot0 + se * (TB * TB * 4) + q * 1024) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -575,7 +596,7 @@ __global__ __launch_bounds__(256, 2) void decode_gemm_kernel(DgArgs p) {
                 const int n = nw0 + j * 16 + 4 * g;
                 f32x4 sum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int s_ = 0; s_ < 8; ++s_) {                  // split order; mine from registers
+                for (int s_ = 0; s_ < MAXS; ++s_) {               // split order; mine from registers
                     const f32x4 v = s_ == split ? acc[i][j] : prt[s_][i * 2 + j];
                     if (s_ < S) sum += v;
                 }
@@ -588,7 +609,13 @@ __global__ __launch_bounds__(256, 2) void decode_gemm_kernel(DgArgs p) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) xr[r] = (float)e0[r] + (float)e1[r];
                     } else {
-                        const bf16x4 x4 = *reinterpret_cast<const bf16x4*>(p.resid + (long)m * p.ldr + n);
+                        bf16x4 x4;
+                        if constexpr (COH) {            // two 4-byte agent-scope loads (the measured-valid widths: 4 / 16 bytes)
+                            const __amdgpu_buffer_rsrc_t rr = dg_rsrc(p.resid, p.bytesR);
+                            const int o_ = (int)(((long)m * p.ldr + n) * 2);
+                            const u32x2 w = {dg_ld1_agent(rr, o_), dg_ld1_agent(rr, o_ + 4)};
+                            x4 = __builtin_bit_cast(bf16x4, w);
+                        } else x4 = *reinterpret_cast<const bf16x4*>(p.resid + (long)m * p.ldr + n);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) xr[r] = (float)x4[r];
                     }
@@ -600,7 +627,8 @@ __global__ __launch_bounds__(256, 2) void decode_gemm_kernel(DgArgs p) {
                         r1 += f;
                         r2 += f * f;
                     }
-                    *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(p.C) + (long)m * p.ldc + n) = o;
+                    if constexpr (COH) dg_st2_agent(dg_rsrc(p.C, p.bytesC), (int)(((long)m * p.ldc + n) * 2), __builtin_bit_cast(u32x2, o));
+                    else *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(p.C) + (long)m * p.ldc + n) = o;
                 }
             }
             // the row's 32 columns of this wave tile live in the four lane groups g: fold them
@@ -608,11 +636,22 @@ __global__ __launch_bounds__(256, 2) void decode_gemm_kernel(DgArgs p) {
             r1 += __shfl_xor(r1, 32, 64); r2 += __shfl_xor(r2, 32, 64);
             if (g == 0 && m < p.M && nw0 < p.N) {
                 float* dst = p.stats_out + ((long)m * DG_NP + (nw0 >> 5)) * 2;
-                dst[0] = r1;
-                dst[1] = r2;
+                if constexpr (COH) {
+                    const f32x2 rr2 = {r1, r2};
+                    dg_st2_agent(dg_rsrc(p.stats_out, p.M * DG_NP * 2 * 4), (m * DG_NP + (nw0 >> 5)) * 8, __builtin_bit_cast(u32x2, rr2));
+                } else {
+                    dst[0] = r1;
+                    dst[1] = r2;
+                }
             }
         }
     }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void decode_gemm_kernel(DgArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // 4 stages | row statistics
+    dg_tile<MODE, false, 4>(p, blockIdx.x, smem);
 }
 
 // W'[n, k] = gamma[k] W[n, k] (bf16), c[n] = sum_k W'[n, k] (of the ROUNDED values: what the product will multiply),
@@ -673,19 +712,28 @@ __global__ __launch_bounds__(256) void decode_embed_add_kernel(const T* __restri
 // even assembled from the c_attn slabs -- they depend on nothing this kernel computes -- so a step with a short prefix costs one
 // memory round trip instead of three dependent ones (slabs -> scores -> values).  Branch-free: rows at or past `pos` are
 // requested from the last valid row and replaced afterwards (key == pos: the token's own row, held in LDS exactly as stored).
-template <typename T>
-__global__ __launch_bounds__(64) void decode_attn_kernel(const T* __restrict__ qkv, T* __restrict__ kc, T* __restrict__ vc,
-        const int* __restrict__ keep, long ldkeep, const int* __restrict__ pos_ptr, T* __restrict__ out,
-        int nH, int Tmax, const float* __restrict__ part, int splits, long slab, const float* __restrict__ bias) {
+// bytes of LDS one (b, head) item needs: scores, key flags, q (f32), this token's k and v
+template <typename T> constexpr int da_lds_bytes() { return 1024 * 4 + 1024 * 4 + 64 * 4 + 2 * 64 * (int)sizeof(T); }
+
+// COH = false: one 64-thread workgroup per (b, head) (__syncthreads() = that wave).  COH = true: one WAVE of a persistent
+// workgroup per item -- the wave's LDS operations complete in order, so its "barrier" is a drain of its own counters -- with the
+// c_attn slabs read and the context row stored through agent-scope accesses (they cross workgroups with only a grid barrier between).
+template <typename T, bool COH>
+__device__ __forceinline__ void da_body(const T* __restrict__ qkv, T* __restrict__ kc, T* __restrict__ vc,
+        const int* __restrict__ keep, long ldkeep, const int pos, T* __restrict__ out, const int B,
+        int nH, int Tmax, const float* __restrict__ part, int splits, long slab, const float* __restrict__ bias,
+        const int h, const int b, const int lane, char* lds) {
     typedef typename Vec16<T>::type V;
     constexpr int EPL = Vec16<T>::N, OCT = 64 / EPL, KPI = 64 / OCT;      // elements per lane, lanes per key, keys per instruction
+    // (the SAME chunking in both forms: the first chunk's scores and the later chunks' come out of differently contracted
+    //  loops, so moving the chunk boundary moves last bits -- the persistent step stays bit-equal to the per-launch one)
     constexpr int UN = 16, UN0 = 12;
-    __shared__ float sp[1024];
-    __shared__ int skeep[1024];
-    __shared__ float sq[64];
-    __shared__ __attribute__((aligned(16))) T sk[64];
-    __shared__ __attribute__((aligned(16))) T sv[64];
-    const int h = blockIdx.x, b = blockIdx.y, lane = threadIdx.x, pos = *pos_ptr;
+    float* const sp = reinterpret_cast<float*>(lds);
+    int* const skeep = reinterpret_cast<int*>(lds + 4096);
+    float* const sq = reinterpret_cast<float*>(lds + 8192);
+    T* const sk = reinterpret_cast<T*>(lds + 8192 + 256);
+    T* const sv = sk + 64;
+#define DA_SYNC() do { if constexpr (COH) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); else __syncthreads(); } while (0)
     const int D = nH * 64;
     const T* row = qkv + (long)b * 3 * D + h * 64;
     T* kbase = kc + (((long)b * nH + h) * Tmax) * 64;
@@ -715,15 +763,28 @@ __global__ __launch_bounds__(64) void decode_attn_kernel(const T* __restrict__ q
         float q = 0.f, k = 0.f, v = 0.f;
         const float bq = bias[h * 64 + lane], bk = bias[D + h * 64 + lane], bv = bias[2 * D + h * 64 + lane];
         float pq[4], pk[4], pv[4];
+        if constexpr (COH) {
+            const __amdgpu_buffer_rsrc_t rp = dg_rsrc(part, (int)((long)splits * slab * 4));
+            const int o0 = (int)(((long)b * 3 * D + h * 64 + lane) * 4);
 #pragma unroll
-        for (int s_ = 0; s_ < 4; ++s_) {
-            const long o = (long)(s_ < splits ? s_ : 0) * slab;
-            pq[s_] = pr[o]; pk[s_] = pr[o + D]; pv[s_] = pr[o + 2 * D];
+            for (int s_ = 0; s_ < 4; ++s_) {
+                const int o = o0 + (int)((long)(s_ < splits ? s_ : 0) * slab * 4);
+                pq[s_] = __builtin_bit_cast(float, dg_ld1_agent(rp, o));
+                pk[s_] = __builtin_bit_cast(float, dg_ld1_agent(rp, o + D * 4));
+                pv[s_] = __builtin_bit_cast(float, dg_ld1_agent(rp, o + 2 * D * 4));
+            }
+        } else {
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_) {
+                const long o = (long)(s_ < splits ? s_ : 0) * slab;
+                pq[s_] = pr[o]; pk[s_] = pr[o + D]; pv[s_] = pr[o + 2 * D];
+            }
         }
 #pragma unroll
         for (int s_ = 0; s_ < 4; ++s_)
             if (s_ < splits) { q += pq[s_]; k += pk[s_]; v += pv[s_]; }
-        for (int s_ = 4; s_ < splits; ++s_) { q += pr[s_ * slab]; k += pr[s_ * slab + D]; v += pr[s_ * slab + 2 * D]; }
+        if constexpr (!COH)
+            for (int s_ = 4; s_ < splits; ++s_) { q += pr[s_ * slab]; k += pr[s_ * slab + D]; v += pr[s_ * slab + 2 * D]; }
         q += bq; k += bk; v += bv;
         sq[lane] = (float)(T)q * 0.125f;
         sk[lane] = (T)k;
@@ -738,7 +799,7 @@ __global__ __launch_bounds__(64) void decode_attn_kernel(const T* __restrict__ q
 #pragma unroll
     for (int i = 0; i < 4; ++i) skeep[lane + 64 * i] = kp[i];
     for (int key = lane + 256; key < nkeys; key += 64) skeep[key] = keep[(long)b * ldkeep + key];
-    __syncthreads();
+    DA_SYNC();
     float qv[EPL];
 #pragma unroll
     for (int e = 0; e < EPL; ++e) qv[e] = sq[oc * EPL + e];
@@ -778,7 +839,7 @@ __global__ __launch_bounds__(64) void decode_attn_kernel(const T* __restrict__ q
             if (oc == 0 && key < nkeys) sp[key] = skeep[key] ? a : -INFINITY;
         }
     }
-    __syncthreads();
+    DA_SYNC();
     float mx = -INFINITY;
     for (int key = lane; key < nkeys; key += 64) mx = fmaxf(mx, sp[key]);
     mx = wave_max(mx);
@@ -791,7 +852,7 @@ __global__ __launch_bounds__(64) void decode_attn_kernel(const T* __restrict__ q
         sum += p;
     }
     sum = wave_sum(sum);
-    __syncthreads();
+    DA_SYNC();
     // ---- values: the first chunk from the rows already in registers, later chunks from the cache
     float acc[EPL];
 #pragma unroll
@@ -827,9 +888,22 @@ __global__ __launch_bounds__(64) void decode_attn_kernel(const T* __restrict__ q
         V o;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) o[e] = (T)(acc[e] * inv);
-        *reinterpret_cast<V*>(out + (long)b * D + h * 64 + oc * EPL) = o;
+        if constexpr (COH) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), dg_rsrc(out, (int)((long)B * D * sizeof(T))),
+                                                                 (int)(((long)b * D + h * 64 + oc * EPL) * sizeof(T)), 0, 16);
+        else *reinterpret_cast<V*>(out + (long)b * D + h * 64 + oc * EPL) = o;
     }
+#undef DA_SYNC
 }
+
+template <typename T>
+__global__ __launch_bounds__(64) void decode_attn_kernel(const T* __restrict__ qkv, T* __restrict__ kc, T* __restrict__ vc,
+        const int* __restrict__ keep, long ldkeep, const int* __restrict__ pos_ptr, T* __restrict__ out,
+        int nH, int Tmax, const float* __restrict__ part, int splits, long slab, const float* __restrict__ bias) {
+    __shared__ __attribute__((aligned(16))) char lds[da_lds_bytes<T>()];
+    da_body<T, false>(qkv, kc, vc, keep, ldkeep, *pos_ptr, out, (int)gridDim.y, nH, Tmax, part, splits, slab, bias,
+                      (int)blockIdx.x, (int)blockIdx.y, (int)threadIdx.x, lds);
+}
+
 
 // logits processor + arg-max + forced-token cadence + append (generate.py:117-142), device-driven.
 __global__ __launch_bounds__(256) void decode_select_kernel(const float* __restrict__ logits, long ldl, int V,
@@ -878,6 +952,111 @@ __global__ __launch_bounds__(256) void decode_select_kernel(const float* __restr
 }
 
 __global__ void decode_advance_kernel(int* pos_ptr) { *pos_ptr += 1; }
+
+// =====================================================================================
+// Round 4: the GPT-2 part of a token step as ONE persistent launch (mmtg_decode_persist).
+//
+// The fused step above is 61 dependent launches for the twelve blocks and the head (c_attn, attention, attn c_proj, c_fc,
+// mlp c_proj per block); each costs ~4 us of kernel begin / end whatever it does and starts from cold caches.  Here the same
+// 61 stages run inside one kernel: a fixed grid of co-resident 256-thread workgroups walks a stage list (device memory, built once
+// per decoder), every workgroup takes the stage's 64 x 64 tile items / every wave its (b, head) items in a strided loop, and a
+// two-level device-wide barrier (one arrival counter per shard of workgroups with equal id % 8 -- one XCD under round-robin
+// placement, a speed assumption only -- whose last arriver bumps the top counter; everybody polls one generation word) separates
+// the stages: 2-3 us instead of a kernel boundary.  Data handed from one stage to the next crosses workgroups, CUs and XCDs with no
+// kernel boundary to flush the non-coherent L2s, so every such tensor (residual stream, LayerNorm statistics, c_attn slabs,
+// attention context, GELU output, split-K partials) is written with agent-scope (sc1, write-through) stores and read with
+// agent-scope loads / LDS-DMA, each wave drains its stores (vmcnt(0)) before its workgroup arrives at the barrier: the hand-off
+// form MI355X_MICROARCH.md measures as valid without L2-wide fences.  Weights, biases and the KV cache rows of earlier steps are
+// ordinary loads.  The arithmetic per item is the fused step's (dg_tile / da_body with COH = true): same K order, same reduction
+// order -- the ids are bit-equal to the per-launch step's (tests/test_decode_gpu.py).
+// Safety: every poll is bounded (a stage that cannot complete -- a workgroup that is not resident -- raises the error word and
+// every workgroup leaves; the host checks it), the grid is sized from the occupancy the runtime reports for THIS kernel.
+struct DaArgs {
+    const float* part; const float* bias; bf16* kc; bf16* vc; const int* keep; const int* pos_ptr; bf16* out;
+    long ldkeep, slab;
+    int splits, B, nH, Tmax;
+};
+struct PStage {
+    int kind, nitems;          // kind 0 / 1 / 2: dg_tile mode; 3: attention; items = tiles x splits, or B x heads
+    DgArgs g;
+    DaArgs a;
+};
+// Two builds: WPC = 3 workgroups per CU (twelve waves per CU for the attention stages; 168 registers, a 3 x 16 KB product ring) and
+// WPC = 2 (256 registers, the stand-alone kernels' 4 x 16 KB ring); mmtg_decode_persist_grid picks (MMTG_DECODE_PERSIST_WGS).
+template <int WPC> constexpr int ps_nbuf() { return WPC >= 3 ? 3 : 4; }
+template <int WPC> constexpr int ps_lds() { return ps_nbuf<WPC>() * 2 * 64 * 128 + 2 * 64 * 4 + 16; }      // ring | statistics | verdict word
+static_assert(4 * da_lds_bytes<bf16>() <= ps_lds<3>(), "the four attention waves' scratch overlays the product ring");
+constexpr unsigned long long PS_TIMEOUT_TICKS = 20000000ull;       // 0.2 s of the 100 MHz wall counter per barrier
+// barrier words (unsigned long long, 128-byte separated): [0] generation, [16] top counter, [32 + 16 k] shard k
+__device__ __forceinline__ unsigned long long ps_ld(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ bool ps_grid_barrier(unsigned long long* bar, unsigned long long target, int* err, int tid) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's agent-scope stores have been acknowledged
+    __syncthreads();
+    bool ok = true;
+    if (tid == 0) {
+        const int nb = gridDim.x, x = blockIdx.x & 7;
+        const unsigned long long per = (unsigned long long)((nb + 7 - x) / 8);
+        const unsigned long long old = __hip_atomic_fetch_add(bar + 32 + 16 * x, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == target * per - 1) {
+            const unsigned long long g = __hip_atomic_fetch_add(bar + 16, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (g == target * 8 - 1) __hip_atomic_store(bar, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (ps_ld(bar) < target) {
+            __builtin_amdgcn_s_sleep(2);
+            if (__builtin_amdgcn_s_memrealtime() - t0 > PS_TIMEOUT_TICKS || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = false;
+                break;
+            }
+        }
+    }
+    return ok;          // thread 0's verdict; the caller publishes it to the workgroup
+}
+
+template <int WPC>
+__global__ __launch_bounds__(256, WPC) void decode_persist_kernel(const PStage* __restrict__ stages, int nstages, unsigned long long* bar, int* err,
+                                                                  unsigned long long* __restrict__ trace) {
+    constexpr int PS_NBUF = ps_nbuf<WPC>();
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // ONE LDS object (a second one beside an LDS-DMA ring can de-pipeline it)
+    int& s_ok = *reinterpret_cast<int*>(smem + ps_lds<WPC>() - 16);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;        // a poisoned decoder: the host must reset it
+    // no barrier is in flight when a launch starts (the previous launch's last barrier completed before any workgroup left)
+    const unsigned long long gen0 = ps_ld(bar);
+    if (trace && blockIdx.x == 0 && tid == 0) trace[2 * nstages] = __builtin_amdgcn_s_memrealtime();
+    for (int s = 0; s < nstages; ++s) {
+        const PStage& S = stages[s];
+        const int kind = S.kind, n = S.nitems;
+        if (kind == 3) {
+            const DaArgs& a = S.a;
+            const int pos = *a.pos_ptr;
+            for (int it = blockIdx.x * 4 + wave; it < n; it += gridDim.x * 4)
+                da_body<bf16, true>(nullptr, a.kc, a.vc, a.keep, a.ldkeep, pos, a.out, a.B, a.nH, a.Tmax, a.part, a.splits, a.slab, a.bias,
+                                    it % a.nH, it / a.nH, lane, smem + wave * da_lds_bytes<bf16>());
+        } else {
+            for (int it = blockIdx.x; it < n; it += gridDim.x) {
+                if (kind == 0) dg_tile<0, true, PS_NBUF>(S.g, it, smem);
+                else if (kind == 1) dg_tile<1, true, PS_NBUF>(S.g, it, smem);
+                else dg_tile<2, true, PS_NBUF, 4>(S.g, it, smem);
+                // the next item (or the next stage) restages the ring and rewrites the row statistics: every wave must be done with them
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+        }
+        if (trace && blockIdx.x == 0 && tid == 0) trace[2 * s] = __builtin_amdgcn_s_memrealtime();
+        // (after the last stage too: it is what lets the NEXT launch read a settled generation word)
+        const bool ok = ps_grid_barrier(bar, gen0 + (unsigned long long)s + 1, err, tid);
+        if (tid == 0) s_ok = ok ? 1 : 0;
+        // diagnostic timeline (mmtg_decode_persist_trace): workgroup 0 stamps the wall clock when it leaves each barrier, and
+        // when its own work of the stage was done (row 2 s: work done, 2 s + 1: barrier passed; entry 2 * nstages: kernel entry)
+        if (trace && blockIdx.x == 0 && tid == 0) trace[2 * s + 1] = __builtin_amdgcn_s_memrealtime();
+        __syncthreads();
+        if (!s_ok) return;
+    }
+}
 
 }  // namespace
 
@@ -1006,17 +1185,16 @@ extern "C" int mmtg_ln_fold_weights(const void* W, long ldw, const float* gamma,
     return MMTG_OK;
 }
 
-extern "C" int mmtg_decode_gemm(int mode, int M, int N, int K, const void* A, long lda, const void* W, long ldw, void* C, long ldc,
-                                const float* bias, const float* colsum, const float* stats_in, int np_in, float eps, int act,
-                                int out_f32, const void* resid, long ldr, float* stats_out, int splits, float* ws, long ws_floats,
-                                unsigned* counters, long n_counters, const void* emb_pos, const void* emb_type,
-                                const long long* type_ids, const int* pos_ptr, void* stream) {
+static int dg_fill(DgArgs& a, int mode, int M, int N, int K, const void* A, long lda, const void* W, long ldw, void* C, long ldc,
+                   const float* bias, const float* colsum, const float* stats_in, int np_in, float eps, int act,
+                   int out_f32, const void* resid, long ldr, float* stats_out, int splits, float* ws, long ws_floats,
+                   unsigned* counters, long n_counters, const void* emb_pos, const void* emb_type,
+                   const long long* type_ids, const int* pos_ptr) {
     MMTG_REQUIRE(mode >= 0 && mode <= 2, "decode_gemm: mode 0 (LN-fold), 1 (LN-fold slabs) or 2 (in-kernel split-K reduce)");
     MMTG_REQUIRE(M > 0 && N > 0 && K > 0 && A && W && C, "decode_gemm: bad arguments");
     MMTG_REQUIRE(K % 8 == 0 && lda % 8 == 0 && ldw % 8 == 0 && N % 4 == 0 && ldc % 4 == 0, "decode_gemm: K, lda, ldw multiples of 8; N, ldc of 4");
     MMTG_REQUIRE(MMTG_ALIGNED16(A) && MMTG_ALIGNED16(W) && MMTG_ALIGNED16(C), "decode_gemm: 16-byte alignment");
     if (splits < 1) splits = 1;
-    DgArgs a;
     memset(&a, 0, sizeof(a));
     a.A = (const bf16*)A; a.W = (const bf16*)W; a.C = C; a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr;
     a.M = M; a.N = N; a.K = K;
@@ -1045,6 +1223,18 @@ extern "C" int mmtg_decode_gemm(int mode, int M, int N, int K, const void* A, lo
         MMTG_REQUIRE(a.splits == 1 || (ws && counters && ws_floats >= (long)a.ntiles * a.splits * 4096 && n_counters >= (long)a.ntiles * 4),
                      "decode_gemm: split products need %ld workspace floats and %ld zeroed counters", (long)a.ntiles * a.splits * 4096, (long)a.ntiles * 4);
     }
+    return MMTG_OK;
+}
+
+extern "C" int mmtg_decode_gemm(int mode, int M, int N, int K, const void* A, long lda, const void* W, long ldw, void* C, long ldc,
+                                const float* bias, const float* colsum, const float* stats_in, int np_in, float eps, int act,
+                                int out_f32, const void* resid, long ldr, float* stats_out, int splits, float* ws, long ws_floats,
+                                unsigned* counters, long n_counters, const void* emb_pos, const void* emb_type,
+                                const long long* type_ids, const int* pos_ptr, void* stream) {
+    DgArgs a;
+    int rc_ = dg_fill(a, mode, M, N, K, A, lda, W, ldw, C, ldc, bias, colsum, stats_in, np_in, eps, act, out_f32, resid, ldr, stats_out, splits,
+                      ws, ws_floats, counters, n_counters, emb_pos, emb_type, type_ids, pos_ptr);
+    if (rc_) return rc_;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(MMTG_PROF_GEMM_BF16, s, 2.0 * M * N * (double)K, 2.0 * ((double)M * K + (double)N * K) + (out_f32 ? 4.0 : 2.0) * (double)M * N);
     const size_t shm = 4 * 2 * 64 * 128 + 2 * 64 * 4;
@@ -1061,5 +1251,90 @@ extern "C" int mmtg_decode_gemm(int mode, int M, int N, int K, const void* A, lo
     else if (mode == 1) hipLaunchKernelGGL(decode_gemm_kernel<1>, grid, block, shm, s, a);
     else hipLaunchKernelGGL(decode_gemm_kernel<2>, grid, block, shm, s, a);
     MMTG_LAUNCH_CHECK("decode_gemm");
+    return MMTG_OK;
+}
+
+// ------------------------------------------------------------------ persistent token step (round 4)
+// Stage descriptors are built on the HOST into a caller-owned byte buffer (mmtg_decode_stage_bytes() each) with the argument lists
+// of the launches they replace, uploaded once per decoder, and walked by decode_persist_kernel.
+extern "C" long mmtg_decode_stage_bytes(void) { return (long)sizeof(PStage); }
+
+extern "C" int mmtg_decode_stage_gemm(void* stages_host, int index, int mode, int M, int N, int K, const void* A, long lda, const void* W,
+                                      long ldw, void* C, long ldc, const float* bias, const float* colsum, const float* stats_in, int np_in,
+                                      float eps, int act, int out_f32, const void* resid, long ldr, float* stats_out, int splits, float* ws,
+                                      long ws_floats, unsigned* counters, long n_counters) {
+    MMTG_REQUIRE(stages_host && index >= 0, "decode_stage_gemm: null descriptor buffer");
+    PStage& st = reinterpret_cast<PStage*>(stages_host)[index];
+    memset(&st, 0, sizeof(st));
+    int rc = dg_fill(st.g, mode, M, N, K, A, lda, W, ldw, C, ldc, bias, colsum, stats_in, np_in, eps, act, out_f32, resid, ldr, stats_out, splits,
+                     ws, ws_floats, counters, n_counters, nullptr, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    const long bytesC = (mode == 1 ? (long)st.g.splits * M : (long)M) * ldc * (out_f32 ? 4 : 2);
+    const long bytesR = resid ? ((long)(M - 1) * ldr + N) * 2 : 0;
+    MMTG_REQUIRE(bytesC < 0x7FFFFF00L && bytesR < 0x7FFFFF00L && (long)M * DG_NP * 8 < 0x7FFFFF00L, "decode_stage_gemm: outputs must stay below 2 GiB");
+    st.g.bytesC = (int)bytesC; st.g.bytesR = (int)bytesR;
+    MMTG_REQUIRE(mode != 2 || st.g.splits <= 4, "decode_stage_gemm: at most 4 K splits per reduce stage in the persistent kernel");
+    st.kind = mode;
+    st.nitems = st.g.ntiles * st.g.splits;
+    return MMTG_OK;
+}
+
+extern "C" int mmtg_decode_stage_attn(void* stages_host, int index, const float* part, int splits, const float* bias, void* kcache,
+                                      void* vcache, const int* keep, long ldkeep, const int* pos_ptr, void* out, int B, int nH, int dh, int Tmax) {
+    MMTG_REQUIRE(stages_host && index >= 0, "decode_stage_attn: null descriptor buffer");
+    MMTG_REQUIRE(part && bias && kcache && vcache && keep && pos_ptr && out, "decode_stage_attn: null pointer");
+    MMTG_REQUIRE(dh == 64 && B > 0 && nH > 0 && Tmax > 0 && Tmax <= 1024 && splits >= 1 && splits <= 4,
+                 "decode_stage_attn: head dim 64, Tmax <= 1024, at most 4 c_attn slabs");
+    PStage& st = reinterpret_cast<PStage*>(stages_host)[index];
+    memset(&st, 0, sizeof(st));
+    st.kind = 3;
+    st.nitems = B * nH;
+    DaArgs& a = st.a;
+    a.part = part; a.bias = bias; a.kc = (bf16*)kcache; a.vc = (bf16*)vcache; a.keep = keep; a.pos_ptr = pos_ptr; a.out = (bf16*)out;
+    a.ldkeep = ldkeep; a.slab = (long)B * 3 * nH * 64; a.splits = splits; a.B = B; a.nH = nH; a.Tmax = Tmax;
+    MMTG_REQUIRE((long)splits * a.slab * 4 < 0x7FFFFF00L, "decode_stage_attn: slabs must stay below 2 GiB");
+    return MMTG_OK;
+}
+
+static unsigned long long* g_ps_trace = nullptr;
+extern "C" int mmtg_decode_persist_trace(void* buf) {      // u64 [2 * stages + 1] or null (diagnostic; tools/decode_persist_timeline.py)
+    g_ps_trace = (unsigned long long*)buf;
+    return MMTG_OK;
+}
+static int g_ps_wpc = 0;            // workgroups per CU of the build in use (set by mmtg_decode_persist_grid)
+extern "C" int mmtg_decode_persist_grid(void) {
+    static int grid = -1;
+    if (grid < 0) {
+        static const int env = getenv("MMTG_DECODE_PERSIST_WGS") ? atoi(getenv("MMTG_DECODE_PERSIST_WGS")) : 0;
+        const int want = env == 2 ? 2 : 3;
+        const void* fn = want == 3 ? (const void*)decode_persist_kernel<3> : (const void*)decode_persist_kernel<2>;
+        const int lds = want == 3 ? ps_lds<3>() : ps_lds<2>();
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return 0;
+        int per = 0, dev = 0;
+        hipDeviceProp_t prop;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, fn, 256, lds) != hipSuccess) return 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+        // (the API can report one block per CU more than the hardware admits near an SGPR edge, MI355X_MICROARCH.md: never plan on
+        //  more than the build was made for, and the bounded polls turn a wrong guess into an error, not a hang)
+        if (per > want) per = want;
+        if (per < 1) return 0;
+        g_ps_wpc = want;
+        grid = per * prop.multiProcessorCount;
+    }
+    return grid;
+}
+
+extern "C" int mmtg_decode_persist(const void* stages_dev, int nstages, void* barrier_ws, long barrier_bytes, int* err_flag, void* stream) {
+    MMTG_REQUIRE(stages_dev && nstages > 0 && barrier_ws && err_flag, "decode_persist: null pointer");
+    MMTG_REQUIRE(barrier_bytes >= 4096 && MMTG_ALIGNED16(barrier_ws), "decode_persist: the barrier workspace is 4096 zero-initialised bytes");
+    const int grid = mmtg_decode_persist_grid();
+    MMTG_REQUIRE(grid >= 8, "decode_persist: the persistent kernel does not fit this device");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(MMTG_PROF_DECODE, s, 0.0, 0.0);
+    if (g_ps_wpc == 3)
+        hipLaunchKernelGGL(decode_persist_kernel<3>, dim3(grid), dim3(256), ps_lds<3>(), s, (const PStage*)stages_dev, nstages, (unsigned long long*)barrier_ws, err_flag, g_ps_trace);
+    else
+        hipLaunchKernelGGL(decode_persist_kernel<2>, dim3(grid), dim3(256), ps_lds<2>(), s, (const PStage*)stages_dev, nstages, (unsigned long long*)barrier_ws, err_flag, g_ps_trace);
+    MMTG_LAUNCH_CHECK("decode_persist");
     return MMTG_OK;
 }

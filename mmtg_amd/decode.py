@@ -118,6 +118,20 @@ class GreedyDecoder:
                 self.folds_for = None
                 # (MMTG_DECODE_EMBED_IN_PROJ=0: projector_layer2 and the embedding add as two launches, the round-3 v8 step)
                 self.embed_in_proj = os.environ.get("MMTG_DECODE_EMBED_IN_PROJ", "1") != "0" and H % 8 == 0
+                # Round 4, persistent token step (OPT-IN, MMTG_DECODE_PERSIST=1): the twelve blocks and the head as ONE launch
+                # (mmtg_decode_persist) instead of 61 -- stage lists built once per (head / no head, position slot), a device-wide
+                # barrier between stages, agent-scope hand-offs.  Bit-equal to the per-launch fused step (tests/test_decode_gpu.py)
+                # and measured SLOWER: 873 (2 workgroups per CU) / 921 us (3) against 720 us per token step at batch 256 -- a barrier
+                # is 2.2-3 us against the ~4 us of a launch boundary, but every stage still pays its dependent memory round trips
+                # (activations now from beyond the L2: agent-scope loads), and the attention stage loses its 32-waves-per-CU
+                # memory-level parallelism (profiles/r04_v2_decode_persistent_*).  The default stays the per-launch step.
+                # (not for lanes: several persistent kernels side by side cannot all be resident)
+                self.persist = (_parent is None and os.environ.get("MMTG_DECODE_PERSIST", "0") == "1" and max(self.splits[1], self.splits[3]) <= 4
+                                and self.splits[0] <= 4 and hip.decode_persist_grid() >= 8)
+                if self.persist:
+                    self.bar = torch.zeros(512, dtype=torch.int64, device=dev)          # 4096 bytes, owned by the kernel from here on
+                    self.err = torch.zeros(1, dtype=torch.int32, device=dev)
+                    self.stage_lists = {}
         self.pos, self.pos_next = self.pos_pair
         self.uniforms = None
         self.graphs = {}
@@ -275,6 +289,43 @@ class GreedyDecoder:
         wf, c, b = self.fh
         hip.ln_fold_weights(eng.Wp("wte"), eng.P(pre + "ln_f.weight"), eng.P(pre + "ln_f.bias"), None, wf, c, b, eng.layout.Vpad, D)
 
+    def _stage_list(self, hcur, hnext, with_head):
+        """The launches of _layers_fused as a stage list of the persistent kernel (same operands, same order)."""
+        eng, sh, B = self.eng, self.eng.sh, self.B
+        D = sh.D
+        pre = "decoder.gpt2.transformer."
+        sq, sp, _, s2 = self.splits
+        NP = D // 32
+        kper = -(-(-(-D // sq)) // 64) * 64
+        nslab = -(-D // kper)
+        x, xo = hcur, hnext
+        st, sto = self.st
+        sl = hip.DecodeStages(5 * sh.L + 1)
+        for l in range(sh.L):
+            p = f"{pre}h.{l}."
+            wf, c, bq = self.fq[l]
+            sl.gemm(1, x, wf, self.part, B, 3 * D, D, colsum=c, stats_in=st, np_in=NP, eps=sh.eps, out_f32=True, splits=sq)
+            sl.attn(self.part, nslab, bq, self.kc[l], self.vc[l], self.keep, self.pos, self.ctx, B, sh.nH, 64, self.Tmax)
+            sl.gemm(2, self.ctx, eng.Wt(p + "attn.c_proj.weight"), xo, B, D, D, bias=eng.P(p + "attn.c_proj.bias"), resid=x,
+                    stats_out=sto, splits=sp, ws=self.rws, counters=self.rcnt)
+            wf, c, bfc = self.ffc[l]
+            sl.gemm(0, xo, wf, self.g, B, 4 * D, D, bias=bfc, colsum=c, stats_in=sto, np_in=NP, eps=sh.eps, act=hip.EPI_GELU)
+            sl.gemm(2, self.g, eng.Wt(p + "mlp.c_proj.weight"), x, B, D, 4 * D, bias=eng.P(p + "mlp.c_proj.bias"), resid=xo,
+                    stats_out=st, splits=s2, ws=self.rws, counters=self.rcnt)
+        if with_head:
+            wf, c, bh = self.fh
+            sl.gemm(0, x, wf, self.logits, B, eng.layout.Vpad, D, bias=bh, colsum=c, stats_in=st, np_in=NP, eps=sh.eps, out_f32=True)
+        return sl.upload(eng.dev)
+
+    def check_persist(self):
+        """Raises if a barrier of the persistent kernel ran into its time bound (not every workgroup was resident): the step's
+        outputs are then undefined.  Re-arms the decoder (one host read; ``generate`` calls it once per generation)."""
+        if getattr(self, "persist", False) and int(self.err.item()) != 0:
+            self.bar.zero_()
+            self.err.zero_()
+            raise RuntimeError("persistent decode step: a device-wide barrier timed out (workgroups not co-resident); "
+                               "set MMTG_DECODE_PERSIST=0 or MMTG_DECODE_PERSIST_WGS=2")
+
     def _layers_fused(self, hcur, hnext, with_head):
         """bf16 fused path: per block c_attn (LN-fold, split-K slabs summed by the attention kernel) -> attention -> attn c_proj
         (split-K reduced in the kernel + bias + residual + statistics) -> c_fc (LN-fold + GELU) -> mlp c_proj (as c_proj); the
@@ -283,6 +334,13 @@ class GreedyDecoder:
         eng, sh, B = self.eng, self.eng.sh, self.B
         D = sh.D
         pre = "decoder.gpt2.transformer."
+        if getattr(self, "persist", False):
+            key = (with_head, self.pos.data_ptr())
+            sl = self.stage_lists.get(key)
+            if sl is None:
+                sl = self.stage_lists[key] = self._stage_list(hcur, hnext, with_head)
+            hip.decode_persist(sl, self.bar, self.err)
+            return
         sq, sp, _, s2 = self.splits
         NP = D // 32
         kper = -(-(-(-D // sq)) // 64) * 64          # K slices are whole 64-deep tiles: the product writes ceil(D / kper) slabs
@@ -331,6 +389,9 @@ class GreedyDecoder:
         return how + (", %d row blocks of %d side by side" % (self.lanes, self.B // self.lanes) if self.lanes > 1 else "")
 
     def kernel_name(self):
+        if getattr(self, "persist", False):
+            return ("decode token step: decode_persist_kernel -- the twelve blocks and the head as one persistent launch (64x64 weight-"
+                    "streaming tiles + KV-cache streaming, 61 stages behind a two-level device-wide barrier, agent-scope hand-offs)")
         if getattr(self, "fused", False):
             return ("decode token step: decode_gemm_kernel<64x64> weight streaming (split-K reduced in the kernel, LayerNorm applied "
                     "algebraically) + decode_attn KV-cache streaming, 5 graph nodes per block")
@@ -338,16 +399,11 @@ class GreedyDecoder:
                 if self.fast else "decode token step: training-side kernels per layer")
 
     @torch.no_grad()
-    def generate(self, batch, length, temperature=1.0, repitition_penalty=1.0, top_k=1, top_p=0.0, generator=None,
-                 use_graph=None, teacher=None, tap=None):
-        """batch: dict with topic_ids/tpw_* [B,P], topic_emb, img_embs, r_embs (no targets needed).
-        Runs `length` iterations of the reference loop and returns the lyric ids
-        [B, 1 + length] (column 0 is the initial [#START#]).  top_k = 1, top_p = 0 is the greedy setting;
-        anything else samples on the device (generate.py:137-141): one uniform per row and position is drawn
-        from `generator` (a CUDA torch.Generator; default: the global one) before the steps are replayed.
-        Parity hooks (tests/test_decode_gpu.py): `teacher` [B, 1 + length] long -- after every step the token the step
-        appended is replaced by teacher[:, j] wherever that is >= 0 (teacher forcing on a reference id list; the step's own
-        pick is handed to `tap` first); `tap(j, with_head, picked [B], logits [B, Vpad] or None)` is called after every step."""
+    def begin(self, batch, length, temperature=1.0, repitition_penalty=1.0, top_k=1, top_p=0.0, generator=None):
+        """Everything of a generation that happens once: the settings, the uniforms of a stochastic run, fresh weight copies /
+        LayerNorm folds, the experience encoder, the prompt and the reset position.  Returns the number of token steps;
+        ``step_at(pos)`` for pos = 0 .. n - 1 then runs them (``generate`` does both; tools/decode_lanes_threads.py drives
+        several decoders' steps from their own threads and streams)."""
         eng, sh = self.eng, self.eng.sh
         B = batch["img_embs"].shape[0]
         if B != self.B:
@@ -379,22 +435,45 @@ class GreedyDecoder:
         self.tpw_mask.copy_(batch["tpw_attention_mask"].to(eng.dev).long())
         self.keep.zero_()
         self.pos_all.zero_()
-        n_steps = sh.P + length                                 # positions 0 .. P+length-1 are consumed
+        return sh.P + length                                    # positions 0 .. P+length-1 are consumed
+
+    def step_at(self, pos):
+        """Token step `pos` of the generation ``begin`` prepared; returns whether the step called the model's head."""
+        sh = self.eng.sh
+        j = pos + 1 - sh.P                                      # lyric index appended after this step
+        forced = j < 1 or (j > 1 and (j + 1) % (sh.msl + 2) in (0, 1))
+        self._run_step(with_head=not forced, parity=pos & 1)
+        return not forced
+
+    @torch.no_grad()
+    def generate(self, batch, length, temperature=1.0, repitition_penalty=1.0, top_k=1, top_p=0.0, generator=None,
+                 use_graph=None, teacher=None, tap=None):
+        """batch: dict with topic_ids/tpw_* [B,P], topic_emb, img_embs, r_embs (no targets needed).
+        Runs `length` iterations of the reference loop and returns the lyric ids
+        [B, 1 + length] (column 0 is the initial [#START#]).  top_k = 1, top_p = 0 is the greedy setting;
+        anything else samples on the device (generate.py:137-141): one uniform per row and position is drawn
+        from `generator` (a CUDA torch.Generator; default: the global one) before the steps are replayed.
+        Parity hooks (tests/test_decode_gpu.py): `teacher` [B, 1 + length] long -- after every step the token the step
+        appended is replaced by teacher[:, j] wherever that is >= 0 (teacher forcing on a reference id list; the step's own
+        pick is handed to `tap` first); `tap(j, with_head, picked [B], logits [B, Vpad] or None)` is called after every step."""
+        n_steps = self.begin(batch, length, temperature, repitition_penalty, top_k, top_p, generator)
+        eng, sh = self.eng, self.eng.sh
         saved_mode = self.use_graph
         if use_graph is not None:
             self.use_graph = use_graph
         try:
             for pos in range(n_steps):
-                j = pos + 1 - sh.P                                  # lyric index appended after this step
-                forced = j < 1 or (j > 1 and (j + 1) % (sh.msl + 2) in (0, 1))
-                self._run_step(with_head=not forced, parity=pos & 1)
+                with_head = self.step_at(pos)
+                j = pos + 1 - sh.P                                  # lyric index appended by this step
                 if tap is not None:
-                    tap(j, not forced, self.seq[:, pos + 1].clone(), self.logits if not forced and not self.children else None)
+                    tap(j, with_head, self.seq[:, pos + 1].clone(), self.logits if with_head and not self.children else None)
                 if teacher is not None and 0 <= j <= length:
                     col = teacher[:, j].to(eng.dev)
                     self.seq[:, pos + 1] = torch.where(col >= 0, col, self.seq[:, pos + 1])
         finally:
             self.use_graph = saved_mode
+        for d in ([self] + self.children):
+            d.check_persist()
         return self.seq[:, sh.P:sh.P + 1 + length].clone()
 
     @staticmethod

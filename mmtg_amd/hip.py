@@ -13,7 +13,7 @@ import os
 import torch
 
 F32, BF16 = 0, 1
-ABI_VERSION = 5
+ABI_VERSION = 6
 EPI_NONE, EPI_GELU, EPI_TANH, EPI_RESID, EPI_DGELU, EPI_DTANH, EPI_ATOMIC, EPI_ROWDOT = range(8)
 GEMM_NO_TR, GEMM_REGSTAGE, GEMM_SKINNY, GEMM_NO_SKINNY, GEMM_WIDE, GEMM_NO_WIDE = 1, 2, 4, 8, 16, 32
 GEMM_PERSIST, GEMM_NO_PERSIST, GEMM_ROW_ORDER, GEMM_OCC4, GEMM_NO_OCC4, GEMM_COL_BLOCK, GEMM_P256, GEMM_NO_P8, GEMM_P8 = 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384
@@ -78,6 +78,12 @@ _SIGS = {
     "mmtg_decode_gemm": ([_i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _vp, _vp, _vp, _i, _f, _i, _i, _vp, _l, _vp, _i, _vp, _l, _vp, _l,
                           _vp, _vp, _vp, _vp, _vp], _i),
     "mmtg_ln_fold_weights": ([_vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp], _i),
+    "mmtg_decode_stage_bytes": ([], _l),
+    "mmtg_decode_stage_gemm": ([_vp, _i, _i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _vp, _vp, _vp, _i, _f, _i, _i, _vp, _l, _vp, _i, _vp, _l, _vp, _l], _i),
+    "mmtg_decode_stage_attn": ([_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _l, _vp, _vp, _i, _i, _i, _i], _i),
+    "mmtg_decode_persist_grid": ([], _i),
+    "mmtg_decode_persist_trace": ([_vp], _i),
+    "mmtg_decode_persist": ([_vp, _i, _vp, _l, _vp, _vp], _i),
     "mmtg_decode_attn": ([_i, _vp, _vp, _vp, _vp, _l, _vp, _vp, _i, _i, _i, _i, _vp], _i),
     "mmtg_decode_attn_split": ([_i, _vp, _i, _vp, _vp, _vp, _vp, _l, _vp, _vp, _i, _i, _i, _i, _vp], _i),
     "mmtg_logits_process_sample": ([_vp, _l, _i, _vp, _l, _vp, _f, _f, _i, _f, _vp, _vp, _vp, _i, _vp], _i),
@@ -484,6 +490,54 @@ def decode_gemm(mode, A, W, C_, M, N, K, bias=None, colsum=None, stats_in=None, 
                                   int(out_f32), _p(resid), N if ldr is None else ldr, _p(stats_out), int(splits), _p(ws),
                                   0 if ws is None else ws.numel(), _p(counters), 0 if counters is None else counters.numel(),
                                   _p(emb_pos), _p(emb_type), _p(type_ids), _p(pos), _stream()), "decode_gemm")
+
+
+class DecodeStages:
+    """Host-side stage list of the persistent token step (include/mmtg_hip.h, mmtg_decode_persist): append the stages with the
+    argument lists of the launches they replace, then ``upload(device)`` once."""
+
+    def __init__(self, capacity):
+        self.nbytes = int(lib().mmtg_decode_stage_bytes())
+        self.buf = C.create_string_buffer(self.nbytes * capacity)
+        self.capacity, self.n = capacity, 0
+        self.keep = []          # the tensors whose addresses the descriptors hold stay alive with the list
+
+    def gemm(self, mode, A, W, C_, M, N, K, bias=None, colsum=None, stats_in=None, np_in=0, eps=1e-5, act=EPI_NONE, out_f32=False,
+             resid=None, stats_out=None, splits=1, ws=None, counters=None, ldc=None):
+        assert self.n < self.capacity
+        _check(lib().mmtg_decode_stage_gemm(C.addressof(self.buf), self.n, int(mode), M, N, K, _p(A), K, _p(W), K, _p(C_),
+                                            N if ldc is None else ldc, _p(bias), _p(colsum), _p(stats_in), int(np_in), float(eps), int(act),
+                                            int(out_f32), _p(resid), N, _p(stats_out), int(splits), _p(ws), 0 if ws is None else ws.numel(),
+                                            _p(counters), 0 if counters is None else counters.numel()), "decode_stage_gemm")
+        self.keep += [A, W, C_, bias, colsum, stats_in, resid, stats_out, ws, counters]
+        self.n += 1
+
+    def attn(self, part, splits, bias, kcache, vcache, keep, pos, out, B, nH, dh, Tmax):
+        assert self.n < self.capacity
+        _check(lib().mmtg_decode_stage_attn(C.addressof(self.buf), self.n, _p(part), int(splits), _p(bias), _p(kcache), _p(vcache), _p(keep),
+                                            keep.stride(0), _p(pos), _p(out), B, nH, dh, Tmax), "decode_stage_attn")
+        self.keep += [part, bias, kcache, vcache, keep, pos, out]
+        self.n += 1
+
+    def upload(self, device):
+        import numpy as np
+        host = np.frombuffer(self.buf, dtype=np.uint8, count=self.nbytes * self.n).copy()
+        self.dev = torch.from_numpy(host).to(device)
+        return self
+
+
+def decode_persist_grid():
+    return int(lib().mmtg_decode_persist_grid())
+
+
+def decode_persist_trace(buf=None):
+    _check(lib().mmtg_decode_persist_trace(_p(buf)), "decode_persist_trace")
+
+
+def decode_persist(stages, barrier_ws, err_flag):
+    """One launch for all the stages of a DecodeStages list (uploaded)."""
+    _check(lib().mmtg_decode_persist(_p(stages.dev), stages.n, _p(barrier_ws), barrier_ws.numel() * barrier_ws.element_size(), _p(err_flag),
+                                     _stream()), "decode_persist")
 
 
 def ln_fold_weights(W, gamma, beta, bias, Wf, colsum, bias_f, N, K, ldw=None):
