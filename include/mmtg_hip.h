@@ -148,8 +148,11 @@ MMTG_API int mmtg_splitk_finish(int dtype, const float* part, int splits, int M,
                        int epi, const void* aux, long ldaux, void* out, long ldo,
                        const float* ln_gamma, const float* ln_beta, void* ln_out, float eps, void* stream);
 
-/* column sums: out[n] += sum_m X[m,n]  (bias gradients), X of `dtype`, out f32 */
-MMTG_API int mmtg_colsum(int dtype, const void* X, long ldx, int M, int N, float* out, void* stream);
+/* column sums: out[n] += sum_m X[m,n]  (bias gradients), X of `dtype`, out f32.  Round 4: summed in a FIXED order -- one workgroup
+ * owns 64 columns and walks all the rows; inputs above 2048 rows go through row slices in `ws` first -- so the result is bit-identical
+ * run to run (the round-1 kernel finished with fp32 atomics from ~1000 workgroups). */
+MMTG_API long mmtg_colsum_ws(int M, int N);      /* workspace floats mmtg_colsum needs for M rows (0: none) */
+MMTG_API int mmtg_colsum(int dtype, const void* X, long ldx, int M, int N, float* out, float* ws, long ws_floats, void* stream);
 
 /* ---------------------------------------------------------------- LayerNorm
  * torch.nn.LayerNorm (model.py:380-382) and GPT-2's ln_1/ln_2/ln_f.          */
@@ -179,8 +182,9 @@ MMTG_API int mmtg_attn_fwd(int dtype, const void* qkv, const int* keep, void* ou
  * MMTG_EPI_ROWDOT does it for free); dq32: [B*T, D] f32 scratch (zeroed by the call);
  * dqkv: [B*T, 3*D] output; dbias (optional): f32 [3*D] += column sums of dqkv as stored (the
  * c_attn bias gradient, from the workgroups that produce each head's columns); dbias_ws (optional
- * scratch, f32 [B * ceil(T / key block)][3*D], key block = 256 bf16 / 128 f32): partial rows that the
- * call sums into dbias -- without it the workgroups use atomics on dbias (slower: contended).       */
+ * scratch, f32 [B * ceil(T / key block) + 44][3*D], key block = 256 bf16 / 128 f32): partial rows that the
+ * call sums into dbias in a fixed order (the 44 spare rows: workspace of the tiled kernels' column sum of dQ) --
+ * without it the workgroups use atomics on dbias (slower: contended, and not reproducible bit for bit).       */
 /* diagnostic: per-wave timeline of the whole-head forward kernel (bf16, T <= 256): buf = u64 [B*nH*8][8]
  * (s_memrealtime at entry / loads issued / first chunk landed / long tile done / stored / exit, XCC id, valid) or NULL */
 MMTG_API int mmtg_attn_trace(void* buf);
@@ -203,9 +207,13 @@ MMTG_API int mmtg_segment_sum(int dtype, const void* g, void* out, int B, int P,
  * (GPT2Model.forward via model.py:282-288).  In place on g allowed.           */
 MMTG_API int mmtg_embed_add(int dtype, const void* g, const void* wpe, const void* wte, const long long* type_ids,
                    void* h, int M, int T, int D, unsigned drop_thresh, unsigned drop_seed, void* stream);
-/* backward: dwpe[t,:] += sum_b dh[b,t,:]; dwte[type,:] += sum dh; (dh masked in place if dropout) */
+/* backward: dwpe[t,:] += sum_b dh[b,t,:]; dwte[type,:] += sum dh; (dh masked in place if dropout).  ws (optional, f32,
+ * mmtg_embed_add_bwd_ws(M, D, ntypes) floats): per-row-block bins of the token-type rows, summed in a fixed order (round 4:
+ * bit-reproducible); without it the bins end in fp32 atomics on dwte. */
+MMTG_API long mmtg_embed_add_bwd_ws(int M, int D, int ntypes);
 MMTG_API int mmtg_embed_add_bwd(int dtype, void* dh, const long long* type_ids, float* dwpe, float* dwte,
-                       int M, int T, int D, int ntypes, unsigned drop_thresh, unsigned drop_seed, void* stream);
+                       int M, int T, int D, int ntypes, unsigned drop_thresh, unsigned drop_seed, float* ws, long ws_floats,
+                       void* stream);
 /* elementwise dropout mask application (backward of a fused-epilogue dropout) */
 MMTG_API int mmtg_dropout_apply(int dtype, const void* x, void* y, long n, int N, unsigned drop_thresh,
                        unsigned drop_seed, void* stream);
@@ -273,10 +281,13 @@ MMTG_API int mmtg_alpha_attn_bwd(int dtype, const void* qkv, const float* prior,
 MMTG_API int mmtg_beta_fuse_fwd(int dtype, const void* topic, const void* img, const void* txt,
                        const float* att_w, const float* att_b, void* o, float* a,
                        int B, int S, int H, void* stream);
+MMTG_API long mmtg_beta_fuse_bwd_ws(int B, int S, int H);
+/* ws (optional, f32, mmtg_beta_fuse_bwd_ws floats): per-(b, step) contributions to d att_w / d att_b, summed over b in a fixed
+ * order, d topic by its single owner (round 4: bit-reproducible); without it the round-1 fp32 atomics. */
 MMTG_API int mmtg_beta_fuse_bwd(int dtype, const void* topic, const void* img, const void* txt,
                        const float* att_w, const float* a, const void* d_o,
                        float* dtopic, void* dimg, void* dtxt, float* datt_w, float* datt_b,
-                       int B, int S, int H, void* stream);
+                       int B, int S, int H, float* ws, long ws_floats, void* stream);
 
 /* Software prefetch (no counterpart in the reference): streams `bytes` of `src` through the cache hierarchy with
  * `workgroups` workgroups of 16-byte loads so that they sit in the 256 MB Infinity Cache when the next kernel of the
@@ -288,8 +299,10 @@ MMTG_API int mmtg_prefetch(const void* src, long bytes, int workgroups, void* si
 MMTG_API int mmtg_zero_ranges(float* base, const long* desc, int n, void* stream);
 
 /* ---------------------------------------------------------------- optimizer (train.py:194-197)
- * sumsq: *out += sum x^2 (global grad-norm partial).                          */
-MMTG_API int mmtg_sumsq(const float* x, long n, float* out, void* stream);
+ * sumsq: *out = sum x^2 (global grad-norm), one partial per workgroup in `ws` (mmtg_sumsq_ws(n) floats) + an ordered final sum:
+ * bit-reproducible (round 4; the round-1 kernel added ~2000 partials to *out with fp32 atomics).                          */
+MMTG_API long mmtg_sumsq_ws(long n);
+MMTG_API int mmtg_sumsq(const float* x, long n, float* out, float* ws, long ws_floats, void* stream);
 /* clip (coef = min(1, max_norm / (sqrt(*normsq) + 1e-6))) + transformers.AdamW
  * (bias-corrected, eps outside the sqrt, decoupled wd) + optional bf16 copy.
  * count (optional, device scalar): g holds a SUM over rows and *count the global row count

@@ -914,31 +914,45 @@ __device__ __forceinline__ void bwd_small_keys_store(const BwdKeys& st, int t, i
                     bk[dt][r] += sk;
                     bv[dt][r] += sv;
                 } else {
+                    // (register-capped build: the 16 key lanes' sum lands in every lane; lane l15 = 4 dt + r keeps the running
+                    //  sum of ITS channel in bk[0][0] / bv[0][0] -- two registers instead of 32, no LDS atomics)
 #pragma unroll
                     for (int o = 1; o < 16; o <<= 1) { sk += __shfl_xor(sk, o, 64); sv += __shfl_xor(sv, o, 64); }
-                    if (l15 == 0) {
-                        atomicAdd(sB + dt * 16 + 4 * g + r, sk);
-                        atomicAdd(sB + DH + dt * 16 + 4 * g + r, sv);
-                    }
+                    if (l15 == dt * 4 + r) { bk[0][0] += sk; bv[0][0] += sv; }
                 }
             }
     }
 }
-// the wave's accumulated bias sums: one reduction over the 16 key lanes, one LDS add per (channel, wave)
-__device__ __forceinline__ void bwd_small_bias_flush(const f32x4 (&bk)[4], const f32x4 (&bv)[4], float* sB, int lane) {
+// The waves' accumulated bias sums -> sB, in WAVE ORDER (round 4): wave w adds its values in phase w of NW barrier-separated
+// phases (plain LDS read-modify-writes: one wave per phase, one lane per channel), so the column sums -- the c_attn bias
+// gradient -- come out bit-identical run to run; the LDS float atomics they replace added in arrival order.  Called by every
+// thread of the workgroup (barriers inside).  ACC: full accumulators (one shuffle reduction over the 16 key lanes first);
+// otherwise the compact per-lane form of bwd_small_keys_store.
+template <bool ACC, int NW>
+__device__ __forceinline__ void bwd_small_bias_flush(const f32x4 (&bk)[4], const f32x4 (&bv)[4], float* sB, int lane, int wave, bool work) {
     const int g = lane >> 4, l15 = lane & 15;
+    // every wave first folds its sums over the 16 key lanes (all waves at once); lane l15 = 4 dt + r keeps channel (dt, r)
+    float ck = bk[0][0], cv = bv[0][0];
+    if constexpr (ACC) {
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
+        for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float sk = bk[dt][r], sv = bv[dt][r];
+            for (int r = 0; r < 4; ++r) {
+                float sk = bk[dt][r], sv = bv[dt][r];
 #pragma unroll
-            for (int o = 1; o < 16; o <<= 1) { sk += __shfl_xor(sk, o, 64); sv += __shfl_xor(sv, o, 64); }
-            if (l15 == 0) {
-                atomicAdd(sB + dt * 16 + 4 * g + r, sk);
-                atomicAdd(sB + DH + dt * 16 + 4 * g + r, sv);
+                for (int o = 1; o < 16; o <<= 1) { sk += __shfl_xor(sk, o, 64); sv += __shfl_xor(sv, o, 64); }
+                if (l15 == dt * 4 + r) { ck = sk; cv = sv; }
             }
+    }
+    const int ch = (l15 >> 2) * 16 + 4 * g + (l15 & 3);
+#pragma unroll 1
+    for (int w = 0; w < NW; ++w) {          // ... then one LDS read-modify-write per lane, wave after wave
+        if (wave == w && work) {
+            sB[ch] += ck;
+            sB[DH + ch] += cv;
         }
+        __syncthreads();
+    }
 }
 
 // NW waves per workgroup: 8 (two workgroups = 16 waves per CU, <= 128 VGPRs) or 4 (two workgroups = 8 waves per CU, up to
@@ -1047,8 +1061,7 @@ __global__ __launch_bounds__(64 * NW, (NW / (MT == 256 ? 2 : 4))) void attn_bwd_
         }
     }
     if (dbias) {
-        if constexpr (BACC) bwd_small_bias_flush(bk, bv, sB, lane);
-        __syncthreads();
+        bwd_small_bias_flush<BACC, NW>(bk, bv, sB, lane, wave, true);
         // this kernel owns the K and V parts of head h's columns: one partial row per batch row
         // (bias_rows: plain stores into row b of the scratch; otherwise atomics onto the gradient)
         if (tid < 2 * DH) {
@@ -1120,8 +1133,10 @@ __device__ __forceinline__ void bwd_small_queries_store(const f32x4 (&dq)[4], in
             for (int r = 0; r < 4; ++r) bq[dt][r] += qok ? (float)(bf16)dq[dt][r] : 0.f;
     }
 }
-__device__ __forceinline__ void bwd_small_bias_flush_q(const f32x4 (&bq)[4], float* sB, int lane) {
+template <int NW>
+__device__ __forceinline__ void bwd_small_bias_flush_q(const f32x4 (&bq)[4], float* sB, int lane, int wave, bool work) {
     const int g = lane >> 4, l15 = lane & 15;
+    float cq = 0.f;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
@@ -1129,8 +1144,14 @@ __device__ __forceinline__ void bwd_small_bias_flush_q(const f32x4 (&bq)[4], flo
             float sq = bq[dt][r];
 #pragma unroll
             for (int o = 1; o < 16; o <<= 1) sq += __shfl_xor(sq, o, 64);
-            if (l15 == 0) atomicAdd(sB + dt * 16 + 4 * g + r, sq);
+            if (l15 == dt * 4 + r) cq = sq;
         }
+    const int ch = (l15 >> 2) * 16 + 4 * g + (l15 & 3);
+#pragma unroll 1
+    for (int w = 0; w < NW; ++w) {          // wave order: see bwd_small_bias_flush
+        if (wave == w && work) sB[ch] += cq;
+        __syncthreads();
+    }
 }
 
 template <bool DROP, int MT = 256>
@@ -1218,8 +1239,7 @@ __global__ __launch_bounds__(2 * MT, 4) void attn_bwd_small_q_kernel(const bf16*
         }
     }
     if (dbias) {
-        if (work) bwd_small_bias_flush_q(bq, sB, lane);
-        __syncthreads();
+        bwd_small_bias_flush_q<NW>(bq, sB, lane, wave, work);
         if (tid < DH) {         // the Q part of head h's columns
             const int col = h * DH + tid;
             if (bias_rows) dbias[(long)b * 3 * D + col] = sB[tid];
@@ -1308,7 +1328,7 @@ extern "C" int mmtg_attn_fwd(int dtype, const void* qkv, const int* keep, void* 
     return MMTG_OK;
 }
 
-extern "C" int mmtg_colsum(int dtype, const void* X, long ldx, int M, int N, float* out, void* stream);
+extern "C" int mmtg_colsum(int dtype, const void* X, long ldx, int M, int N, float* out, float* ws, long ws_floats, void* stream);
 
 extern "C" int mmtg_attn_bwd(int dtype, const void* qkv, const int* keep, const void* out, const void* dout,
                              const float* lse, float* delta, int delta_ready, float* dq32, void* dqkv, float* dbias, float* dbias_ws,
@@ -1401,9 +1421,11 @@ extern "C" int mmtg_attn_bwd(int dtype, const void* qkv, const int* keep, const 
     // (the whole-head kernels write ONE partial bias row per batch row and leave nothing to the dQ column pass)
     const int nkb_ = small_path ? 1 : cdiv(T, dtype == MMTG_F32 ? 4 * AT<float>::KPW : 4 * AT<bf16>::KPW);
     if (bias_rows) {
-        int rc = mmtg_colsum(MMTG_F32, dbias_ws, 3L * D, B * nkb_, 3 * D, dbias, stream);
+        int rc = mmtg_colsum(MMTG_F32, dbias_ws, 3L * D, B * nkb_, 3 * D, dbias, nullptr, 0, stream);      // (few rows: one ordered pass)
         if (rc) return rc;
     }
-    if (dbias && nkb_ > 1) return mmtg_colsum(dtype, dqkv, 3L * D, (int)rows, D, dbias, stream);
+    // (tall: its slices go into the 44 spare rows behind the partial bias rows of dbias_ws -- mmtg_attn_bwd's contract)
+    if (dbias && nkb_ > 1)
+        return mmtg_colsum(dtype, dqkv, 3L * D, (int)rows, D, dbias, dbias_ws ? dbias_ws + (long)B * nkb_ * 3 * D : nullptr, dbias_ws ? 44L * 3 * D : 0, stream);
     return MMTG_OK;
 }

@@ -712,13 +712,20 @@ __global__ __launch_bounds__(256) void decode_embed_add_kernel(const T* __restri
 // even assembled from the c_attn slabs -- they depend on nothing this kernel computes -- so a step with a short prefix costs one
 // memory round trip instead of three dependent ones (slabs -> scores -> values).  Branch-free: rows at or past `pos` are
 // requested from the last valid row and replaced afterwards (key == pos: the token's own row, held in LDS exactly as stored).
+// The KV cache rows are read once per token step and never again by this step: with `nt` (non-temporal) they need not displace the
+// step's 193 MB of weights from the 256 MB Infinity Cache, which every step re-reads (A/B: MMTG_DECODE_KV_NT, profiles/r04_*).
+template <typename V, bool NT> __device__ __forceinline__ V ld_kv(const V* p) {
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+
 // bytes of LDS one (b, head) item needs: scores, key flags, q (f32), this token's k and v
 template <typename T> constexpr int da_lds_bytes() { return 1024 * 4 + 1024 * 4 + 64 * 4 + 2 * 64 * (int)sizeof(T); }
 
 // COH = false: one 64-thread workgroup per (b, head) (__syncthreads() = that wave).  COH = true: one WAVE of a persistent
 // workgroup per item -- the wave's LDS operations complete in order, so its "barrier" is a drain of its own counters -- with the
 // c_attn slabs read and the context row stored through agent-scope accesses (they cross workgroups with only a grid barrier between).
-template <typename T, bool COH>
+template <typename T, bool COH, bool NT = false>
 __device__ __forceinline__ void da_body(const T* __restrict__ qkv, T* __restrict__ kc, T* __restrict__ vc,
         const int* __restrict__ keep, long ldkeep, const int pos, T* __restrict__ out, const int B,
         int nH, int Tmax, const float* __restrict__ part, int splits, long slab, const float* __restrict__ bias,
@@ -745,8 +752,8 @@ __device__ __forceinline__ void da_body(const T* __restrict__ qkv, T* __restrict
 #pragma unroll
     for (int u = 0; u < UN0; ++u) {
         const int key = u * KPI + kg, kr = key < pos ? key : last;
-        kv0[u] = *reinterpret_cast<const V*>(kbase + (long)kr * 64 + oc * EPL);
-        vv0[u] = *reinterpret_cast<const V*>(vbase + (long)kr * 64 + oc * EPL);
+        kv0[u] = ld_kv<V, NT>(reinterpret_cast<const V*>(kbase + (long)kr * 64 + oc * EPL));
+        vv0[u] = ld_kv<V, NT>(reinterpret_cast<const V*>(vbase + (long)kr * 64 + oc * EPL));
     }
     // the key-padding flags of the whole prefix in one coalesced pass, into LDS (round 3: the score loop used to read keep[]
     // from global memory key group by key group -- up to 16 DEPENDENT 4-byte loads, each a full memory round trip)
@@ -826,7 +833,7 @@ __device__ __forceinline__ void da_body(const T* __restrict__ qkv, T* __restrict
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int key = k0 + u * KPI + kg;
-            kv[u] = *reinterpret_cast<const V*>(kbase + (long)(key < nkeys ? key : pos) * 64 + oc * EPL);
+            kv[u] = ld_kv<V, NT>(reinterpret_cast<const V*>(kbase + (long)(key < nkeys ? key : pos) * 64 + oc * EPL));
         }
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
@@ -871,7 +878,7 @@ __device__ __forceinline__ void da_body(const T* __restrict__ qkv, T* __restrict
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int key = k0 + u * KPI + kg;
-            vv[u] = *reinterpret_cast<const V*>(vbase + (long)(key < nkeys ? key : pos) * 64 + oc * EPL);
+            vv[u] = ld_kv<V, NT>(reinterpret_cast<const V*>(vbase + (long)(key < nkeys ? key : pos) * 64 + oc * EPL));
             pp[u] = key < nkeys ? sp[key] : 0.f;
         }
 #pragma unroll
@@ -895,12 +902,12 @@ __device__ __forceinline__ void da_body(const T* __restrict__ qkv, T* __restrict
 #undef DA_SYNC
 }
 
-template <typename T>
+template <typename T, bool NT = false>
 __global__ __launch_bounds__(64) void decode_attn_kernel(const T* __restrict__ qkv, T* __restrict__ kc, T* __restrict__ vc,
         const int* __restrict__ keep, long ldkeep, const int* __restrict__ pos_ptr, T* __restrict__ out,
         int nH, int Tmax, const float* __restrict__ part, int splits, long slab, const float* __restrict__ bias) {
     __shared__ __attribute__((aligned(16))) char lds[da_lds_bytes<T>()];
-    da_body<T, false>(qkv, kc, vc, keep, ldkeep, *pos_ptr, out, (int)gridDim.y, nH, Tmax, part, splits, slab, bias,
+    da_body<T, false, NT>(qkv, kc, vc, keep, ldkeep, *pos_ptr, out, (int)gridDim.y, nH, Tmax, part, splits, slab, bias,
                       (int)blockIdx.x, (int)blockIdx.y, (int)threadIdx.x, lds);
 }
 
@@ -1120,9 +1127,11 @@ extern "C" int mmtg_decode_attn_split(int dtype, const float* part, int splits, 
     const long slab = (long)B * 3 * nH * 64;
     if (dtype == MMTG_F32)
         hipLaunchKernelGGL(decode_attn_kernel<float>, grid, block, 0, s, (const float*)nullptr, (float*)kcache, (float*)vcache, keep, ldkeep, pos_ptr, (float*)out, nH, Tmax, part, splits, slab, bias);
-    else if (dtype == MMTG_BF16)
-        hipLaunchKernelGGL(decode_attn_kernel<bf16>, grid, block, 0, s, (const bf16*)nullptr, (bf16*)kcache, (bf16*)vcache, keep, ldkeep, pos_ptr, (bf16*)out, nH, Tmax, part, splits, slab, bias);
-    else MMTG_FAIL(MMTG_ERR_BAD_ARG, "decode_attn_split: bad dtype");
+    else if (dtype == MMTG_BF16) {
+        static const bool kv_nt = !getenv("MMTG_DECODE_KV_NT") || atoi(getenv("MMTG_DECODE_KV_NT")) != 0;      // default on (700 vs 721 us per token step; =0 for the A/B)
+        if (kv_nt) hipLaunchKernelGGL((decode_attn_kernel<bf16, true>), grid, block, 0, s, (const bf16*)nullptr, (bf16*)kcache, (bf16*)vcache, keep, ldkeep, pos_ptr, (bf16*)out, nH, Tmax, part, splits, slab, bias);
+        else hipLaunchKernelGGL(decode_attn_kernel<bf16>, grid, block, 0, s, (const bf16*)nullptr, (bf16*)kcache, (bf16*)vcache, keep, ldkeep, pos_ptr, (bf16*)out, nH, Tmax, part, splits, slab, bias);
+    } else MMTG_FAIL(MMTG_ERR_BAD_ARG, "decode_attn_split: bad dtype");
     MMTG_LAUNCH_CHECK("decode_attn_split");
     return MMTG_OK;
 }

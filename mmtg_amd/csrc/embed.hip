@@ -90,7 +90,8 @@ __global__ __launch_bounds__(256) void embed_dwpe_kernel(const T* __restrict__ d
 // dwte[type,d] += sum_m [type_ids[m]==type] dh[m,d]; per-block LDS bins then atomics
 template <typename T>
 __global__ __launch_bounds__(256) void embed_dwte_kernel(const T* __restrict__ dh, const long long* __restrict__ type_ids,
-                                                         float* __restrict__ dwte, int M, int D, int ntypes, int rows_per_block) {
+                                                         float* __restrict__ dwte, int M, int D, int ntypes, int rows_per_block,
+                                                         float* __restrict__ ws) {
     extern __shared__ float bins[];  // [ntypes][256]
     const int d = blockIdx.x * 256 + threadIdx.x;
     for (int k = 0; k < ntypes; ++k) bins[k * 256 + threadIdx.x] = 0.f;
@@ -102,7 +103,8 @@ __global__ __launch_bounds__(256) void embed_dwte_kernel(const T* __restrict__ d
         }
         for (int k = 0; k < ntypes; ++k) {
             const float v = bins[k * 256 + threadIdx.x];
-            if (v != 0.f) atomicAdd(dwte + (long)k * D + d, v);
+            if (ws) ws[((long)blockIdx.y * ntypes + k) * D + d] = v;        // row block's bins: summed in order by the second stage
+            else if (v != 0.f) atomicAdd(dwte + (long)k * D + d, v);
         }
     }
 }
@@ -188,8 +190,12 @@ extern "C" int mmtg_dropout_apply(int dtype, const void* x, void* y, long n, int
     return MMTG_OK;
 }
 
+extern "C" int mmtg_colsum(int dtype, const void* X, long ldx, int M, int N, float* out, float* ws, long ws_floats, void* stream);
+extern "C" long mmtg_embed_add_bwd_ws(int M, int D, int ntypes) { return (long)cdiv(M, 128) * ntypes * D; }
+
 extern "C" int mmtg_embed_add_bwd(int dtype, void* dh, const long long* type_ids, float* dwpe, float* dwte,
-                                  int M, int T, int D, int ntypes, unsigned drop_thresh, unsigned drop_seed, void* stream) {
+                                  int M, int T, int D, int ntypes, unsigned drop_thresh, unsigned drop_seed, float* ws, long ws_floats,
+                                  void* stream) {
     MMTG_REQUIRE(M > 0 && T > 0 && M % T == 0 && D > 0 && ntypes > 0 && ntypes <= 32 && dh && type_ids && dwpe && dwte,
                  "embed_add_bwd: bad args");
     hipStream_t s = (hipStream_t)stream;
@@ -204,11 +210,16 @@ extern "C" int mmtg_embed_add_bwd(int dtype, void* dh, const long long* type_ids
     const int rpb = 128;
     dim3 g2(cdiv(D, 256), cdiv(M, rpb));
     const size_t shm = (size_t)ntypes * 256 * sizeof(float);
+    // token-type rows of wte: per-row-block bins -> workspace -> ordered sum over the row blocks (round 4: no fp32 atomics, the
+    // gradient is reproducible bit for bit); without a workspace the round-1 atomics remain
+    MMTG_REQUIRE(!ws || (ws_floats >= mmtg_embed_add_bwd_ws(M, D, ntypes) && D % 4 == 0), "embed_add_bwd: workspace of %ld floats required",
+                 mmtg_embed_add_bwd_ws(M, D, ntypes));
 #define K_(T_, ...)                                                                                                   \
     hipLaunchKernelGGL(embed_dwpe_kernel<T_>, g1, block, 0, s, (const T_*)dh, dwpe, M / T, T, D);                      \
-    hipLaunchKernelGGL(embed_dwte_kernel<T_>, g2, block, shm, s, (const T_*)dh, type_ids, dwte, M, D, ntypes, rpb)
+    hipLaunchKernelGGL(embed_dwte_kernel<T_>, g2, block, shm, s, (const T_*)dh, type_ids, dwte, M, D, ntypes, rpb, ws)
     DISPATCH(dtype, K_, 0)
 #undef K_
     MMTG_LAUNCH_CHECK("embed_add_bwd");
+    if (ws) return mmtg_colsum(MMTG_F32, ws, (long)ntypes * D, cdiv(M, rpb), ntypes * D, dwte, nullptr, 0, stream);
     return MMTG_OK;
 }

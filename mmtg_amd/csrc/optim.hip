@@ -19,7 +19,20 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
     a = wave_sum(a);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = a;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(out, sh[0] + sh[1] + sh[2] + sh[3]);
+    // round 4: one partial per workgroup (plain store) + an ordered final sum instead of ~2000 fp32 atomics on one word -- the
+    // norm, and through the clip coefficient every parameter, is reproducible bit for bit
+    if (threadIdx.x == 0) out[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// out[0] = sum of the n partials in a fixed order (thread t: partials t, t + 256, ...; then lanes, then waves)
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restrict__ part, int n, float* __restrict__ out) {
+    __shared__ float sh[4];
+    float a = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) a += part[i];
+    a = wave_sum(a);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = sh[0] + sh[1] + sh[2] + sh[3];
 }
 
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
@@ -191,11 +204,16 @@ extern "C" int mmtg_zero_ranges(float* base, const long* desc, int n, void* stre
     return MMTG_OK;
 }
 
-extern "C" int mmtg_sumsq(const float* x, long n, float* out, void* stream) {
+extern "C" long mmtg_sumsq_ws(long n) { return (long)grid_for(n / 4 + 1); }
+
+extern "C" int mmtg_sumsq(const float* x, long n, float* out, float* ws, long ws_floats, void* stream) {
     MMTG_REQUIRE(x && out && n > 0 && MMTG_ALIGNED16(x), "sumsq: bad args");
+    const int g = grid_for(n / 4 + 1);
+    MMTG_REQUIRE(ws && ws_floats >= g, "sumsq: workspace of %d floats required (mmtg_sumsq_ws)", g);
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(MMTG_PROF_OPTIM, s, 2.0 * n, 4.0 * n);
-    hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, s, x, n, out);
+    hipLaunchKernelGGL(sumsq_kernel, dim3(g), dim3(256), 0, s, x, n, ws);
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, s, (const float*)ws, g, out);
     MMTG_LAUNCH_CHECK("sumsq");
     return MMTG_OK;
 }

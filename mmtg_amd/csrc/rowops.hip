@@ -540,6 +540,80 @@ __global__ __launch_bounds__(256, (8 * A + 4 * B <= 8 ? 4 : 8 * A + 4 * B <= 12 
 #undef LN3_COL
 }
 
+// Deterministic column sums (round 4).  Every reduction over rows that ends in a gradient tensor -- LayerNorm gains / biases,
+// the Conv1D / Linear bias gradients, the token-type embedding rows -- used to finish with fp32 atomics from many workgroups
+// (order = arrival order: the 123 tensors that differed in their last bits run to run).  Now ONE workgroup owns 64 columns and
+// sums ALL the rows in a fixed order: 16 row lanes stride the rows (eight independent loads in flight each), their partial sums
+// are added in lane order through LDS, and the single writer adds the result to (or stores it into) the destination.
+//   rows r = 0 .. M - 1 at X + r * ldx (+ col0); dst[c] (+)= sum_r X[r][c]
+template <typename T>
+__device__ __forceinline__ void colsum_rows_block(const T* __restrict__ X, long ldx, int M, int N, float* __restrict__ dst, int accumulate,
+                                                  int cb, float (*red)[64]) {
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;          // 64 columns x 16 row lanes
+    const int c = cb * 64 + cl;
+    float a = 0.f;
+    if (c < N) {
+        int r = rl;
+        for (; r + 7 * 16 < M; r += 8 * 16) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = (float)X[(long)(r + 16 * u) * ldx + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a += v[u];
+        }
+        for (; r < M; r += 16) a += (float)X[(long)r * ldx + c];
+    }
+    red[rl][cl] = a;
+    __syncthreads();
+    if (rl == 0 && c < N) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][cl];
+        dst[c] = accumulate ? dst[c] + t : t;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(1024) void colsum_rows_kernel(const T* __restrict__ X, long ldx, int M, int N, float* __restrict__ out, int accumulate) {
+    __shared__ float red[16][64];
+    colsum_rows_block<T>(X, ldx, M, N, out, accumulate, blockIdx.x, red);
+}
+
+// stage 1 of a tall column sum (M in the thousands: too long a serial walk for one workgroup per 64 columns): slice s of the rows
+// -> row s of the workspace (plain stores); stage 2 is colsum_rows_kernel over the slices
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_slices_kernel(const T* __restrict__ X, long ldx, int M, int N, float* __restrict__ ws, int rows_per_block) {
+    __shared__ float red[4][256];
+    const int cq = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = (blockIdx.x * 64 + cq) * 4;
+    const int r0 = blockIdx.y * rows_per_block;
+    const int r1 = min(M, r0 + rows_per_block);
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c < N) {
+        for (int r = r0 + rl; r < r1; r += 4) {
+            float v[4];
+            ld4<T>(X + (long)r * ldx + c, v);
+            a[0] += v[0]; a[1] += v[1]; a[2] += v[2]; a[3] += v[3];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[rl][cq * 4 + e] = a[e];
+    __syncthreads();
+    const int cc = blockIdx.x * 256 + threadIdx.x;
+    if (cc < N) ws[(long)blockIdx.y * N + cc] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// LayerNorm backward, second stage: the per-workgroup partial rows [nblocks][3][cols] (dgamma | dbeta | column sum) -> the three
+// gradients, one workgroup per (64 columns, quantity), fixed order
+__global__ __launch_bounds__(1024) void ln_bwd_finalize_det_kernel(const float* __restrict__ ws, int nblocks, int cols,
+        float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dcol) {
+    __shared__ float red[16][64];
+    const int q = blockIdx.y;
+    float* dst = q == 0 ? dgamma : q == 1 ? dbeta : dcol;
+    if (!dst) return;
+    colsum_rows_block<float>(ws + (long)q * cols, 3L * cols, nblocks, cols, dst, 1, blockIdx.x, red);
+}
+
 // grid (cols/64, 3): block = 64 columns x 4 row groups of one quantity (dgamma / dbeta / colsum)
 __global__ __launch_bounds__(256) void ln_bwd_finalize_kernel(const float* __restrict__ ws, int nblocks, int cols,
         float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dcol) {
@@ -786,24 +860,42 @@ extern "C" int mmtg_layernorm_bwd(int dtype, const void* dy, const void* x, cons
         else
             hipLaunchKernelGGL(ln_bwd_kernel<bf16>, grid, block, 0, s, (const bf16*)dy, (const bf16*)x, gamma, mean, rstd, (const bf16*)dres, (bf16*)dx, (bf16*)dx_masked, ws, rows, cols, want, drop_thresh, drop_seed, ik);
     }
-    hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3(cdiv(cols, 64), 3, 16), dim3(256), 0, s, ws, nb, cols, dgamma, dbeta, dcolsum);
+    static const bool fin_atomic = getenv("MMTG_LN_FINALIZE_ATOMIC") != nullptr;      // A/B: the round-1 z-sliced finalize (fp32 atomics)
+    if (fin_atomic) hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3(cdiv(cols, 64), 3, 16), dim3(256), 0, s, ws, nb, cols, dgamma, dbeta, dcolsum);
+    else hipLaunchKernelGGL(ln_bwd_finalize_det_kernel, dim3(cdiv(cols, 64), 3), dim3(1024), 0, s, ws, nb, cols, dgamma, dbeta, dcolsum);
     MMTG_LAUNCH_CHECK("layernorm_bwd");
     return MMTG_OK;
 }
 
-extern "C" int mmtg_colsum(int dtype, const void* X, long ldx, int M, int N, float* out, void* stream) {
-    MMTG_REQUIRE(M > 0 && N > 0 && N % 4 == 0 && ldx % 4 == 0, "colsum: N=%d, ldx=%ld must be multiples of 4", N, ldx);
+// rows above which the sum runs in two stages (slices -> workspace -> ordered sum of the slices)
+constexpr int COLSUM_TALL = 2048, COLSUM_SLICES = 128;
+extern "C" long mmtg_colsum_ws(int M, int N) { return M > COLSUM_TALL ? (long)COLSUM_SLICES * N : 0; }
+
+extern "C" int mmtg_colsum(int dtype, const void* X, long ldx, int M, int N, float* out, float* ws, long ws_floats, void* stream) {
+    MMTG_REQUIRE(M > 0 && N > 0 && (M <= COLSUM_TALL || (N % 4 == 0 && ldx % 4 == 0)), "colsum: N=%d, ldx=%ld must be multiples of 4 above %d rows", N, ldx, COLSUM_TALL);
     MMTG_REQUIRE(X && out, "colsum: null pointer");
+    MMTG_REQUIRE(dtype == MMTG_F32 || dtype == MMTG_BF16, "colsum: bad dtype");
     hipStream_t s = (hipStream_t)stream;
     const double esz = dtype == MMTG_F32 ? 4 : 2;
     ProfScope prof(MMTG_PROF_MISC, s, (double)M * N, esz * M * N);
-    // ~1024 blocks whatever the shape (a [236, 3072] band matrix used to get 12 blocks: 16 us)
-    const int row_blocks = max(1, 1024 / cdiv(N, 256));
-    const int rpb = max(16, (cdiv(M, row_blocks) + 3) & ~3);
-    dim3 grid(cdiv(N, 256), cdiv(M, rpb)), block(256);
-    if (dtype == MMTG_F32) hipLaunchKernelGGL(colsum_kernel<float>, grid, block, 0, s, (const float*)X, ldx, M, N, out, rpb);
-    else if (dtype == MMTG_BF16) hipLaunchKernelGGL(colsum_kernel<bf16>, grid, block, 0, s, (const bf16*)X, ldx, M, N, out, rpb);
-    else MMTG_FAIL(MMTG_ERR_BAD_ARG, "colsum: bad dtype");
+    if (M <= COLSUM_TALL) {
+        if (dtype == MMTG_F32) hipLaunchKernelGGL(colsum_rows_kernel<float>, dim3(cdiv(N, 64)), dim3(1024), 0, s, (const float*)X, ldx, M, N, out, 1);
+        else hipLaunchKernelGGL(colsum_rows_kernel<bf16>, dim3(cdiv(N, 64)), dim3(1024), 0, s, (const bf16*)X, ldx, M, N, out, 1);
+    } else if (!ws) {
+        // (no workspace: the round-1 kernel -- row slices end in fp32 atomics; correct, not bit-reproducible)
+        const int row_blocks = max(1, 1024 / cdiv(N, 256));
+        const int rpb = max(16, (cdiv(M, row_blocks) + 3) & ~3);
+        dim3 grid(cdiv(N, 256), cdiv(M, rpb)), block(256);
+        if (dtype == MMTG_F32) hipLaunchKernelGGL(colsum_kernel<float>, grid, block, 0, s, (const float*)X, ldx, M, N, out, rpb);
+        else hipLaunchKernelGGL(colsum_kernel<bf16>, grid, block, 0, s, (const bf16*)X, ldx, M, N, out, rpb);
+    } else {
+        MMTG_REQUIRE(ws_floats >= mmtg_colsum_ws(M, N), "colsum: %d rows need a workspace of %ld floats (mmtg_colsum_ws)", M, mmtg_colsum_ws(M, N));
+        const int rpb = (cdiv(M, COLSUM_SLICES) + 3) & ~3, nsl = cdiv(M, rpb);
+        dim3 grid(cdiv(N, 256), nsl), block(256);
+        if (dtype == MMTG_F32) hipLaunchKernelGGL(colsum_slices_kernel<float>, grid, block, 0, s, (const float*)X, ldx, M, N, ws, rpb);
+        else hipLaunchKernelGGL(colsum_slices_kernel<bf16>, grid, block, 0, s, (const bf16*)X, ldx, M, N, ws, rpb);
+        hipLaunchKernelGGL(colsum_rows_kernel<float>, dim3(cdiv(N, 64)), dim3(1024), 0, s, (const float*)ws, (long)N, nsl, N, out, 1);
+    }
     MMTG_LAUNCH_CHECK("colsum");
     return MMTG_OK;
 }

@@ -1024,8 +1024,10 @@ class Engine:
         elif _WGRAD_STREAM and pr > 0 and getattr(self, "_side", None) is not None:
             torch.cuda.current_stream().wait_stream(self._side)  # (only the tied embedding's gradient ran on the side stream)
         # ---- GPT-2 input embedding: h0 = drop(g + wpe + wte[type])
+        nty = min(32, sh.V)
         hip.embed_add_bwd(dx, a["type_ids"], self.G(pre + "wpe.weight"), self.G(pre + "wte.weight"), M, T, D,
-                          min(32, sh.V), drop_p=pe, drop_seed=a["seed"])
+                          nty, drop_p=pe, drop_seed=a["seed"],
+                          ws=self.buf("embed_bwd_ws", (int(hip.lib().mmtg_embed_add_bwd_ws(M, D, nty)),), torch.float32))
         self._ready("wpe")
         # ---- projector (model.py:279-281)
         dh1 = self.buf("d_h1", (M, H))
@@ -1154,8 +1156,7 @@ class Engine:
 
     # ---------------------------------------------------------------- optimizer (train.py:194-197)
     def grad_norm_sq(self):
-        self.normsq.zero_()
-        hip.sumsq(self.grad, self.layout.total, self.normsq)
+        hip.sumsq(self.grad, self.layout.total, self.normsq)        # (written, in a fixed order: no memset, no atomics)
         return self.normsq
 
     def adamw_step(self, lr, max_norm=1.0, betas=(0.9, 0.999), eps=1e-6, wd=0.0, grad_scale=1.0, clip=True, count=None):

@@ -38,7 +38,8 @@ _SIGS = {
     "mmtg_gemm": ([_i, _i, _i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _vp, _i, _vp, _l, _vp, _i, _f, _i, _u, _u, _i, _vp], _i),
     "mmtg_gemm_gather": ([_i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _vp, _i, _vp, _i, _vp, _l, _vp, _i, _vp], _i),
     "mmtg_splitk_finish": ([_i, _vp, _i, _i, _i, _l, _vp, _i, _vp, _l, _vp, _l, _vp, _vp, _vp, _f, _vp], _i),
-    "mmtg_colsum": ([_i, _vp, _l, _i, _i, _vp, _vp], _i),
+    "mmtg_colsum": ([_i, _vp, _l, _i, _i, _vp, _vp, _l, _vp], _i),
+    "mmtg_colsum_ws": ([_i, _i], _l),
     "mmtg_layernorm_fwd": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp], _i),
     "mmtg_layernorm_bwd_ws": ([_i, _i], _l),
     "mmtg_layernorm_bwd": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _u, _u, _vp, _vp, _l, _vp], _i),
@@ -48,7 +49,8 @@ _SIGS = {
     "mmtg_embed_condition": ([_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
     "mmtg_segment_sum": ([_i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp], _i),
     "mmtg_embed_add": ([_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _u, _u, _vp], _i),
-    "mmtg_embed_add_bwd": ([_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _u, _u, _vp], _i),
+    "mmtg_embed_add_bwd": ([_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _u, _u, _vp, _l, _vp], _i),
+    "mmtg_embed_add_bwd_ws": ([_i, _i, _i], _l),
     "mmtg_dropout_apply": ([_i, _vp, _vp, _l, _i, _u, _u, _vp], _i),
     "mmtg_loss_fwd": ([_i, _vp, _l, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp], _i),
     "mmtg_loss_bwd": ([_i, _i, _vp, _l, _i, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _i, _vp, _l, _i, _vp], _i),
@@ -60,10 +62,12 @@ _SIGS = {
     "mmtg_alpha_attn_fwd": ([_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp], _i),
     "mmtg_alpha_attn_bwd": ([_i, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _vp], _i),
     "mmtg_beta_fuse_fwd": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp], _i),
-    "mmtg_beta_fuse_bwd": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp], _i),
+    "mmtg_beta_fuse_bwd": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _l, _vp], _i),
+    "mmtg_beta_fuse_bwd_ws": ([_i, _i, _i], _l),
     "mmtg_prefetch": ([_vp, _l, _i, _vp, _vp], _i),
     "mmtg_zero_ranges": ([_vp, _vp, _i, _vp], _i),
-    "mmtg_sumsq": ([_vp, _l, _vp, _vp], _i),
+    "mmtg_sumsq": ([_vp, _l, _vp, _vp, _l, _vp], _i),
+    "mmtg_sumsq_ws": ([_l], _l),
     "mmtg_adamw": ([_vp, _vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _i, _vp, _f, _f, _vp, _vp], _i),
     "mmtg_cast_f32_to": ([_i, _vp, _vp, _l, _vp], _i),
     "mmtg_cast_pad_rows": ([_i, _vp, _l, _vp, _l, _i, _i, _vp], _i),
@@ -239,8 +243,19 @@ def splitk_finish(part, splits, M, N, out, bias=None, epi=EPI_NONE, aux=None, ld
                                     float(eps), _stream()), "splitk_finish")
 
 
-def colsum(X, M, N, out, ldx=None):
-    _check(lib().mmtg_colsum(dt(X), _p(X), N if ldx is None else ldx, M, N, _p(out), _stream()), "colsum")
+_colsum_ws = {}
+
+
+def colsum(X, M, N, out, ldx=None, ws=None):
+    """out[n] += sum_m X[m, n], in a fixed order (no atomics).  Tall inputs (mmtg_colsum_ws(M, N) > 0) sum in two stages through
+    `ws`; the engine hands over its own, other callers get a cached one."""
+    need = int(lib().mmtg_colsum_ws(M, N))
+    if need and (ws is None or ws.numel() < need):
+        key = (X.device, need)
+        ws = _colsum_ws.get(key)
+        if ws is None:
+            ws = _colsum_ws[key] = torch.empty(need, device=X.device, dtype=torch.float32)
+    _check(lib().mmtg_colsum(dt(X), _p(X), N if ldx is None else ldx, M, N, _p(out), _p(ws) if need else 0, need, _stream()), "colsum")
 
 
 # ------------------------------------------------------------------ LayerNorm
@@ -283,8 +298,9 @@ def attn_trace(buf):
 
 
 def attn_bwd_bias_rows(B, T, dtype_code):
-    """Rows of the dbias_ws scratch of attn_bwd ([rows, 3*D] f32)."""
-    return B * (-(-T // (128 if dtype_code == F32 else 256)))
+    """Rows of the dbias_ws scratch of attn_bwd ([rows, 3*D] f32): one partial bias row per (batch row, key block) + 44 rows the
+    tiled kernels' ordered column sum of dQ uses as its workspace."""
+    return B * (-(-T // (128 if dtype_code == F32 else 256))) + 44
 
 
 # ------------------------------------------------------------------ conditioning front end
@@ -302,9 +318,18 @@ def embed_add(g, wpe, wte, type_ids, h, M, T, D, drop_p=0.0, drop_seed=0):
                                 drop_thresh(drop_p), drop_seed & 0xFFFFFFFF, _stream()), "embed_add")
 
 
-def embed_add_bwd(dh, type_ids, dwpe, dwte, M, T, D, ntypes, drop_p=0.0, drop_seed=0):
+_embed_ws = {}
+
+
+def embed_add_bwd(dh, type_ids, dwpe, dwte, M, T, D, ntypes, drop_p=0.0, drop_seed=0, ws=None):
+    need = int(lib().mmtg_embed_add_bwd_ws(M, D, ntypes))
+    if ws is None or ws.numel() < need:     # (the engine passes its own workspace; tests get a cached one)
+        key = (dh.device, need)
+        ws = _embed_ws.get(key)
+        if ws is None:
+            ws = _embed_ws[key] = torch.empty(need, device=dh.device, dtype=torch.float32)
     _check(lib().mmtg_embed_add_bwd(dt(dh), _p(dh), _p(type_ids), _p(dwpe), _p(dwte), M, T, D, ntypes,
-                                    drop_thresh(drop_p), drop_seed & 0xFFFFFFFF, _stream()), "embed_add_bwd")
+                                    drop_thresh(drop_p), drop_seed & 0xFFFFFFFF, _p(ws), ws.numel(), _stream()), "embed_add_bwd")
 
 
 def dropout_apply(x, y, n, drop_p, drop_seed):
@@ -378,8 +403,9 @@ def beta_fuse_fwd(topic, img, txt, att_w, att_b, o, a, B, S, H):
 
 
 def beta_fuse_bwd(topic, img, txt, att_w, a, d_o, dtopic, dimg, dtxt, datt_w, datt_b, B, S, H):
+    ws = torch.empty(int(lib().mmtg_beta_fuse_bwd_ws(B, S, H)), device=d_o.device, dtype=torch.float32)       # 0.7 MB at the released sizes
     _check(lib().mmtg_beta_fuse_bwd(dt(topic), _p(topic), _p(img), _p(txt), _p(att_w), _p(a), _p(d_o), _p(dtopic),
-                                    _p(dimg), _p(dtxt), _p(datt_w), _p(datt_b), B, S, H, _stream()), "beta_fuse_bwd")
+                                    _p(dimg), _p(dtxt), _p(datt_w), _p(datt_b), B, S, H, _p(ws), ws.numel(), _stream()), "beta_fuse_bwd")
 
 
 # ------------------------------------------------------------------ optimizer / casts
@@ -389,8 +415,17 @@ def prefetch(t, sink, workgroups=256, stream=None):
                                _stream() if stream is None else stream.cuda_stream), "prefetch")
 
 
+_sumsq_ws = {}
+
+
 def sumsq(x, n, out):
-    _check(lib().mmtg_sumsq(_p(x), n, _p(out), _stream()), "sumsq")
+    """out[0] = sum of squares of x[:n] (written, not accumulated), in a fixed summation order."""
+    need = int(lib().mmtg_sumsq_ws(n))
+    key = (x.device, need)
+    ws = _sumsq_ws.get(key)
+    if ws is None:
+        ws = _sumsq_ws[key] = torch.empty(need, device=x.device, dtype=torch.float32)
+    _check(lib().mmtg_sumsq(_p(x), n, _p(out), _p(ws), need, _stream()), "sumsq")
 
 
 def adamw(p, g, m, v, p_bf16, n, lr, beta1, beta2, eps, wd, step, normsq, max_norm, grad_scale=1.0, count=None):

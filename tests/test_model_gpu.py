@@ -957,3 +957,31 @@ def test_single_experience_step_vs_oracle(enc):
         assert float((p.grad.cpu() - r).abs().max()) <= 2e-3 * float(r.abs().max()) + 1e-8 * total, k
         if "weight_hh" in k:
             assert float(p.grad.abs().max()) == 0.0 and float(r.abs().max()) == 0.0, k
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+def test_training_step_is_bit_reproducible(dtype):
+    """Round 4: no reduction of the backward ends in floating-point atomics any more -- LayerNorm gains / biases, every bias
+    gradient (LayerNorm-fused column sums, dGELU bands, the attention kernels' rows), the token-type embedding rows, the fuser's
+    step weights and d topic, and the global gradient norm are summed in a fixed order -- so two trainers started from the same
+    state on the same batch with the same dropout seed produce the SAME gradient buffer and the SAME parameters after two clip +
+    AdamW steps, bit for bit (stage-1 filter and dropout on; allocator history perturbed between the runs).  The full-size run
+    of the same check: tools/determinism_probe.py (profiles/r04_*determinism*)."""
+    from ddp_worker import build as build_small
+    from mmtg_amd import synth
+    grads, params = [], []
+    for rep in range(2):
+        model, mcfg, dcfg, V = build_small(dtype, 0.1, torch.device("cuda", 0))
+        tr = MMTGTrainer(model, lr=1e-3, alpha=0.2)
+        tr.eng.drop_seed = 4242
+        nb = synth.make_batch(12, mcfg, dcfg, V, seed=7)
+        batch = {k: torch.from_numpy(np.asarray(v)).to(DEV) for k, v in nb.items()}
+        if rep:
+            junk = torch.randn(16 << 20, device=DEV)      # a different allocator / cache history
+        tr.step(batch, stage=1)
+        grads.append(tr.eng.grad.detach().clone())
+        tr.step(batch, stage=3)
+        torch.cuda.synchronize()
+        params.append(model.engine().master.detach().clone())
+    assert torch.equal(grads[0], grads[1]), int((grads[0] != grads[1]).sum())
+    assert torch.equal(params[0], params[1]), int((params[0] != params[1]).sum())
