@@ -284,53 +284,55 @@ __global__ __launch_bounds__(64) void beta_fwd_kernel(const T* __restrict__ topi
     if (lane == 0) { a_out[r * 3] = e0; a_out[r * 3 + 1] = e1; a_out[r * 3 + 2] = e2; }
 }
 
-// Backward of the fuser.  One wave per batch row walks its S steps: d topic (the sum over the steps) stays in registers and is
-// written by its single owner; the per-(b, step) contributions to the step's weight row / bias go to a workspace
-// [B][S*H] | [B][S] that the host sums over b in a fixed order (round 4: no fp32 atomics -- att_matrices, topic_fc and
-// ln_layer1 gradients are reproducible bit for bit).  ws == null keeps the round-1 atomics (grid = B x S waves).
+// Backward of the fuser.  ws != null (round 4, the engine's form): one workgroup of S waves per batch row, wave i = step i; d topic
+// -- the sum over the steps -- is folded through LDS in step order and written by its single owner; the per-(b, step)
+// contributions to the step's weight row / bias go to a workspace [B][S*H] | [B][S] that the host sums over b in a fixed order:
+// no fp32 atomics, so the att_matrices, topic_fc and ln_layer1 gradients are reproducible bit for bit.  ws == null keeps the
+// round-1 form (grid = B x S single-wave workgroups, atomics).
 template <typename T>
-__global__ __launch_bounds__(64) void beta_bwd_kernel(const T* __restrict__ topic, const T* __restrict__ img,
+__global__ __launch_bounds__(1024) void beta_bwd_kernel(const T* __restrict__ topic, const T* __restrict__ img,
         const T* __restrict__ txt, const float* __restrict__ att_w, const float* __restrict__ a_in,
         const T* __restrict__ d_o, float* __restrict__ dtopic, T* __restrict__ dimg, T* __restrict__ dtxt,
         float* __restrict__ datt_w, float* __restrict__ datt_b, int B, int S, int H, float* __restrict__ ws) {
-    const int lane = threadIdx.x;
+    extern __shared__ float sdt[];           // [S][H] (ws form)
+    const int lane = threadIdx.x & 63;
     const int b = ws ? blockIdx.x : blockIdx.x / S;
-    const int i_lo = ws ? 0 : blockIdx.x % S, i_hi = ws ? S : i_lo + 1;
-    float tv[BF_MAXC], dt_acc[BF_MAXC];
+    const int i = ws ? (int)(threadIdx.x >> 6) : blockIdx.x % S;
+    const long r = (long)b * S + i;
+    const float a0 = a_in[r * 3], a1 = a_in[r * 3 + 1], a2 = a_in[r * 3 + 2];
+    float tv[BF_MAXC], iv[BF_MAXC], xv[BF_MAXC], dv[BF_MAXC];
+    float d0 = 0.f, d1 = 0.f, d2 = 0.f;
     int n = 0;
-    for (int c = lane; c < H; c += 64, ++n) { tv[n] = (float)topic[(long)b * H + c]; dt_acc[n] = 0.f; }
-    for (int i = i_lo; i < i_hi; ++i) {
-        const long r = (long)b * S + i;
-        const float a0 = a_in[r * 3], a1 = a_in[r * 3 + 1], a2 = a_in[r * 3 + 2];
-        float iv[BF_MAXC], xv[BF_MAXC], dv[BF_MAXC];
-        float d0 = 0.f, d1 = 0.f, d2 = 0.f;
-        n = 0;
-        for (int c = lane; c < H; c += 64, ++n) {
-            iv[n] = (float)img[r * H + c];
-            xv[n] = (float)txt[r * H + c];
-            dv[n] = (float)d_o[r * H + c];
-            d0 += dv[n] * tv[n]; d1 += dv[n] * iv[n]; d2 += dv[n] * xv[n];
-        }
-        d0 = wave_sum(d0); d1 = wave_sum(d1); d2 = wave_sum(d2);
-        const float dot = a0 * d0 + a1 * d1 + a2 * d2;
-        const float ds0 = a0 * (d0 - dot), ds1 = a1 * (d1 - dot), ds2 = a2 * (d2 - dot);
-        n = 0;
-        for (int c = lane; c < H; c += 64, ++n) {
-            const float w = att_w[i * H + c];
-            const float gt = a0 * dv[n] + ds0 * w, gw = ds0 * tv[n] + ds1 * iv[n] + ds2 * xv[n];
-            dimg[r * H + c] = (T)(a1 * dv[n] + ds1 * w);
-            dtxt[r * H + c] = (T)(a2 * dv[n] + ds2 * w);
-            if (ws) { dt_acc[n] += gt; ws[((long)b * S + i) * H + c] = gw; }
-            else { atomicAdd(dtopic + (long)b * H + c, gt); atomicAdd(datt_w + i * H + c, gw); }
-        }
-        if (lane == 0) {
-            if (ws) ws[(long)B * S * H + (long)b * S + i] = ds0 + ds1 + ds2;
-            else atomicAdd(datt_b + i, ds0 + ds1 + ds2);
-        }
+    for (int c = lane; c < H; c += 64, ++n) {
+        tv[n] = (float)topic[(long)b * H + c];
+        iv[n] = (float)img[r * H + c];
+        xv[n] = (float)txt[r * H + c];
+        dv[n] = (float)d_o[r * H + c];
+        d0 += dv[n] * tv[n]; d1 += dv[n] * iv[n]; d2 += dv[n] * xv[n];
+    }
+    d0 = wave_sum(d0); d1 = wave_sum(d1); d2 = wave_sum(d2);
+    const float dot = a0 * d0 + a1 * d1 + a2 * d2;
+    const float ds0 = a0 * (d0 - dot), ds1 = a1 * (d1 - dot), ds2 = a2 * (d2 - dot);
+    n = 0;
+    for (int c = lane; c < H; c += 64, ++n) {
+        const float w = att_w[i * H + c];
+        const float gt = a0 * dv[n] + ds0 * w, gw = ds0 * tv[n] + ds1 * iv[n] + ds2 * xv[n];
+        dimg[r * H + c] = (T)(a1 * dv[n] + ds1 * w);
+        dtxt[r * H + c] = (T)(a2 * dv[n] + ds2 * w);
+        if (ws) { sdt[i * H + c] = gt; ws[((long)b * S + i) * H + c] = gw; }
+        else { atomicAdd(dtopic + (long)b * H + c, gt); atomicAdd(datt_w + i * H + c, gw); }
+    }
+    if (lane == 0) {
+        if (ws) ws[(long)B * S * H + (long)b * S + i] = ds0 + ds1 + ds2;
+        else atomicAdd(datt_b + i, ds0 + ds1 + ds2);
     }
     if (ws) {
-        n = 0;
-        for (int c = lane; c < H; c += 64, ++n) dtopic[(long)b * H + c] += dt_acc[n];
+        __syncthreads();
+        for (int c = threadIdx.x; c < H; c += blockDim.x) {
+            float t = 0.f;
+            for (int k = 0; k < S; ++k) t += sdt[k * H + c];
+            dtopic[(long)b * H + c] += t;
+        }
     }
 }
 
@@ -481,8 +483,10 @@ extern "C" int mmtg_beta_fuse_bwd(int dtype, const void* topic, const void* img,
     const double esz = dtype == MMTG_F32 ? 4 : 2;
     ProfScope prof(MMTG_PROF_ENCODER, s, 24.0 * B * S * H, esz * 6.0 * B * S * H);
     MMTG_REQUIRE(!ws || ws_floats >= mmtg_beta_fuse_bwd_ws(B, S, H), "beta_fuse_bwd: workspace of %ld floats required", mmtg_beta_fuse_bwd_ws(B, S, H));
-    dim3 grid(ws ? B : B * S), block(64);
-#define K_(T) hipLaunchKernelGGL(beta_bwd_kernel<T>, grid, block, 0, s, (const T*)topic, (const T*)img, (const T*)txt, att_w, a, (const T*)d_o, dtopic, (T*)dimg, (T*)dtxt, datt_w, datt_b, B, S, H, ws)
+    MMTG_REQUIRE(!ws || S <= 16, "beta_fuse_bwd: at most 16 experience steps in the workspace form");
+    dim3 grid(ws ? B : B * S), block(ws ? 64 * S : 64);
+    const size_t shm = ws ? (size_t)S * H * sizeof(float) : 0;
+#define K_(T) hipLaunchKernelGGL(beta_bwd_kernel<T>, grid, block, shm, s, (const T*)topic, (const T*)img, (const T*)txt, att_w, a, (const T*)d_o, dtopic, (T*)dimg, (T*)dtxt, datt_w, datt_b, B, S, H, ws)
     DISPATCH(dtype, K_)
 #undef K_
     MMTG_LAUNCH_CHECK("beta_fuse_bwd");
