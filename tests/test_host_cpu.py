@@ -194,6 +194,36 @@ def test_c_abi_exports_every_declared_symbol():
     assert sorted(names) == declared, sorted(set(names) - set(declared))
 
 
+def test_host_side_of_the_round4_abi_without_a_gpu():
+    """The parts of ABI 6 that are host arithmetic run without a GPU: workspace sizes of the ordered reductions, and the stage list
+    of the persistent decode step -- descriptors are built on the HOST with the argument checks of the launches they replace (no
+    device call), so a bad stage is rejected with the library's error message, a good one is counted."""
+    L = hip.lib()
+    assert L.mmtg_colsum_ws(236, 3072) == 0 and L.mmtg_colsum_ws(15104, 512) == 128 * 512          # tall inputs go through 128 row slices
+    assert L.mmtg_embed_add_bwd_ws(15104, 768, 11) == 118 * 11 * 768
+    assert L.mmtg_beta_fuse_bwd_ws(64, 5, 512) == 64 * 5 * 513
+    assert 0 < L.mmtg_sumsq_ws(109064709) <= 4096
+    nbytes = L.mmtg_decode_stage_bytes()
+    assert nbytes > 0 and nbytes % 8 == 0
+    buf = ctypes.create_string_buffer(nbytes * 2)
+    fake = 0x7000000000      # 16-byte aligned stand-ins for device pointers: descriptors only record them
+    M, N, K = 256, 768, 768
+    ok = L.mmtg_decode_stage_gemm(ctypes.addressof(buf), 0, 2, M, N, K, fake, K, fake, K, fake, N, fake, 0, 0, 0, 1e-5, 0, 0, fake, N, fake, 4,
+                                  fake, 4 * 48 * 4 * 4096, fake, 4 * 48)
+    assert ok == 0, L.mmtg_last_error()
+    kind, nitems = np.frombuffer(buf, dtype=np.int32, count=2)
+    assert (int(kind), int(nitems)) == (2, 4 * 12 * 4)                   # reduce mode, 4 row tiles x 12 column tiles x 4 K splits
+    # more than four K splits per reduce stage do not fit the persistent kernel's register budget: rejected on the host
+    bad = L.mmtg_decode_stage_gemm(ctypes.addressof(buf), 1, 2, M, N, 3072, fake, 3072, fake, 3072, fake, N, fake, 0, 0, 0, 1e-5, 0, 0, fake, N, fake, 8,
+                                   fake, 8 * 48 * 4 * 4096, fake, 4 * 48)
+    assert bad != 0 and b"at most 4 K splits" in L.mmtg_last_error()
+    bad = L.mmtg_decode_stage_attn(ctypes.addressof(buf), 1, fake, 5, fake, fake, fake, fake, 144, fake, fake, 256, 12, 64, 144)
+    assert bad != 0 and b"at most 4 c_attn slabs" in L.mmtg_last_error()
+    assert L.mmtg_decode_stage_attn(ctypes.addressof(buf), 1, fake, 2, fake, fake, fake, fake, 144, fake, fake, 256, 12, 64, 144) == 0
+    kind, nitems = np.frombuffer(buf, dtype=np.int32, count=2, offset=nbytes)
+    assert (int(kind), int(nitems)) == (3, 256 * 12)
+
+
 def test_product_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "mmtg_amd")
     for fn in os.listdir(pkg):
