@@ -22,7 +22,7 @@ LIB = os.path.join(HERE, "libmmtg_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-         "-DNDEBUG", "-fvisibility=hidden"]
+         "-DNDEBUG", "-fvisibility=hidden"] + os.environ.get("MMTG_EXTRA_DEFS", "").split()     # (diagnostic builds: -DMMTG_P8_PHASE_TRACE)
 
 
 def _sources():

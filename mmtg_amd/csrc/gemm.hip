@@ -729,24 +729,29 @@ int launch_pp(const GemmArgs& a, int splits, hipStream_t stream) {
 // ONE half tile (two 1-KB DMA blocks per wave) as soon as its last reader has passed a barrier, three half tiles ahead
 // of the tile being consumed; one counted vmcnt(6) per K tile (phase 4) retires the next tile, never vmcnt(0) in the loop.
 // (structure after the guide's 256^2 8-phase template; LDS images, swizzle, descriptors and epilogue are this file's own)
+// (the scalar offset is wave-uniform by construction; said explicitly -- readfirstlane -- because hipcc otherwise wraps each request of
+//  the K-strided form, whose offset goes through a runtime stride, in a waterfall loop: ~10 extra instructions + a branch per
+//  request inside the load wave's phase, found in round 4 with per-phase stamps, profiles/r04_v7_p8_phase_stamps_nt_vs_k_strided.txt)
 __device__ __forceinline__ void p8_issue(__amdgpu_buffer_rsrc_t r, char* d0, char* d1, int v0, int v1, int soff) {
+    soff = __builtin_amdgcn_readfirstlane(soff);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, LDS_PTR(void, d0), 16, v0, soff, 0, 0);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, LDS_PTR(void, d1), 16, v1, soff, 0, 0);
 }
 __device__ __forceinline__ void p8_issue1(__amdgpu_buffer_rsrc_t r, char* d0, int v0, int soff) {
+    soff = __builtin_amdgcn_readfirstlane(soff);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, LDS_PTR(void, d0), 16, v0, soff, 0, 0);
 }
 
 template <int AH, int BH, int NA, int TMW, int FAN>
-__device__ __forceinline__ void p8_mfma(const bf16x8 (&fa)[FAN][2], const bf16x8 (&fb)[2][2], f32x4 (&acc)[TMW][4]) {
-    __builtin_amdgcn_s_setprio(1);
+__device__ __forceinline__ void p8_mfma(const bf16x8 (&fa)[FAN][2], const bf16x8 (&fb)[2][2], f32x4 (&acc)[TMW][4], const bool prio = true) {
+    if (prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
         for (int i = 0; i < NA; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) mma16(fb[j][kk], fa[i][kk], acc[4 * AH + i][2 * BH + j]);
-    __builtin_amdgcn_s_setprio(0);
+    if (prio) __builtin_amdgcn_s_setprio(0);
 }
 
 __device__ __forceinline__ bf16x8 p8_ld(const char* q) { return *reinterpret_cast<const bf16x8*>(q); }
@@ -874,6 +879,9 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(GemmArgs p) {
     if (tr) { ts1 = __builtin_amdgcn_s_memrealtime(); tc1 = __builtin_amdgcn_s_memtime(); }
     if (wr == 1) asm volatile("s_barrier" ::: "memory");          // the second wave group runs one barrier behind the first
 
+    // (A/B: MMTG_P8_NOPRIO=1 -> dbg_flags bit 128: no priority raise around the MFMA clusters -- the K-strided form's load wave
+    //  needs twice the issue slots of the K-contiguous one: 24 transposed reads in phase 1 against 12 ds_read_b128)
+    const bool mprio = !(p.dbg_flags & 128);
     bf16x8 fa[NA1 > 4 ? NA1 : 4][2], fb0[2][2], fb1[2][2];
 #define P8_RD_A(ST, AH, NA)                                                                                \
     _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int i = 0; i < (NA); ++i) {     \
@@ -886,8 +894,19 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(GemmArgs p) {
         else F[j][kk] = tr_read_pair(smem + (ST) * STAGE + (BH) * 16384, ob[j] + kk * 8192, ob[j] + kk * 8192 + 1024); \
     }
     // one K tile held in stage ST (a compile-time 0 / 1: every fragment address is lane offset + immediate)
+    // MMTG_P8_PHASE_TRACE (diagnostic build only, tools/p8_phase_trace.py): shader-clock stamps of K tile 8 in workgroup 0 -- per
+    // phase: start, loads issued, barrier + LDS wait passed (MFMAs start), MFMAs issued, second barrier passed
+#ifdef MMTG_P8_PHASE_TRACE
+    unsigned pst[20];
+#pragma unroll
+    for (int i_ = 0; i_ < 20; ++i_) pst[i_] = 0;
+#define P8_STAMP(kt_, i_) do { if (tr && (kt_) == 8 && blockIdx.x == 0) pst[i_] = (unsigned)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define P8_STAMP(kt_, i_) do { } while (0)
+#endif
 #define P8_TILE(ST, kt)                                                                                    \
     do {                                                                                                   \
+        P8_STAMP(kt, 0);                                                                                   \
         P8_RD_B(ST, 0, fb0);                                                                               \
         __builtin_amdgcn_sched_barrier(0);                                                                 \
         P8_RD_A(ST, 0, 4);                                                                                 \
@@ -895,22 +914,27 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(GemmArgs p) {
         /* the b0 reads are done: b0 may be restaged next phase (K-strided: 8 + 16 reads, the counter saturates at 15) */ \
         if constexpr (!KS) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");                               \
         else asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");                                           \
-        P8_SYNC_IN(); p8_mfma<0, 0, 4, TMW>(fa, fb0, acc); P8_SYNC_OUT();                                   \
+        P8_STAMP(kt, 1);                                                                                   \
+        P8_SYNC_IN(); P8_STAMP(kt, 2); p8_mfma<0, 0, 4, TMW>(fa, fb0, acc, mprio); P8_STAMP(kt, 3); P8_SYNC_OUT(); P8_STAMP(kt, 4);  \
         P8_RD_B(ST, 1, fb1);                                                                               \
         P8_B0((kt) + 2);                                                                                   \
-        P8_SYNC_IN(); p8_mfma<0, 1, 4, TMW>(fa, fb1, acc); P8_SYNC_OUT();                                   \
+        P8_STAMP(kt, 5);                                                                                   \
+        P8_SYNC_IN(); P8_STAMP(kt, 6); p8_mfma<0, 1, 4, TMW>(fa, fb1, acc, mprio); P8_STAMP(kt, 7); P8_SYNC_OUT(); P8_STAMP(kt, 8);  \
         P8_RD_A(ST, 1, NA1);                                                                               \
         P8_A0((kt) + 2);                                                                                   \
-        P8_SYNC_IN(); p8_mfma<1, 1, NA1, TMW>(fa, fb1, acc); P8_SYNC_OUT();                                 \
+        P8_STAMP(kt, 9);                                                                                   \
+        P8_SYNC_IN(); P8_STAMP(kt, 10); p8_mfma<1, 1, NA1, TMW>(fa, fb1, acc, mprio); P8_STAMP(kt, 11); P8_SYNC_OUT(); P8_STAMP(kt, 12); \
         P8_B1((kt) + 2);                                                                                   \
         wait_vmcnt<6>();                                       /* K tile kt + 1 has landed */               \
-        P8_SYNC_IN(); p8_mfma<1, 0, NA1, TMW>(fa, fb0, acc); P8_SYNC_OUT();                                 \
+        P8_STAMP(kt, 13);                                                                                  \
+        P8_SYNC_IN(); P8_STAMP(kt, 14); p8_mfma<1, 0, NA1, TMW>(fa, fb0, acc, mprio); P8_STAMP(kt, 15); P8_SYNC_OUT(); P8_STAMP(kt, 16); \
     } while (0)
     for (int kt = 0; kt < nk; kt += 2) {
         P8_TILE(0, kt);
         P8_TILE(1, kt + 1);
     }
 #undef P8_TILE
+#undef P8_STAMP
 #undef P8_RD_A
 #undef P8_RD_B
 #undef P8_A0
@@ -924,6 +948,13 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(GemmArgs p) {
     if constexpr (KS) p.C = reinterpret_cast<char*>(p.C) + (long)split * p.split_stride;     // MMTG_EPI_SPLIT slab
     // (aux vectors two bands ahead; the 256-row configuration -- 128-row wave tiles -- also carries the dGELU column sums)
     gemm_epilogue<T, false, TMW, 4, (TBM == 256 ? 2 : TBM == 288 ? -1 : -2)>(p, acc, m0 + wr * WTM, n0 + wc * 64, g, l15, smem + wave * epi_scratch_bytes<TMW, 4>(), lane);
+#ifdef MMTG_P8_PHASE_TRACE
+    if (tr && blockIdx.x == 0 && lane == 0 && (int)(gridDim.x + 4 * wave + 4) <= p.trace_n) {
+        unsigned long long* r = p.trace + 6 * (size_t)(gridDim.x + 4 * wave);       // 24 words behind the workgroups' rows
+#pragma unroll
+        for (int i_ = 0; i_ < 20; ++i_) r[i_] = pst[i_];
+    }
+#endif
     if (tr && wave == 0 && (int)blockIdx.x < p.trace_n) {
         wait_vmcnt<0>();                       // the output stores are part of the epilogue's time
         const unsigned long long ts3 = __builtin_amdgcn_s_memrealtime();
@@ -1312,6 +1343,8 @@ extern "C" int mmtg_gemm(int dtype, int transA, int transB, int M, int N, int K,
     a.trace = g_trace; a.trace_n = g_trace_n;
     a.gelu_grad = (flags & MMTG_GEMM_GELU_GRAD) ? 1 : 0;
     a.dbg_flags = ((flags & MMTG_GEMM_ROW_ORDER) ? 1 : 0) | ((flags & MMTG_GEMM_COL_BLOCK) ? 16 : 0) | ((flags & MMTG_GEMM_P256) ? 32 : 0);     // bit 1 (value 2): single-stage kernel, set below
+    static const int p8_noprio = getenv("MMTG_P8_NOPRIO") ? atoi(getenv("MMTG_P8_NOPRIO")) : 0;
+    if (p8_noprio) a.dbg_flags |= 128;
     a.tiles_n = cdiv(N, BN); a.alpha = alpha;
     // byte extents for the buffer descriptors of the LDS-DMA pipeline (offsets are 32-bit)
     const long esz = dtype == MMTG_F32 ? 4 : 2;
