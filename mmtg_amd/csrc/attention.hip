@@ -638,13 +638,30 @@ __device__ __forceinline__ float mask_keep(float p, uint32_t w, int pos) {
     return __builtin_bit_cast(float, __builtin_bit_cast(int, p) & m);
 }
 
+// the same with a wave-uniform bit position: hipcc rewrites the builtin form into v_and + v_cmp + v_cndmask (three VALU per
+// element); the extract is pinned here so it stays v_bfe_i32 + v_and
+__device__ __forceinline__ float mask_keep_u(float p, uint32_t w, int pos) {
+    int m;
+    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(w), "s"(pos));
+    return __builtin_bit_cast(float, __builtin_bit_cast(int, p) & m);
+}
+
 // ---- forward: running state of one 16-query tile, advanced by one 64-key chunk at a time
 struct FwdTile {
     f32x4 o[4];
     float m, l;       // running maximum (in log2 units: s * log2 e) and sum
 };
 
-template <bool DROP, int MT = 256>
+// v_max3_f32 without the NaN-quieting self-maxima hipcc puts in front of every fmaxf operand (scores are never signalling NaNs)
+__device__ __forceinline__ float max3f(float a, float b, float c) {
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+// DIAG: the chunk touches the causal diagonal of the tile (its last chunk): per-key-tile skips and the causal comparison.
+// Every earlier chunk runs the straight-line form (all four key tiles, no comparison, no conditional register copies).
+template <bool DROP, int MT = 256, bool DIAG = true>
 __device__ __forceinline__ void fwd_small_chunk(FwdTile& st, const char* sK, const char* sV, const float* sBias, const uint32_t* sMask,
                                                 const bf16x8 (&qf)[2], int t, int j0, int lane) {
     const int g = lane >> 4, l15 = lane & 15;
@@ -657,19 +674,19 @@ __device__ __forceinline__ void fwd_small_chunk(FwdTile& st, const char* sK, con
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
         s_acc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (j0 + 16 * kt <= qlast) {
+        if (!DIAG || j0 + 16 * kt <= qlast) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) mma16(ld_row(sK, j0 + kt * 16 + l15, ks, g), qf[ks], s_acc[kt]);
             const int k0 = j0 + kt * 16 + 4 * g;
             const f32x4 kb = *reinterpret_cast<const f32x4*>(sBias + k0);
-            if (j0 + 16 * kt + 15 > 16 * t) {
+            if (DIAG && j0 + 16 * kt + 15 > 16 * t) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) s_acc[kt][r] = (k0 + r <= qi) ? s_acc[kt][r] * LOG2E + kb[r] : -INFINITY;
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) s_acc[kt][r] = s_acc[kt][r] * LOG2E + kb[r];
             }
-            mloc = fmaxf(mloc, fmaxf(fmaxf(s_acc[kt][0], s_acc[kt][1]), fmaxf(s_acc[kt][2], s_acc[kt][3])));
+            mloc = max3f(max3f(mloc, s_acc[kt][0], s_acc[kt][1]), s_acc[kt][2], s_acc[kt][3]);
         }
     }
     mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
@@ -692,12 +709,12 @@ __device__ __forceinline__ void fwd_small_chunk(FwdTile& st, const char* sK, con
     }
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
-        if (j0 + 16 * kt <= qlast) {
+        if (!DIAG || j0 + 16 * kt <= qlast) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float p = __builtin_amdgcn_exp2f(s_acc[kt][r] - m_use);   // masked: exp2(-inf) = 0
                 rs += p;
-                if constexpr (DROP) p = mask_keep(p, kt < 2 ? w0 : w1, 16 * (kt & 1) + r);
+                if constexpr (DROP) p = mask_keep_u(p, kt < 2 ? w0 : w1, 16 * (kt & 1) + r);
                 s_acc[kt][r] = p;
             }
         }
@@ -712,13 +729,20 @@ __device__ __forceinline__ void fwd_small_chunk(FwdTile& st, const char* sK, con
     }
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
-        if (j0 + 32 * s2 <= qlast) {
+        if (!DIAG || j0 + 32 * s2 <= qlast) {
             const bf16x8 pb = acc_as_operand(s_acc[2 * s2], s_acc[2 * s2 + 1], bf16());
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
                 mma16(ld_ks(sV, j0 + 32 * s2 + 4 * g, j0 + 32 * s2 + 16 + 4 * g, dt * 16, lane, bf16()), pb, st.o[dt]);
         }
     }
+}
+// one 64-key chunk of tile t: the straight-line form unless the chunk reaches the tile's diagonal
+template <bool DROP, int MT = 256>
+__device__ __forceinline__ void fwd_small_chunk_any(FwdTile& st, const char* sK, const char* sV, const float* sBias, const uint32_t* sMask,
+                                                    const bf16x8 (&qf)[2], int t, int j0, int lane) {
+    if (j0 + 63 <= 16 * t) fwd_small_chunk<DROP, MT, false>(st, sK, sV, sBias, sMask, qf, t, j0, lane);
+    else fwd_small_chunk<DROP, MT, true>(st, sK, sV, sBias, sMask, qf, t, j0, lane);
 }
 
 __device__ __forceinline__ void fwd_small_store(const FwdTile& st, int t, int lane, int b, int h, int Tn, int nH, float inv_keep,
@@ -742,7 +766,7 @@ __global__ __launch_bounds__(2 * MT, 4) void attn_fwd_small_kernel(const bf16* _
         uint32_t keep16, uint32_t drop_seed, float inv_keep, unsigned long long* __restrict__ trace) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned long long ts[6] = {0, 0, 0, 0, 0, 0};
-    if (trace) ts[0] = __builtin_amdgcn_s_memrealtime();
+    ts[0] = __builtin_amdgcn_s_memrealtime();        // (unconditional: testing `trace` first would put a kernel-argument round trip in front of everything)
     constexpr int NW = MT / 32, CROWS = MT / 4;
     const int nchunk = (Tn + CROWS - 1) / CROWS, rows_pad = nchunk * CROWS;
     char* sK = smem;
@@ -803,7 +827,7 @@ __global__ __launch_bounds__(2 * MT, 4) void attn_fwd_small_kernel(const bf16* _
         }
 #pragma unroll 1
         for (int j0 = jb * CROWS; j0 < (jb + 1) * CROWS; j0 += 64)
-            if (work && j0 <= 16 * tB + 15) fwd_small_chunk<DROP, MT>(st, sK, sV, sBias, sMask, qfB, tB, j0, lane);
+            if (work && j0 <= 16 * tB + 15) fwd_small_chunk_any<DROP, MT>(st, sK, sV, sBias, sMask, qfB, tB, j0, lane);
     }
     if (trace) ts[3] = __builtin_amdgcn_s_memrealtime();
     if (work) fwd_small_store(st, tB, lane, b, h, Tn, nH, inv_keep, out, lse);
@@ -814,7 +838,7 @@ __global__ __launch_bounds__(2 * MT, 4) void attn_fwd_small_kernel(const bf16* _
         st.m = -INFINITY;
         st.l = 0.f;
 #pragma unroll 1
-        for (int j0 = 0; j0 <= 16 * tA + 15; j0 += 64) fwd_small_chunk<DROP, MT>(st, sK, sV, sBias, sMask, qfA, tA, j0, lane);
+        for (int j0 = 0; j0 <= 16 * tA + 15; j0 += 64) fwd_small_chunk_any<DROP, MT>(st, sK, sV, sBias, sMask, qfA, tA, j0, lane);
         fwd_small_store(st, tA, lane, b, h, Tn, nH, inv_keep, out, lse);
     }
     if (trace && lane == 0) {
@@ -830,19 +854,22 @@ __global__ __launch_bounds__(2 * MT, 4) void attn_fwd_small_kernel(const bf16* _
 struct BwdKeys {
     f32x4 dk[4], dv[4];
 };
-template <bool DROP, int MT = 256>
+// DIAG: the block holds the tile's diagonal (the first block of a tile's sweep); every later block is wholly below it.
+// NQS 16-query sub-blocks per call: 2 (one 32-query block) or 4 (two blocks back to back below the diagonal -- twice the
+// independent work between the dependent steps LDS read -> product -> element-wise -> product of a two-waves-per-SIMD kernel)
+template <bool DROP, int MT = 256, bool DIAG = true, int NQS = 2>
 __device__ __forceinline__ void bwd_small_keys_block(BwdKeys& st, const char* sQ, const char* sO, const float* sLse, const float* sDel,
                                                      const uint32_t* sMask, const bf16x8 (&kf)[2], const bf16x8 (&vf)[2],
                                                      int t, int q0, int lane, float ik_scale) {
     const int g = lane >> 4, l15 = lane & 15;
     const int key = 16 * t + l15;
     const float c1 = 0.125f * LOG2E;
-    f32x4 pT[2], dsT[2];
+    f32x4 pT[NQS], dsT[NQS];
 #pragma unroll
-    for (int qs = 0; qs < 2; ++qs) {
+    for (int qs = 0; qs < NQS; ++qs) {
         pT[qs] = f32x4{0.f, 0.f, 0.f, 0.f};
         dsT[qs] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (q0 + 16 * qs + 15 >= 16 * t) {          // wave-uniform: a query sub-block wholly above the diagonal contributes nothing
+        if (!DIAG || q0 + 16 * qs + 15 >= 16 * t) { // wave-uniform: a query sub-block wholly above the diagonal contributes nothing
             f32x4 s_acc = {0.f, 0.f, 0.f, 0.f}, dp_acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -852,11 +879,10 @@ __device__ __forceinline__ void bwd_small_keys_block(BwdKeys& st, const char* sQ
             const int qr = q0 + qs * 16 + 4 * g;
             const f32x4 l4 = *reinterpret_cast<const f32x4*>(sLse + qr);       // LSE * log2 e per query row
             const f32x4 d4 = *reinterpret_cast<const f32x4*>(sDel + qr);       // delta / sqrt(64)
-            const bool diag = q0 + 16 * qs < 16 * t + 15;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float x = s_acc[r] * c1 - l4[r];            // (a padded key's column is zeroed at the store, not here)
-                if (diag) x = key <= qr + r ? x : -INFINITY;
+                if constexpr (DIAG) x = key <= qr + r ? x : -INFINITY;
                 const float p = __builtin_amdgcn_exp2f(x);
                 float dp = dp_acc[r];
                 if constexpr (DROP) {
@@ -871,19 +897,63 @@ __device__ __forceinline__ void bwd_small_keys_block(BwdKeys& st, const char* sQ
         }
     }
     // dV^T[d][key] += dO^T[d][q] P[q][key] ;  dK^T[d][key] += Q^T[d][q] dS[q][key]
-    const bf16x8 pb = acc_as_operand(pT[0], pT[1], bf16());
-    const bf16x8 db = acc_as_operand(dsT[0], dsT[1], bf16());
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-        mma16(ld_ks(sO, q0 + 4 * g, q0 + 16 + 4 * g, dt * 16, lane, bf16()), pb, st.dv[dt]);
-        mma16(ld_ks(sQ, q0 + 4 * g, q0 + 16 + 4 * g, dt * 16, lane, bf16()), db, st.dk[dt]);
+    for (int h2 = 0; h2 < NQS / 2; ++h2) {
+        const bf16x8 pb = acc_as_operand(pT[2 * h2], pT[2 * h2 + 1], bf16());
+        const bf16x8 db = acc_as_operand(dsT[2 * h2], dsT[2 * h2 + 1], bf16());
+        const int qa = q0 + 32 * h2 + 4 * g;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            mma16(ld_ks(sO, qa, qa + 16, dt * 16, lane, bf16()), pb, st.dv[dt]);
+            mma16(ld_ks(sQ, qa, qa + 16, dt * 16, lane, bf16()), db, st.dk[dt]);
+        }
     }
 }
-// ACC: the bias-gradient sums of this tile are added to the wave's register accumulators bk / bv (one cross-lane reduction per
-// wave at the end of the kernel, bwd_small_bias_flush) instead of being reduced over the 16 key lanes and added to LDS per tile
-template <bool ACC>
+// the sweep of key tile t over the resident query blocks from block `qb` (below the diagonal) on: pairs, then a last single
+template <bool DROP, int MT, bool PAIRS>
+__device__ __forceinline__ void bwd_small_keys_rest(BwdKeys& st, const char* sQ, const char* sO, const float* sLse, const float* sDel,
+                                                    const uint32_t* sMask, const bf16x8 (&kf)[2], const bf16x8 (&vf)[2],
+                                                    int t, int qb, int nqb, int lane, float ik_scale) {
+    if constexpr (PAIRS) {
+#pragma unroll 1
+        for (; qb + 1 < nqb; qb += 2) bwd_small_keys_block<DROP, MT, false, 4>(st, sQ, sO, sLse, sDel, sMask, kf, vf, t, 32 * qb, lane, ik_scale);
+        if (qb < nqb) bwd_small_keys_block<DROP, MT, false, 2>(st, sQ, sO, sLse, sDel, sMask, kf, vf, t, 32 * qb, lane, ik_scale);
+    } else {
+#pragma unroll 1
+        for (; qb < nqb; ++qb) bwd_small_keys_block<DROP, MT, false, 2>(st, sQ, sO, sLse, sDel, sMask, kf, vf, t, 32 * qb, lane, ik_scale);
+    }
+}
+// sum over the 16 lanes of a row (the 16 keys / queries a tile's lanes own) with DPP rotations: four full-rate VALU adds, no
+// LDS traffic (the __shfl_xor form is a ds_bpermute per step); every lane of the row ends up with the row's sum
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float row_sum16(float x) {
+    x += dpp_mov<0x128>(x);        // row_ror:8
+    x += dpp_mov<0x124>(x);        // row_ror:4
+    x += dpp_mov<0x122>(x);        // row_ror:2
+    x += dpp_mov<0x121>(x);        // row_ror:1
+    return x;
+}
+// c_attn bias gradient, per wave: the column sums of a tile's values AS STORED (v[dt][r] = channel 16 dt + 4 g + r of the
+// lane's key / query, 0 beyond the tensor) folded over the tile's 16 rows; lane l15 = 4 dt + r keeps the sum of channel
+// (l15 >> 2) * 16 + 4 g + (l15 & 3) -- one register per lane carries the wave's running sum over all its tiles (round 4: the
+// 8-wave builds reduced per tile with 128 ds_bpermutes, the 4-wave build carried 32 accumulators and flushed them through
+// eight barrier-separated phases; now every wave writes ONE row of partial sums at the end and the rows are added in wave
+// order -- bit-identical run to run, one barrier).
+__device__ __forceinline__ float bias_fold16(const f32x4 (&v)[4], int l15) {
+    float c = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float sm = row_sum16(v[dt][r]);
+            if (l15 == dt * 4 + r) c = sm;
+        }
+    return c;
+}
 __device__ __forceinline__ void bwd_small_keys_store(const BwdKeys& st, int t, int lane, int b, int h, int Tn, int nH, float inv_keep,
-                                                     bool kpok, bf16* __restrict__ dqkv, float* sB, f32x4 (&bk)[4], f32x4 (&bv)[4]) {
+                                                     bool kpok, bf16* __restrict__ dqkv, bool bias, float& ck, float& cv) {
     const int g = lane >> 4, l15 = lane & 15, key = 16 * t + l15, D = nH * DH;
     const long ld = 3L * D;
     const bool kin = key < Tn;
@@ -904,54 +974,17 @@ __device__ __forceinline__ void bwd_small_keys_store(const BwdKeys& st, int t, i
             *reinterpret_cast<bf16x4*>(dst + 2 * D + dt * 16 + 4 * g) = vv[dt];
         }
     }
-    if (sB) {        // c_attn bias gradient: column sums over keys of the values as stored
+    if (bias) {        // c_attn bias gradient: column sums over keys of the values as stored
+        f32x4 fk[4], fv[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float sk = kin ? (float)kk[dt][r] : 0.f, sv = kin ? (float)vv[dt][r] : 0.f;
-                if constexpr (ACC) {
-                    bk[dt][r] += sk;
-                    bv[dt][r] += sv;
-                } else {
-                    // (register-capped build: the 16 key lanes' sum lands in every lane; lane l15 = 4 dt + r keeps the running
-                    //  sum of ITS channel in bk[0][0] / bv[0][0] -- two registers instead of 32, no LDS atomics)
-#pragma unroll
-                    for (int o = 1; o < 16; o <<= 1) { sk += __shfl_xor(sk, o, 64); sv += __shfl_xor(sv, o, 64); }
-                    if (l15 == dt * 4 + r) { bk[0][0] += sk; bv[0][0] += sv; }
-                }
+                fk[dt][r] = kin ? (float)kk[dt][r] : 0.f;
+                fv[dt][r] = kin ? (float)vv[dt][r] : 0.f;
             }
-    }
-}
-// The waves' accumulated bias sums -> sB, in WAVE ORDER (round 4): wave w adds its values in phase w of NW barrier-separated
-// phases (plain LDS read-modify-writes: one wave per phase, one lane per channel), so the column sums -- the c_attn bias
-// gradient -- come out bit-identical run to run; the LDS float atomics they replace added in arrival order.  Called by every
-// thread of the workgroup (barriers inside).  ACC: full accumulators (one shuffle reduction over the 16 key lanes first);
-// otherwise the compact per-lane form of bwd_small_keys_store.
-template <bool ACC, int NW>
-__device__ __forceinline__ void bwd_small_bias_flush(const f32x4 (&bk)[4], const f32x4 (&bv)[4], float* sB, int lane, int wave, bool work) {
-    const int g = lane >> 4, l15 = lane & 15;
-    // every wave first folds its sums over the 16 key lanes (all waves at once); lane l15 = 4 dt + r keeps channel (dt, r)
-    float ck = bk[0][0], cv = bv[0][0];
-    if constexpr (ACC) {
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float sk = bk[dt][r], sv = bv[dt][r];
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) { sk += __shfl_xor(sk, o, 64); sv += __shfl_xor(sv, o, 64); }
-                if (l15 == dt * 4 + r) { ck = sk; cv = sv; }
-            }
-    }
-    const int ch = (l15 >> 2) * 16 + 4 * g + (l15 & 3);
-#pragma unroll 1
-    for (int w = 0; w < NW; ++w) {          // ... then one LDS read-modify-write per lane, wave after wave
-        if (wave == w && work) {
-            sB[ch] += ck;
-            sB[DH + ch] += cv;
-        }
-        __syncthreads();
+        ck += bias_fold16(fk, l15);
+        cv += bias_fold16(fv, l15);
     }
 }
 
@@ -961,8 +994,10 @@ template <bool DROP, int NW, int MT = 256>
 __global__ __launch_bounds__(64 * NW, (NW / (MT == 256 ? 2 : 4))) void attn_bwd_small_kv_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keep,
         const bf16* __restrict__ d_out, const float* __restrict__ lse, const float* __restrict__ delta,
         bf16* __restrict__ dqkv, float* __restrict__ dbias, int bias_rows, int Tn, int nH,
-        uint32_t keep16, uint32_t drop_seed, float inv_keep) {
+        uint32_t keep16, uint32_t drop_seed, float inv_keep, unsigned long long* __restrict__ trace) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long ts[6] = {0, 0, 0, 0, 0, 0};
+    ts[0] = __builtin_amdgcn_s_memrealtime();        // (unconditional: testing `trace` first would put a kernel-argument round trip in front of everything)
     constexpr int CROWS = MT / 4, PPW = (MT / 32) / NW;            // rows per DMA chunk; tile pairs per wave
     const int nchunk = (Tn + CROWS - 1) / CROWS, rows_pad = nchunk * CROWS;
     char* sQ = smem;
@@ -970,8 +1005,7 @@ __global__ __launch_bounds__(64 * NW, (NW / (MT == 256 ? 2 : 4))) void attn_bwd_
     float* sLse = reinterpret_cast<float*>(sO + rows_pad * 128);    // [MT]
     float* sDel = sLse + MT;                                        // [MT]
     int* sKeep = reinterpret_cast<int*>(sDel + MT);                 // [MT]
-    float* sB = reinterpret_cast<float*>(sKeep + MT);               // [2][64] column sums of dK, dV (in a [MT] slot)
-    uint32_t* sMask = reinterpret_cast<uint32_t*>(sB + MT);         // keep bits
+    uint32_t* sMask = reinterpret_cast<uint32_t*>(sKeep + 2 * MT);  // keep bits (behind a spare [MT] slot)
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = blockIdx.x % nH, b = blockIdx.x / nH;
@@ -980,7 +1014,6 @@ __global__ __launch_bounds__(64 * NW, (NW / (MT == 256 ? 2 : 4))) void attn_bwd_
     const bf16* base = qkv + (long)b * Tn * ld + h * DH;
     const bf16* dob = d_out + (long)b * Tn * D + h * DH;
     const int ntile = (Tn + 15) >> 4, npair = (ntile + 1) >> 1;
-    float* const sBp = dbias ? sB : nullptr;
     // K / V fragments of a key tile (B operands: lane holds row key = 16 t + l15, columns 32 ks + 8 g ..)
     bf16x8 kf[2], vf[2];
     auto load_frags = [&](int t) {
@@ -1002,17 +1035,15 @@ __global__ __launch_bounds__(64 * NW, (NW / (MT == 256 ? 2 : 4))) void attn_bwd_
     dma_issue_scalars<MT>(sDel, delta + (long)b * Tn * nH + h, nH, Tn, wave, lane);
     dma_issue_chunk<NW, MT>(sQ, rq, ld, sO, ro, D, 0, nchunk, wave, lane);
     dma_issue_chunk<NW, MT>(sQ, rq, ld, sO, ro, D, 1, nchunk, wave, lane);
+    if (trace) ts[1] = __builtin_amdgcn_s_memrealtime();
     if constexpr (DROP) gen_keep_mask<64 * NW, MT>(sMask, (uint32_t)(b * nH + h), Tn, drop_seed, keep16, tid);
     // first use of the plain loads: a counted wait here instead of a full drain inside the loop
     asm volatile("" :: "v"(kf[0]), "v"(kf[1]), "v"(vf[0]), "v"(vf[1]));
     BwdKeys st;
 #pragma unroll
     for (int i = 0; i < 4; ++i) st.dk[i] = st.dv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // (the 4-wave build has the registers to carry the bias sums over its four tiles: 32 more; the 8-wave build reduces per tile)
-    constexpr bool BACC = PPW == 2;
-    f32x4 bk[4], bv[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) bk[i] = bv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr bool PAIRS = PPW == 2;          // the half-wave build has the registers for two query blocks per call
+    float ck = 0.f, cv = 0.f;                 // the wave's running bias-gradient sums (bias_fold16)
     const int nqb = (Tn + 31) >> 5;
     const float ik_scale = inv_keep * 0.125f;
     // The wave's first tile (low keys: the longest sweep) takes the query blocks from its diagonal on as they land;
@@ -1026,16 +1057,22 @@ __global__ __launch_bounds__(64 * NW, (NW / (MT == 256 ? 2 : 4))) void attn_bwd_
             raw_barrier();
             if (c < 2) dma_issue_chunk<NW, MT>(sQ, rq, ld, sO, ro, D, c + 2, nchunk, wave, lane);
             if (c == 0) {
-                if (tid < 128) sB[tid] = 0.f;
                 for (int i = tid; i < MT; i += 64 * NW) { sLse[i] *= LOG2E; sDel[i] *= 0.125f; }
                 raw_barrier();
+                if (trace) ts[2] = __builtin_amdgcn_s_memrealtime();
             }
 #pragma unroll 1
             for (int qb = c * (CROWS / 32); qb < (c + 1) * (CROWS / 32) && qb < nqb; ++qb)
-                if (work && qb >= ((16 * tA) >> 5))
-                    bwd_small_keys_block<DROP, MT>(st, sQ, sO, sLse, sDel, sMask, kf, vf, tA, 32 * qb, lane, ik_scale);
+                if (work && qb >= ((16 * tA) >> 5)) {
+                    if (qb == ((16 * tA) >> 5)) bwd_small_keys_block<DROP, MT, true>(st, sQ, sO, sLse, sDel, sMask, kf, vf, tA, 32 * qb, lane, ik_scale);
+                    else if (PAIRS && !(qb & 1) && qb + 1 < nqb) {      // both blocks of this chunk lie below the diagonal
+                        bwd_small_keys_block<DROP, MT, false, 4>(st, sQ, sO, sLse, sDel, sMask, kf, vf, tA, 32 * qb, lane, ik_scale);
+                        ++qb;
+                    } else bwd_small_keys_block<DROP, MT, false>(st, sQ, sO, sLse, sDel, sMask, kf, vf, tA, 32 * qb, lane, ik_scale);
+                }
         }
     }
+    if (trace) ts[3] = __builtin_amdgcn_s_memrealtime();
 #pragma unroll 1
     for (int pi = 0; pi < PPW; ++pi) {
         const int p = wave + NW * pi;
@@ -1045,35 +1082,52 @@ __global__ __launch_bounds__(64 * NW, (NW / (MT == 256 ? 2 : 4))) void attn_bwd_
             load_frags(tA);
 #pragma unroll
             for (int i = 0; i < 4; ++i) st.dk[i] = st.dv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-            for (int qb = (16 * tA) >> 5; qb < nqb; ++qb)
-                bwd_small_keys_block<DROP, MT>(st, sQ, sO, sLse, sDel, sMask, kf, vf, tA, 32 * qb, lane, ik_scale);
+            bwd_small_keys_block<DROP, MT, true>(st, sQ, sO, sLse, sDel, sMask, kf, vf, tA, 32 * ((16 * tA) >> 5), lane, ik_scale);
+            bwd_small_keys_rest<DROP, MT, PAIRS>(st, sQ, sO, sLse, sDel, sMask, kf, vf, tA, ((16 * tA) >> 5) + 1, nqb, lane, ik_scale);
         }
         if (tA != tB) load_frags(tB);
-        bwd_small_keys_store<BACC>(st, tA, lane, b, h, Tn, nH, inv_keep, sKeep[(16 * tA + l15) & (MT - 1)] != 0, dqkv, sBp, bk, bv);
+        bwd_small_keys_store(st, tA, lane, b, h, Tn, nH, inv_keep, sKeep[(16 * tA + l15) & (MT - 1)] != 0, dqkv, dbias != nullptr, ck, cv);
         if (tA != tB) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) st.dk[i] = st.dv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-            for (int qb = (16 * tB) >> 5; qb < nqb; ++qb)
-                bwd_small_keys_block<DROP, MT>(st, sQ, sO, sLse, sDel, sMask, kf, vf, tB, 32 * qb, lane, ik_scale);
-            bwd_small_keys_store<BACC>(st, tB, lane, b, h, Tn, nH, inv_keep, sKeep[(16 * tB + l15) & (MT - 1)] != 0, dqkv, sBp, bk, bv);
+            bwd_small_keys_block<DROP, MT, true>(st, sQ, sO, sLse, sDel, sMask, kf, vf, tB, 32 * ((16 * tB) >> 5), lane, ik_scale);
+            bwd_small_keys_rest<DROP, MT, PAIRS>(st, sQ, sO, sLse, sDel, sMask, kf, vf, tB, ((16 * tB) >> 5) + 1, nqb, lane, ik_scale);
+            bwd_small_keys_store(st, tB, lane, b, h, Tn, nH, inv_keep, sKeep[(16 * tB + l15) & (MT - 1)] != 0, dqkv, dbias != nullptr, ck, cv);
         }
     }
+    if (trace) ts[4] = __builtin_amdgcn_s_memrealtime();
     if (dbias) {
-        bwd_small_bias_flush<BACC, NW>(bk, bv, sB, lane, wave, true);
+        // every wave's row of partial sums -> sBw[wave][128] (K channels, then V; over the first bytes of the Q image once
+        // every wave is done with it), then the rows added in wave order
+        __syncthreads();
+        float* sBw = reinterpret_cast<float*>(smem);
+        const int ch = (l15 >> 2) * 16 + 4 * g + (l15 & 3);
+        sBw[wave * 128 + ch] = ck;
+        sBw[wave * 128 + DH + ch] = cv;
+        __syncthreads();
         // this kernel owns the K and V parts of head h's columns: one partial row per batch row
         // (bias_rows: plain stores into row b of the scratch; otherwise atomics onto the gradient)
         if (tid < 2 * DH) {
+            float sm = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) sm += sBw[w * 128 + tid];
             const int col = (1 + tid / DH) * D + h * DH + tid % DH;
-            if (bias_rows) dbias[(long)b * 3 * D + col] = sB[tid];
-            else atomicAdd(dbias + col, sB[tid]);
+            if (bias_rows) dbias[(long)b * 3 * D + col] = sm;
+            else atomicAdd(dbias + col, sm);
         }
+    }
+    if (trace && lane == 0) {
+        ts[5] = __builtin_amdgcn_s_memrealtime();
+        unsigned long long* r = trace + ((long)blockIdx.x * 16 + wave) * 8;
+        r[0] = ts[0]; r[1] = ts[1]; r[2] = ts[2]; r[3] = ts[3]; r[4] = ts[4]; r[5] = ts[5];
+        r[6] = __builtin_amdgcn_s_getreg((4 << 11) | 20);    // XCC_ID
+        r[7] = 1;
     }
 }
 
 // ---- backward, dQ kernel: the 16 queries of tile t (Q, dO fragments in registers), one 32-key block
-template <bool DROP, int MT = 256>
+// DIAG: the block holds the tile's diagonal (the last block of a tile's sweep); every earlier block is wholly below it
+template <bool DROP, int MT = 256, bool DIAG = true>
 __device__ __forceinline__ void bwd_small_queries_block(f32x4 (&dq)[4], const char* sK, const char* sV, const float* sBias,
                                                         const uint32_t* sMask, const bf16x8 (&qf)[2], const bf16x8 (&of)[2],
                                                         float lse2_q, float dels_q, int t, int j0, int lane, float ik_scale) {
@@ -1086,7 +1140,7 @@ __device__ __forceinline__ void bwd_small_queries_block(f32x4 (&dq)[4], const ch
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
         dsT[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (j0 + 16 * kt <= qlast) {
+        if (!DIAG || j0 + 16 * kt <= qlast) {
             f32x4 s_acc = {0.f, 0.f, 0.f, 0.f}, dp_acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -1095,14 +1149,13 @@ __device__ __forceinline__ void bwd_small_queries_block(f32x4 (&dq)[4], const ch
             }
             const int k0 = j0 + kt * 16 + 4 * g;
             const f32x4 kb = *reinterpret_cast<const f32x4*>(sBias + k0);
-            const bool diag = j0 + 16 * kt + 15 > 16 * t;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float x = s_acc[r] * c1 - lse2_q + kb[r];
-                if (diag) x = k0 + r <= qi ? x : -INFINITY;
+                if constexpr (DIAG) x = k0 + r <= qi ? x : -INFINITY;
                 const float p = __builtin_amdgcn_exp2f(x);
                 float dp = dp_acc[r];
-                if constexpr (DROP) dp = mask_keep(dp, wq, 16 * kt + r);
+                if constexpr (DROP) dp = mask_keep_u(dp, wq, 16 * kt + r);
                 dsT[kt][r] = p * (dp * ik_scale - dels_q);
             }
         }
@@ -1114,7 +1167,7 @@ __device__ __forceinline__ void bwd_small_queries_block(f32x4 (&dq)[4], const ch
         mma16(ld_ks(sK, j0 + 4 * g, j0 + 16 + 4 * g, dt * 16, lane, bf16()), db, dq[dt]);
 }
 __device__ __forceinline__ void bwd_small_queries_store(const f32x4 (&dq)[4], int t, int lane, int b, int h, int Tn, int nH,
-                                                        bf16* __restrict__ dqkv, float* sB, f32x4 (&bq)[4]) {
+                                                        bf16* __restrict__ dqkv, bool bias, float& cq) {
     const int g = lane >> 4, l15 = lane & 15, qi = 16 * t + l15, D = nH * DH;
     const long ld = 3L * D;
     const bool qok = qi < Tn;
@@ -1126,31 +1179,13 @@ __device__ __forceinline__ void bwd_small_queries_store(const f32x4 (&dq)[4], in
             *reinterpret_cast<bf16x4*>(dst + dt * 16 + 4 * g) = qq;
         }
     }
-    if (sB) {        // bias-gradient sums of the values as stored: into the wave's accumulators, reduced once after its last tile
+    if (bias) {      // bias-gradient sums of the values as stored: folded over the tile's 16 queries into the wave's running sum
+        f32x4 fq[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) bq[dt][r] += qok ? (float)(bf16)dq[dt][r] : 0.f;
-    }
-}
-template <int NW>
-__device__ __forceinline__ void bwd_small_bias_flush_q(const f32x4 (&bq)[4], float* sB, int lane, int wave, bool work) {
-    const int g = lane >> 4, l15 = lane & 15;
-    float cq = 0.f;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float sq = bq[dt][r];
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) sq += __shfl_xor(sq, o, 64);
-            if (l15 == dt * 4 + r) cq = sq;
-        }
-    const int ch = (l15 >> 2) * 16 + 4 * g + (l15 & 3);
-#pragma unroll 1
-    for (int w = 0; w < NW; ++w) {          // wave order: see bwd_small_bias_flush
-        if (wave == w && work) sB[ch] += cq;
-        __syncthreads();
+            for (int r = 0; r < 4; ++r) fq[dt][r] = qok ? (float)(bf16)dq[dt][r] : 0.f;
+        cq += bias_fold16(fq, l15);
     }
 }
 
@@ -1158,16 +1193,19 @@ template <bool DROP, int MT = 256>
 __global__ __launch_bounds__(2 * MT, 4) void attn_bwd_small_q_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keep,
         const bf16* __restrict__ d_out, const float* __restrict__ lse, const float* __restrict__ delta,
         bf16* __restrict__ dqkv, float* __restrict__ dbias, int bias_rows, int Tn, int nH,
-        uint32_t keep16, uint32_t drop_seed, float inv_keep) {
+        uint32_t keep16, uint32_t drop_seed, float inv_keep, unsigned long long* __restrict__ trace) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long ts[6] = {0, 0, 0, 0, 0, 0};
+    ts[0] = __builtin_amdgcn_s_memrealtime();        // (unconditional: testing `trace` first would put a kernel-argument round trip in front of everything)
     constexpr int NW = MT / 32, CROWS = MT / 4;
     const int nchunk = (Tn + CROWS - 1) / CROWS, rows_pad = nchunk * CROWS;
     char* sK = smem;
     char* sV = sK + rows_pad * 128;
-    int* sKeep = reinterpret_cast<int*>(sV + rows_pad * 128);      // [MT]
-    float* sBias = reinterpret_cast<float*>(sKeep + MT);           // [MT]
-    float* sB = sBias + MT;                                         // [64] column sums of dQ (in two [MT] slots)
-    uint32_t* sMask = reinterpret_cast<uint32_t*>(sB + 2 * MT);     // keep bits
+    int* sKeep = reinterpret_cast<int*>(sV + rows_pad * 128);      // [MT] key-padding flags, turned IN PLACE into ...
+    float* sBias = reinterpret_cast<float*>(sKeep);                // ... the additive 0 / -inf per key
+    float* sLse = sBias + MT;                                       // [MT] LSE per query row (x log2 e on use)
+    float* sDel = sLse + MT;                                        // [MT] delta per query row (/ sqrt(64) on use)
+    uint32_t* sMask = reinterpret_cast<uint32_t*>(sDel + 2 * MT);   // keep bits (behind a spare [MT] slot)
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = blockIdx.x % nH, b = blockIdx.x / nH;
@@ -1178,36 +1216,39 @@ __global__ __launch_bounds__(2 * MT, 4) void attn_bwd_small_q_kernel(const bf16*
     const int ntile = (Tn + 15) >> 4, npair = (ntile + 1) >> 1;
     const int tA = wave, tB = ntile - 1 - wave;
     const bool work = wave < npair;
-    float* const sBp = dbias ? sB : nullptr;
-    bf16x8 qfA[2], ofA[2], qfB[2], ofB[2];
-    const int qa = 16 * tA + l15, qb_ = 16 * tB + l15;
-    float lseA = 0.f, delA = 0.f, lseB = 0.f, delB = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        qfA[ks] = ofA[ks] = qfB[ks] = ofB[ks] = zero16<bf16>();
-        if (work && qa < Tn) {
-            qfA[ks] = *reinterpret_cast<const bf16x8*>(base + (long)qa * ld + ks * 32 + g * 8);
-            ofA[ks] = *reinterpret_cast<const bf16x8*>(dob + (long)qa * D + ks * 32 + g * 8);
-        }
-        if (work && qb_ < Tn) {
-            qfB[ks] = *reinterpret_cast<const bf16x8*>(base + (long)qb_ * ld + ks * 32 + g * 8);
-            ofB[ks] = *reinterpret_cast<const bf16x8*>(dob + (long)qb_ * D + ks * 32 + g * 8);
-        }
-    }
-    if (work && qa < Tn) { lseA = lse[((long)b * nH + h) * Tn + qa]; delA = delta[((long)b * Tn + qa) * nH + h]; }
-    if (work && qb_ < Tn) { lseB = lse[((long)b * nH + h) * Tn + qb_]; delB = delta[((long)b * Tn + qb_) * nH + h]; }
+    // Requests, in this order: flags and the per-row scalars (LDS-DMA), chunk 0 of K / V, the Q / dO fragments of the wave's
+    // LONG tile (plain loads, branch-free: a row beyond the tensor re-reads the last row and is zeroed below -- a conditional
+    // load ends in a full `s_waitcnt vmcnt(0)` where its value joins the zero of the other path; with the row scalars as
+    // conditional plain loads the prologue waited out two memory round trips before it requested anything: 5.3 us from
+    // entry to "requests issued" in the timeline of round 4), chunk 1.  The short tile's fragments are requested after the
+    // long sweep, under its store (16 registers that are not live during the sweep of a build capped at 128).
     const __amdgpu_buffer_rsrc_t rk = rows_rsrc(base + D, ld, Tn), rv = rows_rsrc(base + 2 * D, ld, Tn);
     dma_issue_scalars<MT>(sKeep, keep + (long)b * Tn, 1, Tn, wave, lane);
+    dma_issue_scalars<MT>(sLse, lse + ((long)b * nH + h) * Tn, 1, Tn, wave, lane);
+    dma_issue_scalars<MT>(sDel, delta + (long)b * Tn * nH + h, nH, Tn, wave, lane);
     dma_issue_chunk<NW, MT>(sK, rk, ld, sV, rv, ld, 0, nchunk, wave, lane);
+    const int qa = 16 * tA + l15, qb_ = 16 * tB + l15;
+    bf16x8 qfB[2], ofB[2];
+    {
+        const int qc = work ? (qb_ < Tn ? qb_ : Tn - 1) : 0;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            qfB[ks] = *reinterpret_cast<const bf16x8*>(base + (long)qc * ld + ks * 32 + g * 8);
+            ofB[ks] = *reinterpret_cast<const bf16x8*>(dob + (long)qc * D + ks * 32 + g * 8);
+        }
+    }
     dma_issue_chunk<NW, MT>(sK, rk, ld, sV, rv, ld, 1, nchunk, wave, lane);
+    if (trace) ts[1] = __builtin_amdgcn_s_memrealtime();
     if constexpr (DROP) gen_keep_mask<2 * MT, MT>(sMask, (uint32_t)(b * nH + h), Tn, drop_seed, keep16, tid);
     // first use of the plain loads: a counted wait here instead of a full drain inside the loop
-    asm volatile("" :: "v"(qfA[0]), "v"(qfA[1]), "v"(ofA[0]), "v"(ofA[1]), "v"(qfB[0]), "v"(qfB[1]), "v"(ofB[0]), "v"(ofB[1]));
-    lseA *= LOG2E; lseB *= LOG2E; delA *= 0.125f; delB *= 0.125f;
+    asm volatile("" :: "v"(qfB[0]), "v"(qfB[1]), "v"(ofB[0]), "v"(ofB[1]));
+    if (!(work && qb_ < Tn)) { qfB[0] = qfB[1] = ofB[0] = ofB[1] = zero16<bf16>(); }
+    float lseB = 0.f, delB = 0.f;
     f32x4 dq[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) dq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float ik_scale = inv_keep * 0.125f;
+    bf16x8 qfA[2], ofA[2];
     // tile B (high queries) consumes the key chunks as they land; tile A (a short range) runs afterwards
 #pragma unroll 1
     for (int c = 0; c < nchunk; ++c) {
@@ -1215,36 +1256,67 @@ __global__ __launch_bounds__(2 * MT, 4) void attn_bwd_small_q_kernel(const bf16*
         raw_barrier();
         if (c < 2) dma_issue_chunk<NW, MT>(sK, rk, ld, sV, rv, ld, c + 2, nchunk, wave, lane);
         if (c == 0) {
-            if (tid < 64) sB[tid] = 0.f;
-            if (tid < MT) sBias[tid] = sKeep[tid] != 0 ? 0.f : -INFINITY;
+            if (tid < MT) sBias[tid] = sKeep[tid] != 0 ? 0.f : -INFINITY;      // (in place: thread tid owns word tid)
+            lseB = sLse[qb_ & (MT - 1)] * LOG2E;                                // (rows beyond the tensor: the DMA's bounds check left 0)
+            delB = sDel[qb_ & (MT - 1)] * 0.125f;
             raw_barrier();
+            if (trace) ts[2] = __builtin_amdgcn_s_memrealtime();
         }
 #pragma unroll 1
         for (int kb = c * (CROWS / 32); kb < (c + 1) * (CROWS / 32); ++kb)
-            if (work && 32 * kb <= 16 * tB + 15)
-                bwd_small_queries_block<DROP, MT>(dq, sK, sV, sBias, sMask, qfB, ofB, lseB, delB, tB, 32 * kb, lane, ik_scale);
+            if (work && 32 * kb <= 16 * tB + 15) {
+                if (32 * kb + 31 <= 16 * tB) bwd_small_queries_block<DROP, MT, false>(dq, sK, sV, sBias, sMask, qfB, ofB, lseB, delB, tB, 32 * kb, lane, ik_scale);
+                else bwd_small_queries_block<DROP, MT, true>(dq, sK, sV, sBias, sMask, qfB, ofB, lseB, delB, tB, 32 * kb, lane, ik_scale);
+            }
     }
-    f32x4 bq[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) bq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (trace) ts[3] = __builtin_amdgcn_s_memrealtime();
+    float cq = 0.f;                 // the wave's running bias-gradient sums (bias_fold16)
     if (work) {
-        bwd_small_queries_store(dq, tB, lane, b, h, Tn, nH, dqkv, sBp, bq);
+        if (tA != tB) {            // the short tile's fragments: requested here, in flight under the long tile's store
+            const int qc = qa < Tn ? qa : Tn - 1;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                qfA[ks] = *reinterpret_cast<const bf16x8*>(base + (long)qc * ld + ks * 32 + g * 8);
+                ofA[ks] = *reinterpret_cast<const bf16x8*>(dob + (long)qc * D + ks * 32 + g * 8);
+            }
+        }
+        bwd_small_queries_store(dq, tB, lane, b, h, Tn, nH, dqkv, dbias != nullptr, cq);
         if (tA != tB) {
+            if (!(qa < Tn)) { qfA[0] = qfA[1] = ofA[0] = ofA[1] = zero16<bf16>(); }
+            const float lseA = sLse[qa & (MT - 1)] * LOG2E, delA = sDel[qa & (MT - 1)] * 0.125f;
 #pragma unroll
             for (int i = 0; i < 4; ++i) dq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            int j0 = 0;
 #pragma unroll 1
-            for (int j0 = 0; j0 <= 16 * tA + 15; j0 += 32)
-                bwd_small_queries_block<DROP, MT>(dq, sK, sV, sBias, sMask, qfA, ofA, lseA, delA, tA, j0, lane, ik_scale);
-            bwd_small_queries_store(dq, tA, lane, b, h, Tn, nH, dqkv, sBp, bq);
+            for (; j0 + 31 <= 16 * tA; j0 += 32)
+                bwd_small_queries_block<DROP, MT, false>(dq, sK, sV, sBias, sMask, qfA, ofA, lseA, delA, tA, j0, lane, ik_scale);
+            bwd_small_queries_block<DROP, MT, true>(dq, sK, sV, sBias, sMask, qfA, ofA, lseA, delA, tA, j0, lane, ik_scale);
+            bwd_small_queries_store(dq, tA, lane, b, h, Tn, nH, dqkv, dbias != nullptr, cq);
         }
     }
+    if (trace) ts[4] = __builtin_amdgcn_s_memrealtime();
     if (dbias) {
-        bwd_small_bias_flush_q<NW>(bq, sB, lane, wave, work);
-        if (tid < DH) {         // the Q part of head h's columns
+        // every wave's row of partial sums -> sBw[wave][64] (over the first bytes of the K image once every wave is done with
+        // it), then the rows added in wave order: the Q part of head h's columns
+        __syncthreads();
+        float* sBw = reinterpret_cast<float*>(smem);
+        sBw[wave * DH + (l15 >> 2) * 16 + 4 * g + (l15 & 3)] = cq;
+        __syncthreads();
+        if (tid < DH) {
+            float sm = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) sm += sBw[w * DH + tid];
             const int col = h * DH + tid;
-            if (bias_rows) dbias[(long)b * 3 * D + col] = sB[tid];
-            else atomicAdd(dbias + col, sB[tid]);
+            if (bias_rows) dbias[(long)b * 3 * D + col] = sm;
+            else atomicAdd(dbias + col, sm);
         }
+    }
+    if (trace && lane == 0) {
+        ts[5] = __builtin_amdgcn_s_memrealtime();
+        unsigned long long* r = trace + ((long)(gridDim.x + blockIdx.x) * 16 + wave) * 8;      // (behind the dK / dV kernel's rows)
+        r[0] = ts[0]; r[1] = ts[1]; r[2] = ts[2]; r[3] = ts[3]; r[4] = ts[4]; r[5] = ts[5];
+        r[6] = __builtin_amdgcn_s_getreg((4 << 11) | 20);
+        r[7] = 1;
     }
 }
 
@@ -1388,9 +1460,9 @@ extern "C" int mmtg_attn_bwd(int dtype, const void* qkv, const int* keep, const 
         // MMTG_ATTN_KV_NW=4|8 (T <= 256) / 8|16 (T <= 512) forces one.
         static const int kv_nw = getenv("MMTG_ATTN_KV_NW") ? atoi(getenv("MMTG_ATTN_KV_NW")) : 0;
 #define KV_SMALL(DROP_, NW_, MT_) hipLaunchKernelGGL((attn_bwd_small_kv_kernel<DROP_, NW_, MT_>), dim3(B * nH), dim3(64 * NW_), small_smem<MT_>(T), s, \
-                                   (const bf16*)qkv, keep, (const bf16*)dout, lse, delta, (bf16*)dqkv, bias_dst, bias_rows, T, nH, kq, drop_seed, ik16)
+                                   (const bf16*)qkv, keep, (const bf16*)dout, lse, delta, (bf16*)dqkv, bias_dst, bias_rows, T, nH, kq, drop_seed, ik16, g_attn_trace)
 #define Q_SMALL(DROP_, MT_) hipLaunchKernelGGL((attn_bwd_small_q_kernel<DROP_, MT_>), dim3(B * nH), dim3(2 * MT_), small_smem<MT_>(T), s, \
-                                   (const bf16*)qkv, keep, (const bf16*)dout, lse, delta, (bf16*)dqkv, bias_dst, bias_rows, T, nH, kq, drop_seed, ik16)
+                                   (const bf16*)qkv, keep, (const bf16*)dout, lse, delta, (bf16*)dqkv, bias_dst, bias_rows, T, nH, kq, drop_seed, ik16, g_attn_trace)
         if (T <= 256) {
             const bool half = kv_nw ? kv_nw == 4 : drop;
             if (drop) { if (half) KV_SMALL(true, 4, 256); else KV_SMALL(true, 8, 256); Q_SMALL(true, 256); }
