@@ -1125,6 +1125,253 @@ __global__ __launch_bounds__(64 * NW, (NW / (MT == 256 ? 2 : 4))) void attn_bwd_
     }
 }
 
+// ---- backward, dK / dV kernel, 32 keys per wave (round 4): a wave owns a UNIT of two adjacent key tiles (keys 32 u .. 32 u + 31)
+// and sweeps the 32-query blocks u .. from their common diagonal block on.  The Q / dO row fragments of a query sub-block and
+// the transposed Q / dO fragments of a block are read from LDS ONCE for both tiles -- half the LDS traffic per product of the
+// 16-key form (whose two-waves-per-SIMD sweep ran the LDS pipe at about half its bandwidth besides the vector work) and half
+// the per-block overhead.  Units pair up like tiles did (u, nunit - 1 - u: 9 blocks of 32 x 32 per wave at T = 236), NW = MT / 64
+// waves per workgroup, up to 256 VGPRs.
+template <bool DROP, int MT, bool DIAG>
+__device__ __forceinline__ void bwd_small_keys2_block(BwdKeys (&st)[2], const char* sQ, const char* sO, const float* sLse, const float* sDel,
+                                                      const uint32_t* sMask, const bf16x8 (&kf)[2][2], const bf16x8 (&vf)[2][2],
+                                                      int u, int q0, int lane, float ik_scale) {
+    const int g = lane >> 4, l15 = lane & 15;
+    const float c1 = 0.125f * LOG2E;
+    f32x4 pT[2][2], dsT[2][2];          // [key tile][query sub-block]
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs) {
+        bf16x8 qrow[2], orow[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            qrow[ks] = ld_row(sQ, q0 + qs * 16 + l15, ks, g);
+            orow[ks] = ld_row(sO, q0 + qs * 16 + l15, ks, g);
+        }
+        const int qr = q0 + qs * 16 + 4 * g;
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(sLse + qr);       // LSE * log2 e per query row
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(sDel + qr);       // delta / sqrt(64)
+        uint32_t w[4] = {0, 0, 0, 0};
+        if constexpr (DROP) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) w[r] = sMask[mask_row_base<MT>(qr + r) + u];       // both tiles' keys live in word u
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            pT[j][qs] = f32x4{0.f, 0.f, 0.f, 0.f};
+            dsT[j][qs] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (DIAG && j == 1 && qs == 0) continue;        // the diagonal block's upper-right quarter: wholly above the diagonal
+            f32x4 s_acc = {0.f, 0.f, 0.f, 0.f}, dp_acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                mma16(qrow[ks], kf[j][ks], s_acc);
+                mma16(orow[ks], vf[j][ks], dp_acc);
+            }
+            const int key = 32 * u + 16 * j + l15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float x = s_acc[r] * c1 - l4[r];            // (a padded key's column is zeroed at the store, not here)
+                if (DIAG && qs == j) x = key <= qr + r ? x : -INFINITY;
+                const float p = __builtin_amdgcn_exp2f(x);
+                float dp = dp_acc[r];
+                if constexpr (DROP) {
+                    dp = mask_keep(dp, w[r], 16 * j + l15);
+                    pT[j][qs][r] = mask_keep(p, w[r], 16 * j + l15);           // (x 1/(1-p) at the end, on dV)
+                } else {
+                    pT[j][qs][r] = p;
+                }
+                dsT[j][qs][r] = p * (dp * ik_scale - d4[r]);                   // ik_scale = (1/(1-p)) / sqrt(64)
+            }
+        }
+    }
+    // dV^T[d][key] += dO^T[d][q] P[q][key] ;  dK^T[d][key] += Q^T[d][q] dS[q][key]
+    bf16x8 pb[2], db[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        pb[j] = acc_as_operand(pT[j][0], pT[j][1], bf16());
+        db[j] = acc_as_operand(dsT[j][0], dsT[j][1], bf16());
+    }
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        const bf16x8 ao = ld_ks(sO, q0 + 4 * g, q0 + 16 + 4 * g, dt * 16, lane, bf16());
+        const bf16x8 aq = ld_ks(sQ, q0 + 4 * g, q0 + 16 + 4 * g, dt * 16, lane, bf16());
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            mma16(ao, pb[j], st[j].dv[dt]);
+            mma16(aq, db[j], st[j].dk[dt]);
+        }
+    }
+}
+// both tiles of a unit: rounded, stored, and their column sums (as stored) folded into the wave's running bias sums
+__device__ __forceinline__ void bwd_small_keys2_store(const BwdKeys (&st)[2], int u, int lane, int b, int h, int Tn, int nH, float inv_keep,
+                                                      const int* sKeep, int mt_mask, bf16* __restrict__ dqkv, bool bias, float& ck, float& cv) {
+    const int g = lane >> 4, l15 = lane & 15, D = nH * DH;
+    const long ld = 3L * D;
+    f32x4 fk[4], fv[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) fk[dt] = fv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int key = 32 * u + 16 * j + l15;
+        const bool kin = key < Tn, kpok = sKeep[key & mt_mask] != 0;
+        // a padded key never receives attention: its probabilities are zero for every query, hence dK = dV = 0.  Each lane
+        // owns one key's column of both products, so the sweep runs unmasked and the column is zeroed here.
+        const float kz = kpok ? 1.f : 0.f, vz = kpok ? inv_keep : 0.f;
+        bf16x4 kk[4], vv[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            kk[dt] = bf16x4{(bf16)(st[j].dk[dt][0] * kz), (bf16)(st[j].dk[dt][1] * kz), (bf16)(st[j].dk[dt][2] * kz), (bf16)(st[j].dk[dt][3] * kz)};
+            vv[dt] = bf16x4{(bf16)(st[j].dv[dt][0] * vz), (bf16)(st[j].dv[dt][1] * vz), (bf16)(st[j].dv[dt][2] * vz), (bf16)(st[j].dv[dt][3] * vz)};
+        }
+        if (kin) {
+            bf16* dst = dqkv + ((long)b * Tn + key) * ld + h * DH;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                *reinterpret_cast<bf16x4*>(dst + D + dt * 16 + 4 * g) = kk[dt];
+                *reinterpret_cast<bf16x4*>(dst + 2 * D + dt * 16 + 4 * g) = vv[dt];
+            }
+        }
+        if (bias) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    fk[dt][r] += kin ? (float)kk[dt][r] : 0.f;
+                    fv[dt][r] += kin ? (float)vv[dt][r] : 0.f;
+                }
+        }
+    }
+    if (bias) {
+        ck += bias_fold16(fk, l15);
+        cv += bias_fold16(fv, l15);
+    }
+}
+
+template <bool DROP, int MT = 256>
+__global__ __launch_bounds__(MT, (MT == 256 ? 2 : 1)) void attn_bwd_small_kv2_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keep,
+        const bf16* __restrict__ d_out, const float* __restrict__ lse, const float* __restrict__ delta,
+        bf16* __restrict__ dqkv, float* __restrict__ dbias, int bias_rows, int Tn, int nH,
+        uint32_t keep16, uint32_t drop_seed, float inv_keep, unsigned long long* __restrict__ trace) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long ts[6] = {0, 0, 0, 0, 0, 0};
+    ts[0] = __builtin_amdgcn_s_memrealtime();
+    constexpr int NW = MT / 64, CROWS = MT / 4;
+    const int nchunk = (Tn + CROWS - 1) / CROWS, rows_pad = nchunk * CROWS;
+    char* sQ = smem;
+    char* sO = sQ + rows_pad * 128;
+    float* sLse = reinterpret_cast<float*>(sO + rows_pad * 128);    // [MT]
+    float* sDel = sLse + MT;                                        // [MT]
+    int* sKeep = reinterpret_cast<int*>(sDel + MT);                 // [MT]
+    uint32_t* sMask = reinterpret_cast<uint32_t*>(sKeep + 2 * MT);  // keep bits (behind a spare [MT] slot)
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = blockIdx.x % nH, b = blockIdx.x / nH;
+    const int D = nH * DH;
+    const long ld = 3L * D;
+    const bf16* base = qkv + (long)b * Tn * ld + h * DH;
+    const bf16* dob = d_out + (long)b * Tn * D + h * DH;
+    const int nunit = (Tn + 31) >> 5, nupair = (nunit + 1) >> 1;      // units of 32 keys = the 32-query blocks
+    const int uA = wave, uB = nunit - 1 - wave;
+    const bool work = wave < nupair;
+    // K / V fragments of a unit's two key tiles (B operands: lane holds row key = 32 u + 16 j + l15, columns 32 ks + 8 g ..)
+    bf16x8 kf[2][2], vf[2][2];
+    auto load_frags = [&](int u) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int key = 32 * u + 16 * j + l15;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                kf[j][ks] = vf[j][ks] = zero16<bf16>();
+                if (key < Tn) {
+                    kf[j][ks] = *reinterpret_cast<const bf16x8*>(base + (long)key * ld + D + ks * 32 + g * 8);
+                    vf[j][ks] = *reinterpret_cast<const bf16x8*>(base + (long)key * ld + 2 * D + ks * 32 + g * 8);
+                }
+            }
+        }
+    };
+    if (work) load_frags(uA);
+    else {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) kf[j][0] = kf[j][1] = vf[j][0] = vf[j][1] = zero16<bf16>();
+    }
+    const __amdgpu_buffer_rsrc_t rq = rows_rsrc(base, ld, Tn), ro = rows_rsrc(dob, D, Tn);
+    dma_issue_scalars<MT>(sKeep, keep + (long)b * Tn, 1, Tn, wave, lane);
+    dma_issue_scalars<MT>(sLse, lse + ((long)b * nH + h) * Tn, 1, Tn, wave, lane);
+    dma_issue_scalars<MT>(sDel, delta + (long)b * Tn * nH + h, nH, Tn, wave, lane);
+    dma_issue_chunk<NW, MT>(sQ, rq, ld, sO, ro, D, 0, nchunk, wave, lane);
+    dma_issue_chunk<NW, MT>(sQ, rq, ld, sO, ro, D, 1, nchunk, wave, lane);
+    if (trace) ts[1] = __builtin_amdgcn_s_memrealtime();
+    if constexpr (DROP) gen_keep_mask<64 * NW, MT>(sMask, (uint32_t)(b * nH + h), Tn, drop_seed, keep16, tid);
+    // first use of the plain loads: a counted wait here instead of a full drain inside the loop
+    asm volatile("" :: "v"(kf[0][0]), "v"(kf[0][1]), "v"(vf[0][0]), "v"(vf[0][1]), "v"(kf[1][0]), "v"(kf[1][1]), "v"(vf[1][0]), "v"(vf[1][1]));
+    BwdKeys st[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) st[j].dk[i] = st[j].dv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float ck = 0.f, cv = 0.f;                 // the wave's running bias-gradient sums (bias_fold16)
+    const float ik_scale = inv_keep * 0.125f;
+    // The wave's first unit (low keys: the longest sweep) takes the query blocks from its diagonal on as they land;
+    // the second one runs on resident data.
+#pragma unroll 1
+    for (int c = 0; c < nchunk; ++c) {
+        dma_wait_chunk<NW, MT>(c);
+        raw_barrier();
+        if (c < 2) dma_issue_chunk<NW, MT>(sQ, rq, ld, sO, ro, D, c + 2, nchunk, wave, lane);
+        if (c == 0) {
+            for (int i = tid; i < MT; i += 64 * NW) { sLse[i] *= LOG2E; sDel[i] *= 0.125f; }
+            raw_barrier();
+            if (trace) ts[2] = __builtin_amdgcn_s_memrealtime();
+        }
+#pragma unroll 1
+        for (int qb = c * (CROWS / 32); qb < (c + 1) * (CROWS / 32) && qb < nunit; ++qb)
+            if (work && qb >= uA) {
+                if (qb == uA) bwd_small_keys2_block<DROP, MT, true>(st, sQ, sO, sLse, sDel, sMask, kf, vf, uA, 32 * qb, lane, ik_scale);
+                else bwd_small_keys2_block<DROP, MT, false>(st, sQ, sO, sLse, sDel, sMask, kf, vf, uA, 32 * qb, lane, ik_scale);
+            }
+    }
+    if (trace) ts[3] = __builtin_amdgcn_s_memrealtime();
+    if (work) {
+        if (uB != uA) load_frags(uB);            // (in flight under the first unit's store)
+        bwd_small_keys2_store(st, uA, lane, b, h, Tn, nH, inv_keep, sKeep, MT - 1, dqkv, dbias != nullptr, ck, cv);
+        if (uB != uA) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) st[j].dk[i] = st[j].dv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            bwd_small_keys2_block<DROP, MT, true>(st, sQ, sO, sLse, sDel, sMask, kf, vf, uB, 32 * uB, lane, ik_scale);
+#pragma unroll 1
+            for (int qb = uB + 1; qb < nunit; ++qb)
+                bwd_small_keys2_block<DROP, MT, false>(st, sQ, sO, sLse, sDel, sMask, kf, vf, uB, 32 * qb, lane, ik_scale);
+            bwd_small_keys2_store(st, uB, lane, b, h, Tn, nH, inv_keep, sKeep, MT - 1, dqkv, dbias != nullptr, ck, cv);
+        }
+    }
+    if (trace) ts[4] = __builtin_amdgcn_s_memrealtime();
+    if (dbias) {
+        // every wave's row of partial sums -> sBw[wave][128] (K channels, then V; over the first bytes of the Q image once
+        // every wave is done with it), then the rows added in wave order
+        __syncthreads();
+        float* sBw = reinterpret_cast<float*>(smem);
+        const int ch = (l15 >> 2) * 16 + 4 * g + (l15 & 3);
+        sBw[wave * 128 + ch] = ck;
+        sBw[wave * 128 + DH + ch] = cv;
+        __syncthreads();
+        if (tid < 2 * DH) {
+            float sm = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) sm += sBw[w * 128 + tid];
+            const int col = (1 + tid / DH) * D + h * DH + tid % DH;
+            if (bias_rows) dbias[(long)b * 3 * D + col] = sm;
+            else atomicAdd(dbias + col, sm);
+        }
+    }
+    if (trace && lane == 0) {
+        ts[5] = __builtin_amdgcn_s_memrealtime();
+        unsigned long long* r = trace + ((long)blockIdx.x * 16 + wave) * 8;
+        r[0] = ts[0]; r[1] = ts[1]; r[2] = ts[2]; r[3] = ts[3]; r[4] = ts[4]; r[5] = ts[5];
+        r[6] = __builtin_amdgcn_s_getreg((4 << 11) | 20);    // XCC_ID
+        r[7] = 1;
+    }
+}
+
 // ---- backward, dQ kernel: the 16 queries of tile t (Q, dO fragments in registers), one 32-key block
 // DIAG: the block holds the tile's diagonal (the last block of a tile's sweep); every earlier block is wholly below it
 template <bool DROP, int MT = 256, bool DIAG = true>
@@ -1446,6 +1693,8 @@ extern "C" int mmtg_attn_bwd(int dtype, const void* qkv, const int* keep, const 
             SET_LDS((attn_bwd_small_kv_kernel<false, 16, 512>), shm5); SET_LDS((attn_bwd_small_kv_kernel<true, 16, 512>), shm5);
             SET_LDS((attn_bwd_small_kv_kernel<false, 8, 512>), shm5); SET_LDS((attn_bwd_small_kv_kernel<true, 8, 512>), shm5);
             SET_LDS((attn_bwd_small_q_kernel<false, 512>), shm5); SET_LDS((attn_bwd_small_q_kernel<true, 512>), shm5);
+            SET_LDS((attn_bwd_small_kv2_kernel<false, 256>), shm2); SET_LDS((attn_bwd_small_kv2_kernel<true, 256>), shm2);
+            SET_LDS((attn_bwd_small_kv2_kernel<false, 512>), shm5); SET_LDS((attn_bwd_small_kv2_kernel<true, 512>), shm5);
 #undef SET_LDS
             if (!ok) MMTG_FAIL(MMTG_ERR_HIP, "attn_bwd: cannot raise dynamic LDS");
             attr_small = true;
@@ -1463,7 +1712,15 @@ extern "C" int mmtg_attn_bwd(int dtype, const void* qkv, const int* keep, const 
                                    (const bf16*)qkv, keep, (const bf16*)dout, lse, delta, (bf16*)dqkv, bias_dst, bias_rows, T, nH, kq, drop_seed, ik16, g_attn_trace)
 #define Q_SMALL(DROP_, MT_) hipLaunchKernelGGL((attn_bwd_small_q_kernel<DROP_, MT_>), dim3(B * nH), dim3(2 * MT_), small_smem<MT_>(T), s, \
                                    (const bf16*)qkv, keep, (const bf16*)dout, lse, delta, (bf16*)dqkv, bias_dst, bias_rows, T, nH, kq, drop_seed, ik16, g_attn_trace)
-        if (T <= 256) {
+        static const bool kv2 = !(getenv("MMTG_ATTN_KV2") && atoi(getenv("MMTG_ATTN_KV2")) == 0);     // 32 keys per wave (round 4); 0 = the 16-key builds
+#define KV2_SMALL(DROP_, MT_) hipLaunchKernelGGL((attn_bwd_small_kv2_kernel<DROP_, MT_>), dim3(B * nH), dim3(MT_), small_smem<MT_>(T), s, \
+                                   (const bf16*)qkv, keep, (const bf16*)dout, lse, delta, (bf16*)dqkv, bias_dst, bias_rows, T, nH, kq, drop_seed, ik16, g_attn_trace)
+        if (kv2 && !kv_nw) {
+            if (T <= 256) { if (drop) KV2_SMALL(true, 256); else KV2_SMALL(false, 256); }
+            else { if (drop) KV2_SMALL(true, 512); else KV2_SMALL(false, 512); }
+            if (T <= 256) { if (drop) Q_SMALL(true, 256); else Q_SMALL(false, 256); }
+            else { if (drop) Q_SMALL(true, 512); else Q_SMALL(false, 512); }
+        } else if (T <= 256) {
             const bool half = kv_nw ? kv_nw == 4 : drop;
             if (drop) { if (half) KV_SMALL(true, 4, 256); else KV_SMALL(true, 8, 256); Q_SMALL(true, 256); }
             else { if (half) KV_SMALL(false, 4, 256); else KV_SMALL(false, 8, 256); Q_SMALL(false, 256); }
@@ -1473,6 +1730,7 @@ extern "C" int mmtg_attn_bwd(int dtype, const void* qkv, const int* keep, const 
             else { if (half) KV_SMALL(false, 8, 512); else KV_SMALL(false, 16, 512); Q_SMALL(false, 512); }
         }
 #undef KV_SMALL
+#undef KV2_SMALL
 #undef Q_SMALL
     } else if (dtype == MMTG_BF16) {
         const int KB = 4 * AT<bf16>::KPW;
