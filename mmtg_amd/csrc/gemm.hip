@@ -504,6 +504,9 @@ __global__ __launch_bounds__(256, (AKS && BKS ? 4 : OCC_FWD)) void gemm_occ4_ker
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, l15 = lane & 15;
     const int wm = wave >> 1, wn = wave & 1;
+    // (the prologue's kernel arguments in one batch of scalar loads -- see gemm_p8_kernel)
+    asm volatile("" :: "s"(p.A), "s"(p.B), "s"(p.M), "s"(p.N), "s"(p.K), "s"(p.lda), "s"(p.ldb), "s"(p.ntiles), "s"(p.tiles_n),
+                 "s"(p.tiles_m_fast), "s"(p.cbw), "s"(p.bytesA), "s"(p.bytesB), "s"(p.kper));
     int m0, n0, split;
     tile_origin(p, blockIdx.x, gridDim.x, m0, n0, split, TBM, TBN);
     const int kbeg = split * p.kper;
@@ -789,9 +792,14 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(GemmArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, l15 = lane & 15;
     const int wr = wave >> 2, wc = wave & 3;
+    // Every kernel argument the prologue needs, requested in ONE batch: left to itself hipcc loads them where they are first
+    // used -- behind the branches of the trace test and of tile_origin's order modes -- as a chain of five dependent
+    // scalar-cache round trips in front of the first LDS-DMA request.
+    asm volatile("" :: "s"(p.A), "s"(p.B), "s"(p.M), "s"(p.N), "s"(p.K), "s"(p.lda), "s"(p.ldb), "s"(p.ntiles), "s"(p.tiles_n),
+                 "s"(p.tiles_m_fast), "s"(p.cbw), "s"(p.trace), "s"(p.dbg_flags), "s"(p.bytesA), "s"(p.bytesB), "s"(p.kper));
     const bool tr = p.trace != nullptr;                     // diagnostic timeline (mmtg_gemm_trace)
     unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, tc1 = 0, tc2 = 0;      // wall stamps (100 MHz) + shader-clock stamps around the K loop
-    if (tr) ts0 = __builtin_amdgcn_s_memrealtime();
+    ts0 = __builtin_amdgcn_s_memrealtime();
     int m0, n0, split;
     tile_origin(p, blockIdx.x, gridDim.x, m0, n0, split, TBM, 256);
     const int kbeg = KS ? split * p.kper : 0;               // host: K % 128 == 0; K splits (kper % 128 == 0) for KS only

@@ -196,24 +196,34 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // traffic of the wgrad GEMMs 2.3-2.8x algorithmic before, see profiles/).
 // (`bid` of `nwg` work items; a persistent launch passes item numbers bid = blockIdx.x + i * gridDim.x
 //  with gridDim.x a multiple of 8, which keeps every item on the XCD the map assumes.)
+// floor(a / b) for 0 <= a < 2^20, 0 < b < 2^20 (work-item and tile counts): one v_rcp_f32 and a multiply instead of the ~40
+// instructions of a 32-bit integer division -- a workgroup's prologue ran four of them in front of its first LDS-DMA request.
+// (a + 0.5) / b is at least 0.5 / b away from an integer, i.e. a relative 0.5 / (a + 0.5) > 4.7e-7 x 2^20 / a away; rcp + mul err
+// by < 3 ulp = 3.6e-7 relative, so the truncation lands on the exact quotient for every a < 2^20.)
+__device__ __forceinline__ int fdiv_small(int a, int b) {
+    return (int)(((float)a + 0.5f) * __builtin_amdgcn_rcpf((float)b));
+}
 __device__ __forceinline__ void tile_origin(const GemmArgs& p, int bid, int nwg, int& m0, int& n0, int& split, int bm = BM, int bn = BN) {
     const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
     const int v = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
-    split = v / p.ntiles;
+    split = fdiv_small(v, p.ntiles);
     const int t = v - split * p.ntiles;
     if (p.tiles_m_fast) {       // tile_m fastest: an XCD's run is (all tile rows) x (a few tile columns)
-        const int tm = p.ntiles / p.tiles_n;
-        m0 = (t % tm) * bm;
-        n0 = (t / tm) * bn;
+        const int tm = fdiv_small(p.ntiles, p.tiles_n);
+        const int tn = fdiv_small(t, tm);
+        m0 = (t - tn * tm) * bm;
+        n0 = tn * bn;
     } else if (p.cbw > 0) {     // column blocks whose B panels stay in the XCD's L2 while the A rows stream by
-        const int per = (p.ntiles / p.tiles_n) * p.cbw;
-        const int cb = t / per, u = t - cb * per;
+        const int per = fdiv_small(p.ntiles, p.tiles_n) * p.cbw;
+        const int cb = fdiv_small(t, per), u = t - cb * per;
         const int w = min(p.cbw, p.tiles_n - cb * p.cbw);
-        m0 = (u / w) * bm;
-        n0 = (cb * p.cbw + u % w) * bn;
+        const int um = fdiv_small(u, w);
+        m0 = um * bm;
+        n0 = (cb * p.cbw + u - um * w) * bn;
     } else {
-        m0 = (t / p.tiles_n) * bm;
-        n0 = (t % p.tiles_n) * bn;
+        const int tmi = fdiv_small(t, p.tiles_n);
+        m0 = tmi * bm;
+        n0 = (t - tmi * p.tiles_n) * bn;
     }
 }
 
