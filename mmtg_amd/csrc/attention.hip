@@ -1710,16 +1710,34 @@ extern "C" int mmtg_attn_bwd(int dtype, const void* qkv, const int* keep, const 
         static const int kv_nw = getenv("MMTG_ATTN_KV_NW") ? atoi(getenv("MMTG_ATTN_KV_NW")) : 0;
 #define KV_SMALL(DROP_, NW_, MT_) hipLaunchKernelGGL((attn_bwd_small_kv_kernel<DROP_, NW_, MT_>), dim3(B * nH), dim3(64 * NW_), small_smem<MT_>(T), s, \
                                    (const bf16*)qkv, keep, (const bf16*)dout, lse, delta, (bf16*)dqkv, bias_dst, bias_rows, T, nH, kq, drop_seed, ik16, g_attn_trace)
-#define Q_SMALL(DROP_, MT_) hipLaunchKernelGGL((attn_bwd_small_q_kernel<DROP_, MT_>), dim3(B * nH), dim3(2 * MT_), small_smem<MT_>(T), s, \
+#define Q_SMALL(DROP_, MT_) hipLaunchKernelGGL((attn_bwd_small_q_kernel<DROP_, MT_>), dim3(B * nH), dim3(2 * MT_), small_smem<MT_>(T), sq, \
                                    (const bf16*)qkv, keep, (const bf16*)dout, lse, delta, (bf16*)dqkv, bias_dst, bias_rows, T, nH, kq, drop_seed, ik16, g_attn_trace)
         static const bool kv2 = !(getenv("MMTG_ATTN_KV2") && atoi(getenv("MMTG_ATTN_KV2")) == 0);     // 32 keys per wave (round 4); 0 = the 16-key builds
 #define KV2_SMALL(DROP_, MT_) hipLaunchKernelGGL((attn_bwd_small_kv2_kernel<DROP_, MT_>), dim3(B * nH), dim3(MT_), small_smem<MT_>(T), s, \
                                    (const bf16*)qkv, keep, (const bf16*)dout, lse, delta, (bf16*)dqkv, bias_dst, bias_rows, T, nH, kq, drop_seed, ik16, g_attn_trace)
+        // MMTG_ATTN_BWD_FORK=1 (A/B, round 4): the dQ kernel on a second stream beside the dK / dV kernel (they share inputs only;
+        // the 768 + 768 workgroups then fill the half-empty second round of either kernel with the other's)
+        static const bool fork = getenv("MMTG_ATTN_BWD_FORK") && atoi(getenv("MMTG_ATTN_BWD_FORK")) == 1;
+        static hipStream_t s2 = nullptr;
+        static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+        if (fork && !s2) {
+            if (hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess)
+                MMTG_FAIL(MMTG_ERR_HIP, "attn_bwd: cannot create the side stream");
+        }
+        hipStream_t sq = s;
+        if (fork && kv2 && !kv_nw) {
+            sq = s2;
+            if (hipEventRecord(ev_fork, s) != hipSuccess || hipStreamWaitEvent(s2, ev_fork, 0) != hipSuccess) MMTG_FAIL(MMTG_ERR_HIP, "attn_bwd: fork failed");
+        }
         if (kv2 && !kv_nw) {
             if (T <= 256) { if (drop) KV2_SMALL(true, 256); else KV2_SMALL(false, 256); }
             else { if (drop) KV2_SMALL(true, 512); else KV2_SMALL(false, 512); }
             if (T <= 256) { if (drop) Q_SMALL(true, 256); else Q_SMALL(false, 256); }
             else { if (drop) Q_SMALL(true, 512); else Q_SMALL(false, 512); }
+            if (sq != s) {
+                if (hipEventRecord(ev_join, s2) != hipSuccess || hipStreamWaitEvent(s, ev_join, 0) != hipSuccess) MMTG_FAIL(MMTG_ERR_HIP, "attn_bwd: join failed");
+            }
         } else if (T <= 256) {
             const bool half = kv_nw ? kv_nw == 4 : drop;
             if (drop) { if (half) KV_SMALL(true, 4, 256); else KV_SMALL(true, 8, 256); Q_SMALL(true, 256); }
