@@ -39,6 +39,7 @@ struct WgProb {
 struct WgArgs {
     WgProb pr[WG_MAXP];
     int n, K, kper, splits, ntiles, accumulate;
+    int touch;             // MMTG_WGRAD_TOUCH: K tiles of L2 touch-prefetch lead (0 = off)
     float* ws;
     unsigned* cnt;
 };
@@ -200,6 +201,17 @@ __global__ __launch_bounds__(256, 4) void wgrad_group_kernel(WgArgs a) {
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // TOUCH (ABLATE == 3, MMTG_WGRAD_TOUCH=P): every thread requests ONE dword of one 128-byte line of the tile P steps ahead (waves
+    // 0-1: the 64 k-rows x 2 lines of the A slice, waves 2-3: of the B slice) into a register nobody reads -- the line is in the L2
+    // when the LDS-DMA of that tile asks for it.  A quarter of this launch's fill bytes are compulsory L2 misses (a K slice of 7552
+    // tokens against 3-24 tiles per operand panel), and a miss costs its whole latency: the single-stage loop has nothing else in
+    // flight.  The request is the youngest of its wave at the tile wait, so that wait becomes vmcnt(1); returns are in order, so
+    // the hipcc-tracked load is consumed one tile later, behind that tile's DMA requests (a counted wait).
+    int touch_sink = 0;
+    const bool t_b = wave >= 2;
+    const int t_row = (tid & 127) >> 1, t_half = tid & 1;
+    const int t_ok = t_b ? (n0 + t_half * 64 < N) : (m0 + t_half * 64 < M);
+    const int t_v = (int)((long)t_row * (t_b ? ldb : lda) * 2) + t_half * 128;
     for (int kt = 0; kt < nk; ++kt) {
         if (kt) __builtin_amdgcn_s_barrier();      // every wave is done reading the previous tile
         const bool full = kt < nk_full;
@@ -216,9 +228,17 @@ __global__ __launch_bounds__(256, 4) void wgrad_group_kernel(WgArgs a) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, LDS_PTR(void, smem + TA + (wave + NW * i) * 1024), 16, o, sb, 0, 0);
         }
         }
+        if constexpr (ABLATE == 3) {
+            const int tp = a.touch;
+            const int vo = (t_ok && (kt + tp) * BK + t_row < klen) ? t_v : OOB;
+            const int so = __builtin_amdgcn_readfirstlane(t_b ? sb + tp * stepb : sa + tp * stepa);
+            asm volatile("" :: "v"(touch_sink));           // the previous tile's touch is consumed HERE (a counted wait behind this tile's DMA requests)
+            if (t_b) touch_sink = __builtin_amdgcn_raw_buffer_load_b32(rb, vo, so, 0);
+            else touch_sink = __builtin_amdgcn_raw_buffer_load_b32(ra, vo, so, 0);
+        }
         sa += stepa;
         sb += stepb;
-        wait_vmcnt<0>();
+        if constexpr (ABLATE == 3) wait_vmcnt<1>(); else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();              // the tile is complete
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -240,6 +260,7 @@ __global__ __launch_bounds__(256, 4) void wgrad_group_kernel(WgArgs a) {
                 for (int j = 0; j < TN; ++j) mma16(fb[j], fa[i], acc[i][j]);
         }
     }
+    if constexpr (ABLATE == 3) { wait_vmcnt<0>(); asm volatile("" :: "v"(touch_sink)); }
     __builtin_amdgcn_s_barrier();                  // the stage becomes the waves' private epilogue scratch
     wg_reduce_store<FENCE, TM, TBM * TBN>(a, P.C, P.ldc, M, N, m0 + wm * 64, n0 + wn * 64, t, split, NW, wave, lane, acc,
                                           smem + wave * 4096);
@@ -411,6 +432,8 @@ extern "C" int mmtg_wgrad_group(int config, int n, const mmtg_wgrad_problem* pro
                  "wgrad_group: workspace needs %ld floats and %ld counters", (long)tiles * splits * TB * TB, (long)tiles * NWV);
     a.n = n; a.K = K; a.kper = kper; a.splits = splits; a.ntiles = tiles; a.accumulate = accumulate;
     a.ws = ws; a.cnt = counters;
+    static const int touch = getenv("MMTG_WGRAD_TOUCH") ? atoi(getenv("MMTG_WGRAD_TOUCH")) : 0;
+    a.touch = touch;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(MMTG_PROF_GEMM_BF16, s, flops, bytes);
     static bool attr_done = false;
@@ -445,7 +468,11 @@ extern "C" int mmtg_wgrad_group(int config, int n, const mmtg_wgrad_problem* pro
         if (ablate == 1) hipLaunchKernelGGL((wgrad_group_kernel<false, 1>), dim3(tiles * splits), dim3(256), shm, s, a);
         else hipLaunchKernelGGL((wgrad_group_kernel<false, 2>), dim3(tiles * splits), dim3(256), shm, s, a);
     } else if (fence) hipLaunchKernelGGL(wgrad_group_kernel<true>, dim3(tiles * splits), dim3(256), shm, s, a);
-    else hipLaunchKernelGGL(wgrad_group_kernel<false>, dim3(tiles * splits), dim3(256), shm, s, a);
+    else if (touch > 0) {
+        static bool t_done = false;
+        if (!t_done) { (void)hipFuncSetAttribute((const void*)wgrad_group_kernel<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); t_done = true; }
+        hipLaunchKernelGGL((wgrad_group_kernel<false, 3>), dim3(tiles * splits), dim3(256), shm, s, a);
+    } else hipLaunchKernelGGL(wgrad_group_kernel<false>, dim3(tiles * splits), dim3(256), shm, s, a);
     MMTG_LAUNCH_CHECK("wgrad_group");
     return MMTG_OK;
 }
