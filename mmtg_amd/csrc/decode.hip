@@ -714,6 +714,27 @@ __global__ __launch_bounds__(256) void decode_embed_add_kernel(const T* __restri
 // requested from the last valid row and replaced afterwards (key == pos: the token's own row, held in LDS exactly as stored).
 // The KV cache rows are read once per token step and never again by this step: with `nt` (non-temporal) they need not displace the
 // step's 193 MB of weights from the 256 MB Infinity Cache, which every step re-reads (A/B: MMTG_DECODE_KV_NT, profiles/r04_*).
+// cross-lane folds of the score loop by DPP (full-rate VALU, no LDS crossbar: the __shfl_xor forms are a ds_bpermute + address
+// arithmetic per step and sat on the per-chunk dependent chain).  fold_sum_lanes<OCT>: the sum over the OCT adjacent lanes of a key
+// (quad swaps, then the mirror inside 8 / 16 lanes: every lane ends with the group's sum).  wave_max_of_groups<OCT>: the maximum
+// over the whole wave of a value that is already uniform inside each group of OCT lanes; returned wave-uniform (readlane 63).
+template <int CTRL, int ROWS = 0xF> __device__ __forceinline__ float dpp_keep(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, x), __builtin_bit_cast(int, x), CTRL, ROWS, 0xF, false));
+}
+template <int OCT> __device__ __forceinline__ float fold_sum_lanes(float a) {
+    a += dpp_keep<0xB1>(a);                    // quad_perm [1,0,3,2]
+    a += dpp_keep<0x4E>(a);                    // quad_perm [2,3,0,1]
+    a += dpp_keep<0x141>(a);                   // row_half_mirror
+    if constexpr (OCT == 16) a += dpp_keep<0x140>(a);      // row_mirror
+    return a;
+}
+template <int OCT> __device__ __forceinline__ float wave_max_of_groups(float x) {
+    if constexpr (OCT == 8) x = fmaxf(x, dpp_keep<0x140>(x));          // the row's two groups
+    x = fmaxf(x, dpp_keep<0x142, 0xA>(x));     // row_bcast15 into rows 1, 3
+    x = fmaxf(x, dpp_keep<0x143, 0xC>(x));     // row_bcast31 into rows 2, 3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
+}
+
 template <typename V, bool NT> __device__ __forceinline__ V ld_kv(const V* p) {
     if constexpr (NT) return __builtin_nontemporal_load(p);
     else return *p;
@@ -734,7 +755,7 @@ __device__ __forceinline__ void da_body(const T* __restrict__ qkv, T* __restrict
     constexpr int EPL = Vec16<T>::N, OCT = 64 / EPL, KPI = 64 / OCT;      // elements per lane, lanes per key, keys per instruction
     // (the SAME chunking in both forms: the first chunk's scores and the later chunks' come out of differently contracted
     //  loops, so moving the chunk boundary moves last bits -- the persistent step stays bit-equal to the per-launch one)
-    constexpr int UN = 16, UN0 = 12;
+    constexpr int UN = 4, CH = UN * KPI;         // a chunk: UN keys per lane group = 32 keys (bf16) / 16 (f32)
     float* const sp = reinterpret_cast<float*>(lds);
     int* const skeep = reinterpret_cast<int*>(lds + 4096);
     float* const sq = reinterpret_cast<float*>(lds + 8192);
@@ -748,12 +769,20 @@ __device__ __forceinline__ void da_body(const T* __restrict__ qkv, T* __restrict
     const int nkeys = pos + 1;
     const int oc = lane % OCT, kg = lane / OCT;
     const int last = pos > 0 ? pos - 1 : 0;
-    V kv0[UN0], vv0[UN0];
+    // chunks 0 and 1 (K and V rows) are requested at the very top: they depend on nothing this kernel computes.  Branch-free:
+    // rows at or past `pos` are requested from the last valid row and replaced (key == pos: the token's own row, from LDS) or masked
+    V kA[UN], vA[UN], kB[UN], vB[UN];
 #pragma unroll
-    for (int u = 0; u < UN0; ++u) {
+    for (int u = 0; u < UN; ++u) {
         const int key = u * KPI + kg, kr = key < pos ? key : last;
-        kv0[u] = ld_kv<V, NT>(reinterpret_cast<const V*>(kbase + (long)kr * 64 + oc * EPL));
-        vv0[u] = ld_kv<V, NT>(reinterpret_cast<const V*>(vbase + (long)kr * 64 + oc * EPL));
+        kA[u] = ld_kv<V, NT>(reinterpret_cast<const V*>(kbase + (long)kr * 64 + oc * EPL));
+        vA[u] = ld_kv<V, NT>(reinterpret_cast<const V*>(vbase + (long)kr * 64 + oc * EPL));
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+        const int key = CH + u * KPI + kg, kr = key < pos ? key : last;
+        kB[u] = ld_kv<V, NT>(reinterpret_cast<const V*>(kbase + (long)kr * 64 + oc * EPL));
+        vB[u] = ld_kv<V, NT>(reinterpret_cast<const V*>(vbase + (long)kr * 64 + oc * EPL));
     }
     // the key-padding flags of the whole prefix in one coalesced pass, into LDS (round 3: the score loop used to read keep[]
     // from global memory key group by key group -- up to 16 DEPENDENT 4-byte loads, each a full memory round trip)
@@ -811,81 +840,66 @@ __device__ __forceinline__ void da_body(const T* __restrict__ qkv, T* __restrict
 #pragma unroll
     for (int e = 0; e < EPL; ++e) qv[e] = sq[oc * EPL + e];
     const V knew = *reinterpret_cast<const V*>(sk + oc * EPL), vnew = *reinterpret_cast<const V*>(sv + oc * EPL);
-#pragma unroll
-    for (int u = 0; u < UN0; ++u) {
-        const int key = u * KPI + kg;
-        const bool isnew = key == pos;
-        float a = 0.f;
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) {
-            a += qv[e] * (float)(isnew ? knew[e] : kv0[u][e]);
-            vv0[u][e] = isnew ? vnew[e] : vv0[u][e];
-        }
-#pragma unroll
-        for (int o = 1; o < OCT; o <<= 1) a += __shfl_xor(a, o, 64);
-        if (oc == 0 && key < nkeys) sp[key] = skeep[key] ? a : -INFINITY;
-    }
-    // ---- scores of the later chunks: UN independent 16-byte loads per lane are requested before the first is used
-    //      (the token's own row was stored above and is published by the barrier: re-read from the cache like any other)
-#pragma unroll 1
-    for (int k0 = UN0 * KPI; k0 < nkeys; k0 += UN * KPI) {
-        V kv[UN];
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const int key = k0 + u * KPI + kg;
-            kv[u] = ld_kv<V, NT>(reinterpret_cast<const V*>(kbase + (long)(key < nkeys ? key : pos) * 64 + oc * EPL));
-        }
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const int key = k0 + u * KPI + kg;
-            float a = 0.f;
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) a += qv[e] * (float)kv[u][e];
-#pragma unroll
-            for (int o = 1; o < OCT; o <<= 1) a += __shfl_xor(a, o, 64);
-            if (oc == 0 && key < nkeys) sp[key] = skeep[key] ? a : -INFINITY;
-        }
-    }
-    DA_SYNC();
-    float mx = -INFINITY;
-    for (int key = lane; key < nkeys; key += 64) mx = fmaxf(mx, sp[key]);
-    mx = wave_max(mx);
-    const float muse = mx == -INFINITY ? 0.f : mx;
-    float sum = 0.f;
-    for (int key = lane; key < nkeys; key += 64) {
-        const float s = sp[key];
-        const float p = s == -INFINITY ? 0.f : expf(s - muse);
-        sp[key] = p;
-        sum += p;
-    }
-    sum = wave_sum(sum);
-    DA_SYNC();
-    // ---- values: the first chunk from the rows already in registers, later chunks from the cache
+    // ---- ONE pass over the cache (round 4): scores, running maximum / sum and the value accumulation per chunk of CH keys, all in
+    // registers -- a lane group's eight (bf16) lanes all hold the score of the group's key after the fold, and the same lanes own the
+    // channel octets of that key's value row, so no score ever goes through LDS.  Two chunks are always in flight (buffer c & 1 is
+    // refilled with chunk c + 2 as soon as chunk c is consumed): the two-pass form walked the cache as K chunks, then softmax, then V
+    // chunks -- up to five DEPENDENT memory round trips per layer at a full prefix against two here.
+    float m_run = -INFINITY, sum = 0.f;
     float acc[EPL];
 #pragma unroll
     for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
-#pragma unroll
-    for (int u = 0; u < UN0; ++u) {
-        const int key = u * KPI + kg;
-        const float pp = key < nkeys ? sp[key] : 0.f;
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) acc[e] += pp * (float)vv0[u][e];
-    }
+#define DA_STEP(KB_, VB_, K0_)                                                                                       \
+    do {                                                                                                             \
+        float a_[UN];                                                                                                \
+        float cm_ = -INFINITY;                                                                                       \
+        _Pragma("unroll") for (int u = 0; u < UN; ++u) {                                                             \
+            const int key = (K0_) + u * KPI + kg;                                                                    \
+            const bool isnew = key == pos;                                                                           \
+            float a = 0.f;                                                                                           \
+            _Pragma("unroll") for (int e = 0; e < EPL; ++e) {                                                        \
+                a += qv[e] * (float)(isnew ? knew[e] : KB_[u][e]);                                                   \
+                VB_[u][e] = isnew ? vnew[e] : VB_[u][e];                                                             \
+            }                                                                                                        \
+            a = fold_sum_lanes<OCT>(a);                                                                              \
+            a_[u] = (key < nkeys && skeep[key < nkeys ? key : pos]) ? a : -INFINITY;                                 \
+            cm_ = fmaxf(cm_, a_[u]);                                                                                 \
+        }                                                                                                            \
+        cm_ = wave_max_of_groups<OCT>(cm_);                                                                          \
+        const float m_new = fmaxf(m_run, cm_);                                                                       \
+        const float muse = m_new == -INFINITY ? 0.f : m_new;                                                         \
+        const float alpha = expf(m_run - muse);                                                                      \
+        sum *= alpha;                                                                                                \
+        _Pragma("unroll") for (int e = 0; e < EPL; ++e) acc[e] *= alpha;                                             \
+        _Pragma("unroll") for (int u = 0; u < UN; ++u) {                                                             \
+            const float p = a_[u] == -INFINITY ? 0.f : expf(a_[u] - muse);                                           \
+            sum += p;                                                                                                \
+            _Pragma("unroll") for (int e = 0; e < EPL; ++e) acc[e] += p * (float)VB_[u][e];                          \
+        }                                                                                                            \
+        m_run = m_new;                                                                                               \
+    } while (0)
+#define DA_ISSUE(KB_, VB_, K0_)                                                                                      \
+    do {                                                                                                             \
+        _Pragma("unroll") for (int u = 0; u < UN; ++u) {                                                             \
+            const int key = (K0_) + u * KPI + kg, kr = key < pos ? key : last;                                       \
+            KB_[u] = ld_kv<V, NT>(reinterpret_cast<const V*>(kbase + (long)kr * 64 + oc * EPL));                     \
+            VB_[u] = ld_kv<V, NT>(reinterpret_cast<const V*>(vbase + (long)kr * 64 + oc * EPL));                     \
+        }                                                                                                            \
+    } while (0)
 #pragma unroll 1
-    for (int k0 = UN0 * KPI; k0 < nkeys; k0 += UN * KPI) {
-        V vv[UN];
-        float pp[UN];
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const int key = k0 + u * KPI + kg;
-            vv[u] = ld_kv<V, NT>(reinterpret_cast<const V*>(vbase + (long)(key < nkeys ? key : pos) * 64 + oc * EPL));
-            pp[u] = key < nkeys ? sp[key] : 0.f;
+    for (int k0 = 0; k0 < nkeys; k0 += 2 * CH) {
+        DA_STEP(kA, vA, k0);
+        if (k0 + 2 * CH < nkeys) DA_ISSUE(kA, vA, k0 + 2 * CH);
+        if (k0 + CH < nkeys) {
+            DA_STEP(kB, vB, k0 + CH);
+            if (k0 + 3 * CH < nkeys) DA_ISSUE(kB, vB, k0 + 3 * CH);
         }
-#pragma unroll
-        for (int u = 0; u < UN; ++u)
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) acc[e] += pp[u] * (float)vv[u][e];
     }
+#undef DA_STEP
+#undef DA_ISSUE
+    // fold over the key groups: every lane group holds the partial sums of ITS keys (the same value in its OCT lanes)
+#pragma unroll
+    for (int o = OCT; o < 64; o <<= 1) sum += __shfl_xor(sum, o, 64);
 #pragma unroll
     for (int e = 0; e < EPL; ++e)
 #pragma unroll
@@ -903,7 +917,7 @@ __device__ __forceinline__ void da_body(const T* __restrict__ qkv, T* __restrict
 }
 
 template <typename T, bool NT = false>
-__global__ __launch_bounds__(64) void decode_attn_kernel(const T* __restrict__ qkv, T* __restrict__ kc, T* __restrict__ vc,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void decode_attn_kernel(const T* __restrict__ qkv, T* __restrict__ kc, T* __restrict__ vc,
         const int* __restrict__ keep, long ldkeep, const int* __restrict__ pos_ptr, T* __restrict__ out,
         int nH, int Tmax, const float* __restrict__ part, int splits, long slab, const float* __restrict__ bias) {
     __shared__ __attribute__((aligned(16))) char lds[da_lds_bytes<T>()];
