@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MMTG_ABI_VERSION 6
+#define MMTG_ABI_VERSION 7
 
 /* The library is built with -fvisibility=hidden: only the entry points below are exported. */
 #define MMTG_API __attribute__((visibility("default")))
@@ -426,6 +426,17 @@ MMTG_API int mmtg_decode_persist_grid(void);
  * stage s ([2 s]), after the barrier behind it ([2 s + 1]) and at kernel entry ([2 * stages]) */
 MMTG_API int mmtg_decode_persist_trace(void* buf);
 MMTG_API int mmtg_decode_persist(const void* stages_dev, int nstages, void* barrier_ws, long barrier_bytes, int* err_flag, void* stream);
+
+/* Round 4 (ABI 7), CHAINED launch: the product stages [first, first + count) of an uploaded stage list (mmtg_decode_stage_gemm
+ * descriptors; count <= 8) as ONE launch of `nitems` = the sum of their item counts workgroups, one 64 x 64 tile item each, in
+ * stage order.  An item of stage j > 0 starts when the 64-row block it reads has been stored completely by stage j - 1 -- a
+ * counter per row block (deps: 4096 zero-initialised 32-bit words per link -- the words of two row blocks sit 128 bytes apart --, re-armed by the last consumer of a block), bumped by
+ * every wave after its write-through stores were acknowledged -- instead of behind a kernel boundary; activations, LayerNorm
+ * statistics, residual rows and split-K partials move through agent-scope accesses.  Replaces, per GPT-2 block of the greedy decode
+ * step behind /root/reference/src/generate.py:124, the four launches attn.c_proj -> mlp.c_fc -> mlp.c_proj -> (next block's
+ * c_attn | LM head): same arithmetic per item, bit-equal ids.  Every poll is bounded (0.2 s): on a timeout *err_flag becomes
+ * non-zero, every workgroup leaves, the outputs are undefined and the caller falls back to the per-launch step. */
+MMTG_API int mmtg_decode_chain(const void* stages_dev, int first, int count, int nitems, unsigned* deps, long deps_words, int* err_flag, void* stream);
 /* Wf[n, k] = gamma[k] W[n, k] (bf16), colsum[n] = sum_k Wf[n, k], bias_f[n] = bias[n] + sum_k beta[k] W[n, k]: the operands of the
  * LN-fold products, LN(x) W^T + b = rstd (x Wf^T - mu colsum) + bias_f.  W: [N, ldw] bf16 K-contiguous; bias may be null.   */
 MMTG_API int mmtg_ln_fold_weights(const void* W, long ldw, const float* gamma, const float* beta, const float* bias, void* Wf,

@@ -414,14 +414,33 @@ __device__ __forceinline__ void dg_st2_agent(__amdgpu_buffer_rsrc_t r, int byte_
 __device__ __forceinline__ uint32_t dg_ld1_agent(__amdgpu_buffer_rsrc_t r, int byte_off) { return __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 16); }
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t dg_rsrc(const void* p, int bytes) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000); }
 
+// Chained launch (mmtg_decode_chain, round 4): several dependent products in ONE launch, one item per workgroup; an item of a later
+// stage waits until the 64-row block it reads has been written completely by the stage before it (a counter per row block, bumped
+// by every wave that stored a wave tile of that block) instead of behind a kernel boundary.  `wait` / `done`: counters of the block;
+// `seen`: how many consumers have passed the wait -- the last one re-arms both words for the next launch.  Polls are bounded.
+struct DgDep {
+    unsigned* wait; unsigned expected; unsigned* seen; unsigned consumers;     // null wait: no dependency inside the launch
+    unsigned sleep0;                                                           // ~4 us naps before the first poll
+    unsigned* done;                                                            // null: nobody inside the launch waits for this stage
+    int* err; int* s_flag;                                                     // error word (device), verdict word (LDS)
+    unsigned long long t_wait;                                                 // diagnostic: wall stamp when thread 0 passed the wait
+};
+constexpr unsigned long long DG_TIMEOUT_TICKS = 20000000ull;                   // 0.2 s of the 100 MHz wall counter per wait
+constexpr int DG_DEP_STRIDE = 32;              // 32-bit words between the counters of two row blocks (128 bytes: one line, one channel each)
+constexpr int DG_DEP_LINK = 2 * 64 * DG_DEP_STRIDE;        // words per link: 64 row-block counters + 64 consumer counts
+
 // One 64 x 64 output tile (x one K slice) = work item `bid`.  COH = false: the stand-alone launches (one item per workgroup).
 // COH = true: the persistent token step (decode_persist_kernel) -- activations, statistics and slabs move through agent-scope
 // accesses; the caller puts a workgroup barrier between two items (LDS ring / statistics reuse).
-template <int MODE, bool COH, int NBUF, int MAXS = 8>
-__device__ __forceinline__ void dg_tile(const DgArgs& p, const int bid, char* smem) {
+// COHL: the LOADS of activations / statistics / residual rows carry the agent scope too (the persistent form: a buffer may be read,
+// rewritten by a later stage and read again inside one launch, so a consumer's L2 can hold a stale line); the chained launch orders its
+// stages so that no tensor is read again after it was rewritten inside the launch, and reads through the L2 like a stand-alone launch
+// (a line a consumer asks for after its row block's counter is complete was never in its L2 before: the launch began with an invalidate).
+template <int MODE, bool COH, int NBUF, int MAXS = 8, bool CHAIN = false, bool COHL = COH>
+__device__ __forceinline__ void dg_tile(const DgArgs& p, const int bid, char* smem, const DgDep* dep = nullptr) {
     constexpr int TB = 64, NW = 4, BK = 64, NB = 2;
     constexpr int TA = TB * 128, STAGE = 2 * TA;
-    constexpr int AUXA = COH ? 16 : 0;                                // cache policy of the activation operand's LDS-DMA
+    constexpr int AUXA = COHL ? 16 : 0;                               // cache policy of the activation operand's LDS-DMA
     float* const smu = reinterpret_cast<float*>(smem + NBUF * STAGE);
     float* const srs = smu + TB;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -445,6 +464,47 @@ __device__ __forceinline__ void dg_tile(const DgArgs& p, const int bid, char* sm
     for (int i = 0; i < NB; ++i) {
         va[i] = dma_voff<false, TB>(p.lda, m0, p.M, BK, wave + NW * i, lane);
         vb[i] = dma_voff<false, TB>(p.ldw, n0, p.N, BK, wave + NW * i, lane);
+    }
+    const int rblk = m0 / TB;
+    if constexpr (CHAIN) {
+        if (dep->wait) {
+            // the rows this item reads (activations, statistics, residual) are complete when every wave tile of the block has been
+            // stored AND acknowledged (the producers' s_waitcnt vmcnt(0) in front of their increment)
+            if (tid == 0) {
+                int ok = 1;
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                // Polls go past the L2 to ONE memory channel per word: hundreds of workgroups polling every few hundred cycles made
+                // that channel the slowest line of every K tile of the stages that were running (first version: the c_fc stage took
+                // 22-38 us instead of 7).  So: the words of different row blocks sit 128 bytes apart, a stage sleeps through the time
+                // its producers need at least (`sleep0` x ~4 us) before its first poll, and polls ~0.6 us apart afterwards.
+                for (unsigned i = 0; i < dep->sleep0; ++i) __builtin_amdgcn_s_sleep(127);
+                unsigned it_ = 0;
+                while (__hip_atomic_load(dep->wait + rblk * DG_DEP_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < dep->expected) {
+#ifdef MMTG_CHAIN_SLEEP_X
+                    __builtin_amdgcn_s_sleep(60);
+#else
+                    __builtin_amdgcn_s_sleep(20);
+#endif
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > DG_TIMEOUT_TICKS ||
+                        ((++it_ & 63u) == 0 && __hip_atomic_load(dep->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                        __hip_atomic_store(dep->err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ok = 0;
+                        break;
+                    }
+                }
+                if (ok) {       // the last consumer of the block re-arms its words (every producer and consumer has passed them)
+                    const unsigned sn = __hip_atomic_fetch_add(dep->seen + rblk * DG_DEP_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (sn == dep->consumers - 1) {
+                        __hip_atomic_store(dep->wait + rblk * DG_DEP_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(dep->seen + rblk * DG_DEP_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                *dep->s_flag = ok;
+                const_cast<DgDep*>(dep)->t_wait = __builtin_amdgcn_s_memrealtime();
+            }
+            __syncthreads();
+            if (!*dep->s_flag) return;
+        }
     }
     f32x4 acc[2][2];
 #pragma unroll
@@ -476,7 +536,7 @@ __device__ __forceinline__ void dg_tile(const DgArgs& p, const int bid, char* sm
             const int m = min(m0 + tid, p.M - 1);
             const f32x4* src = reinterpret_cast<const f32x4*>(p.stats_in + (long)m * DG_NP * 2);
             f32x4 sp[DG_NP / 2];
-            if constexpr (COH) {
+            if constexpr (COHL) {
                 const __amdgpu_buffer_rsrc_t rs = dg_rsrc(p.stats_in, p.M * DG_NP * 2 * 4);
 #pragma unroll
                 for (int i = 0; i < DG_NP / 2; ++i) sp[i] = i * 2 < p.np_in ? dg_ld4_agent(rs, (m * DG_NP * 2 + 4 * i) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -558,6 +618,12 @@ __device__ __forceinline__ void dg_tile(const DgArgs& p, const int bid, char* sm
                 }
             }
         }
+        if constexpr (CHAIN) {
+            if (dep->done) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's write-through stores have been acknowledged
+                if (lane == 0) __hip_atomic_fetch_add(dep->done + rblk * DG_DEP_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     } else {
         // ---- split-K reduced by the last-arriving wave (csrc/wgrad.hip), + bias + residual + row statistics
         const int S = p.splits;
@@ -610,7 +676,7 @@ __device__ __forceinline__ void dg_tile(const DgArgs& p, const int bid, char* sm
                         for (int r = 0; r < 4; ++r) xr[r] = (float)e0[r] + (float)e1[r];
                     } else {
                         bf16x4 x4;
-                        if constexpr (COH) {            // two 4-byte agent-scope loads (the measured-valid widths: 4 / 16 bytes)
+                        if constexpr (COHL) {           // two 4-byte agent-scope loads (the measured-valid widths: 4 / 16 bytes)
                             const __amdgpu_buffer_rsrc_t rr = dg_rsrc(p.resid, p.bytesR);
                             const int o_ = (int)(((long)m * p.ldr + n) * 2);
                             const u32x2 w = {dg_ld1_agent(rr, o_), dg_ld1_agent(rr, o_ + 4)};
@@ -643,6 +709,12 @@ __device__ __forceinline__ void dg_tile(const DgArgs& p, const int bid, char* sm
                     dst[0] = r1;
                     dst[1] = r2;
                 }
+            }
+        }
+        if constexpr (CHAIN) {
+            if (dep->done) {       // (only the wave that wrote the wave tile gets here: the other splits returned above)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_fetch_add(dep->done + rblk * DG_DEP_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }
@@ -1079,6 +1151,54 @@ __global__ __launch_bounds__(256, WPC) void decode_persist_kernel(const PStage* 
     }
 }
 
+// ---- chained launch: stages [first, first + count) of a stage list (products only) in ONE launch, one item per workgroup in
+// stage order (the dispatcher hands workgroups out in index order, so a stage's producers are resident before -- or exit before --
+// its consumers get their slots; a consumer that cannot make progress within DG_TIMEOUT_TICKS raises the error word and everybody
+// leaves: the host falls back to the per-launch step).  deps: count - 1 links of 128 words (64 row-block counters + 64 consumer
+// counts), zero between launches.  Per item the arithmetic is the stand-alone launch's (dg_tile), activations / statistics /
+// residual / partials through agent-scope accesses as in the persistent form: the ids are bit-equal to the per-launch step's.
+constexpr int chain_lds() { return 4 * 2 * 64 * 128 + 2 * 64 * 4 + 16; }
+__global__ __launch_bounds__(256, 2) void decode_chain_kernel(const PStage* __restrict__ stages, int first, int count, unsigned* deps, int* err,
+                                                              unsigned long long* __restrict__ trace) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned long long te = __builtin_amdgcn_s_memrealtime();
+    int it = blockIdx.x, j = 0;
+    while (j + 1 < count && it >= stages[first + j].nitems) { it -= stages[first + j].nitems; ++j; }
+    const PStage& S = stages[first + j];
+    DgDep dep;
+    dep.err = err;
+    dep.s_flag = reinterpret_cast<int*>(smem + chain_lds() - 16);
+    dep.wait = nullptr; dep.seen = nullptr; dep.expected = 0; dep.consumers = 0; dep.sleep0 = 0;
+    if (j > 0) {
+        const PStage& Pv = stages[first + j - 1];
+        dep.wait = deps + (long)(j - 1) * DG_DEP_LINK;
+        dep.seen = dep.wait + 64 * DG_DEP_STRIDE;
+#ifdef MMTG_CHAIN_SLEEP_X
+        dep.sleep0 = (unsigned)(MMTG_CHAIN_SLEEP_X * j * (j + 1) / 2);
+#else
+        dep.sleep0 = (unsigned)(j * (j + 1) / 2);          // 1, 3, 6, ... naps: a product takes at least ~4 us
+#endif
+        dep.expected = 4u * (unsigned)Pv.g.tiles_n * (Pv.kind == 2 ? 1u : (unsigned)Pv.g.splits);
+        dep.consumers = (unsigned)S.g.tiles_n * (unsigned)S.g.splits;
+    }
+    dep.done = j + 1 < count ? deps + (long)j * DG_DEP_LINK : nullptr;
+    dep.t_wait = 0;
+#ifdef MMTG_CHAIN_PLAIN_STORES          // timing experiment only (results undefined): ordinary write-back stores of the stage outputs
+    constexpr bool CST = false;
+#else
+    constexpr bool CST = true;
+#endif
+    if (S.kind == 0) dg_tile<0, CST, 4, 8, true, false>(S.g, it, smem, &dep);
+    else if (S.kind == 1) dg_tile<1, CST, 4, 8, true, false>(S.g, it, smem, &dep);
+    else dg_tile<2, CST, 4, 8, true, false>(S.g, it, smem, &dep);
+    // diagnostic timeline (mmtg_decode_persist_trace): per workgroup [stage, entry, wait passed, exit] (thread 0; a wave that
+    // returned early from a reduce item has no exit stamp of its own: thread 0's is the workgroup's first wave)
+    if (trace && threadIdx.x == 0) {
+        unsigned long long* r = trace + (long)blockIdx.x * 4;
+        r[0] = (unsigned long long)j; r[1] = te; r[2] = dep.t_wait ? dep.t_wait : te; r[3] = __builtin_amdgcn_s_memrealtime();
+    }
+}
+
 }  // namespace
 
 extern "C" int mmtg_decode_embed(int dtype, const void* table, const long long* seq, long ldseq, const void* c, void* x,
@@ -1345,6 +1465,23 @@ extern "C" int mmtg_decode_persist_grid(void) {
         grid = per * prop.multiProcessorCount;
     }
     return grid;
+}
+
+extern "C" int mmtg_decode_chain(const void* stages_dev, int first, int count, int nitems, unsigned* deps, long deps_words, int* err_flag, void* stream) {
+    MMTG_REQUIRE(stages_dev && deps && err_flag, "decode_chain: null pointer");
+    MMTG_REQUIRE(first >= 0 && count >= 1 && count <= 8 && nitems > 0, "decode_chain: 1-8 stages, a positive item count");
+    MMTG_REQUIRE(deps_words >= (long)DG_DEP_LINK * (count - 1), "decode_chain: the dependency words are %d per link (zero-initialised)", DG_DEP_LINK);
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)decode_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, chain_lds()) != hipSuccess)
+            MMTG_FAIL(MMTG_ERR_HIP, "decode_chain: cannot raise dynamic LDS to %d bytes", chain_lds());
+        attr_done = true;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(MMTG_PROF_GEMM_BF16, s, 0.0, 0.0);
+    hipLaunchKernelGGL(decode_chain_kernel, dim3(nitems), dim3(256), chain_lds(), s, (const PStage*)stages_dev, first, count, deps, err_flag, g_ps_trace);
+    MMTG_LAUNCH_CHECK("decode_chain");
+    return MMTG_OK;
 }
 
 extern "C" int mmtg_decode_persist(const void* stages_dev, int nstages, void* barrier_ws, long barrier_bytes, int* err_flag, void* stream) {

@@ -132,6 +132,22 @@ class GreedyDecoder:
                     self.bar = torch.zeros(512, dtype=torch.int64, device=dev)          # 4096 bytes, owned by the kernel from here on
                     self.err = torch.zeros(1, dtype=torch.int32, device=dev)
                     self.stage_lists = {}
+                # Round 4, chained launches (OPT-IN, MMTG_DECODE_CHAIN=1): per block attn.c_proj -> mlp.c_fc -> mlp.c_proj as ONE launch
+                # (mmtg_decode_chain) -- an item of a later product starts when the 64-row block it reads is complete (a counter per
+                # row block) instead of behind a kernel boundary: 41 launches per token step instead of 65, bit-equal ids (the
+                # arithmetic per item is the stand-alone launch's).  Measured SLOWER: a chain takes 38-42 us against 26 us for its
+                # three launches (1172 us per token step against 683 before the polls were throttled) -- hand-offs between XCDs go
+                # through memory (write-through stores, their acknowledgement, an atomic, a poll past the L2, cold first tiles), which
+                # costs each stage more than the ~4 us kernel boundary it replaces (the per-workgroup timeline:
+                # tools/decode_chain_timeline.py).  A wait that ran into its time bound raises the error word; ``generate`` then
+                # repeats the generation with the per-launch step.
+                # (not for lanes: an opt-in mode whose side-by-side kernels were never measured with it)
+                self.chain = (not self.persist and _parent is None and self.lanes == 1 and os.environ.get("MMTG_DECODE_CHAIN", "0") == "1"
+                              and max(self.splits[1], self.splits[3]) <= 4 and B <= 64 * 64)
+                if self.chain:
+                    self.deps = torch.zeros(4096 * 7, dtype=torch.int32, device=dev)
+                    self.err = torch.zeros(1, dtype=torch.int32, device=dev)
+                    self.chain_lists = {}
         self.pos, self.pos_next = self.pos_pair
         self.uniforms = None
         self.graphs = {}
@@ -317,6 +333,46 @@ class GreedyDecoder:
             sl.gemm(0, x, wf, self.logits, B, eng.layout.Vpad, D, bias=bh, colsum=c, stats_in=st, np_in=NP, eps=sh.eps, out_f32=True)
         return sl.upload(eng.dev)
 
+    def _chain_list(self, hcur, hnext, with_head):
+        """attn.c_proj, mlp.c_fc and mlp.c_proj of every block as one stage list; chains[l] = (first stage, stages, work items) of
+        block l's chained launch."""
+        eng, sh, B = self.eng, self.eng.sh, self.B
+        D = sh.D
+        pre = "decoder.gpt2.transformer."
+        sq, sp, _, s2 = self.splits
+        NP = D // 32
+        x, xo = hcur, hnext
+        st, sto = self.st
+        sl = hip.DecodeStages(3 * sh.L)
+        chains = []
+        for l in range(sh.L):
+            p = f"{pre}h.{l}."
+            first = sl.n
+            sl.gemm(2, self.ctx, eng.Wt(p + "attn.c_proj.weight"), xo, B, D, D, bias=eng.P(p + "attn.c_proj.bias"), resid=x,
+                    stats_out=sto, splits=sp, ws=self.rws, counters=self.rcnt)
+            wf, c, bfc = self.ffc[l]
+            sl.gemm(0, xo, wf, self.g, B, 4 * D, D, bias=bfc, colsum=c, stats_in=sto, np_in=NP, eps=sh.eps, act=hip.EPI_GELU)
+            sl.gemm(2, self.g, eng.Wt(p + "mlp.c_proj.weight"), x, B, D, 4 * D, bias=eng.P(p + "mlp.c_proj.bias"), resid=xo,
+                    stats_out=st, splits=s2, ws=self.rws, counters=self.rcnt)
+            # (the next block's c_attn / the head stay launches of their own: they read the residual stream that this chain's first
+            #  stage read as its residual BEFORE the third rewrote it -- a consumer's L2 could still hold the old line, and reading it
+            #  past the L2 costs the product more than the launch boundary: measured 1267 vs 683 us per token step)
+            chains.append((first, sl.n - first, sum(sl.items[first:sl.n])))
+        sl.upload(eng.dev)
+        return sl, chains
+
+    def check_chain(self):
+        """True if a wait of a chained launch ran into its time bound since the last check (the outputs are then undefined);
+        re-arms the words and turns the chained launches off for this decoder."""
+        if getattr(self, "chain", False) and int(self.err.item()) != 0:
+            self.deps.zero_()
+            self.err.zero_()
+            self.rcnt.zero_()
+            self.chain = False
+            self.graphs = {}
+            return True
+        return False
+
     def check_persist(self):
         """Raises if a barrier of the persistent kernel ran into its time bound (not every workgroup was resident): the step's
         outputs are then undefined.  Re-arms the decoder (one host read; ``generate`` calls it once per generation)."""
@@ -347,6 +403,23 @@ class GreedyDecoder:
         nslab = -(-D // kper)
         x, xo = hcur, hnext
         st, sto = self.st
+        if getattr(self, "chain", False):
+            cl = self.chain_lists.get(with_head)
+            if cl is None:
+                cl = self.chain_lists[with_head] = self._chain_list(hcur, hnext, with_head)
+            sl, chains = cl
+            for l in range(sh.L):
+                wf, c, bq = self.fq[l]
+                hip.decode_gemm(1, x, wf, self.part, B, 3 * D, D, colsum=c, stats_in=st, np_in=NP, eps=sh.eps, out_f32=True, splits=sq)
+                hip.decode_attn_split(self.part, nslab, bq, self.kc[l], self.vc[l], self.keep, self.pos,
+                                      self.ctx, B, sh.nH, 64, self.Tmax)
+                first, count, nitems = chains[l]
+                hip.decode_chain(sl, first, count, nitems, self.deps, self.err)
+            if with_head:
+                wf, c, bh = self.fh
+                hip.decode_gemm(0, x, wf, self.logits, B, eng.layout.Vpad, D, bias=bh, colsum=c, stats_in=st, np_in=NP, eps=sh.eps,
+                                out_f32=True)
+            return
         for l in range(sh.L):
             p = f"{pre}h.{l}."
             wf, c, bq = self.fq[l]
@@ -392,6 +465,10 @@ class GreedyDecoder:
         if getattr(self, "persist", False):
             return ("decode token step: decode_persist_kernel -- the twelve blocks and the head as one persistent launch (64x64 weight-"
                     "streaming tiles + KV-cache streaming, 61 stages behind a two-level device-wide barrier, agent-scope hand-offs)")
+        if getattr(self, "chain", False):
+            return ("decode token step: decode_gemm_kernel<64x64> (c_attn, head) + decode_chain_kernel (per block attn.c_proj -> c_fc -> "
+                    "mlp.c_proj as one launch of 64x64 weight-streaming tiles, row-block counters instead of kernel boundaries; split-K "
+                    "reduced in the kernel, LayerNorm applied algebraically) + decode_attn KV-cache streaming (one pass), 3 graph nodes per block")
         if getattr(self, "fused", False):
             return ("decode token step: decode_gemm_kernel<64x64> weight streaming (split-K reduced in the kernel, LayerNorm applied "
                     "algebraically) + decode_attn KV-cache streaming, 5 graph nodes per block")
@@ -474,6 +551,10 @@ class GreedyDecoder:
             self.use_graph = saved_mode
         for d in ([self] + self.children):
             d.check_persist()
+        if any(d.check_chain() for d in ([self] + self.children)):
+            # a chained launch gave up (its producers were not resident in time): the outputs are undefined -- the generation is
+            # repeated with the per-launch step, which this decoder keeps from here on
+            return self.generate(batch, length, temperature, repitition_penalty, top_k, top_p, generator, use_graph, teacher, tap)
         return self.seq[:, sh.P:sh.P + 1 + length].clone()
 
     @staticmethod

@@ -13,7 +13,7 @@ import os
 import torch
 
 F32, BF16 = 0, 1
-ABI_VERSION = 6
+ABI_VERSION = 7
 EPI_NONE, EPI_GELU, EPI_TANH, EPI_RESID, EPI_DGELU, EPI_DTANH, EPI_ATOMIC, EPI_ROWDOT = range(8)
 GEMM_NO_TR, GEMM_REGSTAGE, GEMM_SKINNY, GEMM_NO_SKINNY, GEMM_WIDE, GEMM_NO_WIDE = 1, 2, 4, 8, 16, 32
 GEMM_PERSIST, GEMM_NO_PERSIST, GEMM_ROW_ORDER, GEMM_OCC4, GEMM_NO_OCC4, GEMM_COL_BLOCK, GEMM_P256, GEMM_NO_P8, GEMM_P8 = 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384
@@ -88,6 +88,7 @@ _SIGS = {
     "mmtg_decode_persist_grid": ([], _i),
     "mmtg_decode_persist_trace": ([_vp], _i),
     "mmtg_decode_persist": ([_vp, _i, _vp, _l, _vp, _vp], _i),
+    "mmtg_decode_chain": ([_vp, _i, _i, _i, _vp, _l, _vp, _vp], _i),
     "mmtg_decode_attn": ([_i, _vp, _vp, _vp, _vp, _l, _vp, _vp, _i, _i, _i, _i, _vp], _i),
     "mmtg_decode_attn_split": ([_i, _vp, _i, _vp, _vp, _vp, _vp, _l, _vp, _vp, _i, _i, _i, _i, _vp], _i),
     "mmtg_logits_process_sample": ([_vp, _l, _i, _vp, _l, _vp, _f, _f, _i, _f, _vp, _vp, _vp, _i, _vp], _i),
@@ -535,6 +536,7 @@ class DecodeStages:
         self.nbytes = int(lib().mmtg_decode_stage_bytes())
         self.buf = C.create_string_buffer(self.nbytes * capacity)
         self.capacity, self.n = capacity, 0
+        self.items = []         # work items (64 x 64 tiles x K slices) per product stage, 0 for attention stages
         self.keep = []          # the tensors whose addresses the descriptors hold stay alive with the list
 
     def gemm(self, mode, A, W, C_, M, N, K, bias=None, colsum=None, stats_in=None, np_in=0, eps=1e-5, act=EPI_NONE, out_f32=False,
@@ -545,6 +547,8 @@ class DecodeStages:
                                             int(out_f32), _p(resid), N, _p(stats_out), int(splits), _p(ws), 0 if ws is None else ws.numel(),
                                             _p(counters), 0 if counters is None else counters.numel()), "decode_stage_gemm")
         self.keep += [A, W, C_, bias, colsum, stats_in, resid, stats_out, ws, counters]
+        kper = -(-(-(-K // int(splits))) // 64) * 64          # (as mmtg_decode_stage_gemm: K slices are whole 64-deep tiles)
+        self.items.append(-(-M // 64) * -(-N // 64) * -(-K // kper))
         self.n += 1
 
     def attn(self, part, splits, bias, kcache, vcache, keep, pos, out, B, nH, dh, Tmax):
@@ -552,6 +556,7 @@ class DecodeStages:
         _check(lib().mmtg_decode_stage_attn(C.addressof(self.buf), self.n, _p(part), int(splits), _p(bias), _p(kcache), _p(vcache), _p(keep),
                                             keep.stride(0), _p(pos), _p(out), B, nH, dh, Tmax), "decode_stage_attn")
         self.keep += [part, bias, kcache, vcache, keep, pos, out]
+        self.items.append(0)
         self.n += 1
 
     def upload(self, device):
@@ -573,6 +578,12 @@ def decode_persist(stages, barrier_ws, err_flag):
     """One launch for all the stages of a DecodeStages list (uploaded)."""
     _check(lib().mmtg_decode_persist(_p(stages.dev), stages.n, _p(barrier_ws), barrier_ws.numel() * barrier_ws.element_size(), _p(err_flag),
                                      _stream()), "decode_persist")
+
+
+def decode_chain(stages, first, count, nitems, deps, err_flag):
+    """Stages [first, first + count) of an uploaded DecodeStages list (products only) as one chained launch."""
+    _check(lib().mmtg_decode_chain(_p(stages.dev), int(first), int(count), int(nitems), _p(deps), deps.numel(), _p(err_flag), _stream()),
+           "decode_chain")
 
 
 def ln_fold_weights(W, gamma, beta, bias, Wf, colsum, bias_f, N, K, ldw=None):

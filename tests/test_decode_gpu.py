@@ -508,3 +508,51 @@ def test_persistent_decode_step_is_bit_equal_to_the_per_launch_step(size, monkey
         del dec
     assert torch.equal(outs["1"][1], outs["0"][1]), float((outs["1"][1] - outs["0"][1]).abs().max())
     assert torch.equal(outs["1"][0], outs["0"][0])
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size", ["tiny", "full"])
+def test_chained_decode_launches_are_bit_equal_to_the_per_launch_step(size, monkeypatch):
+    """Round 4: attn.c_proj -> c_fc -> mlp.c_proj of every block as ONE chained launch (mmtg_decode_chain: a later product's item
+    starts when the row block it reads is complete -- a counter per row block -- instead of behind a kernel boundary) against the
+    per-launch fused step on the same model and prompts: same code per tile in the same order, so the fp32 logits of the first
+    model call AND every generated id are bit-equal -- tiny 2-layer model at batch 3 and the full 12-layer model at batch 256;
+    the error word stays clear and the chained launches stay on (no fallback); graph replay and eager launches agree; two
+    generations in a row agree (the counters are re-armed by their last consumer).  (Opt-in: it measured slower.)"""
+    if size == "tiny":
+        fx, batch, model = build("bf16")
+        tb = {k: v for k, v in batch_to_torch(batch, DEV).items() if k not in ("rating", "targets")}
+        B, Ln = 3, 90
+    else:
+        from mmtg_amd import synth
+        from mmtg_amd.configs import data_config, gpt2_config, make_model_cfgs
+        S, V, B, Ln = 5, 13317, 256, 48
+        mcfg, dcfg = make_model_cfgs(seq_len=S), data_config(seq_len=S)
+        model = MMTG(mcfg, dcfg, V, gpt2_config=gpt2_config(n_layer=12, vocab_size=V), compute_dtype="bf16",
+                     token_table=synth.make_token_table(V, seed=2))
+        model.reset_parameters(seed=0)
+        model.to(DEV).eval()
+        nb = synth.make_batch(B, mcfg, dcfg, V, seed=7)
+        tb = {k: torch.from_numpy(np.asarray(v)).to(DEV) for k, v in nb.items() if k not in ("rating", "targets")}
+    outs = {}
+    monkeypatch.setenv("MMTG_DECODE_PERSIST", "0")
+    for chain in ("1", "0"):
+        monkeypatch.setenv("MMTG_DECODE_CHAIN", chain)
+        dec = GreedyDecoder(model, max_batch=B, max_len=Ln)
+        assert dec.fused and getattr(dec, "chain", False) == (chain == "1")
+        first = []
+
+        def tap(j, with_head, picked, logits, first=first):
+            if with_head and not first:
+                first.append(logits.float().cpu().clone())
+
+        ids = dec.generate(tb, Ln, temperature=1.1, repitition_penalty=1.5, tap=tap)
+        ids2 = dec.generate(tb, Ln, temperature=1.1, repitition_penalty=1.5)
+        eager = dec.generate(tb, Ln, temperature=1.1, repitition_penalty=1.5, use_graph=False)
+        assert torch.equal(ids, ids2) and torch.equal(ids, eager)
+        if chain == "1":
+            assert dec.chain and int(dec.err.item()) == 0 and int(dec.deps.abs().sum().item()) == 0
+        outs[chain] = (ids.cpu(), first[0])
+        del dec
+    assert torch.equal(outs["1"][1], outs["0"][1]), float((outs["1"][1] - outs["0"][1]).abs().max())
+    assert torch.equal(outs["1"][0], outs["0"][0])
+
