@@ -38,8 +38,14 @@ def build(dtype, pdrop, dev, seed=100):
 def main():
     mode, out = sys.argv[1], sys.argv[2]
     rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", "0"))
+    # MMTG_DDP_TEST_BACKEND=gloo + LOCAL_RANK=0 for every rank: several ranks SHARE one GPU and exchange through the host (RCCL
+    # refuses two ranks on one device) -- the same trainer, reducer and kernels, so the N > 1 arithmetic runs on a single-GPU box
+    backend = os.environ.get("MMTG_DDP_TEST_BACKEND", "nccl")
     dev = torch.device("cuda", local)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)     # first GPU touch of this process
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)     # first GPU touch of this process
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
     torch.cuda.set_device(dev)
     from mmtg_amd import synth
     from mmtg_amd.trainer import MMTGTrainer

@@ -28,6 +28,8 @@ def _launch(mode, world, out, extra_env=None, timeout=600):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         env.update(extra_env or {})
+        if env.get("MMTG_DDP_TEST_BACKEND", "nccl") != "nccl":
+            env["LOCAL_RANK"] = "0"          # every rank on the one GPU there is
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "ddp_worker.py"), mode, out], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     logs = []
@@ -85,6 +87,22 @@ def test_two_rank_gradient_equals_single_rank_on_the_concatenated_batch(tmp_path
     res = _launch("shards", 2, str(tmp_path / "w2"))
     assert all(r.get("ok") for r in res)
     assert res[0]["count"] == res[1]["count"] == res[0]["count_single"] == res[0]["n_local"] + res[1]["n_local"]
+    for r in res:
+        g, ref = r["grad"], res[0]["grad_single"]
+        assert float((g - ref).norm() / ref.norm()) < 1e-4
+    assert torch.equal(res[0]["grad"], res[1]["grad"])
+
+
+def test_two_rank_gradient_equals_single_rank_two_processes_on_one_gpu(tmp_path):
+    """The 2-rank arithmetic on a ONE-GPU box: two processes share cuda:0 and all-reduce through the host (gloo; RCCL refuses
+    two ranks on one device).  Same trainer, same GradReducer (buckets in gradient-ready order, the device-scalar row count),
+    same kernels as the RCCL run: contiguous row shards of one 16-row batch, stage-1 filter per shard (unequal shards) -- the
+    all-reduced gradient divided by the all-reduced row count equals the single-process gradient of the whole batch, and both
+    ranks hold the same bits."""
+    res = _launch("shards", 2, str(tmp_path / "w2g"), {"MMTG_DDP_TEST_BACKEND": "gloo"})
+    assert all(r.get("ok") for r in res) and res[0]["backend"] == "gloo"
+    assert res[0]["count"] == res[1]["count"] == res[0]["count_single"] == res[0]["n_local"] + res[1]["n_local"]
+    assert res[0]["n_local"] != res[1]["n_local"]
     for r in res:
         g, ref = r["grad"], res[0]["grad_single"]
         assert float((g - ref).norm() / ref.norm()) < 1e-4
