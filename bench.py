@@ -567,12 +567,20 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
+    # MMTG_BENCH_ONE_GPU_BACKEND=gloo (rehearsal only, never a measurement): every rank on cuda:0, the exchange through the host --
+    # the N > 1 code of this file and of the trainer run on a one-GPU box (RCCL refuses two ranks on one device); the line says so
+    one_gpu_backend = os.environ.get("MMTG_BENCH_ONE_GPU_BACKEND")
+    if one_gpu_backend:
+        local = 0
     dev = torch.device("cuda", local)
     force_ddp = bool(os.environ.get("MMTG_FORCE_DDP"))     # exercise the RCCL path on one GPU (self-test)
     if world > 1 or force_ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if one_gpu_backend:
+            dist.init_process_group(one_gpu_backend, rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     torch.cuda.set_device(local)
 
     from mmtg_amd import MMTG, hip, synth
@@ -712,6 +720,9 @@ def main():
                             "overlap with; inside the step they run on RCCL's stream beside the backward; finish_wait_ms_per_step = how "
                             "long the compute stream waited for them after the backward (HIP events around GradReducer.finish, this rank): "
                             "the exposed part of the exchange; cu_budget = CUs the GEMM tile rule leaves to (< 0) the RCCL kernels"}
+        if one_gpu_backend:
+            ddp_info["rehearsal"] = ("MMTG_BENCH_ONE_GPU_BACKEND=%s: all %d ranks share cuda:0 and exchange through the host -- a run of "
+                                     "the N > 1 code path on a one-GPU box, NOT a throughput measurement" % (one_gpu_backend, world))
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == "base":
