@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MMTG_ABI_VERSION 7
+#define MMTG_ABI_VERSION 8
 
 /* The library is built with -fvisibility=hidden: only the entry points below are exported. */
 #define MMTG_API __attribute__((visibility("default")))
@@ -111,6 +111,27 @@ MMTG_API int mmtg_gemm(int dtype, int transA, int transB, int M, int N, int K,
               const float* bias, int epi, const void* aux, long ldaux, void* aux2,
               int out_f32, float alpha, int splits, unsigned drop_thresh, unsigned drop_seed,
               int flags, void* stream);
+
+/* Split-precision ("bf16x3") product, round 5 -- the mode in which north_star's numeric gates (logits within 1e-3, greedy ids
+ * bit-exact) hold at bf16 matrix-core speed.  Replaces the SAME fp32 products as mmtg_gemm (the Conv1D / Linear layers of GPT-2
+ * behind model.py:282-288,320-326 and the tied lm_head) when both operands are K-contiguous:
+ *   C[M, N] (fp32) = epi( A . B^T + bias ),   A [M, K], B [N, K] fp32 tensors handed over as (hi | lo) PLANE PAIRS of bf16
+ *   (hi = bf16(x), lo = bf16(x - hi); the lo plane lies planeA / planeB ELEMENTS behind the hi plane, same leading dimension),
+ *   computed as A_hi B_hi^T + A_lo B_hi^T + A_hi B_lo^T with fp32 accumulation in ONE kernel (a 3K-deep loop of the eight-phase
+ *   kernel).  aux / aux2 / C are fp32 with the meanings of mmtg_gemm's epilogues NONE, GELU, TANH, RESID (+ dropout), DGELU
+ *   (+ column sums), DTANH, ROWDOT.  `planes` (nullable; ld = ldp, lo plane plane_out elements behind) receives the epilogue's
+ *   result as a plane pair for the next split-precision product; C may be NULL when only the planes are consumed.
+ *   K % 128 == 0; N, lda, ldb, ldc, ldp % 8 == 0; every plane pair below 2 GiB.  Plane pairs come from mmtg_split_planes,
+ *   mmtg_layernorm_fwd_x3, this function's `planes` output, and mmtg_adamw (weights).                                      */
+MMTG_API int mmtg_gemm_x3(int M, int N, int K, const void* A, long lda, long planeA, const void* B, long ldb, long planeB,
+                 float* C, long ldc, void* planes, long ldp, long plane_out, const float* bias, int epi,
+                 const float* aux, long ldaux, void* aux2, unsigned drop_thresh, unsigned drop_seed, int flags, void* stream);
+/* fp32 [rows, cols] (ld = lds) -> its (hi | lo) bf16 plane pair (ld = ldp, lo plane `plane` elements behind the hi plane). */
+MMTG_API int mmtg_split_planes(const float* src, long lds, int rows, int cols, void* planes, long ldp, long plane, void* stream);
+/* LayerNorm forward (fp32 rows in, statistics out as mmtg_layernorm_fwd) whose output goes straight to a plane pair: the
+ * GPT-2 LayerNorms feed products only (ln_1 -> c_attn, ln_2 -> c_fc, ln_f -> lm_head), so the fp32 rows are never stored. */
+MMTG_API int mmtg_layernorm_fwd_x3(const float* x, void* planes, long ldp, long plane, const float* gamma, const float* beta,
+                          float* mean, float* rstd, int rows, int cols, float eps, void* stream);
 
 /* Products whose operand rows are GATHERED from a table by index -- the multi-modal conditioning front end of
  * GPT2_Decoder.forward (model.py:254-281) without materialising X[m] = E[id_m] + c[b, seg_m] (62 MB at B = 64):
@@ -308,7 +329,8 @@ MMTG_API int mmtg_sumsq(const float* x, long n, float* out, float* ws, long ws_f
  * count (optional, device scalar): g holds a SUM over rows and *count the global row count
  * (all-reduced on the device, never read by the host): the gradient is g * grad_scale / *count;
  * *count == 0 leaves every buffer untouched (the reference skips an empty batch, train.py:184-185). */
-MMTG_API int mmtg_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, long n,
+/* p_lo (nullable; with p_bf16): the x3 mode's lo plane, bf16(p - bf16(p)) -- p_bf16 / p_lo are then the weights' plane pair. */
+MMTG_API int mmtg_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, void* p_lo, long n,
                float lr, float beta1, float beta2, float eps, float wd, int step,
                const float* normsq, float max_norm, float grad_scale, const float* count, void* stream);
 MMTG_API int mmtg_cast_f32_to(int dtype, const float* src, void* dst, long n, void* stream);
@@ -334,12 +356,16 @@ MMTG_API int mmtg_slab_sum(const float* part, int splits, long stride, float* ds
  * `probs` is a HOST array (read during the call).  M, N, lda, ldb multiples of 8; operands below 2 GiB.
  * config 0: 128x128 tiles, four 256-thread workgroups per CU (any shape; 16384 floats and 4 counters per tile and split);
  * config 1: 256x256 tiles on the eight-phase K-strided main loop, one 512-thread workgroup per CU (65536 floats and 8
- *           counters per tile and split; K slices are multiples of 128).                                                  */
+ *           counters per tile and split; K slices are multiples of 128).
+ * config 2 (round 5, the split-precision mode; 128x128 tiles): A_p and B_p are (hi | lo) bf16 plane pairs of fp32 tensors -- the
+ *           lo plane planeA / planeB ELEMENTS behind the hi plane -- and every K slice is walked three times,
+ *           A_hi^T B_hi + A_lo^T B_hi + A_hi^T B_lo (see mmtg_gemm_x3); planeA / planeB are ignored otherwise.            */
 typedef struct mmtg_wgrad_problem {
     const void* A; long lda;
     const void* B; long ldb;
     float* C; long ldc;
     int M, N;
+    long planeA, planeB;
 } mmtg_wgrad_problem;
 MMTG_API int mmtg_wgrad_group(int config, int n, const mmtg_wgrad_problem* probs, int K, int splits, float* ws, long ws_floats,
                      unsigned* counters, long n_counters, int accumulate, void* stream);

@@ -780,9 +780,15 @@ __device__ __forceinline__ int p8_ks_voff(long ld, int col0, int ncols, int h, i
     return (col0 + col < ncols) ? (int)(((long)k * ld + col) * 2) : OOB;
 }
 
-template <int TBM, bool KS = false>
+// X3 = true (round 5, the split-precision mode): both operands are (hi | lo) bf16 plane pairs of fp32 tensors and the K loop
+// walks the SAME K range three times -- (A hi, B hi), (A lo, B hi), (A hi, B lo) -- as one 3 nk-tile loop: only the scalar
+// offset of a K tile changes (t -> pass t / nk, tile t % nk, + the plane distance where the pass reads a lo plane), so the
+// phase protocol, the counted waits and the LDS images are untouched.  The epilogue is the fp32 one (aux / outputs fp32,
+// optionally the result's own plane pair for the next product).
+template <int TBM, bool KS = false, bool X3 = false>
 __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(GemmArgs p) {
-    typedef bf16 T;
+    typedef typename std::conditional<X3, float, bf16>::type TE;      // epilogue storage type
+    static_assert(!(X3 && (KS || TBM == 288)), "x3: K-contiguous operands, 256- or 192-row tiles");
     static_assert(TBM == 256 || ((TBM == 192 || TBM == 288) && !KS), "row tiles of 256 or (K-contiguous operands) 192 / 288");
     constexpr int WTM = TBM / 2, TMW = WTM / 16, NA1 = TMW - 4;       // wave rows, 16-row tiles per wave, tiles in a1
     constexpr int NBG = TBM / 16;                                     // DMA blocks (8 rows) per wave-row group
@@ -803,7 +809,8 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(GemmArgs p) {
     int m0, n0, split;
     tile_origin(p, blockIdx.x, gridDim.x, m0, n0, split, TBM, 256);
     const int kbeg = KS ? split * p.kper : 0;               // host: K % 128 == 0; K splits (kper % 128 == 0) for KS only
-    const int nk = max(0, (KS ? min(p.K, kbeg + p.kper) : p.K) - kbeg) >> 6;
+    const int nk1 = max(0, (KS ? min(p.K, kbeg + p.kper) : p.K) - kbeg) >> 6;
+    const int nk = X3 ? 3 * nk1 : nk1;                      // x3: three passes over the K range
 
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, p.bytesA, 0x00020000);
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, p.bytesB, 0x00020000);
@@ -841,20 +848,24 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(GemmArgs p) {
         vB00 = p8_ks_voff<4>(p.ldb, n0, p.N, 0, wave, lane); vB01 = p8_ks_voff<4>(p.ldb, n0, p.N, 0, wave + 8, lane);
         vB10 = p8_ks_voff<4>(p.ldb, n0, p.N, 1, wave, lane); vB11 = p8_ks_voff<4>(p.ldb, n0, p.N, 1, wave + 8, lane);
     }
+    // scalar byte offset of K tile t of an operand (x3: pass = t / nk1 -- 1 reads A's lo plane, 2 reads B's -- tile t % nk1)
+#define P8_PASS(t) (((t) >= nk1 ? 1 : 0) + ((t) >= 2 * nk1 ? 1 : 0))
+#define P8_SA(t) (X3 ? sa0 + ((t) - P8_PASS(t) * nk1) * stepa + (P8_PASS(t) == 1 ? p.planeA : 0) : sa0 + (t) * stepa)
+#define P8_SB(t) (X3 ? sb0 + ((t) - P8_PASS(t) * nk1) * stepb + (P8_PASS(t) == 2 ? p.planeB : 0) : sb0 + (t) * stepb)
     // half tile H of K tile t into stage t & 1 (a tile past the end issues out-of-range, zero-filling loads: uniform counts)
-#define P8_A0(t) p8_issue(ra, smem + ((t) & 1) * STAGE + lA00, smem + ((t) & 1) * STAGE + lA01, (t) < nk ? vA00 : OOB, (t) < nk ? vA01 : OOB, sa0 + (t) * stepa)
+#define P8_A0(t) p8_issue(ra, smem + ((t) & 1) * STAGE + lA00, smem + ((t) & 1) * STAGE + lA01, (t) < nk ? vA00 : OOB, (t) < nk ? vA01 : OOB, P8_SA(t))
 #define P8_A1(t)                                                                                                                       \
     do {                                                                                                                               \
         if constexpr (TBM != 192)                                                                                                      \
-            p8_issue(ra, smem + ((t) & 1) * STAGE + lA10, smem + ((t) & 1) * STAGE + lA11, (t) < nk ? vA10 : OOB, (t) < nk ? vA11 : OOB, sa0 + (t) * stepa); \
+            p8_issue(ra, smem + ((t) & 1) * STAGE + lA10, smem + ((t) & 1) * STAGE + lA11, (t) < nk ? vA10 : OOB, (t) < nk ? vA11 : OOB, P8_SA(t)); \
         else                                                                                                                           \
-            p8_issue1(ra, smem + ((t) & 1) * STAGE + lA10, (t) < nk ? vA10 : OOB, sa0 + (t) * stepa);                                  \
+            p8_issue1(ra, smem + ((t) & 1) * STAGE + lA10, (t) < nk ? vA10 : OOB, P8_SA(t));                                  \
         if constexpr (TBM == 288) {                                                                                                    \
-            if (wave < 4 && (t) < nk) p8_issue1(ra, smem + ((t) & 1) * STAGE + lA12, vA12, sa0 + (t) * stepa);                         \
+            if (wave < 4 && (t) < nk) p8_issue1(ra, smem + ((t) & 1) * STAGE + lA12, vA12, P8_SA(t));                         \
         }                                                                                                                              \
     } while (0)
-#define P8_B0(t) p8_issue(rb, smem + ((t) & 1) * STAGE + lB00, smem + ((t) & 1) * STAGE + lB01, (t) < nk ? vB00 : OOB, (t) < nk ? vB01 : OOB, sb0 + (t) * stepb)
-#define P8_B1(t) p8_issue(rb, smem + ((t) & 1) * STAGE + lB10, smem + ((t) & 1) * STAGE + lB11, (t) < nk ? vB10 : OOB, (t) < nk ? vB11 : OOB, sb0 + (t) * stepb)
+#define P8_B0(t) p8_issue(rb, smem + ((t) & 1) * STAGE + lB00, smem + ((t) & 1) * STAGE + lB01, (t) < nk ? vB00 : OOB, (t) < nk ? vB01 : OOB, P8_SB(t))
+#define P8_B1(t) p8_issue(rb, smem + ((t) & 1) * STAGE + lB10, smem + ((t) & 1) * STAGE + lB11, (t) < nk ? vB10 : OOB, (t) < nk ? vB11 : OOB, P8_SB(t))
 
     // lane offsets of the fragments inside a stage.  K-contiguous: A rows WTM wr + 64 ah + 16 i + l15, B rows (= columns) 64 wc +
     // 32 bh + 16 j + l15; the chunk swizzle (row & 7) does not depend on wr / ah / bh / i / j (all multiples of 8), so one offset
@@ -949,13 +960,16 @@ __global__ __launch_bounds__(512, 1) void gemm_p8_kernel(GemmArgs p) {
 #undef P8_A1
 #undef P8_B0
 #undef P8_B1
+#undef P8_SA
+#undef P8_SB
+#undef P8_PASS
     wait_vmcnt<0>();                                     // the zero-fill tail loads
     if (tr) { ts2 = __builtin_amdgcn_s_memrealtime(); tc2 = __builtin_amdgcn_s_memtime(); }
     if (wr == 0) asm volatile("s_barrier" ::: "memory");           // re-join the two groups
     asm volatile("s_barrier" ::: "memory");                        // every wave is done with the stages: they become epilogue scratch
     if constexpr (KS) p.C = reinterpret_cast<char*>(p.C) + (long)split * p.split_stride;     // MMTG_EPI_SPLIT slab
     // (aux vectors two bands ahead; the 256-row configuration -- 128-row wave tiles -- also carries the dGELU column sums)
-    gemm_epilogue<T, false, TMW, 4, (TBM == 256 ? 2 : TBM == 288 ? -1 : -2)>(p, acc, m0 + wr * WTM, n0 + wc * 64, g, l15, smem + wave * epi_scratch_bytes<TMW, 4>(), lane);
+    gemm_epilogue<TE, false, TMW, 4, (TBM == 256 ? 2 : TBM == 288 ? -1 : -2), X3>(p, acc, m0 + wr * WTM, n0 + wc * 64, g, l15, smem + wave * epi_scratch_bytes<TMW, 4>(), lane);
 #ifdef MMTG_P8_PHASE_TRACE
     if (tr && blockIdx.x == 0 && lane == 0 && (int)(gridDim.x + 4 * wave + 4) <= p.trace_n) {
         unsigned long long* r = p.trace + 6 * (size_t)(gridDim.x + 4 * wave);       // 24 words behind the workgroups' rows
@@ -1127,12 +1141,12 @@ int launch_p8p(const GemmArgs& a, hipStream_t stream) {
     return MMTG_OK;
 }
 
-template <int TBM, bool KS = false>
+template <int TBM, bool KS = false, bool X3 = false>
 int launch_p8(const GemmArgs& a, int splits, hipStream_t stream) {
     static bool attr_done = false;
     const size_t shm = 2 * (TBM + 256) * 128;
     if (!attr_done) {
-        int rc = set_lds(gemm_p8_kernel<TBM, KS>, shm, 512, KS ? "eight-phase 256x256 K-strided" : TBM == 256 ? "eight-phase 256x256" : TBM == 288 ? "eight-phase 288x256" : "eight-phase 192x256");
+        int rc = set_lds(gemm_p8_kernel<TBM, KS, X3>, shm, 512, KS ? "eight-phase 256x256 K-strided" : TBM == 256 ? "eight-phase 256x256" : TBM == 288 ? "eight-phase 288x256" : "eight-phase 192x256");
         if (rc) return rc;
         attr_done = true;
     }
@@ -1143,7 +1157,7 @@ int launch_p8(const GemmArgs& a, int splits, hipStream_t stream) {
     b.tiles_m_fast = KS && b.tiles_n > cdiv(a.M, TBM) && !(a.dbg_flags & 1);
     b.cbw = 0;
     if (!KS && !(a.dbg_flags & 1)) b.cbw = column_block(a, TBM, 256, num_cus());
-    hipLaunchKernelGGL((gemm_p8_kernel<TBM, KS>), dim3(b.nitems), dim3(512), shm, stream, b);
+    hipLaunchKernelGGL((gemm_p8_kernel<TBM, KS, X3>), dim3(b.nitems), dim3(512), shm, stream, b);
     return MMTG_OK;
 }
 
@@ -1381,6 +1395,8 @@ extern "C" int mmtg_gemm(int dtype, int transA, int transB, int M, int N, int K,
     ProfScope prof(dtype == MMTG_F32 ? MMTG_PROF_GEMM_F32 : MMTG_PROF_GEMM_BF16, s, 2.0 * M * N * (double)K, alg_bytes);
     a.ntiles = cdiv(M, BM) * cdiv(N, BN);
     a.nitems = a.ntiles * splits;
+    // (tile_origin divides by float reciprocal: exact below 2^20 work items, gemm_common.h fdiv_small)
+    MMTG_REQUIRE((long)cdiv(M, BM) * cdiv(N, BN) * splits < (1L << 20), "gemm: %ld work items exceed the tile-order arithmetic's 2^20", (long)cdiv(M, BM) * cdiv(N, BN) * splits);
     dim3 grid(a.nitems);
     // small-M products with K-contiguous weights (decode): 256x32 tiles -> N/32 workgroups
     const int skinny = (flags & MMTG_GEMM_SKINNY) || (!transA && transB && M <= 256 && !(flags & MMTG_GEMM_NO_SKINNY));
@@ -1494,3 +1510,65 @@ extern "C" int mmtg_gemm(int dtype, int transA, int transB, int M, int N, int K,
     MMTG_LAUNCH_CHECK("gemm");
     return MMTG_OK;
 }
+
+// ------------------------------------------------------------------ split-precision ("bf16x3") product, round 5
+// C[M,N] (fp32) = epi( A B^T ) with A [M,K], B [N,K] both given as (hi | lo) pairs of bf16 planes of fp32 tensors:
+// A B^T ~ A_hi B_hi^T + A_lo B_hi^T + A_hi B_lo^T, fp32 accumulate, on the eight-phase kernel (one 3K-deep loop).
+// The reference's arithmetic is fp32 (/root/reference/src/model.py:279-288, the Conv1D / Linear products of GPT-2); this is
+// the mode that keeps north_star's "logits within 1e-3, greedy ids bit-exact" at bf16 matrix-core speed.
+extern "C" int mmtg_gemm_x3(int M, int N, int K, const void* A, long lda, long planeA, const void* B, long ldb, long planeB,
+                            float* C, long ldc, void* planes, long ldp, long plane_out, const float* bias, int epi,
+                            const float* aux, long ldaux, void* aux2, unsigned drop_thresh, unsigned drop_seed, int flags, void* stream) {
+    MMTG_REQUIRE(M > 0 && N > 0 && K > 0 && A && B, "gemm_x3: empty problem or null operand");
+    MMTG_REQUIRE(C || planes, "gemm_x3: needs an fp32 output, a plane-pair output, or both");
+    MMTG_REQUIRE(K % 128 == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0, "gemm_x3: K %% 128 == 0, N, lda, ldb %% 8 == 0 (K=%d N=%d)", K, N);
+    MMTG_REQUIRE(MMTG_ALIGNED16(A) && MMTG_ALIGNED16(B) && MMTG_ALIGNED16(C) && MMTG_ALIGNED16(planes) && planeA % 8 == 0 && planeB % 8 == 0,
+                 "gemm_x3: operands and plane distances must be 16-byte aligned");
+    MMTG_REQUIRE(!C || ldc % 8 == 0, "gemm_x3: ldc %% 8 == 0");
+    MMTG_REQUIRE(!planes || (ldp % 8 == 0 && plane_out % 8 == 0 && plane_out >= (long)(M - 1) * ldp + N), "gemm_x3: plane output: ldp, plane distance %% 8 == 0, planes disjoint");
+    MMTG_REQUIRE(planeA >= (long)(M - 1) * lda + K && planeB >= (long)(N - 1) * ldb + K, "gemm_x3: an operand's lo plane must lie behind its hi plane");
+    MMTG_REQUIRE(epi == MMTG_EPI_NONE || epi == MMTG_EPI_GELU || epi == MMTG_EPI_TANH || epi == MMTG_EPI_RESID || epi == MMTG_EPI_DGELU ||
+                 epi == MMTG_EPI_DTANH || epi == MMTG_EPI_ROWDOT, "gemm_x3: epilogue %d is not built for the split-precision product", epi);
+    if (epi == MMTG_EPI_RESID || epi == MMTG_EPI_DGELU || epi == MMTG_EPI_DTANH || epi == MMTG_EPI_ROWDOT)
+        MMTG_REQUIRE(aux && ldaux % 8 == 0 && MMTG_ALIGNED16(aux), "gemm_x3: epilogue %d needs a 16-byte aligned fp32 aux with ldaux %% 8 == 0", epi);
+    if (epi == MMTG_EPI_GELU) MMTG_REQUIRE(aux2 && MMTG_ALIGNED16(aux2) && ldc % 8 == 0 && ldc >= N, "gemm_x3: GELU needs aux2 (fp32 pre-activation, ld = ldc)");
+    if (epi == MMTG_EPI_ROWDOT) MMTG_REQUIRE(aux2 && !bias && N % 64 == 0, "gemm_x3: ROWDOT needs aux2 (f32 [M, N/64]), no bias, N %% 64 == 0");
+    MMTG_REQUIRE(!bias || MMTG_ALIGNED16(bias), "gemm_x3: bias must be 16-byte aligned");
+    const long bytesA = (planeA + (long)(M - 1) * lda + K) * 2, bytesB = (planeB + (long)(N - 1) * ldb + K) * 2;
+    MMTG_REQUIRE(bytesA < 0x7FFFFF00L && bytesB < 0x7FFFFF00L, "gemm_x3: an operand's plane pair must stay below 2 GiB");
+    GemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.A = A; a.B = B; a.C = C; a.bias = bias; a.aux = aux; a.aux2 = aux2;
+    a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldaux = ldaux;
+    a.epi = epi; a.out_f32 = 1; a.use_tr = 1; a.alpha = 1.0f;
+    a.trace = g_trace; a.trace_n = g_trace_n;
+    a.gelu_grad = (flags & MMTG_GEMM_GELU_GRAD) ? 1 : 0;
+    a.dbg_flags = (flags & MMTG_GEMM_ROW_ORDER) ? 1 : 0;
+    a.bytesA = (int)bytesA; a.bytesB = (int)bytesB;
+    a.planeA = (int)(planeA * 2); a.planeB = (int)(planeB * 2);
+    a.planes = planes; a.ldp = ldp; a.plane_out = plane_out;
+    a.x3 = 1;
+    a.kper = K;
+    a.drop_thresh = drop_thresh; a.drop_seed = drop_seed;
+    a.drop_inv_keep = drop_thresh ? (float)(4294967296.0 / (4294967296.0 - (double)drop_thresh)) : 1.0f;
+    hipStream_t s = (hipStream_t)stream;
+    // algorithmic bytes: the fp32 tensors the product stands for (A, B, C once, + the epilogue's aux / second output)
+    double alg_bytes = 4.0 * ((double)M * K + (double)N * K + (double)M * N);
+    if (epi == MMTG_EPI_RESID || epi == MMTG_EPI_DGELU || epi == MMTG_EPI_DTANH || epi == MMTG_EPI_ROWDOT || epi == MMTG_EPI_GELU) alg_bytes += 4.0 * (double)M * N;
+    ProfScope prof(MMTG_PROF_GEMM_BF16, s, 2.0 * M * N * (double)K, alg_bytes);
+    // row tile: the cost model of mmtg_gemm with three times the K tiles
+    const long t256 = (long)cdiv(M, 256) * cdiv(N, 256), t192 = (long)cdiv(M, 192) * cdiv(N, 256);
+    MMTG_REQUIRE(t192 < (1L << 20), "gemm_x3: too many output tiles for the tile-order arithmetic (%ld)", t192);
+    const long ncu = p8_cus();
+    const double nkt = 3.0 * (double)K / 64.0;
+    auto cost = [&](long tiles, double r) { const double tk = 1.41 * r / 256.0; return (double)cdiv(tiles, ncu) * (5.6 + nkt * (tk < 1.15 ? 1.15 : tk)); };
+    int rows = cost(t192, 192) < 0.97 * cost(t256, 256) ? 192 : 256;
+    static const int rows_env = getenv("MMTG_X3_P8_ROWS") ? atoi(getenv("MMTG_X3_P8_ROWS")) : 0;
+    if (rows_env == 192 || rows_env == 256) rows = rows_env;
+    if (epi == MMTG_EPI_DGELU && aux2) rows = 256;      // the fused column sums need 64-row-aligned wave tiles
+    const int rc = rows == 192 ? launch_p8<192, false, true>(a, 1, s) : launch_p8<256, false, true>(a, 1, s);
+    if (rc) return rc;
+    MMTG_LAUNCH_CHECK("gemm_x3");
+    return MMTG_OK;
+}
+

@@ -8,6 +8,7 @@
 //       swz(k) = ((k&3)<<1) | (((k>>3)&1)<<3) -> ds_read_b64_tr_b16 reads are conflict free.
 #pragma once
 #include "mma.h"
+#include <type_traits>
 
 namespace {
 
@@ -38,6 +39,12 @@ struct GemmArgs {
     int gelu_grad;         // MMTG_GEMM_GELU_GRAD: GELU stores gelu'(pre) in aux2; DGELU multiplies by aux as stored
     const int* gather;     // mmtg_gemm_gather: table row of output row m (mode 0: A rows) / of reduction index k (mode 1: B rows)
     const int* aux_rows;   // row of `aux` that output row m reads (null: row m)
+    // split-precision ("bf16x3") products: every fp32 operand travels as a (hi | lo) pair of bf16 planes, x ~ hi + lo with
+    // hi = bf16(x), lo = bf16(x - hi); the K loop runs three passes hi*hi + lo*hi + hi*lo (fp32 accumulate) over the same tiles
+    int x3;
+    int planeA, planeB;    // bytes from an operand's hi plane to its lo plane (x3 kernels only)
+    void* planes;          // optional second output of the x3 epilogues: the result as a (hi | lo) plane pair, ld = ldp
+    long ldp, plane_out;   // plane_out: ELEMENTS from the hi plane to the lo plane of `planes`
 };
 
 template <typename T> struct GT {
@@ -309,7 +316,7 @@ template <> __device__ __forceinline__ void store8<bf16>(bf16* p, const float (&
 // writes (16 rows, same c) and for the row-wise read-back -- i.e. 4 KB per wave at WTN = 64.
 // `lds` = this wave's scratch (epi_scratch_bytes); LDS operations of one wave complete in order, so
 // the passes need no barrier between them.
-template <typename T, int EPI, int TM, int TN, int PFD>
+template <typename T, int EPI, int TM, int TN, int PFD, bool X3 = false>
 __device__ __forceinline__ void epi_tiles(const GemmArgs& p, f32x4 (&acc)[TM][TN], int mw0, int nw0, int g, int l15,
                                           char* lds, int lane) {
     constexpr int WTN = TN * 16;               // wave-tile columns
@@ -320,6 +327,9 @@ __device__ __forceinline__ void epi_tiles(const GemmArgs& p, f32x4 (&acc)[TM][TN
     constexpr bool HAS_AUX = EPI == MMTG_EPI_RESID || EPI == MMTG_EPI_DGELU || EPI == MMTG_EPI_DTANH || EPI == MMTG_EPI_ROWDOT ||
                              EPI == MMTG_EPI_TANH_ADD;
     const T* aux = reinterpret_cast<const T*>(p.aux);
+    // transcendental forms: the x3 mode stores fp32 but takes the v_exp_f32 / v_rcp_f32 forms (~1 ulp of fp32 each: two orders
+    // below the split products' own error) -- libm tanhf in an exposed epilogue costs ~25 instructions per element
+    typedef typename std::conditional<X3, bf16, T>::type TF;
     // Everything that comes from global memory is requested ahead of its use -- the lane's 8 bias
     // values once (its columns are the same in every band) and the aux vectors of its rows PFD bands
     // ahead (all of them up front where the register budget allows) -- so the epilogue waits for one
@@ -384,19 +394,19 @@ __device__ __forceinline__ void epi_tiles(const GemmArgs& p, f32x4 (&acc)[TM][TN
                 if (p.gelu_grad) {          // the backward's only use of the pre-activation is gelu': store THAT (round 3)
                     float gd[8];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) gd[e] = gelu_new_grad_t<T>(v[e]);
+                    for (int e = 0; e < 8; ++e) gd[e] = gelu_new_grad_t<TF>(v[e]);
                     store8<T>(reinterpret_cast<T*>(p.aux2) + (long)m * p.ldc + n, gd);
                 } else {
                     store8<T>(reinterpret_cast<T*>(p.aux2) + (long)m * p.ldc + n, v);
                 }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = gelu_new_t<T>(v[e]);
+                for (int e = 0; e < 8; ++e) v[e] = gelu_new_t<TF>(v[e]);
             } else if constexpr (EPI == MMTG_EPI_TANH) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = tanh_t<T>(v[e]);
+                for (int e = 0; e < 8; ++e) v[e] = tanh_t<TF>(v[e]);
             } else if constexpr (EPI == MMTG_EPI_TANH_ADD) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = tanh_t<T>(v[e] + a8[e]);
+                for (int e = 0; e < 8; ++e) v[e] = tanh_t<TF>(v[e] + a8[e]);
             } else if constexpr (EPI == MMTG_EPI_RESID) {
                 if (p.drop_thresh) {
 #pragma unroll
@@ -408,7 +418,7 @@ __device__ __forceinline__ void epi_tiles(const GemmArgs& p, f32x4 (&acc)[TM][TN
             } else if constexpr (EPI == MMTG_EPI_DGELU) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    v[e] *= p.gelu_grad ? a8[e] : gelu_new_grad_t<T>(a8[e]);
+                    v[e] *= p.gelu_grad ? a8[e] : gelu_new_grad_t<TF>(a8[e]);
                     if constexpr (COLSUM) cs[e] += (float)(T)v[e];      // column sums of the output as stored
                 }
             } else if constexpr (EPI == MMTG_EPI_DTANH) {
@@ -426,8 +436,21 @@ __device__ __forceinline__ void epi_tiles(const GemmArgs& p, f32x4 (&acc)[TM][TN
                 dot += __shfl_xor(dot, 4, 64);
                 if ((lane & 7) == 0) reinterpret_cast<float*>(p.aux2)[(long)m * (p.N >> 6) + (n >> 6)] = dot;
             }
-            if (p.out_f32) store8<float>(reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n, v);
-            else store8<T>(reinterpret_cast<T*>(p.C) + (long)m * p.ldc + n, v);
+            if constexpr (X3) {
+                // fp32 result (optional) and / or its (hi | lo) bf16 planes: what the next split-precision product reads
+                if (p.C) store8<float>(reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n, v);
+                if (p.planes) {
+                    bf16x8 hi, lo;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { hi[e] = (bf16)v[e]; lo[e] = (bf16)(v[e] - (float)hi[e]); }
+                    bf16* dst = reinterpret_cast<bf16*>(p.planes) + (long)m * p.ldp + n;
+                    *reinterpret_cast<bf16x8*>(dst) = hi;
+                    *reinterpret_cast<bf16x8*>(dst + p.plane_out) = lo;
+                }
+            } else {
+                if (p.out_f32) store8<float>(reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n, v);
+                else store8<T>(reinterpret_cast<T*>(p.C) + (long)m * p.ldc + n, v);
+            }
         }
         if constexpr (COLSUM) {
             // aux2 (optional): f32 [ceil(M/64)][N] <- column sums of the output per 64-row band (four 16-row passes of this
@@ -462,7 +485,7 @@ template <int TM, int TN> constexpr int epi_scratch_bytes() { return 16 * (TN * 
 
 // `lds`: this wave's scratch of epi_scratch_bytes<TM,TN>() bytes; the caller has made sure (barrier) that
 // no wave still reads the main-loop tiles it overlays.
-template <typename T, bool std_orient, int TM, int TN, int PFD = TM>
+template <typename T, bool std_orient, int TM, int TN, int PFD = TM, bool X3 = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM][TN], int mw0, int nw0, int g, int l15,
                                               char* lds, int lane) {
     if constexpr (std_orient) {
@@ -480,16 +503,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
             }
     } else {
         switch (p.epi) {
-            case MMTG_EPI_GELU: epi_tiles<T, MMTG_EPI_GELU, TM, TN, PFD>(p, acc, mw0, nw0, g, l15, lds, lane); break;
-            case MMTG_EPI_TANH: epi_tiles<T, MMTG_EPI_TANH, TM, TN, PFD>(p, acc, mw0, nw0, g, l15, lds, lane); break;
-            case MMTG_EPI_TANH_ADD: epi_tiles<T, MMTG_EPI_TANH_ADD, TM, TN, PFD>(p, acc, mw0, nw0, g, l15, lds, lane); break;
-            case MMTG_EPI_RESID: epi_tiles<T, MMTG_EPI_RESID, TM, TN, PFD>(p, acc, mw0, nw0, g, l15, lds, lane); break;
-            case MMTG_EPI_DGELU: epi_tiles<T, MMTG_EPI_DGELU, TM, TN, PFD>(p, acc, mw0, nw0, g, l15, lds, lane); break;
-            case MMTG_EPI_DTANH: epi_tiles<T, MMTG_EPI_DTANH, TM, TN, PFD>(p, acc, mw0, nw0, g, l15, lds, lane); break;
+            case MMTG_EPI_GELU: epi_tiles<T, MMTG_EPI_GELU, TM, TN, PFD, X3>(p, acc, mw0, nw0, g, l15, lds, lane); break;
+            case MMTG_EPI_TANH: epi_tiles<T, MMTG_EPI_TANH, TM, TN, PFD, X3>(p, acc, mw0, nw0, g, l15, lds, lane); break;
+            case MMTG_EPI_TANH_ADD: epi_tiles<T, MMTG_EPI_TANH_ADD, TM, TN, PFD, X3>(p, acc, mw0, nw0, g, l15, lds, lane); break;
+            case MMTG_EPI_RESID: epi_tiles<T, MMTG_EPI_RESID, TM, TN, PFD, X3>(p, acc, mw0, nw0, g, l15, lds, lane); break;
+            case MMTG_EPI_DGELU: epi_tiles<T, MMTG_EPI_DGELU, TM, TN, PFD, X3>(p, acc, mw0, nw0, g, l15, lds, lane); break;
+            case MMTG_EPI_DTANH: epi_tiles<T, MMTG_EPI_DTANH, TM, TN, PFD, X3>(p, acc, mw0, nw0, g, l15, lds, lane); break;
             case MMTG_EPI_ROWDOT:
-                if constexpr (TN == 4) epi_tiles<T, MMTG_EPI_ROWDOT, TM, TN, PFD>(p, acc, mw0, nw0, g, l15, lds, lane);
+                if constexpr (TN == 4) epi_tiles<T, MMTG_EPI_ROWDOT, TM, TN, PFD, X3>(p, acc, mw0, nw0, g, l15, lds, lane);
                 break;
-            default: epi_tiles<T, MMTG_EPI_NONE, TM, TN, PFD>(p, acc, mw0, nw0, g, l15, lds, lane); break;
+            default: epi_tiles<T, MMTG_EPI_NONE, TM, TN, PFD, X3>(p, acc, mw0, nw0, g, l15, lds, lane); break;
         }
     }
 }

@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restric
 }
 
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
-        float* __restrict__ m, float* __restrict__ v, bf16* __restrict__ pc, long n, float lr, float b1, float b2,
+        float* __restrict__ m, float* __restrict__ v, bf16* __restrict__ pc, bf16* __restrict__ pl, long n, float lr, float b1, float b2,
         float eps, float wd, float step_size, const float* __restrict__ normsq, float max_norm, float gscale,
         const float* __restrict__ count) {
     // data-parallel steps hand over SUMS of per-row gradients and the global row count as a device scalar
@@ -56,12 +56,12 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     // 16-byte vectors (four parameters per lane and pass); the flat buffers are 16-byte aligned and n is a multiple of 4
     // for every layout the engine builds (a scalar tail covers anything else)
     const bool vec_ok = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
-                          reinterpret_cast<uintptr_t>(v)) & 15) == 0 && (reinterpret_cast<uintptr_t>(pc) & 7) == 0;
+                          reinterpret_cast<uintptr_t>(v)) & 15) == 0 && ((reinterpret_cast<uintptr_t>(pc) | reinterpret_cast<uintptr_t>(pl)) & 7) == 0;
     const long n4 = vec_ok ? n >> 2 : 0;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         const f32x4 g4 = reinterpret_cast<const f32x4*>(g)[i];
         f32x4 m4 = reinterpret_cast<f32x4*>(m)[i], v4 = reinterpret_cast<f32x4*>(v)[i], p4 = reinterpret_cast<f32x4*>(p)[i];
-        bf16x4 c4;
+        bf16x4 c4, l4;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float gi = g4[e] * coef;
@@ -71,11 +71,13 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
             if (wd > 0.f) pi -= lr * wd * pi;
             m4[e] = mi; v4[e] = vi; p4[e] = pi;
             c4[e] = (bf16)pi;
+            l4[e] = (bf16)(pi - (float)c4[e]);
         }
         reinterpret_cast<f32x4*>(m)[i] = m4;
         reinterpret_cast<f32x4*>(v)[i] = v4;
         reinterpret_cast<f32x4*>(p)[i] = p4;
         if (pc) reinterpret_cast<bf16x4*>(pc)[i] = c4;
+        if (pl) reinterpret_cast<bf16x4*>(pl)[i] = l4;
     }
     for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         const float gi = g[i] * coef;
@@ -85,6 +87,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
         if (wd > 0.f) pi -= lr * wd * pi;
         m[i] = mi; v[i] = vi; p[i] = pi;
         if (pc) pc[i] = (bf16)pi;
+        if (pl) pl[i] = (bf16)(pi - (float)(bf16)pi);
     }
 }
 
@@ -218,16 +221,17 @@ extern "C" int mmtg_sumsq(const float* x, long n, float* out, float* ws, long ws
     return MMTG_OK;
 }
 
-extern "C" int mmtg_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, long n,
+extern "C" int mmtg_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, void* p_lo, long n,
                           float lr, float beta1, float beta2, float eps, float wd, int step,
                           const float* normsq, float max_norm, float grad_scale, const float* count, void* stream) {
     MMTG_REQUIRE(p && g && m && v && n > 0 && step >= 1, "adamw: bad args");
+    MMTG_REQUIRE(!p_lo || p_bf16, "adamw: the lo plane comes with the hi plane (p_bf16)");
     hipStream_t s = (hipStream_t)stream;
-    ProfScope prof(MMTG_PROF_OPTIM, s, 12.0 * n, (28.0 + (p_bf16 ? 2 : 0)) * n);
+    ProfScope prof(MMTG_PROF_OPTIM, s, 12.0 * n, (28.0 + (p_bf16 ? 2 : 0) + (p_lo ? 2 : 0)) * n);
     // transformers.AdamW(correct_bias=True): step_size = lr * sqrt(1-b2^t) / (1-b1^t)
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
     const float step_size = (float)((double)lr * sqrt(bc2) / bc1);
-    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, s, p, g, m, v, (bf16*)p_bf16, n, lr, beta1, beta2,
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, s, p, g, m, v, (bf16*)p_bf16, (bf16*)p_lo, n, lr, beta1, beta2,
                        eps, wd, step_size, normsq, max_norm, grad_scale, count);
     MMTG_LAUNCH_CHECK("adamw");
     return MMTG_OK;

@@ -35,6 +35,7 @@ struct WgProb {
     long lda, ldb, ldc;
     int M, N, tiles_m, tiles_n, tile0, m_fast;
     int bytesA, bytesB;
+    int planeA, planeB;    // x3: bytes from the hi plane to the lo plane of an operand
 };
 struct WgArgs {
     WgProb pr[WG_MAXP];
@@ -166,7 +167,9 @@ __device__ __forceinline__ int wg_locate(const WgArgs& a, int& t, int& split, in
 
 // ABLATE (timing only, wrong results; MMTG_WGRAD_ABLATE=1|2): 1 = every fragment by ONE ds_read_b128 instead of two
 // ds_read_b64_tr_b16 (what an 8-row register transpose of plain reads would issue); 2 = no LDS-DMA fills after the first tile.
-template <bool FENCE, int ABLATE = 0>
+// X3 (round 5, the split-precision mode): A_p and B_p are (hi | lo) bf16 plane pairs of fp32 activations / gradients and the K
+// slice is walked three times -- (A hi, B hi), (A lo, B hi), (A hi, B lo) -- into the same accumulators (gemm.hip, gemm_p8_kernel).
+template <bool FENCE, int ABLATE = 0, bool X3 = false>
 __global__ __launch_bounds__(256, 4) void wgrad_group_kernel(WgArgs a) {
     constexpr int TBM = 128, TBN = 128, NW = 4, TM = 4, TN = 4, BK = 64;
     constexpr int NB = TBM / 8 / NW;
@@ -187,8 +190,9 @@ __global__ __launch_bounds__(256, 4) void wgrad_group_kernel(WgArgs a) {
     ks_offsets<TBN, TN>(wn * 64, lane, ob);
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(P.A), 0, P.bytesA, 0x00020000);
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(P.B), 0, P.bytesB, 0x00020000);
-    int sa = (int)(((long)kbeg * lda + m0) * 2);
-    int sb = (int)(((long)kbeg * ldb + n0) * 2);
+    const int sa_base = (int)(((long)kbeg * lda + m0) * 2);
+    const int sb_base = (int)(((long)kbeg * ldb + n0) * 2);
+    int sa = sa_base, sb = sb_base;
     const int stepa = (int)((long)BK * lda * 2), stepb = (int)((long)BK * ldb * 2);
     int va[NB], vb[NB];
 #pragma unroll
@@ -212,8 +216,13 @@ __global__ __launch_bounds__(256, 4) void wgrad_group_kernel(WgArgs a) {
     const int t_row = (tid & 127) >> 1, t_half = tid & 1;
     const int t_ok = t_b ? (n0 + t_half * 64 < N) : (m0 + t_half * 64 < M);
     const int t_v = (int)((long)t_row * (t_b ? ldb : lda) * 2) + t_half * 128;
+    for (int pass = 0; pass < (X3 ? 3 : 1); ++pass) {
+    if constexpr (X3) {
+        sa = sa_base + (pass == 1 ? P.planeA : 0);
+        sb = sb_base + (pass == 2 ? P.planeB : 0);
+    }
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt) __builtin_amdgcn_s_barrier();      // every wave is done reading the previous tile
+        if (kt || pass) __builtin_amdgcn_s_barrier();      // every wave is done reading the previous tile
         const bool full = kt < nk_full;
         const int krem = klen - kt * BK;
         if (ABLATE != 2 || kt == 0) {
@@ -259,6 +268,7 @@ __global__ __launch_bounds__(256, 4) void wgrad_group_kernel(WgArgs a) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) mma16(fb[j], fa[i], acc[i][j]);
         }
+    }
     }
     if constexpr (ABLATE == 3) { wait_vmcnt<0>(); asm volatile("" :: "v"(touch_sink)); }
     __builtin_amdgcn_s_barrier();                  // the stage becomes the waves' private epilogue scratch
@@ -398,7 +408,9 @@ __global__ __launch_bounds__(512, 1) void wgrad_group_p8_kernel(WgArgs a) {
 
 extern "C" int mmtg_wgrad_group(int config, int n, const mmtg_wgrad_problem* probs, int K, int splits, float* ws, long ws_floats,
                                 unsigned* counters, long n_counters, int accumulate, void* stream) {
-    MMTG_REQUIRE(config == 0 || config == 1, "wgrad_group: config 0 (128x128 tiles) or 1 (256x256 eight-phase tiles)");
+    const bool x3 = (config & 2) != 0;             // split-precision operands (plane pairs), 128x128 tiles only
+    config &= ~2;
+    MMTG_REQUIRE(config == 0 || (config == 1 && !x3), "wgrad_group: config 0 (128x128 tiles), 1 (256x256 eight-phase tiles) or 2 (128x128 tiles, x3 operands)");
     const int TB = config ? 256 : 128, NWV = config ? 8 : 4, KQ = config ? 128 : 64;
     MMTG_REQUIRE(n >= 1 && n <= WG_MAXP && probs, "wgrad_group: 1..%d problems", WG_MAXP);
     MMTG_REQUIRE(K > 0 && splits >= 1, "wgrad_group: K and splits must be positive");
@@ -412,7 +424,9 @@ extern "C" int mmtg_wgrad_group(int config, int n, const mmtg_wgrad_problem* pro
         MMTG_REQUIRE(MMTG_ALIGNED16(q.A) && MMTG_ALIGNED16(q.B) && MMTG_ALIGNED16(q.C), "wgrad_group: operands must be 16-byte aligned");
         MMTG_REQUIRE(q.lda % 8 == 0 && q.ldb % 8 == 0 && q.M % 8 == 0 && q.N % 8 == 0 && q.ldc % 4 == 0 && q.lda >= q.M && q.ldb >= q.N && q.ldc >= q.N,
                      "wgrad_group: problem %d: M, N, lda, ldb multiples of 8, ldc of 4, leading dimensions >= extents", i);
-        const long bytesA = ((long)(K - 1) * q.lda + q.M) * 2, bytesB = ((long)(K - 1) * q.ldb + q.N) * 2;
+        if (x3) MMTG_REQUIRE(q.planeA % 8 == 0 && q.planeB % 8 == 0 && q.planeA >= (long)(K - 1) * q.lda + q.M && q.planeB >= (long)(K - 1) * q.ldb + q.N,
+                             "wgrad_group: problem %d: an operand's lo plane must lie behind its hi plane (distance %% 8 == 0)", i);
+        const long bytesA = ((x3 ? q.planeA : 0) + (long)(K - 1) * q.lda + q.M) * 2, bytesB = ((x3 ? q.planeB : 0) + (long)(K - 1) * q.ldb + q.N) * 2;
         MMTG_REQUIRE(bytesA < 0x7FFFFF00L && bytesB < 0x7FFFFF00L, "wgrad_group: operands must stay below 2 GiB");
         WgProb& p = a.pr[i];
         p.A = q.A; p.B = q.B; p.C = q.C; p.lda = q.lda; p.ldb = q.ldb; p.ldc = q.ldc; p.M = q.M; p.N = q.N;
@@ -421,6 +435,7 @@ extern "C" int mmtg_wgrad_group(int config, int n, const mmtg_wgrad_problem* pro
         // the squarer block of the tile grid per XCD run (see launch_dma_cfg in gemm.hip)
         p.m_fast = p.tiles_n > p.tiles_m;
         p.bytesA = (int)bytesA; p.bytesB = (int)bytesB;
+        p.planeA = x3 ? (int)(q.planeA * 2) : 0; p.planeB = x3 ? (int)(q.planeB * 2) : 0;
         tiles += p.tiles_m * p.tiles_n;
         flops += 2.0 * q.M * q.N * (double)K;
         bytes += 2.0 * ((double)q.M * K + (double)q.N * K) + 4.0 * (double)q.M * q.N;
@@ -458,7 +473,15 @@ extern "C" int mmtg_wgrad_group(int config, int n, const mmtg_wgrad_problem* pro
         attr_done = true;
     }
     static const int ablate = getenv("MMTG_WGRAD_ABLATE") ? atoi(getenv("MMTG_WGRAD_ABLATE")) : 0;
-    if (ablate) {
+    if (x3) {
+        static bool x3_done = false;
+        if (!x3_done) {
+            if (hipFuncSetAttribute((const void*)wgrad_group_kernel<false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
+                MMTG_FAIL(MMTG_ERR_HIP, "wgrad_group: cannot raise dynamic LDS to %zu bytes", shm);
+            x3_done = true;
+        }
+        hipLaunchKernelGGL((wgrad_group_kernel<false, 0, true>), dim3(tiles * splits), dim3(256), shm, s, a);
+    } else if (ablate) {
         static bool abl_done = false;
         if (!abl_done) {
             (void)hipFuncSetAttribute((const void*)wgrad_group_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);

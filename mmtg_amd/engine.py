@@ -279,8 +279,10 @@ def initial_drop_seed(rank=0):
 class Engine:
     """Owns the flat buffers and runs forward / loss / backward / optimizer."""
 
-    def __init__(self, model_cfgs, data_cfg, gpt2_cfg, master, table, dtype=hip.BF16):
+    def __init__(self, model_cfgs, data_cfg, gpt2_cfg, master, table, dtype=hip.BF16, x3=False):
         hip.lib()  # fail loudly if the extension is not built
+        if x3 and dtype != hip.F32:
+            raise ValueError("the split-precision (bf16x3) products belong to fp32 storage")
         if not master.is_cuda:
             raise RuntimeError("the MMTG engine runs on an MI355X (cuda) device only -- there is no CPU path")
         self.sh = Shapes(model_cfgs, data_cfg, gpt2_cfg)
@@ -292,7 +294,11 @@ class Engine:
         self.master = master
         self.grad = None
         self.wc = master if dtype == hip.F32 else torch.zeros(self.layout.total, device=self.dev, dtype=torch.bfloat16)
-        self.copies_fresh = dtype == hip.F32
+        # x3 (round 5): fp32 storage everywhere, the GPT-2 / LM-head products on the bf16 matrix cores as three passes over
+        # (hi | lo) bf16 plane pairs (hip.gemm_x3).  wc2 = the plane pair of the whole flat parameter buffer.
+        self.x3 = bool(x3)
+        self.wc2 = torch.zeros(2, self.layout.total, device=self.dev, dtype=torch.bfloat16) if self.x3 else None
+        self.copies_fresh = dtype == hip.F32 and not self.x3
         self._init_transposed()
         self.set_table(table)
         self.prior = torch.from_numpy(gaussian_prior(self.sh.S)).to(self.dev)
@@ -415,7 +421,7 @@ class Engine:
         self.wt = None
         self.wte_t = None
         self.wt_entries = {}
-        if self.dtype == hip.F32:
+        if self.dtype == hip.F32 and not self.x3:
             return
         pre, desc, off = "decoder.gpt2.transformer.", [], 0
         for l in range(self.sh.L):
@@ -426,14 +432,17 @@ class Engine:
                 desc.append((soff, shape[0], shape[1], off))
                 self.wt_entries[key] = (off, (shape[1], shape[0]), n)
                 off += n
-        self.wt = torch.zeros(off, device=self.dev, dtype=torch.bfloat16)
+        # (x3: one more leading dimension, the (hi | lo) plane)
+        self.wt = torch.zeros(*((2, off) if self.x3 else (off,)), device=self.dev, dtype=torch.bfloat16)
+        self.wt_total = off
         self.wt_desc = torch.tensor(desc, dtype=torch.int64, device=self.dev)
         self.wt_max = (max(d[1] for d in desc), max(d[2] for d in desc))
         # ... and a [D, Vpad] copy of the tied embedding matrix: the LM head's dgrad d_h = dlogits @ wte contracts over the
         # vocabulary, wte's ROW index -- through the copy it is a K-contiguous x K-contiguous product like every other
         # forward / dgrad product (eight-phase kernel).  Its own launch: a shared grid would be sized by its 13440 rows.
         woff, wn = self.layout.pack_range["wte"]
-        self.wte_t = torch.zeros(self.sh.D, self.layout.Vpad, device=self.dev, dtype=torch.bfloat16) if _WTE_T else None
+        self.wte_t = (torch.zeros(*((2,) if self.x3 else ()), self.sh.D, self.layout.Vpad, device=self.dev, dtype=torch.bfloat16)
+                      if (_WTE_T or self.x3) else None)
         self.wte_desc = torch.tensor([(woff, self.layout.Vpad, self.sh.D, 0)], dtype=torch.int64, device=self.dev)
 
     def Wt(self, key):   # [out, in] copy of a Conv1D weight (bf16 mode)
@@ -441,22 +450,63 @@ class Engine:
         return self.wt[off:off + n].view(shape)
 
     def _refresh_transposed(self):
-        if self.wt is not None:
+        if self.wt is not None and self.x3:
+            for pl in (0, 1):
+                hip.transpose_batch(self.wc2[pl], self.wt[pl], self.wt_desc, self.wt_desc.shape[0], *self.wt_max)
+                hip.transpose_batch(self.wc2[pl], self.wte_t[pl], self.wte_desc, 1, self.layout.Vpad, self.sh.D)
+        elif self.wt is not None:
             hip.transpose_batch(self.wc, self.wt, self.wt_desc, self.wt_desc.shape[0], *self.wt_max)
             if self.wte_t is not None:
                 hip.transpose_batch(self.wc, self.wte_t, self.wte_desc, 1, self.layout.Vpad, self.sh.D)
 
     def refresh_copies(self):
         """bf16 mode: re-derive the GEMM weight copies from the fp32 masters (an
-        external optimizer may have updated them).  654 MB of traffic, ~0.15 ms."""
-        if self.dtype != hip.F32 and not self.copies_fresh:
+        external optimizer may have updated them).  654 MB of traffic, ~0.15 ms.
+        x3 mode: the (hi | lo) plane pair of the flat buffer and its transposed copies."""
+        if self.copies_fresh:
+            return
+        if self.x3:
+            hip.split_planes(self.master, 1, self.layout.total, hip.Planes(self.wc2, 1, self.layout.total))
+            self._refresh_transposed()
+            self.copies_fresh = True
+        elif self.dtype != hip.F32:
             hip.cast_f32_to(self.master, self.wc, self.layout.total)
             self._refresh_transposed()
             self.copies_fresh = True
 
     def invalidate_copies(self):
-        if self.dtype != hip.F32:
+        if self.dtype != hip.F32 or self.x3:
             self.copies_fresh = False
+
+    # ---------------------------------------------------------------- split-precision (x3) operands
+    def Wx(self, key):
+        """Plane pair of a parameter as stored ([out,in] Linear / [in,out] Conv1D)."""
+        off, shape, n = self.layout.entries[key]
+        return hip.Planes(self.wc2[0, off:off + n], shape[0], shape[1], plane=self.layout.total)
+
+    def Wtx(self, key):
+        """Plane pair of the [out,in] copy of a Conv1D weight."""
+        off, shape, n = self.wt_entries[key]
+        return hip.Planes(self.wt[0, off:off + n], shape[0], shape[1], plane=self.wt_total)
+
+    def Wpx(self, pack, rows, cols):
+        off, n = self.layout.pack_range[pack]
+        return hip.Planes(self.wc2[0, off:off + n], rows, cols, plane=self.layout.total)
+
+    def pbuf(self, name, rows, cols):
+        """Named (hi | lo) plane-pair workspace of an fp32 [rows, cols] activation."""
+        t = self.buf(name, (2, rows, cols), torch.bfloat16)
+        return hip.Planes(t, rows, cols)
+
+    def _fwd_x3(self, xp, wkey, out, M, bias=None, planes=None, **kw):
+        """x3 forward product through the [out,in] plane pair of a Conv1D weight: out / planes = epi(x W + bias)."""
+        w = self.Wtx(wkey)
+        hip.gemm_x3(xp, w, out, M, w.rows, w.cols, planes=planes, bias=bias, **kw)
+
+    def _dgrad_x3(self, dyp, wkey, dx, M, planes=None, **kw):
+        """x3 input gradient of a Conv1D layer: dy [M,out] W[in,out]^T -- the weight as stored is the K-contiguous operand."""
+        w = self.Wx(wkey)
+        hip.gemm_x3(dyp, w, dx, M, w.rows, w.cols, planes=planes, **kw)
 
     # ---------------------------------------------------------------- GEMM helpers
     def _gemm_few_rows(self, A, Bm, out, M, N, K, transB, ldb, bias=None, lda=None):
@@ -715,11 +765,41 @@ class Engine:
 
         # ---------------- GPT-2 blocks
         layers = []
+        x3 = self.x3 and D % 128 == 0
+        a["x3"] = x3
         for l in range(sh.L):
             p = f"{pre}h.{l}."
             s = (mix_seed(seed, 3 * l + 1), mix_seed(seed, 3 * l + 2), mix_seed(seed, 3 * l + 3))   # attn, resid 1, resid 2
             mu1 = self.buf(f"l{l}_mu1", (M,), torch.float32)
             rs1 = self.buf(f"l{l}_rs1", (M,), torch.float32)
+            mu2 = self.buf(f"l{l}_mu2", (M,), torch.float32)
+            rs2 = self.buf(f"l{l}_rs2", (M,), torch.float32)
+            if x3:
+                # split-precision block: the LayerNorms and the GELU write (hi | lo) plane pairs -- only products read them --
+                # the attention context is needed in fp32 by its backward AND as planes by c_proj
+                a1 = self.pbuf(f"l{l}_a", M, D)
+                hip.layernorm_fwd_x3(hcur, a1, self.P(p + "ln_1.weight"), self.P(p + "ln_1.bias"), mu1, rs1, M, D, sh.eps)
+                qkv = self.buf(f"l{l}_qkv", (M, 3 * D))
+                self._fwd_x3(a1, p + "attn.c_attn.weight", qkv, M, bias=self.P(p + "attn.c_attn.bias"))
+                ctx = self.buf(f"l{l}_ctx", (M, D))
+                lse = self.buf(f"l{l}_lse", (B, sh.nH, T), torch.float32)
+                hip.attn_fwd(qkv, keep, ctx, lse, B, T, sh.nH, D // sh.nH, drop_p=pa, drop_seed=s[0])
+                ctxp = hip.split_planes(ctx, M, D, self.pbuf(f"l{l}_ctxp", M, D))
+                xmid = self.buf(f"l{l}_xmid", (M, D))
+                self._fwd_x3(ctxp, p + "attn.c_proj.weight", xmid, M, bias=self.P(p + "attn.c_proj.bias"),
+                             epi=hip.EPI_RESID, aux=hcur, ldaux=D, drop_p=pr, drop_seed=s[1])
+                m2 = self.pbuf(f"l{l}_m", M, D)
+                hip.layernorm_fwd_x3(xmid, m2, self.P(p + "ln_2.weight"), self.P(p + "ln_2.bias"), mu2, rs2, M, D, sh.eps)
+                u = self.buf(f"l{l}_u", (M, 4 * D))
+                gact = self.pbuf(f"l{l}_g", M, 4 * D)
+                self._fwd_x3(m2, p + "mlp.c_fc.weight", None, M, bias=self.P(p + "mlp.c_fc.bias"), planes=gact, ldc=4 * D,
+                             epi=hip.EPI_GELU, aux2=u)
+                xout = self.buf(f"resid_{l + 1}", (M, D))
+                self._fwd_x3(gact, p + "mlp.c_proj.weight", xout, M, bias=self.P(p + "mlp.c_proj.bias"),
+                             epi=hip.EPI_RESID, aux=xmid, ldaux=D, drop_p=pr, drop_seed=s[2])
+                layers.append((hcur, mu1, rs1, a1, qkv, ctx, lse, xmid, mu2, rs2, m2, u, gact, s, ctxp))
+                hcur = xout
+                continue
             a1 = self.buf(f"l{l}_a", (M, D))
             hip.layernorm_fwd(hcur, a1, self.P(p + "ln_1.weight"), self.P(p + "ln_1.bias"), mu1, rs1, M, D, sh.eps)
             qkv = self.buf(f"l{l}_qkv", (M, 3 * D))
@@ -730,8 +810,6 @@ class Engine:
             xmid = self.buf(f"l{l}_xmid", (M, D))
             self._fwd(ctx, p + "attn.c_proj.weight", xmid, M, "conv1d", bias=self.P(p + "attn.c_proj.bias"),
                       epi=hip.EPI_RESID, aux=hcur, ldaux=D, drop_p=pr, drop_seed=s[1])
-            mu2 = self.buf(f"l{l}_mu2", (M,), torch.float32)
-            rs2 = self.buf(f"l{l}_rs2", (M,), torch.float32)
             m2 = self.buf(f"l{l}_m", (M, D))
             hip.layernorm_fwd(xmid, m2, self.P(p + "ln_2.weight"), self.P(p + "ln_2.bias"), mu2, rs2, M, D, sh.eps)
             u = self.buf(f"l{l}_u", (M, 4 * D))
@@ -743,18 +821,23 @@ class Engine:
             xout = self.buf(f"resid_{l + 1}", (M, D))
             self._fwd(gact, p + "mlp.c_proj.weight", xout, M, "conv1d", bias=self.P(p + "mlp.c_proj.bias"),
                       epi=hip.EPI_RESID, aux=xmid, ldaux=D, drop_p=pr, drop_seed=s[2])
-            layers.append((hcur, mu1, rs1, a1, qkv, ctx, lse, xmid, mu2, rs2, m2, u, gact, s))
+            layers.append((hcur, mu1, rs1, a1, qkv, ctx, lse, xmid, mu2, rs2, m2, u, gact, s, None))
             hcur = xout
         muf = self.buf("lnf_mu", (M,), torch.float32)
         rsf = self.buf("lnf_rs", (M,), torch.float32)
-        hf = self.buf("hf", (M, D))
-        hip.layernorm_fwd(hcur, hf, self.P(pre + "ln_f.weight"), self.P(pre + "ln_f.bias"), muf, rsf, M, D, sh.eps)
         Vp = self.layout.Vpad
         # fp32 logits for the reference-shaped surface (MMTG.forward returns them); the fused trainer of the
         # bf16 mode keeps them in bf16 like every other activation (logits_f32=False)
         l32 = logits_f32 or self.dtype == hip.F32
         logits = self.buf("logits" if l32 else "logits_c", (M, Vp), torch.float32 if l32 else self.tdt)
-        hip.gemm(hf, self.Wp("wte"), logits, M, Vp, D, transB=True, ldb=D, out_f32=l32)
+        if x3:
+            hf = self.pbuf("hf", M, D)
+            hip.layernorm_fwd_x3(hcur, hf, self.P(pre + "ln_f.weight"), self.P(pre + "ln_f.bias"), muf, rsf, M, D, sh.eps)
+            hip.gemm_x3(hf, self.Wpx("wte", Vp, D), logits, M, Vp, D)
+        else:
+            hf = self.buf("hf", (M, D))
+            hip.layernorm_fwd(hcur, hf, self.P(pre + "ln_f.weight"), self.P(pre + "ln_f.bias"), muf, rsf, M, D, sh.eps)
+            hip.gemm(hf, self.Wp("wte"), logits, M, Vp, D, transB=True, ldb=D, out_f32=l32)
         a.update(xt=xt, t_raw=t_raw, t_ln=t_ln, st=st, enc=enc, alpha=alpha, kl=kl, o=o, ba=ba, c=c, x=x, ids32=ids32, h1=h1,
                  type_ids=type_ids, keep=keep, layers=layers, x_last=hcur, muf=muf, rsf=rsf, hf=hf, logits=logits)
         self.act = a
@@ -864,12 +947,30 @@ class Engine:
         pre = "decoder.gpt2.transformer."
         # ---- LM head (tied wte)
         dhf = self.buf("d_hf", (M, D))
-        if getattr(self, "wte_t", None) is not None and Vp % 128 == 0:
+        x3 = bool(a.get("x3"))
+        if x3:
+            # split-precision backward: d(logits) as a plane pair feeds both the LM head's dgrad (through the [D, Vpad] copy of the
+            # tied embedding) and its weight gradient (grouped kernel, config 2: written, not accumulated with atomics)
+            dlp = hip.split_planes(dlogits, M, Vp, self.pbuf("dlogits_p", M, Vp))
+            hip.gemm_x3(dlp, hip.Planes(self.wte_t, D, Vp), dhf, M, D, Vp)
+            tiles = hip.wgrad_group_sizes(((Vp, D),), 1, 0)[0]
+            hs = _LMHEAD_GROUP_SPLITS or _group_splits(tiles, M)
+            _, nws, ncnt = hip.wgrad_group_sizes(((Vp, D),), hs, 0)
+            hws = self.buf("wgrad_group_ws_head", (nws,), torch.float32) if hs > 1 else None
+            hcnt = self.ws.get(("wgrad_group_cnt", torch.int32))
+            if hcnt is None or hcnt.numel() < ncnt:
+                hcnt = self.ws[("wgrad_group_cnt", torch.int32)] = torch.zeros(ncnt, device=self.dev, dtype=torch.int32)
+            hip.wgrad_group([(dlp, a["hf"], self.Gp("wte"), Vp, D, Vp, D, D)], M, hs, hws, hcnt, accumulate=not self.wgrad_overwrite, config=2)
+            if self.wgrad_overwrite and self._ow_rec is not None:
+                self._ow_rec[1].append((self.layout.pack_range["wte"][0], Vp * D))
+        elif getattr(self, "wte_t", None) is not None and Vp % 128 == 0:
             hip.gemm(dlogits, self.wte_t, dhf, M, D, Vp, transB=True, ldb=Vp)
         else:
             hip.gemm(dlogits, self.Wp("wte"), dhf, M, D, Vp, transB=False, ldb=D)
         # (Vpad rows: the pad columns of dlogits are zero, so the pad rows of the pack receive +0)
-        if _WGRAD_GROUP and _LMHEAD_GROUP and self.dtype == hip.BF16 and M >= 256 and D % 8 == 0 and Vp % 8 == 0:
+        if x3:
+            pass
+        elif _WGRAD_GROUP and _LMHEAD_GROUP and self.dtype == hip.BF16 and M >= 256 and D % 8 == 0 and Vp % 8 == 0:
             # the tied embedding's gradient through the grouped kernel too: no fp32 atomics (bit-reproducible), and the
             # gradient is WRITTEN, so the lazy zero_grad can skip its 41 MB (the type-embedding rows are added later)
             tiles = hip.wgrad_group_sizes(((Vp, D),), 1, 0)[0]
@@ -902,12 +1003,12 @@ class Engine:
         # One grouped launch per block for its four weight gradients (mmtg_wgrad_group): the mlp.c_proj product's dy must then
         # outlive the LayerNorm backward that produces the attention c_proj's dy, so the masked gradients alternate
         # between two buffers.
-        group = _WGRAD_GROUP and self.dtype == hip.BF16 and M >= 256 and D % 8 == 0
+        group = (_WGRAD_GROUP and self.dtype == hip.BF16 and M >= 256 and D % 8 == 0) or x3
         dmask = self.buf("d_masked", (M, D)) if pr > 0 else None
         dmask_b = (self.buf("d_masked_b", (M, D)) if group else dmask) if pr > 0 else None
         if group:
             gshapes = ((D, 4 * D), (4 * D, D), (D, D), (D, 3 * D))
-            gcfg = 1 if (_WGRAD_GROUP_CFG and D >= 256) else 0
+            gcfg = 1 if (_WGRAD_GROUP_CFG and D >= 256 and not x3) else 0
             gtiles = hip.wgrad_group_sizes(gshapes, 1, gcfg)[0]
             gsplits = _group_splits(gtiles, M, 256 if gcfg else 1024)
             _, nws, ncnt = hip.wgrad_group_sizes(gshapes, gsplits, gcfg)
@@ -917,20 +1018,20 @@ class Engine:
                 gcnt = self.ws[("wgrad_group_cnt", torch.int32)] = torch.zeros(ncnt, device=self.dev, dtype=torch.int32)
         lastp = f"{pre}h.{sh.L - 1}."
         # (MMTG_WGRAD_STREAM: the top block's masked gradient goes into the buffer set of that block's parity, see below)
-        dmask_top = self.buf("d_masked_1", (M, D)) if (group and _WGRAD_STREAM and pr > 0 and (sh.L - 1) & 1) else dmask
+        dmask_top = self.buf("d_masked_1", (M, D)) if (group and not x3 and _WGRAD_STREAM and pr > 0 and (sh.L - 1) & 1) else dmask
         hip.layernorm_bwd(dhf, a["x_last"], self.P(pre + "ln_f.weight"), a["muf"], a["rsf"], None, dx,
                           self.G(pre + "ln_f.weight"), self.G(pre + "ln_f.bias"), M, D,
                           dx_masked=dmask_top, drop_p=pr, drop_seed=a["layers"][sh.L - 1][13][2],
                           dcolsum=self.G(lastp + "mlp.c_proj.bias"), ws=lnws)
         self._ready("ln_f.b")
-        du = self.buf("d_u", (M, 4 * D))
+        du = None if x3 else self.buf("d_u", (M, 4 * D))
         dm = self.buf("d_m", (M, D))
         dctx = self.buf("d_ctx", (M, D))
         dqkv = self.buf("d_qkv", (M, 3 * D))
         # MMTG_WGRAD_STREAM: block l's grouped weight gradients run on a side stream while the main stream already walks block
         # l - 1 -- the operands the chain produces (du, the two masked residual gradients, dqkv) then live in two buffer sets that
         # alternate block by block, and the main stream waits for block l + 1's launch before it rewrites that block's set.
-        stream_mode = group and _WGRAD_STREAM and pr > 0
+        stream_mode = group and _WGRAD_STREAM and pr > 0 and not x3
         if stream_mode:
             side = self._side_stream()
             odd = (self.buf("d_u_1", (M, 4 * D)), self.buf("d_masked_1", (M, D)), self.buf("d_masked_b_1", (M, D)),
@@ -942,9 +1043,46 @@ class Engine:
         dq32 = self.buf("attn_dq32", (M, D), torch.float32)
         for l in range(sh.L - 1, -1, -1):
             p = f"{pre}h.{l}."
-            (xin, mu1, rs1, a1, qkv, ctx, lse, xmid, mu2, rs2, m2, u, gact, s) = a["layers"][l]
+            (xin, mu1, rs1, a1, qkv, ctx, lse, xmid, mu2, rs2, m2, u, gact, s, ctxp) = a["layers"][l]
             if stream_mode:
                 du, dmask, dmask_b, dqkv = sets[l & 1]
+            if x3:
+                # ---- split-precision block backward: every gradient that feeds a product travels as a plane pair
+                dy = dmask if pr > 0 else dx
+                dyp = hip.split_planes(dy, M, D, self.pbuf("d_masked_p", M, D))
+                bands = self.buf("d_u_bands", ((M + 63) // 64, 4 * D), torch.float32)
+                dup = self.pbuf("d_u_p", M, 4 * D)
+                self._dgrad_x3(dyp, p + "mlp.c_proj.weight", None, M, planes=dup, ldc=4 * D, epi=hip.EPI_DGELU, aux=u, ldaux=4 * D, aux2=bands)
+                hip.colsum(bands, bands.shape[0], 4 * D, self.G(p + "mlp.c_fc.bias"))
+                self._dgrad_x3(dup, p + "mlp.c_fc.weight", dm, M)
+                hip.layernorm_bwd(dm, xmid, self.P(p + "ln_2.weight"), mu2, rs2, dx, dx2,
+                                  self.G(p + "ln_2.weight"), self.G(p + "ln_2.bias"), M, D,
+                                  dx_masked=dmask_b, drop_p=pr, drop_seed=s[1],
+                                  dcolsum=self.G(p + "attn.c_proj.bias"), ws=lnws)
+                dy2 = dmask_b if pr > 0 else dx2
+                dy2p = hip.split_planes(dy2, M, D, self.pbuf("d_masked_b_p", M, D))
+                self._dgrad_x3(dy2p, p + "attn.c_proj.weight", dctx, M)
+                hip.attn_bwd(qkv, a["keep"], ctx, dctx, lse, delta, dq32, dqkv, B, T, sh.nH, D // sh.nH,
+                             drop_p=pa, drop_seed=s[0], delta_ready=False, dbias=self.G(p + "attn.c_attn.bias"),
+                             dbias_ws=self.buf("attn_dbias_rows", (hip.attn_bwd_bias_rows(B, T, self.dtype), 3 * D), torch.float32))
+                dqkvp = hip.split_planes(dqkv, M, 3 * D, self.pbuf("d_qkv_p", M, 3 * D))
+                self._dgrad_x3(dqkvp, p + "attn.c_attn.weight", da, M)
+                keys = (p + "mlp.c_fc.weight", p + "mlp.c_proj.weight", p + "attn.c_proj.weight", p + "attn.c_attn.weight")
+                probs = [(m2, dup, self.G(keys[0]), D, 4 * D), (gact, dyp, self.G(keys[1]), 4 * D, D),
+                         (ctxp, dy2p, self.G(keys[2]), D, D), (a1, dqkvp, self.G(keys[3]), D, 3 * D)]
+                hip.wgrad_group(probs, M, gsplits, gws, gcnt, accumulate=not self.wgrad_overwrite, config=2)
+                if self.wgrad_overwrite and self._ow_rec is not None:
+                    self._ow_rec[1].extend((self.layout.entries[k][0], self.layout.entries[k][2]) for k in keys)
+                if l > 0:
+                    hip.layernorm_bwd(da, xin, self.P(p + "ln_1.weight"), mu1, rs1, dx2, dx,
+                                      self.G(p + "ln_1.weight"), self.G(p + "ln_1.bias"), M, D,
+                                      dx_masked=dmask, drop_p=pr, drop_seed=a["layers"][l - 1][13][2],
+                                      dcolsum=self.G(f"{pre}h.{l - 1}.mlp.c_proj.bias"), ws=lnws)
+                else:
+                    hip.layernorm_bwd(da, xin, self.P(p + "ln_1.weight"), mu1, rs1, dx2, dx,
+                                      self.G(p + "ln_1.weight"), self.G(p + "ln_1.bias"), M, D, ws=lnws)
+                self._ready(p + "ln_1.bias")
+                continue
             # x_out = x_mid + drop(gact W2 + b2): dy = dx * mask (already produced, with its bias gradient)
             dy = dmask if pr > 0 else dx
             # (the dGELU epilogue also emits the column sums of du per 64-row band: a [M/64, 4D] reduction
@@ -1168,7 +1306,9 @@ class Engine:
             self.opt_v = torch.zeros_like(self.master)
         self.step_count += 1
         ns = self.grad_norm_sq() if clip else None
-        hip.adamw(self.master, self.grad, self.opt_m, self.opt_v, None if self.dtype == hip.F32 else self.wc,
-                  self.layout.total, lr, betas[0], betas[1], eps, wd, self.step_count, ns, max_norm, grad_scale, count=count)
+        hip.adamw(self.master, self.grad, self.opt_m, self.opt_v,
+                  self.wc2[0] if self.x3 else None if self.dtype == hip.F32 else self.wc,
+                  self.layout.total, lr, betas[0], betas[1], eps, wd, self.step_count, ns, max_norm, grad_scale, count=count,
+                  p_lo=self.wc2[1] if self.x3 else None)
         self._refresh_transposed()
         self.copies_fresh = True

@@ -13,7 +13,7 @@ import os
 import torch
 
 F32, BF16 = 0, 1
-ABI_VERSION = 7
+ABI_VERSION = 8
 EPI_NONE, EPI_GELU, EPI_TANH, EPI_RESID, EPI_DGELU, EPI_DTANH, EPI_ATOMIC, EPI_ROWDOT = range(8)
 GEMM_NO_TR, GEMM_REGSTAGE, GEMM_SKINNY, GEMM_NO_SKINNY, GEMM_WIDE, GEMM_NO_WIDE = 1, 2, 4, 8, 16, 32
 GEMM_PERSIST, GEMM_NO_PERSIST, GEMM_ROW_ORDER, GEMM_OCC4, GEMM_NO_OCC4, GEMM_COL_BLOCK, GEMM_P256, GEMM_NO_P8, GEMM_P8 = 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384
@@ -68,7 +68,10 @@ _SIGS = {
     "mmtg_zero_ranges": ([_vp, _vp, _i, _vp], _i),
     "mmtg_sumsq": ([_vp, _l, _vp, _vp, _l, _vp], _i),
     "mmtg_sumsq_ws": ([_l], _l),
-    "mmtg_adamw": ([_vp, _vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _i, _vp, _f, _f, _vp, _vp], _i),
+    "mmtg_adamw": ([_vp, _vp, _vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _i, _vp, _f, _f, _vp, _vp], _i),
+    "mmtg_gemm_x3": ([_i, _i, _i, _vp, _l, _l, _vp, _l, _l, _vp, _l, _vp, _l, _l, _vp, _i, _vp, _l, _vp, _u, _u, _i, _vp], _i),
+    "mmtg_split_planes": ([_vp, _l, _i, _i, _vp, _l, _l, _vp], _i),
+    "mmtg_layernorm_fwd_x3": ([_vp, _vp, _l, _l, _vp, _vp, _vp, _vp, _i, _i, _f, _vp], _i),
     "mmtg_cast_f32_to": ([_i, _vp, _vp, _l, _vp], _i),
     "mmtg_cast_pad_rows": ([_i, _vp, _l, _vp, _l, _i, _i, _vp], _i),
     "mmtg_cast_to_f32": ([_i, _vp, _vp, _l, _vp], _i),
@@ -227,6 +230,52 @@ def gemm(A, B, C_, M, N, K, transA=False, transB=False, lda=None, ldb=None, ldc=
 
 EPI_SPLIT = 8
 EPI_TANH_ADD = 9
+
+
+# ------------------------------------------------------------------ split-precision ("bf16x3") products
+class Planes:
+    """(hi | lo) bf16 plane pair of an fp32 matrix [rows, cols]: ``t`` is a bf16 tensor [2, rows, ld] (or any tensor whose
+    storage holds the two planes ``plane`` elements apart, the hi plane at its data pointer)."""
+    __slots__ = ("t", "rows", "cols", "ld", "plane")
+
+    def __init__(self, t, rows, cols, ld=None, plane=None):
+        self.t, self.rows, self.cols = t, rows, cols
+        self.ld = cols if ld is None else ld
+        self.plane = rows * self.ld if plane is None else plane
+
+    @staticmethod
+    def empty(rows, cols, device):
+        return Planes(torch.empty(2, rows, cols, device=device, dtype=torch.bfloat16), rows, cols)
+
+    def float(self):
+        """hi + lo as fp32 [rows, cols] (tests)."""
+        flat = self.t.reshape(-1)
+        hi = torch.as_strided(flat, (self.rows, self.cols), (self.ld, 1), 0)
+        lo = torch.as_strided(flat, (self.rows, self.cols), (self.ld, 1), self.plane)
+        return hi.float() + lo.float()
+
+
+def split_planes(src, rows, cols, out, lds=None):
+    """fp32 [rows, cols] -> Planes ``out``."""
+    _check(lib().mmtg_split_planes(_p(src), cols if lds is None else lds, rows, cols, _p(out.t), out.ld, out.plane, _stream()), "split_planes")
+    return out
+
+
+def layernorm_fwd_x3(x, out, gamma, beta, mean, rstd, rows, cols, eps=1e-5):
+    _check(lib().mmtg_layernorm_fwd_x3(_p(x), _p(out.t), out.ld, out.plane, _p(gamma), _p(beta), _p(mean), _p(rstd), rows, cols,
+                                       float(eps), _stream()), "layernorm_fwd_x3")
+
+
+def gemm_x3(A, B, C_, M, N, K, planes=None, ldc=None, bias=None, epi=EPI_NONE, aux=None, ldaux=0, aux2=None,
+            drop_p=0.0, drop_seed=0, flags=0):
+    """C[M,N] (fp32, nullable) / planes (Planes, nullable) = epi(A B^T + bias), A [M,K] and B [N,K] as Planes
+    (include/mmtg_hip.h, mmtg_gemm_x3)."""
+    if aux is not None and not ldaux:
+        ldaux = N
+    _check(lib().mmtg_gemm_x3(M, N, K, _p(A.t), A.ld, A.plane, _p(B.t), B.ld, B.plane, _p(C_), N if ldc is None else ldc,
+                              0 if planes is None else _p(planes.t), 0 if planes is None else planes.ld,
+                              0 if planes is None else planes.plane, _p(bias), epi, _p(aux), ldaux, _p(aux2),
+                              drop_thresh(drop_p), drop_seed & 0xFFFFFFFF, flags, _stream()), "gemm_x3")
 
 
 def gemm_gather(mode, A, B, C_, M, N, K, rows, table_rows, lda, ldb, ldc=None, bias=None, epi=EPI_NONE, aux=None, ldaux=0,
@@ -429,9 +478,10 @@ def sumsq(x, n, out):
     _check(lib().mmtg_sumsq(_p(x), n, _p(out), _p(ws), need, _stream()), "sumsq")
 
 
-def adamw(p, g, m, v, p_bf16, n, lr, beta1, beta2, eps, wd, step, normsq, max_norm, grad_scale=1.0, count=None):
-    """count: optional device scalar (float32) = global row count; g is then a SUM over rows (see the header)."""
-    _check(lib().mmtg_adamw(_p(p), _p(g), _p(m), _p(v), _p(p_bf16), n, float(lr), float(beta1), float(beta2),
+def adamw(p, g, m, v, p_bf16, n, lr, beta1, beta2, eps, wd, step, normsq, max_norm, grad_scale=1.0, count=None, p_lo=None):
+    """count: optional device scalar (float32) = global row count; g is then a SUM over rows (see the header).
+    p_lo: the x3 mode's lo plane (p_bf16 is then the hi plane)."""
+    _check(lib().mmtg_adamw(_p(p), _p(g), _p(m), _p(v), _p(p_bf16), _p(p_lo), n, float(lr), float(beta1), float(beta2),
                             float(eps), float(wd), int(step), _p(normsq), float(max_norm), float(grad_scale),
                             _p(count), _stream()), "adamw")
 
@@ -460,7 +510,8 @@ def slab_sum(part, splits, stride, dst, n, accumulate=True):
 class WgradProblem(C.Structure):
     """mmtg_wgrad_problem of include/mmtg_hip.h."""
     _fields_ = [("A", C.c_void_p), ("lda", C.c_long), ("B", C.c_void_p), ("ldb", C.c_long),
-                ("C", C.c_void_p), ("ldc", C.c_long), ("M", C.c_int), ("N", C.c_int)]
+                ("C", C.c_void_p), ("ldc", C.c_long), ("M", C.c_int), ("N", C.c_int),
+                ("planeA", C.c_long), ("planeB", C.c_long)]
 
 
 def wgrad_group_sizes(shapes, splits, config=0):
@@ -472,12 +523,16 @@ def wgrad_group_sizes(shapes, splits, config=0):
 
 def wgrad_group(problems, K, splits, ws, counters, accumulate=False, config=0):
     """Grouped weight gradients C (+)= A^T B (include/mmtg_hip.h, mmtg_wgrad_group).
-    problems: list of (A [K, lda] bf16, B [K, ldb] bf16, C [M, ldc] f32, M, N[, lda, ldb, ldc])."""
+    problems: list of (A [K, lda] bf16, B [K, ldb] bf16, C [M, ldc] f32, M, N[, lda, ldb, ldc]).
+    config 2 (x3): A and B are Planes (hi | lo plane pairs)."""
     arr = (WgradProblem * len(problems))()
     for i, pr in enumerate(problems):
         A, B, C_, M, N = pr[:5]
         lda, ldb, ldc = (pr[5:8] if len(pr) >= 8 else (M, N, N))
-        arr[i] = WgradProblem(_p(A), lda, _p(B), ldb, _p(C_), ldc, M, N)
+        if config & 2:
+            arr[i] = WgradProblem(_p(A.t), lda, _p(B.t), ldb, _p(C_), ldc, M, N, A.plane, B.plane)
+        else:
+            arr[i] = WgradProblem(_p(A), lda, _p(B), ldb, _p(C_), ldc, M, N, 0, 0)
     _check(lib().mmtg_wgrad_group(int(config), len(problems), C.addressof(arr), int(K), int(splits), _p(ws), 0 if ws is None else ws.numel(),
                                   _p(counters), 0 if counters is None else counters.numel(), int(accumulate), _stream()), "wgrad_group")
 

@@ -147,7 +147,9 @@ class MMTG(nn.Module):
     Extra keyword arguments (all optional, the positional contract is unchanged):
       gpt2_config   dict overriding config/model_config.json
       token_table   WenLan table (dict or [V,2048]); default ./vocab/token_id2emb_dict.pkl
-      compute_dtype 'bf16' (default; bf16 storage, fp32 accumulate) or 'f32' (exact fp32 MFMA)
+      compute_dtype 'bf16' (default; bf16 storage, fp32 accumulate), 'f32' (exact fp32 MFMA) or 'bf16x3' (fp32 storage,
+                    the GPT-2 / lm_head products as three bf16 matrix-core passes over (hi | lo) split operands: the
+                    fp32 mode's parity at a multiple of its speed)
     """
 
     def __init__(self, model_cfgs, data_config, vocab_size, train_flag=False, gpt2_config=None,
@@ -162,7 +164,8 @@ class MMTG(nn.Module):
         assert model_cfgs["topic"]["hidden_dim"] == model_cfgs["image"]["hidden_dim"] == model_cfgs["text"]["hidden_dim"], \
             "The hidden dim of topic, image and text must be equal."
         compute_dtype = compute_dtype or os.environ.get("MMTG_DTYPE", "bf16")
-        self.compute_dtype = {"bf16": hip.BF16, "f32": hip.F32, "fp32": hip.F32}[compute_dtype]
+        self.compute_dtype = {"bf16": hip.BF16, "f32": hip.F32, "fp32": hip.F32, "bf16x3": hip.F32}[compute_dtype]
+        self.x3 = compute_dtype == "bf16x3"
 
         self.encoder = MultiModalEncoder()
         self.ln_layer1 = _Holder()
@@ -300,7 +303,7 @@ class MMTG(nn.Module):
                 raise RuntimeError("MMTG.forward needs the model on an MI355X: call model.to('cuda'). "
                                    "The hot path is HIP-only (no CPU fallback).")
             self._engine = Engine(self.model_cfgs, self.data_config, self.gpt2_cfg, self._flat,
-                                  self.decoder._table, self.compute_dtype)
+                                  self.decoder._table, self.compute_dtype, x3=self.x3)
             self._anchor = torch.zeros((), device=self._flat.device, requires_grad=True)
         return self._engine
 

@@ -25,6 +25,9 @@ DEV = "cuda"
 
 
 CASES = ["tiny_s5", "tiny_s2", "tiny_lstm2_rnn2", "tiny_gru2_lstm1"]     # the last two: LSTM / ReLU-RNN / multi-layer encoder channels
+# the two modes held to north_star's numeric gates (logits within 1e-3, greedy ids bit-exact): exact fp32 MFMA, and (round 5) fp32
+# storage with the GPT-2 / lm_head products as three bf16 matrix-core passes over (hi | lo) split operands -- SAME tolerances
+PARITY_MODES = ["f32", "bf16x3"]
 
 
 def build(case, dtype, train_flag=True):
@@ -37,9 +40,10 @@ def build(case, dtype, train_flag=True):
     return fx, meta, mcfg, gcfg, dcfg, weights, table, batch, model
 
 
+@pytest.mark.parametrize("mode", PARITY_MODES)
 @pytest.mark.parametrize("case", CASES)
-def test_forward_f32_vs_golden(case):
-    fx, meta, mcfg, gcfg, dcfg, weights, table, batch, model = build(case, "f32")
+def test_forward_f32_vs_golden(case, mode):
+    fx, meta, mcfg, gcfg, dcfg, weights, table, batch, model = build(case, mode)
     with torch.no_grad():
         lm, kl, logits = model(batch_to_torch(batch, DEV))
     err = float((logits.cpu() - torch.from_numpy(fx["logits"])).abs().max())
@@ -70,13 +74,15 @@ def test_forward_f32_vs_golden(case):
     chk("img_inner", a["alpha"]["img"][1].view(B, S, -1), fx["int_img_inner"])
     chk("mm_out", a["c"].view(B, S, -1).transpose(0, 1), fx["int_mm_out"])
     chk("block0", a["layers"][1][0].view(B, T, -1)[:, ::ts], fx["int_block0"])
-    chk("ln_f", a["hf"].view(B, T, -1)[:, ::ts], fx["int_ln_f"])
+    hf = a["hf"].float() if mode == "bf16x3" else a["hf"]          # (x3: ln_f writes the (hi | lo) plane pair only)
+    chk("ln_f", hf.view(B, T, -1)[:, ::ts], fx["int_ln_f"])
 
 
+@pytest.mark.parametrize("mode", PARITY_MODES)
 @pytest.mark.parametrize("case", CASES)
-def test_dropin_backward_f32_vs_golden(case):
+def test_dropin_backward_f32_vs_golden(case, mode):
     """reference loop train.py:188-194: forward, MyLoss, total.backward(), clip."""
-    fx, meta, mcfg, gcfg, dcfg, weights, table, batch, model = build(case, "f32")
+    fx, meta, mcfg, gcfg, dcfg, weights, table, batch, model = build(case, mode)
     hp = json.loads(str(fx["train_hparams"]))
     tb = batch_to_torch(batch, DEV)
     lm, kl, logits = model(tb)
@@ -112,9 +118,10 @@ def test_dropin_backward_f32_vs_golden(case):
     assert sd["ln_layer1.weight"].grad is None
 
 
+@pytest.mark.parametrize("mode", PARITY_MODES)
 @pytest.mark.parametrize("case", CASES)
-def test_fused_train_step_f32_vs_golden(case):
-    fx, meta, mcfg, gcfg, dcfg, weights, table, batch, model = build(case, "f32")
+def test_fused_train_step_f32_vs_golden(case, mode):
+    fx, meta, mcfg, gcfg, dcfg, weights, table, batch, model = build(case, mode)
     hp = json.loads(str(fx["train_hparams"]))
     tr = MMTGTrainer(model, lr=hp["lr"], alpha=hp["alpha"], max_norm=hp["clip"], eps=hp["eps"], weight_decay=hp["wd"])
     out = tr.step(batch_to_torch(batch, DEV), stage=hp["stage"], filter_rows=False)
@@ -132,8 +139,9 @@ def test_fused_train_step_f32_vs_golden(case):
         np.testing.assert_allclose(got, fx["pval_" + k], atol=0.2 * hp["lr"], rtol=0, err_msg=k)
 
 
-def test_full_shape_f32_spot_checks():
-    fx, meta, mcfg, gcfg, dcfg, weights, table, batch, model = build("full_12l", "f32")
+@pytest.mark.parametrize("mode", PARITY_MODES)
+def test_full_shape_f32_spot_checks(mode):
+    fx, meta, mcfg, gcfg, dcfg, weights, table, batch, model = build("full_12l", mode)
     with torch.no_grad():
         lm, kl, logits = model(batch_to_torch(batch, DEV))
     lg = logits.cpu()
@@ -183,15 +191,16 @@ def test_bf16_vs_oracle(case):
         assert 0.9 < float(g.norm() / (r.norm() + 1e-30)) < 1.1, k
 
 
+@pytest.mark.parametrize("mode", PARITY_MODES)
 @pytest.mark.parametrize("route", ["cached", "rerun"])
 @pytest.mark.parametrize("length,row,case", [(30, 0, "tiny_s5"), (30, 1, "tiny_s5"), (220, 0, "tiny_s5"), (30, 0, "tiny_lstm2_rnn2")])
-def test_greedy_decode_bit_exact(length, row, case, route, monkeypatch):
+def test_greedy_decode_bit_exact(length, row, case, route, mode, monkeypatch):
     """The drop-in sample_sequence against the reference's own id lists, on both of its routes: the KV-cached graph-replayed
     decoder (the default for the reference's call) and the reference-shaped loop that re-runs the prefix (MMTG_SAMPLE_RERUN)."""
     from mmtg_amd import generate as G
     if route == "rerun":
         monkeypatch.setenv("MMTG_SAMPLE_RERUN", "1")
-    fx, meta, mcfg, gcfg, dcfg, weights, table, batch, model = build(case, "f32", train_flag=False)
+    fx, meta, mcfg, gcfg, dcfg, weights, table, batch, model = build(case, mode, train_flag=False)
     probe = {"targets": np.asarray([1])}
     assert (G._cached_decoder(model, probe, length) is not None) == (route == "cached")
     dp = json.loads(str(fx["decode_params"]))
@@ -227,9 +236,10 @@ def test_sample_sequence_stochastic_setting_follows_the_rules():
                 assert ids[j] not in (1, 2, 100, 102)
 
 
-def test_inference_branch_logits_vs_golden():
+@pytest.mark.parametrize("mode", PARITY_MODES)
+def test_inference_branch_logits_vs_golden(mode):
     """Inference-branch forward (rebuilt type ids / mask, model.py:290-326) at a few prefix lengths."""
-    fx, meta, mcfg, gcfg, dcfg, weights, table, batch, model = build("tiny_s5", "f32", train_flag=False)
+    fx, meta, mcfg, gcfg, dcfg, weights, table, batch, model = build("tiny_s5", mode, train_flag=False)
     ids = fx["greedy_len220_row0"]
     raw = fx["greedy_len220_row0_rawlogits"]
     tb = batch_to_torch(batch, DEV)
@@ -572,7 +582,7 @@ def test_full_12l_bf16_logits_vs_golden():
     assert abs(kl.item() - float(fx["kl"])) < 3e-2 * abs(float(fx["kl"]))
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16x3", "bf16"])
 def test_full_12l_gradients_vs_golden(dtype):
     """Full-size backward (12 layers, V = 13317, T = 236, B = 2) against the reference's autograd: global norm,
     per-tensor norms and the sampled gradient values of every one of the 197 parameter tensors (train.py:188-194
@@ -585,7 +595,7 @@ def test_full_12l_gradients_vs_golden(dtype):
     loss = MyLoss(dcfg, mcfg)(logits.contiguous(), tb["targets"].contiguous(), tb["rating"], hp["stage"])
     total = loss.mean() + hp["alpha"] * kl.mean()
     total.backward()
-    f32 = dtype == "f32"
+    f32 = dtype in PARITY_MODES
     ref_total = float(fx["train_total_loss"])
     assert abs(total.item() - ref_total) < (1e-4 if f32 else 5e-3) * abs(ref_total)
     gn = float(torch.nn.utils.clip_grad_norm_(model.parameters(), hp["clip"]).item())
@@ -629,9 +639,10 @@ def test_full_12l_gradients_vs_golden(dtype):
             min_family_cosine=cos_min)
 
 
-def test_full_12l_fused_step_f32_vs_golden():
+@pytest.mark.parametrize("mode", PARITY_MODES)
+def test_full_12l_fused_step_f32_vs_golden(mode):
     """One fused clip + AdamW step at full size lands on the reference's parameters (sampled, every tensor)."""
-    fx, meta, mcfg, gcfg, dcfg, weights, table, batch, model = build("full_12l", "f32")
+    fx, meta, mcfg, gcfg, dcfg, weights, table, batch, model = build("full_12l", mode)
     hp = json.loads(str(fx["train_hparams"]))
     tr = MMTGTrainer(model, lr=hp["lr"], alpha=hp["alpha"], max_norm=hp["clip"], eps=hp["eps"], weight_decay=hp["wd"])
     out = tr.step(batch_to_torch(batch, DEV), stage=hp["stage"], filter_rows=False)
@@ -693,7 +704,7 @@ def _teacher_forced_greedy(model, fx, batch, case_len, row, bound):
 
 
 @pytest.mark.parametrize("case,dtype,bound", [("tiny_s5", "bf16", 0.12), ("full_12l", "bf16", BF16_12L_LOGIT_MAX),
-                                               ("full_12l", "f32", 1e-3)])
+                                               ("full_12l", "f32", 1e-3), ("full_12l", "bf16x3", 1e-3)])
 def test_greedy_ids_vs_golden_at_reduced_precision(case, dtype, bound):
     """Greedy token agreement of the bf16 mode with the reference's id lists (and of the f32 mode at full depth): at
     every call whose reference top-2 margin exceeds twice the mode's logit error bound (divided by the temperature
@@ -704,7 +715,7 @@ def test_greedy_ids_vs_golden_at_reduced_precision(case, dtype, bound):
             first_divergence_margin=None if first is None else first[1], worst_missed_margin=worst)
     assert n >= 120
     assert worst <= 2 * bound / 1.1, (worst, first)
-    if dtype == "f32":
+    if dtype in PARITY_MODES:
         assert ok == n
 
 
