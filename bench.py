@@ -535,7 +535,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="rows per GPU")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "bf16x3"])
     ap.add_argument("--layers", type=int, default=12)
     ap.add_argument("--config", default="base", choices=["base", "medium"],
                     help="medium: BASELINE configs[4] (GPT-2-medium 24L/1024/16H, S=8, T=512, rating skew K=32)")

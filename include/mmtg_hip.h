@@ -429,6 +429,30 @@ MMTG_API int mmtg_decode_gemm(int mode, int M, int N, int K, const void* A, long
                      const void* resid, long ldr, float* stats_out, int splits, float* ws, long ws_floats, unsigned* counters,
                      long n_counters, const void* emb_pos, const void* emb_type, const long long* type_ids, const int* pos_ptr,
                      void* stream);
+/* ---- split-precision ("bf16x3") token step, round 5.  The products of the decode step on (hi | lo) bf16 plane pairs of fp32 tensors
+ * (three passes A_hi W_hi + A_lo W_hi + A_hi W_lo, fp32 accumulate; see mmtg_gemm_x3): fp32 residual stream, fp32 KV cache, fp32
+ * logits -- greedy ids equal to the reference's fp32 loop (generate.py:117-142) at a multiple of the exact-fp32 kernels' speed.
+ * mmtg_decode_gemm_x3: the three modes of mmtg_decode_gemm with A [M, K] / W [N, K] as plane pairs (lo plane planeA / planeW elements
+ *   behind), K % 64 == 0.  mode 0: fp32 rows C (the logits) OR the activation as a plane pair Cp (ld = ldcp, lo plane planeC elements
+ *   behind); mode 1: fp32 slabs C [splits][M][ldc]; mode 2: v = act(sum + bias) + residual with act in {NONE, TANH}, residual = resid
+ *   (fp32, nullable) or wpe[*pos] + wte[type_ids[m]] (fp32 tables), written as fp32 rows C and / or a plane pair Cp, + the row
+ *   statistics of v (stats_out nullable).
+ * mmtg_ln_fold_weights_x3: W' = gamma (.) W re-split into a plane pair, colsum[n] = sum_k W'[n, k], bias_f = bias + beta W.
+ * mmtg_decode_attn_split_x3: mmtg_decode_attn_split on an fp32 KV cache, the context rows written as a plane pair.
+ * mmtg_decode_embed_x3: mmtg_decode_embed on the fp32 table / experience vectors, x written as a plane pair.                         */
+MMTG_API int mmtg_decode_gemm_x3(int mode, int M, int N, int K, const void* A, long lda, long planeA, const void* W, long ldw, long planeW,
+                        float* C, long ldc, void* Cp, long ldcp, long planeC, const float* bias, const float* colsum,
+                        const float* stats_in, int np_in, float eps, int act, const float* resid, long ldr, float* stats_out,
+                        int splits, float* ws, long ws_floats, unsigned* counters, long n_counters, const float* emb_pos,
+                        const float* emb_type, const long long* type_ids, const int* pos_ptr, void* stream);
+MMTG_API int mmtg_ln_fold_weights_x3(const void* W, long ldw, long planeW, const float* gamma, const float* beta, const float* bias,
+                            void* Wf, long ldf, long planeF, float* colsum, float* bias_f, int N, int K, void* stream);
+MMTG_API int mmtg_decode_attn_split_x3(const float* part, int splits, const float* bias, float* kcache, float* vcache, const int* keep,
+                              long ldkeep, const int* pos_ptr, void* out_planes, long plane, int B, int nH, int dh, int Tmax, void* stream);
+MMTG_API int mmtg_decode_embed_x3(const float* table, const long long* seq, long ldseq, const float* c, void* x_planes, long plane,
+                         const int* pos_ptr, const long long* tpw_type, const long long* tpw_mask, long long* type_out, int* keep,
+                         long ldkeep, int B, int P, int S, int E, int two_sents, int V, int sent, int max_sent_num, void* stream);
+
 /* Round 4 -- the twelve GPT-2 blocks and the head of a token step as ONE persistent launch (replaces the 61 dependent launches behind
  * generate.py:124's per-token model call).  A stage list is built on the HOST, one descriptor of mmtg_decode_stage_bytes() bytes per
  * stage, with the argument lists of the launches it replaces (mmtg_decode_stage_gemm = mmtg_decode_gemm without the embedding

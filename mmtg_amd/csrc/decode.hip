@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) void decode_embed_kernel(const T* __restrict__
         long ldseq, const T* __restrict__ c, T* __restrict__ x, const int* __restrict__ pos_ptr,
         const long long* __restrict__ tpw_type, const long long* __restrict__ tpw_mask,
         long long* __restrict__ type_out, int* __restrict__ keep, long ldkeep,
-        int P, int S, int E, int two_sents, int V, int sent, int max_sent_num) {
+        int P, int S, int E, int two_sents, int V, int sent, int max_sent_num, bf16* __restrict__ xp = nullptr, long planeX = 0) {
     typedef typename Vec16<T>::type V16t;
     constexpr int N = Vec16<T>::N;
     const int b = blockIdx.x, pos = *pos_ptr;
@@ -359,6 +359,16 @@ __global__ __launch_bounds__(256) void decode_embed_kernel(const T* __restrict__
             V16t w = *reinterpret_cast<const V16t*>(cs + e);
 #pragma unroll
             for (int k = 0; k < N; ++k) v[k] = (T)((float)v[k] + (float)w[k]);
+        }
+        if constexpr (N == 4) {
+            if (xp) {        // x3: the conditioned embedding as a (hi | lo) plane pair (the projector product is its only reader)
+                bf16x4 hi, lo;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { hi[k] = (bf16)(float)v[k]; lo[k] = (bf16)((float)v[k] - (float)hi[k]); }
+                *reinterpret_cast<bf16x4*>(xp + (long)b * E + e) = hi;
+                *reinterpret_cast<bf16x4*>(xp + planeX + (long)b * E + e) = lo;
+                continue;
+            }
         }
         *reinterpret_cast<V16t*>(dst + e) = v;
     }
@@ -405,6 +415,10 @@ struct DgArgs {
     // mode 2, residual = wpe[*pos_ptr] + wte[type_ids[m]] instead of a tensor (the GPT-2 input embedding added in the projector's epilogue)
     const bf16* emb_pos; const bf16* emb_type; const long long* type_ids; const int* pos_ptr;
     int bytesC, bytesR;        // extents of C (all slabs) and of the residual: buffer descriptors of the coherent (persistent) form
+    // x3 (round 5, mmtg_decode_gemm_x3): A and W are (hi | lo) bf16 plane pairs of fp32 tensors, walked as three passes; C / resid /
+    // the embedding tables are fp32; Cp (nullable) receives the result as a plane pair for the next product
+    int planeA, planeW;        // bytes from the hi plane to the lo plane
+    bf16* Cp; long ldcp, planeC;       // planeC: elements
 };
 
 // Agent-scope (sc1: write-through store / L1-bypassing load, cache-policy operand 16) accessors of the persistent token step: a
@@ -436,8 +450,11 @@ constexpr int DG_DEP_LINK = 2 * 64 * DG_DEP_STRIDE;        // words per link: 64
 // rewritten by a later stage and read again inside one launch, so a consumer's L2 can hold a stale line); the chained launch orders its
 // stages so that no tensor is read again after it was rewritten inside the launch, and reads through the L2 like a stand-alone launch
 // (a line a consumer asks for after its row block's counter is complete was never in its L2 before: the launch began with an invalidate).
-template <int MODE, bool COH, int NBUF, int MAXS = 8, bool CHAIN = false, bool COHL = COH>
+// X3 (round 5): the split-precision form -- operands as (hi | lo) plane pairs, the K slice walked three times (A hi x W hi, A lo x W hi,
+// A hi x W lo: only the scalar offsets of a tile change), fp32 residual stream / embeddings, results as fp32 and / or plane pairs.
+template <int MODE, bool COH, int NBUF, int MAXS = 8, bool CHAIN = false, bool COHL = COH, bool X3 = false>
 __device__ __forceinline__ void dg_tile(const DgArgs& p, const int bid, char* smem, const DgDep* dep = nullptr) {
+    static_assert(!X3 || (!COH && !CHAIN), "x3: stand-alone launches only");
     constexpr int TB = 64, NW = 4, BK = 64, NB = 2;
     constexpr int TA = TB * 128, STAGE = 2 * TA;
     constexpr int AUXA = COHL ? 16 : 0;                               // cache policy of the activation operand's LDS-DMA
@@ -455,7 +472,8 @@ __device__ __forceinline__ void dg_tile(const DgArgs& p, const int bid, char* sm
     const int m0 = (t / p.tiles_n) * TB, n0 = (t % p.tiles_n) * TB;
     const int kbeg = split * p.kper;
     const int klen = max(0, min(p.K, kbeg + p.kper) - kbeg);
-    const int nk = (klen + BK - 1) / BK, nk_full = klen / BK;
+    const int nk1 = (klen + BK - 1) / BK;                  // (x3: the host keeps K slices whole 64-deep tiles)
+    const int nk = X3 ? 3 * nk1 : nk1, nk_full = X3 ? nk : klen / BK;
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.A), 0, p.bytesA, 0x00020000);
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.W), 0, p.bytesW, 0x00020000);
     int sa = (int)(((long)m0 * p.lda + kbeg) * 2), sb = (int)(((long)n0 * p.ldw + kbeg) * 2);
@@ -516,14 +534,20 @@ __device__ __forceinline__ void dg_tile(const DgArgs& p, const int bid, char* sm
         char* st_ = smem + ((tt) % NBUF) * STAGE;                                                                      \
         const bool full_ = (tt) < nk_full, live_ = (tt) < nk;                                                          \
         const int krem_ = klen - (tt) * BK;                                                                            \
+        /* x3: pass = tt / nk1 (1 reads A's lo plane, 2 reads W's), K tile tt % nk1 of the slice */                     \
+        const int pass_ = X3 ? ((tt) >= nk1 ? 1 : 0) + ((tt) >= 2 * nk1 ? 1 : 0) : 0;                                  \
+        const int sa_ = X3 ? sa + ((tt) - pass_ * nk1) * (BK * 2) + (pass_ == 1 ? p.planeA : 0) : sa;                  \
+        const int sb_ = X3 ? sb + ((tt) - pass_ * nk1) * (BK * 2) + (pass_ == 2 ? p.planeW : 0) : sb;                  \
         _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                                               \
             const int oa_ = !live_ ? OOB : full_ ? va[i] : dma_voff<false, TB>(p.lda, m0, p.M, krem_, wave + NW * i, lane); \
             const int ob_ = !live_ ? OOB : full_ ? vb[i] : dma_voff<false, TB>(p.ldw, n0, p.N, krem_, wave + NW * i, lane); \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, LDS_PTR(void, st_ + (wave + NW * i) * 1024), 16, oa_, live_ ? sa : 0, 0, AUXA); \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, LDS_PTR(void, st_ + TA + (wave + NW * i) * 1024), 16, ob_, live_ ? sb : 0, 0, 0); \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, LDS_PTR(void, st_ + (wave + NW * i) * 1024), 16, oa_, live_ ? sa_ : 0, 0, AUXA); \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, LDS_PTR(void, st_ + TA + (wave + NW * i) * 1024), 16, ob_, live_ ? sb_ : 0, 0, 0); \
         }                                                                                                              \
-        sa += BK * 2;                                                                                                  \
-        sb += BK * 2;                                                                                                  \
+        if constexpr (!X3) {                                                                                           \
+            sa += BK * 2;                                                                                              \
+            sb += BK * 2;                                                                                              \
+        }                                                                                                              \
     } while (0)
 #pragma unroll
     for (int t0 = 0; t0 < NBUF - 1; ++t0) DG_ISSUE(t0);
@@ -610,6 +634,13 @@ __device__ __forceinline__ void dg_tile(const DgArgs& p, const int bid, char* sm
                     if (p.out_f32) {
                         if constexpr (COH) dg_st4_agent(dg_rsrc(p.C, p.bytesC), (int)(((long)m * p.ldc + n) * 4), v);
                         else *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n) = v;
+                    } else if constexpr (X3) {          // the activation as a plane pair: only the next product reads it
+                        bf16x4 hi, lo;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { hi[r] = (bf16)v[r]; lo[r] = (bf16)(v[r] - (float)hi[r]); }
+                        bf16* dst = p.Cp + (long)m * p.ldcp + n;
+                        *reinterpret_cast<bf16x4*>(dst) = hi;
+                        *reinterpret_cast<bf16x4*>(dst + p.planeC) = lo;
                     } else {
                         const bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
                         if constexpr (COH) dg_st2_agent(dg_rsrc(p.C, p.bytesC), (int)(((long)m * p.ldc + n) * 2), __builtin_bit_cast(u32x2, o));
@@ -666,6 +697,36 @@ __device__ __forceinline__ void dg_tile(const DgArgs& p, const int bid, char* sm
                     const f32x4 v = s_ == split ? acc[i][j] : prt[s_][i * 2 + j];
                     if (s_ < S) sum += v;
                 }
+                if constexpr (X3) {
+                    if (m < p.M && n < p.N) {
+                        const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + n);
+                        f32x4 xr = {0.f, 0.f, 0.f, 0.f};
+                        if (p.type_ids) {
+                            const f32x4 e0 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.emb_pos) + (long)*p.pos_ptr * p.ldr + n);
+                            const f32x4 e1 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.emb_type) + p.type_ids[m] * p.ldr + n);
+                            xr = e0 + e1;
+                        } else if (p.resid) xr = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.resid) + (long)m * p.ldr + n);
+                        f32x4 f;
+                        bf16x4 hi, lo;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            f[r] = sum[r] + b4[r];
+                            if (p.act == MMTG_EPI_TANH) f[r] = tanh_t<bf16>(f[r]);
+                            f[r] += xr[r];
+                            r1 += f[r];
+                            r2 += f[r] * f[r];
+                            hi[r] = (bf16)f[r];
+                            lo[r] = (bf16)(f[r] - (float)hi[r]);
+                        }
+                        if (p.C) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n) = f;
+                        if (p.Cp) {
+                            bf16* dst = p.Cp + (long)m * p.ldcp + n;
+                            *reinterpret_cast<bf16x4*>(dst) = hi;
+                            *reinterpret_cast<bf16x4*>(dst + p.planeC) = lo;
+                        }
+                    }
+                    continue;
+                }
                 if (m < p.M && n < p.N) {
                     const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + n);
                     float xr[4];
@@ -700,7 +761,7 @@ __device__ __forceinline__ void dg_tile(const DgArgs& p, const int bid, char* sm
             // the row's 32 columns of this wave tile live in the four lane groups g: fold them
             r1 += __shfl_xor(r1, 16, 64); r2 += __shfl_xor(r2, 16, 64);
             r1 += __shfl_xor(r1, 32, 64); r2 += __shfl_xor(r2, 32, 64);
-            if (g == 0 && m < p.M && nw0 < p.N) {
+            if (g == 0 && m < p.M && nw0 < p.N && (!X3 || p.stats_out)) {
                 float* dst = p.stats_out + ((long)m * DG_NP + (nw0 >> 5)) * 2;
                 if constexpr (COH) {
                     const f32x2 rr2 = {r1, r2};
@@ -724,6 +785,41 @@ template <int MODE>
 __global__ __launch_bounds__(256, 2) void decode_gemm_kernel(DgArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];      // 4 stages | row statistics
     dg_tile<MODE, false, 4>(p, blockIdx.x, smem);
+}
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void decode_gemm_x3_kernel(DgArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // 4 stages | row statistics
+    dg_tile<MODE, false, 4, 8, false, false, true>(p, blockIdx.x, smem);
+}
+
+// x3 weight preparation, one wave per output row n of a K-contiguous weight given as a plane pair W = hi + lo ([N, K]):
+//   W'[n, k] = gamma[k] W[n, k] re-split into a plane pair, c[n] = sum_k (W'_hi + W'_lo)[n, k] (of what the product multiplies),
+//   bf[n] = bias[n] + sum_k beta[k] W[n, k]
+__global__ __launch_bounds__(256) void ln_fold_x3_kernel(const bf16* __restrict__ W, long ldw, long planeW, const float* __restrict__ gamma,
+        const float* __restrict__ beta, const float* __restrict__ bias, bf16* __restrict__ Wf, long ldf, long planeF, float* __restrict__ c,
+        float* __restrict__ bf, int N, int K) {
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (n >= N) return;
+    float sc = 0.f, sb = 0.f;
+    for (int k = lane * 8; k < K; k += 512) {
+        const bf16x8 wh = *reinterpret_cast<const bf16x8*>(W + (long)n * ldw + k);
+        const bf16x8 wl = *reinterpret_cast<const bf16x8*>(W + planeW + (long)n * ldw + k);
+        bf16x8 oh, ol;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float w = (float)wh[e] + (float)wl[e];
+            const float f = gamma[k + e] * w;
+            oh[e] = (bf16)f;
+            ol[e] = (bf16)(f - (float)oh[e]);
+            sc += (float)oh[e] + (float)ol[e];
+            sb += beta[k + e] * w;
+        }
+        *reinterpret_cast<bf16x8*>(Wf + (long)n * ldf + k) = oh;
+        *reinterpret_cast<bf16x8*>(Wf + planeF + (long)n * ldf + k) = ol;
+    }
+    sc = wave_sum(sc);
+    sb = wave_sum(sb);
+    if (lane == 0) { c[n] = sc; bf[n] = (bias ? bias[n] : 0.f) + sb; }
 }
 
 // W'[n, k] = gamma[k] W[n, k] (bf16), c[n] = sum_k W'[n, k] (of the ROUNDED values: what the product will multiply),
@@ -822,13 +918,12 @@ template <typename T, bool COH, bool NT = false>
 __device__ __forceinline__ void da_body(const T* __restrict__ qkv, T* __restrict__ kc, T* __restrict__ vc,
         const int* __restrict__ keep, long ldkeep, const int pos, T* __restrict__ out, const int B,
         int nH, int Tmax, const float* __restrict__ part, int splits, long slab, const float* __restrict__ bias,
-        const int h, const int b, const int lane, char* lds) {
+        const int h, const int b, const int lane, char* lds, bf16* __restrict__ oplanes = nullptr, long oplane = 0) {
     typedef typename Vec16<T>::type V;
     constexpr int EPL = Vec16<T>::N, OCT = 64 / EPL, KPI = 64 / OCT;      // elements per lane, lanes per key, keys per instruction
     // (the SAME chunking in both forms: the first chunk's scores and the later chunks' come out of differently contracted
     //  loops, so moving the chunk boundary moves last bits -- the persistent step stays bit-equal to the per-launch one)
     constexpr int UN = 4, CH = UN * KPI;         // a chunk: UN keys per lane group = 32 keys (bf16) / 16 (f32)
-    float* const sp = reinterpret_cast<float*>(lds);
     int* const skeep = reinterpret_cast<int*>(lds + 4096);
     float* const sq = reinterpret_cast<float*>(lds + 8192);
     T* const sk = reinterpret_cast<T*>(lds + 8192 + 256);
@@ -981,6 +1076,17 @@ __device__ __forceinline__ void da_body(const T* __restrict__ qkv, T* __restrict
         V o;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) o[e] = (T)(acc[e] * inv);
+        if constexpr (EPL == 4 && !COH) {
+            if (oplanes) {        // x3: the context row as a (hi | lo) plane pair (attn.c_proj is its only reader)
+                bf16x4 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { hi[e] = (bf16)(float)o[e]; lo[e] = (bf16)((float)o[e] - (float)hi[e]); }
+                bf16* dst = oplanes + (long)b * D + h * 64 + oc * 4;
+                *reinterpret_cast<bf16x4*>(dst) = hi;
+                *reinterpret_cast<bf16x4*>(dst + oplane) = lo;
+                return;
+            }
+        }
         if constexpr (COH) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), dg_rsrc(out, (int)((long)B * D * sizeof(T))),
                                                                  (int)(((long)b * D + h * 64 + oc * EPL) * sizeof(T)), 0, 16);
         else *reinterpret_cast<V*>(out + (long)b * D + h * 64 + oc * EPL) = o;
@@ -991,10 +1097,11 @@ __device__ __forceinline__ void da_body(const T* __restrict__ qkv, T* __restrict
 template <typename T, bool NT = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void decode_attn_kernel(const T* __restrict__ qkv, T* __restrict__ kc, T* __restrict__ vc,
         const int* __restrict__ keep, long ldkeep, const int* __restrict__ pos_ptr, T* __restrict__ out,
-        int nH, int Tmax, const float* __restrict__ part, int splits, long slab, const float* __restrict__ bias) {
+        int nH, int Tmax, const float* __restrict__ part, int splits, long slab, const float* __restrict__ bias,
+        bf16* __restrict__ oplanes = nullptr, long oplane = 0) {
     __shared__ __attribute__((aligned(16))) char lds[da_lds_bytes<T>()];
     da_body<T, false, NT>(qkv, kc, vc, keep, ldkeep, *pos_ptr, out, (int)gridDim.y, nH, Tmax, part, splits, slab, bias,
-                      (int)blockIdx.x, (int)blockIdx.y, (int)threadIdx.x, lds);
+                      (int)blockIdx.x, (int)blockIdx.y, (int)threadIdx.x, lds, oplanes, oplane);
 }
 
 
@@ -1394,6 +1501,119 @@ extern "C" int mmtg_decode_gemm(int mode, int M, int N, int K, const void* A, lo
     else if (mode == 1) hipLaunchKernelGGL(decode_gemm_kernel<1>, grid, block, shm, s, a);
     else hipLaunchKernelGGL(decode_gemm_kernel<2>, grid, block, shm, s, a);
     MMTG_LAUNCH_CHECK("decode_gemm");
+    return MMTG_OK;
+}
+
+// ------------------------------------------------------------------ split-precision token step (round 5)
+// The same fused products on (hi | lo) plane pairs: fp32 residual stream, fp32 KV cache, fp32 logits -- the decode step whose
+// greedy ids equal the reference's (generate.py:117-142 in fp32 arithmetic) at a multiple of the exact-fp32 kernels' speed.
+extern "C" int mmtg_decode_gemm_x3(int mode, int M, int N, int K, const void* A, long lda, long planeA, const void* W, long ldw, long planeW,
+                                   float* C, long ldc, void* Cp, long ldcp, long planeC, const float* bias, const float* colsum,
+                                   const float* stats_in, int np_in, float eps, int act, const float* resid, long ldr, float* stats_out,
+                                   int splits, float* ws, long ws_floats, unsigned* counters, long n_counters, const float* emb_pos,
+                                   const float* emb_type, const long long* type_ids, const int* pos_ptr, void* stream) {
+    MMTG_REQUIRE(mode >= 0 && mode <= 2, "decode_gemm_x3: mode 0 (LN-fold), 1 (LN-fold slabs) or 2 (in-kernel split-K reduce)");
+    MMTG_REQUIRE(M > 0 && N > 0 && K > 0 && A && W && (C || Cp), "decode_gemm_x3: bad arguments");
+    MMTG_REQUIRE(K % 64 == 0 && lda % 8 == 0 && ldw % 8 == 0 && N % 4 == 0 && planeA % 8 == 0 && planeW % 8 == 0,
+                 "decode_gemm_x3: K a multiple of 64; lda, ldw, plane distances of 8; N of 4");
+    MMTG_REQUIRE(MMTG_ALIGNED16(A) && MMTG_ALIGNED16(W) && MMTG_ALIGNED16(C) && MMTG_ALIGNED16(Cp) && (!C || ldc % 4 == 0) && (!Cp || (ldcp % 4 == 0 && planeC % 4 == 0)),
+                 "decode_gemm_x3: 16-byte alignment");
+    MMTG_REQUIRE(planeA >= (long)(M - 1) * lda + K && planeW >= (long)(N - 1) * ldw + K && (!Cp || planeC >= (long)(M - 1) * ldcp + N),
+                 "decode_gemm_x3: a lo plane must lie behind its hi plane");
+    if (splits < 1) splits = 1;
+    DgArgs a;
+    memset(&a, 0, sizeof(a));
+    a.A = (const bf16*)A; a.W = (const bf16*)W; a.C = C; a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr;
+    a.Cp = (bf16*)Cp; a.ldcp = ldcp; a.planeC = planeC;
+    a.M = M; a.N = N; a.K = K;
+    a.kper = cdiv(cdiv(K, splits), 64) * 64;
+    a.splits = cdiv(K, a.kper);
+    a.tiles_n = cdiv(N, 64);
+    a.ntiles = cdiv(M, 64) * a.tiles_n;
+    const long bytesA = (planeA + (long)(M - 1) * lda + K) * 2, bytesW = (planeW + (long)(N - 1) * ldw + K) * 2;
+    MMTG_REQUIRE(bytesA < 0x7FFFFF00L && bytesW < 0x7FFFFF00L, "decode_gemm_x3: plane pairs must stay below 2 GiB");
+    a.bytesA = (int)bytesA; a.bytesW = (int)bytesW; a.planeA = (int)(planeA * 2); a.planeW = (int)(planeW * 2);
+    a.bias = bias; a.colsum = colsum; a.stats_in = stats_in; a.np_in = np_in; a.eps = eps; a.inv_k = 1.0f / (float)K;
+    a.act = act; a.out_f32 = C != nullptr; a.resid = (const bf16*)resid; a.stats_out = stats_out; a.ws = ws; a.cnt = counters;
+    a.ws_bytes = (int)(ws_floats < (1L << 29) ? ws_floats * 4 : 0x7FFFFFF0L);
+    if (mode != 2) {
+        MMTG_REQUIRE(colsum && stats_in && np_in >= 1 && np_in <= DG_NP && MMTG_ALIGNED16(stats_in) && MMTG_ALIGNED16(colsum),
+                     "decode_gemm_x3: LN-fold needs the weight column sums and the row statistics ([M][%d][2] floats, np_in partials)", DG_NP);
+        MMTG_REQUIRE(mode == 1 || (bias && MMTG_ALIGNED16(bias) && a.splits == 1), "decode_gemm_x3: mode 0 is a single K slice with the folded bias");
+        MMTG_REQUIRE(mode == 0 || (C && !Cp), "decode_gemm_x3: mode 1 writes fp32 slabs [splits][M][ldc]");
+        MMTG_REQUIRE(mode == 1 || ((C != nullptr) != (Cp != nullptr)), "decode_gemm_x3: mode 0 writes fp32 rows OR a plane pair");
+        MMTG_REQUIRE(act == MMTG_EPI_NONE || act == MMTG_EPI_GELU, "decode_gemm_x3: LN-fold activation NONE or GELU");
+    } else {
+        MMTG_REQUIRE(!type_ids || (emb_pos && emb_type && pos_ptr && !resid), "decode_gemm_x3: the embedding residual takes wpe, wte, type ids and the position (and no resid)");
+        a.emb_pos = (const bf16*)emb_pos; a.emb_type = (const bf16*)emb_type; a.type_ids = type_ids; a.pos_ptr = pos_ptr;
+        MMTG_REQUIRE(bias && MMTG_ALIGNED16(bias) && N % 32 == 0 && ldr % 4 == 0 && (!stats_out || N / 32 <= DG_NP),
+                     "decode_gemm_x3: the reduce mode needs a bias; N a multiple of 32 (at most %d with statistics)", 32 * DG_NP);
+        MMTG_REQUIRE(act == MMTG_EPI_NONE || act == MMTG_EPI_TANH, "decode_gemm_x3: reduce-mode activation NONE or TANH (before the residual)");
+        MMTG_REQUIRE(a.splits <= 8, "decode_gemm_x3: at most 8 K splits in the reduce mode");
+        MMTG_REQUIRE(a.splits == 1 || (ws && counters && ws_floats >= (long)a.ntiles * a.splits * 4096 && n_counters >= (long)a.ntiles * 4),
+                     "decode_gemm_x3: split products need %ld workspace floats and %ld zeroed counters", (long)a.ntiles * a.splits * 4096, (long)a.ntiles * 4);
+    }
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(MMTG_PROF_GEMM_BF16, s, 2.0 * M * N * (double)K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
+    const size_t shm = 4 * 2 * 64 * 128 + 2 * 64 * 4;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)decode_gemm_x3_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess ||
+            hipFuncSetAttribute((const void*)decode_gemm_x3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess ||
+            hipFuncSetAttribute((const void*)decode_gemm_x3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
+            MMTG_FAIL(MMTG_ERR_HIP, "decode_gemm_x3: cannot raise dynamic LDS");
+        attr_done = true;
+    }
+    const dim3 grid(a.ntiles * a.splits), block(256);
+    if (mode == 0) hipLaunchKernelGGL(decode_gemm_x3_kernel<0>, grid, block, shm, s, a);
+    else if (mode == 1) hipLaunchKernelGGL(decode_gemm_x3_kernel<1>, grid, block, shm, s, a);
+    else hipLaunchKernelGGL(decode_gemm_x3_kernel<2>, grid, block, shm, s, a);
+    MMTG_LAUNCH_CHECK("decode_gemm_x3");
+    return MMTG_OK;
+}
+
+extern "C" int mmtg_ln_fold_weights_x3(const void* W, long ldw, long planeW, const float* gamma, const float* beta, const float* bias,
+                                       void* Wf, long ldf, long planeF, float* colsum, float* bias_f, int N, int K, void* stream) {
+    MMTG_REQUIRE(W && gamma && beta && Wf && colsum && bias_f && N > 0 && K > 0 && K % 8 == 0 && ldw % 8 == 0 && ldw >= K && ldf % 8 == 0 && ldf >= K &&
+                 planeW % 8 == 0 && planeF % 8 == 0, "ln_fold_weights_x3: bad arguments (K, leading dimensions, plane distances multiples of 8)");
+    MMTG_REQUIRE(MMTG_ALIGNED16(W) && MMTG_ALIGNED16(Wf), "ln_fold_weights_x3: 16-byte alignment");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(MMTG_PROF_MISC, s, 5.0 * N * (double)K, 8.0 * N * (double)K);
+    hipLaunchKernelGGL(ln_fold_x3_kernel, dim3(cdiv(N, 4)), dim3(256), 0, s, (const bf16*)W, ldw, planeW, gamma, beta, bias, (bf16*)Wf, ldf, planeF,
+                       colsum, bias_f, N, K);
+    MMTG_LAUNCH_CHECK("ln_fold_weights_x3");
+    return MMTG_OK;
+}
+
+extern "C" int mmtg_decode_attn_split_x3(const float* part, int splits, const float* bias, float* kcache, float* vcache, const int* keep,
+                                         long ldkeep, const int* pos_ptr, void* out_planes, long plane, int B, int nH, int dh, int Tmax,
+                                         void* stream) {
+    MMTG_REQUIRE(part && bias && splits > 0 && kcache && vcache && keep && pos_ptr && out_planes, "decode_attn_split_x3: null pointer");
+    MMTG_REQUIRE(dh == 64 && B > 0 && nH > 0 && Tmax > 0 && Tmax <= 1024 && plane % 4 == 0 && plane >= (long)B * nH * 64 && (((uintptr_t)out_planes) & 7) == 0,
+                 "decode_attn_split_x3: head dim 64, Tmax <= 1024, the lo plane behind the hi plane");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(MMTG_PROF_DECODE, s, 4.0 * B * nH * (double)Tmax * dh, 8.0 * B * nH * (double)Tmax * dh);
+    const long slab = (long)B * 3 * nH * 64;
+    static const bool kv_nt = !getenv("MMTG_DECODE_KV_NT") || atoi(getenv("MMTG_DECODE_KV_NT")) != 0;
+    if (kv_nt) hipLaunchKernelGGL((decode_attn_kernel<float, true>), dim3(nH, B), dim3(64), 0, s, (const float*)nullptr, kcache, vcache, keep, ldkeep, pos_ptr,
+                                  (float*)nullptr, nH, Tmax, part, splits, slab, bias, (bf16*)out_planes, plane);
+    else hipLaunchKernelGGL((decode_attn_kernel<float, false>), dim3(nH, B), dim3(64), 0, s, (const float*)nullptr, kcache, vcache, keep, ldkeep, pos_ptr,
+                            (float*)nullptr, nH, Tmax, part, splits, slab, bias, (bf16*)out_planes, plane);
+    MMTG_LAUNCH_CHECK("decode_attn_split_x3");
+    return MMTG_OK;
+}
+
+extern "C" int mmtg_decode_embed_x3(const float* table, const long long* seq, long ldseq, const float* c, void* x_planes, long plane,
+                                    const int* pos_ptr, const long long* tpw_type, const long long* tpw_mask, long long* type_out, int* keep,
+                                    long ldkeep, int B, int P, int S, int E, int two_sents, int V, int sent, int max_sent_num, void* stream) {
+    MMTG_REQUIRE(table && seq && c && x_planes && pos_ptr && tpw_type && tpw_mask && type_out && keep, "decode_embed_x3: null pointer");
+    MMTG_REQUIRE(B > 0 && E % 8 == 0 && sent > 1 && max_sent_num > 1 && plane % 4 == 0 && plane >= (long)B * E && (((uintptr_t)x_planes) & 7) == 0,
+                 "decode_embed_x3: bad sizes");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(MMTG_PROF_DECODE, s, (double)B * E, 12.0 * B * E);
+    hipLaunchKernelGGL(decode_embed_kernel<float>, dim3(B), dim3(256), 0, s, table, seq, ldseq, c, (float*)nullptr, pos_ptr, tpw_type, tpw_mask, type_out, keep,
+                       ldkeep, P, S, E, two_sents, V, sent, max_sent_num, (bf16*)x_planes, plane);
+    MMTG_LAUNCH_CHECK("decode_embed_x3");
     return MMTG_OK;
 }
 

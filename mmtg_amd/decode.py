@@ -77,8 +77,13 @@ class GreedyDecoder:
         #  own tail -- measured at batch 256, us per token step: 2,4,1,4 -> 714-716; 2,3,1,4 -> 715; 2,2,1,4 -> 721; 3,4,1,4 -> 720;
         #  2,4,1,3 -> 726; 2,4,1,8 -> 728; 2,4,1,6 -> 739; 2,6,1,4 -> 746; 2,4,1,2 -> 751; 4,4,1,4 -> 755; profiles/r03_v8_*)
         fused_ok = self.eng.dtype == hip.BF16 and not os.environ.get("MMTG_DECODE_PLAIN") and os.environ.get("MMTG_DECODE_FUSED", "1") != "0"
+        # Round 5, the split-precision step (compute_dtype="bf16x3"): the fused step's launch structure on (hi | lo) plane pairs --
+        # fp32 residual stream / KV cache / logits, every product three bf16 matrix-core passes (mmtg_decode_gemm_x3).
+        # MMTG_DECODE_X3=0 keeps the exact-fp32 kernels (the f32 mode's step) for the A/B.
+        self.x3 = (bool(getattr(self.eng, "x3", False)) and self.fast and os.environ.get("MMTG_DECODE_X3", "1") != "0"
+                   and D % 64 == 0 and D // 32 <= hip.DG_NP and H % 64 == 0 and E % 64 == 0 and self.eng.layout.Vpad % 4 == 0)
         self.splits = tuple(int(x) for x in os.environ.get(
-            "MMTG_DECODE_SPLITS", ("2,4,1,4" if fused_ok else "2,4,1,8") if bf else "8,12,8,24").split(","))
+            "MMTG_DECODE_SPLITS", "2,4,1,8" if self.x3 else ("2,4,1,4" if fused_ok else "2,4,1,8") if bf else "8,12,8,24").split(","))
         # (measured at batch 256, us per token step: 2,3,2,6 -> 1020; 4,6,3,12 -> 1248; 1,1,1,2 -> 1183; unsplit 1264;
         #  with the one-slice c_fc + fused GELU: 2,3,1,8 -> 940, 2,3,1,6 -> 943, 1,3,1,8 -> 963, 2,3,1,12 -> 1003)
         #  round 2, 64x64 tiles (graph-replayed per-product times, profiles/r02_decode_gemm_tiles.log): 2,4,1,8)
@@ -98,6 +103,24 @@ class GreedyDecoder:
             if self.fast:
                 slab = max(self.splits[0] * 3 * D, self.splits[1] * D, self.splits[2] * 4 * D, self.splits[3] * D)
                 self.part = torch.empty(slab * B, dtype=torch.float32, device=dev)
+            if self.x3:
+                L, Vp = sh.L, self.eng.layout.Vpad
+                f32 = lambda *s_: torch.empty(*s_, dtype=torch.float32, device=dev)
+                PL = lambda r, c_: hip.Planes.empty(r, c_, dev)
+                self.xp, self.h1p = PL(B, E), PL(B, H)
+                self.hp, self.h2p = PL(B, D), PL(B, D)
+                self.ctxp, self.gp = PL(B, D), PL(B, 4 * D)
+                self.fq = [(PL(3 * D, D), f32(3 * D), f32(3 * D)) for _ in range(L)]          # gamma-folded c_attn plane pair, column sums, folded bias
+                self.ffc = [(PL(4 * D, D), f32(4 * D), f32(4 * D)) for _ in range(L)]
+                self.fh = (PL(Vp, D), f32(Vp), f32(Vp))
+                self.st = (torch.zeros(B, hip.DG_NP, 2, dtype=torch.float32, device=dev),
+                           torch.zeros(B, hip.DG_NP, 2, dtype=torch.float32, device=dev))
+                # K slices of the two projector products (K = 2048 / 512): in-kernel reduction like attn.c_proj
+                self.psplits = tuple(int(x) for x in os.environ.get("MMTG_DECODE_X3_PSPLITS", "8,2").split(","))
+                rt = -(-B // 64)
+                tiles = rt * max(D // 64, H // 64)
+                self.rws = f32(tiles * max(self.splits[1], self.splits[3], *self.psplits) * 4096)
+                self.rcnt = torch.zeros(tiles * 4, dtype=torch.int32, device=dev)
             # Round 3, fused step (5 graph nodes per block instead of 7): split-K products reduced in the kernel by the last-arriving
             # wave (+ bias + residual + LayerNorm statistics), LayerNorms applied algebraically in the consuming products
             # (mmtg_decode_gemm).  MMTG_DECODE_FUSED=0 keeps the round-2 products + finish launches.
@@ -181,6 +204,10 @@ class GreedyDecoder:
         pre = "decoder.gpt2.transformer."
         temperature, rep, top_k, top_p = self.params
         sent = sh.msl + 2
+        if getattr(self, "x3", False):
+            self._step_x3(with_head)
+            self._select(with_head)
+            return
         hip.decode_embed(eng.table, self.seq, self.c, self.x, self.pos, self.tpw_type, self.tpw_mask, self.types,
                          self.keep, B, sh.P, sh.S, E, sh.two_sents, eng.table.shape[0], sent,
                          sh.max_seq_length // sent + 1)
@@ -203,10 +230,17 @@ class GreedyDecoder:
             self._layers_split(hcur, hnext, with_head)
         else:
             self._layers_plain(hcur, hnext, with_head)
+        if with_head and not fused:
+            hip.gemm(self.a, eng.Wp("wte"), self.logits, B, eng.layout.Vpad, D, transB=True, ldb=D, out_f32=True)
+        self._select(with_head)
+
+    def _select(self, with_head):
+        """The step's last launch: logits processing + arg-max / draw + the forced cadence + the next position (generate.py:117-142)."""
+        eng, sh, B = self.eng, self.eng.sh, self.B
+        temperature, rep, top_k, top_p = self.params
+        sent = sh.msl + 2
         if with_head:
             Vp = eng.layout.Vpad
-            if not fused:
-                hip.gemm(self.a, eng.Wp("wte"), self.logits, B, Vp, D, transB=True, ldb=D, out_f32=True)
             if top_k == 1 and top_p == 0.0:
                 hip.decode_select(self.logits, Vp, min(sh.V, 13317), self.seq, self.pos, sh.P, sent, temperature, rep, B,
                                   pos_next=self.pos_next)
@@ -215,6 +249,44 @@ class GreedyDecoder:
                                   top_k, top_p, self.uniforms, B, pos_next=self.pos_next)
         else:
             hip.decode_select(None, 0, 0, self.seq, self.pos, sh.P, sent, temperature, rep, B, pos_next=self.pos_next)
+
+    def _step_x3(self, with_head):
+        """The split-precision token step: embedding -> projector -> 12 blocks -> head, every product through mmtg_decode_gemm_x3
+        on plane pairs.  Per block: c_attn (LN-fold, fp32 slabs summed by the attention kernel) -> attention over the fp32 KV cache
+        (context as a plane pair) -> attn.c_proj (+ bias + fp32 residual, statistics; fp32 stream AND its plane pair) -> c_fc
+        (LN-fold + GELU, plane pair) -> mlp.c_proj (as attn.c_proj); the head is an LN-fold product writing fp32 logits."""
+        eng, sh, B = self.eng, self.eng.sh, self.B
+        D, H, E = sh.D, sh.H, sh.E
+        pre = "decoder.gpt2.transformer."
+        sent = sh.msl + 2
+        sq, sp, _, s2 = self.splits
+        p1, p2 = self.psplits
+        NP = D // 32
+        hip.decode_embed_x3(eng.table, self.seq, self.c, self.xp, self.pos, self.tpw_type, self.tpw_mask, self.types,
+                            self.keep, B, sh.P, sh.S, E, sh.two_sents, eng.table.shape[0], sent, sh.max_seq_length // sent + 1)
+        hip.decode_gemm_x3(2, self.xp, eng.Wx("decoder.projector_layer1.weight"), B, H, E, Cp=self.h1p,
+                           bias=eng.P("decoder.projector_layer1.bias"), act=hip.EPI_TANH, splits=p1, ws=self.rws, counters=self.rcnt)
+        x, xo, xp, xop = self.h, self.h2, self.hp, self.h2p
+        st, sto = self.st
+        hip.decode_gemm_x3(2, self.h1p, eng.Wx("decoder.projector_layer2.weight"), B, D, H, C_=x, Cp=xp,
+                           bias=eng.P("decoder.projector_layer2.bias"), stats_out=st, splits=p2, ws=self.rws, counters=self.rcnt,
+                           emb_pos=eng.P(pre + "wpe.weight"), emb_type=eng.P(pre + "wte.weight"), type_ids=self.types, pos=self.pos, ldr=D)
+        kper = -(-(-(-D // sq)) // 64) * 64
+        nslab = -(-D // kper)
+        for l in range(sh.L):
+            p = f"{pre}h.{l}."
+            wf, c, bq = self.fq[l]
+            hip.decode_gemm_x3(1, xp, wf, B, 3 * D, D, C_=self.part, colsum=c, stats_in=st, np_in=NP, eps=sh.eps, splits=sq)
+            hip.decode_attn_split_x3(self.part, nslab, bq, self.kc[l], self.vc[l], self.keep, self.pos, self.ctxp, B, sh.nH, 64, self.Tmax)
+            hip.decode_gemm_x3(2, self.ctxp, eng.Wtx(p + "attn.c_proj.weight"), B, D, D, C_=xo, Cp=xop, bias=eng.P(p + "attn.c_proj.bias"),
+                               resid=x, stats_out=sto, splits=sp, ws=self.rws, counters=self.rcnt)
+            wf, c, bfc = self.ffc[l]
+            hip.decode_gemm_x3(0, xop, wf, B, 4 * D, D, Cp=self.gp, bias=bfc, colsum=c, stats_in=sto, np_in=NP, eps=sh.eps, act=hip.EPI_GELU)
+            hip.decode_gemm_x3(2, self.gp, eng.Wtx(p + "mlp.c_proj.weight"), B, D, 4 * D, C_=x, Cp=xp, bias=eng.P(p + "mlp.c_proj.bias"),
+                               resid=xo, stats_out=st, splits=s2, ws=self.rws, counters=self.rcnt)
+        if with_head:
+            wf, c, bh = self.fh
+            hip.decode_gemm_x3(0, xp, wf, B, eng.layout.Vpad, D, C_=self.logits, bias=bh, colsum=c, stats_in=st, np_in=NP, eps=sh.eps)
 
     def _layers_plain(self, hcur, hnext, with_head):
         """One GPT-2 block per layer with the training-side kernels (fp32 parity mode)."""
@@ -294,6 +366,19 @@ class GreedyDecoder:
         eng, sh = self.eng, self.eng.sh
         D = sh.D
         pre = "decoder.gpt2.transformer."
+        if getattr(self, "x3", False):
+            for l in range(sh.L):
+                p = f"{pre}h.{l}."
+                wf, c, b = self.fq[l]
+                hip.ln_fold_weights_x3(eng.Wtx(p + "attn.c_attn.weight"), eng.P(p + "ln_1.weight"), eng.P(p + "ln_1.bias"),
+                                       eng.P(p + "attn.c_attn.bias"), wf, c, b, 3 * D, D)
+                wf, c, b = self.ffc[l]
+                hip.ln_fold_weights_x3(eng.Wtx(p + "mlp.c_fc.weight"), eng.P(p + "ln_2.weight"), eng.P(p + "ln_2.bias"),
+                                       eng.P(p + "mlp.c_fc.bias"), wf, c, b, 4 * D, D)
+            wf, c, b = self.fh
+            hip.ln_fold_weights_x3(eng.Wpx("wte", eng.layout.Vpad, D), eng.P(pre + "ln_f.weight"), eng.P(pre + "ln_f.bias"), None, wf, c, b,
+                                   eng.layout.Vpad, D)
+            return
         for l in range(sh.L):
             p = f"{pre}h.{l}."
             wf, c, b = self.fq[l]
@@ -462,6 +547,10 @@ class GreedyDecoder:
         return how + (", %d row blocks of %d side by side" % (self.lanes, self.B // self.lanes) if self.lanes > 1 else "")
 
     def kernel_name(self):
+        if getattr(self, "x3", False):
+            return ("decode token step (bf16x3): decode_gemm_x3_kernel<64x64> weight streaming over (hi | lo) plane pairs, three bf16 matrix-core "
+                    "passes per product (split-K reduced in the kernel, LayerNorm applied algebraically, fp32 residual stream) + decode_attn "
+                    "streaming an fp32 KV cache, 5 graph nodes per block")
         if getattr(self, "persist", False):
             return ("decode token step: decode_persist_kernel -- the twelve blocks and the head as one persistent launch (64x64 weight-"
                     "streaming tiles + KV-cache streaming, 61 stages behind a two-level device-wide barrier, agent-scope hand-offs)")
@@ -501,7 +590,7 @@ class GreedyDecoder:
         eng.invalidate_copies()
         self.eng.refresh_copies()
         for d in ([self] + self.children):          # (a lane has its own folded copies: they are part of its scratch)
-            if getattr(d, "fused", False):
+            if getattr(d, "fused", False) or getattr(d, "x3", False):
                 d._refresh_folds()
         a = eng.forward(batch, train_flag=False, training=False, encode_only=True)
         self.c.copy_(a["c"])

@@ -85,6 +85,11 @@ _SIGS = {
     "mmtg_decode_gemm": ([_i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _vp, _vp, _vp, _i, _f, _i, _i, _vp, _l, _vp, _i, _vp, _l, _vp, _l,
                           _vp, _vp, _vp, _vp, _vp], _i),
     "mmtg_ln_fold_weights": ([_vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp], _i),
+    "mmtg_decode_gemm_x3": ([_i, _i, _i, _i, _vp, _l, _l, _vp, _l, _l, _vp, _l, _vp, _l, _l, _vp, _vp, _vp, _i, _f, _i, _vp, _l, _vp, _i, _vp, _l,
+                             _vp, _l, _vp, _vp, _vp, _vp, _vp], _i),
+    "mmtg_ln_fold_weights_x3": ([_vp, _l, _l, _vp, _vp, _vp, _vp, _l, _l, _vp, _vp, _i, _i, _vp], _i),
+    "mmtg_decode_attn_split_x3": ([_vp, _i, _vp, _vp, _vp, _vp, _l, _vp, _vp, _l, _i, _i, _i, _i, _vp], _i),
+    "mmtg_decode_embed_x3": ([_vp, _vp, _l, _vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
     "mmtg_decode_stage_bytes": ([], _l),
     "mmtg_decode_stage_gemm": ([_vp, _i, _i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _vp, _vp, _vp, _i, _f, _i, _i, _vp, _l, _vp, _i, _vp, _l, _vp, _l], _i),
     "mmtg_decode_stage_attn": ([_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _l, _vp, _vp, _i, _i, _i, _i], _i),
@@ -581,6 +586,33 @@ def decode_gemm(mode, A, W, C_, M, N, K, bias=None, colsum=None, stats_in=None, 
                                   int(out_f32), _p(resid), N if ldr is None else ldr, _p(stats_out), int(splits), _p(ws),
                                   0 if ws is None else ws.numel(), _p(counters), 0 if counters is None else counters.numel(),
                                   _p(emb_pos), _p(emb_type), _p(type_ids), _p(pos), _stream()), "decode_gemm")
+
+
+def decode_gemm_x3(mode, A, W, M, N, K, C_=None, Cp=None, ldc=None, bias=None, colsum=None, stats_in=None, np_in=0, eps=1e-5, act=EPI_NONE,
+                   resid=None, ldr=None, stats_out=None, splits=1, ws=None, counters=None, emb_pos=None, emb_type=None, type_ids=None, pos=None):
+    """The fused decode products on plane pairs (include/mmtg_hip.h, mmtg_decode_gemm_x3); A, W, Cp: Planes."""
+    _check(lib().mmtg_decode_gemm_x3(int(mode), M, N, K, _p(A.t), A.ld, A.plane, _p(W.t), W.ld, W.plane, _p(C_), N if ldc is None else ldc,
+                                     0 if Cp is None else _p(Cp.t), 0 if Cp is None else Cp.ld, 0 if Cp is None else Cp.plane,
+                                     _p(bias), _p(colsum), _p(stats_in), int(np_in), float(eps), int(act), _p(resid), N if ldr is None else ldr,
+                                     _p(stats_out), int(splits), _p(ws), 0 if ws is None else ws.numel(), _p(counters),
+                                     0 if counters is None else counters.numel(), _p(emb_pos), _p(emb_type), _p(type_ids), _p(pos), _stream()),
+           "decode_gemm_x3")
+
+
+def ln_fold_weights_x3(W, gamma, beta, bias, Wf, colsum, bias_f, N, K):
+    _check(lib().mmtg_ln_fold_weights_x3(_p(W.t), W.ld, W.plane, _p(gamma), _p(beta), _p(bias), _p(Wf.t), Wf.ld, Wf.plane, _p(colsum), _p(bias_f),
+                                         N, K, _stream()), "ln_fold_weights_x3")
+
+
+def decode_attn_split_x3(part, splits, bias, kcache, vcache, keep, pos, out, B, nH, dh, Tmax):
+    _check(lib().mmtg_decode_attn_split_x3(_p(part), splits, _p(bias), _p(kcache), _p(vcache), _p(keep), keep.stride(0), _p(pos), _p(out.t),
+                                           out.plane, B, nH, dh, Tmax, _stream()), "decode_attn_split_x3")
+
+
+def decode_embed_x3(table, seq, c, x, pos, tpw_type, tpw_mask, type_out, keep, B, P, S, E, two_sents, V, sent, max_sent_num):
+    _check(lib().mmtg_decode_embed_x3(_p(table), _p(seq), seq.stride(0), _p(c), _p(x.t), x.plane, _p(pos), _p(tpw_type), _p(tpw_mask),
+                                      _p(type_out), _p(keep), keep.stride(0), B, P, S, E, two_sents, V, sent, max_sent_num, _stream()),
+           "decode_embed_x3")
 
 
 class DecodeStages:

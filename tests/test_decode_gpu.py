@@ -23,12 +23,14 @@ def build(dtype):
     return fx, batch, model
 
 
+@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
 @pytest.mark.parametrize("use_graph", [False, True])
-def test_kv_cache_decode_matches_reference_ids(use_graph, monkeypatch):
-    fx, batch, model = build("f32")
+def test_kv_cache_decode_matches_reference_ids(use_graph, mode, monkeypatch):
+    fx, batch, model = build(mode)
     dp = json.loads(str(fx["decode_params"]))
     tb = {k: v for k, v in batch_to_torch(batch, DEV).items() if k not in ("rating", "targets")}
     dec = GreedyDecoder(model, max_batch=3, use_graph=use_graph)
+    assert dec.x3 == (mode == "bf16x3"), "the bf16x3 model must take the split-precision token step"
     for length in (30, 220):
         ids = dec.generate(tb, length, temperature=dp["temperature"], repitition_penalty=dp["repitition_penalty"]).cpu().numpy()
         assert ids.shape == (3, 1 + length)
@@ -389,18 +391,21 @@ def _report(name, **kv):
             f.write(json.dumps(dict(test=name, **{k: (float(v) if isinstance(v, (np.floating, float)) else v) for k, v in kv.items()})) + "\n")
 
 
-@pytest.mark.parametrize("case,bound", [("tiny_s5", 0.12), ("full_12l", 0.15)])
+@pytest.mark.parametrize("case,bound,mode", [("tiny_s5", 0.12, "bf16"), ("full_12l", 0.15, "bf16"),
+                                             ("tiny_s5", 1e-3, "bf16x3"), ("full_12l", 1e-3, "bf16x3")])
 @pytest.mark.parametrize("use_graph", [True, False])
-def test_bf16_fused_decoder_teacher_forced_on_the_reference_ids(case, bound, use_graph):
+def test_bf16_fused_decoder_teacher_forced_on_the_reference_ids(case, bound, mode, use_graph):
     """The BENCHMARKED decode path -- the bf16 fused, KV-cached, graph-replayed GreedyDecoder -- against the reference's own
     sample_sequence run (generate.py:117-142): row 0 is teacher-forced on the reference's 220-position greedy id list, and at
     every model call (a) the decoder's raw fp32 logits are compared with the logits the reference's model produced at that call
     (tiny_s5: all V of them; full_12l: the reference's top-8 ids) under the bf16-mode bound, (b) the token the device-side
     processing + arg-max picked equals the reference's wherever the reference's top-2 margin of the PROCESSED logits exceeds
     twice that bound over the temperature.  The decoder-side twin of test_greedy_ids_vs_golden_at_reduced_precision, which goes
-    through model.forward and never touches the decode kernels."""
+    through model.forward and never touches the decode kernels.
+    Round 5: the same harness on the split-precision decoder (compute_dtype="bf16x3": fp32 stream / KV cache, three bf16 passes per
+    product) under north_star's OWN gates: raw logits within 1e-3 of the reference's at every call and EVERY pick the reference's."""
     fx, meta, mcfg, gcfg, dcfg, weights, table, batch = load_case(case)
-    model = MMTG(mcfg, dcfg, meta["V"], train_flag=False, gpt2_config=gcfg, token_table=table, compute_dtype="bf16")
+    model = MMTG(mcfg, dcfg, meta["V"], train_flag=False, gpt2_config=gcfg, token_table=table, compute_dtype=mode)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})
     model.to(DEV).eval()
     tb = {k: v for k, v in batch_to_torch(batch, DEV).items() if k not in ("rating", "targets")}
@@ -409,7 +414,10 @@ def test_bf16_fused_decoder_teacher_forced_on_the_reference_ids(case, bound, use
     ids = fx[key].tolist()                       # [1, t1, ...]: what sample_sequence returned (lags the last append)
     length = len(ids) - 1
     dec = GreedyDecoder(model, max_batch=B, use_graph=use_graph)
-    assert dec.fused, "the bf16 decoder must take the fused token step (the benchmarked path)"
+    if mode == "bf16":
+        assert dec.fused, "the bf16 decoder must take the fused token step (the benchmarked path)"
+    else:
+        assert dec.x3, "the bf16x3 decoder must take the split-precision token step (the benchmarked path)"
     teacher = torch.full((B, 1 + length), -1, dtype=torch.long)
     teacher[0, :len(ids)] = torch.tensor(ids)
     V = meta["V"]
@@ -455,13 +463,15 @@ def test_bf16_fused_decoder_teacher_forced_on_the_reference_ids(case, bound, use
             worst_missed = max(worst_missed, margin)
             if first_div is None:
                 first_div = (c, margin)
-    _report("decoder_teacher_forced_%s_bf16_fused_%s" % (case, "graph" if use_graph else "eager"), calls=n, agree=ok,
+    _report("decoder_teacher_forced_%s_%s_fused_%s" % (case, mode, "graph" if use_graph else "eager"), calls=n, agree=ok,
             logit_err_max=err_max, worst_missed_margin=worst_missed,
             first_divergence_call=None if first_div is None else first_div[0],
             first_divergence_margin=None if first_div is None else first_div[1])
     assert n >= 120
     assert worst_missed <= 2 * bound / 1.1, (worst_missed, first_div)
     assert ok >= 0.6 * n
+    if mode == "bf16x3":
+        assert ok == n, (ok, n, first_div)
 
 
 @pytest.mark.parametrize("size", ["tiny", "full"])
