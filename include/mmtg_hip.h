@@ -190,6 +190,12 @@ MMTG_API int mmtg_layernorm_bwd(int dtype, const void* dy, const void* x, const 
                        float* dgamma, float* dbeta, int rows, int cols,
                        void* dx_masked, unsigned drop_thresh, unsigned drop_seed, float* dcolsum,
                        float* ws, long ws_floats, void* stream);
+/* x3 mode: mmtg_layernorm_bwd on fp32 rows whose dropout-masked input gradient (dx itself without dropout) goes to a (hi | lo) bf16
+ * plane pair [rows, cols] (lo plane `plane` elements behind) instead of an fp32 tensor: only split-precision products read it. */
+MMTG_API int mmtg_layernorm_bwd_x3(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                          const float* dres, float* dx, float* dgamma, float* dbeta, int rows, int cols,
+                          void* dx_planes, long plane, unsigned drop_thresh, unsigned drop_seed, float* dcolsum,
+                          float* ws, long ws_floats, void* stream);
 
 /* ---------------------------------------------------------------- causal self-attention
  * GPT2Attention._attn: softmax(QK^T/sqrt(dh) + causal + key padding) V with
@@ -198,6 +204,10 @@ MMTG_API int mmtg_layernorm_bwd(int dtype, const void* dy, const void* x, const 
  * keep: [B,T] int32 key mask (1 = attend); out: [B*T, D]; lse: [B,nH,T] f32.  */
 MMTG_API int mmtg_attn_fwd(int dtype, const void* qkv, const int* keep, void* out, float* lse,
                   int B, int T, int nH, int dh, unsigned drop_thresh, unsigned drop_seed, void* stream);
+/* x3 mode: the same forward on fp32 qkv; the context rows go to `out` (fp32: the backward reads them) AND to a (hi | lo) bf16 plane
+ * pair [B*T, D] (lo plane `plane` elements behind): the operand of attn.c_proj's split-precision product. */
+MMTG_API int mmtg_attn_fwd_x3(const float* qkv, const int* keep, float* out, void* out_planes, long plane, float* lse,
+                     int B, int T, int nH, int dh, unsigned drop_thresh, unsigned drop_seed, void* stream);
 /* delta: [B*T, nH] f32, delta[m,h] = sum_d dout[m,h,d] * out[m,h,d]: computed by the call, or --
  * delta_ready != 0 -- already filled by the caller (the GEMM producing dout with
  * MMTG_EPI_ROWDOT does it for free); dq32: [B*T, D] f32 scratch (zeroed by the call);
@@ -258,6 +268,11 @@ MMTG_API int mmtg_loss_fwd(int logits_dtype, const void* logits, long ldl, int V
 MMTG_API int mmtg_loss_bwd(int dtype, int logits_dtype, const void* logits, long ldl, int V, const long long* topic_ids,
                   const long long* targets, const float* lse, const float* coef, float gscale, float lm_coef,
                   int B, int P, int L, void* dlogits, long ldd, int Vpad, void* stream);
+/* x3 mode: the same gradient of fp32 logits written as a (hi | lo) bf16 plane pair (ld = ldd, lo plane `plane` elements behind
+ * the hi plane) -- the operand of the LM head's split-precision dgrad / weight gradient; the fp32 rows are never stored. */
+MMTG_API int mmtg_loss_bwd_x3(const float* logits, long ldl, int V, const long long* topic_ids, const long long* targets, const float* lse,
+                     const float* coef, float gscale, float lm_coef, int B, int P, int L, void* planes, long ldd, long plane,
+                     int Vpad, void* stream);
 
 /* ---------------------------------------------------------------- encoder / fuser pieces
  * GRU cell (nn.GRU math, model.py:78-79): gi (row stride ld_gi), gh (row stride ld_gh >= 3H, or 0 = one

@@ -81,7 +81,8 @@ template <typename T> __device__ __forceinline__ typename Vec16<T>::type zero16(
 template <typename T>
 __global__ __launch_bounds__(256, ATTN_FWD_WAVES) void attn_fwd_kernel(const T* __restrict__ qkv, const int* __restrict__ keep,
         T* __restrict__ out, float* __restrict__ lse, int Tn, int nH,
-        uint32_t drop_thresh, uint32_t drop_seed, float inv_keep) {
+        uint32_t drop_thresh, uint32_t drop_seed, float inv_keep, bf16* __restrict__ oplanes = nullptr, long oplane = 0) {
+    // oplanes (x3 mode, T = float): the context rows ALSO as a (hi | lo) bf16 plane pair -- attn.c_proj's split-precision operand
     typedef typename Vec16<T>::type V;
     typedef AT<T> A;
     __shared__ __attribute__((aligned(16))) char sK[64 * A::ROWB];
@@ -235,6 +236,16 @@ __global__ __launch_bounds__(256, ATTN_FWD_WAVES) void attn_fwd_kernel(const T* 
             typedef T T4 __attribute__((ext_vector_type(4)));
             T4 o = {(T)(o_acc[dt][0] * inv), (T)(o_acc[dt][1] * inv), (T)(o_acc[dt][2] * inv), (T)(o_acc[dt][3] * inv)};
             *reinterpret_cast<T4*>(dst + dt * 16 + 4 * g) = o;
+            if constexpr (sizeof(T) == 4) {
+                if (oplanes) {
+                    bf16x4 hi, lo;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { hi[e] = (bf16)(float)o[e]; lo[e] = (bf16)((float)o[e] - (float)hi[e]); }
+                    bf16* pd = oplanes + ((long)b * Tn + qi) * D + h * DH + dt * 16 + 4 * g;
+                    *reinterpret_cast<bf16x4*>(pd) = hi;
+                    *reinterpret_cast<bf16x4*>(pd + oplane) = lo;
+                }
+            }
         }
         if (g == 0) lse[((long)b * nH + h) * Tn + qi] = l_run > 0.f ? m_run + logf(l_run) : -INFINITY;
     }
@@ -1644,6 +1655,22 @@ extern "C" int mmtg_attn_fwd(int dtype, const void* qkv, const int* keep, void* 
         hipLaunchKernelGGL(attn_fwd_kernel<bf16>, grid, block, 0, s, (const bf16*)qkv, keep, (bf16*)out, lse, T, nH, drop_thresh, drop_seed, ik);
     else MMTG_FAIL(MMTG_ERR_BAD_ARG, "attn_fwd: bad dtype");
     MMTG_LAUNCH_CHECK("attn_fwd");
+    return MMTG_OK;
+}
+
+/* x3 mode: mmtg_attn_fwd on fp32 qkv whose context rows go to the fp32 `out` (the backward reads it) AND to a (hi | lo) bf16 plane pair
+ * [B*T, D] (attn.c_proj's split-precision operand). */
+extern "C" int mmtg_attn_fwd_x3(const float* qkv, const int* keep, float* out, void* out_planes, long plane, float* lse,
+                                int B, int T, int nH, int dh, unsigned drop_thresh, unsigned drop_seed, void* stream) {
+    MMTG_REQUIRE(dh == DH, "attn_fwd_x3: head dim %d unsupported (built for 64)", dh);
+    MMTG_REQUIRE(B > 0 && T > 0 && nH > 0 && qkv && keep && out && lse && out_planes, "attn_fwd_x3: bad sizes / null pointer");
+    MMTG_REQUIRE(MMTG_ALIGNED16(qkv) && MMTG_ALIGNED16(out) && MMTG_ALIGNED16(out_planes) && plane % 8 == 0 && plane >= (long)B * T * nH * DH,
+                 "attn_fwd_x3: alignment / plane layout");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(MMTG_PROF_ATTN_FWD, s, 2.0 * B * nH * (double)T * T * dh, 4.0 * 5.0 * B * T * nH * dh);
+    hipLaunchKernelGGL(attn_fwd_kernel<float>, dim3(cdiv(T, 64), nH, B), dim3(256), 0, s, qkv, keep, out, lse, T, nH, drop_thresh, drop_seed,
+                       inv_keep_of(drop_thresh), (bf16*)out_planes, plane);
+    MMTG_LAUNCH_CHECK("attn_fwd_x3");
     return MMTG_OK;
 }
 

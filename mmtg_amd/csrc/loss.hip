@@ -172,7 +172,9 @@ template <typename T, typename LT>
 __global__ __launch_bounds__(256) void loss_bwd_kernel(const LT* logits, long ldl, int V,
         const long long* __restrict__ topic_ids, const long long* __restrict__ targets,
         const float* __restrict__ lse, const float* __restrict__ coef, float gscale, float lm_coef, int P, int L,
-        T* dlogits, long ldd, int Vpad) {
+        T* dlogits, long ldd, int Vpad, long plane = 0) {
+    // plane > 0 (x3 mode, T = bf16, fp32 logits): dlogits is a (hi | lo) plane pair -- the LM head's dgrad and weight gradient are
+    // split-precision products and nothing else reads d(logits), so the fp32 rows are never stored
     const int Tt = P + L;
     const long m = blockIdx.x;
     const int b = (int)(m / Tt), t = (int)(m % Tt);
@@ -184,7 +186,10 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const LT* logits, long ld
             V16 z;
 #pragma unroll
             for (int e = 0; e < Vec16<T>::N; ++e) z[e] = (T)0.f;
-            for (int v = threadIdx.x * Vec16<T>::N; v < Vpad; v += 256 * Vec16<T>::N) *reinterpret_cast<V16*>(drow + v) = z;
+            for (int v = threadIdx.x * Vec16<T>::N; v < Vpad; v += 256 * Vec16<T>::N) {
+                *reinterpret_cast<V16*>(drow + v) = z;
+                if (plane) *reinterpret_cast<V16*>(drow + plane + v) = z;
+            }
         } else {
             for (int v = threadIdx.x; v < Vpad; v += 256) drow[v] = (T)0.f;
         }
@@ -208,6 +213,12 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const LT* logits, long ld
             if constexpr (sizeof(T) == 2) {
                 bf16x8 o = {(bf16)d[0], (bf16)d[1], (bf16)d[2], (bf16)d[3], (bf16)d[4], (bf16)d[5], (bf16)d[6], (bf16)d[7]};
                 *reinterpret_cast<bf16x8*>(drow + v) = o;
+                if (plane) {
+                    bf16x8 lo;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) lo[e] = (bf16)(d[e] - (float)o[e]);
+                    *reinterpret_cast<bf16x8*>(drow + plane + v) = lo;
+                }
             } else {
                 *reinterpret_cast<f32x4*>(drow + v) = f32x4{d[0], d[1], d[2], d[3]};
                 *reinterpret_cast<f32x4*>(drow + v + 4) = f32x4{d[4], d[5], d[6], d[7]};
@@ -264,5 +275,22 @@ extern "C" int mmtg_loss_bwd(int dtype, int logits_dtype, const void* logits, lo
     else LB(bf16, bf16);
 #undef LB
     MMTG_LAUNCH_CHECK("loss_bwd");
+    return MMTG_OK;
+}
+
+/* x3 mode: d(logits) of fp32 logits straight into a (hi | lo) bf16 plane pair (ld = ldd, lo plane `plane` elements behind). */
+extern "C" int mmtg_loss_bwd_x3(const float* logits, long ldl, int V, const long long* topic_ids, const long long* targets, const float* lse,
+                                const float* coef, float gscale, float lm_coef, int B, int P, int L, void* planes, long ldd, long plane,
+                                int Vpad, void* stream) {
+    MMTG_REQUIRE(B > 0 && L >= 1 && P + L >= 2 && V > 0 && Vpad >= V && ldd >= Vpad && Vpad % 8 == 0 && ldd % 8 == 0 && ldl % 4 == 0 && ldl >= Vpad,
+                 "loss_bwd_x3: bad sizes (Vpad, ldd multiples of 8, ldl >= Vpad)");
+    MMTG_REQUIRE(logits && targets && lse && coef && planes && MMTG_ALIGNED16(planes) && MMTG_ALIGNED16(logits), "loss_bwd_x3: null / misaligned pointer");
+    const long M = (long)B * (P + L);
+    MMTG_REQUIRE(plane % 8 == 0 && plane >= (M - 1) * ldd + Vpad, "loss_bwd_x3: the lo plane must lie behind the hi plane");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(MMTG_PROF_LOSS, s, 3.0 * M * V, 8.0 * M * V);
+    hipLaunchKernelGGL((loss_bwd_kernel<bf16, float>), dim3((unsigned)M), dim3(256), 0, s, logits, ldl, V, topic_ids, targets, lse, coef, gscale, lm_coef,
+                       P, L, (bf16*)planes, ldd, Vpad, plane);
+    MMTG_LAUNCH_CHECK("loss_bwd_x3");
     return MMTG_OK;
 }

@@ -251,7 +251,10 @@ __global__ __launch_bounds__(256, LN_BWD_WAVES) void ln_bwd2_kernel(const T* __r
                                                       const float* __restrict__ rstd, const T* __restrict__ dres,
                                                       T* __restrict__ dx, T* __restrict__ dxm, float* __restrict__ ws,
                                                       int rows, int cols, int want_colsum,
-                                                      uint32_t thresh, uint32_t seed, float inv_keep) {
+                                                      uint32_t thresh, uint32_t seed, float inv_keep,
+                                                      bf16* __restrict__ dxp = nullptr, long plane = 0) {
+    // dxp (x3 mode, T = float): the masked gradient also / instead as a (hi | lo) bf16 plane pair [rows, cols] -- the operand of the
+    // split-precision products that consume it (mmtg_layernorm_bwd_x3)
     typedef typename Vec16<T>::type V;
     constexpr int EPC = Vec16<T>::N;
     __shared__ float sred[4][1024];
@@ -355,7 +358,7 @@ __global__ __launch_bounds__(256, LN_BWD_WAVES) void ln_bwd2_kernel(const T* __r
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) ov[e] = (T)o[e];
                 *reinterpret_cast<V*>(dx + base + ch * EPC) = ov;
-                if (want_colsum || dxm) {
+                if (want_colsum || dxm || dxp) {
                     // the consumer sees the rounded dx: mask / sum exactly what it will read
                     V mv;
 #pragma unroll
@@ -366,6 +369,15 @@ __global__ __launch_bounds__(256, LN_BWD_WAVES) void ln_bwd2_kernel(const T* __r
                         ac[i][e] += (float)mv[e];
                     }
                     if (dxm) *reinterpret_cast<V*>(dxm + base + ch * EPC) = mv;
+                    if constexpr (EPC == 4) {
+                        if (dxp) {
+                            bf16x4 hi, lo;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { hi[e] = (bf16)(float)mv[e]; lo[e] = (bf16)((float)mv[e] - (float)hi[e]); }
+                            *reinterpret_cast<bf16x4*>(dxp + base + ch * 4) = hi;
+                            *reinterpret_cast<bf16x4*>(dxp + plane + base + ch * 4) = lo;
+                        }
+                    }
                 }
             }
         }
@@ -374,7 +386,7 @@ __global__ __launch_bounds__(256, LN_BWD_WAVES) void ln_bwd2_kernel(const T* __r
     float* out = ws + (long)blockIdx.x * 3 * cols;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        if (k == 2 && !want_colsum && !dxm) {
+        if (k == 2 && !want_colsum && !dxm && !dxp) {
             for (int c = threadIdx.x; c < cols; c += 256) out[2 * cols + c] = 0.f;
             break;
         }
@@ -864,6 +876,42 @@ extern "C" int mmtg_layernorm_bwd(int dtype, const void* dy, const void* x, cons
     if (fin_atomic) hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3(cdiv(cols, 64), 3, 16), dim3(256), 0, s, ws, nb, cols, dgamma, dbeta, dcolsum);
     else hipLaunchKernelGGL(ln_bwd_finalize_det_kernel, dim3(cdiv(cols, 64), 3), dim3(1024), 0, s, ws, nb, cols, dgamma, dbeta, dcolsum);
     MMTG_LAUNCH_CHECK("layernorm_bwd");
+    return MMTG_OK;
+}
+
+/* x3 mode (fp32 rows): mmtg_layernorm_bwd whose (dropout-masked) input gradient ALSO / INSTEAD goes to a (hi | lo) bf16 plane pair
+ * [rows, cols] (lo plane `plane` elements behind) -- the operand of the block's split-precision dgrad / weight-gradient products. */
+extern "C" int mmtg_layernorm_bwd_x3(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                                     const float* dres, float* dx, float* dgamma, float* dbeta, int rows, int cols,
+                                     void* dx_planes, long plane, unsigned drop_thresh, unsigned drop_seed, float* dcolsum,
+                                     float* ws, long ws_floats, void* stream) {
+    MMTG_REQUIRE(rows > 0 && cols > 0 && cols % 8 == 0 && cols <= 1024, "layernorm_bwd_x3: cols=%d must be a multiple of 8 and <= 1024", cols);
+    MMTG_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && dx_planes, "layernorm_bwd_x3: null pointer");
+    MMTG_REQUIRE(ws && ws_floats >= mmtg_layernorm_bwd_ws(rows, cols), "layernorm_bwd_x3: workspace of %ld floats required", mmtg_layernorm_bwd_ws(rows, cols));
+    MMTG_REQUIRE(MMTG_ALIGNED16(dy) && MMTG_ALIGNED16(x) && MMTG_ALIGNED16(dx) && (!dres || MMTG_ALIGNED16(dres)) && MMTG_ALIGNED16(gamma) &&
+                 MMTG_ALIGNED16(dx_planes) && plane % 8 == 0 && plane >= (long)rows * cols, "layernorm_bwd_x3: alignment / plane layout");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(MMTG_PROF_LAYERNORM, s, 16.0 * rows * cols, ((dres ? 4.0 : 3.0) + 1.0) * 4.0 * rows * cols);
+    int nb = ln_bwd_blocks(rows);
+    const float ik = drop_thresh ? (float)(4294967296.0 / (4294967296.0 - (double)drop_thresh)) : 1.0f;
+    const int want = dcolsum != nullptr;
+    static int cap = 0;
+    if (!cap) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        cap = 2 * cus;
+    }
+    if (nb > cap) nb = cap;
+    const int sweeps = cdiv(cdiv(rows, 8), nb);
+    nb = cdiv(cdiv(rows, 8), sweeps);
+    const int nc = cdiv(cols / 4, 32);
+    dim3 grid(nb), block(256);
+#define LN2X(NC) hipLaunchKernelGGL((ln_bwd2_kernel<float, NC>), grid, block, 0, s, dy, x, gamma, mean, rstd, dres, dx, (float*)nullptr, ws, rows, cols, \
+                                    want, drop_thresh, drop_seed, ik, (bf16*)dx_planes, plane)
+    if (nc <= 4) LN2X(4); else if (nc <= 6) LN2X(6); else LN2X(8);
+#undef LN2X
+    hipLaunchKernelGGL(ln_bwd_finalize_det_kernel, dim3(cdiv(cols, 64), 3), dim3(1024), 0, s, ws, nb, cols, dgamma, dbeta, dcolsum);
+    MMTG_LAUNCH_CHECK("layernorm_bwd_x3");
     return MMTG_OK;
 }
 

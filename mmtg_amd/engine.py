@@ -432,6 +432,14 @@ class Engine:
                 desc.append((soff, shape[0], shape[1], off))
                 self.wt_entries[key] = (off, (shape[1], shape[0]), n)
                 off += n
+        if self.x3:
+            # x3: the input gradient of a Linear layer, dy [M,out] W[out,in], needs the [in,out] copy as its K-contiguous operand
+            key = "decoder.projector_layer2.weight"
+            soff, shape, n = self.layout.entries[key]
+            if soff % 8 == 0 and shape[0] % 8 == 0 and shape[1] % 8 == 0:
+                desc.append((soff, shape[0], shape[1], off))
+                self.wt_entries[key] = (off, (shape[1], shape[0]), n)
+                off += n
         # (x3: one more leading dimension, the (hi | lo) plane)
         self.wt = torch.zeros(*((2, off) if self.x3 else (off,)), device=self.dev, dtype=torch.bfloat16)
         self.wt_total = off
@@ -513,9 +521,13 @@ class Engine:
         """Encoder-sized products (M = B or B*S rows, K >= 1024): a handful of output tiles each walking a long K
         serially leaves most CUs idle, so the bf16 mode splits K into fp32 slabs (deterministic) and lets the
         finish kernel add the bias.  Returns False when the plain launch should be used."""
-        if self.dtype != hip.BF16 or K < 1024 or K % 8 or N % 8 or out.dtype != self.tdt or _NO_FEW_ROWS:
+        if K < 1024 or K % 8 or N % 8 or out.dtype != self.tdt or _NO_FEW_ROWS:
             return False
-        tiles = (N + 31) // 32 if (transB and M <= 256) else ((M + 127) // 128) * ((N + 127) // 128)
+        if self.dtype == hip.F32 and (K % 32 or (lda or K) % 4):
+            return False
+        # (fp32 kernel, round 5: the same K slabs through its MMTG_EPI_SPLIT epilogue -- 128x128 tiles; the encoder's 2048-deep
+        #  products on 6-36 tiles were 2.7 ms of the bf16x3 step at 6 TFLOP/s)
+        tiles = (N + 31) // 32 if (transB and M <= 256 and self.dtype == hip.BF16) else ((M + 127) // 128) * ((N + 127) // 128)
         splits = min(K // 256, 384 // tiles)
         if tiles > 48 or splits < 2:
             return False
@@ -727,6 +739,9 @@ class Engine:
         type_ids = type_ids.contiguous().view(-1)
         keep = (keep != 0).to(torch.int32).contiguous()
         h1 = self.buf("h1", (M, H))
+        px3 = (self.x3 and E % 128 == 0 and H % 128 == 0 and D % 8 == 0 and "decoder.projector_layer2.weight" in self.wt_entries
+               and _os.environ.get("MMTG_X3_PROJECTOR", "1") != "0")
+        a["px3"] = px3
         gather = self.dtype == hip.BF16 and M > 256 and not _NO_GATHER
         if gather:
             # Fused conditioning (model.py:254-281): X[m] = E[id_m] + c[b, seg_m] is never materialised.  By linearity
@@ -755,10 +770,21 @@ class Engine:
             ids32 = None
             x = self.buf("x_cond", (M, E))
             hip.embed_condition(self.table, topic_ids, targets, c, x, B, P, L, S, E, sh.two_sents, self.table.shape[0])
-            self._fwd(x, "decoder.projector_layer1.weight", h1, M, "linear", bias=self.P("decoder.projector_layer1.bias"),
-                      epi=hip.EPI_TANH)
+            if px3:
+                # split-precision projector (model.py:279-281): X and tanh(X W1^T + b1) also as plane pairs (the products' operands)
+                xp = hip.split_planes(x, M, E, self.pbuf("x_cond_p", M, E))
+                h1p = self.pbuf("h1_p", M, H)
+                hip.gemm_x3(xp, self.Wx("decoder.projector_layer1.weight"), h1, M, H, E, planes=h1p,
+                            bias=self.P("decoder.projector_layer1.bias"), epi=hip.EPI_TANH)
+                a.update(xp=xp, h1p=h1p)
+            else:
+                self._fwd(x, "decoder.projector_layer1.weight", h1, M, "linear", bias=self.P("decoder.projector_layer1.bias"),
+                          epi=hip.EPI_TANH)
         hcur = self.buf("resid_0", (M, D))
-        self._fwd(h1, "decoder.projector_layer2.weight", hcur, M, "linear", bias=self.P("decoder.projector_layer2.bias"))
+        if px3:
+            hip.gemm_x3(a["h1p"], self.Wx("decoder.projector_layer2.weight"), hcur, M, D, H, bias=self.P("decoder.projector_layer2.bias"))
+        else:
+            self._fwd(h1, "decoder.projector_layer2.weight", hcur, M, "linear", bias=self.P("decoder.projector_layer2.bias"))
         pre = "decoder.gpt2.transformer."
         hip.embed_add(hcur, self.W(pre + "wpe.weight"), self.W(pre + "wte.weight"), type_ids, hcur, M, T, D,
                       drop_p=pe, drop_seed=seed)
@@ -783,8 +809,8 @@ class Engine:
                 self._fwd_x3(a1, p + "attn.c_attn.weight", qkv, M, bias=self.P(p + "attn.c_attn.bias"))
                 ctx = self.buf(f"l{l}_ctx", (M, D))
                 lse = self.buf(f"l{l}_lse", (B, sh.nH, T), torch.float32)
-                hip.attn_fwd(qkv, keep, ctx, lse, B, T, sh.nH, D // sh.nH, drop_p=pa, drop_seed=s[0])
-                ctxp = hip.split_planes(ctx, M, D, self.pbuf(f"l{l}_ctxp", M, D))
+                ctxp = self.pbuf(f"l{l}_ctxp", M, D)
+                hip.attn_fwd_x3(qkv, keep, ctx, ctxp, lse, B, T, sh.nH, D // sh.nH, drop_p=pa, drop_seed=s[0])
                 xmid = self.buf(f"l{l}_xmid", (M, D))
                 self._fwd_x3(ctxp, p + "attn.c_proj.weight", xmid, M, bias=self.P(p + "attn.c_proj.bias"),
                              epi=hip.EPI_RESID, aux=hcur, ldaux=D, drop_p=pr, drop_seed=s[1])
@@ -883,6 +909,12 @@ class Engine:
     def loss_backward(self, gscale=1.0, lm_coef=0.0):
         """d(gscale * MyLoss + lm_scale * LM loss)/d logits into the engine's dlogits buffer."""
         a, sh = self.act, self.sh
+        if a.get("x3"):
+            # x3: the gradient goes straight into the plane pair the LM head's split-precision products read
+            dlp = self.pbuf("dlogits_p", a["M"], self.layout.Vpad)
+            hip.loss_bwd_x3(a["logits"], self.layout.Vpad, sh.V, a["topic_ids"], a["targets"], a["lse_rows"], a["coef"],
+                            gscale, a["B"], sh.P, a["L"], dlp, self.layout.Vpad, lm_coef=lm_coef)
+            return dlp
         # compute-dtype logits are overwritten in place by their gradient
         dl = a["logits"] if a["logits"].dtype == self.tdt and self.dtype != hip.F32 else self.buf("dlogits", (a["M"], self.layout.Vpad))
         hip.loss_bwd(a["logits"], self.layout.Vpad, sh.V, a["topic_ids"], a["targets"], a["lse_rows"], a["coef"],
@@ -951,7 +983,7 @@ class Engine:
         if x3:
             # split-precision backward: d(logits) as a plane pair feeds both the LM head's dgrad (through the [D, Vpad] copy of the
             # tied embedding) and its weight gradient (grouped kernel, config 2: written, not accumulated with atomics)
-            dlp = hip.split_planes(dlogits, M, Vp, self.pbuf("dlogits_p", M, Vp))
+            dlp = dlogits if isinstance(dlogits, hip.Planes) else hip.split_planes(dlogits, M, Vp, self.pbuf("dlogits_p", M, Vp))
             hip.gemm_x3(dlp, hip.Planes(self.wte_t, D, Vp), dhf, M, D, Vp)
             tiles = hip.wgrad_group_sizes(((Vp, D),), 1, 0)[0]
             hs = _LMHEAD_GROUP_SPLITS or _group_splits(tiles, M)
@@ -1004,8 +1036,8 @@ class Engine:
         # outlive the LayerNorm backward that produces the attention c_proj's dy, so the masked gradients alternate
         # between two buffers.
         group = (_WGRAD_GROUP and self.dtype == hip.BF16 and M >= 256 and D % 8 == 0) or x3
-        dmask = self.buf("d_masked", (M, D)) if pr > 0 else None
-        dmask_b = (self.buf("d_masked_b", (M, D)) if group else dmask) if pr > 0 else None
+        dmask = self.buf("d_masked", (M, D)) if (pr > 0 and not x3) else None
+        dmask_b = (self.buf("d_masked_b", (M, D)) if group else dmask) if (pr > 0 and not x3) else None
         if group:
             gshapes = ((D, 4 * D), (4 * D, D), (D, D), (D, 3 * D))
             gcfg = 1 if (_WGRAD_GROUP_CFG and D >= 256 and not x3) else 0
@@ -1019,10 +1051,18 @@ class Engine:
         lastp = f"{pre}h.{sh.L - 1}."
         # (MMTG_WGRAD_STREAM: the top block's masked gradient goes into the buffer set of that block's parity, see below)
         dmask_top = self.buf("d_masked_1", (M, D)) if (group and not x3 and _WGRAD_STREAM and pr > 0 and (sh.L - 1) & 1) else dmask
-        hip.layernorm_bwd(dhf, a["x_last"], self.P(pre + "ln_f.weight"), a["muf"], a["rsf"], None, dx,
-                          self.G(pre + "ln_f.weight"), self.G(pre + "ln_f.bias"), M, D,
-                          dx_masked=dmask_top, drop_p=pr, drop_seed=a["layers"][sh.L - 1][13][2],
-                          dcolsum=self.G(lastp + "mlp.c_proj.bias"), ws=lnws)
+        if x3:
+            # (x3: every LayerNorm backward writes the masked gradient entering the previous residual branch as the plane pair
+            #  that branch's split-precision products read -- no fp32 copy, no separate split pass)
+            dyp = self.pbuf("d_masked_p", M, D)
+            hip.layernorm_bwd_x3(dhf, a["x_last"], self.P(pre + "ln_f.weight"), a["muf"], a["rsf"], None, dx,
+                                 self.G(pre + "ln_f.weight"), self.G(pre + "ln_f.bias"), M, D, dyp,
+                                 drop_p=pr, drop_seed=a["layers"][sh.L - 1][13][2], dcolsum=self.G(lastp + "mlp.c_proj.bias"), ws=lnws)
+        else:
+            hip.layernorm_bwd(dhf, a["x_last"], self.P(pre + "ln_f.weight"), a["muf"], a["rsf"], None, dx,
+                              self.G(pre + "ln_f.weight"), self.G(pre + "ln_f.bias"), M, D,
+                              dx_masked=dmask_top, drop_p=pr, drop_seed=a["layers"][sh.L - 1][13][2],
+                              dcolsum=self.G(lastp + "mlp.c_proj.bias"), ws=lnws)
         self._ready("ln_f.b")
         du = None if x3 else self.buf("d_u", (M, 4 * D))
         dm = self.buf("d_m", (M, D))
@@ -1048,19 +1088,15 @@ class Engine:
                 du, dmask, dmask_b, dqkv = sets[l & 1]
             if x3:
                 # ---- split-precision block backward: every gradient that feeds a product travels as a plane pair
-                dy = dmask if pr > 0 else dx
-                dyp = hip.split_planes(dy, M, D, self.pbuf("d_masked_p", M, D))
                 bands = self.buf("d_u_bands", ((M + 63) // 64, 4 * D), torch.float32)
                 dup = self.pbuf("d_u_p", M, 4 * D)
                 self._dgrad_x3(dyp, p + "mlp.c_proj.weight", None, M, planes=dup, ldc=4 * D, epi=hip.EPI_DGELU, aux=u, ldaux=4 * D, aux2=bands)
                 hip.colsum(bands, bands.shape[0], 4 * D, self.G(p + "mlp.c_fc.bias"))
                 self._dgrad_x3(dup, p + "mlp.c_fc.weight", dm, M)
-                hip.layernorm_bwd(dm, xmid, self.P(p + "ln_2.weight"), mu2, rs2, dx, dx2,
-                                  self.G(p + "ln_2.weight"), self.G(p + "ln_2.bias"), M, D,
-                                  dx_masked=dmask_b, drop_p=pr, drop_seed=s[1],
-                                  dcolsum=self.G(p + "attn.c_proj.bias"), ws=lnws)
-                dy2 = dmask_b if pr > 0 else dx2
-                dy2p = hip.split_planes(dy2, M, D, self.pbuf("d_masked_b_p", M, D))
+                dy2p = self.pbuf("d_masked_b_p", M, D)
+                hip.layernorm_bwd_x3(dm, xmid, self.P(p + "ln_2.weight"), mu2, rs2, dx, dx2,
+                                     self.G(p + "ln_2.weight"), self.G(p + "ln_2.bias"), M, D, dy2p,
+                                     drop_p=pr, drop_seed=s[1], dcolsum=self.G(p + "attn.c_proj.bias"), ws=lnws)
                 self._dgrad_x3(dy2p, p + "attn.c_proj.weight", dctx, M)
                 hip.attn_bwd(qkv, a["keep"], ctx, dctx, lse, delta, dq32, dqkv, B, T, sh.nH, D // sh.nH,
                              drop_p=pa, drop_seed=s[0], delta_ready=False, dbias=self.G(p + "attn.c_attn.bias"),
@@ -1074,10 +1110,10 @@ class Engine:
                 if self.wgrad_overwrite and self._ow_rec is not None:
                     self._ow_rec[1].extend((self.layout.entries[k][0], self.layout.entries[k][2]) for k in keys)
                 if l > 0:
-                    hip.layernorm_bwd(da, xin, self.P(p + "ln_1.weight"), mu1, rs1, dx2, dx,
-                                      self.G(p + "ln_1.weight"), self.G(p + "ln_1.bias"), M, D,
-                                      dx_masked=dmask, drop_p=pr, drop_seed=a["layers"][l - 1][13][2],
-                                      dcolsum=self.G(f"{pre}h.{l - 1}.mlp.c_proj.bias"), ws=lnws)
+                    hip.layernorm_bwd_x3(da, xin, self.P(p + "ln_1.weight"), mu1, rs1, dx2, dx,
+                                         self.G(p + "ln_1.weight"), self.G(p + "ln_1.bias"), M, D, dyp,
+                                         drop_p=pr, drop_seed=a["layers"][l - 1][13][2],
+                                         dcolsum=self.G(f"{pre}h.{l - 1}.mlp.c_proj.bias"), ws=lnws)
                 else:
                     hip.layernorm_bwd(da, xin, self.P(p + "ln_1.weight"), mu1, rs1, dx2, dx,
                                       self.G(p + "ln_1.weight"), self.G(p + "ln_1.bias"), M, D, ws=lnws)
@@ -1169,8 +1205,33 @@ class Engine:
         self._ready("wpe")
         # ---- projector (model.py:279-281)
         dh1 = self.buf("d_h1", (M, H))
-        self._dgrad(dx, "decoder.projector_layer2.weight", dh1, M, "linear", epi=hip.EPI_DTANH, aux=a["h1"], ldaux=H)
-        self._wgrad(a["h1"], dx, "decoder.projector_layer2.weight", "decoder.projector_layer2.bias", M, "linear")
+        px3 = bool(a.get("px3"))
+        if px3:
+            # split-precision projector backward: d h1_pre = (dx W2) (1 - h1^2) through the [in,out] plane copy of W2, and BOTH
+            # weight gradients (W2: dx^T h1, W1: d h1_pre^T X) in one grouped launch on plane pairs
+            dxp = hip.split_planes(dx, M, D, self.pbuf("d_resid0_p", M, D))
+            dh1p = self.pbuf("d_h1_p", M, H)
+            hip.gemm_x3(dxp, self.Wtx("decoder.projector_layer2.weight"), dh1, M, H, D, planes=dh1p, epi=hip.EPI_DTANH, aux=a["h1"], ldaux=H)
+            pshapes = ((D, H), (H, E))
+            ptiles = hip.wgrad_group_sizes(pshapes, 1, 0)[0]
+            psplits = _group_splits(ptiles, M)
+            _, pnws, pncnt = hip.wgrad_group_sizes(pshapes, psplits, 0)
+            pws = self.buf("wgrad_group_ws_proj", (pnws,), torch.float32) if psplits > 1 else None
+            pcnt = self.ws.get(("wgrad_group_cnt", torch.int32))
+            if pcnt is None or pcnt.numel() < pncnt:
+                pcnt = self.ws[("wgrad_group_cnt", torch.int32)] = torch.zeros(pncnt, device=self.dev, dtype=torch.int32)
+            pkeys = ("decoder.projector_layer2.weight", "decoder.projector_layer1.weight")
+            for k in pkeys:      # (tensors the lazy zero_grad skipped are overwritten below; otherwise accumulate as ever)
+                if self._lazy is not None and (self.layout.entries[k][0], self.layout.entries[k][2]) in self._lazy and not self.wgrad_overwrite:
+                    self.G(k).zero_()
+            hip.wgrad_group([(dxp, a["h1p"], self.G(pkeys[0]), D, H), (dh1p, a["xp"], self.G(pkeys[1]), H, E)], M, psplits, pws, pcnt,
+                            accumulate=not self.wgrad_overwrite, config=2)
+            if self.wgrad_overwrite and self._ow_rec is not None:
+                self._ow_rec[1].extend((self.layout.entries[k][0], self.layout.entries[k][2]) for k in pkeys)
+            hip.colsum(dx, M, D, self.G("decoder.projector_layer2.bias"))
+        else:
+            self._dgrad(dx, "decoder.projector_layer2.weight", dh1, M, "linear", epi=hip.EPI_DTANH, aux=a["h1"], ldaux=H)
+            self._wgrad(a["h1"], dx, "decoder.projector_layer2.weight", "decoder.projector_layer2.bias", M, "linear")
         # d c[b,k] = (sum over the segment's tokens of d h1_pre) W1   (the add is linear)
         seg = self.buf("d_seg", (B * S, H))
         hip.segment_sum(dh1, seg, B, P, L, S, H, sh.two_sents)
@@ -1185,6 +1246,8 @@ class Engine:
             hip.slab_sum(part, splits, H * E, gw, H * E, accumulate=not self.wgrad_overwrite)
             hip.gemm(seg, a["c"], gw, H, E, B * S, transA=True, transB=False, lda=H, ldb=E, ldc=E, epi=hip.EPI_ATOMIC, splits=1)
             hip.colsum(dh1, M, H, self.G("decoder.projector_layer1.bias"))
+        elif px3:
+            hip.colsum(dh1, M, H, self.G("decoder.projector_layer1.bias"))      # (the weight gradient went with W2's above)
         else:
             self._wgrad(a["x"], dh1, "decoder.projector_layer1.weight", "decoder.projector_layer1.bias", M, "linear")
         dc = self.buf("d_c", (B * S, E))

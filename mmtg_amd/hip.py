@@ -43,7 +43,9 @@ _SIGS = {
     "mmtg_layernorm_fwd": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp], _i),
     "mmtg_layernorm_bwd_ws": ([_i, _i], _l),
     "mmtg_layernorm_bwd": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _u, _u, _vp, _vp, _l, _vp], _i),
+    "mmtg_layernorm_bwd_x3": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _l, _u, _u, _vp, _vp, _l, _vp], _i),
     "mmtg_attn_fwd": ([_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _u, _u, _vp], _i),
+    "mmtg_attn_fwd_x3": ([_vp, _vp, _vp, _vp, _l, _vp, _i, _i, _i, _i, _u, _u, _vp], _i),
     "mmtg_attn_trace": ([_vp], _i),
     "mmtg_attn_bwd": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _u, _u, _vp], _i),
     "mmtg_embed_condition": ([_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
@@ -54,6 +56,7 @@ _SIGS = {
     "mmtg_dropout_apply": ([_i, _vp, _vp, _l, _i, _u, _u, _vp], _i),
     "mmtg_loss_fwd": ([_i, _vp, _l, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp], _i),
     "mmtg_loss_bwd": ([_i, _i, _vp, _l, _i, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _i, _vp, _l, _i, _vp], _i),
+    "mmtg_loss_bwd_x3": ([_vp, _l, _i, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _i, _vp, _l, _l, _i, _vp], _i),
     "mmtg_gru_cell_fwd": ([_i, _vp, _l, _vp, _l, _vp, _l, _vp, _l, _vp, _i, _i, _vp], _i),
     "mmtg_gru_cell_bwd_fused": ([_i, _vp, _l, _vp, _vp, _i, _vp, _vp, _l, _vp, _l, _vp, _vp, _i, _i, _vp], _i),
     "mmtg_rnn_cell_fwd": ([_i, _i, _vp, _l, _vp, _l, _vp, _vp, _l, _vp, _vp, _i, _i, _vp], _i),
@@ -335,10 +338,22 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, cols,
                                     drop_seed & 0xFFFFFFFF, _p(dcolsum), _p(ws), ws.numel(), _stream()), "layernorm_bwd")
 
 
+def layernorm_bwd_x3(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, cols, dx_planes, drop_p=0.0, drop_seed=0, dcolsum=None, ws=None):
+    """fp32 LayerNorm backward whose (masked) input gradient goes to the Planes ``dx_planes`` (x3 mode)."""
+    _check(lib().mmtg_layernorm_bwd_x3(_p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx), _p(dgamma), _p(dbeta), rows, cols,
+                                       _p(dx_planes.t), dx_planes.plane, drop_thresh(drop_p), drop_seed & 0xFFFFFFFF, _p(dcolsum),
+                                       _p(ws), ws.numel(), _stream()), "layernorm_bwd_x3")
+
+
 # ------------------------------------------------------------------ attention
 def attn_fwd(qkv, keep, out, lse, B, T, nH, dh, drop_p=0.0, drop_seed=0):
     _check(lib().mmtg_attn_fwd(dt(qkv), _p(qkv), _p(keep), _p(out), _p(lse), B, T, nH, dh,
                                drop_thresh(drop_p), drop_seed & 0xFFFFFFFF, _stream()), "attn_fwd")
+
+
+def attn_fwd_x3(qkv, keep, out, out_planes, lse, B, T, nH, dh, drop_p=0.0, drop_seed=0):
+    _check(lib().mmtg_attn_fwd_x3(_p(qkv), _p(keep), _p(out), _p(out_planes.t), out_planes.plane, _p(lse), B, T, nH, dh,
+                                  drop_thresh(drop_p), drop_seed & 0xFFFFFFFF, _stream()), "attn_fwd_x3")
 
 
 def attn_bwd(qkv, keep, out, dout, lse, delta, dq32, dqkv, B, T, nH, dh, drop_p=0.0, drop_seed=0, delta_ready=False,
@@ -403,6 +418,12 @@ def loss_fwd(logits, ldl, V, topic_ids, targets, ratings, stage, label_zero, B, 
 def loss_bwd(logits, ldl, V, topic_ids, targets, lse, coef, gscale, B, P, L, dlogits, ldd, Vpad, lm_coef=0.0):
     _check(lib().mmtg_loss_bwd(dt(dlogits), dt(logits), _p(logits), ldl, V, _p(topic_ids), _p(targets), _p(lse), _p(coef),
                                float(gscale), float(lm_coef), B, P, L, _p(dlogits), ldd, Vpad, _stream()), "loss_bwd")
+
+
+def loss_bwd_x3(logits, ldl, V, topic_ids, targets, lse, coef, gscale, B, P, L, planes, Vpad, lm_coef=0.0):
+    """d(logits) of fp32 logits as a Planes pair (x3 mode)."""
+    _check(lib().mmtg_loss_bwd_x3(_p(logits), ldl, V, _p(topic_ids), _p(targets), _p(lse), _p(coef), float(gscale), float(lm_coef), B, P, L,
+                                  _p(planes.t), planes.ld, planes.plane, Vpad, _stream()), "loss_bwd_x3")
 
 
 # ------------------------------------------------------------------ encoder pieces

@@ -334,6 +334,68 @@ def mmtg_forward(w, sh, table, batch, train_flag=True, collect=None, per_row_inf
     return lm_loss_shifted(logits, labels), (ikl + tkl).mean(), logits
 
 
+class CachedForward:
+    """KV-cached stand-in for ``forward_fn`` of ``sample_sequence`` (batch 1, inference branch).
+
+    The reference re-runs the whole prefix for every token (generate.py:117-142, O(L^2)).  GPT-2 is causal and the
+    inference branch's rebuilt type ids / key mask of a position depend on that position's own token only
+    (model.py:296-312), so the logits of the LAST position are a function of the new positions' rows and the K / V rows
+    of the earlier ones.  This object keeps those per layer and, at every call, runs only the positions it has not seen
+    -- the SURVEY 8(d) "cached" CPU baseline.  Returns logits [1, n_new, V] (sample_sequence reads [0, -1, :]).
+    Pinned by tests/test_oracle_golden.py: identical ids, logits within fp32 rounding of the uncached loop."""
+
+    def __init__(self, w, sh, table):
+        self.w, self.sh, self.table = w, sh, table
+        self.n = 0                   # decoder positions already in the cache (prompt + lyrics)
+        self.k = [None] * sh.L
+        self.v = [None] * sh.L
+        self.keep = None             # key mask of the cached positions
+        self.c = None                # experience vectors [1, S, E]
+
+    def __call__(self, batch):
+        w, sh = self.w, self.sh
+        pre = "decoder.gpt2.transformer."
+        if self.c is None:
+            topic_emb = batch["topic_emb"].float()
+            img = batch["img_embs"].float().transpose(0, 1)
+            txt = batch["r_embs"].float().transpose(0, 1)
+            _, (tn, im, tx) = encoder_forward(w, topic_emb, img, txt)
+            priors = gaussian_priors(sh.S)
+            ia, _ = alpha_attention(w, "img_inner_atten_layer", im.transpose(0, 1), sh.heads, priors)
+            ta, _ = alpha_attention(w, "text_inner_atten_layer", tx.transpose(0, 1), sh.heads, priors)
+            self.c = beta_attention(w, tn, ia.transpose(0, 1), ta.transpose(0, 1)).transpose(0, 1)
+        input_ids, topic_ids = batch["targets"], batch["topic_ids"]
+        x = condition_embeddings(self.table, topic_ids, input_ids, self.c, sh.two_sents)
+        type_ids, mask = inference_type_ids_and_mask(sh, input_ids, batch["tpw_type_ids"], batch["tpw_attention_mask"])
+        T = x.shape[1]
+        n0 = self.n
+        g = projector(w, x[:, n0:])
+        D = g.shape[-1]
+        nH, dh = sh.nH, D // sh.nH
+        h = g + w[pre + "wpe.weight"][n0:T] + w[pre + "wte.weight"][type_ids[:, n0:].long()]
+        nn = T - n0
+        keep_k = mask.bool()[:, None, None, :]                                   # [1,1,1,T]
+        causal = (torch.arange(T)[None, :] <= (n0 + torch.arange(nn))[:, None])   # [nn, T]
+        keep = causal[None, None] & keep_k
+        for l in range(sh.L):
+            p = f"{pre}h.{l}."
+            a = layer_norm(h, w[p + "ln_1.weight"], w[p + "ln_1.bias"], sh.eps)
+            qkv = a @ w[p + "attn.c_attn.weight"] + w[p + "attn.c_attn.bias"]
+            q, k, v = (t.view(1, nn, nH, dh).transpose(1, 2) for t in qkv.split(D, -1))
+            self.k[l] = k if self.k[l] is None else torch.cat([self.k[l], k], 2)
+            self.v[l] = v if self.v[l] is None else torch.cat([self.v[l], v], 2)
+            sc = (q @ self.k[l].transpose(-1, -2)) / math.sqrt(dh)
+            pr = torch.softmax(sc.masked_fill(~keep, float("-inf")), -1)
+            ctx = (pr @ self.v[l]).transpose(1, 2).reshape(1, nn, D)
+            h = h + ctx @ w[p + "attn.c_proj.weight"] + w[p + "attn.c_proj.bias"]
+            m = layer_norm(h, w[p + "ln_2.weight"], w[p + "ln_2.bias"], sh.eps)
+            m = gelu_new(m @ w[p + "mlp.c_fc.weight"] + w[p + "mlp.c_fc.bias"])
+            h = h + m @ w[p + "mlp.c_proj.weight"] + w[p + "mlp.c_proj.bias"]
+        self.n = T
+        hf = layer_norm(h[:, -1:], w[pre + "ln_f.weight"], w[pre + "ln_f.bias"], sh.eps)
+        return hf @ w["decoder.gpt2.lm_head.weight"].t()
+
+
 # --------------------------------------------------------------------------
 # loss / optimiser / schedule  (loss.py:45-74, train.py:137-148,192-197)
 # --------------------------------------------------------------------------

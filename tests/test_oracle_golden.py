@@ -159,6 +159,21 @@ def test_greedy_decode_ids(length, row, case):
     np.testing.assert_allclose(got, raw, atol=3e-4, rtol=0)
 
 
+@pytest.mark.parametrize("length,row,case", [(30, 1, "tiny_s5"), (220, 0, "tiny_s5"), (30, 0, "tiny_lstm2_rnn2")])
+def test_kv_cached_oracle_loop_equals_the_reference_loop(length, row, case):
+    """The KV-cached CPU loop (oracle.CachedForward: bench.py's "cached" cpu_baseline leg) against the reference's own
+    id lists and raw per-call logits -- the same golden vectors that pin the prefix-re-running loop."""
+    fx, meta, sh, w, table, batch = _setup(case)
+    dp = json.loads(str(fx["decode_params"]))
+    start = {k: v[row].numpy() for k, v in batch.items() if k != "rating"}
+    start["targets"] = np.asarray([1])
+    trace = []
+    ids = O.sample_sequence(O.CachedForward(w, sh, table), start, length, temperature=dp["temperature"], top_k=dp["top_k"],
+                            top_p=dp["top_p"], repitition_penalty=dp["repitition_penalty"], greedy=True, trace=trace)
+    assert ids == fx[f"greedy_len{length}_row{row}"].tolist()
+    np.testing.assert_allclose(torch.stack(trace).numpy(), fx[f"greedy_len{length}_row{row}_rawlogits"], atol=3e-4, rtol=0)
+
+
 def test_curriculum_filter_and_schedule():
     r = torch.tensor([1, 5, 3, 2, 4, 5, 1])
     assert O.curriculum_filter(r, 1).tolist() == [0, 6, 1, 5]
