@@ -67,7 +67,7 @@ def _host_threads():
     return max(1, min(ncpu, quota, 64))
 
 
-def cpu_baseline(mcfg, dcfg, gcfg, V, T, seconds_budget=120.0):
+def cpu_baseline(mcfg, dcfg, gcfg, V, T, seconds_budget=100.0):
     """Oracle train step (fwd + MyLoss + bwd + clip + AdamW) on the host cores: B=4 and B=32, 3 warm-up + 5 timed
     steps each as SURVEY 8(d) asks, every leg cut short by a time budget (the sample string says what ran)."""
     from mmtg_amd import synth
@@ -103,7 +103,7 @@ def cpu_baseline(mcfg, dcfg, gcfg, V, T, seconds_budget=120.0):
                                                   legs[1]["timed_steps"], int(seconds_budget))}
 
 
-def cpu_decode_baseline(mcfg, dcfg, gcfg, V, positions=220, seconds_budget=60.0):
+def cpu_decode_baseline(mcfg, dcfg, gcfg, V, positions=220, seconds_budget=45.0):
     """Oracle greedy decoding on the host cores, batch 1, as SURVEY 8(d) defines the leg: `positions` (220) lyric positions after
     the 15-token prompt, BOTH ways -- as the reference runs it (generate.py:117-142: no KV cache, the whole prefix re-run for every
     token, O(L^2)) and with per-layer K / V kept (oracle.CachedForward).  The cached loop runs first and in full; the reference-shaped
@@ -193,7 +193,9 @@ def bench_decode(args, world, rank, dev, steps, warmup, with_cpu=True):
         print({k: (v["launches"], round(v["ms"], 2)) for k, v in pr.items() if v["launches"]})
         return None
     dec = GreedyDecoder(model, max_batch=B, max_len=Ln, use_graph=not getattr(args, "decode_eager", False))
-    for _ in range(max(1, warmup)):
+    # (counter-collection passes -- eager launches under rocprofv3 --pmc -- may ask for NO warm-up generation: every dispatch is
+    #  counted, and the profiler's counter pass has died on runs of much more than 10 k dispatches)
+    for _ in range(warmup if (warmup == 0 and getattr(args, "decode_eager", False)) else max(1, warmup)):
         ids = dec.generate(batch, Ln, temperature=1.1, repitition_penalty=1.5)
     out_ids = [None]
 
@@ -692,6 +694,10 @@ def main():
             trainer.step(batches[i % 2], stage=stage)
 
     run(args.warmup)
+    tune_steps = 0
+    while getattr(trainer, "_tune", None) is not None and tune_steps < 32:
+        run(1)                  # (data-parallel runs: the CU-reservation tuning finishes inside the untimed warm-up)
+        tune_steps += 1
     el = _timed(lambda: run(args.steps), world, dev)
     ms_step = 1e3 * el / args.steps
     tokens = B * world * T
@@ -755,13 +761,20 @@ def main():
         ddp_info = {"rccl_world": dist.get_world_size(), "backend": dist.get_backend(),
                     "cu_budget": cu_budget_setting() if world > 1 else 0,
                     "finish_wait_ms_per_step": None if finish_wait is None else round(finish_wait, 3),
+                    "budget_chosen": cu_budget_setting() if world > 1 else 0, "budget_tuning": trainer.budget_report,
+                    "extra_warmup_steps_for_tuning": tune_steps,
                     "buckets": len(trainer.reducer.buckets), "bucket_mb": args.bucket_mb,
+                    "bucket_sizes_mb": [round(4 * (e - s_) / 2 ** 20, 1) for s_, e in trainer.reducer.buckets],
+                    "tail_bucket_mb": round(trainer.reducer.tail_bytes() / 2 ** 20, 1),
                     "gradient_bytes": int(trainer.eng.layout.total * 4),
                     "allreduce_ms_per_step_isolated": round(allreduce_probe(trainer, max(3, min(args.steps, 10)), world, dev), 3),
                     "note": "allreduce_ms_per_step_isolated = the step's bucketed SUM all-reduces (+ the row count) alone, nothing to "
                             "overlap with; inside the step they run on RCCL's stream beside the backward; finish_wait_ms_per_step = how "
                             "long the compute stream waited for them after the backward (HIP events around GradReducer.finish, this rank): "
-                            "the exposed part of the exchange; cu_budget = CUs the GEMM tile rule leaves to (< 0) the RCCL kernels"}
+                            "the exposed part of the exchange; cu_budget = CUs the GEMM tile rule leaves to (< 0) the RCCL kernels -- budget_tuning: the trainer "
+                            "timed 3 steps under each of 0 / -16 / -32 during the warm-up and all ranks agreed on the fastest (MAX over ranks, "
+                            "one all-reduce; MMTG_DDP_GEMM_CUS pins it instead); tail_bucket_mb = what can only leave after the backward's last "
+                            "kernel (buckets end after wpe and after the fuser, so the tied embedding / projector leave before the encoder's backward)"}
         if one_gpu_backend:
             ddp_info["rehearsal"] = ("MMTG_BENCH_ONE_GPU_BACKEND=%s: all %d ranks share cuda:0 and exchange through the host -- a run of "
                                      "the N > 1 code path on a one-GPU box, NOT a throughput measurement" % (one_gpu_backend, world))

@@ -31,9 +31,45 @@ import torch.distributed as dist
 _budget_users = 0
 
 
+# what the self-tuning picked for this process (None: not tuned -- the environment's value or the default applies)
+_budget_chosen = None
+BUDGET_CANDIDATES = (0, -16, -32)
+# packs after which a bucket always ends (ParamLayout.buckets split_after): the tail of the backward
+TAIL_SPLIT = tuple(x for x in os.environ.get("MMTG_DDP_TAIL_SPLIT", "wpe,att_b").split(",") if x)
+
+
+def cu_budget_fixed():
+    """True when the environment pins the reservation (MMTG_DDP_GEMM_CUS): no self-tuning then."""
+    return "MMTG_DDP_GEMM_CUS" in os.environ
+
+
 def cu_budget_setting():
-    """The CU reservation a data-parallel run asks the GEMM tile rule for (MMTG_DDP_GEMM_CUS; < 0: CUs left to RCCL)."""
+    """The CU reservation a data-parallel run asks the GEMM tile rule for (< 0: CUs left to RCCL): the value the self-tuning
+    agreed on, else MMTG_DDP_GEMM_CUS, else 32 CUs left to the collectives."""
+    if _budget_chosen is not None and not cu_budget_fixed():
+        return _budget_chosen
     return int(os.environ.get("MMTG_DDP_GEMM_CUS", "-32"))
+
+
+def agree_on_budget(times_ms, candidates=BUDGET_CANDIDATES, group=None, device=None):
+    """Every rank timed the same few steps under each candidate reservation; the group keeps the candidate whose SLOWEST rank
+    was fastest (one MAX all-reduce of the timings: every rank computes the same arg-min -- first candidate on ties -- so the
+    tile rule, and with it the arithmetic order of every product, stays identical across ranks).  Returns (choice, agreed ms)."""
+    t = torch.tensor([float(x) for x in times_ms], dtype=torch.float64, device=device)
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    agreed = [float(x) for x in t.tolist()]
+    best = min(range(len(candidates)), key=lambda i: (agreed[i], i))
+    return candidates[best], agreed
+
+
+def set_chosen_budget(value):
+    """Install the agreed reservation (process-global, like the library setting it drives)."""
+    global _budget_chosen
+    _budget_chosen = value
+    if _budget_users > 0:
+        from . import hip
+        hip.gemm_cu_budget(cu_budget_setting())
 
 
 def _budget_acquire():
@@ -60,7 +96,7 @@ class GradReducer:
         self.layout = layout
         # MMTG_FORCE_DDP: run the collectives even at world size 1 (single-GPU self-test of the RCCL path)
         self.force = dist.is_initialized() and bool(os.environ.get("MMTG_FORCE_DDP"))
-        self.buckets = layout.buckets(int(bucket_mb * 1024 * 1024 / 4))
+        self.buckets = layout.buckets(int(bucket_mb * 1024 * 1024 / 4), split_after=TAIL_SPLIT)
         self._budget_set = False
         if self.world > 1 and torch.cuda.is_available():
             # the RCCL kernels run beside the backward and hold their CUs for the whole collective; a workgroup of the
@@ -110,6 +146,11 @@ class GradReducer:
             s, e = self.buckets[self.next_bucket]
             self.handles.append(dist.all_reduce(grad_flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
             self.next_bucket += 1
+
+    def tail_bytes(self):
+        """Bytes of the last bucket: what can only leave after the backward's last kernel (the exposed part's upper bound)."""
+        s, e = self.buckets[-1]
+        return 4 * (e - s)
 
     def finish(self, grad_flat):
         """Flush the remaining buckets and make the current stream wait for all of them (and for the row count)."""

@@ -109,14 +109,18 @@ class ParamLayout:
         off, n = self.pack_range[name]
         return flat[off:off + n]
 
-    def buckets(self, bucket_elems):
+    def buckets(self, bucket_elems, split_after=()):
         """Contiguous [start, end) ranges of ~bucket_elems elements on pack boundaries,
-        in gradient-ready order."""
+        in gradient-ready order.  `split_after`: pack names after which a bucket ends whatever its size -- the points of the
+        backward's TAIL at which a run of gradients is final (the tied embedding + wpe once the input-embedding backward has
+        run, the projector / fuser after the fuser's backward): what is left for the exchange after the last kernel is then
+        the encoder's gradients only, not everything since the last full bucket."""
         out, start = [], 0
+        forced = set(split_after)
         for name in self.pack_order:
             o, n = self.pack_range[name]
             end = o + n
-            if end - start >= bucket_elems:
+            if end - start >= bucket_elems or (name in forced and end > start):
                 out.append((start, end))
                 start = end
         if start < self.total:

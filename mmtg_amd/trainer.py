@@ -57,6 +57,18 @@ class MMTGTrainer:
         self.measure_finish, self.finish_events = False, []
         if self.reducer is not None:
             self.eng.bucket_hook = lambda pack: self.reducer.on_pack_ready(self.eng.grad, pack)
+        # Self-tuning CU reservation (round 5): a multi-rank GPU run whose environment does not pin MMTG_DDP_GEMM_CUS spends its
+        # first steps under each candidate (ddp.BUDGET_CANDIDATES: 0 / 16 / 32 CUs left to the RCCL kernels; TUNE_STEPS real
+        # optimisation steps each, the first of every candidate untimed), then all ranks agree on the fastest through one MAX
+        # all-reduce of the timings (ddp.agree_on_budget) -- whether RCCL holds CUs beside the backward depends on the node
+        # (profiles/r04_v1_ddp_cu_contention_one_gpu.txt priced a wrong guess at 5 % of the step either way).
+        from . import ddp as _ddp
+        self._tune = None
+        self.budget_report = None
+        if (self.reducer is not None and self.reducer.world > 1 and self.eng.dev.type == "cuda" and not _ddp.cu_budget_fixed()
+                and os.environ.get("MMTG_DDP_TUNE", "1") != "0"):
+            self._tune = {"cand": list(_ddp.BUDGET_CANDIDATES), "i": 0, "k": 0, "events": [[] for _ in _ddp.BUDGET_CANDIDATES]}
+            _ddp.set_chosen_budget(self._tune["cand"][0])
 
     def current_lr(self):
         if self.total is None:
@@ -103,6 +115,45 @@ class MMTGTrainer:
         either counter moves (train.py:184-185).  Shards of a shuffled global batch that are ALL empty after the stage
         filter do not occur with the released data (every rating occurs in every batch of 64+ rows); the price of the
         exact behaviour would be a host read of the all-reduced count every step."""
+        eng = self.eng
+        tune_ev = None
+        if self._tune is not None:
+            tune_ev = torch.cuda.Event(enable_timing=True)
+            tune_ev.record()
+        try:
+            return self._step(batch, stage, filter_rows)
+        finally:
+            if tune_ev is not None:
+                self._tune_after_step(tune_ev)
+
+    TUNE_STEPS = 3
+
+    def _tune_after_step(self, ev0):
+        """Book-keeping of the CU-reservation tuning: one event pair per step; after TUNE_STEPS steps of the last candidate the
+        ranks agree (the only host synchronisation of the tuning) and the choice is installed for the rest of the run."""
+        from . import ddp as _ddp
+        t = self._tune
+        ev1 = torch.cuda.Event(enable_timing=True)
+        ev1.record()
+        t["events"][t["i"]].append((ev0, ev1))
+        t["k"] += 1
+        if t["k"] < self.TUNE_STEPS:
+            return
+        t["k"] = 0
+        t["i"] += 1
+        if t["i"] < len(t["cand"]):
+            _ddp.set_chosen_budget(t["cand"][t["i"]])
+            return
+        torch.cuda.synchronize()
+        ms = [sum(a.elapsed_time(b) for a, b in evs[1:]) / max(1, len(evs) - 1) for evs in t["events"]]
+        choice, agreed = _ddp.agree_on_budget(ms, t["cand"], self.reducer.group, device=self.eng.dev)
+        _ddp.set_chosen_budget(choice)
+        self.budget_report = {"candidates": t["cand"], "ms_per_step_this_rank": [round(x, 3) for x in ms],
+                              "ms_per_step_slowest_rank": [round(x, 3) for x in agreed], "budget_chosen": choice,
+                              "steps_per_candidate": self.TUNE_STEPS}
+        self._tune = None
+
+    def _step(self, batch, stage, filter_rows):
         eng = self.eng
         if filter_rows and stage in (1, 2):
             # The selected row COUNT shapes every launch of the step, so the host has to know it: computed from a host copy

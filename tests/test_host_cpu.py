@@ -272,6 +272,19 @@ def _ddp_worker(rank, world, port, outdir):
         red.start_count(cnt)            # the row count rides with the buckets (no host-side exchange of its own)
         red.finish(grad)
         n = int(cnt.item())
+        # the tail of the backward: buckets end right after "wpe" and "att_b" (ddp.TAIL_SPLIT), so those runs of gradients leave
+        # when their own backward is done and only the encoder's gradients are left for after the last kernel
+        ends = {e for _, e in red.buckets}
+        assert red.pack_end["wpe"] in ends and red.pack_end["att_b"] in ends
+        assert 0 < red.tail_bytes() <= 4 * (lay.total - red.pack_end["att_b"])
+        # the CU-reservation tuning: the ranks time the candidates DIFFERENTLY (rank 0 finds 0 fastest, rank 1 finds -32 fastest);
+        # one MAX all-reduce later both hold the same choice -- the candidate whose slowest rank was fastest
+        from mmtg_amd.ddp import agree_on_budget
+        times = [10.0, 12.0, 15.0] if rank == 0 else [16.0, 12.5, 11.0]
+        choice, agreed = agree_on_budget(times, (0, -16, -32))
+        assert agreed == [16.0, 12.5, 15.0] and choice == -16
+        tie, _ = agree_on_budget([5.0, 5.0, 5.0], (0, -16, -32))
+        assert tie == 0                 # ties go to the first candidate on every rank
         torch.save((rank, mine, grad, len(red.buckets), n, launched), os.path.join(outdir, 'r%d.pt' % rank))
     finally:
         dist.destroy_process_group()
