@@ -204,9 +204,18 @@ MMTG_API int mmtg_layernorm_bwd_x3(const float* dy, const float* x, const float*
  * keep: [B,T] int32 key mask (1 = attend); out: [B*T, D]; lse: [B,nH,T] f32.  */
 MMTG_API int mmtg_attn_fwd(int dtype, const void* qkv, const int* keep, void* out, float* lse,
                   int B, int T, int nH, int dh, unsigned drop_thresh, unsigned drop_seed, void* stream);
-/* x3 mode: the same forward on fp32 qkv; the context rows go to `out` (fp32: the backward reads them) AND to a (hi | lo) bf16 plane
- * pair [B*T, D] (lo plane `plane` elements behind): the operand of attn.c_proj's split-precision product. */
+/* x3 mode (round 5): causal attention of the fp32-storage split-precision mode on the bf16 matrix cores -- the tiled algorithm of
+ * mmtg_attn_fwd / mmtg_attn_bwd with every product (Q K^T, P V, dO V^T, dO^T P, Q^T dS, dS K) as three passes over (hi | lo) splits:
+ * tiles are split while they are staged into LDS, P and dS in registers; softmax / masks / dropout in fp32 as the fp32 kernels
+ * (same dropout counter stream).  qkv, out, dout fp32.  Forward: context rows to `out` (fp32: the backward reads them) AND,
+ * when out_planes is given, to a (hi | lo) bf16 plane pair [B*T, D] (attn.c_proj's operand).  Backward: d(qkv) is written ONLY as
+ * a plane pair [B*T, 3D] (lo plane dplane elements behind): the c_attn dgrad / weight gradient read nothing else.  dq32: fp32
+ * [B*T, D] scratch (zeroed by the call; key blocks of 128 add into it with fp32 atomics); delta: [B*T, nH] scratch; dbias
+ * (nullable): [3D] += column sums of d(qkv), through dbias_ws (>= (B * ceil(T/128) + ceil(B*T/64)) * 3D floats).               */
 MMTG_API int mmtg_attn_fwd_x3(const float* qkv, const int* keep, float* out, void* out_planes, long plane, float* lse,
+                     int B, int T, int nH, int dh, unsigned drop_thresh, unsigned drop_seed, void* stream);
+MMTG_API int mmtg_attn_bwd_x3(const float* qkv, const int* keep, const float* out, const float* dout, const float* lse, float* delta,
+                     float* dq32, void* dqkv_planes, long dplane, float* dbias, float* dbias_ws, long dbias_ws_floats,
                      int B, int T, int nH, int dh, unsigned drop_thresh, unsigned drop_seed, void* stream);
 /* delta: [B*T, nH] f32, delta[m,h] = sum_d dout[m,h,d] * out[m,h,d]: computed by the call, or --
  * delta_ready != 0 -- already filled by the caller (the GEMM producing dout with

@@ -15,63 +15,9 @@
 // and f32 (v_mfma_f32_16x16x4_f32, the exact parity-gate mode).
 #include <stdlib.h>
 
-#include "mma.h"
+#include "attn_common.h"
 
 namespace {
-
-constexpr int DH = 64;
-
-template <typename T> struct AT {
-    static constexpr int EPC = 16 / sizeof(T);          // elements per 16-byte chunk
-    static constexpr int ROWB = DH * sizeof(T);         // bytes per [*, 64] row: 128 / 256
-    static constexpr int CPR = ROWB / 16;               // chunks per row: 8 / 16
-    static constexpr int KSTEPS = ROWB / 64;            // 64-byte k-blocks over dh: 2 / 4
-    static constexpr int KBE = 64 / sizeof(T);          // elements per k-block: 32 / 16
-    static constexpr int KPW = sizeof(T) == 2 ? 64 : 32;  // backward: keys per wave
-};
-
-__device__ __forceinline__ int vswz(int row) { return ((row >> 1) & 3) << 1; }
-// row-read ("KC") image: chunk ^ (row & 7);  transposed-read ("KS") image: chunk ^ vswz(row)
-template <typename T> __device__ __forceinline__ int off_kc(int row, int chunk) {
-    return row * AT<T>::ROWB + ((chunk ^ (row & 7)) << 4);
-}
-template <typename T> __device__ __forceinline__ int off_ks(int row, int chunk) {
-    return row * AT<T>::ROWB + ((chunk ^ vswz(row)) << 4);
-}
-
-template <typename T>
-__device__ __forceinline__ typename Vec16<T>::type ld_kc(const char* img, int row, int ks, int g) {
-    return *reinterpret_cast<const typename Vec16<T>::type*>(img + off_kc<T>(row, ks * 4 + g));
-}
-
-// A/B fragment whose k index runs over the ROWS of a KS image, column block [col0, col0+16).
-// bf16: rows {r_lo .. r_lo+3} and {r_hi .. r_hi+3} (per 16-lane group), via two transposed reads.
-__device__ __forceinline__ bf16x8 ld_ks(const char* img, int r_lo, int r_hi, int col0, int lane, bf16) {
-    const int q = (lane & 15) >> 2, p = lane & 3;
-    const int chunk = (col0 >> 3) + (p >> 1), sub = 8 * (p & 1);
-    return tr_read_pair(img, off_ks<bf16>(r_lo + q, chunk) + sub, off_ks<bf16>(r_hi + q, chunk) + sub);
-}
-// f32: rows r_lo + s, s = 0..3
-__device__ __forceinline__ f32x4 ld_ks(const char* img, int r_lo, int, int col0, int lane, float) {
-    const int c = col0 + (lane & 15);
-    f32x4 o;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) o[s] = *reinterpret_cast<const float*>(img + off_ks<float>(r_lo + s, c >> 2) + (c & 3) * 4);
-    return o;
-}
-
-// exp: accurate expf in the fp32 parity mode, hardware v_exp_f32 path for bf16 storage
-template <typename T> __device__ __forceinline__ float fexp(float x) {
-    if constexpr (sizeof(T) == 2) return __expf(x);
-    else return expf(x);
-}
-
-template <typename T> __device__ __forceinline__ typename Vec16<T>::type zero16() {
-    typename Vec16<T>::type v;
-#pragma unroll
-    for (int e = 0; e < Vec16<T>::N; ++e) v[e] = (T)0.f;
-    return v;
-}
 
 // ======================================================================== forward
 // (waves per SIMD the forward kernel is compiled for; 4 = at most 128 VGPRs, four workgroups per CU)
@@ -81,8 +27,7 @@ template <typename T> __device__ __forceinline__ typename Vec16<T>::type zero16(
 template <typename T>
 __global__ __launch_bounds__(256, ATTN_FWD_WAVES) void attn_fwd_kernel(const T* __restrict__ qkv, const int* __restrict__ keep,
         T* __restrict__ out, float* __restrict__ lse, int Tn, int nH,
-        uint32_t drop_thresh, uint32_t drop_seed, float inv_keep, bf16* __restrict__ oplanes = nullptr, long oplane = 0) {
-    // oplanes (x3 mode, T = float): the context rows ALSO as a (hi | lo) bf16 plane pair -- attn.c_proj's split-precision operand
+        uint32_t drop_thresh, uint32_t drop_seed, float inv_keep) {
     typedef typename Vec16<T>::type V;
     typedef AT<T> A;
     __shared__ __attribute__((aligned(16))) char sK[64 * A::ROWB];
@@ -236,16 +181,6 @@ __global__ __launch_bounds__(256, ATTN_FWD_WAVES) void attn_fwd_kernel(const T* 
             typedef T T4 __attribute__((ext_vector_type(4)));
             T4 o = {(T)(o_acc[dt][0] * inv), (T)(o_acc[dt][1] * inv), (T)(o_acc[dt][2] * inv), (T)(o_acc[dt][3] * inv)};
             *reinterpret_cast<T4*>(dst + dt * 16 + 4 * g) = o;
-            if constexpr (sizeof(T) == 4) {
-                if (oplanes) {
-                    bf16x4 hi, lo;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { hi[e] = (bf16)(float)o[e]; lo[e] = (bf16)((float)o[e] - (float)hi[e]); }
-                    bf16* pd = oplanes + ((long)b * Tn + qi) * D + h * DH + dt * 16 + 4 * g;
-                    *reinterpret_cast<bf16x4*>(pd) = hi;
-                    *reinterpret_cast<bf16x4*>(pd + oplane) = lo;
-                }
-            }
         }
         if (g == 0) lse[((long)b * nH + h) * Tn + qi] = l_run > 0.f ? m_run + logf(l_run) : -INFINITY;
     }
@@ -1655,22 +1590,6 @@ extern "C" int mmtg_attn_fwd(int dtype, const void* qkv, const int* keep, void* 
         hipLaunchKernelGGL(attn_fwd_kernel<bf16>, grid, block, 0, s, (const bf16*)qkv, keep, (bf16*)out, lse, T, nH, drop_thresh, drop_seed, ik);
     else MMTG_FAIL(MMTG_ERR_BAD_ARG, "attn_fwd: bad dtype");
     MMTG_LAUNCH_CHECK("attn_fwd");
-    return MMTG_OK;
-}
-
-/* x3 mode: mmtg_attn_fwd on fp32 qkv whose context rows go to the fp32 `out` (the backward reads it) AND to a (hi | lo) bf16 plane pair
- * [B*T, D] (attn.c_proj's split-precision operand). */
-extern "C" int mmtg_attn_fwd_x3(const float* qkv, const int* keep, float* out, void* out_planes, long plane, float* lse,
-                                int B, int T, int nH, int dh, unsigned drop_thresh, unsigned drop_seed, void* stream) {
-    MMTG_REQUIRE(dh == DH, "attn_fwd_x3: head dim %d unsupported (built for 64)", dh);
-    MMTG_REQUIRE(B > 0 && T > 0 && nH > 0 && qkv && keep && out && lse && out_planes, "attn_fwd_x3: bad sizes / null pointer");
-    MMTG_REQUIRE(MMTG_ALIGNED16(qkv) && MMTG_ALIGNED16(out) && MMTG_ALIGNED16(out_planes) && plane % 8 == 0 && plane >= (long)B * T * nH * DH,
-                 "attn_fwd_x3: alignment / plane layout");
-    hipStream_t s = (hipStream_t)stream;
-    ProfScope prof(MMTG_PROF_ATTN_FWD, s, 2.0 * B * nH * (double)T * T * dh, 4.0 * 5.0 * B * T * nH * dh);
-    hipLaunchKernelGGL(attn_fwd_kernel<float>, dim3(cdiv(T, 64), nH, B), dim3(256), 0, s, qkv, keep, out, lse, T, nH, drop_thresh, drop_seed,
-                       inv_keep_of(drop_thresh), (bf16*)out_planes, plane);
-    MMTG_LAUNCH_CHECK("attn_fwd_x3");
     return MMTG_OK;
 }
 

@@ -225,6 +225,8 @@ _LMHEAD_GROUP = _os.environ.get("MMTG_LMHEAD_GROUP", "1") != "0"      # the tied
 _LMHEAD_GROUP_SPLITS = int(_os.environ.get("MMTG_LMHEAD_GROUP_SPLITS", "0"))
 # the grouped weight-gradient launches on a SIDE stream, one block behind the dgrad chain (MMTG_WGRAD_STREAM; see Engine.backward)
 _WGRAD_STREAM = _os.environ.get("MMTG_WGRAD_STREAM", "0") != "0"
+# x3 mode: attention on the bf16 matrix cores as three passes over split operands (A/B switch: 0 = the exact-fp32 attention kernels)
+_X3_ATTN = _os.environ.get("MMTG_X3_ATTN", "1") != "0"
 _WGRAD_GROUP_CFG = int(_os.environ.get("MMTG_WGRAD_GROUP_CFG", "0"))          # 0: 128x128 tiles, four workgroups per CU; 1: 256x256 eight-phase
 
 
@@ -814,7 +816,11 @@ class Engine:
                 ctx = self.buf(f"l{l}_ctx", (M, D))
                 lse = self.buf(f"l{l}_lse", (B, sh.nH, T), torch.float32)
                 ctxp = self.pbuf(f"l{l}_ctxp", M, D)
-                hip.attn_fwd_x3(qkv, keep, ctx, ctxp, lse, B, T, sh.nH, D // sh.nH, drop_p=pa, drop_seed=s[0])
+                if _X3_ATTN:
+                    hip.attn_fwd_x3(qkv, keep, ctx, ctxp, lse, B, T, sh.nH, D // sh.nH, drop_p=pa, drop_seed=s[0])
+                else:
+                    hip.attn_fwd(qkv, keep, ctx, lse, B, T, sh.nH, D // sh.nH, drop_p=pa, drop_seed=s[0])
+                    hip.split_planes(ctx, M, D, ctxp)
                 xmid = self.buf(f"l{l}_xmid", (M, D))
                 self._fwd_x3(ctxp, p + "attn.c_proj.weight", xmid, M, bias=self.P(p + "attn.c_proj.bias"),
                              epi=hip.EPI_RESID, aux=hcur, ldaux=D, drop_p=pr, drop_seed=s[1])
@@ -1102,10 +1108,16 @@ class Engine:
                                      self.G(p + "ln_2.weight"), self.G(p + "ln_2.bias"), M, D, dy2p,
                                      drop_p=pr, drop_seed=s[1], dcolsum=self.G(p + "attn.c_proj.bias"), ws=lnws)
                 self._dgrad_x3(dy2p, p + "attn.c_proj.weight", dctx, M)
-                hip.attn_bwd(qkv, a["keep"], ctx, dctx, lse, delta, dq32, dqkv, B, T, sh.nH, D // sh.nH,
-                             drop_p=pa, drop_seed=s[0], delta_ready=False, dbias=self.G(p + "attn.c_attn.bias"),
-                             dbias_ws=self.buf("attn_dbias_rows", (hip.attn_bwd_bias_rows(B, T, self.dtype), 3 * D), torch.float32))
-                dqkvp = hip.split_planes(dqkv, M, 3 * D, self.pbuf("d_qkv_p", M, 3 * D))
+                dqkvp = self.pbuf("d_qkv_p", M, 3 * D)
+                if _X3_ATTN:
+                    hip.attn_bwd_x3(qkv, a["keep"], ctx, dctx, lse, delta, dq32, dqkvp, B, T, sh.nH, D // sh.nH, drop_p=pa, drop_seed=s[0],
+                                    dbias=self.G(p + "attn.c_attn.bias"),
+                                    dbias_ws=self.buf("attn_dbias_x3", (hip.attn_bwd_x3_ws(B, T, D),), torch.float32))
+                else:
+                    hip.attn_bwd(qkv, a["keep"], ctx, dctx, lse, delta, dq32, dqkv, B, T, sh.nH, D // sh.nH,
+                                 drop_p=pa, drop_seed=s[0], delta_ready=False, dbias=self.G(p + "attn.c_attn.bias"),
+                                 dbias_ws=self.buf("attn_dbias_rows", (hip.attn_bwd_bias_rows(B, T, self.dtype), 3 * D), torch.float32))
+                    hip.split_planes(dqkv, M, 3 * D, dqkvp)
                 self._dgrad_x3(dqkvp, p + "attn.c_attn.weight", da, M)
                 keys = (p + "mlp.c_fc.weight", p + "mlp.c_proj.weight", p + "attn.c_proj.weight", p + "attn.c_attn.weight")
                 probs = [(m2, dup, self.G(keys[0]), D, 4 * D), (gact, dyp, self.G(keys[1]), 4 * D, D),

@@ -46,6 +46,7 @@ _SIGS = {
     "mmtg_layernorm_bwd_x3": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _l, _u, _u, _vp, _vp, _l, _vp], _i),
     "mmtg_attn_fwd": ([_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _u, _u, _vp], _i),
     "mmtg_attn_fwd_x3": ([_vp, _vp, _vp, _vp, _l, _vp, _i, _i, _i, _i, _u, _u, _vp], _i),
+    "mmtg_attn_bwd_x3": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _vp, _vp, _l, _i, _i, _i, _i, _u, _u, _vp], _i),
     "mmtg_attn_trace": ([_vp], _i),
     "mmtg_attn_bwd": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _u, _u, _vp], _i),
     "mmtg_embed_condition": ([_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
@@ -352,8 +353,22 @@ def attn_fwd(qkv, keep, out, lse, B, T, nH, dh, drop_p=0.0, drop_seed=0):
 
 
 def attn_fwd_x3(qkv, keep, out, out_planes, lse, B, T, nH, dh, drop_p=0.0, drop_seed=0):
-    _check(lib().mmtg_attn_fwd_x3(_p(qkv), _p(keep), _p(out), _p(out_planes.t), out_planes.plane, _p(lse), B, T, nH, dh,
+    """Split-precision attention forward on fp32 qkv (include/mmtg_hip.h); out_planes: Planes or None."""
+    _check(lib().mmtg_attn_fwd_x3(_p(qkv), _p(keep), _p(out), 0 if out_planes is None else _p(out_planes.t),
+                                  0 if out_planes is None else out_planes.plane, _p(lse), B, T, nH, dh,
                                   drop_thresh(drop_p), drop_seed & 0xFFFFFFFF, _stream()), "attn_fwd_x3")
+
+
+def attn_bwd_x3_ws(B, T, D):
+    """Floats of the dbias workspace of attn_bwd_x3."""
+    return (B * (-(-T // 128)) + -(-(B * T) // 64)) * 3 * D
+
+
+def attn_bwd_x3(qkv, keep, out, dout, lse, delta, dq32, dqkv_planes, B, T, nH, dh, drop_p=0.0, drop_seed=0, dbias=None, dbias_ws=None):
+    """Split-precision attention backward: d(qkv) as the Planes ``dqkv_planes`` [B*T, 3D]."""
+    _check(lib().mmtg_attn_bwd_x3(_p(qkv), _p(keep), _p(out), _p(dout), _p(lse), _p(delta), _p(dq32), _p(dqkv_planes.t), dqkv_planes.plane,
+                                  _p(dbias), _p(dbias_ws), 0 if dbias_ws is None else dbias_ws.numel(), B, T, nH, dh,
+                                  drop_thresh(drop_p), drop_seed & 0xFFFFFFFF, _stream()), "attn_bwd_x3")
 
 
 def attn_bwd(qkv, keep, out, dout, lse, delta, dq32, dqkv, B, T, nH, dh, drop_p=0.0, drop_seed=0, delta_ready=False,

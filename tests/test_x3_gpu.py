@@ -177,3 +177,44 @@ def test_adamw_writes_the_weight_plane_pair():
     hip.adamw(p, gr, m, v, pl[0], n, 1e-3, 0.9, 0.999, 1e-6, 0.0, 1, None, 1.0, p_lo=pl[1])
     assert torch.equal(pl[0].float(), p.bfloat16().float())
     assert ((pl[0].float() + pl[1].float() - p).abs() <= 2.0 ** -17 * p.abs()).all()
+
+
+@pytest.mark.parametrize("B,T,drop", [(3, 236, 0.0), (2, 100, 0.0), (2, 236, 0.1), (1, 300, 0.1)])
+def test_attention_x3_matches_the_exact_fp32_kernels(B, T, drop):
+    """The split-precision attention (three bf16 passes per product, tiles split while staged) against the exact-fp32 kernels it
+    replaces in the bf16x3 mode: same masks (causal + key padding), same dropout stream -- forward context / LSE and the backward's
+    d(qkv) plane pair + c_attn bias gradient."""
+    nH, dh = 12, 64
+    D = nH * dh
+    g = torch.Generator(device=DEV).manual_seed(B * 1000 + T)
+    qkv = torch.randn(B * T, 3 * D, device=DEV, generator=g) * 0.8
+    keep = torch.ones(B, T, dtype=torch.int32, device=DEV)
+    keep[0, T - 7:] = 0                                   # padded tail keys on row 0
+    keep[B - 1, 5] = 0
+    dout = torch.randn(B * T, D, device=DEV, generator=g) * 0.1
+    seed = 4242
+    # exact fp32 reference kernels
+    out32 = torch.empty(B * T, D, device=DEV)
+    lse32 = torch.empty(B, nH, T, device=DEV)
+    hip.attn_fwd(qkv, keep, out32, lse32, B, T, nH, dh, drop_p=drop, drop_seed=seed)
+    delta = torch.empty(B * T, nH, device=DEV)
+    dq32 = torch.empty(B * T, D, device=DEV)
+    dqkv32 = torch.zeros(B * T, 3 * D, device=DEV)
+    db32 = torch.zeros(3 * D, device=DEV)
+    ws = torch.empty(hip.attn_bwd_bias_rows(B, T, hip.F32), 3 * D, device=DEV)
+    hip.attn_bwd(qkv, keep, out32, dout, lse32, delta, dq32, dqkv32, B, T, nH, dh, drop_p=drop, drop_seed=seed, dbias=db32, dbias_ws=ws)
+    # split-precision kernels
+    out = torch.full((B * T, D), float("nan"), device=DEV)
+    outp = hip.Planes.empty(B * T, D, DEV)
+    lse = torch.empty(B, nH, T, device=DEV)
+    hip.attn_fwd_x3(qkv, keep, out, outp, lse, B, T, nH, dh, drop_p=drop, drop_seed=seed)
+    assert (out - out32).abs().max().item() < 2e-5 * max(1.0, out32.abs().max().item())
+    assert (lse - lse32).abs().max().item() < 2e-5 * max(1.0, lse32.abs().max().item())
+    assert ((outp.float() - out).abs() <= 2.0 ** -17 * out.abs() + 1e-30).all()
+    dqp = hip.Planes.empty(B * T, 3 * D, DEV)
+    db = torch.zeros(3 * D, device=DEV)
+    ws3 = torch.empty(hip.attn_bwd_x3_ws(B, T, D), device=DEV)
+    hip.attn_bwd_x3(qkv, keep, out, dout, lse, delta, dq32, dqp, B, T, nH, dh, drop_p=drop, drop_seed=seed, dbias=db, dbias_ws=ws3)
+    scale = dqkv32.abs().max().item()
+    assert (dqp.float() - dqkv32).abs().max().item() < 4e-5 * scale, ((dqp.float() - dqkv32).abs().max().item(), scale)
+    assert (db - db32).abs().max().item() < 1e-4 * max(1.0, db32.abs().max().item())
