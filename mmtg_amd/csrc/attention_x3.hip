@@ -260,6 +260,15 @@ __global__ __launch_bounds__(64 * XNW, 1) void attn_bwd_x3_kernel(const float* _
     const uint32_t dbase = (uint32_t)(b * nH + h) * (uint32_t)Tn;
     const int nqt = (Tn + 31) / 32;
     const int kl = kw0 + l15, key = kb0 + kl;
+    // this wave's K / V fragments (its 16 keys, both k-blocks, hi | lo) do not change over the query sweep: registers, not 16 LDS
+    // reads per query tile
+    __syncthreads();
+    bf16x8 kfh[2], kfl[2], vfh[2], vfl[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        kfh[ks] = ld_kc<bf16>(sKr, kl, ks, g); kfl[ks] = ld_kc<bf16>(sKr + XIMG_K, kl, ks, g);
+        vfh[ks] = ld_kc<bf16>(sVr, kl, ks, g); vfl[ks] = ld_kc<bf16>(sVr + XIMG_K, kl, ks, g);
+    }
     for (int qt = kb0 / 32; qt < nqt; ++qt) {
         const int q0 = qt * 32;
         __syncthreads();
@@ -301,10 +310,8 @@ __global__ __launch_bounds__(64 * XNW, 1) void attn_bwd_x3_kernel(const float* _
                 f32x4 s_acc = {0.f, 0.f, 0.f, 0.f}, dp_acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
-                    mma3(ld_kc<bf16>(sQr, qs * 16 + l15, ks, g), ld_kc<bf16>(sQr + XIMG_Q, qs * 16 + l15, ks, g),
-                         ld_kc<bf16>(sKr, kl, ks, g), ld_kc<bf16>(sKr + XIMG_K, kl, ks, g), s_acc);
-                    mma3(ld_kc<bf16>(sOr, qs * 16 + l15, ks, g), ld_kc<bf16>(sOr + XIMG_Q, qs * 16 + l15, ks, g),
-                         ld_kc<bf16>(sVr, kl, ks, g), ld_kc<bf16>(sVr + XIMG_K, kl, ks, g), dp_acc);
+                    mma3(ld_kc<bf16>(sQr, qs * 16 + l15, ks, g), ld_kc<bf16>(sQr + XIMG_Q, qs * 16 + l15, ks, g), kfh[ks], kfl[ks], s_acc);
+                    mma3(ld_kc<bf16>(sOr, qs * 16 + l15, ks, g), ld_kc<bf16>(sOr + XIMG_Q, qs * 16 + l15, ks, g), vfh[ks], vfl[ks], dp_acc);
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -423,22 +430,42 @@ __global__ __launch_bounds__(64 * XNW, 1) void attn_bwd_x3_kernel(const float* _
 }
 
 // dq32 [rows, D] (fp32, summed over the key blocks by atomics) -> the q columns of d(qkv)'s plane pair + their column sums
-// (the q part of the c_attn bias gradient): one workgroup per 64-row band, partial sums to bias_rows[band][D]
+// (the q part of the c_attn bias gradient): one workgroup per 16-row band (a wave per 4 rows x 256 columns at a time), partial
+// sums to qsum[band][D] (the host sums the bands in a fixed order)
+constexpr int XFB = 16;      // rows per band
 __global__ __launch_bounds__(256) void attn_dq_finish_x3_kernel(const float* __restrict__ dq32, bf16* __restrict__ dqkv_p, long dplane,
                                                                float* __restrict__ qsum, long rows, int D) {
-    const long r0 = (long)blockIdx.x * 64;
-    for (int c = threadIdx.x * 4; c < D; c += 1024) {
+    __shared__ float sred[4][1024];
+    const long r0 = (long)blockIdx.x * XFB;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int c0 = 0; c0 < D; c0 += 256) {
+        const int c = c0 + lane * 4;
         f32x4 cs = {0.f, 0.f, 0.f, 0.f};
-        for (int r = 0; r < 64 && r0 + r < rows; ++r) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(dq32 + (r0 + r) * D + c);
-            bf16x4 hi, lo;
+        if (c < D) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { hi[e] = (bf16)v[e]; lo[e] = (bf16)(v[e] - (float)hi[e]); cs[e] += v[e]; }
-            bf16* dst = dqkv_p + (r0 + r) * 3 * D + c;
-            *reinterpret_cast<bf16x4*>(dst) = hi;
-            *reinterpret_cast<bf16x4*>(dst + dplane) = lo;
+            for (int i = 0; i < XFB / 4; ++i) {
+                const long r = r0 + wave * (XFB / 4) + i;
+                if (r < rows) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(dq32 + r * D + c);
+                    bf16x4 hi, lo;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { hi[e] = (bf16)v[e]; lo[e] = (bf16)(v[e] - (float)hi[e]); cs[e] += v[e]; }
+                    bf16* dst = dqkv_p + r * 3 * D + c;
+                    *reinterpret_cast<bf16x4*>(dst) = hi;
+                    *reinterpret_cast<bf16x4*>(dst + dplane) = lo;
+                }
+            }
         }
-        if (qsum) *reinterpret_cast<f32x4*>(qsum + (long)blockIdx.x * D + c) = cs;
+        if (qsum) {
+            __syncthreads();
+            if (c < D) *reinterpret_cast<f32x4*>(&sred[wave][lane * 4]) = cs;
+            __syncthreads();
+            if (wave == 0 && c < D) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(&sred[0][lane * 4]), b = *reinterpret_cast<const f32x4*>(&sred[1][lane * 4]);
+                const f32x4 d = *reinterpret_cast<const f32x4*>(&sred[2][lane * 4]), e = *reinterpret_cast<const f32x4*>(&sred[3][lane * 4]);
+                *reinterpret_cast<f32x4*>(qsum + (long)blockIdx.x * D + c) = (a + b) + (d + e);
+            }
+        }
     }
 }
 
@@ -476,9 +503,10 @@ extern "C" int mmtg_attn_fwd_x3(const float* qkv, const int* keep, float* out, v
 /* Backward of mmtg_attn_fwd_x3.  qkv, out, dout fp32; d(qkv) is written as a (hi | lo) bf16 plane pair [B*T, 3D] (lo plane `dplane`
  * elements behind) -- the c_attn dgrad and weight gradient are split-precision products and nothing else reads it.  dq32: fp32
  * [B*T, D] scratch (zeroed by the call; the key blocks add into it with fp32 atomics); delta: [B*T, nH] scratch; dbias (nullable):
- * [3D] += column sums of d(qkv); dbias_ws: >= (B * ceil(T / 128) + ceil(B*T / 64)) * 3D floats. */
+ * [3D] += column sums of d(qkv); dbias_ws: >= (B * ceil(T / 128) + ceil(B*T / 16)) * 3D floats;
+ * delta_ready != 0: delta was filled by the caller (the c_proj dgrad's MMTG_EPI_ROWDOT epilogue). */
 extern "C" int mmtg_attn_bwd_x3(const float* qkv, const int* keep, const float* out, const float* dout, const float* lse, float* delta,
-                                float* dq32, void* dqkv_planes, long dplane, float* dbias, float* dbias_ws, long dbias_ws_floats,
+                                int delta_ready, float* dq32, void* dqkv_planes, long dplane, float* dbias, float* dbias_ws, long dbias_ws_floats,
                                 int B, int T, int nH, int dh, unsigned drop_thresh, unsigned drop_seed, void* stream) {
     MMTG_REQUIRE(dh == DH, "attn_bwd_x3: head dim %d unsupported (built for 64)", dh);
     MMTG_REQUIRE(B > 0 && T > 0 && nH > 0 && qkv && keep && out && dout && lse && delta && dq32 && dqkv_planes, "attn_bwd_x3: bad sizes / null pointer");
@@ -486,7 +514,7 @@ extern "C" int mmtg_attn_bwd_x3(const float* qkv, const int* keep, const float* 
     const int D = nH * dh;
     MMTG_REQUIRE(MMTG_ALIGNED16(qkv) && MMTG_ALIGNED16(dout) && MMTG_ALIGNED16(dq32) && (((uintptr_t)dqkv_planes) & 7) == 0 && dplane % 4 == 0 &&
                  dplane >= rows * 3 * D, "attn_bwd_x3: alignment / plane layout");
-    const int nkb = cdiv(T, XKB), nband = cdiv(rows, 64);
+    const int nkb = cdiv(T, XKB), nband = cdiv(rows, XFB);
     MMTG_REQUIRE(!dbias || (dbias_ws && dbias_ws_floats >= ((long)B * nkb + nband) * 3 * D), "attn_bwd_x3: the bias gradient needs %ld workspace floats",
                  ((long)B * nkb + nband) * 3 * D);
     hipStream_t s = (hipStream_t)stream;
@@ -497,7 +525,7 @@ extern "C" int mmtg_attn_bwd_x3(const float* qkv, const int* keep, const float* 
             MMTG_FAIL(MMTG_ERR_HIP, "attn_bwd_x3: cannot raise dynamic LDS to %d", BwdLds::END);
         attr_set = true;
     }
-    hipLaunchKernelGGL(attn_delta_x3_kernel, dim3(cdiv(rows * nH, 4)), dim3(256), 0, s, out, dout, delta, nH, rows);
+    if (!delta_ready) hipLaunchKernelGGL(attn_delta_x3_kernel, dim3(cdiv(rows * nH, 4)), dim3(256), 0, s, out, dout, delta, nH, rows);
     if (hipMemsetAsync(dq32, 0, rows * D * sizeof(float), s) != hipSuccess) MMTG_FAIL(MMTG_ERR_HIP, "attn_bwd_x3: memset failed");
     float* const kv_rows = dbias ? dbias_ws : nullptr;                       // [B * nkb][3D]: k and v parts (q part zero)
     float* const q_rows = dbias ? dbias_ws + (long)B * nkb * 3 * D : nullptr; // [nband][D]

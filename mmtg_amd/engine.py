@@ -1107,13 +1107,15 @@ class Engine:
                 hip.layernorm_bwd_x3(dm, xmid, self.P(p + "ln_2.weight"), mu2, rs2, dx, dx2,
                                      self.G(p + "ln_2.weight"), self.G(p + "ln_2.bias"), M, D, dy2p,
                                      drop_p=pr, drop_seed=s[1], dcolsum=self.G(p + "attn.c_proj.bias"), ws=lnws)
-                self._dgrad_x3(dy2p, p + "attn.c_proj.weight", dctx, M)
                 dqkvp = self.pbuf("d_qkv_p", M, 3 * D)
                 if _X3_ATTN:
+                    # (the dgrad's epilogue also emits delta = rowsum(d ctx * ctx) per head: no separate pass over ctx / d ctx)
+                    self._dgrad_x3(dy2p, p + "attn.c_proj.weight", dctx, M, epi=hip.EPI_ROWDOT, aux=ctx, ldaux=D, aux2=delta)
                     hip.attn_bwd_x3(qkv, a["keep"], ctx, dctx, lse, delta, dq32, dqkvp, B, T, sh.nH, D // sh.nH, drop_p=pa, drop_seed=s[0],
-                                    dbias=self.G(p + "attn.c_attn.bias"),
+                                    dbias=self.G(p + "attn.c_attn.bias"), delta_ready=True,
                                     dbias_ws=self.buf("attn_dbias_x3", (hip.attn_bwd_x3_ws(B, T, D),), torch.float32))
                 else:
+                    self._dgrad_x3(dy2p, p + "attn.c_proj.weight", dctx, M)
                     hip.attn_bwd(qkv, a["keep"], ctx, dctx, lse, delta, dq32, dqkv, B, T, sh.nH, D // sh.nH,
                                  drop_p=pa, drop_seed=s[0], delta_ready=False, dbias=self.G(p + "attn.c_attn.bias"),
                                  dbias_ws=self.buf("attn_dbias_rows", (hip.attn_bwd_bias_rows(B, T, self.dtype), 3 * D), torch.float32))
@@ -1324,7 +1326,7 @@ class Engine:
                 # every step's d(gh) is kept (time-major) so that the recurrent weight / bias gradients are ONE
                 # product and ONE column sum after the loop instead of one per step
                 dgh_tm = self.buf("d_gh_tm", (S, B, 3 * H))
-                ks = 6 if bf and (3 * H) % (6 * 64) == 0 else 0      # split-K slabs of the carry product (bf16 kernels only)
+                ks = 6 if (3 * H) % (6 * 64) == 0 else 0      # split-K slabs of the carry product (fp32 kernel too, round 5: 92 -> us per step)
                 part = self.buf("d_hp_slabs", (max(ks, 1), B, H), torch.float32)
                 for t in range(S - 1, -1, -1):
                     # total gradient wrt h_t = rows b*S+t of dh_all + carry dh_{t+1} z_{t+1} + d(gh_{t+1}) W_hh, assembled in the cell kernel

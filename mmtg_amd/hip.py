@@ -46,7 +46,7 @@ _SIGS = {
     "mmtg_layernorm_bwd_x3": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _l, _u, _u, _vp, _vp, _l, _vp], _i),
     "mmtg_attn_fwd": ([_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _u, _u, _vp], _i),
     "mmtg_attn_fwd_x3": ([_vp, _vp, _vp, _vp, _l, _vp, _i, _i, _i, _i, _u, _u, _vp], _i),
-    "mmtg_attn_bwd_x3": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _vp, _vp, _l, _i, _i, _i, _i, _u, _u, _vp], _i),
+    "mmtg_attn_bwd_x3": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _l, _vp, _vp, _l, _i, _i, _i, _i, _u, _u, _vp], _i),
     "mmtg_attn_trace": ([_vp], _i),
     "mmtg_attn_bwd": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _u, _u, _vp], _i),
     "mmtg_embed_condition": ([_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
@@ -361,12 +361,13 @@ def attn_fwd_x3(qkv, keep, out, out_planes, lse, B, T, nH, dh, drop_p=0.0, drop_
 
 def attn_bwd_x3_ws(B, T, D):
     """Floats of the dbias workspace of attn_bwd_x3."""
-    return (B * (-(-T // 128)) + -(-(B * T) // 64)) * 3 * D
+    return (B * (-(-T // 128)) + -(-(B * T) // 16)) * 3 * D
 
 
-def attn_bwd_x3(qkv, keep, out, dout, lse, delta, dq32, dqkv_planes, B, T, nH, dh, drop_p=0.0, drop_seed=0, dbias=None, dbias_ws=None):
+def attn_bwd_x3(qkv, keep, out, dout, lse, delta, dq32, dqkv_planes, B, T, nH, dh, drop_p=0.0, drop_seed=0, dbias=None, dbias_ws=None,
+                delta_ready=False):
     """Split-precision attention backward: d(qkv) as the Planes ``dqkv_planes`` [B*T, 3D]."""
-    _check(lib().mmtg_attn_bwd_x3(_p(qkv), _p(keep), _p(out), _p(dout), _p(lse), _p(delta), _p(dq32), _p(dqkv_planes.t), dqkv_planes.plane,
+    _check(lib().mmtg_attn_bwd_x3(_p(qkv), _p(keep), _p(out), _p(dout), _p(lse), _p(delta), int(delta_ready), _p(dq32), _p(dqkv_planes.t), dqkv_planes.plane,
                                   _p(dbias), _p(dbias_ws), 0 if dbias_ws is None else dbias_ws.numel(), B, T, nH, dh,
                                   drop_thresh(drop_p), drop_seed & 0xFFFFFFFF, _stream()), "attn_bwd_x3")
 

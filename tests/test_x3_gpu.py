@@ -214,7 +214,7 @@ def test_attention_x3_matches_the_exact_fp32_kernels(B, T, drop):
     dqp = hip.Planes.empty(B * T, 3 * D, DEV)
     db = torch.zeros(3 * D, device=DEV)
     ws3 = torch.empty(hip.attn_bwd_x3_ws(B, T, D), device=DEV)
-    hip.attn_bwd_x3(qkv, keep, out, dout, lse, delta, dq32, dqp, B, T, nH, dh, drop_p=drop, drop_seed=seed, dbias=db, dbias_ws=ws3)
+    hip.attn_bwd_x3(qkv, keep, out, dout, lse, torch.empty_like(delta), dq32, dqp, B, T, nH, dh, drop_p=drop, drop_seed=seed, dbias=db, dbias_ws=ws3)
     scale = dqkv32.abs().max().item()
     assert (dqp.float() - dqkv32).abs().max().item() < 4e-5 * scale, ((dqp.float() - dqkv32).abs().max().item(), scale)
     assert (db - db32).abs().max().item() < 1e-4 * max(1.0, db32.abs().max().item())
