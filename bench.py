@@ -270,8 +270,8 @@ def decode_roofline(args, model, batch, B, Ln, dec, step_us_events):
                 m = json.load(fh)
         except Exception:
             continue
-        if m.get("kernel_source_sha") == hip.source_sha() and B == 256 and args.dtype == "bf16":
-            if m.get("step") == "fused" and getattr(dec, "fused", False):
+        if m.get("kernel_source_sha") == hip.source_sha() and B == 256 and m.get("dtype", "bf16") == args.dtype:
+            if m.get("step") in ("fused", "bf16x3") and (getattr(dec, "fused", False) or getattr(dec, "x3", False)):
                 # counter pass of the fused step, taken at the generation length the file names (the KV-cache share scales with it)
                 traffic = m["hbm_bytes_per_token_step"]
                 tsrc = os.path.relpath(f, ROOT) + (" [FUSED step at --decode-len %d: %d bytes per token step against %d algorithmic at that length]"
@@ -597,7 +597,10 @@ def main():
     ap.add_argument("--no-f32", action="store_true", help="skip the f32 (parity-gate mode) object of the default line")
     ap.add_argument("--no-x3", action="store_true", help="skip the bf16x3 (split-precision parity mode) object of the default line")
     ap.add_argument("--no-medium", action="store_true", help="skip the configs[4] (GPT-2-medium, T = 512) object of the default line")
+    ap.add_argument("--primary-only", action="store_true", help="the primary train measurement only: no decode / bf16x3 / f32 / medium objects (profiling passes)")
     args = ap.parse_args()
+    if args.primary_only:
+        args.no_decode = args.no_x3 = args.no_f32 = args.no_medium = True
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # no launcher: become one (before anything touches the GPU)

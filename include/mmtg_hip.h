@@ -89,6 +89,8 @@ enum {
 };
 
 MMTG_API int mmtg_abi_version(void);
+/* extra -D flags the library was compiled with ("" for the product build; diagnostic builds name theirs) */
+MMTG_API const char* mmtg_build_flags(void);
 MMTG_API const char* mmtg_last_error(void);
 
 /* Live per-kernel timing with HIP events recorded on the launch stream.

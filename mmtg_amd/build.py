@@ -21,8 +21,11 @@ OBJ = os.path.join(CSRC, "_build")
 LIB = os.path.join(HERE, "libmmtg_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
+EXTRA = os.environ.get("MMTG_EXTRA_DEFS", "").split()     # (diagnostic builds: -DMMTG_P8_PHASE_TRACE)
+# the extra defines are compiled INTO the library (mmtg_build_flags()): hip.lib() refuses a diagnostic build unless
+# MMTG_ALLOW_DIAGNOSTIC_BUILD=1, so it cannot be mistaken for the product by a later run, bench.py or a committed profile
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-         "-DNDEBUG", "-fvisibility=hidden"] + os.environ.get("MMTG_EXTRA_DEFS", "").split()     # (diagnostic builds: -DMMTG_P8_PHASE_TRACE)
+         "-DNDEBUG", "-fvisibility=hidden", '-DMMTG_BUILD_FLAGS="%s"' % " ".join(EXTRA)] + EXTRA
 
 
 def _sources():

@@ -24,6 +24,10 @@ int mmtg_check_launch(const char* what) {
 }
 
 extern "C" int mmtg_abi_version(void) { return MMTG_ABI_VERSION; }
+#ifndef MMTG_BUILD_FLAGS
+#define MMTG_BUILD_FLAGS ""
+#endif
+extern "C" const char* mmtg_build_flags(void) { return MMTG_BUILD_FLAGS; }
 extern "C" const char* mmtg_last_error(void) { return g_err; }
 
 // ---------------------------------------------------------------- profiler

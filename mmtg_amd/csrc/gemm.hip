@@ -1481,9 +1481,9 @@ extern "C" int mmtg_gemm(int dtype, int transA, int transB, int M, int N, int K,
             // next workgroup of that CU is already fetching its first tiles; a persistent one has them in its own vmcnt queue in
             // front of the next item's tiles, and every CU writes its 128-256 KB at the same moment.
             static const int p8_persist = getenv("MMTG_GEMM_P8_PERSIST") ? atoi(getenv("MMTG_GEMM_P8_PERSIST")) : 0;
-            const long tiles = rows == 192 ? t192 : rows == 288 ? t288 : t256;
             const bool want_persist = p8_persist || ((flags & MMTG_GEMM_P8) && (flags & MMTG_GEMM_PERSIST));
             if (want_persist && rows == 288) rows = 256;      // (no persistent 288-row instantiation)
+            const long tiles = rows == 192 ? t192 : rows == 288 ? t288 : t256;
             if (want_persist && tiles > num_cus() && num_cus() % 8 == 0) rc = rows == 192 ? launch_p8p<192>(a, s) : launch_p8p<256>(a, s);
             else rc = rows == 192 ? launch_p8<192>(a, 1, s) : rows == 288 ? launch_p8<288>(a, 1, s) : launch_p8<256>(a, 1, s);
             if (rc) return rc;

@@ -621,7 +621,9 @@ class GreedyDecoder:
         from `generator` (a CUDA torch.Generator; default: the global one) before the steps are replayed.
         Parity hooks (tests/test_decode_gpu.py): `teacher` [B, 1 + length] long -- after every step the token the step
         appended is replaced by teacher[:, j] wherever that is >= 0 (teacher forcing on a reference id list; the step's own
-        pick is handed to `tap` first); `tap(j, with_head, picked [B], logits [B, Vpad] or None)` is called after every step."""
+        pick is handed to `tap` first); `tap(j, with_head, picked [B], logits [B, Vpad] or None)` is called after every step
+        (`tap(None, False, None, None)` = restart: an opt-in chained launch gave up and the generation is being repeated)."""
+        gen_state = generator.get_state() if generator is not None else None     # (a chained launch that gives up repeats the generation)
         n_steps = self.begin(batch, length, temperature, repitition_penalty, top_k, top_p, generator)
         eng, sh = self.eng, self.eng.sh
         saved_mode = self.use_graph
@@ -642,7 +644,12 @@ class GreedyDecoder:
             d.check_persist()
         if any(d.check_chain() for d in ([self] + self.children)):
             # a chained launch gave up (its producers were not resident in time): the outputs are undefined -- the generation is
-            # repeated with the per-launch step, which this decoder keeps from here on
+            # repeated with the per-launch step, which this decoder keeps from here on; the generator is rewound so the repeat draws
+            # the SAME uniforms (a seeded run stays reproducible) and `tap` is told that everything it saw so far is void
+            if gen_state is not None:
+                generator.set_state(gen_state)
+            if tap is not None:
+                tap(None, False, None, None)
             return self.generate(batch, length, temperature, repitition_penalty, top_k, top_p, generator, use_graph, teacher, tap)
         return self.seq[:, sh.P:sh.P + 1 + length].clone()
 

@@ -30,6 +30,7 @@ _vp, _i, _l, _f, _u = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_uint
 _SIGS = {
     "mmtg_abi_version": ([], _i),
     "mmtg_last_error": ([], C.c_char_p),
+    "mmtg_build_flags": ([], C.c_char_p),
     "mmtg_prof_enable": ([_i], _i),
     "mmtg_prof_read": ([_vp, _vp, _vp, _vp], _i),
     "mmtg_gemm_trace": ([_vp, _i], _i),
@@ -148,6 +149,10 @@ def lib():
             fn.restype = res
         if L.mmtg_abi_version() != ABI_VERSION:
             raise RuntimeError("libmmtg_hip.so ABI version mismatch")
+        flags = L.mmtg_build_flags().decode()
+        if flags and os.environ.get("MMTG_ALLOW_DIAGNOSTIC_BUILD") != "1":
+            raise RuntimeError("libmmtg_hip.so is a diagnostic build (MMTG_EXTRA_DEFS=%r): rebuild with `python -m mmtg_amd.build` "
+                               "or set MMTG_ALLOW_DIAGNOSTIC_BUILD=1" % flags)
         _lib = L
     return _lib
 
@@ -307,10 +312,10 @@ _colsum_ws = {}
 
 def colsum(X, M, N, out, ldx=None, ws=None):
     """out[n] += sum_m X[m, n], in a fixed order (no atomics).  Tall inputs (mmtg_colsum_ws(M, N) > 0) sum in two stages through
-    `ws`; the engine hands over its own, other callers get a cached one."""
+    `ws` (default: a cached workspace per device, size and stream)."""
     need = int(lib().mmtg_colsum_ws(M, N))
     if need and (ws is None or ws.numel() < need):
-        key = (X.device, need)
+        key = (X.device, need, _stream())        # per stream: two streams summing the same width must not share slices
         ws = _colsum_ws.get(key)
         if ws is None:
             ws = _colsum_ws[key] = torch.empty(need, device=X.device, dtype=torch.float32)
@@ -513,7 +518,7 @@ _sumsq_ws = {}
 def sumsq(x, n, out):
     """out[0] = sum of squares of x[:n] (written, not accumulated), in a fixed summation order."""
     need = int(lib().mmtg_sumsq_ws(n))
-    key = (x.device, need)
+    key = (x.device, need, _stream())
     ws = _sumsq_ws.get(key)
     if ws is None:
         ws = _sumsq_ws[key] = torch.empty(need, device=x.device, dtype=torch.float32)

@@ -7,7 +7,7 @@ mkdir -p gpurun_out/pmc_bench
 export TMPDIR=/tmp
 R=$(pwd)
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc_bench -o $c -- python3 bench.py --steps 2 --warmup 1 --no-roofline --no-cpu-baseline --no-decode --no-check > gpurun_out/pmc_bench/$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc_bench -o $c -- python3 bench.py --steps 2 --warmup 1 --no-roofline --no-cpu-baseline --primary-only --no-check > gpurun_out/pmc_bench/$c.log 2>&1
 done
 python3 - <<'PY'
 import csv, glob, json, sys

@@ -3,7 +3,7 @@
 mkdir -p gpurun_out/prof
 export TMPDIR=/tmp
 R=$(pwd)
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o bench -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-decode --no-check > gpurun_out/prof_bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o bench -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --primary-only --no-check > gpurun_out/prof_bench.log 2>&1
 echo "rocprof exit $?" >> gpurun_out/prof_bench.log
 tail -3 gpurun_out/prof_bench.log
 find gpurun_out/prof -name "*stats*" | head; 
