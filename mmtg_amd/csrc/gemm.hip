@@ -1103,9 +1103,9 @@ __global__ __launch_bounds__(512, 1) void gemm_p8p_kernel(GemmArgs p) {
         gemm_epilogue<T, false, TMW, 4, (TBM == 256 ? 2 : -2)>(p, acc, m0 + wr * WTM, n0 + wc * 64, g, l15,
                                                                smem + 2 * STAGE + wave * epi_scratch_bytes<TMW, 4>(), lane);
         if (!has_next) break;
-#pragma unroll
+        // (no unroll pragma: constant trip counts, fully unrolled anyway -- with the pragma hipcc reports the already-unrolled
+        //  loop as "not unrolled" after the epilogue's inlining)
         for (int i = 0; i < TMW; ++i)
-#pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         item = nxt; m0 = m0n; n0 = n0n;
     }

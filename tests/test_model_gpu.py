@@ -996,3 +996,31 @@ def test_training_step_is_bit_reproducible(dtype):
         params.append(model.engine().master.detach().clone())
     assert torch.equal(grads[0], grads[1]), int((grads[0] != grads[1]).sum())
     assert torch.equal(params[0], params[1]), int((params[0] != params[1]).sum())
+
+
+def test_bf16x3_training_step_with_dropout_matches_the_f32_mode():
+    """Training mode (dropout 0.1 at GPT-2's three sites) in the split-precision mode against the exact-fp32 mode: both modes draw the
+    SAME counter-hash masks from the same seeds (the x3 products' residual epilogues, the x3 attention kernels and the plane-writing
+    LayerNorm backward use the fp32 kernels' counters), so one fused step gives the same loss, the same gradients and the same
+    parameters up to the products' 1e-5 -- no golden needed, the f32 mode is pinned to the reference."""
+    fx, meta, mcfg, gcfg, dcfg, weights, table, batch = load_case("tiny_s5")
+    gc = dict(gcfg, embd_pdrop=0.1, attn_pdrop=0.1, resid_pdrop=0.1)
+    tb = batch_to_torch(batch, DEV)
+    res = {}
+    for mode in ("f32", "bf16x3"):
+        torch.manual_seed(1234)                     # the dropout counter starts from a hash of torch's seed
+        model = MMTG(mcfg, dcfg, meta["V"], train_flag=True, gpt2_config=gc, token_table=table, compute_dtype=mode)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})
+        model.to(DEV).train()
+        tr = MMTGTrainer(model, lr=1e-4, alpha=0.2)
+        out = tr.step(tb, stage=3, filter_rows=False)
+        res[mode] = (out["loss"].item(), out["kl"].item(), model.engine().grad.clone(), model._flat.detach().clone(), float(tr.grad_norm()))
+    l32, k32, g32, p32, n32 = res["f32"]
+    l3, k3, g3, p3, n3 = res["bf16x3"]
+    assert abs(l3 - l32) < 1e-4 * max(1.0, abs(l32)), (l3, l32)
+    assert abs(k3 - k32) < 1e-4 * max(1e-3, abs(k32))
+    assert abs(n3 - n32) < 1e-3 * n32, (n3, n32)
+    cos = float((g3.double() @ g32.double()) / (g3.double().norm() * g32.double().norm()))
+    assert cos > 0.999999, cos
+    assert float((g3 - g32).abs().max()) < 2e-3 * float(g32.abs().max())
+    assert float((p3 - p32).abs().max()) <= 0.21 * 1e-4              # Adam's first step moves a weight by ~lr
