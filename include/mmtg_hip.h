@@ -480,40 +480,6 @@ MMTG_API int mmtg_decode_embed_x3(const float* table, const long long* seq, long
                          const int* pos_ptr, const long long* tpw_type, const long long* tpw_mask, long long* type_out, int* keep,
                          long ldkeep, int B, int P, int S, int E, int two_sents, int V, int sent, int max_sent_num, void* stream);
 
-/* Round 4 -- the twelve GPT-2 blocks and the head of a token step as ONE persistent launch (replaces the 61 dependent launches behind
- * generate.py:124's per-token model call).  A stage list is built on the HOST, one descriptor of mmtg_decode_stage_bytes() bytes per
- * stage, with the argument lists of the launches it replaces (mmtg_decode_stage_gemm = mmtg_decode_gemm without the embedding
- * residual, at most 4 K splits in mode 2; mmtg_decode_stage_attn = mmtg_decode_attn_split, bf16, at most 4 slabs), copied to the
- * device once, and walked by mmtg_decode_persist: a fixed grid of co-resident workgroups (mmtg_decode_persist_grid(): 2 or 3 per CU,
- * from the runtime's occupancy answer for the kernel) takes every stage's 64 x 64 tile items / (b, head) items in a strided loop; a
- * two-level device-wide barrier separates the stages; every tensor handed from one stage to the next moves through agent-scope
- * (write-through / L1-bypassing) accesses.  barrier_ws: >= 4096 bytes, ZEROED once by the caller and then owned by the kernel (its
- * counters are monotonic across launches); err_flag: int, zero on entry -- set to 1 if a barrier poll ran into its time bound (a
- * workgroup was not resident), in which case every workgroup leaves early, the outputs are undefined, and the caller must zero
- * barrier_ws and err_flag before the next launch.  Results are bit-equal to the per-launch fused step's. */
-MMTG_API long mmtg_decode_stage_bytes(void);
-MMTG_API int mmtg_decode_stage_gemm(void* stages_host, int index, int mode, int M, int N, int K, const void* A, long lda, const void* W,
-                           long ldw, void* C, long ldc, const float* bias, const float* colsum, const float* stats_in, int np_in,
-                           float eps, int act, int out_f32, const void* resid, long ldr, float* stats_out, int splits, float* ws,
-                           long ws_floats, unsigned* counters, long n_counters);
-MMTG_API int mmtg_decode_stage_attn(void* stages_host, int index, const float* part, int splits, const float* bias, void* kcache,
-                           void* vcache, const int* keep, long ldkeep, const int* pos_ptr, void* out, int B, int nH, int dh, int Tmax);
-MMTG_API int mmtg_decode_persist_grid(void);
-/* diagnostic: u64 device buffer [2 * stages + 1] (or null = off) -- workgroup 0 stamps the 100 MHz wall clock after its own work of
- * stage s ([2 s]), after the barrier behind it ([2 s + 1]) and at kernel entry ([2 * stages]) */
-MMTG_API int mmtg_decode_persist_trace(void* buf);
-MMTG_API int mmtg_decode_persist(const void* stages_dev, int nstages, void* barrier_ws, long barrier_bytes, int* err_flag, void* stream);
-
-/* Round 4 (ABI 7), CHAINED launch: the product stages [first, first + count) of an uploaded stage list (mmtg_decode_stage_gemm
- * descriptors; count <= 8) as ONE launch of `nitems` = the sum of their item counts workgroups, one 64 x 64 tile item each, in
- * stage order.  An item of stage j > 0 starts when the 64-row block it reads has been stored completely by stage j - 1 -- a
- * counter per row block (deps: 4096 zero-initialised 32-bit words per link -- the words of two row blocks sit 128 bytes apart --, re-armed by the last consumer of a block), bumped by
- * every wave after its write-through stores were acknowledged -- instead of behind a kernel boundary; activations, LayerNorm
- * statistics, residual rows and split-K partials move through agent-scope accesses.  Replaces, per GPT-2 block of the greedy decode
- * step behind /root/reference/src/generate.py:124, the four launches attn.c_proj -> mlp.c_fc -> mlp.c_proj -> (next block's
- * c_attn | LM head): same arithmetic per item, bit-equal ids.  Every poll is bounded (0.2 s): on a timeout *err_flag becomes
- * non-zero, every workgroup leaves, the outputs are undefined and the caller falls back to the per-launch step. */
-MMTG_API int mmtg_decode_chain(const void* stages_dev, int first, int count, int nitems, unsigned* deps, long deps_words, int* err_flag, void* stream);
 /* Wf[n, k] = gamma[k] W[n, k] (bf16), colsum[n] = sum_k Wf[n, k], bias_f[n] = bias[n] + sum_k beta[k] W[n, k]: the operands of the
  * LN-fold products, LN(x) W^T + b = rstd (x Wf^T - mu colsum) + bias_f.  W: [N, ldw] bf16 K-contiguous; bias may be null.   */
 MMTG_API int mmtg_ln_fold_weights(const void* W, long ldw, const float* gamma, const float* beta, const float* bias, void* Wf,

@@ -97,7 +97,6 @@ __global__ __launch_bounds__(256) void logits_argmax_kernel(const float* __restr
     }
 }
 
-
 // ------------------------------------------------------------------ stochastic selection (generate.py:64-94,127-141)
 // One workgroup per row: processed logits (penalty, temperature, bans, as above) -> top-k filter
 // (`logits < kth largest` dropped, ties at the k-th value kept) -> nucleus filter over the survivors (sorted
@@ -374,7 +373,6 @@ __global__ __launch_bounds__(256) void decode_embed_kernel(const T* __restrict__
     }
 }
 
-
 // =====================================================================================
 // Round 3: the decode step's batch-sized products with the row-wise glue fused in (5 graph nodes per GPT-2 block instead of 7).
 //
@@ -414,50 +412,21 @@ struct DgArgs {
     float* ws; unsigned* cnt; int ws_bytes;
     // mode 2, residual = wpe[*pos_ptr] + wte[type_ids[m]] instead of a tensor (the GPT-2 input embedding added in the projector's epilogue)
     const bf16* emb_pos; const bf16* emb_type; const long long* type_ids; const int* pos_ptr;
-    int bytesC, bytesR;        // extents of C (all slabs) and of the residual: buffer descriptors of the coherent (persistent) form
     // x3 (round 5, mmtg_decode_gemm_x3): A and W are (hi | lo) bf16 plane pairs of fp32 tensors, walked as three passes; C / resid /
     // the embedding tables are fp32; Cp (nullable) receives the result as a plane pair for the next product
     int planeA, planeW;        // bytes from the hi plane to the lo plane
     bf16* Cp; long ldcp, planeC;       // planeC: elements
 };
 
-// Agent-scope (sc1: write-through store / L1-bypassing load, cache-policy operand 16) accessors of the persistent token step: a
-// tensor written in one stage is read by OTHER workgroups -- other CUs, other XCDs -- in the next, with only a grid barrier in
-// between, so EVERY store and EVERY load of such a tensor carries the scope bit (MI355X_MICROARCH.md, valid hand-off forms).
-__device__ __forceinline__ void dg_st2_agent(__amdgpu_buffer_rsrc_t r, int byte_off, u32x2 v) { __builtin_amdgcn_raw_buffer_store_b64(v, r, byte_off, 0, 16); }
-__device__ __forceinline__ uint32_t dg_ld1_agent(__amdgpu_buffer_rsrc_t r, int byte_off) { return __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 16); }
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t dg_rsrc(const void* p, int bytes) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000); }
-
-// Chained launch (mmtg_decode_chain, round 4): several dependent products in ONE launch, one item per workgroup; an item of a later
-// stage waits until the 64-row block it reads has been written completely by the stage before it (a counter per row block, bumped
-// by every wave that stored a wave tile of that block) instead of behind a kernel boundary.  `wait` / `done`: counters of the block;
-// `seen`: how many consumers have passed the wait -- the last one re-arms both words for the next launch.  Polls are bounded.
-struct DgDep {
-    unsigned* wait; unsigned expected; unsigned* seen; unsigned consumers;     // null wait: no dependency inside the launch
-    unsigned sleep0;                                                           // ~4 us naps before the first poll
-    unsigned* done;                                                            // null: nobody inside the launch waits for this stage
-    int* err; int* s_flag;                                                     // error word (device), verdict word (LDS)
-    unsigned long long t_wait;                                                 // diagnostic: wall stamp when thread 0 passed the wait
-};
-constexpr unsigned long long DG_TIMEOUT_TICKS = 20000000ull;                   // 0.2 s of the 100 MHz wall counter per wait
-constexpr int DG_DEP_STRIDE = 32;              // 32-bit words between the counters of two row blocks (128 bytes: one line, one channel each)
-constexpr int DG_DEP_LINK = 2 * 64 * DG_DEP_STRIDE;        // words per link: 64 row-block counters + 64 consumer counts
-
-// One 64 x 64 output tile (x one K slice) = work item `bid`.  COH = false: the stand-alone launches (one item per workgroup).
-// COH = true: the persistent token step (decode_persist_kernel) -- activations, statistics and slabs move through agent-scope
-// accesses; the caller puts a workgroup barrier between two items (LDS ring / statistics reuse).
-// COHL: the LOADS of activations / statistics / residual rows carry the agent scope too (the persistent form: a buffer may be read,
-// rewritten by a later stage and read again inside one launch, so a consumer's L2 can hold a stale line); the chained launch orders its
-// stages so that no tensor is read again after it was rewritten inside the launch, and reads through the L2 like a stand-alone launch
-// (a line a consumer asks for after its row block's counter is complete was never in its L2 before: the launch began with an invalidate).
+// One 64 x 64 output tile (x one K slice) = work item `bid` of a stand-alone launch (one item per workgroup).
+// (The persistent one-launch token step and the chained launches of round 4 -- bit-equal, measured slower -- live in
+//  tools/experiments/decode_persistent_and_chained.patch.)
 // X3 (round 5): the split-precision form -- operands as (hi | lo) plane pairs, the K slice walked three times (A hi x W hi, A lo x W hi,
 // A hi x W lo: only the scalar offsets of a tile change), fp32 residual stream / embeddings, results as fp32 and / or plane pairs.
-template <int MODE, bool COH, int NBUF, int MAXS = 8, bool CHAIN = false, bool COHL = COH, bool X3 = false>
-__device__ __forceinline__ void dg_tile(const DgArgs& p, const int bid, char* smem, const DgDep* dep = nullptr) {
-    static_assert(!X3 || (!COH && !CHAIN), "x3: stand-alone launches only");
+template <int MODE, int NBUF, int MAXS = 8, bool X3 = false>
+__device__ __forceinline__ void dg_tile(const DgArgs& p, const int bid, char* smem) {
     constexpr int TB = 64, NW = 4, BK = 64, NB = 2;
     constexpr int TA = TB * 128, STAGE = 2 * TA;
-    constexpr int AUXA = COHL ? 16 : 0;                               // cache policy of the activation operand's LDS-DMA
     float* const smu = reinterpret_cast<float*>(smem + NBUF * STAGE);
     float* const srs = smu + TB;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -483,47 +452,7 @@ __device__ __forceinline__ void dg_tile(const DgArgs& p, const int bid, char* sm
         va[i] = dma_voff<false, TB>(p.lda, m0, p.M, BK, wave + NW * i, lane);
         vb[i] = dma_voff<false, TB>(p.ldw, n0, p.N, BK, wave + NW * i, lane);
     }
-    const int rblk = m0 / TB;
-    if constexpr (CHAIN) {
-        if (dep->wait) {
-            // the rows this item reads (activations, statistics, residual) are complete when every wave tile of the block has been
-            // stored AND acknowledged (the producers' s_waitcnt vmcnt(0) in front of their increment)
-            if (tid == 0) {
-                int ok = 1;
-                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-                // Polls go past the L2 to ONE memory channel per word: hundreds of workgroups polling every few hundred cycles made
-                // that channel the slowest line of every K tile of the stages that were running (first version: the c_fc stage took
-                // 22-38 us instead of 7).  So: the words of different row blocks sit 128 bytes apart, a stage sleeps through the time
-                // its producers need at least (`sleep0` x ~4 us) before its first poll, and polls ~0.6 us apart afterwards.
-                for (unsigned i = 0; i < dep->sleep0; ++i) __builtin_amdgcn_s_sleep(127);
-                unsigned it_ = 0;
-                while (__hip_atomic_load(dep->wait + rblk * DG_DEP_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < dep->expected) {
-#ifdef MMTG_CHAIN_SLEEP_X
-                    __builtin_amdgcn_s_sleep(60);
-#else
-                    __builtin_amdgcn_s_sleep(20);
-#endif
-                    if (__builtin_amdgcn_s_memrealtime() - t0 > DG_TIMEOUT_TICKS ||
-                        ((++it_ & 63u) == 0 && __hip_atomic_load(dep->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-                        __hip_atomic_store(dep->err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        ok = 0;
-                        break;
-                    }
-                }
-                if (ok) {       // the last consumer of the block re-arms its words (every producer and consumer has passed them)
-                    const unsigned sn = __hip_atomic_fetch_add(dep->seen + rblk * DG_DEP_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (sn == dep->consumers - 1) {
-                        __hip_atomic_store(dep->wait + rblk * DG_DEP_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store(dep->seen + rblk * DG_DEP_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                }
-                *dep->s_flag = ok;
-                const_cast<DgDep*>(dep)->t_wait = __builtin_amdgcn_s_memrealtime();
-            }
-            __syncthreads();
-            if (!*dep->s_flag) return;
-        }
-    }
+
     f32x4 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -541,7 +470,7 @@ __device__ __forceinline__ void dg_tile(const DgArgs& p, const int bid, char* sm
         _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                                               \
             const int oa_ = !live_ ? OOB : full_ ? va[i] : dma_voff<false, TB>(p.lda, m0, p.M, krem_, wave + NW * i, lane); \
             const int ob_ = !live_ ? OOB : full_ ? vb[i] : dma_voff<false, TB>(p.ldw, n0, p.N, krem_, wave + NW * i, lane); \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, LDS_PTR(void, st_ + (wave + NW * i) * 1024), 16, oa_, live_ ? sa_ : 0, 0, AUXA); \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, LDS_PTR(void, st_ + (wave + NW * i) * 1024), 16, oa_, live_ ? sa_ : 0, 0, 0); \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, LDS_PTR(void, st_ + TA + (wave + NW * i) * 1024), 16, ob_, live_ ? sb_ : 0, 0, 0); \
         }                                                                                                              \
         if constexpr (!X3) {                                                                                           \
@@ -560,14 +489,8 @@ __device__ __forceinline__ void dg_tile(const DgArgs& p, const int bid, char* sm
             const int m = min(m0 + tid, p.M - 1);
             const f32x4* src = reinterpret_cast<const f32x4*>(p.stats_in + (long)m * DG_NP * 2);
             f32x4 sp[DG_NP / 2];
-            if constexpr (COHL) {
-                const __amdgpu_buffer_rsrc_t rs = dg_rsrc(p.stats_in, p.M * DG_NP * 2 * 4);
 #pragma unroll
-                for (int i = 0; i < DG_NP / 2; ++i) sp[i] = i * 2 < p.np_in ? dg_ld4_agent(rs, (m * DG_NP * 2 + 4 * i) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-            } else {
-#pragma unroll
-                for (int i = 0; i < DG_NP / 2; ++i) sp[i] = i * 2 < p.np_in ? src[i] : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
+            for (int i = 0; i < DG_NP / 2; ++i) sp[i] = i * 2 < p.np_in ? src[i] : f32x4{0.f, 0.f, 0.f, 0.f};
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int i = 0; i < DG_NP / 2; ++i) { s1 += sp[i][0] + sp[i][2]; s2 += sp[i][1] + sp[i][3]; }
@@ -623,8 +546,7 @@ __device__ __forceinline__ void dg_tile(const DgArgs& p, const int bid, char* sm
                     // slab `split` of the consumer's fp32 input: the mean term rides on slab 0, the bias is the consumer's
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = rs * acc[i][j][r] - (split == 0 ? rs * mu * c4[j][r] : 0.f);
-                    if constexpr (COH) dg_st4_agent(dg_rsrc(p.C, p.bytesC), (int)((((long)split * p.M + m) * p.ldc + n) * 4), v);
-                    else *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + ((long)split * p.M + m) * p.ldc + n) = v;
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + ((long)split * p.M + m) * p.ldc + n) = v;
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -632,8 +554,7 @@ __device__ __forceinline__ void dg_tile(const DgArgs& p, const int bid, char* sm
                         if (p.act == MMTG_EPI_GELU) v[r] = gelu_new_t<bf16>(v[r]);
                     }
                     if (p.out_f32) {
-                        if constexpr (COH) dg_st4_agent(dg_rsrc(p.C, p.bytesC), (int)(((long)m * p.ldc + n) * 4), v);
-                        else *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n) = v;
+                        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n) = v;
                     } else if constexpr (X3) {          // the activation as a plane pair: only the next product reads it
                         bf16x4 hi, lo;
 #pragma unroll
@@ -643,18 +564,12 @@ __device__ __forceinline__ void dg_tile(const DgArgs& p, const int bid, char* sm
                         *reinterpret_cast<bf16x4*>(dst + p.planeC) = lo;
                     } else {
                         const bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-                        if constexpr (COH) dg_st2_agent(dg_rsrc(p.C, p.bytesC), (int)(((long)m * p.ldc + n) * 2), __builtin_bit_cast(u32x2, o));
-                        else *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(p.C) + (long)m * p.ldc + n) = o;
+                        *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(p.C) + (long)m * p.ldc + n) = o;
                     }
                 }
             }
         }
-        if constexpr (CHAIN) {
-            if (dep->done) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's write-through stores have been acknowledged
-                if (lane == 0) __hip_atomic_fetch_add(dep->done + rblk * DG_DEP_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
+
     } else {
         // ---- split-K reduced by the last-arriving wave (csrc/wgrad.hip), + bias + residual + row statistics
         const int S = p.splits;
@@ -673,7 +588,7 @@ __device__ __forceinline__ void dg_tile(const DgArgs& p, const int bid, char* sm
             old = __builtin_amdgcn_readfirstlane(old);
             if (old != (unsigned)(S - 1)) return;
             // (re-armed for the next product: an agent-scope store in the persistent form, where no kernel boundary flushes it)
-            if (lane == 0) { if constexpr (COH) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *cnt = 0u; }
+            if (lane == 0) *cnt = 0u;
         }
         // every split's partial (my own slot included: statically indexed registers, no scratch), all requested back to back:
         // one memory round trip for the whole reduction
@@ -737,12 +652,7 @@ __device__ __forceinline__ void dg_tile(const DgArgs& p, const int bid, char* sm
                         for (int r = 0; r < 4; ++r) xr[r] = (float)e0[r] + (float)e1[r];
                     } else {
                         bf16x4 x4;
-                        if constexpr (COHL) {           // two 4-byte agent-scope loads (the measured-valid widths: 4 / 16 bytes)
-                            const __amdgpu_buffer_rsrc_t rr = dg_rsrc(p.resid, p.bytesR);
-                            const int o_ = (int)(((long)m * p.ldr + n) * 2);
-                            const u32x2 w = {dg_ld1_agent(rr, o_), dg_ld1_agent(rr, o_ + 4)};
-                            x4 = __builtin_bit_cast(bf16x4, w);
-                        } else x4 = *reinterpret_cast<const bf16x4*>(p.resid + (long)m * p.ldr + n);
+                        x4 = *reinterpret_cast<const bf16x4*>(p.resid + (long)m * p.ldr + n);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) xr[r] = (float)x4[r];
                     }
@@ -754,8 +664,7 @@ __device__ __forceinline__ void dg_tile(const DgArgs& p, const int bid, char* sm
                         r1 += f;
                         r2 += f * f;
                     }
-                    if constexpr (COH) dg_st2_agent(dg_rsrc(p.C, p.bytesC), (int)(((long)m * p.ldc + n) * 2), __builtin_bit_cast(u32x2, o));
-                    else *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(p.C) + (long)m * p.ldc + n) = o;
+                    *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(p.C) + (long)m * p.ldc + n) = o;
                 }
             }
             // the row's 32 columns of this wave tile live in the four lane groups g: fold them
@@ -763,19 +672,8 @@ __device__ __forceinline__ void dg_tile(const DgArgs& p, const int bid, char* sm
             r1 += __shfl_xor(r1, 32, 64); r2 += __shfl_xor(r2, 32, 64);
             if (g == 0 && m < p.M && nw0 < p.N && (!X3 || p.stats_out)) {
                 float* dst = p.stats_out + ((long)m * DG_NP + (nw0 >> 5)) * 2;
-                if constexpr (COH) {
-                    const f32x2 rr2 = {r1, r2};
-                    dg_st2_agent(dg_rsrc(p.stats_out, p.M * DG_NP * 2 * 4), (m * DG_NP + (nw0 >> 5)) * 8, __builtin_bit_cast(u32x2, rr2));
-                } else {
-                    dst[0] = r1;
-                    dst[1] = r2;
-                }
-            }
-        }
-        if constexpr (CHAIN) {
-            if (dep->done) {       // (only the wave that wrote the wave tile gets here: the other splits returned above)
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (lane == 0) __hip_atomic_fetch_add(dep->done + rblk * DG_DEP_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                dst[0] = r1;
+                dst[1] = r2;
             }
         }
     }
@@ -784,12 +682,12 @@ __device__ __forceinline__ void dg_tile(const DgArgs& p, const int bid, char* sm
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void decode_gemm_kernel(DgArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];      // 4 stages | row statistics
-    dg_tile<MODE, false, 4>(p, blockIdx.x, smem);
+    dg_tile<MODE, 4>(p, blockIdx.x, smem);
 }
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void decode_gemm_x3_kernel(DgArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];      // 4 stages | row statistics
-    dg_tile<MODE, false, 4, 8, false, false, true>(p, blockIdx.x, smem);
+    dg_tile<MODE, 4, 8, true>(p, blockIdx.x, smem);
 }
 
 // x3 weight preparation, one wave per output row n of a K-contiguous weight given as a plane pair W = hi + lo ([N, K]):
@@ -911,10 +809,8 @@ template <typename V, bool NT> __device__ __forceinline__ V ld_kv(const V* p) {
 // bytes of LDS one (b, head) item needs: scores, key flags, q (f32), this token's k and v
 template <typename T> constexpr int da_lds_bytes() { return 1024 * 4 + 1024 * 4 + 64 * 4 + 2 * 64 * (int)sizeof(T); }
 
-// COH = false: one 64-thread workgroup per (b, head) (__syncthreads() = that wave).  COH = true: one WAVE of a persistent
-// workgroup per item -- the wave's LDS operations complete in order, so its "barrier" is a drain of its own counters -- with the
-// c_attn slabs read and the context row stored through agent-scope accesses (they cross workgroups with only a grid barrier between).
-template <typename T, bool COH, bool NT = false>
+// one 64-thread workgroup per (b, head)
+template <typename T, bool NT = false>
 __device__ __forceinline__ void da_body(const T* __restrict__ qkv, T* __restrict__ kc, T* __restrict__ vc,
         const int* __restrict__ keep, long ldkeep, const int pos, T* __restrict__ out, const int B,
         int nH, int Tmax, const float* __restrict__ part, int splits, long slab, const float* __restrict__ bias,
@@ -928,7 +824,7 @@ __device__ __forceinline__ void da_body(const T* __restrict__ qkv, T* __restrict
     float* const sq = reinterpret_cast<float*>(lds + 8192);
     T* const sk = reinterpret_cast<T*>(lds + 8192 + 256);
     T* const sv = sk + 64;
-#define DA_SYNC() do { if constexpr (COH) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); else __syncthreads(); } while (0)
+#define DA_SYNC() __syncthreads()
     const int D = nH * 64;
     const T* row = qkv + (long)b * 3 * D + h * 64;
     T* kbase = kc + (((long)b * nH + h) * Tmax) * 64;
@@ -966,28 +862,15 @@ __device__ __forceinline__ void da_body(const T* __restrict__ qkv, T* __restrict
         float q = 0.f, k = 0.f, v = 0.f;
         const float bq = bias[h * 64 + lane], bk = bias[D + h * 64 + lane], bv = bias[2 * D + h * 64 + lane];
         float pq[4], pk[4], pv[4];
-        if constexpr (COH) {
-            const __amdgpu_buffer_rsrc_t rp = dg_rsrc(part, (int)((long)splits * slab * 4));
-            const int o0 = (int)(((long)b * 3 * D + h * 64 + lane) * 4);
 #pragma unroll
-            for (int s_ = 0; s_ < 4; ++s_) {
-                const int o = o0 + (int)((long)(s_ < splits ? s_ : 0) * slab * 4);
-                pq[s_] = __builtin_bit_cast(float, dg_ld1_agent(rp, o));
-                pk[s_] = __builtin_bit_cast(float, dg_ld1_agent(rp, o + D * 4));
-                pv[s_] = __builtin_bit_cast(float, dg_ld1_agent(rp, o + 2 * D * 4));
-            }
-        } else {
-#pragma unroll
-            for (int s_ = 0; s_ < 4; ++s_) {
-                const long o = (long)(s_ < splits ? s_ : 0) * slab;
-                pq[s_] = pr[o]; pk[s_] = pr[o + D]; pv[s_] = pr[o + 2 * D];
-            }
+        for (int s_ = 0; s_ < 4; ++s_) {
+            const long o = (long)(s_ < splits ? s_ : 0) * slab;
+            pq[s_] = pr[o]; pk[s_] = pr[o + D]; pv[s_] = pr[o + 2 * D];
         }
 #pragma unroll
         for (int s_ = 0; s_ < 4; ++s_)
             if (s_ < splits) { q += pq[s_]; k += pk[s_]; v += pv[s_]; }
-        if constexpr (!COH)
-            for (int s_ = 4; s_ < splits; ++s_) { q += pr[s_ * slab]; k += pr[s_ * slab + D]; v += pr[s_ * slab + 2 * D]; }
+        for (int s_ = 4; s_ < splits; ++s_) { q += pr[s_ * slab]; k += pr[s_ * slab + D]; v += pr[s_ * slab + 2 * D]; }
         q += bq; k += bk; v += bv;
         sq[lane] = (float)(T)q * 0.125f;
         sk[lane] = (T)k;
@@ -1076,7 +959,7 @@ __device__ __forceinline__ void da_body(const T* __restrict__ qkv, T* __restrict
         V o;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) o[e] = (T)(acc[e] * inv);
-        if constexpr (EPL == 4 && !COH) {
+        if constexpr (EPL == 4) {
             if (oplanes) {        // x3: the context row as a (hi | lo) plane pair (attn.c_proj is its only reader)
                 bf16x4 hi, lo;
 #pragma unroll
@@ -1087,9 +970,7 @@ __device__ __forceinline__ void da_body(const T* __restrict__ qkv, T* __restrict
                 return;
             }
         }
-        if constexpr (COH) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), dg_rsrc(out, (int)((long)B * D * sizeof(T))),
-                                                                 (int)(((long)b * D + h * 64 + oc * EPL) * sizeof(T)), 0, 16);
-        else *reinterpret_cast<V*>(out + (long)b * D + h * 64 + oc * EPL) = o;
+        *reinterpret_cast<V*>(out + (long)b * D + h * 64 + oc * EPL) = o;
     }
 #undef DA_SYNC
 }
@@ -1100,10 +981,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void de
         int nH, int Tmax, const float* __restrict__ part, int splits, long slab, const float* __restrict__ bias,
         bf16* __restrict__ oplanes = nullptr, long oplane = 0) {
     __shared__ __attribute__((aligned(16))) char lds[da_lds_bytes<T>()];
-    da_body<T, false, NT>(qkv, kc, vc, keep, ldkeep, *pos_ptr, out, (int)gridDim.y, nH, Tmax, part, splits, slab, bias,
+    da_body<T, NT>(qkv, kc, vc, keep, ldkeep, *pos_ptr, out, (int)gridDim.y, nH, Tmax, part, splits, slab, bias,
                       (int)blockIdx.x, (int)blockIdx.y, (int)threadIdx.x, lds, oplanes, oplane);
 }
-
 
 // logits processor + arg-max + forced-token cadence + append (generate.py:117-142), device-driven.
 __global__ __launch_bounds__(256) void decode_select_kernel(const float* __restrict__ logits, long ldl, int V,
@@ -1152,159 +1032,6 @@ __global__ __launch_bounds__(256) void decode_select_kernel(const float* __restr
 }
 
 __global__ void decode_advance_kernel(int* pos_ptr) { *pos_ptr += 1; }
-
-// =====================================================================================
-// Round 4: the GPT-2 part of a token step as ONE persistent launch (mmtg_decode_persist).
-//
-// The fused step above is 61 dependent launches for the twelve blocks and the head (c_attn, attention, attn c_proj, c_fc,
-// mlp c_proj per block); each costs ~4 us of kernel begin / end whatever it does and starts from cold caches.  Here the same
-// 61 stages run inside one kernel: a fixed grid of co-resident 256-thread workgroups walks a stage list (device memory, built once
-// per decoder), every workgroup takes the stage's 64 x 64 tile items / every wave its (b, head) items in a strided loop, and a
-// two-level device-wide barrier (one arrival counter per shard of workgroups with equal id % 8 -- one XCD under round-robin
-// placement, a speed assumption only -- whose last arriver bumps the top counter; everybody polls one generation word) separates
-// the stages: 2-3 us instead of a kernel boundary.  Data handed from one stage to the next crosses workgroups, CUs and XCDs with no
-// kernel boundary to flush the non-coherent L2s, so every such tensor (residual stream, LayerNorm statistics, c_attn slabs,
-// attention context, GELU output, split-K partials) is written with agent-scope (sc1, write-through) stores and read with
-// agent-scope loads / LDS-DMA, each wave drains its stores (vmcnt(0)) before its workgroup arrives at the barrier: the hand-off
-// form MI355X_MICROARCH.md measures as valid without L2-wide fences.  Weights, biases and the KV cache rows of earlier steps are
-// ordinary loads.  The arithmetic per item is the fused step's (dg_tile / da_body with COH = true): same K order, same reduction
-// order -- the ids are bit-equal to the per-launch step's (tests/test_decode_gpu.py).
-// Safety: every poll is bounded (a stage that cannot complete -- a workgroup that is not resident -- raises the error word and
-// every workgroup leaves; the host checks it), the grid is sized from the occupancy the runtime reports for THIS kernel.
-struct DaArgs {
-    const float* part; const float* bias; bf16* kc; bf16* vc; const int* keep; const int* pos_ptr; bf16* out;
-    long ldkeep, slab;
-    int splits, B, nH, Tmax;
-};
-struct PStage {
-    int kind, nitems;          // kind 0 / 1 / 2: dg_tile mode; 3: attention; items = tiles x splits, or B x heads
-    DgArgs g;
-    DaArgs a;
-};
-// Two builds: WPC = 3 workgroups per CU (twelve waves per CU for the attention stages; 168 registers, a 3 x 16 KB product ring) and
-// WPC = 2 (256 registers, the stand-alone kernels' 4 x 16 KB ring); mmtg_decode_persist_grid picks (MMTG_DECODE_PERSIST_WGS).
-template <int WPC> constexpr int ps_nbuf() { return WPC >= 3 ? 3 : 4; }
-template <int WPC> constexpr int ps_lds() { return ps_nbuf<WPC>() * 2 * 64 * 128 + 2 * 64 * 4 + 16; }      // ring | statistics | verdict word
-static_assert(4 * da_lds_bytes<bf16>() <= ps_lds<3>(), "the four attention waves' scratch overlays the product ring");
-constexpr unsigned long long PS_TIMEOUT_TICKS = 20000000ull;       // 0.2 s of the 100 MHz wall counter per barrier
-// barrier words (unsigned long long, 128-byte separated): [0] generation, [16] top counter, [32 + 16 k] shard k
-__device__ __forceinline__ unsigned long long ps_ld(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-__device__ __forceinline__ bool ps_grid_barrier(unsigned long long* bar, unsigned long long target, int* err, int tid) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's agent-scope stores have been acknowledged
-    __syncthreads();
-    bool ok = true;
-    if (tid == 0) {
-        const int nb = gridDim.x, x = blockIdx.x & 7;
-        const unsigned long long per = (unsigned long long)((nb + 7 - x) / 8);
-        const unsigned long long old = __hip_atomic_fetch_add(bar + 32 + 16 * x, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old == target * per - 1) {
-            const unsigned long long g = __hip_atomic_fetch_add(bar + 16, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (g == target * 8 - 1) __hip_atomic_store(bar, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        while (ps_ld(bar) < target) {
-            __builtin_amdgcn_s_sleep(2);
-            if (__builtin_amdgcn_s_memrealtime() - t0 > PS_TIMEOUT_TICKS || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-                __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ok = false;
-                break;
-            }
-        }
-    }
-    return ok;          // thread 0's verdict; the caller publishes it to the workgroup
-}
-
-template <int WPC>
-__global__ __launch_bounds__(256, WPC) void decode_persist_kernel(const PStage* __restrict__ stages, int nstages, unsigned long long* bar, int* err,
-                                                                  unsigned long long* __restrict__ trace) {
-    constexpr int PS_NBUF = ps_nbuf<WPC>();
-    extern __shared__ __attribute__((aligned(16))) char smem[];      // ONE LDS object (a second one beside an LDS-DMA ring can de-pipeline it)
-    int& s_ok = *reinterpret_cast<int*>(smem + ps_lds<WPC>() - 16);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;        // a poisoned decoder: the host must reset it
-    // no barrier is in flight when a launch starts (the previous launch's last barrier completed before any workgroup left)
-    const unsigned long long gen0 = ps_ld(bar);
-    if (trace && blockIdx.x == 0 && tid == 0) trace[2 * nstages] = __builtin_amdgcn_s_memrealtime();
-    for (int s = 0; s < nstages; ++s) {
-        const PStage& S = stages[s];
-        const int kind = S.kind, n = S.nitems;
-        if (kind == 3) {
-            const DaArgs& a = S.a;
-            const int pos = *a.pos_ptr;
-            for (int it = blockIdx.x * 4 + wave; it < n; it += gridDim.x * 4)
-                da_body<bf16, true>(nullptr, a.kc, a.vc, a.keep, a.ldkeep, pos, a.out, a.B, a.nH, a.Tmax, a.part, a.splits, a.slab, a.bias,
-                                    it % a.nH, it / a.nH, lane, smem + wave * da_lds_bytes<bf16>());
-        } else {
-            for (int it = blockIdx.x; it < n; it += gridDim.x) {
-                if (kind == 0) dg_tile<0, true, PS_NBUF>(S.g, it, smem);
-                else if (kind == 1) dg_tile<1, true, PS_NBUF>(S.g, it, smem);
-                else dg_tile<2, true, PS_NBUF, 4>(S.g, it, smem);
-                // the next item (or the next stage) restages the ring and rewrites the row statistics: every wave must be done with them
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-            }
-        }
-        if (trace && blockIdx.x == 0 && tid == 0) trace[2 * s] = __builtin_amdgcn_s_memrealtime();
-        // (after the last stage too: it is what lets the NEXT launch read a settled generation word)
-        const bool ok = ps_grid_barrier(bar, gen0 + (unsigned long long)s + 1, err, tid);
-        if (tid == 0) s_ok = ok ? 1 : 0;
-        // diagnostic timeline (mmtg_decode_persist_trace): workgroup 0 stamps the wall clock when it leaves each barrier, and
-        // when its own work of the stage was done (row 2 s: work done, 2 s + 1: barrier passed; entry 2 * nstages: kernel entry)
-        if (trace && blockIdx.x == 0 && tid == 0) trace[2 * s + 1] = __builtin_amdgcn_s_memrealtime();
-        __syncthreads();
-        if (!s_ok) return;
-    }
-}
-
-// ---- chained launch: stages [first, first + count) of a stage list (products only) in ONE launch, one item per workgroup in
-// stage order (the dispatcher hands workgroups out in index order, so a stage's producers are resident before -- or exit before --
-// its consumers get their slots; a consumer that cannot make progress within DG_TIMEOUT_TICKS raises the error word and everybody
-// leaves: the host falls back to the per-launch step).  deps: count - 1 links of 128 words (64 row-block counters + 64 consumer
-// counts), zero between launches.  Per item the arithmetic is the stand-alone launch's (dg_tile), activations / statistics /
-// residual / partials through agent-scope accesses as in the persistent form: the ids are bit-equal to the per-launch step's.
-constexpr int chain_lds() { return 4 * 2 * 64 * 128 + 2 * 64 * 4 + 16; }
-__global__ __launch_bounds__(256, 2) void decode_chain_kernel(const PStage* __restrict__ stages, int first, int count, unsigned* deps, int* err,
-                                                              unsigned long long* __restrict__ trace) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const unsigned long long te = __builtin_amdgcn_s_memrealtime();
-    int it = blockIdx.x, j = 0;
-    while (j + 1 < count && it >= stages[first + j].nitems) { it -= stages[first + j].nitems; ++j; }
-    const PStage& S = stages[first + j];
-    DgDep dep;
-    dep.err = err;
-    dep.s_flag = reinterpret_cast<int*>(smem + chain_lds() - 16);
-    dep.wait = nullptr; dep.seen = nullptr; dep.expected = 0; dep.consumers = 0; dep.sleep0 = 0;
-    if (j > 0) {
-        const PStage& Pv = stages[first + j - 1];
-        dep.wait = deps + (long)(j - 1) * DG_DEP_LINK;
-        dep.seen = dep.wait + 64 * DG_DEP_STRIDE;
-#ifdef MMTG_CHAIN_SLEEP_X
-        dep.sleep0 = (unsigned)(MMTG_CHAIN_SLEEP_X * j * (j + 1) / 2);
-#else
-        dep.sleep0 = (unsigned)(j * (j + 1) / 2);          // 1, 3, 6, ... naps: a product takes at least ~4 us
-#endif
-        dep.expected = 4u * (unsigned)Pv.g.tiles_n * (Pv.kind == 2 ? 1u : (unsigned)Pv.g.splits);
-        dep.consumers = (unsigned)S.g.tiles_n * (unsigned)S.g.splits;
-    }
-    dep.done = j + 1 < count ? deps + (long)j * DG_DEP_LINK : nullptr;
-    dep.t_wait = 0;
-#ifdef MMTG_CHAIN_PLAIN_STORES          // timing experiment only (results undefined): ordinary write-back stores of the stage outputs
-    constexpr bool CST = false;
-#else
-    constexpr bool CST = true;
-#endif
-    if (S.kind == 0) dg_tile<0, CST, 4, 8, true, false>(S.g, it, smem, &dep);
-    else if (S.kind == 1) dg_tile<1, CST, 4, 8, true, false>(S.g, it, smem, &dep);
-    else dg_tile<2, CST, 4, 8, true, false>(S.g, it, smem, &dep);
-    // diagnostic timeline (mmtg_decode_persist_trace): per workgroup [stage, entry, wait passed, exit] (thread 0; a wave that
-    // returned early from a reduce item has no exit stamp of its own: thread 0's is the workgroup's first wave)
-    if (trace && threadIdx.x == 0) {
-        unsigned long long* r = trace + (long)blockIdx.x * 4;
-        r[0] = (unsigned long long)j; r[1] = te; r[2] = dep.t_wait ? dep.t_wait : te; r[3] = __builtin_amdgcn_s_memrealtime();
-    }
-}
 
 }  // namespace
 
@@ -1614,107 +1341,5 @@ extern "C" int mmtg_decode_embed_x3(const float* table, const long long* seq, lo
     hipLaunchKernelGGL(decode_embed_kernel<float>, dim3(B), dim3(256), 0, s, table, seq, ldseq, c, (float*)nullptr, pos_ptr, tpw_type, tpw_mask, type_out, keep,
                        ldkeep, P, S, E, two_sents, V, sent, max_sent_num, (bf16*)x_planes, plane);
     MMTG_LAUNCH_CHECK("decode_embed_x3");
-    return MMTG_OK;
-}
-
-// ------------------------------------------------------------------ persistent token step (round 4)
-// Stage descriptors are built on the HOST into a caller-owned byte buffer (mmtg_decode_stage_bytes() each) with the argument lists
-// of the launches they replace, uploaded once per decoder, and walked by decode_persist_kernel.
-extern "C" long mmtg_decode_stage_bytes(void) { return (long)sizeof(PStage); }
-
-extern "C" int mmtg_decode_stage_gemm(void* stages_host, int index, int mode, int M, int N, int K, const void* A, long lda, const void* W,
-                                      long ldw, void* C, long ldc, const float* bias, const float* colsum, const float* stats_in, int np_in,
-                                      float eps, int act, int out_f32, const void* resid, long ldr, float* stats_out, int splits, float* ws,
-                                      long ws_floats, unsigned* counters, long n_counters) {
-    MMTG_REQUIRE(stages_host && index >= 0, "decode_stage_gemm: null descriptor buffer");
-    PStage& st = reinterpret_cast<PStage*>(stages_host)[index];
-    memset(&st, 0, sizeof(st));
-    int rc = dg_fill(st.g, mode, M, N, K, A, lda, W, ldw, C, ldc, bias, colsum, stats_in, np_in, eps, act, out_f32, resid, ldr, stats_out, splits,
-                     ws, ws_floats, counters, n_counters, nullptr, nullptr, nullptr, nullptr);
-    if (rc) return rc;
-    const long bytesC = (mode == 1 ? (long)st.g.splits * M : (long)M) * ldc * (out_f32 ? 4 : 2);
-    const long bytesR = resid ? ((long)(M - 1) * ldr + N) * 2 : 0;
-    MMTG_REQUIRE(bytesC < 0x7FFFFF00L && bytesR < 0x7FFFFF00L && (long)M * DG_NP * 8 < 0x7FFFFF00L, "decode_stage_gemm: outputs must stay below 2 GiB");
-    st.g.bytesC = (int)bytesC; st.g.bytesR = (int)bytesR;
-    MMTG_REQUIRE(mode != 2 || st.g.splits <= 4, "decode_stage_gemm: at most 4 K splits per reduce stage in the persistent kernel");
-    st.kind = mode;
-    st.nitems = st.g.ntiles * st.g.splits;
-    return MMTG_OK;
-}
-
-extern "C" int mmtg_decode_stage_attn(void* stages_host, int index, const float* part, int splits, const float* bias, void* kcache,
-                                      void* vcache, const int* keep, long ldkeep, const int* pos_ptr, void* out, int B, int nH, int dh, int Tmax) {
-    MMTG_REQUIRE(stages_host && index >= 0, "decode_stage_attn: null descriptor buffer");
-    MMTG_REQUIRE(part && bias && kcache && vcache && keep && pos_ptr && out, "decode_stage_attn: null pointer");
-    MMTG_REQUIRE(dh == 64 && B > 0 && nH > 0 && Tmax > 0 && Tmax <= 1024 && splits >= 1 && splits <= 4,
-                 "decode_stage_attn: head dim 64, Tmax <= 1024, at most 4 c_attn slabs");
-    PStage& st = reinterpret_cast<PStage*>(stages_host)[index];
-    memset(&st, 0, sizeof(st));
-    st.kind = 3;
-    st.nitems = B * nH;
-    DaArgs& a = st.a;
-    a.part = part; a.bias = bias; a.kc = (bf16*)kcache; a.vc = (bf16*)vcache; a.keep = keep; a.pos_ptr = pos_ptr; a.out = (bf16*)out;
-    a.ldkeep = ldkeep; a.slab = (long)B * 3 * nH * 64; a.splits = splits; a.B = B; a.nH = nH; a.Tmax = Tmax;
-    MMTG_REQUIRE((long)splits * a.slab * 4 < 0x7FFFFF00L, "decode_stage_attn: slabs must stay below 2 GiB");
-    return MMTG_OK;
-}
-
-static unsigned long long* g_ps_trace = nullptr;
-extern "C" int mmtg_decode_persist_trace(void* buf) {      // u64 [2 * stages + 1] or null (diagnostic; tools/decode_persist_timeline.py)
-    g_ps_trace = (unsigned long long*)buf;
-    return MMTG_OK;
-}
-static int g_ps_wpc = 0;            // workgroups per CU of the build in use (set by mmtg_decode_persist_grid)
-extern "C" int mmtg_decode_persist_grid(void) {
-    static int grid = -1;
-    if (grid < 0) {
-        static const int env = getenv("MMTG_DECODE_PERSIST_WGS") ? atoi(getenv("MMTG_DECODE_PERSIST_WGS")) : 0;
-        const int want = env == 2 ? 2 : 3;
-        const void* fn = want == 3 ? (const void*)decode_persist_kernel<3> : (const void*)decode_persist_kernel<2>;
-        const int lds = want == 3 ? ps_lds<3>() : ps_lds<2>();
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return 0;
-        int per = 0, dev = 0;
-        hipDeviceProp_t prop;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, fn, 256, lds) != hipSuccess) return 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-        // (the API can report one block per CU more than the hardware admits near an SGPR edge, MI355X_MICROARCH.md: never plan on
-        //  more than the build was made for, and the bounded polls turn a wrong guess into an error, not a hang)
-        if (per > want) per = want;
-        if (per < 1) return 0;
-        g_ps_wpc = want;
-        grid = per * prop.multiProcessorCount;
-    }
-    return grid;
-}
-
-extern "C" int mmtg_decode_chain(const void* stages_dev, int first, int count, int nitems, unsigned* deps, long deps_words, int* err_flag, void* stream) {
-    MMTG_REQUIRE(stages_dev && deps && err_flag, "decode_chain: null pointer");
-    MMTG_REQUIRE(first >= 0 && count >= 1 && count <= 8 && nitems > 0, "decode_chain: 1-8 stages, a positive item count");
-    MMTG_REQUIRE(deps_words >= (long)DG_DEP_LINK * (count - 1), "decode_chain: the dependency words are %d per link (zero-initialised)", DG_DEP_LINK);
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)decode_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, chain_lds()) != hipSuccess)
-            MMTG_FAIL(MMTG_ERR_HIP, "decode_chain: cannot raise dynamic LDS to %d bytes", chain_lds());
-        attr_done = true;
-    }
-    hipStream_t s = (hipStream_t)stream;
-    ProfScope prof(MMTG_PROF_GEMM_BF16, s, 0.0, 0.0);
-    hipLaunchKernelGGL(decode_chain_kernel, dim3(nitems), dim3(256), chain_lds(), s, (const PStage*)stages_dev, first, count, deps, err_flag, g_ps_trace);
-    MMTG_LAUNCH_CHECK("decode_chain");
-    return MMTG_OK;
-}
-
-extern "C" int mmtg_decode_persist(const void* stages_dev, int nstages, void* barrier_ws, long barrier_bytes, int* err_flag, void* stream) {
-    MMTG_REQUIRE(stages_dev && nstages > 0 && barrier_ws && err_flag, "decode_persist: null pointer");
-    MMTG_REQUIRE(barrier_bytes >= 4096 && MMTG_ALIGNED16(barrier_ws), "decode_persist: the barrier workspace is 4096 zero-initialised bytes");
-    const int grid = mmtg_decode_persist_grid();
-    MMTG_REQUIRE(grid >= 8, "decode_persist: the persistent kernel does not fit this device");
-    hipStream_t s = (hipStream_t)stream;
-    ProfScope prof(MMTG_PROF_DECODE, s, 0.0, 0.0);
-    if (g_ps_wpc == 3)
-        hipLaunchKernelGGL(decode_persist_kernel<3>, dim3(grid), dim3(256), ps_lds<3>(), s, (const PStage*)stages_dev, nstages, (unsigned long long*)barrier_ws, err_flag, g_ps_trace);
-    else
-        hipLaunchKernelGGL(decode_persist_kernel<2>, dim3(grid), dim3(256), ps_lds<2>(), s, (const PStage*)stages_dev, nstages, (unsigned long long*)barrier_ws, err_flag, g_ps_trace);
-    MMTG_LAUNCH_CHECK("decode_persist");
     return MMTG_OK;
 }

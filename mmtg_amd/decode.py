@@ -141,36 +141,6 @@ class GreedyDecoder:
                 self.folds_for = None
                 # (MMTG_DECODE_EMBED_IN_PROJ=0: projector_layer2 and the embedding add as two launches, the round-3 v8 step)
                 self.embed_in_proj = os.environ.get("MMTG_DECODE_EMBED_IN_PROJ", "1") != "0" and H % 8 == 0
-                # Round 4, persistent token step (OPT-IN, MMTG_DECODE_PERSIST=1): the twelve blocks and the head as ONE launch
-                # (mmtg_decode_persist) instead of 61 -- stage lists built once per (head / no head, position slot), a device-wide
-                # barrier between stages, agent-scope hand-offs.  Bit-equal to the per-launch fused step (tests/test_decode_gpu.py)
-                # and measured SLOWER: 873 (2 workgroups per CU) / 921 us (3) against 720 us per token step at batch 256 -- a barrier
-                # is 2.2-3 us against the ~4 us of a launch boundary, but every stage still pays its dependent memory round trips
-                # (activations now from beyond the L2: agent-scope loads), and the attention stage loses its 32-waves-per-CU
-                # memory-level parallelism (profiles/r04_v2_decode_persistent_*).  The default stays the per-launch step.
-                # (not for lanes: several persistent kernels side by side cannot all be resident)
-                self.persist = (_parent is None and os.environ.get("MMTG_DECODE_PERSIST", "0") == "1" and max(self.splits[1], self.splits[3]) <= 4
-                                and self.splits[0] <= 4 and hip.decode_persist_grid() >= 8)
-                if self.persist:
-                    self.bar = torch.zeros(512, dtype=torch.int64, device=dev)          # 4096 bytes, owned by the kernel from here on
-                    self.err = torch.zeros(1, dtype=torch.int32, device=dev)
-                    self.stage_lists = {}
-                # Round 4, chained launches (OPT-IN, MMTG_DECODE_CHAIN=1): per block attn.c_proj -> mlp.c_fc -> mlp.c_proj as ONE launch
-                # (mmtg_decode_chain) -- an item of a later product starts when the 64-row block it reads is complete (a counter per
-                # row block) instead of behind a kernel boundary: 41 launches per token step instead of 65, bit-equal ids (the
-                # arithmetic per item is the stand-alone launch's).  Measured SLOWER: a chain takes 38-42 us against 26 us for its
-                # three launches (1172 us per token step against 683 before the polls were throttled) -- hand-offs between XCDs go
-                # through memory (write-through stores, their acknowledgement, an atomic, a poll past the L2, cold first tiles), which
-                # costs each stage more than the ~4 us kernel boundary it replaces (the per-workgroup timeline:
-                # tools/decode_chain_timeline.py).  A wait that ran into its time bound raises the error word; ``generate`` then
-                # repeats the generation with the per-launch step.
-                # (not for lanes: an opt-in mode whose side-by-side kernels were never measured with it)
-                self.chain = (not self.persist and _parent is None and self.lanes == 1 and os.environ.get("MMTG_DECODE_CHAIN", "0") == "1"
-                              and max(self.splits[1], self.splits[3]) <= 4 and B <= 64 * 64)
-                if self.chain:
-                    self.deps = torch.zeros(4096 * 7, dtype=torch.int32, device=dev)
-                    self.err = torch.zeros(1, dtype=torch.int32, device=dev)
-                    self.chain_lists = {}
         self.pos, self.pos_next = self.pos_pair
         self.uniforms = None
         self.graphs = {}
@@ -390,121 +360,21 @@ class GreedyDecoder:
         wf, c, b = self.fh
         hip.ln_fold_weights(eng.Wp("wte"), eng.P(pre + "ln_f.weight"), eng.P(pre + "ln_f.bias"), None, wf, c, b, eng.layout.Vpad, D)
 
-    def _stage_list(self, hcur, hnext, with_head):
-        """The launches of _layers_fused as a stage list of the persistent kernel (same operands, same order)."""
-        eng, sh, B = self.eng, self.eng.sh, self.B
-        D = sh.D
-        pre = "decoder.gpt2.transformer."
-        sq, sp, _, s2 = self.splits
-        NP = D // 32
-        kper = -(-(-(-D // sq)) // 64) * 64
-        nslab = -(-D // kper)
-        x, xo = hcur, hnext
-        st, sto = self.st
-        sl = hip.DecodeStages(5 * sh.L + 1)
-        for l in range(sh.L):
-            p = f"{pre}h.{l}."
-            wf, c, bq = self.fq[l]
-            sl.gemm(1, x, wf, self.part, B, 3 * D, D, colsum=c, stats_in=st, np_in=NP, eps=sh.eps, out_f32=True, splits=sq)
-            sl.attn(self.part, nslab, bq, self.kc[l], self.vc[l], self.keep, self.pos, self.ctx, B, sh.nH, 64, self.Tmax)
-            sl.gemm(2, self.ctx, eng.Wt(p + "attn.c_proj.weight"), xo, B, D, D, bias=eng.P(p + "attn.c_proj.bias"), resid=x,
-                    stats_out=sto, splits=sp, ws=self.rws, counters=self.rcnt)
-            wf, c, bfc = self.ffc[l]
-            sl.gemm(0, xo, wf, self.g, B, 4 * D, D, bias=bfc, colsum=c, stats_in=sto, np_in=NP, eps=sh.eps, act=hip.EPI_GELU)
-            sl.gemm(2, self.g, eng.Wt(p + "mlp.c_proj.weight"), x, B, D, 4 * D, bias=eng.P(p + "mlp.c_proj.bias"), resid=xo,
-                    stats_out=st, splits=s2, ws=self.rws, counters=self.rcnt)
-        if with_head:
-            wf, c, bh = self.fh
-            sl.gemm(0, x, wf, self.logits, B, eng.layout.Vpad, D, bias=bh, colsum=c, stats_in=st, np_in=NP, eps=sh.eps, out_f32=True)
-        return sl.upload(eng.dev)
-
-    def _chain_list(self, hcur, hnext, with_head):
-        """attn.c_proj, mlp.c_fc and mlp.c_proj of every block as one stage list; chains[l] = (first stage, stages, work items) of
-        block l's chained launch."""
-        eng, sh, B = self.eng, self.eng.sh, self.B
-        D = sh.D
-        pre = "decoder.gpt2.transformer."
-        sq, sp, _, s2 = self.splits
-        NP = D // 32
-        x, xo = hcur, hnext
-        st, sto = self.st
-        sl = hip.DecodeStages(3 * sh.L)
-        chains = []
-        for l in range(sh.L):
-            p = f"{pre}h.{l}."
-            first = sl.n
-            sl.gemm(2, self.ctx, eng.Wt(p + "attn.c_proj.weight"), xo, B, D, D, bias=eng.P(p + "attn.c_proj.bias"), resid=x,
-                    stats_out=sto, splits=sp, ws=self.rws, counters=self.rcnt)
-            wf, c, bfc = self.ffc[l]
-            sl.gemm(0, xo, wf, self.g, B, 4 * D, D, bias=bfc, colsum=c, stats_in=sto, np_in=NP, eps=sh.eps, act=hip.EPI_GELU)
-            sl.gemm(2, self.g, eng.Wt(p + "mlp.c_proj.weight"), x, B, D, 4 * D, bias=eng.P(p + "mlp.c_proj.bias"), resid=xo,
-                    stats_out=st, splits=s2, ws=self.rws, counters=self.rcnt)
-            # (the next block's c_attn / the head stay launches of their own: they read the residual stream that this chain's first
-            #  stage read as its residual BEFORE the third rewrote it -- a consumer's L2 could still hold the old line, and reading it
-            #  past the L2 costs the product more than the launch boundary: measured 1267 vs 683 us per token step)
-            chains.append((first, sl.n - first, sum(sl.items[first:sl.n])))
-        sl.upload(eng.dev)
-        return sl, chains
-
-    def check_chain(self):
-        """True if a wait of a chained launch ran into its time bound since the last check (the outputs are then undefined);
-        re-arms the words and turns the chained launches off for this decoder."""
-        if getattr(self, "chain", False) and int(self.err.item()) != 0:
-            self.deps.zero_()
-            self.err.zero_()
-            self.rcnt.zero_()
-            self.chain = False
-            self.graphs = {}
-            return True
-        return False
-
-    def check_persist(self):
-        """Raises if a barrier of the persistent kernel ran into its time bound (not every workgroup was resident): the step's
-        outputs are then undefined.  Re-arms the decoder (one host read; ``generate`` calls it once per generation)."""
-        if getattr(self, "persist", False) and int(self.err.item()) != 0:
-            self.bar.zero_()
-            self.err.zero_()
-            raise RuntimeError("persistent decode step: a device-wide barrier timed out (workgroups not co-resident); "
-                               "set MMTG_DECODE_PERSIST=0 or MMTG_DECODE_PERSIST_WGS=2")
-
     def _layers_fused(self, hcur, hnext, with_head):
         """bf16 fused path: per block c_attn (LN-fold, split-K slabs summed by the attention kernel) -> attention -> attn c_proj
         (split-K reduced in the kernel + bias + residual + statistics) -> c_fc (LN-fold + GELU) -> mlp c_proj (as c_proj); the
         head is an LN-fold product writing fp32 logits.  The residual stream alternates between two buffers and so do its
-        LayerNorm statistics."""
+        LayerNorm statistics.  (Round 4's persistent one-launch step and chained launches -- bit-equal, measured slower -- are kept as
+        tools/experiments/decode_persistent_and_chained.patch.)"""
         eng, sh, B = self.eng, self.eng.sh, self.B
         D = sh.D
         pre = "decoder.gpt2.transformer."
-        if getattr(self, "persist", False):
-            key = (with_head, self.pos.data_ptr())
-            sl = self.stage_lists.get(key)
-            if sl is None:
-                sl = self.stage_lists[key] = self._stage_list(hcur, hnext, with_head)
-            hip.decode_persist(sl, self.bar, self.err)
-            return
         sq, sp, _, s2 = self.splits
         NP = D // 32
         kper = -(-(-(-D // sq)) // 64) * 64          # K slices are whole 64-deep tiles: the product writes ceil(D / kper) slabs
         nslab = -(-D // kper)
         x, xo = hcur, hnext
         st, sto = self.st
-        if getattr(self, "chain", False):
-            cl = self.chain_lists.get(with_head)
-            if cl is None:
-                cl = self.chain_lists[with_head] = self._chain_list(hcur, hnext, with_head)
-            sl, chains = cl
-            for l in range(sh.L):
-                wf, c, bq = self.fq[l]
-                hip.decode_gemm(1, x, wf, self.part, B, 3 * D, D, colsum=c, stats_in=st, np_in=NP, eps=sh.eps, out_f32=True, splits=sq)
-                hip.decode_attn_split(self.part, nslab, bq, self.kc[l], self.vc[l], self.keep, self.pos,
-                                      self.ctx, B, sh.nH, 64, self.Tmax)
-                first, count, nitems = chains[l]
-                hip.decode_chain(sl, first, count, nitems, self.deps, self.err)
-            if with_head:
-                wf, c, bh = self.fh
-                hip.decode_gemm(0, x, wf, self.logits, B, eng.layout.Vpad, D, bias=bh, colsum=c, stats_in=st, np_in=NP, eps=sh.eps,
-                                out_f32=True)
-            return
         for l in range(sh.L):
             p = f"{pre}h.{l}."
             wf, c, bq = self.fq[l]
@@ -551,13 +421,6 @@ class GreedyDecoder:
             return ("decode token step (bf16x3): decode_gemm_x3_kernel<64x64> weight streaming over (hi | lo) plane pairs, three bf16 matrix-core "
                     "passes per product (split-K reduced in the kernel, LayerNorm applied algebraically, fp32 residual stream) + decode_attn "
                     "streaming an fp32 KV cache, 5 graph nodes per block")
-        if getattr(self, "persist", False):
-            return ("decode token step: decode_persist_kernel -- the twelve blocks and the head as one persistent launch (64x64 weight-"
-                    "streaming tiles + KV-cache streaming, 61 stages behind a two-level device-wide barrier, agent-scope hand-offs)")
-        if getattr(self, "chain", False):
-            return ("decode token step: decode_gemm_kernel<64x64> (c_attn, head) + decode_chain_kernel (per block attn.c_proj -> c_fc -> "
-                    "mlp.c_proj as one launch of 64x64 weight-streaming tiles, row-block counters instead of kernel boundaries; split-K "
-                    "reduced in the kernel, LayerNorm applied algebraically) + decode_attn KV-cache streaming (one pass), 3 graph nodes per block")
         if getattr(self, "fused", False):
             return ("decode token step: decode_gemm_kernel<64x64> weight streaming (split-K reduced in the kernel, LayerNorm applied "
                     "algebraically) + decode_attn KV-cache streaming, 5 graph nodes per block")
@@ -621,9 +484,7 @@ class GreedyDecoder:
         from `generator` (a CUDA torch.Generator; default: the global one) before the steps are replayed.
         Parity hooks (tests/test_decode_gpu.py): `teacher` [B, 1 + length] long -- after every step the token the step
         appended is replaced by teacher[:, j] wherever that is >= 0 (teacher forcing on a reference id list; the step's own
-        pick is handed to `tap` first); `tap(j, with_head, picked [B], logits [B, Vpad] or None)` is called after every step
-        (`tap(None, False, None, None)` = restart: an opt-in chained launch gave up and the generation is being repeated)."""
-        gen_state = generator.get_state() if generator is not None else None     # (a chained launch that gives up repeats the generation)
+        pick is handed to `tap` first); `tap(j, with_head, picked [B], logits [B, Vpad] or None)` is called after every step."""
         n_steps = self.begin(batch, length, temperature, repitition_penalty, top_k, top_p, generator)
         eng, sh = self.eng, self.eng.sh
         saved_mode = self.use_graph
@@ -640,17 +501,6 @@ class GreedyDecoder:
                     self.seq[:, pos + 1] = torch.where(col >= 0, col, self.seq[:, pos + 1])
         finally:
             self.use_graph = saved_mode
-        for d in ([self] + self.children):
-            d.check_persist()
-        if any(d.check_chain() for d in ([self] + self.children)):
-            # a chained launch gave up (its producers were not resident in time): the outputs are undefined -- the generation is
-            # repeated with the per-launch step, which this decoder keeps from here on; the generator is rewound so the repeat draws
-            # the SAME uniforms (a seeded run stays reproducible) and `tap` is told that everything it saw so far is void
-            if gen_state is not None:
-                generator.set_state(gen_state)
-            if tap is not None:
-                tap(None, False, None, None)
-            return self.generate(batch, length, temperature, repitition_penalty, top_k, top_p, generator, use_graph, teacher, tap)
         return self.seq[:, sh.P:sh.P + 1 + length].clone()
 
     @staticmethod

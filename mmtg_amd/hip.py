@@ -95,13 +95,6 @@ _SIGS = {
     "mmtg_ln_fold_weights_x3": ([_vp, _l, _l, _vp, _vp, _vp, _vp, _l, _l, _vp, _vp, _i, _i, _vp], _i),
     "mmtg_decode_attn_split_x3": ([_vp, _i, _vp, _vp, _vp, _vp, _l, _vp, _vp, _l, _i, _i, _i, _i, _vp], _i),
     "mmtg_decode_embed_x3": ([_vp, _vp, _l, _vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
-    "mmtg_decode_stage_bytes": ([], _l),
-    "mmtg_decode_stage_gemm": ([_vp, _i, _i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _vp, _vp, _vp, _i, _f, _i, _i, _vp, _l, _vp, _i, _vp, _l, _vp, _l], _i),
-    "mmtg_decode_stage_attn": ([_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _l, _vp, _vp, _i, _i, _i, _i], _i),
-    "mmtg_decode_persist_grid": ([], _i),
-    "mmtg_decode_persist_trace": ([_vp], _i),
-    "mmtg_decode_persist": ([_vp, _i, _vp, _l, _vp, _vp], _i),
-    "mmtg_decode_chain": ([_vp, _i, _i, _i, _vp, _l, _vp, _vp], _i),
     "mmtg_decode_attn": ([_i, _vp, _vp, _vp, _vp, _l, _vp, _vp, _i, _i, _i, _i, _vp], _i),
     "mmtg_decode_attn_split": ([_i, _vp, _i, _vp, _vp, _vp, _vp, _l, _vp, _vp, _i, _i, _i, _i, _vp], _i),
     "mmtg_logits_process_sample": ([_vp, _l, _i, _vp, _l, _vp, _f, _f, _i, _f, _vp, _vp, _vp, _i, _vp], _i),
@@ -655,64 +648,6 @@ def decode_embed_x3(table, seq, c, x, pos, tpw_type, tpw_mask, type_out, keep, B
     _check(lib().mmtg_decode_embed_x3(_p(table), _p(seq), seq.stride(0), _p(c), _p(x.t), x.plane, _p(pos), _p(tpw_type), _p(tpw_mask),
                                       _p(type_out), _p(keep), keep.stride(0), B, P, S, E, two_sents, V, sent, max_sent_num, _stream()),
            "decode_embed_x3")
-
-
-class DecodeStages:
-    """Host-side stage list of the persistent token step (include/mmtg_hip.h, mmtg_decode_persist): append the stages with the
-    argument lists of the launches they replace, then ``upload(device)`` once."""
-
-    def __init__(self, capacity):
-        self.nbytes = int(lib().mmtg_decode_stage_bytes())
-        self.buf = C.create_string_buffer(self.nbytes * capacity)
-        self.capacity, self.n = capacity, 0
-        self.items = []         # work items (64 x 64 tiles x K slices) per product stage, 0 for attention stages
-        self.keep = []          # the tensors whose addresses the descriptors hold stay alive with the list
-
-    def gemm(self, mode, A, W, C_, M, N, K, bias=None, colsum=None, stats_in=None, np_in=0, eps=1e-5, act=EPI_NONE, out_f32=False,
-             resid=None, stats_out=None, splits=1, ws=None, counters=None, ldc=None):
-        assert self.n < self.capacity
-        _check(lib().mmtg_decode_stage_gemm(C.addressof(self.buf), self.n, int(mode), M, N, K, _p(A), K, _p(W), K, _p(C_),
-                                            N if ldc is None else ldc, _p(bias), _p(colsum), _p(stats_in), int(np_in), float(eps), int(act),
-                                            int(out_f32), _p(resid), N, _p(stats_out), int(splits), _p(ws), 0 if ws is None else ws.numel(),
-                                            _p(counters), 0 if counters is None else counters.numel()), "decode_stage_gemm")
-        self.keep += [A, W, C_, bias, colsum, stats_in, resid, stats_out, ws, counters]
-        kper = -(-(-(-K // int(splits))) // 64) * 64          # (as mmtg_decode_stage_gemm: K slices are whole 64-deep tiles)
-        self.items.append(-(-M // 64) * -(-N // 64) * -(-K // kper))
-        self.n += 1
-
-    def attn(self, part, splits, bias, kcache, vcache, keep, pos, out, B, nH, dh, Tmax):
-        assert self.n < self.capacity
-        _check(lib().mmtg_decode_stage_attn(C.addressof(self.buf), self.n, _p(part), int(splits), _p(bias), _p(kcache), _p(vcache), _p(keep),
-                                            keep.stride(0), _p(pos), _p(out), B, nH, dh, Tmax), "decode_stage_attn")
-        self.keep += [part, bias, kcache, vcache, keep, pos, out]
-        self.items.append(0)
-        self.n += 1
-
-    def upload(self, device):
-        import numpy as np
-        host = np.frombuffer(self.buf, dtype=np.uint8, count=self.nbytes * self.n).copy()
-        self.dev = torch.from_numpy(host).to(device)
-        return self
-
-
-def decode_persist_grid():
-    return int(lib().mmtg_decode_persist_grid())
-
-
-def decode_persist_trace(buf=None):
-    _check(lib().mmtg_decode_persist_trace(_p(buf)), "decode_persist_trace")
-
-
-def decode_persist(stages, barrier_ws, err_flag):
-    """One launch for all the stages of a DecodeStages list (uploaded)."""
-    _check(lib().mmtg_decode_persist(_p(stages.dev), stages.n, _p(barrier_ws), barrier_ws.numel() * barrier_ws.element_size(), _p(err_flag),
-                                     _stream()), "decode_persist")
-
-
-def decode_chain(stages, first, count, nitems, deps, err_flag):
-    """Stages [first, first + count) of an uploaded DecodeStages list (products only) as one chained launch."""
-    _check(lib().mmtg_decode_chain(_p(stages.dev), int(first), int(count), int(nitems), _p(deps), deps.numel(), _p(err_flag), _stream()),
-           "decode_chain")
 
 
 def ln_fold_weights(W, gamma, beta, bias, Wf, colsum, bias_f, N, K, ldw=None):

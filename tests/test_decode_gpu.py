@@ -166,12 +166,13 @@ def test_checkpoint_resume_continues_the_run(tmp_path, enc):
         t2.load_state_dict(bad)
 
 
-def test_batched_sampling_decode_rules_and_greedy_limit():
+@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
+def test_batched_sampling_decode_rules_and_greedy_limit(mode):
     """Device-side sampling in the KV-cached decoder (top_k = 30 as in generate.sh): forced [#START#]/[#EOS#]
     cadence, no banned id, sticky PAD, rows differ from each other and between seeds, the same CUDA generator
     seed reproduces the ids; top_k = 1 reduces to the greedy decoder bit for bit."""
     fx, meta, mcfg, gcfg, dcfg, weights, table, batch = load_case("tiny_s5")
-    model = MMTG(mcfg, dcfg, meta["V"], train_flag=False, gpt2_config=gcfg, token_table=table, compute_dtype="f32")
+    model = MMTG(mcfg, dcfg, meta["V"], train_flag=False, gpt2_config=gcfg, token_table=table, compute_dtype=mode)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})
     model.to("cuda").eval()
     tb = batch_to_torch(batch, "cuda")
@@ -472,97 +473,3 @@ def test_bf16_fused_decoder_teacher_forced_on_the_reference_ids(case, bound, mod
     assert ok >= 0.6 * n
     if mode == "bf16x3":
         assert ok == n, (ok, n, first_div)
-
-
-@pytest.mark.parametrize("size", ["tiny", "full"])
-def test_persistent_decode_step_is_bit_equal_to_the_per_launch_step(size, monkeypatch):
-    """Round 4: the twelve blocks + head of a token step as ONE persistent launch (mmtg_decode_persist: stage list, device-wide
-    barrier, agent-scope hand-offs) against the per-launch fused step (MMTG_DECODE_PERSIST=0) on the same model and prompts: the
-    arithmetic per tile is the same code in the same order, so the fp32 logits of the first model call AND every generated id are
-    bit-equal -- tiny 2-layer model at batch 3 and the full 12-layer model at batch 256 (BASELINE configs[3]); the barrier's error
-    word stays clear; graph replay and eager launches agree; two generations in a row agree (the barrier counters carry over).
-    (The persistent step is opt-in -- it measured slower than the per-launch step -- so the test switches it on.)"""
-    if size == "tiny":
-        fx, batch, model = build("bf16")
-        tb = {k: v for k, v in batch_to_torch(batch, DEV).items() if k not in ("rating", "targets")}
-        B, Ln = 3, 90
-    else:
-        from mmtg_amd import synth
-        from mmtg_amd.configs import data_config, gpt2_config, make_model_cfgs
-        S, V, B, Ln = 5, 13317, 256, 48
-        mcfg, dcfg = make_model_cfgs(seq_len=S), data_config(seq_len=S)
-        model = MMTG(mcfg, dcfg, V, gpt2_config=gpt2_config(n_layer=12, vocab_size=V), compute_dtype="bf16",
-                     token_table=synth.make_token_table(V, seed=2))
-        model.reset_parameters(seed=0)
-        model.to(DEV).eval()
-        nb = synth.make_batch(B, mcfg, dcfg, V, seed=7)
-        tb = {k: torch.from_numpy(np.asarray(v)).to(DEV) for k, v in nb.items() if k not in ("rating", "targets")}
-    outs = {}
-    for persist in ("1", "0"):
-        monkeypatch.setenv("MMTG_DECODE_PERSIST", persist)
-        dec = GreedyDecoder(model, max_batch=B, max_len=Ln)
-        assert dec.fused and getattr(dec, "persist", False) == (persist == "1")
-        first = []
-
-        def tap(j, with_head, picked, logits, first=first):
-            if with_head and not first:
-                first.append(logits.float().cpu().clone())
-
-        ids = dec.generate(tb, Ln, temperature=1.1, repitition_penalty=1.5, tap=tap)
-        ids2 = dec.generate(tb, Ln, temperature=1.1, repitition_penalty=1.5)
-        eager = dec.generate(tb, Ln, temperature=1.1, repitition_penalty=1.5, use_graph=False)
-        assert torch.equal(ids, ids2) and torch.equal(ids, eager)
-        if persist == "1":
-            assert int(dec.err.item()) == 0
-        outs[persist] = (ids.cpu(), first[0])
-        del dec
-    assert torch.equal(outs["1"][1], outs["0"][1]), float((outs["1"][1] - outs["0"][1]).abs().max())
-    assert torch.equal(outs["1"][0], outs["0"][0])
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("size", ["tiny", "full"])
-def test_chained_decode_launches_are_bit_equal_to_the_per_launch_step(size, monkeypatch):
-    """Round 4: attn.c_proj -> c_fc -> mlp.c_proj of every block as ONE chained launch (mmtg_decode_chain: a later product's item
-    starts when the row block it reads is complete -- a counter per row block -- instead of behind a kernel boundary) against the
-    per-launch fused step on the same model and prompts: same code per tile in the same order, so the fp32 logits of the first
-    model call AND every generated id are bit-equal -- tiny 2-layer model at batch 3 and the full 12-layer model at batch 256;
-    the error word stays clear and the chained launches stay on (no fallback); graph replay and eager launches agree; two
-    generations in a row agree (the counters are re-armed by their last consumer).  (Opt-in: it measured slower.)"""
-    if size == "tiny":
-        fx, batch, model = build("bf16")
-        tb = {k: v for k, v in batch_to_torch(batch, DEV).items() if k not in ("rating", "targets")}
-        B, Ln = 3, 90
-    else:
-        from mmtg_amd import synth
-        from mmtg_amd.configs import data_config, gpt2_config, make_model_cfgs
-        S, V, B, Ln = 5, 13317, 256, 48
-        mcfg, dcfg = make_model_cfgs(seq_len=S), data_config(seq_len=S)
-        model = MMTG(mcfg, dcfg, V, gpt2_config=gpt2_config(n_layer=12, vocab_size=V), compute_dtype="bf16",
-                     token_table=synth.make_token_table(V, seed=2))
-        model.reset_parameters(seed=0)
-        model.to(DEV).eval()
-        nb = synth.make_batch(B, mcfg, dcfg, V, seed=7)
-        tb = {k: torch.from_numpy(np.asarray(v)).to(DEV) for k, v in nb.items() if k not in ("rating", "targets")}
-    outs = {}
-    monkeypatch.setenv("MMTG_DECODE_PERSIST", "0")
-    for chain in ("1", "0"):
-        monkeypatch.setenv("MMTG_DECODE_CHAIN", chain)
-        dec = GreedyDecoder(model, max_batch=B, max_len=Ln)
-        assert dec.fused and getattr(dec, "chain", False) == (chain == "1")
-        first = []
-
-        def tap(j, with_head, picked, logits, first=first):
-            if with_head and not first:
-                first.append(logits.float().cpu().clone())
-
-        ids = dec.generate(tb, Ln, temperature=1.1, repitition_penalty=1.5, tap=tap)
-        ids2 = dec.generate(tb, Ln, temperature=1.1, repitition_penalty=1.5)
-        eager = dec.generate(tb, Ln, temperature=1.1, repitition_penalty=1.5, use_graph=False)
-        assert torch.equal(ids, ids2) and torch.equal(ids, eager)
-        if chain == "1":
-            assert dec.chain and int(dec.err.item()) == 0 and int(dec.deps.abs().sum().item()) == 0
-        outs[chain] = (ids.cpu(), first[0])
-        del dec
-    assert torch.equal(outs["1"][1], outs["0"][1]), float((outs["1"][1] - outs["0"][1]).abs().max())
-    assert torch.equal(outs["1"][0], outs["0"][0])
-

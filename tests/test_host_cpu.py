@@ -195,33 +195,17 @@ def test_c_abi_exports_every_declared_symbol():
 
 
 def test_host_side_of_the_round4_abi_without_a_gpu():
-    """The parts of ABI 6 that are host arithmetic run without a GPU: workspace sizes of the ordered reductions, and the stage list
-    of the persistent decode step -- descriptors are built on the HOST with the argument checks of the launches they replace (no
-    device call), so a bad stage is rejected with the library's error message, a good one is counted."""
+    """The parts of the ABI that are host arithmetic run without a GPU: workspace sizes of the ordered reductions, the build-flag
+    string, and argument validation (a bad call is rejected with the library's error message before any device call)."""
     L = hip.lib()
     assert L.mmtg_colsum_ws(236, 3072) == 0 and L.mmtg_colsum_ws(15104, 512) == 128 * 512          # tall inputs go through 128 row slices
     assert L.mmtg_embed_add_bwd_ws(15104, 768, 11) == 118 * 11 * 768
     assert L.mmtg_beta_fuse_bwd_ws(64, 5, 512) == 64 * 5 * 513
     assert 0 < L.mmtg_sumsq_ws(109064709) <= 4096
-    nbytes = L.mmtg_decode_stage_bytes()
-    assert nbytes > 0 and nbytes % 8 == 0
-    buf = ctypes.create_string_buffer(nbytes * 2)
-    fake = 0x7000000000      # 16-byte aligned stand-ins for device pointers: descriptors only record them
-    M, N, K = 256, 768, 768
-    ok = L.mmtg_decode_stage_gemm(ctypes.addressof(buf), 0, 2, M, N, K, fake, K, fake, K, fake, N, fake, 0, 0, 0, 1e-5, 0, 0, fake, N, fake, 4,
-                                  fake, 4 * 48 * 4 * 4096, fake, 4 * 48)
-    assert ok == 0, L.mmtg_last_error()
-    kind, nitems = np.frombuffer(buf, dtype=np.int32, count=2)
-    assert (int(kind), int(nitems)) == (2, 4 * 12 * 4)                   # reduce mode, 4 row tiles x 12 column tiles x 4 K splits
-    # more than four K splits per reduce stage do not fit the persistent kernel's register budget: rejected on the host
-    bad = L.mmtg_decode_stage_gemm(ctypes.addressof(buf), 1, 2, M, N, 3072, fake, 3072, fake, 3072, fake, N, fake, 0, 0, 0, 1e-5, 0, 0, fake, N, fake, 8,
-                                   fake, 8 * 48 * 4 * 4096, fake, 4 * 48)
-    assert bad != 0 and b"at most 4 K splits" in L.mmtg_last_error()
-    bad = L.mmtg_decode_stage_attn(ctypes.addressof(buf), 1, fake, 5, fake, fake, fake, fake, 144, fake, fake, 256, 12, 64, 144)
-    assert bad != 0 and b"at most 4 c_attn slabs" in L.mmtg_last_error()
-    assert L.mmtg_decode_stage_attn(ctypes.addressof(buf), 1, fake, 2, fake, fake, fake, fake, 144, fake, fake, 256, 12, 64, 144) == 0
-    kind, nitems = np.frombuffer(buf, dtype=np.int32, count=2, offset=nbytes)
-    assert (int(kind), int(nitems)) == (3, 256 * 12)
+    # the error contract without a GPU: argument checks run on the host before any launch
+    assert L.mmtg_build_flags() == b""                                    # the product build carries no diagnostic defines
+    bad = L.mmtg_split_planes(0x7000000000, 8, 4, 12, 0x7100000000, 16, 64, None)
+    assert bad != 0 and b"split_planes" in L.mmtg_last_error()           # cols % 8 != 0
 
 
 def test_product_never_imports_the_oracle():
@@ -394,3 +378,25 @@ def test_grouped_weight_gradient_split_rule_and_workspace_sizes():
     t8, ws8, c8 = hip.wgrad_group_sizes(base, 2, 1)
     assert (t8, ws8, c8) == (108, 108 * 2 * 65536, 108 * 8)
     assert _group_splits(t8, 15104, 256) == 2
+
+
+def test_split_precision_mode_host_contract():
+    """bf16x3 = fp32 storage + split-precision products: the mode string maps to the fp32 storage code with the x3 flag, plane pairs
+    address (hi | lo) views of one allocation, and the engine refuses the flag on bf16 storage (no GPU needed)."""
+    from mmtg_amd import MMTG, hip, synth
+    from mmtg_amd.configs import data_config
+    mcfg, dcfg = make_model_cfgs(seq_len=2), data_config(seq_len=2)
+    gcfg = gpt2_config(n_layer=2, vocab_size=160, n_positions=128)
+    m = MMTG(mcfg, dcfg, 160, gpt2_config=gcfg, token_table=synth.make_token_table(160, seed=1), compute_dtype="bf16x3")
+    assert m.compute_dtype == hip.F32 and m.x3
+    assert not MMTG(mcfg, dcfg, 160, gpt2_config=gcfg, token_table=synth.make_token_table(160, seed=1), compute_dtype="f32").x3
+    with pytest.raises(KeyError):
+        MMTG(mcfg, dcfg, 160, gpt2_config=gcfg, token_table=synth.make_token_table(160, seed=1), compute_dtype="bf16x2")
+    with pytest.raises(RuntimeError):
+        m.engine()                       # the hot path is HIP-only: no CPU engine in any mode
+    t = torch.arange(2 * 3 * 8, dtype=torch.float32).bfloat16().view(2, 3, 8)
+    p = hip.Planes(t, 3, 8)
+    assert (p.ld, p.plane) == (8, 24)
+    assert torch.equal(p.float(), t[0].float() + t[1].float())
+    sub = hip.Planes(t[0, :, 4:], 3, 4, ld=8, plane=24)        # a column block of both planes
+    assert sub.t.data_ptr() == t.data_ptr() + 8 and sub.plane == 24
