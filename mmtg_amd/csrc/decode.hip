@@ -423,10 +423,14 @@ struct DgArgs {
 //  tools/experiments/decode_persistent_and_chained.patch.)
 // X3 (round 5): the split-precision form -- operands as (hi | lo) plane pairs, the K slice walked three times (A hi x W hi, A lo x W hi,
 // A hi x W lo: only the scalar offsets of a tile change), fp32 residual stream / embeddings, results as fp32 and / or plane pairs.
-template <int MODE, int NBUF, int MAXS = 8, bool X3 = false>
+// X3C: the x3 form with ONE K loop over combined stages -- a stage holds the K tile of all four planes (A hi | A lo | W hi | W lo,
+// 32 KB) and every fragment pair feeds three MFMAs -- instead of three passes that re-stage A hi and W hi: two thirds of the bytes
+// through the CU's L2 -> LDS port, a third of the barriers; NBUF = 2 (64 KB: still two workgroups per CU).
+template <int MODE, int NBUF, int MAXS = 8, bool X3 = false, bool X3C = false>
 __device__ __forceinline__ void dg_tile(const DgArgs& p, const int bid, char* smem) {
+    static_assert(!X3C || X3, "combined stages belong to the x3 form");
     constexpr int TB = 64, NW = 4, BK = 64, NB = 2;
-    constexpr int TA = TB * 128, STAGE = 2 * TA;
+    constexpr int TA = TB * 128, STAGE = (X3C ? 4 : 2) * TA;
     float* const smu = reinterpret_cast<float*>(smem + NBUF * STAGE);
     float* const srs = smu + TB;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -442,7 +446,7 @@ __device__ __forceinline__ void dg_tile(const DgArgs& p, const int bid, char* sm
     const int kbeg = split * p.kper;
     const int klen = max(0, min(p.K, kbeg + p.kper) - kbeg);
     const int nk1 = (klen + BK - 1) / BK;                  // (x3: the host keeps K slices whole 64-deep tiles)
-    const int nk = X3 ? 3 * nk1 : nk1, nk_full = X3 ? nk : klen / BK;
+    const int nk = (X3 && !X3C) ? 3 * nk1 : nk1, nk_full = X3 ? nk : klen / BK;
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.A), 0, p.bytesA, 0x00020000);
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.W), 0, p.bytesW, 0x00020000);
     int sa = (int)(((long)m0 * p.lda + kbeg) * 2), sb = (int)(((long)n0 * p.ldw + kbeg) * 2);
@@ -464,9 +468,18 @@ __device__ __forceinline__ void dg_tile(const DgArgs& p, const int bid, char* sm
         const bool full_ = (tt) < nk_full, live_ = (tt) < nk;                                                          \
         const int krem_ = klen - (tt) * BK;                                                                            \
         /* x3: pass = tt / nk1 (1 reads A's lo plane, 2 reads W's), K tile tt % nk1 of the slice */                     \
-        const int pass_ = X3 ? ((tt) >= nk1 ? 1 : 0) + ((tt) >= 2 * nk1 ? 1 : 0) : 0;                                  \
+        const int pass_ = (X3 && !X3C) ? ((tt) >= nk1 ? 1 : 0) + ((tt) >= 2 * nk1 ? 1 : 0) : 0;                        \
         const int sa_ = X3 ? sa + ((tt) - pass_ * nk1) * (BK * 2) + (pass_ == 1 ? p.planeA : 0) : sa;                  \
         const int sb_ = X3 ? sb + ((tt) - pass_ * nk1) * (BK * 2) + (pass_ == 2 ? p.planeW : 0) : sb;                  \
+        if constexpr (X3C) {        /* all four planes of K tile tt: A hi | A lo | W hi | W lo */                      \
+            _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                                           \
+                const int oa_ = live_ ? va[i] : OOB, ob_ = live_ ? vb[i] : OOB;                                        \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, LDS_PTR(void, st_ + (wave + NW * i) * 1024), 16, oa_, live_ ? sa_ : 0, 0, 0); \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, LDS_PTR(void, st_ + TA + (wave + NW * i) * 1024), 16, oa_, live_ ? sa_ + p.planeA : 0, 0, 0); \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, LDS_PTR(void, st_ + 2 * TA + (wave + NW * i) * 1024), 16, ob_, live_ ? sb_ : 0, 0, 0); \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, LDS_PTR(void, st_ + 3 * TA + (wave + NW * i) * 1024), 16, ob_, live_ ? sb_ + p.planeW : 0, 0, 0); \
+            }                                                                                                          \
+        } else                                                                                                         \
         _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                                               \
             const int oa_ = !live_ ? OOB : full_ ? va[i] : dma_voff<false, TB>(p.lda, m0, p.M, krem_, wave + NW * i, lane); \
             const int ob_ = !live_ ? OOB : full_ ? vb[i] : dma_voff<false, TB>(p.ldw, n0, p.N, krem_, wave + NW * i, lane); \
@@ -508,10 +521,32 @@ __device__ __forceinline__ void dg_tile(const DgArgs& p, const int bid, char* sm
         }
     }
     for (int kt = 0; kt < nk; ++kt) {
-        wait_vmcnt<(NBUF - 2) * 2 * NB>();         // my part of tile kt has landed (two younger tiles may be in flight)
+        wait_vmcnt<(NBUF - 2) * (X3C ? 4 : 2) * NB>();     // my part of tile kt has landed (the younger tiles may be in flight)
         __builtin_amdgcn_s_barrier();              // ... and everyone's; every wave is done reading tile kt - 1
         DG_ISSUE(kt + NBUF - 1);
         const char* tA = smem + (kt % NBUF) * STAGE;
+        if constexpr (X3C) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 fah[2], fal[2], fbh[2], fbl[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    fah[i] = ld_frag_kc<bf16>(tA, wm * 32 + i * 16 + l15, kk, g);
+                    fal[i] = ld_frag_kc<bf16>(tA + TA, wm * 32 + i * 16 + l15, kk, g);
+                    fbh[i] = ld_frag_kc<bf16>(tA + 2 * TA, wn * 32 + i * 16 + l15, kk, g);
+                    fbl[i] = ld_frag_kc<bf16>(tA + 3 * TA, wn * 32 + i * 16 + l15, kk, g);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        mma16(fbh[j], fah[i], acc[i][j]);
+                        mma16(fbh[j], fal[i], acc[i][j]);
+                        mma16(fbl[j], fah[i], acc[i][j]);
+                    }
+            }
+            continue;
+        }
         const char* tB = tA + TA;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -684,10 +719,10 @@ __global__ __launch_bounds__(256, 2) void decode_gemm_kernel(DgArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];      // 4 stages | row statistics
     dg_tile<MODE, 4>(p, blockIdx.x, smem);
 }
-template <int MODE>
+template <int MODE, bool COMB = false>
 __global__ __launch_bounds__(256, 2) void decode_gemm_x3_kernel(DgArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];      // 4 stages | row statistics
-    dg_tile<MODE, 4, 8, true>(p, blockIdx.x, smem);
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // 4 stages of 16 KB (three passes) / 2 of 32 KB (combined) | row statistics
+    dg_tile<MODE, (COMB ? 2 : 4), 8, true, COMB>(p, blockIdx.x, smem);
 }
 
 // x3 weight preparation, one wave per output row n of a K-contiguous weight given as a plane pair W = hi + lo ([N, K]):
@@ -1282,17 +1317,26 @@ extern "C" int mmtg_decode_gemm_x3(int mode, int M, int N, int K, const void* A,
     }
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(MMTG_PROF_GEMM_BF16, s, 2.0 * M * N * (double)K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
-    const size_t shm = 4 * 2 * 64 * 128 + 2 * 64 * 4;
+    const size_t shm = 4 * 2 * 64 * 128 + 2 * 64 * 4;        // (both forms: 4 x 16 KB or 2 x 32 KB)
+    // MMTG_DECODE_X3_COMBINED (A/B switch): 1 = one K loop over combined stages, 0 = three passes over 16 KB stages
+    static const int comb = getenv("MMTG_DECODE_X3_COMBINED") ? atoi(getenv("MMTG_DECODE_X3_COMBINED")) : 1;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void*)decode_gemm_x3_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess ||
             hipFuncSetAttribute((const void*)decode_gemm_x3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess ||
-            hipFuncSetAttribute((const void*)decode_gemm_x3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
+            hipFuncSetAttribute((const void*)decode_gemm_x3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess ||
+            hipFuncSetAttribute((const void*)decode_gemm_x3_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess ||
+            hipFuncSetAttribute((const void*)decode_gemm_x3_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess ||
+            hipFuncSetAttribute((const void*)decode_gemm_x3_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
             MMTG_FAIL(MMTG_ERR_HIP, "decode_gemm_x3: cannot raise dynamic LDS");
         attr_done = true;
     }
     const dim3 grid(a.ntiles * a.splits), block(256);
-    if (mode == 0) hipLaunchKernelGGL(decode_gemm_x3_kernel<0>, grid, block, shm, s, a);
+    if (comb) {
+        if (mode == 0) hipLaunchKernelGGL((decode_gemm_x3_kernel<0, true>), grid, block, shm, s, a);
+        else if (mode == 1) hipLaunchKernelGGL((decode_gemm_x3_kernel<1, true>), grid, block, shm, s, a);
+        else hipLaunchKernelGGL((decode_gemm_x3_kernel<2, true>), grid, block, shm, s, a);
+    } else if (mode == 0) hipLaunchKernelGGL(decode_gemm_x3_kernel<0>, grid, block, shm, s, a);
     else if (mode == 1) hipLaunchKernelGGL(decode_gemm_x3_kernel<1>, grid, block, shm, s, a);
     else hipLaunchKernelGGL(decode_gemm_x3_kernel<2>, grid, block, shm, s, a);
     MMTG_LAUNCH_CHECK("decode_gemm_x3");
