@@ -492,8 +492,17 @@ def beta_fuse_fwd(topic, img, txt, att_w, att_b, o, a, B, S, H):
                                     B, S, H, _stream()), "beta_fuse_fwd")
 
 
+_beta_ws = {}
+
+
 def beta_fuse_bwd(topic, img, txt, att_w, a, d_o, dtopic, dimg, dtxt, datt_w, datt_b, B, S, H):
-    ws = torch.empty(int(lib().mmtg_beta_fuse_bwd_ws(B, S, H)), device=d_o.device, dtype=torch.float32)       # 0.7 MB at the released sizes
+    need = int(lib().mmtg_beta_fuse_bwd_ws(B, S, H))             # 0.7 MB at the released sizes
+    key = (d_o.device, need, _stream())                          # one workspace per device, size and stream (not one per step)
+    ws = _beta_ws.get(key)
+    if ws is None:
+        if len(_beta_ws) > 64:
+            _beta_ws.clear()
+        ws = _beta_ws[key] = torch.empty(need, device=d_o.device, dtype=torch.float32)
     _check(lib().mmtg_beta_fuse_bwd(dt(topic), _p(topic), _p(img), _p(txt), _p(att_w), _p(a), _p(d_o), _p(dtopic),
                                     _p(dimg), _p(dtxt), _p(datt_w), _p(datt_b), B, S, H, _p(ws), ws.numel(), _stream()), "beta_fuse_bwd")
 
