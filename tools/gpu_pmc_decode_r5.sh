@@ -12,9 +12,17 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 R=$(pwd)
 cd /tmp
+# (the counter pass of this workload hangs INTERMITTENTLY inside rocprofv3 -- rounds 3-5: same command, same sources, 2 of 3 attempts complete in ~25 s,
+#  the third sits until the timeout -- so every pass gets up to three attempts under a short timeout; rc.txt records each one)
+rm -f $R/$OUT/rc.txt
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --kernel-trace --pmc $c --kernel-include-regex "decode_" --output-format csv -d $R/$OUT -o $c -- python3 $R/bench.py --mode decode --dtype $DT --decode-len $DLEN --steps 1 --warmup 0 --no-roofline --no-cpu-baseline --decode-eager > $R/$OUT/$c.log 2>&1
-  echo "pass $c rc=$?" >> $R/$OUT/rc.txt
+  for attempt in 1 2 3; do
+    rm -f $R/$OUT/${c}_counter_collection.csv
+    timeout 240 rocprofv3 --kernel-trace --pmc $c --kernel-include-regex "decode_" --output-format csv -d $R/$OUT -o $c -- python3 $R/bench.py --mode decode --dtype $DT --decode-len $DLEN --steps 1 --warmup 0 --no-roofline --no-cpu-baseline --decode-eager > $R/$OUT/$c.log 2>&1
+    rc=$?
+    echo "pass $c attempt $attempt rc=$rc" >> $R/$OUT/rc.txt
+    [ $rc -eq 0 ] && [ -s $R/$OUT/${c}_counter_collection.csv ] && break
+  done
 done
 cd $R
 cat $OUT/rc.txt
