@@ -7,7 +7,8 @@
 //     staged: global fp32 -> registers -> hi and lo bf16 images in LDS (the bf16 kernels' image layouts, attn_common.h);
 //   * the probabilities P and the score gradients dS are split in registers where they become MFMA operands;
 //   * S = Qh Kh + Ql Kh + Qh Kl, O = Ph Vh + Pl Vh + Ph Vl, and likewise dP, dV, dK, dQ; softmax, masks, dropout in fp32
-//     exactly as the fp32 kernels do them (same counter-hash dropout stream: forward and backward of either family pair up).
+//     as the fp32 kernels do them (same counter-hash dropout stream: forward and backward of either family pair up), with the
+//     hardware exponential (v_exp_f32, ~1e-6 relative: below the products' own 4e-6) instead of libm's expf.
 // Outputs fp32 (+ the plane pairs the next split-precision products read).  Reference arithmetic: the fp32 attention of
 // transformers' GPT-2 behind /root/reference/src/model.py:282-288.
 #include <stdlib.h>
@@ -135,14 +136,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_x3_kernel(const float* __rest
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
         const float m_new = fmaxf(m_run, mloc);
         const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-        const float alpha = (m_run == -INFINITY) ? 0.f : expf(m_run - m_use);
+        const float alpha = (m_run == -INFINITY) ? 0.f : __expf(m_run - m_use);
         float rs = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float s = s_acc[kt][r];
-                float p = (s == -INFINITY) ? 0.f : expf(s - m_use);
+                float p = (s == -INFINITY) ? 0.f : __expf(s - m_use);
                 rs += p;
                 if (drop_thresh) {
                     const int kj = j0 + kt * 16 + 4 * g + r;
@@ -269,18 +270,34 @@ __global__ __launch_bounds__(64 * XNW, 1) void attn_bwd_x3_kernel(const float* _
         kfh[ks] = ld_kc<bf16>(sKr, kl, ks, g); kfl[ks] = ld_kc<bf16>(sKr + XIMG_K, kl, ks, g);
         vfh[ks] = ld_kc<bf16>(sVr, kl, ks, g); vfl[ks] = ld_kc<bf16>(sVr + XIMG_K, kl, ks, g);
     }
+    // the Q / dO rows of a query tile travel global -> registers -> hi / lo images; the NEXT tile's rows are requested right after this
+    // tile's images are written, so their HBM latency (one workgroup per CU: nothing else would hide it) overlaps this tile's arithmetic
+    f32x4 q0v = {0.f, 0.f, 0.f, 0.f}, q1v = q0v, o0v = q0v, o1v = q0v;
+    float lse_n = 0.f, del_n = 0.f;
+#define X3_FETCH_Q(Q0)                                                                                        \
+    do {                                                                                                      \
+        if (tid < 32 * 8) {                                                                                   \
+            const int r = tid >> 3, c = tid & 7;                                                              \
+            q0v = q1v = o0v = o1v = f32x4{0.f, 0.f, 0.f, 0.f};                                                \
+            if ((Q0) + r < Tn) {                                                                              \
+                const float* qs_ = base + (long)((Q0) + r) * ld + c * 8;                                      \
+                const float* os_ = dob + (long)((Q0) + r) * D + c * 8;                                        \
+                q0v = *reinterpret_cast<const f32x4*>(qs_); q1v = *reinterpret_cast<const f32x4*>(qs_ + 4);   \
+                o0v = *reinterpret_cast<const f32x4*>(os_); o1v = *reinterpret_cast<const f32x4*>(os_ + 4);   \
+            }                                                                                                 \
+        } else if (tid < 32 * 8 + 32) {                                                                       \
+            const int r = tid - 256;                                                                          \
+            const bool ok = (Q0) + r < Tn;                                                                    \
+            lse_n = ok ? lse[((long)b * nH + h) * Tn + (Q0) + r] : 0.f;                                       \
+            del_n = ok ? delta[((long)b * Tn + (Q0) + r) * nH + h] : 0.f;                                     \
+        }                                                                                                     \
+    } while (0)
+    X3_FETCH_Q((kb0 / 32) * 32);
     for (int qt = kb0 / 32; qt < nqt; ++qt) {
         const int q0 = qt * 32;
         __syncthreads();
         if (tid < 32 * 8) {
             const int r = tid >> 3, c = tid & 7;
-            f32x4 q0v = {0.f, 0.f, 0.f, 0.f}, q1v = q0v, o0v = q0v, o1v = q0v;
-            if (q0 + r < Tn) {
-                const float* qs_ = base + (long)(q0 + r) * ld + c * 8;
-                const float* os_ = dob + (long)(q0 + r) * D + c * 8;
-                q0v = *reinterpret_cast<const f32x4*>(qs_); q1v = *reinterpret_cast<const f32x4*>(qs_ + 4);
-                o0v = *reinterpret_cast<const f32x4*>(os_); o1v = *reinterpret_cast<const f32x4*>(os_ + 4);
-            }
             bf16x8 hi, lo;
             split8f(q0v, q1v, 1.0f, hi, lo);
             *reinterpret_cast<bf16x8*>(sQr + off_kc<bf16>(r, c)) = hi;
@@ -293,11 +310,10 @@ __global__ __launch_bounds__(64 * XNW, 1) void attn_bwd_x3_kernel(const float* _
             *reinterpret_cast<bf16x8*>(sOt + off_ks<bf16>(r, c)) = hi;
             *reinterpret_cast<bf16x8*>(sOt + XIMG_Q + off_ks<bf16>(r, c)) = lo;
         } else if (tid < 32 * 8 + 32) {
-            const int r = tid - 256;
-            const bool ok = q0 + r < Tn;
-            sLse[r] = ok ? lse[((long)b * nH + h) * Tn + q0 + r] : 0.f;
-            sDel[r] = ok ? delta[((long)b * Tn + q0 + r) * nH + h] : 0.f;
+            sLse[tid - 256] = lse_n;
+            sDel[tid - 256] = del_n;
         }
+        if (qt + 1 < nqt) X3_FETCH_Q(q0 + 32);
         __syncthreads();
 
         const bool active = (kb0 + kw0 <= q0 + 31) && (kb0 + kw0 < Tn);
@@ -317,7 +333,7 @@ __global__ __launch_bounds__(64 * XNW, 1) void attn_bwd_x3_kernel(const float* _
                 for (int r = 0; r < 4; ++r) {
                     const int ql_ = qs * 16 + 4 * g + r, q = q0 + ql_;
                     const bool valid = key <= q && q < Tn && kpok;
-                    const float p = valid ? expf(s_acc[r] * scale - sLse[ql_]) : 0.f;
+                    const float p = valid ? __expf(s_acc[r] * scale - sLse[ql_]) : 0.f;
                     float dp = dp_acc[r];
                     if (drop_thresh) {
                         const float ms = dropout_scale(drop_seed, (dbase + (uint32_t)q) * (uint32_t)Tn + (uint32_t)key, drop_thresh, inv_keep);
@@ -380,6 +396,7 @@ __global__ __launch_bounds__(64 * XNW, 1) void attn_bwd_x3_kernel(const float* _
         }
     }
 
+#undef X3_FETCH_Q
     // dK, dV of this wave's keys: straight into the (hi | lo) plane pair of d(qkv) -- only split-precision products read it
     if (key < Tn) {
         bf16* dst = dqkv_p + ((long)b * Tn + key) * ld + h * DH;
