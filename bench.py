@@ -210,27 +210,28 @@ def bench_decode(args, world, rank, dev, steps, warmup, with_cpu=True):
              "banned_ids_sampled": int(torch.isin(ids[:, free], torch.tensor([1, 2, 100, 102], device=ids.device)).sum().item()),
              "distinct_ids": int(torch.unique(ids).numel())}
     roof = cpu = None
+    step_us = n_token_steps = None
+    if rank == 0:
+        # HIP events on the launch stream around the token steps of one more generation (after its once-per-generation part: weight
+        # copies, encoder, the prompt's batched prefill): the token step's duration
+        step_us, n_token_steps = token_step_us(dec, batch, Ln)
     if rank == 0 and not args.no_roofline:
-        # HIP events on the launch stream around one more graph-replayed generation: the token step's duration
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        dec.generate(batch, Ln, temperature=1.1, repitition_penalty=1.5)
-        e1.record()
-        torch.cuda.synchronize()
-        roof = decode_roofline(args, model, batch, B, Ln, dec, 1e3 * e0.elapsed_time(e1) / (dcfg.topic_prompt_length + Ln))
+        roof = decode_roofline(args, model, batch, B, Ln, dec, step_us)
     if rank == 0 and world == 1 and with_cpu and not args.no_cpu_baseline:
         cpu = cpu_decode_baseline(mcfg, dcfg, gcfg, V)
     if rank != 0:
         return None
-    steps_per_seq = dcfg.topic_prompt_length + Ln
     out = {"metric": "greedy-decode tokens/sec, full MMTG config", "value": round(B * world * Ln * steps / el, 1),
            "unit": "tokens/s", "n_gpus": world, "steps": steps, "warmup": warmup,
            "ms_per_step": round(1e3 * el / steps, 3), "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
            "config": {"workload": "batched greedy generation, KV cache, %s: batch %d, "
-                                  "%d generated positions after a 15-token prompt, GPT-2 %dL/768/12H V=%d"
-                                  % (dec.describe(), B, Ln, args.layers, V),
-                      "us_per_token_step": round(1e6 * el / steps / steps_per_seq, 2),
+                                  "%d generated positions after a 15-token prompt (%s), GPT-2 %dL/768/12H V=%d"
+                                  % (dec.describe(), B, Ln, "prefilled in one batched pass" if dec.first_pos else "fed as token steps",
+                                     args.layers, V),
+                      "us_per_token_step": round(step_us, 2), "token_steps_per_generation": n_token_steps,
+                      # what a generation spends outside its token steps: fresh weight copies / LayerNorm folds, the encoder, the prompt
+                      "once_per_generation_ms": round(1e3 * el / steps - 1e-3 * step_us * n_token_steps, 3),
                       "parallelism": "replicas x%d (no exchange)" % world},
            "check": check}
     if roof is not None:
@@ -238,6 +239,31 @@ def bench_decode(args, world, rank, dev, steps, warmup, with_cpu=True):
     if cpu is not None:
         out["cpu_baseline"] = cpu
     return out
+
+
+def decode_mean_kv_rows(first_pos, n_steps):
+    """K / V rows a token step touches per layer and batch row, averaged over positions first_pos .. first_pos + n_steps - 1: `pos`
+    cached rows read + the step's own row written."""
+    return first_pos + (n_steps - 1) / 2.0 + 1.0
+
+
+def token_step_us(dec, batch, Ln, eager=False):
+    """(us per token step, token steps) of one generation: HIP events around the step loop only -- begin() (weight copies, LayerNorm
+    folds, encoder, the prompt's prefill) runs before the first event."""
+    saved = dec.use_graph
+    if eager:
+        dec.use_graph = False
+    try:
+        n = dec.begin(batch, Ln, temperature=1.1, repitition_penalty=1.5)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for pos in range(dec.first_pos, n):
+            dec.step_at(pos)
+        e1.record()
+        torch.cuda.synchronize()
+    finally:
+        dec.use_graph = saved
+    return 1e3 * e0.elapsed_time(e1) / (n - dec.first_pos), n - dec.first_pos
 
 
 def decode_roofline(args, model, batch, B, Ln, dec, step_us_events):
@@ -249,15 +275,23 @@ def decode_roofline(args, model, batch, B, Ln, dec, step_us_events):
     esz = 2 if args.dtype == "bf16" else 4
     D, L, V, H, E = sh.D, sh.L, sh.V, sh.H, sh.E
     w_bytes = esz * (L * 12 * D * D + V * D + E * H + H * D)
-    steps_per_seq = sh.P + Ln
     kv_row = 2 * L * D * esz                                # K and V of one position, all layers
-    mean_prefix = (steps_per_seq + 1) / 2.0
-    kv_bytes = B * kv_row * (mean_prefix + 1)
+    # live per-launch timing of one generation's token steps through the library's profiling hooks (HIP events on the launch stream)
+    saved = dec.use_graph
+    dec.use_graph = False
+    try:
+        n_end = dec.begin(batch, Ln, temperature=1.1, repitition_penalty=1.5)
+        first = dec.first_pos
+        hip.prof_enable(True)
+        for pos in range(first, n_end):
+            dec.step_at(pos)
+        hip.prof_enable(False)
+    finally:
+        dec.use_graph = saved
+    steps_per_seq = n_end - first
+    # the token step at position pos reads the pos cached rows of every layer and writes one: mean over the steps that run
+    kv_bytes = B * kv_row * decode_mean_kv_rows(first, steps_per_seq)
     alg = w_bytes + kv_bytes
-    # live per-launch timing of one generation through the library's profiling hooks (HIP events on the launch stream)
-    hip.prof_enable(True)
-    dec.generate(batch, Ln, temperature=1.1, repitition_penalty=1.5, use_graph=False)
-    hip.prof_enable(False)
     pr = hip.prof_read()
     tot_ms = sum(v["ms"] for v in pr.values())
     step_us = step_us_events
@@ -294,8 +328,10 @@ def decode_roofline(args, model, batch, B, Ln, dec, step_us_events):
             "eager_kernel_us_per_token_step": round(1e3 * tot_ms / steps_per_seq, 2),
             "launches_per_token_step": round(sum(v["launches"] for v in pr.values()) / steps_per_seq, 1),
             "per_category_ms_per_generation": {k: round(v["ms"], 3) for k, v in pr.items() if v["launches"]},
-            "note": "achieved = algorithmic bytes of a token step / HIP-event duration of a graph-replayed token step; the per-category "
-                    "times are an eager (un-captured, host-bound) replay of the same launches through the library's profiling hooks"}
+            "token_steps_per_generation": steps_per_seq, "first_token_step_position": first,
+            "note": "achieved = algorithmic bytes of a token step (every weight once + the mean KV prefix of the positions the token steps run at) "
+                    "/ HIP-event duration of a graph-replayed token step; the per-category times are an eager (un-captured, host-bound) replay of "
+                    "the same token steps through the library's profiling hooks"}
 
 
 def _pmc_traffic(kernel_sha):

@@ -142,6 +142,9 @@ class GreedyDecoder:
                 # (MMTG_DECODE_EMBED_IN_PROJ=0: projector_layer2 and the embedding add as two launches, the round-3 v8 step)
                 self.embed_in_proj = os.environ.get("MMTG_DECODE_EMBED_IN_PROJ", "1") != "0" and H % 8 == 0
         self.pos, self.pos_next = self.pos_pair
+        # the prompt in one batched pass (round 5; MMTG_DECODE_PREFILL=0: P token steps, as rounds 1-4 ran it)
+        self.prefill = _parent is None and os.environ.get("MMTG_DECODE_PREFILL", "1") != "0"
+        self.first_pos = 0
         self.uniforms = None
         self.graphs = {}
         self.params = None
@@ -430,8 +433,8 @@ class GreedyDecoder:
     @torch.no_grad()
     def begin(self, batch, length, temperature=1.0, repitition_penalty=1.0, top_k=1, top_p=0.0, generator=None):
         """Everything of a generation that happens once: the settings, the uniforms of a stochastic run, fresh weight copies /
-        LayerNorm folds, the experience encoder, the prompt and the reset position.  Returns the number of token steps;
-        ``step_at(pos)`` for pos = 0 .. n - 1 then runs them (``generate`` does both; tools/decode_lanes_threads.py drives
+        LayerNorm folds, the experience encoder, the prompt (prefilled in one batched pass: ``first_pos`` = P afterwards) and the
+        reset position.  Returns the end position n; ``step_at(pos)`` for pos = first_pos .. n - 1 then runs the token steps (``generate`` does both; tools/decode_lanes_threads.py drives
         several decoders' steps from their own threads and streams)."""
         eng, sh = self.eng, self.eng.sh
         B = batch["img_embs"].shape[0]
@@ -455,8 +458,6 @@ class GreedyDecoder:
         for d in ([self] + self.children):          # (a lane has its own folded copies: they are part of its scratch)
             if getattr(d, "fused", False) or getattr(d, "x3", False):
                 d._refresh_folds()
-        a = eng.forward(batch, train_flag=False, training=False, encode_only=True)
-        self.c.copy_(a["c"])
         self.seq.zero_()
         self.seq[:, :sh.P] = batch["topic_ids"].to(eng.dev).long()
         self.seq[:, sh.P] = 1                                   # [#START#]
@@ -464,7 +465,35 @@ class GreedyDecoder:
         self.tpw_mask.copy_(batch["tpw_attention_mask"].to(eng.dev).long())
         self.keep.zero_()
         self.pos_all.zero_()
-        return sh.P + length                                    # positions 0 .. P+length-1 are consumed
+        self.first_pos = 0
+        if self.prefill and sh.P > 0:
+            self._prefill(batch)
+        else:
+            a = eng.forward(batch, train_flag=False, training=False, encode_only=True)
+            self.c.copy_(a["c"])
+        return sh.P + length                                    # positions first_pos .. P+length-1 are consumed by token steps
+
+    def _prefill(self, batch):
+        """The P prompt positions in ONE batched pass instead of P token steps (a token step costs the same whatever it appends; the
+        reference has no such distinction -- its every call re-runs the whole prefix, generate.py:124).  The engine's inference-branch
+        forward (model.py:290-326) over [prompt, [#START#]] computes every block's K / V rows for all prompt positions at once
+        (B x (P + 1) rows through the training-side kernels of the compute mode: causal, so the rows of the P prompt positions do not
+        depend on the extra one); they go into the caches, the key mask of the prompt is the prompt's attention mask, and the token
+        steps start at position P."""
+        eng, sh = self.eng, self.eng.sh
+        P = sh.P
+        pb = dict(batch)
+        pb["targets"] = self.seq[:, P:P + 1]
+        a = eng.forward(pb, train_flag=False, training=False, per_row_infer=True, need_logits=False)
+        self.c.copy_(a["c"])
+        B, T, nH = a["B"], a["T"], sh.nH
+        for l, rec in enumerate(a["layers"]):
+            qkv = rec[4].view(B, T, 3, nH, 64)
+            self.kc[l][:, :, :P].copy_(qkv[:, :P, 1].permute(0, 2, 1, 3))
+            self.vc[l][:, :, :P].copy_(qkv[:, :P, 2].permute(0, 2, 1, 3))
+        self.keep[:, :P] = (self.tpw_mask != 0).to(torch.int32)
+        self.pos_all.fill_(P)
+        self.first_pos = P
 
     def step_at(self, pos):
         """Token step `pos` of the generation ``begin`` prepared; returns whether the step called the model's head."""
@@ -491,7 +520,10 @@ class GreedyDecoder:
         if use_graph is not None:
             self.use_graph = use_graph
         try:
-            for pos in range(n_steps):
+            if teacher is not None and self.first_pos > 0:          # (the prompt steps a prefill skipped would have placed column 0)
+                col = teacher[:, 0].to(eng.dev)
+                self.seq[:, sh.P] = torch.where(col >= 0, col, self.seq[:, sh.P])
+            for pos in range(self.first_pos, n_steps):
                 with_head = self.step_at(pos)
                 j = pos + 1 - sh.P                                  # lyric index appended by this step
                 if tap is not None:

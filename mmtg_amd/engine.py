@@ -666,7 +666,8 @@ class Engine:
     def forward(self, batch, train_flag=True, training=False, per_row_infer=True, need_logits=True, logits_f32=True,
                 encode_only=False):
         """MMTG.forward (model.py:356-400).  Returns dict(logits_pad [M,Vpad] f32, B, T, ...);
-        lm_loss / kl are device scalars in self.scalars after loss()."""
+        lm_loss / kl are device scalars in self.scalars after loss().  need_logits=False stops after the last block (no ln_f, no
+        LM head: the decoder's prompt prefill reads the blocks' K / V rows only); encode_only=True stops after the fuser."""
         sh, dt = self.sh, self.dtype
         if self.table is None:
             raise RuntimeError("no WenLan token table set (vocab/token_id2emb_dict.pkl or set_token_table())")
@@ -859,6 +860,10 @@ class Engine:
                       epi=hip.EPI_RESID, aux=xmid, ldaux=D, drop_p=pr, drop_seed=s[2])
             layers.append((hcur, mu1, rs1, a1, qkv, ctx, lse, xmid, mu2, rs2, m2, u, gact, s, None))
             hcur = xout
+        if not need_logits:      # the decoder's prompt prefill: only the blocks' K / V rows (layers[l][4]) are wanted
+            a.update(c=c, kl=kl, type_ids=type_ids, keep=keep, layers=layers, x_last=hcur, logits=None)
+            self.act = a
+            return a
         muf = self.buf("lnf_mu", (M,), torch.float32)
         rsf = self.buf("lnf_rs", (M,), torch.float32)
         Vp = self.layout.Vpad

@@ -54,6 +54,34 @@ def test_kv_cache_decode_matches_reference_ids(use_graph, mode, monkeypatch):
     assert GreedyDecoder.reference_return(ids[2].tolist(), 220) == ref
 
 
+@pytest.mark.parametrize("mode", ["f32", "bf16x3", "bf16"])
+def test_prompt_prefill_fills_the_caches_the_token_steps_would(mode, monkeypatch):
+    """The prompt's batched prefill (one inference-branch forward over [prompt, [#START#]], decode.py::_prefill) against the P prompt
+    token steps it replaces (MMTG_DECODE_PREFILL=0): same key mask, K / V rows of every block and prompt position within the mode's
+    rounding, and -- in the parity-qualified modes -- the same greedy ids."""
+    fx, batch, model = build(mode)
+    tb = {k: v for k, v in batch_to_torch(batch, DEV).items() if k not in ("rating", "targets")}
+    P = model.shapes.P
+    dec = GreedyDecoder(model, max_batch=3, use_graph=False)
+    assert dec.prefill
+    ids = dec.generate(tb, 60, temperature=1.1, repitition_penalty=1.5)
+    assert dec.first_pos == P
+    kc, vc, keep = dec.kc[:, :, :, :P].float().clone(), dec.vc[:, :, :, :P].float().clone(), dec.keep[:, :P].clone()
+    monkeypatch.setenv("MMTG_DECODE_PREFILL", "0")
+    dec0 = GreedyDecoder(model, max_batch=3, use_graph=False)
+    assert not dec0.prefill
+    ids0 = dec0.generate(tb, 60, temperature=1.1, repitition_penalty=1.5)
+    assert dec0.first_pos == 0
+    assert torch.equal(keep, dec0.keep[:, :P])
+    tol = 3e-2 if mode == "bf16" else 2e-5
+    for a, b in ((kc, dec0.kc[:, :, :, :P].float()), (vc, dec0.vc[:, :, :, :P].float())):
+        assert (a - b).abs().max().item() <= tol * max(1.0, b.abs().max().item()), (mode, (a - b).abs().max().item(), b.abs().max().item())
+    if mode != "bf16":
+        assert torch.equal(ids, ids0)
+    else:
+        assert ids.shape == ids0.shape and (ids[:, 0] == 1).all()
+
+
 def test_bf16_decode_runs_and_respects_the_rules():
     fx, batch, model = build("bf16")
     tb = {k: v for k, v in batch_to_torch(batch, DEV).items() if k not in ("rating", "targets")}

@@ -55,7 +55,7 @@ for lanes in (int(x) for x in a.lanes.split(",")):
 
         def loop(d, s):
             with torch.cuda.stream(s):
-                for pos in range(n_steps):
+                for pos in range(d.first_pos, n_steps):
                     d.step_at(pos)
 
         t0 = time.perf_counter()

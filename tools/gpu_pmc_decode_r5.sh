@@ -2,7 +2,8 @@
 # Round 5: HBM traffic of the decode token step from PMC counters AT THE BENCHMARKED LENGTH (128 positions).
 #   bash tools/gpu_pmc_decode_r5.sh [decode_len=128] [dtype=bf16]
 # What changed against tools/gpu_pmc_decode_r4.sh (whose counter pass hung / crashed at 128 positions, 18.9 k dispatches):
-#   * ONE generation (--warmup 0 --steps 1 with --decode-eager: no warm-up generation) = (15 + len) x ~66 dispatches, 9.4 k at 128;
+#   * ONE generation (--warmup 0 --steps 1 with --decode-eager: no warm-up generation) = len x ~66 dispatches, 8.4 k at 128
+#     (the 15 prompt positions are prefilled by training-side kernels, which the filter below leaves out);
 #   * --kernel-include-regex decode_ : only the token step's kernels are instrumented (no torch fills / copies / once-per-generation folds).
 # FETCH_SIZE and WRITE_SIZE in separate passes, --kernel-trace only, the program directly after `--` (MI355X_MICROARCH.md).
 DLEN=${1:-128}
@@ -49,14 +50,17 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         key = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][-60:]
         per[key] = per.get(key, 0.0) + v
     out[c] = (n, tot, per)
-gens, steps = 1, 15 + DLEN
+# the prompt is prefilled in one batched pass (training-side kernels: not matched by the decode_ filter), the token steps run at
+# positions 15 .. 15 + DLEN - 1 (MMTG_DECODE_PREFILL=0: the prompt as 15 more token steps from position 0)
+first = 0 if os.environ.get("MMTG_DECODE_PREFILL") == "0" else 15
+gens, steps = 1, 15 + DLEN - first
 read_b = out["FETCH_SIZE"][1] * 1024 * 2 / (gens * steps)
 write_b = out["WRITE_SIZE"][1] * 1024 / (gens * steps)
 L, D, V, E, H, B = 12, 768, 13317, 2048, 512, 256
 esz = 2 if DT == "bf16" else 4
 w_bytes = esz * (L * 12 * D * D + V * D + E * H + H * D)
 kv_row = 2 * L * D * esz
-alg = w_bytes + B * kv_row * ((steps + 1) / 2.0 + 1)
+alg = w_bytes + B * kv_row * (first + (steps - 1) / 2.0 + 1.0)      # bench.py decode_mean_kv_rows
 res = {"what": "decode token step, batch 256, dtype %s, the kernels of the fused token step (eager launches of the graph's node list)" % DT,
        "step": "fused" if DT == "bf16" else DT, "dtype": DT, "decode_len": DLEN,
        "kernel_source_sha": hip.source_sha(), "dispatches_counted": out["FETCH_SIZE"][0],
