@@ -211,10 +211,17 @@ def bench_decode(args, world, rank, dev, steps, warmup, with_cpu=True):
              "distinct_ids": int(torch.unique(ids).numel())}
     roof = cpu = None
     step_us = n_token_steps = None
-    if rank == 0:
+    once_ms = None
+    if rank == 0 and not args.no_roofline:
         # HIP events on the launch stream around the token steps of one more generation (after its once-per-generation part: weight
         # copies, encoder, the prompt's batched prefill): the token step's duration
         step_us, n_token_steps = token_step_us(dec, batch, Ln)
+        once_ms = round(1e3 * el / steps - 1e-3 * step_us * n_token_steps, 3)
+    elif rank == 0:
+        # (--no-roofline, the counter-collection passes: no extra generation -- every dispatch is instrumented; the figure below then
+        #  includes the generation's once-only part)
+        n_token_steps = dcfg.topic_prompt_length + Ln - dec.first_pos
+        step_us = 1e6 * el / steps / n_token_steps
     if rank == 0 and not args.no_roofline:
         roof = decode_roofline(args, model, batch, B, Ln, dec, step_us)
     if rank == 0 and world == 1 and with_cpu and not args.no_cpu_baseline:
@@ -231,7 +238,7 @@ def bench_decode(args, world, rank, dev, steps, warmup, with_cpu=True):
                                      args.layers, V),
                       "us_per_token_step": round(step_us, 2), "token_steps_per_generation": n_token_steps,
                       # what a generation spends outside its token steps: fresh weight copies / LayerNorm folds, the encoder, the prompt
-                      "once_per_generation_ms": round(1e3 * el / steps - 1e-3 * step_us * n_token_steps, 3),
+                      "once_per_generation_ms": once_ms,
                       "parallelism": "replicas x%d (no exchange)" % world},
            "check": check}
     if roof is not None:
