@@ -175,7 +175,6 @@ class GreedyDecoder:
         eng, sh, B = self.eng, self.eng.sh, self.B
         D, H, E = sh.D, sh.H, sh.E
         pre = "decoder.gpt2.transformer."
-        temperature, rep, top_k, top_p = self.params
         sent = sh.msl + 2
         if getattr(self, "x3", False):
             self._step_x3(with_head)

@@ -454,7 +454,7 @@ class Engine:
         # ... and a [D, Vpad] copy of the tied embedding matrix: the LM head's dgrad d_h = dlogits @ wte contracts over the
         # vocabulary, wte's ROW index -- through the copy it is a K-contiguous x K-contiguous product like every other
         # forward / dgrad product (eight-phase kernel).  Its own launch: a shared grid would be sized by its 13440 rows.
-        woff, wn = self.layout.pack_range["wte"]
+        woff = self.layout.pack_range["wte"][0]
         self.wte_t = (torch.zeros(*((2,) if self.x3 else ()), self.sh.D, self.layout.Vpad, device=self.dev, dtype=torch.bfloat16)
                       if (_WTE_T or self.x3) else None)
         self.wte_desc = torch.tensor([(woff, self.layout.Vpad, self.sh.D, 0)], dtype=torch.int64, device=self.dev)
@@ -668,7 +668,7 @@ class Engine:
         """MMTG.forward (model.py:356-400).  Returns dict(logits_pad [M,Vpad] f32, B, T, ...);
         lm_loss / kl are device scalars in self.scalars after loss().  need_logits=False stops after the last block (no ln_f, no
         LM head: the decoder's prompt prefill reads the blocks' K / V rows only); encode_only=True stops after the fuser."""
-        sh, dt = self.sh, self.dtype
+        sh = self.sh
         if self.table is None:
             raise RuntimeError("no WenLan token table set (vocab/token_id2emb_dict.pkl or set_token_table())")
         self.refresh_copies()
@@ -1289,7 +1289,7 @@ class Engine:
         dhp32 = self.buf("d_hp32", (B, H), torch.float32)
         tmp32 = self.buf("d_tmp32", (B, H), torch.float32)
         for mod, ch, lnk, dctx_a in (("text", "text", "ln_layer3", dct), ("img", "image", "ln_layer2", dci)):
-            qkv_a, ctx_a, probs = a["alpha"][mod]
+            qkv_a, _, probs = a["alpha"][mod]
             layers, h_ln = a["enc"][ch]
             h_all = layers[-1]["h"]
             dqkv_a = self.buf("d_aqkv", (B * S, 3 * H))
@@ -1321,7 +1321,6 @@ class Engine:
         kind, NL = sh.rnn[ch]
         G = hip.RNN_GATES[kind]
         r = f"encoder.rnns_{ch}."
-        bf = self.dtype == hip.BF16
         for l in range(NL - 1, -1, -1):
             sfx = "_l%d" % l
             rec = layers[l]

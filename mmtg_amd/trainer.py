@@ -115,7 +115,6 @@ class MMTGTrainer:
         either counter moves (train.py:184-185).  Shards of a shuffled global batch that are ALL empty after the stage
         filter do not occur with the released data (every rating occurs in every batch of 64+ rows); the price of the
         exact behaviour would be a host read of the all-reduced count every step."""
-        eng = self.eng
         tune_ev = None
         if self._tune is not None:
             tune_ev = torch.cuda.Event(enable_timing=True)
@@ -179,7 +178,7 @@ class MMTGTrainer:
         if n_local > 0:
             eng.forward(batch, train_flag=True, training=self.model.training, logits_f32=_LOGITS_F32)
             sc = eng.loss(batch["rating"], stage, batch_den=n_local)
-            B, T = eng.act["B"], eng.act["T"]
+            T = eng.act["T"]
             dl = eng.loss_backward(float(n_local), lm_coef=self.lm_weight / (T - 1) if self.lm_weight else 0.0)
             eng.wgrad_overwrite = True      # gradients were zeroed above and every weight is written once
             try:
