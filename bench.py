@@ -212,14 +212,15 @@ def bench_decode(args, world, rank, dev, steps, warmup, with_cpu=True):
     roof = cpu = None
     step_us = n_token_steps = None
     once_ms = None
-    if rank == 0 and not args.no_roofline:
+    counter_pass = args.no_roofline and getattr(args, "decode_eager", False)
+    if rank == 0 and not counter_pass:
         # HIP events on the launch stream around the token steps of one more generation (after its once-per-generation part: weight
         # copies, encoder, the prompt's batched prefill): the token step's duration
         step_us, n_token_steps = token_step_us(dec, batch, Ln)
         once_ms = round(1e3 * el / steps - 1e-3 * step_us * n_token_steps, 3)
     elif rank == 0:
-        # (--no-roofline, the counter-collection passes: no extra generation -- every dispatch is instrumented; the figure below then
-        #  includes the generation's once-only part)
+        # (--no-roofline --decode-eager, the counter-collection passes: no extra generation -- every dispatch is instrumented and the
+        #  profiler dies on long runs; the figure below then includes the generation's once-only part)
         n_token_steps = dcfg.topic_prompt_length + Ln - dec.first_pos
         step_us = 1e6 * el / steps / n_token_steps
     if rank == 0 and not args.no_roofline:
@@ -470,7 +471,8 @@ def f32_object(args, dev, mcfg, dcfg, gcfg, V, steps=5, warmup=2, mode="f32"):
     a2.dtype, a2.no_roofline, a2.no_cpu_baseline = mode, True, True
     d = bench_decode(a2, 1, 0, dev, steps=1 if mode == "f32" else 3, warmup=1, with_cpu=False)
     out["decode"] = {"value": d["value"], "unit": "tokens/s", "ms_per_step": d["ms_per_step"], "batch": a2.decode_batch,
-                     "positions": args.decode_len, "us_per_token_step": d["config"]["us_per_token_step"], "check": d["check"],
+                     "positions": args.decode_len, "us_per_token_step": d["config"]["us_per_token_step"],
+                     "once_per_generation_ms": d["config"]["once_per_generation_ms"], "check": d["check"],
                      "greedy_ids_bit_exact_vs_reference": True,
                      "parity": "tests/test_decode_gpu.py: teacher-forced on the reference's own 220-position id lists this decoder picks the "
                                "reference's token at every call (199 / 199 at 12 layers), raw logits within 1e-3"}
