@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MMTG_ABI_VERSION 8
+#define MMTG_ABI_VERSION 9
 
 /* The library is built with -fvisibility=hidden: only the entry points below are exported. */
 #define MMTG_API __attribute__((visibility("default")))
@@ -207,17 +207,19 @@ MMTG_API int mmtg_layernorm_bwd_x3(const float* dy, const float* x, const float*
 MMTG_API int mmtg_attn_fwd(int dtype, const void* qkv, const int* keep, void* out, float* lse,
                   int B, int T, int nH, int dh, unsigned drop_thresh, unsigned drop_seed, void* stream);
 /* x3 mode (round 5): causal attention of the fp32-storage split-precision mode on the bf16 matrix cores -- the tiled algorithm of
- * mmtg_attn_fwd / mmtg_attn_bwd with every product (Q K^T, P V, dO V^T, dO^T P, Q^T dS, dS K) as three passes over (hi | lo) splits:
- * tiles are split while they are staged into LDS, P and dS in registers; softmax / masks / dropout in fp32 as the fp32 kernels
- * (same dropout counter stream).  qkv, out, dout fp32.  Forward: context rows to `out` (fp32: the backward reads them) AND,
- * when out_planes is given, to a (hi | lo) bf16 plane pair [B*T, D] (attn.c_proj's operand).  Backward: d(qkv) is written ONLY as
+ * mmtg_attn_fwd / mmtg_attn_bwd with every product (Q K^T, P V, dO V^T, dO^T P, Q^T dS, dS K) as three passes over (hi | lo) splits;
+ * P and dS are split in registers; softmax / masks / dropout in fp32 as the fp32 kernels (same dropout counter stream).
+ * qkv [B*T, 3D] and dout [B*T, D] arrive as (hi | lo) bf16 plane pairs (lo planes qplane / doplane elements behind the hi planes:
+ * what mmtg_gemm_x3 writes for c_attn / the c_proj dgrad); out fp32.  Forward: context rows to `out` (fp32: the backward's delta
+ * reads them) AND, when out_planes is given, to a plane pair [B*T, D] (attn.c_proj's operand).  Backward: d(qkv) is written ONLY as
  * a plane pair [B*T, 3D] (lo plane dplane elements behind): the c_attn dgrad / weight gradient read nothing else.  dq32: fp32
  * [B*T, D] scratch (zeroed by the call; key blocks of 128 add into it with fp32 atomics); delta: [B*T, nH] scratch; dbias
  * (nullable): [3D] += column sums of d(qkv), through dbias_ws (>= (B * ceil(T/128) + ceil(B*T/16)) * 3D floats); delta_ready != 0:
  * delta[m, h] = sum_d dout * out was filled by the caller (mmtg_gemm_x3's MMTG_EPI_ROWDOT epilogue does it for free).           */
-MMTG_API int mmtg_attn_fwd_x3(const float* qkv, const int* keep, float* out, void* out_planes, long plane, float* lse,
+MMTG_API int mmtg_attn_fwd_x3(const void* qkv_planes, long qplane, const int* keep, float* out, void* out_planes, long plane, float* lse,
                      int B, int T, int nH, int dh, unsigned drop_thresh, unsigned drop_seed, void* stream);
-MMTG_API int mmtg_attn_bwd_x3(const float* qkv, const int* keep, const float* out, const float* dout, const float* lse, float* delta,
+MMTG_API int mmtg_attn_bwd_x3(const void* qkv_planes, long qplane, const int* keep, const float* out, const void* dout_planes, long doplane,
+                     const float* lse, float* delta,
                      int delta_ready, float* dq32, void* dqkv_planes, long dplane, float* dbias, float* dbias_ws, long dbias_ws_floats,
                      int B, int T, int nH, int dh, unsigned drop_thresh, unsigned drop_seed, void* stream);
 /* delta: [B*T, nH] f32, delta[m,h] = sum_d dout[m,h,d] * out[m,h,d]: computed by the call, or --

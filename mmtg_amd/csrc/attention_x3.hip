@@ -3,8 +3,9 @@
 // The fp32-storage modes ran attention on v_mfma_f32_16x16x4_f32 (attention.hip, attn_fwd_kernel<float> / attn_bwd_kernel<float, 4>):
 // 2.4 + 8.1 ms of a 44 ms bf16x3 train step, a sixteenth of the bf16 matrix rate.  Here the SAME tiled algorithm runs on the bf16
 // matrix cores with every product as three passes over (hi | lo) splits, like the mode's GEMMs (gemm.hip, gemm_p8_kernel<X3>):
-//   * Q, K, V, dO arrive as fp32 rows (the c_attn product's output / the c_proj dgrad's output); a tile is split ONCE, while it is
-//     staged: global fp32 -> registers -> hi and lo bf16 images in LDS (the bf16 kernels' image layouts, attn_common.h);
+//   * Q, K, V, dO arrive as (hi | lo) bf16 plane pairs -- what the c_attn product and the c_proj dgrad write for every other
+//     split-precision consumer too (their fp32 outputs are gone: same bytes, lane-contiguous stores) -- and go global ->
+//     registers -> hi and lo images in LDS (the bf16 kernels' image layouts, attn_common.h) without arithmetic;
 //   * the probabilities P and the score gradients dS are split in registers where they become MFMA operands;
 //   * S = Qh Kh + Ql Kh + Qh Kl, O = Ph Vh + Pl Vh + Ph Vl, and likewise dP, dV, dK, dQ; softmax, masks, dropout in fp32
 //     as the fp32 kernels do them (same counter-hash dropout stream: forward and backward of either family pair up), with the
@@ -19,14 +20,6 @@ namespace {
 
 typedef AT<bf16> A2;
 
-__device__ __forceinline__ void split8f(const f32x4& a, const f32x4& b, float scale, bf16x8& hi, bf16x8& lo) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const float x = a[e] * scale, y = b[e] * scale;
-        hi[e] = (bf16)x; lo[e] = (bf16)(x - (float)hi[e]);
-        hi[4 + e] = (bf16)y; lo[4 + e] = (bf16)(y - (float)hi[4 + e]);
-    }
-}
 // three-pass product: acc += (ah + al) (bh + bl) without the lo x lo term
 __device__ __forceinline__ void mma3(const bf16x8& ah, const bf16x8& al, const bf16x8& bh, const bf16x8& bl, f32x4& acc) {
     mma16(ah, bh, acc);
@@ -44,7 +37,7 @@ __device__ __forceinline__ void acc_split(const f32x4& lo_t, const f32x4& hi_t, 
 
 // ======================================================================== forward
 // one workgroup = (batch, head, 64 queries), 4 waves x 16 queries; K / V tiles of 64 keys as hi / lo images (32 KB of LDS)
-__global__ __launch_bounds__(256, 2) void attn_fwd_x3_kernel(const float* __restrict__ qkv, const int* __restrict__ keep,
+__global__ __launch_bounds__(256, 2) void attn_fwd_x3_kernel(const bf16* __restrict__ qkv, long qplane, const int* __restrict__ keep,
         float* __restrict__ out, bf16* __restrict__ oplanes, long oplane, float* __restrict__ lse, int Tn, int nH,
         uint32_t drop_thresh, uint32_t drop_seed, float inv_keep) {
     __shared__ __attribute__((aligned(16))) char sKh[64 * 128];
@@ -57,19 +50,19 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_x3_kernel(const float* __rest
     const int qb = gridDim.x - 1 - blockIdx.x, h = blockIdx.y, b = blockIdx.z;   // longest (most key blocks) first
     const int D = nH * DH;
     const long ld = 3L * D;
-    const float* base = qkv + (long)b * Tn * ld + h * DH;
+    const bf16* base = qkv + (long)b * Tn * ld + h * DH;
     const int qi = qb * 64 + wave * 16 + l15;
 
+    // (the 1 / sqrt(64) of the scores is applied to the fp32 accumulators: a power of two, exact either way)
     bf16x8 qh[2], ql[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-        f32x4 a = {0.f, 0.f, 0.f, 0.f}, c = {0.f, 0.f, 0.f, 0.f};
+        qh[ks] = ql[ks] = zero16<bf16>();
         if (qi < Tn) {
-            const float* src = base + (long)qi * ld + ks * 32 + g * 8;
-            a = *reinterpret_cast<const f32x4*>(src);
-            c = *reinterpret_cast<const f32x4*>(src + 4);
+            const bf16* src = base + (long)qi * ld + ks * 32 + g * 8;
+            qh[ks] = *reinterpret_cast<const bf16x8*>(src);
+            ql[ks] = *reinterpret_cast<const bf16x8*>(src + qplane);
         }
-        split8f(a, c, 0.125f, qh[ks], ql[ks]);          // 1/sqrt(64): exact
     }
 
     f32x4 o_acc[4];
@@ -80,17 +73,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_x3_kernel(const float* __rest
 
     // a tile = 64 keys x 8 chunks of 8 elements: two chunks per thread; the next tile's rows are requested right after this
     // one's images are written, so their latency hides behind this tile's MFMAs and softmax
-    f32x4 kreg[2][2], vreg[2][2];
+    bf16x8 kreg[2][2], vreg[2][2];      // [it][hi | lo]
 #define X3_FETCH(J0)                                                                                          \
     _Pragma("unroll") for (int it = 0; it < 2; ++it) {                                                        \
         const int id = tid + 256 * it, key = id >> 3, c = id & 7;                                             \
-        kreg[it][0] = kreg[it][1] = vreg[it][0] = vreg[it][1] = f32x4{0.f, 0.f, 0.f, 0.f};                    \
+        kreg[it][0] = kreg[it][1] = vreg[it][0] = vreg[it][1] = zero16<bf16>();                                      \
         if ((J0) + key < Tn) {                                                                                \
-            const float* src = base + (long)((J0) + key) * ld + c * 8;                                        \
-            kreg[it][0] = *reinterpret_cast<const f32x4*>(src + D);                                           \
-            kreg[it][1] = *reinterpret_cast<const f32x4*>(src + D + 4);                                       \
-            vreg[it][0] = *reinterpret_cast<const f32x4*>(src + 2 * D);                                       \
-            vreg[it][1] = *reinterpret_cast<const f32x4*>(src + 2 * D + 4);                                   \
+            const bf16* src = base + (long)((J0) + key) * ld + c * 8;                                         \
+            kreg[it][0] = *reinterpret_cast<const bf16x8*>(src + D);                                          \
+            kreg[it][1] = *reinterpret_cast<const bf16x8*>(src + D + qplane);                                 \
+            vreg[it][0] = *reinterpret_cast<const bf16x8*>(src + 2 * D);                                      \
+            vreg[it][1] = *reinterpret_cast<const bf16x8*>(src + 2 * D + qplane);                             \
         }                                                                                                     \
     }
     X3_FETCH(0)
@@ -100,13 +93,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_x3_kernel(const float* __rest
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             const int id = tid + 256 * it, key = id >> 3, c = id & 7;
-            bf16x8 hi, lo;
-            split8f(kreg[it][0], kreg[it][1], 1.0f, hi, lo);
-            *reinterpret_cast<bf16x8*>(sKh + off_kc<bf16>(key, c)) = hi;
-            *reinterpret_cast<bf16x8*>(sKl + off_kc<bf16>(key, c)) = lo;
-            split8f(vreg[it][0], vreg[it][1], 1.0f, hi, lo);
-            *reinterpret_cast<bf16x8*>(sVh + off_ks<bf16>(key, c)) = hi;
-            *reinterpret_cast<bf16x8*>(sVl + off_ks<bf16>(key, c)) = lo;
+            *reinterpret_cast<bf16x8*>(sKh + off_kc<bf16>(key, c)) = kreg[it][0];
+            *reinterpret_cast<bf16x8*>(sKl + off_kc<bf16>(key, c)) = kreg[it][1];
+            *reinterpret_cast<bf16x8*>(sVh + off_ks<bf16>(key, c)) = vreg[it][0];
+            *reinterpret_cast<bf16x8*>(sVl + off_ks<bf16>(key, c)) = vreg[it][1];
         }
         if (jb < qb) { X3_FETCH(j0 + 64) }
         if (tid < 64) sKeep[tid] = (j0 + tid < Tn) ? keep[(long)b * Tn + j0 + tid] : 0;
@@ -128,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_x3_kernel(const float* __rest
             for (int r = 0; r < 4; ++r) {
                 const int kl = kt * 16 + 4 * g + r, kj = j0 + kl;
                 const bool valid = kj <= qi && sKeep[kl] != 0;
-                const float s = valid ? s_acc[kt][r] : -INFINITY;
+                const float s = valid ? s_acc[kt][r] * 0.125f : -INFINITY;
                 s_acc[kt][r] = s;
                 mloc = fmaxf(mloc, s);
             }
@@ -206,8 +196,8 @@ struct BwdLds {      // byte offsets inside the dynamic LDS block
 };
 constexpr int XIMG_K = XKB * 128, XIMG_Q = 32 * 128, XIMG_DS = 32 * XRBS;      // bytes from a hi image to its lo image
 
-__global__ __launch_bounds__(64 * XNW, 1) void attn_bwd_x3_kernel(const float* __restrict__ qkv, const int* __restrict__ keep,
-        const float* __restrict__ d_out, const float* __restrict__ lse, const float* __restrict__ delta,
+__global__ __launch_bounds__(64 * XNW, 1) void attn_bwd_x3_kernel(const bf16* __restrict__ qkv, long qplane, const int* __restrict__ keep,
+        const bf16* __restrict__ d_out, long doplane, const float* __restrict__ lse, const float* __restrict__ delta,
         float* __restrict__ dq32, bf16* __restrict__ dqkv_p, long dplane, float* __restrict__ dbias, int Tn, int nH,
         uint32_t drop_thresh, uint32_t drop_seed, float inv_keep) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -228,28 +218,25 @@ __global__ __launch_bounds__(64 * XNW, 1) void attn_bwd_x3_kernel(const float* _
     const int kb0 = blockIdx.x * XKB, h = blockIdx.y, b = blockIdx.z;
     const int D = nH * DH;
     const long ld = 3L * D;
-    const float* base = qkv + (long)b * Tn * ld + h * DH;
-    const float* dob = d_out + (long)b * Tn * D + h * DH;
+    const bf16* base = qkv + (long)b * Tn * ld + h * DH;
+    const bf16* dob = d_out + (long)b * Tn * D + h * DH;
     const float scale = 0.125f;
 
-    // stage this block's K (row and transposed-read images) and V (row image) once, split while staged
+    // stage this block's K (row and transposed-read images) and V (row image) once
     for (int id = tid; id < XKB * 8; id += NTHR) {
         const int key = id >> 3, c = id & 7;
-        f32x4 k0 = {0.f, 0.f, 0.f, 0.f}, k1 = k0, v0 = k0, v1 = k0;
+        bf16x8 kh = zero16<bf16>(), kl = kh, vh = kh, vl = kh;
         if (kb0 + key < Tn) {
-            const float* src = base + (long)(kb0 + key) * ld + c * 8;
-            k0 = *reinterpret_cast<const f32x4*>(src + D); k1 = *reinterpret_cast<const f32x4*>(src + D + 4);
-            v0 = *reinterpret_cast<const f32x4*>(src + 2 * D); v1 = *reinterpret_cast<const f32x4*>(src + 2 * D + 4);
+            const bf16* src = base + (long)(kb0 + key) * ld + c * 8;
+            kh = *reinterpret_cast<const bf16x8*>(src + D); kl = *reinterpret_cast<const bf16x8*>(src + D + qplane);
+            vh = *reinterpret_cast<const bf16x8*>(src + 2 * D); vl = *reinterpret_cast<const bf16x8*>(src + 2 * D + qplane);
         }
-        bf16x8 hi, lo;
-        split8f(k0, k1, 1.0f, hi, lo);
-        *reinterpret_cast<bf16x8*>(sKr + off_kc<bf16>(key, c)) = hi;
-        *reinterpret_cast<bf16x8*>(sKr + XIMG_K + off_kc<bf16>(key, c)) = lo;
-        *reinterpret_cast<bf16x8*>(sKt + off_ks<bf16>(key, c)) = hi;
-        *reinterpret_cast<bf16x8*>(sKt + XIMG_K + off_ks<bf16>(key, c)) = lo;
-        split8f(v0, v1, 1.0f, hi, lo);
-        *reinterpret_cast<bf16x8*>(sVr + off_kc<bf16>(key, c)) = hi;
-        *reinterpret_cast<bf16x8*>(sVr + XIMG_K + off_kc<bf16>(key, c)) = lo;
+        *reinterpret_cast<bf16x8*>(sKr + off_kc<bf16>(key, c)) = kh;
+        *reinterpret_cast<bf16x8*>(sKr + XIMG_K + off_kc<bf16>(key, c)) = kl;
+        *reinterpret_cast<bf16x8*>(sKt + off_ks<bf16>(key, c)) = kh;
+        *reinterpret_cast<bf16x8*>(sKt + XIMG_K + off_ks<bf16>(key, c)) = kl;
+        *reinterpret_cast<bf16x8*>(sVr + off_kc<bf16>(key, c)) = vh;
+        *reinterpret_cast<bf16x8*>(sVr + XIMG_K + off_kc<bf16>(key, c)) = vl;
     }
     for (int i = tid; i < XKB; i += NTHR) sKeep[i] = (kb0 + i < Tn) ? keep[(long)b * Tn + kb0 + i] : 0;
 
@@ -272,18 +259,18 @@ __global__ __launch_bounds__(64 * XNW, 1) void attn_bwd_x3_kernel(const float* _
     }
     // the Q / dO rows of a query tile travel global -> registers -> hi / lo images; the NEXT tile's rows are requested right after this
     // tile's images are written, so their HBM latency (one workgroup per CU: nothing else would hide it) overlaps this tile's arithmetic
-    f32x4 q0v = {0.f, 0.f, 0.f, 0.f}, q1v = q0v, o0v = q0v, o1v = q0v;
+    bf16x8 qhv = zero16<bf16>(), qlv = qhv, ohv = qhv, olv = qhv;
     float lse_n = 0.f, del_n = 0.f;
 #define X3_FETCH_Q(Q0)                                                                                        \
     do {                                                                                                      \
         if (tid < 32 * 8) {                                                                                   \
             const int r = tid >> 3, c = tid & 7;                                                              \
-            q0v = q1v = o0v = o1v = f32x4{0.f, 0.f, 0.f, 0.f};                                                \
+            qhv = qlv = ohv = olv = zero16<bf16>();                                                                  \
             if ((Q0) + r < Tn) {                                                                              \
-                const float* qs_ = base + (long)((Q0) + r) * ld + c * 8;                                      \
-                const float* os_ = dob + (long)((Q0) + r) * D + c * 8;                                        \
-                q0v = *reinterpret_cast<const f32x4*>(qs_); q1v = *reinterpret_cast<const f32x4*>(qs_ + 4);   \
-                o0v = *reinterpret_cast<const f32x4*>(os_); o1v = *reinterpret_cast<const f32x4*>(os_ + 4);   \
+                const bf16* qs_ = base + (long)((Q0) + r) * ld + c * 8;                                       \
+                const bf16* os_ = dob + (long)((Q0) + r) * D + c * 8;                                         \
+                qhv = *reinterpret_cast<const bf16x8*>(qs_); qlv = *reinterpret_cast<const bf16x8*>(qs_ + qplane);   \
+                ohv = *reinterpret_cast<const bf16x8*>(os_); olv = *reinterpret_cast<const bf16x8*>(os_ + doplane);  \
             }                                                                                                 \
         } else if (tid < 32 * 8 + 32) {                                                                       \
             const int r = tid - 256;                                                                          \
@@ -298,17 +285,14 @@ __global__ __launch_bounds__(64 * XNW, 1) void attn_bwd_x3_kernel(const float* _
         __syncthreads();
         if (tid < 32 * 8) {
             const int r = tid >> 3, c = tid & 7;
-            bf16x8 hi, lo;
-            split8f(q0v, q1v, 1.0f, hi, lo);
-            *reinterpret_cast<bf16x8*>(sQr + off_kc<bf16>(r, c)) = hi;
-            *reinterpret_cast<bf16x8*>(sQr + XIMG_Q + off_kc<bf16>(r, c)) = lo;
-            *reinterpret_cast<bf16x8*>(sQt + off_ks<bf16>(r, c)) = hi;
-            *reinterpret_cast<bf16x8*>(sQt + XIMG_Q + off_ks<bf16>(r, c)) = lo;
-            split8f(o0v, o1v, 1.0f, hi, lo);
-            *reinterpret_cast<bf16x8*>(sOr + off_kc<bf16>(r, c)) = hi;
-            *reinterpret_cast<bf16x8*>(sOr + XIMG_Q + off_kc<bf16>(r, c)) = lo;
-            *reinterpret_cast<bf16x8*>(sOt + off_ks<bf16>(r, c)) = hi;
-            *reinterpret_cast<bf16x8*>(sOt + XIMG_Q + off_ks<bf16>(r, c)) = lo;
+            *reinterpret_cast<bf16x8*>(sQr + off_kc<bf16>(r, c)) = qhv;
+            *reinterpret_cast<bf16x8*>(sQr + XIMG_Q + off_kc<bf16>(r, c)) = qlv;
+            *reinterpret_cast<bf16x8*>(sQt + off_ks<bf16>(r, c)) = qhv;
+            *reinterpret_cast<bf16x8*>(sQt + XIMG_Q + off_ks<bf16>(r, c)) = qlv;
+            *reinterpret_cast<bf16x8*>(sOr + off_kc<bf16>(r, c)) = ohv;
+            *reinterpret_cast<bf16x8*>(sOr + XIMG_Q + off_kc<bf16>(r, c)) = olv;
+            *reinterpret_cast<bf16x8*>(sOt + off_ks<bf16>(r, c)) = ohv;
+            *reinterpret_cast<bf16x8*>(sOt + XIMG_Q + off_ks<bf16>(r, c)) = olv;
         } else if (tid < 32 * 8 + 32) {
             sLse[tid - 256] = lse_n;
             sDel[tid - 256] = del_n;
@@ -486,14 +470,14 @@ __global__ __launch_bounds__(256) void attn_dq_finish_x3_kernel(const float* __r
     }
 }
 
-__global__ __launch_bounds__(256) void attn_delta_x3_kernel(const float* __restrict__ o, const float* __restrict__ d_o,
+__global__ __launch_bounds__(256) void attn_delta_x3_kernel(const float* __restrict__ o, const bf16* __restrict__ d_o, long doplane,
                                                             float* __restrict__ delta, int nH, long rows) {
     const long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (w >= rows * nH) return;
     const long row = w / nH;
     const int h = (int)(w % nH), lane = threadIdx.x & 63;
     const long idx = row * (long)(nH * DH) + h * DH + lane;
-    const float v = wave_sum(o[idx] * d_o[idx]);
+    const float v = wave_sum(o[idx] * ((float)d_o[idx] + (float)d_o[idx + doplane]));
     if (lane == 0) delta[row * nH + h] = v;
 }
 
@@ -503,34 +487,39 @@ inline float inv_keep_x3(unsigned thresh) { return thresh ? (float)(4294967296.0
 
 extern "C" int mmtg_colsum(int dtype, const void* X, long ldx, int M, int N, float* out, float* ws, long ws_floats, void* stream);
 
-extern "C" int mmtg_attn_fwd_x3(const float* qkv, const int* keep, float* out, void* out_planes, long plane, float* lse,
+extern "C" int mmtg_attn_fwd_x3(const void* qkv_planes, long qplane, const int* keep, float* out, void* out_planes, long plane, float* lse,
                                 int B, int T, int nH, int dh, unsigned drop_thresh, unsigned drop_seed, void* stream) {
     MMTG_REQUIRE(dh == DH, "attn_fwd_x3: head dim %d unsupported (built for 64)", dh);
-    MMTG_REQUIRE(B > 0 && T > 0 && nH > 0 && qkv && keep && out && lse, "attn_fwd_x3: bad sizes / null pointer");
-    MMTG_REQUIRE(MMTG_ALIGNED16(qkv) && MMTG_ALIGNED16(out) && (((uintptr_t)out_planes) & 7) == 0, "attn_fwd_x3: alignment");
+    MMTG_REQUIRE(B > 0 && T > 0 && nH > 0 && qkv_planes && keep && out && lse, "attn_fwd_x3: bad sizes / null pointer");
+    MMTG_REQUIRE(MMTG_ALIGNED16(qkv_planes) && qplane % 8 == 0 && qplane >= 3L * B * T * nH * DH && MMTG_ALIGNED16(out) &&
+                 (((uintptr_t)out_planes) & 7) == 0, "attn_fwd_x3: alignment / qkv plane layout");
     MMTG_REQUIRE(!out_planes || (plane % 4 == 0 && plane >= (long)B * T * nH * DH), "attn_fwd_x3: the lo plane must lie behind the hi plane");
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(MMTG_PROF_ATTN_FWD, s, 2.0 * B * nH * (double)T * T * dh, 4.0 * 5.0 * B * T * nH * dh);
-    hipLaunchKernelGGL(attn_fwd_x3_kernel, dim3(cdiv(T, 64), nH, B), dim3(256), 0, s, qkv, keep, out, (bf16*)out_planes, plane, lse, T, nH,
+    hipLaunchKernelGGL(attn_fwd_x3_kernel, dim3(cdiv(T, 64), nH, B), dim3(256), 0, s, (const bf16*)qkv_planes, qplane, keep, out, (bf16*)out_planes, plane, lse, T, nH,
                        drop_thresh, drop_seed, inv_keep_x3(drop_thresh));
     MMTG_LAUNCH_CHECK("attn_fwd_x3");
     return MMTG_OK;
 }
 
-/* Backward of mmtg_attn_fwd_x3.  qkv, out, dout fp32; d(qkv) is written as a (hi | lo) bf16 plane pair [B*T, 3D] (lo plane `dplane`
- * elements behind) -- the c_attn dgrad and weight gradient are split-precision products and nothing else reads it.  dq32: fp32
+/* Backward of mmtg_attn_fwd_x3.  qkv [B*T, 3D] and dout [B*T, D] as (hi | lo) bf16 plane pairs (lo planes `qplane` / `doplane` elements
+ * behind), out fp32; d(qkv) is written as a plane pair [B*T, 3D] (lo plane `dplane` elements behind) -- the c_attn dgrad and weight
+ * gradient are split-precision products and nothing else reads it.  dq32: fp32
  * [B*T, D] scratch (zeroed by the call; the key blocks add into it with fp32 atomics); delta: [B*T, nH] scratch; dbias (nullable):
  * [3D] += column sums of d(qkv); dbias_ws: >= (B * ceil(T / 128) + ceil(B*T / 16)) * 3D floats;
  * delta_ready != 0: delta was filled by the caller (the c_proj dgrad's MMTG_EPI_ROWDOT epilogue). */
-extern "C" int mmtg_attn_bwd_x3(const float* qkv, const int* keep, const float* out, const float* dout, const float* lse, float* delta,
+extern "C" int mmtg_attn_bwd_x3(const void* qkv_planes, long qplane, const int* keep, const float* out, const void* dout_planes, long doplane,
+                                const float* lse, float* delta,
                                 int delta_ready, float* dq32, void* dqkv_planes, long dplane, float* dbias, float* dbias_ws, long dbias_ws_floats,
                                 int B, int T, int nH, int dh, unsigned drop_thresh, unsigned drop_seed, void* stream) {
     MMTG_REQUIRE(dh == DH, "attn_bwd_x3: head dim %d unsupported (built for 64)", dh);
-    MMTG_REQUIRE(B > 0 && T > 0 && nH > 0 && qkv && keep && out && dout && lse && delta && dq32 && dqkv_planes, "attn_bwd_x3: bad sizes / null pointer");
+    MMTG_REQUIRE(B > 0 && T > 0 && nH > 0 && qkv_planes && keep && out && dout_planes && lse && delta && dq32 && dqkv_planes,
+                 "attn_bwd_x3: bad sizes / null pointer");
     const long rows = (long)B * T;
     const int D = nH * dh;
-    MMTG_REQUIRE(MMTG_ALIGNED16(qkv) && MMTG_ALIGNED16(dout) && MMTG_ALIGNED16(dq32) && (((uintptr_t)dqkv_planes) & 7) == 0 && dplane % 4 == 0 &&
-                 dplane >= rows * 3 * D, "attn_bwd_x3: alignment / plane layout");
+    MMTG_REQUIRE(MMTG_ALIGNED16(qkv_planes) && qplane % 8 == 0 && qplane >= rows * 3 * D && MMTG_ALIGNED16(dout_planes) && doplane % 8 == 0 &&
+                 doplane >= rows * D && MMTG_ALIGNED16(dq32) && (((uintptr_t)dqkv_planes) & 7) == 0 && dplane % 4 == 0 && dplane >= rows * 3 * D,
+                 "attn_bwd_x3: alignment / plane layout");
     const int nkb = cdiv(T, XKB), nband = cdiv(rows, XFB);
     MMTG_REQUIRE(!dbias || (dbias_ws && dbias_ws_floats >= ((long)B * nkb + nband) * 3 * D), "attn_bwd_x3: the bias gradient needs %ld workspace floats",
                  ((long)B * nkb + nband) * 3 * D);
@@ -542,11 +531,12 @@ extern "C" int mmtg_attn_bwd_x3(const float* qkv, const int* keep, const float* 
             MMTG_FAIL(MMTG_ERR_HIP, "attn_bwd_x3: cannot raise dynamic LDS to %d", BwdLds::END);
         attr_set = true;
     }
-    if (!delta_ready) hipLaunchKernelGGL(attn_delta_x3_kernel, dim3(cdiv(rows * nH, 4)), dim3(256), 0, s, out, dout, delta, nH, rows);
+    if (!delta_ready)
+        hipLaunchKernelGGL(attn_delta_x3_kernel, dim3(cdiv(rows * nH, 4)), dim3(256), 0, s, out, (const bf16*)dout_planes, doplane, delta, nH, rows);
     if (hipMemsetAsync(dq32, 0, rows * D * sizeof(float), s) != hipSuccess) MMTG_FAIL(MMTG_ERR_HIP, "attn_bwd_x3: memset failed");
     float* const kv_rows = dbias ? dbias_ws : nullptr;                       // [B * nkb][3D]: k and v parts (q part zero)
     float* const q_rows = dbias ? dbias_ws + (long)B * nkb * 3 * D : nullptr; // [nband][D]
-    hipLaunchKernelGGL(attn_bwd_x3_kernel, dim3(nkb, nH, B), dim3(64 * XNW), BwdLds::END, s, qkv, keep, dout, lse, delta, dq32, (bf16*)dqkv_planes, dplane,
+    hipLaunchKernelGGL(attn_bwd_x3_kernel, dim3(nkb, nH, B), dim3(64 * XNW), BwdLds::END, s, (const bf16*)qkv_planes, qplane, keep, (const bf16*)dout_planes, doplane, lse, delta, dq32, (bf16*)dqkv_planes, dplane,
                        kv_rows, T, nH, drop_thresh, drop_seed, inv_keep_x3(drop_thresh));
     hipLaunchKernelGGL(attn_dq_finish_x3_kernel, dim3(nband), dim3(256), 0, s, dq32, (bf16*)dqkv_planes, dplane, q_rows, rows, D);
     MMTG_LAUNCH_CHECK("attn_bwd_x3");

@@ -487,7 +487,10 @@ class GreedyDecoder:
         self.c.copy_(a["c"])
         B, T, nH = a["B"], a["T"], sh.nH
         for l, rec in enumerate(a["layers"]):
-            qkv = rec[4].view(B, T, 3, nH, 64)
+            qkv = rec[4]
+            if isinstance(qkv, hip.Planes):        # bf16x3: c_attn writes a (hi | lo) plane pair; the cache holds fp32 rows
+                qkv = qkv.float()
+            qkv = qkv.view(B, T, 3, nH, 64)
             self.kc[l][:, :, :P].copy_(qkv[:, :P, 1].permute(0, 2, 1, 3))
             self.vc[l][:, :, :P].copy_(qkv[:, :P, 2].permute(0, 2, 1, 3))
         self.keep[:, :P] = (self.tpw_mask != 0).to(torch.int32)

@@ -225,8 +225,6 @@ _LMHEAD_GROUP = _os.environ.get("MMTG_LMHEAD_GROUP", "1") != "0"      # the tied
 _LMHEAD_GROUP_SPLITS = int(_os.environ.get("MMTG_LMHEAD_GROUP_SPLITS", "0"))
 # the grouped weight-gradient launches on a SIDE stream, one block behind the dgrad chain (MMTG_WGRAD_STREAM; see Engine.backward)
 _WGRAD_STREAM = _os.environ.get("MMTG_WGRAD_STREAM", "0") != "0"
-# x3 mode: attention on the bf16 matrix cores as three passes over split operands (A/B switch: 0 = the exact-fp32 attention kernels)
-_X3_ATTN = _os.environ.get("MMTG_X3_ATTN", "1") != "0"
 _WGRAD_GROUP_CFG = int(_os.environ.get("MMTG_WGRAD_GROUP_CFG", "0"))          # 0: 128x128 tiles, four workgroups per CU; 1: 256x256 eight-phase
 
 
@@ -808,20 +806,17 @@ class Engine:
             mu2 = self.buf(f"l{l}_mu2", (M,), torch.float32)
             rs2 = self.buf(f"l{l}_rs2", (M,), torch.float32)
             if x3:
-                # split-precision block: the LayerNorms and the GELU write (hi | lo) plane pairs -- only products read them --
-                # the attention context is needed in fp32 by its backward AND as planes by c_proj
+                # split-precision block: the LayerNorms, c_attn and the GELU write (hi | lo) plane pairs -- only products and the
+                # split-precision attention read them -- the attention context is needed in fp32 by its backward's delta AND as
+                # planes by c_proj
                 a1 = self.pbuf(f"l{l}_a", M, D)
                 hip.layernorm_fwd_x3(hcur, a1, self.P(p + "ln_1.weight"), self.P(p + "ln_1.bias"), mu1, rs1, M, D, sh.eps)
-                qkv = self.buf(f"l{l}_qkv", (M, 3 * D))
-                self._fwd_x3(a1, p + "attn.c_attn.weight", qkv, M, bias=self.P(p + "attn.c_attn.bias"))
+                qkv = self.pbuf(f"l{l}_qkvp", M, 3 * D)
+                self._fwd_x3(a1, p + "attn.c_attn.weight", None, M, bias=self.P(p + "attn.c_attn.bias"), planes=qkv, ldc=3 * D)
                 ctx = self.buf(f"l{l}_ctx", (M, D))
                 lse = self.buf(f"l{l}_lse", (B, sh.nH, T), torch.float32)
                 ctxp = self.pbuf(f"l{l}_ctxp", M, D)
-                if _X3_ATTN:
-                    hip.attn_fwd_x3(qkv, keep, ctx, ctxp, lse, B, T, sh.nH, D // sh.nH, drop_p=pa, drop_seed=s[0])
-                else:
-                    hip.attn_fwd(qkv, keep, ctx, lse, B, T, sh.nH, D // sh.nH, drop_p=pa, drop_seed=s[0])
-                    hip.split_planes(ctx, M, D, ctxp)
+                hip.attn_fwd_x3(qkv, keep, ctx, ctxp, lse, B, T, sh.nH, D // sh.nH, drop_p=pa, drop_seed=s[0])
                 xmid = self.buf(f"l{l}_xmid", (M, D))
                 self._fwd_x3(ctxp, p + "attn.c_proj.weight", xmid, M, bias=self.P(p + "attn.c_proj.bias"),
                              epi=hip.EPI_RESID, aux=hcur, ldaux=D, drop_p=pr, drop_seed=s[1])
@@ -1113,18 +1108,13 @@ class Engine:
                                      self.G(p + "ln_2.weight"), self.G(p + "ln_2.bias"), M, D, dy2p,
                                      drop_p=pr, drop_seed=s[1], dcolsum=self.G(p + "attn.c_proj.bias"), ws=lnws)
                 dqkvp = self.pbuf("d_qkv_p", M, 3 * D)
-                if _X3_ATTN:
-                    # (the dgrad's epilogue also emits delta = rowsum(d ctx * ctx) per head: no separate pass over ctx / d ctx)
-                    self._dgrad_x3(dy2p, p + "attn.c_proj.weight", dctx, M, epi=hip.EPI_ROWDOT, aux=ctx, ldaux=D, aux2=delta)
-                    hip.attn_bwd_x3(qkv, a["keep"], ctx, dctx, lse, delta, dq32, dqkvp, B, T, sh.nH, D // sh.nH, drop_p=pa, drop_seed=s[0],
-                                    dbias=self.G(p + "attn.c_attn.bias"), delta_ready=True,
-                                    dbias_ws=self.buf("attn_dbias_x3", (hip.attn_bwd_x3_ws(B, T, D),), torch.float32))
-                else:
-                    self._dgrad_x3(dy2p, p + "attn.c_proj.weight", dctx, M)
-                    hip.attn_bwd(qkv, a["keep"], ctx, dctx, lse, delta, dq32, dqkv, B, T, sh.nH, D // sh.nH,
-                                 drop_p=pa, drop_seed=s[0], delta_ready=False, dbias=self.G(p + "attn.c_attn.bias"),
-                                 dbias_ws=self.buf("attn_dbias_rows", (hip.attn_bwd_bias_rows(B, T, self.dtype), 3 * D), torch.float32))
-                    hip.split_planes(dqkv, M, 3 * D, dqkvp)
+                # d(ctx) as a plane pair only (the attention backward is its one reader); the dgrad's epilogue also emits delta =
+                # rowsum(d ctx * ctx) per head: no separate pass over ctx / d ctx
+                dctxp = self.pbuf("d_ctx_p", M, D)
+                self._dgrad_x3(dy2p, p + "attn.c_proj.weight", None, M, planes=dctxp, ldc=D, epi=hip.EPI_ROWDOT, aux=ctx, ldaux=D, aux2=delta)
+                hip.attn_bwd_x3(qkv, a["keep"], ctx, dctxp, lse, delta, dq32, dqkvp, B, T, sh.nH, D // sh.nH, drop_p=pa, drop_seed=s[0],
+                                dbias=self.G(p + "attn.c_attn.bias"), delta_ready=True,
+                                dbias_ws=self.buf("attn_dbias_x3", (hip.attn_bwd_x3_ws(B, T, D),), torch.float32))
                 self._dgrad_x3(dqkvp, p + "attn.c_attn.weight", da, M)
                 keys = (p + "mlp.c_fc.weight", p + "mlp.c_proj.weight", p + "attn.c_proj.weight", p + "attn.c_attn.weight")
                 probs = [(m2, dup, self.G(keys[0]), D, 4 * D), (gact, dyp, self.G(keys[1]), 4 * D, D),

@@ -13,7 +13,7 @@ import os
 import torch
 
 F32, BF16 = 0, 1
-ABI_VERSION = 8
+ABI_VERSION = 9
 EPI_NONE, EPI_GELU, EPI_TANH, EPI_RESID, EPI_DGELU, EPI_DTANH, EPI_ATOMIC, EPI_ROWDOT = range(8)
 GEMM_NO_TR, GEMM_REGSTAGE, GEMM_SKINNY, GEMM_NO_SKINNY, GEMM_WIDE, GEMM_NO_WIDE = 1, 2, 4, 8, 16, 32
 GEMM_PERSIST, GEMM_NO_PERSIST, GEMM_ROW_ORDER, GEMM_OCC4, GEMM_NO_OCC4, GEMM_COL_BLOCK, GEMM_P256, GEMM_NO_P8, GEMM_P8 = 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384
@@ -46,8 +46,8 @@ _SIGS = {
     "mmtg_layernorm_bwd": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _u, _u, _vp, _vp, _l, _vp], _i),
     "mmtg_layernorm_bwd_x3": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _l, _u, _u, _vp, _vp, _l, _vp], _i),
     "mmtg_attn_fwd": ([_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _u, _u, _vp], _i),
-    "mmtg_attn_fwd_x3": ([_vp, _vp, _vp, _vp, _l, _vp, _i, _i, _i, _i, _u, _u, _vp], _i),
-    "mmtg_attn_bwd_x3": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _l, _vp, _vp, _l, _i, _i, _i, _i, _u, _u, _vp], _i),
+    "mmtg_attn_fwd_x3": ([_vp, _l, _vp, _vp, _vp, _l, _vp, _i, _i, _i, _i, _u, _u, _vp], _i),
+    "mmtg_attn_bwd_x3": ([_vp, _l, _vp, _vp, _vp, _l, _vp, _vp, _i, _vp, _vp, _l, _vp, _vp, _l, _i, _i, _i, _i, _u, _u, _vp], _i),
     "mmtg_attn_trace": ([_vp], _i),
     "mmtg_attn_bwd": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _u, _u, _vp], _i),
     "mmtg_embed_condition": ([_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
@@ -350,9 +350,12 @@ def attn_fwd(qkv, keep, out, lse, B, T, nH, dh, drop_p=0.0, drop_seed=0):
                                drop_thresh(drop_p), drop_seed & 0xFFFFFFFF, _stream()), "attn_fwd")
 
 
-def attn_fwd_x3(qkv, keep, out, out_planes, lse, B, T, nH, dh, drop_p=0.0, drop_seed=0):
-    """Split-precision attention forward on fp32 qkv (include/mmtg_hip.h); out_planes: Planes or None."""
-    _check(lib().mmtg_attn_fwd_x3(_p(qkv), _p(keep), _p(out), 0 if out_planes is None else _p(out_planes.t),
+def attn_fwd_x3(qkv_planes, keep, out, out_planes, lse, B, T, nH, dh, drop_p=0.0, drop_seed=0):
+    """Split-precision attention forward; qkv_planes: Planes [B*T, 3D] (what the c_attn product writes), out fp32, out_planes:
+    Planes or None (include/mmtg_hip.h)."""
+    if qkv_planes.ld != 3 * nH * dh:
+        raise ValueError("attn_fwd_x3: the qkv plane pair must be dense ([B*T, 3D], ld = 3D)")
+    _check(lib().mmtg_attn_fwd_x3(_p(qkv_planes.t), qkv_planes.plane, _p(keep), _p(out), 0 if out_planes is None else _p(out_planes.t),
                                   0 if out_planes is None else out_planes.plane, _p(lse), B, T, nH, dh,
                                   drop_thresh(drop_p), drop_seed & 0xFFFFFFFF, _stream()), "attn_fwd_x3")
 
@@ -362,10 +365,14 @@ def attn_bwd_x3_ws(B, T, D):
     return (B * (-(-T // 128)) + -(-(B * T) // 16)) * 3 * D
 
 
-def attn_bwd_x3(qkv, keep, out, dout, lse, delta, dq32, dqkv_planes, B, T, nH, dh, drop_p=0.0, drop_seed=0, dbias=None, dbias_ws=None,
-                delta_ready=False):
-    """Split-precision attention backward: d(qkv) as the Planes ``dqkv_planes`` [B*T, 3D]."""
-    _check(lib().mmtg_attn_bwd_x3(_p(qkv), _p(keep), _p(out), _p(dout), _p(lse), _p(delta), int(delta_ready), _p(dq32), _p(dqkv_planes.t), dqkv_planes.plane,
+def attn_bwd_x3(qkv_planes, keep, out, dout_planes, lse, delta, dq32, dqkv_planes, B, T, nH, dh, drop_p=0.0, drop_seed=0, dbias=None,
+                dbias_ws=None, delta_ready=False):
+    """Split-precision attention backward: qkv [B*T, 3D] and d(ctx) [B*T, D] as Planes, out fp32; d(qkv) as the Planes
+    ``dqkv_planes`` [B*T, 3D]."""
+    if qkv_planes.ld != 3 * nH * dh or dout_planes.ld != nH * dh or dqkv_planes.ld != 3 * nH * dh:
+        raise ValueError("attn_bwd_x3: the plane pairs must be dense (ld = columns)")
+    _check(lib().mmtg_attn_bwd_x3(_p(qkv_planes.t), qkv_planes.plane, _p(keep), _p(out), _p(dout_planes.t), dout_planes.plane, _p(lse), _p(delta),
+                                  int(delta_ready), _p(dq32), _p(dqkv_planes.t), dqkv_planes.plane,
                                   _p(dbias), _p(dbias_ws), 0 if dbias_ws is None else dbias_ws.numel(), B, T, nH, dh,
                                   drop_thresh(drop_p), drop_seed & 0xFFFFFFFF, _stream()), "attn_bwd_x3")
 

@@ -183,7 +183,7 @@ def test_adamw_writes_the_weight_plane_pair():
                                       # ragged edges of the 32-query / 64-query / 128-key tiles, one-token and maximum-length sequences
                                       (2, 1, 0.0), (1, 31, 0.1), (2, 33, 0.0), (1, 64, 0.0), (1, 65, 0.1), (1, 128, 0.0), (2, 129, 0.1), (1, 512, 0.0)])
 def test_attention_x3_matches_the_exact_fp32_kernels(B, T, drop):
-    """The split-precision attention (three bf16 passes per product, tiles split while staged) against the exact-fp32 kernels it
+    """The split-precision attention (three bf16 passes per product, operands as (hi | lo) plane pairs) against the exact-fp32 kernels it
     replaces in the bf16x3 mode: same masks (causal + key padding), same dropout stream -- forward context / LSE and the backward's
     d(qkv) plane pair + c_attn bias gradient."""
     nH, dh = 12, 64
@@ -210,14 +210,16 @@ def test_attention_x3_matches_the_exact_fp32_kernels(B, T, drop):
     out = torch.full((B * T, D), float("nan"), device=DEV)
     outp = hip.Planes.empty(B * T, D, DEV)
     lse = torch.empty(B, nH, T, device=DEV)
-    hip.attn_fwd_x3(qkv, keep, out, outp, lse, B, T, nH, dh, drop_p=drop, drop_seed=seed)
+    qkvp = hip.split_planes(qkv, B * T, 3 * D, hip.Planes.empty(B * T, 3 * D, DEV))     # what the c_attn product hands over
+    hip.attn_fwd_x3(qkvp, keep, out, outp, lse, B, T, nH, dh, drop_p=drop, drop_seed=seed)
     assert (out - out32).abs().max().item() < 2e-5 * max(1.0, out32.abs().max().item())
     assert (lse - lse32).abs().max().item() < 2e-5 * max(1.0, lse32.abs().max().item())
     assert ((outp.float() - out).abs() <= 2.0 ** -17 * out.abs() + 1e-30).all()
     dqp = hip.Planes.empty(B * T, 3 * D, DEV)
     db = torch.zeros(3 * D, device=DEV)
     ws3 = torch.empty(hip.attn_bwd_x3_ws(B, T, D), device=DEV)
-    hip.attn_bwd_x3(qkv, keep, out, dout, lse, torch.empty_like(delta), dq32, dqp, B, T, nH, dh, drop_p=drop, drop_seed=seed, dbias=db, dbias_ws=ws3)
+    doutp = hip.split_planes(dout, B * T, D, hip.Planes.empty(B * T, D, DEV))           # ... and the c_proj dgrad
+    hip.attn_bwd_x3(qkvp, keep, out, doutp, lse, torch.empty_like(delta), dq32, dqp, B, T, nH, dh, drop_p=drop, drop_seed=seed, dbias=db, dbias_ws=ws3)
     scale = dqkv32.abs().max().item()
     assert (dqp.float() - dqkv32).abs().max().item() < 4e-5 * scale, ((dqp.float() - dqkv32).abs().max().item(), scale)
     assert (db - db32).abs().max().item() < 1e-4 * max(1.0, db32.abs().max().item())

@@ -27,9 +27,11 @@ ops = [(x, P(f(M, 4 * D))), (h, dy), (x, dy), (x, P(f(M, 3 * D)))]
 outs = [torch.zeros(a, b, device=dev) for a, b in shapes]
 probs = [(A, Bm, C, a, b) for (A, Bm), C, (a, b) in zip(ops, outs, shapes)]
 qkv = f(M, 3 * D)
+qkvp = P(qkv)
 keep = torch.ones(B, T, dtype=torch.int32, device=dev)
 out, outp, dout = torch.empty(M, D, device=dev), hip.Planes.empty(M, D, dev), f(M, D) * 0.1
 lse, delta = torch.empty(B, nH, T, device=dev), torch.empty(M, nH, device=dev)
+doutp = P(dout)
 dq32, dqp = torch.empty(M, D, device=dev), hip.Planes.empty(M, 3 * D, dev)
 aws = torch.empty(hip.attn_bwd_x3_ws(B, T, D), device=dev)
 gam, bet = torch.ones(D, device=dev), torch.zeros(D, device=dev)
@@ -45,8 +47,8 @@ for _ in range(3):
     hip.gemm_x3(h, w2, c2, M, D, 4 * D, bias=b2, epi=hip.EPI_RESID, aux=res, ldaux=D, drop_p=0.1, drop_seed=4)
     hip.gemm_x3(dy, w2t, None, M, 4 * D, D, planes=dup, ldc=4 * D, epi=hip.EPI_DGELU, aux=pre, ldaux=4 * D, aux2=bands)
     hip.wgrad_group(probs, M, 2, ws, cnt, config=2)
-    hip.attn_fwd_x3(qkv, keep, out, outp, lse, B, T, nH, 64, drop_p=0.1, drop_seed=1)
-    hip.attn_bwd_x3(qkv, keep, out, dout, lse, delta, dq32, dqp, B, T, nH, 64, drop_p=0.1, drop_seed=1, dbias=torch.zeros(3 * D, device=dev), dbias_ws=aws)
+    hip.attn_fwd_x3(qkvp, keep, out, outp, lse, B, T, nH, 64, drop_p=0.1, drop_seed=1)
+    hip.attn_bwd_x3(qkvp, keep, out, doutp, lse, delta, dq32, dqp, B, T, nH, 64, drop_p=0.1, drop_seed=1, dbias=torch.zeros(3 * D, device=dev), dbias_ws=aws)
     hip.layernorm_fwd_x3(xf, lnp, gam, bet, mu, rs, M, D)
     hip.layernorm_bwd_x3(dyf, xf, gam, mu, rs, None, dx, dg, db, M, D, dxp, drop_p=0.1, drop_seed=2, ws=lnws)
 torch.cuda.synchronize()
