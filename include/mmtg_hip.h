@@ -388,7 +388,9 @@ MMTG_API int mmtg_slab_sum(const float* part, int splits, long stride, float* ds
  *           counters per tile and split; K slices are multiples of 128).
  * config 2 (round 5, the split-precision mode; 128x128 tiles): A_p and B_p are (hi | lo) bf16 plane pairs of fp32 tensors -- the
  *           lo plane planeA / planeB ELEMENTS behind the hi plane -- and every K slice is walked three times,
- *           A_hi^T B_hi + A_lo^T B_hi + A_hi^T B_lo (see mmtg_gemm_x3); planeA / planeB are ignored otherwise.            */
+ *           A_hi^T B_hi + A_lo^T B_hi + A_hi^T B_lo (see mmtg_gemm_x3); planeA / planeB are ignored otherwise.
+ * config 6 (= 2 | 4): the same products on combined stages -- a 64 KB stage holds the K tile of all four planes and every fragment
+ *           pair feeds the three MFMA passes (two workgroups per CU; a third fewer bytes through the L2 -> LDS port).      */
 typedef struct mmtg_wgrad_problem {
     const void* A; long lda;
     const void* B; long ldb;

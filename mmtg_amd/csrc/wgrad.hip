@@ -169,8 +169,12 @@ __device__ __forceinline__ int wg_locate(const WgArgs& a, int& t, int& split, in
 // ds_read_b64_tr_b16 (what an 8-row register transpose of plain reads would issue); 2 = no LDS-DMA fills after the first tile.
 // X3 (round 5, the split-precision mode): A_p and B_p are (hi | lo) bf16 plane pairs of fp32 activations / gradients and the K
 // slice is walked three times -- (A hi, B hi), (A lo, B hi), (A hi, B lo) -- into the same accumulators (gemm.hip, gemm_p8_kernel).
-template <bool FENCE, int ABLATE = 0, bool X3 = false>
-__global__ __launch_bounds__(256, 4) void wgrad_group_kernel(WgArgs a) {
+// X3C (round 5, late): the x3 form with ONE K loop over combined stages -- a stage holds the K tile of all four planes (A hi | A lo |
+// B hi | B lo, 64 KB: two workgroups per CU instead of four) and every fragment pair feeds three MFMAs -- instead of three passes that
+// re-stage A hi and B hi: two thirds of the bytes through the CU's L2 -> LDS port (what bounds this kernel), a third of the barriers.
+template <bool FENCE, int ABLATE = 0, bool X3 = false, bool X3C = false>
+__global__ __launch_bounds__(256, (X3C ? 2 : 4)) void wgrad_group_kernel(WgArgs a) {
+    static_assert(!X3C || X3, "combined stages belong to the x3 form");
     constexpr int TBM = 128, TBN = 128, NW = 4, TM = 4, TN = 4, BK = 64;
     constexpr int NB = TBM / 8 / NW;
     constexpr int TA = TBM * 128;
@@ -216,6 +220,53 @@ __global__ __launch_bounds__(256, 4) void wgrad_group_kernel(WgArgs a) {
     const int t_row = (tid & 127) >> 1, t_half = tid & 1;
     const int t_ok = t_b ? (n0 + t_half * 64 < N) : (m0 + t_half * 64 < M);
     const int t_v = (int)((long)t_row * (t_b ? ldb : lda) * 2) + t_half * 128;
+    if constexpr (X3C) {
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt) __builtin_amdgcn_s_barrier();          // every wave is done reading the previous stage
+            const bool full = kt < nk_full;
+            const int krem = klen - kt * BK;
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int o = full ? va[i] : dma_voff<true, TBM>(lda, m0, M, krem, wave + NW * i, lane);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, LDS_PTR(void, smem + (wave + NW * i) * 1024), 16, o, sa, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, LDS_PTR(void, smem + TA + (wave + NW * i) * 1024), 16, o, sa + P.planeA, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int o = full ? vb[i] : dma_voff<true, TBN>(ldb, n0, N, krem, wave + NW * i, lane);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, LDS_PTR(void, smem + 2 * TA + (wave + NW * i) * 1024), 16, o, sb, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, LDS_PTR(void, smem + 3 * TA + (wave + NW * i) * 1024), 16, o, sb + P.planeB, 0, 0);
+            }
+            sa += stepa;
+            sb += stepb;
+            wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();                  // the stage is complete
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 fah[TM], fal[TM], fbh[TN], fbl[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int o = oa[i] + kk * 32 * 2 * TBM;
+                    fah[i] = tr_read_pair(smem, o, o + 4 * 2 * TBM);
+                    fal[i] = tr_read_pair(smem + TA, o, o + 4 * 2 * TBM);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int o = ob[j] + kk * 32 * 2 * TBN;
+                    fbh[j] = tr_read_pair(smem + 2 * TA, o, o + 4 * 2 * TBN);
+                    fbl[j] = tr_read_pair(smem + 3 * TA, o, o + 4 * 2 * TBN);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        mma16(fbh[j], fah[i], acc[i][j]);
+                        mma16(fbh[j], fal[i], acc[i][j]);
+                        mma16(fbl[j], fah[i], acc[i][j]);
+                    }
+            }
+        }
+    } else
     for (int pass = 0; pass < (X3 ? 3 : 1); ++pass) {
     if constexpr (X3) {
         sa = sa_base + (pass == 1 ? P.planeA : 0);
@@ -409,8 +460,10 @@ __global__ __launch_bounds__(512, 1) void wgrad_group_p8_kernel(WgArgs a) {
 extern "C" int mmtg_wgrad_group(int config, int n, const mmtg_wgrad_problem* probs, int K, int splits, float* ws, long ws_floats,
                                 unsigned* counters, long n_counters, int accumulate, void* stream) {
     const bool x3 = (config & 2) != 0;             // split-precision operands (plane pairs), 128x128 tiles only
-    config &= ~2;
-    MMTG_REQUIRE(config == 0 || (config == 1 && !x3), "wgrad_group: config 0 (128x128 tiles), 1 (256x256 eight-phase tiles) or 2 (128x128 tiles, x3 operands)");
+    const bool x3c = x3 && (config & 4) != 0;      // ... on combined stages (all four planes of a K tile per stage, two workgroups per CU)
+    config &= ~6;
+    MMTG_REQUIRE(config == 0 || (config == 1 && !x3),
+                 "wgrad_group: config 0 (128x128 tiles), 1 (256x256 eight-phase tiles), 2 (128x128 tiles, x3 operands) or 6 (x3, combined stages)");
     const int TB = config ? 256 : 128, NWV = config ? 8 : 4, KQ = config ? 128 : 64;
     MMTG_REQUIRE(n >= 1 && n <= WG_MAXP && probs, "wgrad_group: 1..%d problems", WG_MAXP);
     MMTG_REQUIRE(K > 0 && splits >= 1, "wgrad_group: K and splits must be positive");
@@ -473,7 +526,16 @@ extern "C" int mmtg_wgrad_group(int config, int n, const mmtg_wgrad_problem* pro
         attr_done = true;
     }
     static const int ablate = getenv("MMTG_WGRAD_ABLATE") ? atoi(getenv("MMTG_WGRAD_ABLATE")) : 0;
-    if (x3) {
+    if (x3c) {        // combined stages: A hi | A lo | B hi | B lo
+        const size_t shmc = 2 * shm;
+        static bool x3c_done = false;
+        if (!x3c_done) {
+            if (hipFuncSetAttribute((const void*)wgrad_group_kernel<false, 0, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmc) != hipSuccess)
+                MMTG_FAIL(MMTG_ERR_HIP, "wgrad_group: cannot raise dynamic LDS to %zu bytes", shmc);
+            x3c_done = true;
+        }
+        hipLaunchKernelGGL((wgrad_group_kernel<false, 0, true, true>), dim3(tiles * splits), dim3(256), shmc, s, a);
+    } else if (x3) {
         static bool x3_done = false;
         if (!x3_done) {
             if (hipFuncSetAttribute((const void*)wgrad_group_kernel<false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)

@@ -225,6 +225,9 @@ _LMHEAD_GROUP = _os.environ.get("MMTG_LMHEAD_GROUP", "1") != "0"      # the tied
 _LMHEAD_GROUP_SPLITS = int(_os.environ.get("MMTG_LMHEAD_GROUP_SPLITS", "0"))
 # the grouped weight-gradient launches on a SIDE stream, one block behind the dgrad chain (MMTG_WGRAD_STREAM; see Engine.backward)
 _WGRAD_STREAM = _os.environ.get("MMTG_WGRAD_STREAM", "0") != "0"
+# x3 grouped weight gradients: config 6 = combined stages (all four planes of a K tile per 64 KB stage, two workgroups per CU: 512
+# slots), MMTG_WGRAD_X3_COMBINED=0 = config 2, three passes over 32 KB stages at four workgroups per CU (A/B switch)
+_X3_WG_CFG = 6 if _os.environ.get("MMTG_WGRAD_X3_COMBINED", "1") != "0" else 2
 _WGRAD_GROUP_CFG = int(_os.environ.get("MMTG_WGRAD_GROUP_CFG", "0"))          # 0: 128x128 tiles, four workgroups per CU; 1: 256x256 eight-phase
 
 
@@ -234,6 +237,21 @@ def _group_splits(tiles, K, slots=1024):
     if _WGRAD_GROUP_SPLITS > 0:
         return _WGRAD_GROUP_SPLITS
     return int(max(1, min(slots // max(1, tiles), K // 1024, 16)))
+
+
+def _group_splits_x3(tiles, K):
+    """K splits of a split-precision grouped launch.  Combined stages (config 6, two workgroups per CU = 512 slots), measured at
+    K = 15104 (tools/bench_wgrad_x3.py): one full round when the tiles fit (projector: 88 tiles x 5 = 122 us against 172 at x 6),
+    else about four rounds' worth (tied embedding, 630 tiles: x 3 = 783 us, x 2 = 845, x 1 = 1054); a block's 432 tiles run within
+    2 % of their best at any count from 1 to 5."""
+    if _X3_WG_CFG != 6:
+        return _group_splits(tiles, K)
+    if _WGRAD_GROUP_SPLITS > 0:
+        return _WGRAD_GROUP_SPLITS
+    s = 512 // max(1, tiles)
+    if s == 0:
+        s = 2048 // tiles
+    return int(max(1, min(s, K // 1024, 16)))
 
 
 def _wgrad_splits_p8(M, N, K, cus=256):
@@ -996,13 +1014,13 @@ class Engine:
             dlp = dlogits if isinstance(dlogits, hip.Planes) else hip.split_planes(dlogits, M, Vp, self.pbuf("dlogits_p", M, Vp))
             hip.gemm_x3(dlp, hip.Planes(self.wte_t, D, Vp), dhf, M, D, Vp)
             tiles = hip.wgrad_group_sizes(((Vp, D),), 1, 0)[0]
-            hs = _LMHEAD_GROUP_SPLITS or _group_splits(tiles, M)
+            hs = _LMHEAD_GROUP_SPLITS or _group_splits_x3(tiles, M)
             _, nws, ncnt = hip.wgrad_group_sizes(((Vp, D),), hs, 0)
             hws = self.buf("wgrad_group_ws_head", (nws,), torch.float32) if hs > 1 else None
             hcnt = self.ws.get(("wgrad_group_cnt", torch.int32))
             if hcnt is None or hcnt.numel() < ncnt:
                 hcnt = self.ws[("wgrad_group_cnt", torch.int32)] = torch.zeros(ncnt, device=self.dev, dtype=torch.int32)
-            hip.wgrad_group([(dlp, a["hf"], self.Gp("wte"), Vp, D, Vp, D, D)], M, hs, hws, hcnt, accumulate=not self.wgrad_overwrite, config=2)
+            hip.wgrad_group([(dlp, a["hf"], self.Gp("wte"), Vp, D, Vp, D, D)], M, hs, hws, hcnt, accumulate=not self.wgrad_overwrite, config=_X3_WG_CFG)
             if self.wgrad_overwrite and self._ow_rec is not None:
                 self._ow_rec[1].append((self.layout.pack_range["wte"][0], Vp * D))
         elif getattr(self, "wte_t", None) is not None and Vp % 128 == 0:
@@ -1052,7 +1070,7 @@ class Engine:
             gshapes = ((D, 4 * D), (4 * D, D), (D, D), (D, 3 * D))
             gcfg = 1 if (_WGRAD_GROUP_CFG and D >= 256 and not x3) else 0
             gtiles = hip.wgrad_group_sizes(gshapes, 1, gcfg)[0]
-            gsplits = _group_splits(gtiles, M, 256 if gcfg else 1024)
+            gsplits = _group_splits_x3(gtiles, M) if x3 else _group_splits(gtiles, M, 256 if gcfg else 1024)
             _, nws, ncnt = hip.wgrad_group_sizes(gshapes, gsplits, gcfg)
             gws = self.buf("wgrad_group_ws", (nws,), torch.float32) if gsplits > 1 else None
             gcnt = self.ws.get(("wgrad_group_cnt", torch.int32))
@@ -1119,7 +1137,7 @@ class Engine:
                 keys = (p + "mlp.c_fc.weight", p + "mlp.c_proj.weight", p + "attn.c_proj.weight", p + "attn.c_attn.weight")
                 probs = [(m2, dup, self.G(keys[0]), D, 4 * D), (gact, dyp, self.G(keys[1]), 4 * D, D),
                          (ctxp, dy2p, self.G(keys[2]), D, D), (a1, dqkvp, self.G(keys[3]), D, 3 * D)]
-                hip.wgrad_group(probs, M, gsplits, gws, gcnt, accumulate=not self.wgrad_overwrite, config=2)
+                hip.wgrad_group(probs, M, gsplits, gws, gcnt, accumulate=not self.wgrad_overwrite, config=_X3_WG_CFG)
                 if self.wgrad_overwrite and self._ow_rec is not None:
                     self._ow_rec[1].extend((self.layout.entries[k][0], self.layout.entries[k][2]) for k in keys)
                 if l > 0:
@@ -1227,7 +1245,7 @@ class Engine:
             hip.gemm_x3(dxp, self.Wtx("decoder.projector_layer2.weight"), dh1, M, H, D, planes=dh1p, epi=hip.EPI_DTANH, aux=a["h1"], ldaux=H)
             pshapes = ((D, H), (H, E))
             ptiles = hip.wgrad_group_sizes(pshapes, 1, 0)[0]
-            psplits = _group_splits(ptiles, M)
+            psplits = _group_splits_x3(ptiles, M)
             _, pnws, pncnt = hip.wgrad_group_sizes(pshapes, psplits, 0)
             pws = self.buf("wgrad_group_ws_proj", (pnws,), torch.float32) if psplits > 1 else None
             pcnt = self.ws.get(("wgrad_group_cnt", torch.int32))
@@ -1238,7 +1256,7 @@ class Engine:
                 if self._lazy is not None and (self.layout.entries[k][0], self.layout.entries[k][2]) in self._lazy and not self.wgrad_overwrite:
                     self.G(k).zero_()
             hip.wgrad_group([(dxp, a["h1p"], self.G(pkeys[0]), D, H), (dh1p, a["xp"], self.G(pkeys[1]), H, E)], M, psplits, pws, pcnt,
-                            accumulate=not self.wgrad_overwrite, config=2)
+                            accumulate=not self.wgrad_overwrite, config=_X3_WG_CFG)
             if self.wgrad_overwrite and self._ow_rec is not None:
                 self._ow_rec[1].extend((self.layout.entries[k][0], self.layout.entries[k][2]) for k in pkeys)
             hip.colsum(dx, M, D, self.G("decoder.projector_layer2.bias"))

@@ -142,8 +142,9 @@ def test_layernorm_fwd_x3_vs_torch():
         assert (mu.double() - x.double().mean(1)).abs().max().item() < 1e-5
 
 
+@pytest.mark.parametrize("config", [2, 6])        # 2: three passes over (A | B) stages; 6: one loop over combined four-plane stages
 @pytest.mark.parametrize("K,splits", [(1024, 1), (3000, 2), (4096, 4)])
-def test_wgrad_group_x3_vs_float64(K, splits):
+def test_wgrad_group_x3_vs_float64(K, splits, config):
     g = torch.Generator(device=DEV).manual_seed(K)
     shapes = ((768, 3072), (256, 768), (136, 264))
     probs, refs = [], []
@@ -156,12 +157,12 @@ def test_wgrad_group_x3_vs_float64(K, splits):
     tiles, nws, ncnt = hip.wgrad_group_sizes(shapes, splits, 0)
     ws = torch.empty(nws, device=DEV) if splits > 1 else None
     cnt = torch.zeros(ncnt, dtype=torch.int32, device=DEV)
-    hip.wgrad_group(probs, K, splits, ws, cnt, accumulate=False, config=2)
+    hip.wgrad_group(probs, K, splits, ws, cnt, accumulate=False, config=config)
     for (pr, (ref, scale)) in zip(probs, refs):
         assert (pr[2].double() - ref).abs().max().item() < 4e-5 * scale
     assert int(cnt.abs().sum().item()) == 0
     first = [pr[2].clone() for pr in probs]
-    hip.wgrad_group(probs, K, splits, ws, cnt, accumulate=True, config=2)          # accumulate: exactly twice the first result
+    hip.wgrad_group(probs, K, splits, ws, cnt, accumulate=True, config=config)     # accumulate: exactly twice the first result
     for pr, f in zip(probs, first):
         assert torch.equal(pr[2], f + f)
 
