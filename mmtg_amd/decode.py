@@ -488,11 +488,15 @@ class GreedyDecoder:
         B, T, nH = a["B"], a["T"], sh.nH
         for l, rec in enumerate(a["layers"]):
             qkv = rec[4]
-            if isinstance(qkv, hip.Planes):        # bf16x3: c_attn writes a (hi | lo) plane pair; the cache holds fp32 rows
-                qkv = qkv.float()
-            qkv = qkv.view(B, T, 3, nH, 64)
-            self.kc[l][:, :, :P].copy_(qkv[:, :P, 1].permute(0, 2, 1, 3))
-            self.vc[l][:, :, :P].copy_(qkv[:, :P, 2].permute(0, 2, 1, 3))
+            if isinstance(qkv, hip.Planes):        # bf16x3: c_attn writes a (hi | lo) plane pair [2, M, 3D]; the cache holds fp32 rows
+                hi, lo = qkv.t[0].view(B, T, 3, nH, 64), qkv.t[1].view(B, T, 3, nH, 64)
+                kv = hi[:, :P, 1:3].float() + lo[:, :P, 1:3].float()           # [B, P, 2, nH, 64]: only what the cache takes
+                k, v = kv[:, :, 0], kv[:, :, 1]
+            else:
+                qkv = qkv.view(B, T, 3, nH, 64)
+                k, v = qkv[:, :P, 1], qkv[:, :P, 2]
+            self.kc[l][:, :, :P].copy_(k.permute(0, 2, 1, 3))
+            self.vc[l][:, :, :P].copy_(v.permute(0, 2, 1, 3))
         self.keep[:, :P] = (self.tpw_mask != 0).to(torch.int32)
         self.pos_all.fill_(P)
         self.first_pos = P

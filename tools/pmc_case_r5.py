@@ -46,7 +46,7 @@ for _ in range(3):
     hip.gemm_x3(x, wp, c2, M, D, D, bias=b2, epi=hip.EPI_RESID, aux=res, ldaux=D, drop_p=0.1, drop_seed=3)
     hip.gemm_x3(h, w2, c2, M, D, 4 * D, bias=b2, epi=hip.EPI_RESID, aux=res, ldaux=D, drop_p=0.1, drop_seed=4)
     hip.gemm_x3(dy, w2t, None, M, 4 * D, D, planes=dup, ldc=4 * D, epi=hip.EPI_DGELU, aux=pre, ldaux=4 * D, aux2=bands)
-    hip.wgrad_group(probs, M, 2, ws, cnt, config=2)
+    hip.wgrad_group(probs, M, 2, ws, cnt, config=6)
     hip.attn_fwd_x3(qkvp, keep, out, outp, lse, B, T, nH, 64, drop_p=0.1, drop_seed=1)
     hip.attn_bwd_x3(qkvp, keep, out, doutp, lse, delta, dq32, dqp, B, T, nH, 64, drop_p=0.1, drop_seed=1, dbias=torch.zeros(3 * D, device=dev), dbias_ws=aws)
     hip.layernorm_fwd_x3(xf, lnp, gam, bet, mu, rs, M, D)
