@@ -213,15 +213,16 @@ MMTG_API int mmtg_attn_fwd(int dtype, const void* qkv, const int* keep, void* ou
  * what mmtg_gemm_x3 writes for c_attn / the c_proj dgrad); out fp32.  Forward: context rows to `out` (fp32: the backward's delta
  * reads them) AND, when out_planes is given, to a plane pair [B*T, D] (attn.c_proj's operand).  Backward: d(qkv) is written ONLY as
  * a plane pair [B*T, 3D] (lo plane dplane elements behind): the c_attn dgrad / weight gradient read nothing else.  dq32: fp32
- * [B*T, D] scratch (zeroed by the call; key blocks of 128 add into it with fp32 atomics); delta: [B*T, nH] scratch; dbias
+ * scratch of dq32_floats >= ceil(T/128) * B*T * D floats (one [B*T, D] buffer per block of 128 keys: plain stores, summed in block
+ * order by the finish kernel -- no atomics, bit-reproducible); delta: [B*T, nH] scratch; dbias
  * (nullable): [3D] += column sums of d(qkv), through dbias_ws (>= (B * ceil(T/128) + ceil(B*T/16)) * 3D floats); delta_ready != 0:
  * delta[m, h] = sum_d dout * out was filled by the caller (mmtg_gemm_x3's MMTG_EPI_ROWDOT epilogue does it for free).           */
 MMTG_API int mmtg_attn_fwd_x3(const void* qkv_planes, long qplane, const int* keep, float* out, void* out_planes, long plane, float* lse,
                      int B, int T, int nH, int dh, unsigned drop_thresh, unsigned drop_seed, void* stream);
 MMTG_API int mmtg_attn_bwd_x3(const void* qkv_planes, long qplane, const int* keep, const float* out, const void* dout_planes, long doplane,
                      const float* lse, float* delta,
-                     int delta_ready, float* dq32, void* dqkv_planes, long dplane, float* dbias, float* dbias_ws, long dbias_ws_floats,
-                     int B, int T, int nH, int dh, unsigned drop_thresh, unsigned drop_seed, void* stream);
+                     int delta_ready, float* dq32, long dq32_floats, void* dqkv_planes, long dplane, float* dbias, float* dbias_ws,
+                     long dbias_ws_floats, int B, int T, int nH, int dh, unsigned drop_thresh, unsigned drop_seed, void* stream);
 /* delta: [B*T, nH] f32, delta[m,h] = sum_d dout[m,h,d] * out[m,h,d]: computed by the call, or --
  * delta_ready != 0 -- already filled by the caller (the GEMM producing dout with
  * MMTG_EPI_ROWDOT does it for free); dq32: [B*T, D] f32 scratch (zeroed by the call);

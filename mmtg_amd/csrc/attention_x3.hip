@@ -198,7 +198,7 @@ constexpr int XIMG_K = XKB * 128, XIMG_Q = 32 * 128, XIMG_DS = 32 * XRBS;      /
 
 __global__ __launch_bounds__(64 * XNW, 1) void attn_bwd_x3_kernel(const bf16* __restrict__ qkv, long qplane, const int* __restrict__ keep,
         const bf16* __restrict__ d_out, long doplane, const float* __restrict__ lse, const float* __restrict__ delta,
-        float* __restrict__ dq32, bf16* __restrict__ dqkv_p, long dplane, float* __restrict__ dbias, int Tn, int nH,
+        float* __restrict__ dq32, long dq_stride, bf16* __restrict__ dqkv_p, long dplane, float* __restrict__ dbias, int Tn, int nH,
         uint32_t drop_thresh, uint32_t drop_seed, float inv_keep) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const sKr = smem + BwdLds::KR;
@@ -375,7 +375,9 @@ __global__ __launch_bounds__(64 * XNW, 1) void attn_bwd_x3_kernel(const bf16* __
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int q = q0 + qs * 16 + 4 * g + r;
-                if (q < Tn) atomicAdd(dq32 + ((long)b * Tn + q) * D + h * DH + dt * 16 + l15, acc[r]);
+                // (this key block's OWN dQ buffer, plain stores: every (query tile, key block) pair belongs to exactly one workgroup;
+                //  the finish kernel adds the blocks in order -- no atomics, no zero fill, the same bits every run)
+                if (q < Tn) dq32[(long)blockIdx.x * dq_stride + ((long)b * Tn + q) * D + h * DH + dt * 16 + l15] = acc[r];
             }
         }
     }
@@ -402,10 +404,8 @@ __global__ __launch_bounds__(64 * XNW, 1) void attn_bwd_x3_kernel(const bf16* __
     // c_attn bias gradient, k and v parts: column sums over this block's keys, one partial row per workgroup (the host sums the
     // rows in a fixed order); the q part comes from the dQ finish kernel
     if (dbias) {
-        float* sB = reinterpret_cast<float*>(smem);      // [2][64], overlays the K image
+        float* sB = reinterpret_cast<float*>(smem);      // [waves][2][64], overlays the K image: a slot per wave, summed in wave order
         __syncthreads();                                  // every wave is done with the staged tiles
-        if (tid < 2 * DH) sB[tid] = 0.f;
-        __syncthreads();
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
             float sk[4], sv[4];
@@ -416,25 +416,29 @@ __global__ __launch_bounds__(64 * XNW, 1) void attn_bwd_x3_kernel(const bf16* __
 #pragma unroll
                 for (int o = 1; o < 16; o <<= 1) { sk[r] += __shfl_xor(sk[r], o, 64); sv[r] += __shfl_xor(sv[r], o, 64); }
                 if (l15 == 0) {
-                    atomicAdd(sB + dt * 16 + 4 * g + r, sk[r]);
-                    atomicAdd(sB + DH + dt * 16 + 4 * g + r, sv[r]);
+                    sB[wave * 2 * DH + dt * 16 + 4 * g + r] = sk[r];
+                    sB[wave * 2 * DH + DH + dt * 16 + 4 * g + r] = sv[r];
                 }
             }
         }
         __syncthreads();
         if (tid < 2 * DH) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < XNW; ++w) t += sB[w * 2 * DH + tid];
             const int col = (1 + tid / DH) * D + h * DH + tid % DH;
-            dbias[((long)b * gridDim.x + blockIdx.x) * 3 * D + col] = sB[tid];
+            dbias[((long)b * gridDim.x + blockIdx.x) * 3 * D + col] = t;
         }
         if (tid < DH) dbias[((long)b * gridDim.x + blockIdx.x) * 3 * D + h * DH + tid] = 0.f;      // (q part: the finish kernel's)
     }
 }
 
-// dq32 [rows, D] (fp32, summed over the key blocks by atomics) -> the q columns of d(qkv)'s plane pair + their column sums
+// dq32 [key blocks][rows, D] (fp32: block kb holds the rows of the queries q >= 128 kb) -> their sum in block order = the q columns of
+// d(qkv)'s plane pair + their column sums
 // (the q part of the c_attn bias gradient): one workgroup per 16-row band (a wave per 4 rows x 256 columns at a time), partial
 // sums to qsum[band][D] (the host sums the bands in a fixed order)
 constexpr int XFB = 16;      // rows per band
-__global__ __launch_bounds__(256) void attn_dq_finish_x3_kernel(const float* __restrict__ dq32, bf16* __restrict__ dqkv_p, long dplane,
+__global__ __launch_bounds__(256) void attn_dq_finish_x3_kernel(const float* __restrict__ dq32, long dq_stride, int Tn, bf16* __restrict__ dqkv_p, long dplane,
                                                                float* __restrict__ qsum, long rows, int D) {
     __shared__ float sred[4][1024];
     const long r0 = (long)blockIdx.x * XFB;
@@ -447,7 +451,9 @@ __global__ __launch_bounds__(256) void attn_dq_finish_x3_kernel(const float* __r
             for (int i = 0; i < XFB / 4; ++i) {
                 const long r = r0 + wave * (XFB / 4) + i;
                 if (r < rows) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(dq32 + r * D + c);
+                    const int nb = (int)(r % Tn) / XKB + 1;                  // key blocks that hold keys <= this query
+                    f32x4 v = *reinterpret_cast<const f32x4*>(dq32 + r * D + c);
+                    for (int kb = 1; kb < nb; ++kb) v += *reinterpret_cast<const f32x4*>(dq32 + kb * dq_stride + r * D + c);
                     bf16x4 hi, lo;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { hi[e] = (bf16)v[e]; lo[e] = (bf16)(v[e] - (float)hi[e]); cs[e] += v[e]; }
@@ -504,13 +510,14 @@ extern "C" int mmtg_attn_fwd_x3(const void* qkv_planes, long qplane, const int* 
 
 /* Backward of mmtg_attn_fwd_x3.  qkv [B*T, 3D] and dout [B*T, D] as (hi | lo) bf16 plane pairs (lo planes `qplane` / `doplane` elements
  * behind), out fp32; d(qkv) is written as a plane pair [B*T, 3D] (lo plane `dplane` elements behind) -- the c_attn dgrad and weight
- * gradient are split-precision products and nothing else reads it.  dq32: fp32
- * [B*T, D] scratch (zeroed by the call; the key blocks add into it with fp32 atomics); delta: [B*T, nH] scratch; dbias (nullable):
+ * gradient are split-precision products and nothing else reads it.  dq32: fp32 scratch of ceil(T / 128) x [B*T, D] floats (every block
+ * of 128 keys stores its dQ contribution into its own buffer, the finish kernel adds them in block order: no atomics, bit-reproducible);
+ * delta: [B*T, nH] scratch; dbias (nullable):
  * [3D] += column sums of d(qkv); dbias_ws: >= (B * ceil(T / 128) + ceil(B*T / 16)) * 3D floats;
  * delta_ready != 0: delta was filled by the caller (the c_proj dgrad's MMTG_EPI_ROWDOT epilogue). */
 extern "C" int mmtg_attn_bwd_x3(const void* qkv_planes, long qplane, const int* keep, const float* out, const void* dout_planes, long doplane,
                                 const float* lse, float* delta,
-                                int delta_ready, float* dq32, void* dqkv_planes, long dplane, float* dbias, float* dbias_ws, long dbias_ws_floats,
+                                int delta_ready, float* dq32, long dq32_floats, void* dqkv_planes, long dplane, float* dbias, float* dbias_ws, long dbias_ws_floats,
                                 int B, int T, int nH, int dh, unsigned drop_thresh, unsigned drop_seed, void* stream) {
     MMTG_REQUIRE(dh == DH, "attn_bwd_x3: head dim %d unsupported (built for 64)", dh);
     MMTG_REQUIRE(B > 0 && T > 0 && nH > 0 && qkv_planes && keep && out && dout_planes && lse && delta && dq32 && dqkv_planes,
@@ -521,6 +528,7 @@ extern "C" int mmtg_attn_bwd_x3(const void* qkv_planes, long qplane, const int* 
                  doplane >= rows * D && MMTG_ALIGNED16(dq32) && (((uintptr_t)dqkv_planes) & 7) == 0 && dplane % 4 == 0 && dplane >= rows * 3 * D,
                  "attn_bwd_x3: alignment / plane layout");
     const int nkb = cdiv(T, XKB), nband = cdiv(rows, XFB);
+    MMTG_REQUIRE(dq32_floats >= (long)nkb * rows * D, "attn_bwd_x3: dq32 needs %ld floats (one [B*T, D] buffer per block of 128 keys)", (long)nkb * rows * D);
     MMTG_REQUIRE(!dbias || (dbias_ws && dbias_ws_floats >= ((long)B * nkb + nband) * 3 * D), "attn_bwd_x3: the bias gradient needs %ld workspace floats",
                  ((long)B * nkb + nband) * 3 * D);
     hipStream_t s = (hipStream_t)stream;
@@ -533,12 +541,11 @@ extern "C" int mmtg_attn_bwd_x3(const void* qkv_planes, long qplane, const int* 
     }
     if (!delta_ready)
         hipLaunchKernelGGL(attn_delta_x3_kernel, dim3(cdiv(rows * nH, 4)), dim3(256), 0, s, out, (const bf16*)dout_planes, doplane, delta, nH, rows);
-    if (hipMemsetAsync(dq32, 0, rows * D * sizeof(float), s) != hipSuccess) MMTG_FAIL(MMTG_ERR_HIP, "attn_bwd_x3: memset failed");
     float* const kv_rows = dbias ? dbias_ws : nullptr;                       // [B * nkb][3D]: k and v parts (q part zero)
     float* const q_rows = dbias ? dbias_ws + (long)B * nkb * 3 * D : nullptr; // [nband][D]
-    hipLaunchKernelGGL(attn_bwd_x3_kernel, dim3(nkb, nH, B), dim3(64 * XNW), BwdLds::END, s, (const bf16*)qkv_planes, qplane, keep, (const bf16*)dout_planes, doplane, lse, delta, dq32, (bf16*)dqkv_planes, dplane,
+    hipLaunchKernelGGL(attn_bwd_x3_kernel, dim3(nkb, nH, B), dim3(64 * XNW), BwdLds::END, s, (const bf16*)qkv_planes, qplane, keep, (const bf16*)dout_planes, doplane, lse, delta, dq32, rows * D, (bf16*)dqkv_planes, dplane,
                        kv_rows, T, nH, drop_thresh, drop_seed, inv_keep_x3(drop_thresh));
-    hipLaunchKernelGGL(attn_dq_finish_x3_kernel, dim3(nband), dim3(256), 0, s, dq32, (bf16*)dqkv_planes, dplane, q_rows, rows, D);
+    hipLaunchKernelGGL(attn_dq_finish_x3_kernel, dim3(nband), dim3(256), 0, s, dq32, rows * D, T, (bf16*)dqkv_planes, dplane, q_rows, rows, D);
     MMTG_LAUNCH_CHECK("attn_bwd_x3");
     if (dbias) {
         int rc = mmtg_colsum(MMTG_F32, kv_rows, 3 * D, B * nkb, 3 * D, dbias, nullptr, 0, stream);

@@ -1108,7 +1108,8 @@ class Engine:
             wdone = {}
         da = self.buf("d_a", (M, D))
         delta = self.buf("attn_delta", (M, sh.nH), torch.float32)
-        dq32 = self.buf("attn_dq32", (M, D), torch.float32)
+        # (x3: one [M, D] buffer per block of 128 keys -- plain stores summed in block order, no atomics)
+        dq32 = self.buf("attn_dq32", (hip.attn_bwd_x3_dq_floats(B, T, D),) if x3 else (M, D), torch.float32)
         for l in range(sh.L - 1, -1, -1):
             p = f"{pre}h.{l}."
             (xin, mu1, rs1, a1, qkv, ctx, lse, xmid, mu2, rs2, m2, u, gact, s, ctxp) = a["layers"][l]

@@ -47,7 +47,7 @@ _SIGS = {
     "mmtg_layernorm_bwd_x3": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _l, _u, _u, _vp, _vp, _l, _vp], _i),
     "mmtg_attn_fwd": ([_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _u, _u, _vp], _i),
     "mmtg_attn_fwd_x3": ([_vp, _l, _vp, _vp, _vp, _l, _vp, _i, _i, _i, _i, _u, _u, _vp], _i),
-    "mmtg_attn_bwd_x3": ([_vp, _l, _vp, _vp, _vp, _l, _vp, _vp, _i, _vp, _vp, _l, _vp, _vp, _l, _i, _i, _i, _i, _u, _u, _vp], _i),
+    "mmtg_attn_bwd_x3": ([_vp, _l, _vp, _vp, _vp, _l, _vp, _vp, _i, _vp, _l, _vp, _l, _vp, _vp, _l, _i, _i, _i, _i, _u, _u, _vp], _i),
     "mmtg_attn_trace": ([_vp], _i),
     "mmtg_attn_bwd": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _u, _u, _vp], _i),
     "mmtg_embed_condition": ([_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
@@ -360,6 +360,11 @@ def attn_fwd_x3(qkv_planes, keep, out, out_planes, lse, B, T, nH, dh, drop_p=0.0
                                   drop_thresh(drop_p), drop_seed & 0xFFFFFFFF, _stream()), "attn_fwd_x3")
 
 
+def attn_bwd_x3_dq_floats(B, T, D):
+    """Floats of attn_bwd_x3's dq32 scratch: one [B*T, D] buffer per block of 128 keys."""
+    return (-(-T // 128)) * B * T * D
+
+
 def attn_bwd_x3_ws(B, T, D):
     """Floats of the dbias workspace of attn_bwd_x3."""
     return (B * (-(-T // 128)) + -(-(B * T) // 16)) * 3 * D
@@ -368,11 +373,11 @@ def attn_bwd_x3_ws(B, T, D):
 def attn_bwd_x3(qkv_planes, keep, out, dout_planes, lse, delta, dq32, dqkv_planes, B, T, nH, dh, drop_p=0.0, drop_seed=0, dbias=None,
                 dbias_ws=None, delta_ready=False):
     """Split-precision attention backward: qkv [B*T, 3D] and d(ctx) [B*T, D] as Planes, out fp32; d(qkv) as the Planes
-    ``dqkv_planes`` [B*T, 3D]."""
+    ``dqkv_planes`` [B*T, 3D]; dq32: fp32 scratch of attn_bwd_x3_dq_floats(B, T, D) elements."""
     if qkv_planes.ld != 3 * nH * dh or dout_planes.ld != nH * dh or dqkv_planes.ld != 3 * nH * dh:
         raise ValueError("attn_bwd_x3: the plane pairs must be dense (ld = columns)")
     _check(lib().mmtg_attn_bwd_x3(_p(qkv_planes.t), qkv_planes.plane, _p(keep), _p(out), _p(dout_planes.t), dout_planes.plane, _p(lse), _p(delta),
-                                  int(delta_ready), _p(dq32), _p(dqkv_planes.t), dqkv_planes.plane,
+                                  int(delta_ready), _p(dq32), dq32.numel(), _p(dqkv_planes.t), dqkv_planes.plane,
                                   _p(dbias), _p(dbias_ws), 0 if dbias_ws is None else dbias_ws.numel(), B, T, nH, dh,
                                   drop_thresh(drop_p), drop_seed & 0xFFFFFFFF, _stream()), "attn_bwd_x3")
 

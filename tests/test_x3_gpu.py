@@ -220,7 +220,12 @@ def test_attention_x3_matches_the_exact_fp32_kernels(B, T, drop):
     db = torch.zeros(3 * D, device=DEV)
     ws3 = torch.empty(hip.attn_bwd_x3_ws(B, T, D), device=DEV)
     doutp = hip.split_planes(dout, B * T, D, hip.Planes.empty(B * T, D, DEV))           # ... and the c_proj dgrad
-    hip.attn_bwd_x3(qkvp, keep, out, doutp, lse, torch.empty_like(delta), dq32, dqp, B, T, nH, dh, drop_p=drop, drop_seed=seed, dbias=db, dbias_ws=ws3)
+    dqs = torch.full((hip.attn_bwd_x3_dq_floats(B, T, D),), float("nan"), device=DEV)      # (never zeroed: every element read is written first)
+    hip.attn_bwd_x3(qkvp, keep, out, doutp, lse, torch.empty_like(delta), dqs, dqp, B, T, nH, dh, drop_p=drop, drop_seed=seed, dbias=db, dbias_ws=ws3)
     scale = dqkv32.abs().max().item()
     assert (dqp.float() - dqkv32).abs().max().item() < 4e-5 * scale, ((dqp.float() - dqkv32).abs().max().item(), scale)
     assert (db - db32).abs().max().item() < 1e-4 * max(1.0, db32.abs().max().item())
+    # no atomics anywhere in the split-precision backward: a second run gives the same bits
+    dqp2, db2 = hip.Planes.empty(B * T, 3 * D, DEV), torch.zeros(3 * D, device=DEV)
+    hip.attn_bwd_x3(qkvp, keep, out, doutp, lse, torch.empty_like(delta), dqs, dqp2, B, T, nH, dh, drop_p=drop, drop_seed=seed, dbias=db2, dbias_ws=ws3)
+    assert torch.equal(dqp2.t, dqp.t) and torch.equal(db2, db)

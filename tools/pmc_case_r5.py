@@ -32,7 +32,7 @@ keep = torch.ones(B, T, dtype=torch.int32, device=dev)
 out, outp, dout = torch.empty(M, D, device=dev), hip.Planes.empty(M, D, dev), f(M, D) * 0.1
 lse, delta = torch.empty(B, nH, T, device=dev), torch.empty(M, nH, device=dev)
 doutp = P(dout)
-dq32, dqp = torch.empty(M, D, device=dev), hip.Planes.empty(M, 3 * D, dev)
+dq32, dqp = torch.empty(hip.attn_bwd_x3_dq_floats(B, T, D), device=dev), hip.Planes.empty(M, 3 * D, dev)
 aws = torch.empty(hip.attn_bwd_x3_ws(B, T, D), device=dev)
 gam, bet = torch.ones(D, device=dev), torch.zeros(D, device=dev)
 mu, rs = torch.zeros(M, device=dev), torch.ones(M, device=dev)
