@@ -400,3 +400,15 @@ def test_split_precision_mode_host_contract():
     assert torch.equal(p.float(), t[0].float() + t[1].float())
     sub = hip.Planes(t[0, :, 4:], 3, 4, ld=8, plane=24)        # a column block of both planes
     assert sub.t.data_ptr() == t.data_ptr() + 8 and sub.plane == 24
+    # scratch sizes the mode's host code hands the library (include/mmtg_hip.h): one dQ buffer per block of 128 keys, the
+    # attention bias-gradient rows; and the K-split rule of its grouped weight gradients (combined stages: 512 workgroup slots)
+    assert hip.attn_bwd_x3_dq_floats(64, 236, 768) == 2 * 64 * 236 * 768
+    assert hip.attn_bwd_x3_dq_floats(1, 128, 768) == 128 * 768 and hip.attn_bwd_x3_dq_floats(2, 129, 64) == 2 * 2 * 129 * 64
+    assert hip.attn_bwd_x3_ws(64, 236, 768) == (64 * 2 + (64 * 236 + 15) // 16) * 3 * 768
+    from mmtg_amd import engine as E
+    if E._X3_WG_CFG == 6 and E._WGRAD_GROUP_SPLITS <= 0:
+        assert E._group_splits_x3(432, 15104) == 1          # a GPT-2 block: one round of 432 workgroups
+        assert E._group_splits_x3(88, 15104) == 5           # the projector: 440 workgroups
+        assert E._group_splits_x3(630, 15104) == 3          # the tied embedding: ~4 rounds' worth
+        assert E._group_splits_x3(88, 2048) == 2            # never a K slice under 1024 tokens
+        assert E._group_splits_x3(4, 10 ** 6) == 16
