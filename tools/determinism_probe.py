@@ -28,7 +28,7 @@ rows = int(os.environ.get("ROWS", "64" if os.environ.get("FULL") else "12"))
 for trial in range(int(os.environ.get("TRIALS", "8"))):
     grads = []
     for rep in range(2):
-        model, mcfg, dcfg, V = build("bf16", 0.1, dev)
+        model, mcfg, dcfg, V = build(os.environ.get("DTYPE", "bf16"), 0.1, dev)
         tr = MMTGTrainer(model, lr=0.0, alpha=0.2, distributed=False)
         tr.eng.drop_seed = 4242
         nb = synth.make_batch(rows, mcfg, dcfg, V, seed=7)
