@@ -682,7 +682,7 @@ class Engine:
     def forward(self, batch, train_flag=True, training=False, per_row_infer=True, need_logits=True, logits_f32=True,
                 encode_only=False):
         """MMTG.forward (model.py:356-400).  Returns dict(logits_pad [M,Vpad] f32, B, T, ...);
-        lm_loss / kl are device scalars in self.scalars after loss().  need_logits=False stops after the last block (no ln_f, no
+        lm_loss / kl are device scalars in self.scalars after loss().  need_logits=False stops after the last block's c_attn (no ln_f, no
         LM head: the decoder's prompt prefill reads the blocks' K / V rows only); encode_only=True stops after the fuser."""
         sh = self.sh
         if self.table is None:
@@ -831,6 +831,9 @@ class Engine:
                 hip.layernorm_fwd_x3(hcur, a1, self.P(p + "ln_1.weight"), self.P(p + "ln_1.bias"), mu1, rs1, M, D, sh.eps)
                 qkv = self.pbuf(f"l{l}_qkvp", M, 3 * D)
                 self._fwd_x3(a1, p + "attn.c_attn.weight", None, M, bias=self.P(p + "attn.c_attn.bias"), planes=qkv, ldc=3 * D)
+                if not need_logits and l == sh.L - 1:      # (the prefill wants K / V only: nothing of the last block beyond c_attn)
+                    layers.append((hcur, mu1, rs1, a1, qkv))
+                    break
                 ctx = self.buf(f"l{l}_ctx", (M, D))
                 lse = self.buf(f"l{l}_lse", (B, sh.nH, T), torch.float32)
                 ctxp = self.pbuf(f"l{l}_ctxp", M, D)
@@ -854,6 +857,9 @@ class Engine:
             hip.layernorm_fwd(hcur, a1, self.P(p + "ln_1.weight"), self.P(p + "ln_1.bias"), mu1, rs1, M, D, sh.eps)
             qkv = self.buf(f"l{l}_qkv", (M, 3 * D))
             self._fwd(a1, p + "attn.c_attn.weight", qkv, M, "conv1d", bias=self.P(p + "attn.c_attn.bias"))
+            if not need_logits and l == sh.L - 1:          # (the prefill wants K / V only: nothing of the last block beyond c_attn)
+                layers.append((hcur, mu1, rs1, a1, qkv))
+                break
             ctx = self.buf(f"l{l}_ctx", (M, D))
             lse = self.buf(f"l{l}_lse", (B, sh.nH, T), torch.float32)
             hip.attn_fwd(qkv, keep, ctx, lse, B, T, sh.nH, D // sh.nH, drop_p=pa, drop_seed=s[0])
