@@ -476,8 +476,9 @@ class GreedyDecoder:
         """The P prompt positions in ONE batched pass instead of P token steps (a token step costs the same whatever it appends; the
         reference has no such distinction -- its every call re-runs the whole prefix, generate.py:124).  The engine's inference-branch
         forward (model.py:290-326) over [prompt, [#START#]] computes every block's K / V rows for all prompt positions at once
-        (B x (P + 1) rows through the training-side kernels of the compute mode: causal, so the rows of the P prompt positions do not
-        depend on the extra one); they go into the caches, the key mask of the prompt is the prompt's attention mask, and the token
+        (B x (P + 1) rows through the training-side kernels of the compute mode, nothing of the last block beyond its c_attn; causal,
+        so the rows of the P prompt positions do not depend on the extra one -- the conditioning kernel wants at least one lyric
+        position); they go into the caches, the key mask of the prompt is the prompt's attention mask, and the token
         steps start at position P."""
         eng, sh = self.eng, self.eng.sh
         P = sh.P
