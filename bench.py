@@ -150,6 +150,21 @@ def cpu_decode_baseline(mcfg, dcfg, gcfg, V, positions=220, seconds_budget=45.0)
                       "kv_cached = the same loop with per-layer K / V kept, all %d positions" % (V, done, positions, int(seconds_budget), positions)}
 
 
+def gpu_rewarm(dev, seconds=0.4):
+    """Keep the matrix cores busy for a moment before an optional object's warm-up: the CPU baselines leave the GPU idle for up to
+    two minutes, and the first launches after that run at ramping clocks (one default run measured its first decode generation at
+    ~400 ms instead of 90 with only the object's own one-generation warm-up in front of it).  Outside every timed region."""
+    from mmtg_amd import hip
+    a = torch.randn(4096, 4096, device=dev).bfloat16()
+    c = torch.empty(4096, 4096, device=dev, dtype=torch.bfloat16)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(20):
+            hip.gemm(a, a, c, 4096, 4096, 4096, transB=True)
+        torch.cuda.synchronize()
+
+
 def _timed(fn, world, dev):
     """barrier + synchronize on both sides of fn(); max over ranks."""
     if world > 1:
@@ -193,6 +208,8 @@ def bench_decode(args, world, rank, dev, steps, warmup, with_cpu=True):
         print({k: (v["launches"], round(v["ms"], 2)) for k, v in pr.items() if v["launches"]})
         return None
     dec = GreedyDecoder(model, max_batch=B, max_len=Ln, use_graph=not getattr(args, "decode_eager", False))
+    if not (args.no_roofline and getattr(args, "decode_eager", False)):      # (not in the counter passes: every dispatch is instrumented)
+        gpu_rewarm(dev)
     # (counter-collection passes -- eager launches under rocprofv3 --pmc -- may ask for NO warm-up generation: every dispatch is
     #  counted, and the profiler's counter pass has died on runs of much more than 10 k dispatches)
     for _ in range(warmup if (warmup == 0 and getattr(args, "decode_eager", False)) else max(1, warmup)):
@@ -428,6 +445,7 @@ def f32_object(args, dev, mcfg, dcfg, gcfg, V, steps=5, warmup=2, mode="f32"):
     model = MMTG(mcfg, dcfg, V, train_flag=True, gpt2_config=gcfg, compute_dtype=mode, token_table=synth.make_token_table(V, seed=2))
     model.reset_parameters(seed=0)
     model.to(dev).train()
+    gpu_rewarm(dev)
     trainer = MMTGTrainer(model, lr=1e-5, alpha=0.2, warmup_steps=10, total_steps=100000)
     B = args.batch
     batches = [{k: torch.from_numpy(np.asarray(v)).to(dev) for k, v in synth.make_batch(B, mcfg, dcfg, V, seed=i).items()} for i in range(2)]
@@ -493,6 +511,7 @@ def medium_object(args, dev, steps=5, warmup=3):
     model = MMTG(mcfg, dcfg, V, train_flag=True, gpt2_config=gcfg, compute_dtype="bf16", token_table=synth.make_token_table(V, seed=2))
     model.reset_parameters(seed=0)
     model.to(dev).train()
+    gpu_rewarm(dev)
     trainer = MMTGTrainer(model, lr=1e-5, alpha=0.2, warmup_steps=10, total_steps=100000)
     batches = []
     for i in range(2):
@@ -836,7 +855,7 @@ def main():
         del trainer
         model = None
         torch.cuda.empty_cache()
-        decode = bench_decode(args, world, rank, dev, steps=3, warmup=1)
+        decode = bench_decode(args, world, rank, dev, steps=5, warmup=2)
     # the optional objects below run AFTER the primary measurement and must never cost it: a failure becomes {"error": ...}
     def guarded(fn, *a, **kw):
         try:
