@@ -760,6 +760,8 @@ def main():
         for i in range(n):
             trainer.step(batches[i % 2], stage=stage)
 
+    if not os.environ.get("MMTG_BENCH_NO_REWARM"):
+        gpu_rewarm(dev)          # a fresh box's GPU has been idle: W short warm-up steps alone may still run at ramping clocks
     run(args.warmup)
     tune_steps = 0
     while getattr(trainer, "_tune", None) is not None and tune_steps < 32:
