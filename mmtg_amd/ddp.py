@@ -38,6 +38,18 @@ BUDGET_CANDIDATES = (0, -16, -32)
 TAIL_SPLIT = tuple(x for x in os.environ.get("MMTG_DDP_TAIL_SPLIT", "wpe,att_b").split(",") if x)
 
 
+def grad_exchange_dtype():
+    """MMTG_DDP_GRAD_DTYPE=bf16 (opt-in, round 6): the gradient buckets cross xGMI as bf16 -- cast, SUM all-reduce in bf16, cast
+    back into the flat fp32 buffer -- half of the 436 MB per rank and step.  For the bf16 compute mode, whose gradients carry bf16
+    rounding anyway; the default (fp32) is what the reference's arithmetic implies and what the parity tests hold."""
+    v = os.environ.get("MMTG_DDP_GRAD_DTYPE", "f32").lower()
+    if v in ("f32", "fp32", "float32"):
+        return torch.float32
+    if v in ("bf16", "bfloat16"):
+        return torch.bfloat16
+    raise ValueError("MMTG_DDP_GRAD_DTYPE must be f32 or bf16, got %r" % v)
+
+
 def cu_budget_fixed():
     """True when the environment pins the reservation (MMTG_DDP_GEMM_CUS): no self-tuning then."""
     return "MMTG_DDP_GEMM_CUS" in os.environ
@@ -107,6 +119,12 @@ class GradReducer:
             _budget_acquire()
             self._budget_set = True
         self.pack_end = {name: o + n for name, (o, n) in layout.pack_range.items()}
+        self.xdtype = grad_exchange_dtype()
+        self._stage = {}            # bucket index -> bf16 staging tensor (MMTG_DDP_GRAD_DTYPE=bf16), reused step after step
+        # first-contact instrumentation (bench.py --gpus N): per bucket, when the backward handed it to RCCL and how long the
+        # compute stream then sat in its wait -- events on the compute stream, collected only while `measure` is on
+        self.measure = False
+        self.timeline = []
         self.reset()
 
     def close(self):
@@ -129,6 +147,13 @@ class GradReducer:
     def reset(self):
         self.next_bucket = 0
         self.handles = []
+        self._pending = []          # (bucket index, staging tensor) of the buckets in flight in a narrower dtype
+        self._marks = []            # measure: (bucket index, launch event)
+
+    def _event(self):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
 
     def start_count(self, count):
         """Asynchronous SUM all-reduce (in place) of the one-element device tensor holding this rank's row count."""
@@ -143,8 +168,19 @@ class GradReducer:
         if not self.active:
             return
         while self.next_bucket < len(self.buckets) and self.buckets[self.next_bucket][1] <= end_offset:
-            s, e = self.buckets[self.next_bucket]
-            self.handles.append(dist.all_reduce(grad_flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            i = self.next_bucket
+            s, e = self.buckets[i]
+            buf = grad_flat[s:e]
+            if self.xdtype != torch.float32:
+                st = self._stage.get(i)
+                if st is None or st.numel() != e - s or st.device != buf.device:
+                    st = self._stage[i] = torch.empty(e - s, dtype=self.xdtype, device=buf.device)
+                st.copy_(buf)               # the cast (round to nearest even), on the compute stream, before the collective reads it
+                self._pending.append((i, st))
+                buf = st
+            if self.measure and grad_flat.is_cuda:
+                self._marks.append((i, self._event()))
+            self.handles.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
             self.next_bucket += 1
 
     def tail_bytes(self):
@@ -156,9 +192,46 @@ class GradReducer:
         """Flush the remaining buckets and make the current stream wait for all of them (and for the row count)."""
         if self.active:
             self.on_ready(grad_flat, self.layout.total)
+            timed = self.measure and grad_flat.is_cuda
+            waits = [self._event()] if timed else None
             for h in self.handles:
                 h.wait()
+                if timed:
+                    waits.append(self._event())
+            for i, st in self._pending:         # narrow exchange: the reduced sums back into the flat fp32 buffer
+                s, e = self.buckets[i]
+                grad_flat[s:e].copy_(st)
+            if timed:
+                self.timeline.append((list(self._marks), waits, len(self.handles)))
         self.reset()
+
+    def timeline_report(self):
+        """Per bucket, averaged over the measured steps (synchronises; clears the record): `launch_ms` = when the backward handed the
+        bucket to RCCL, relative to the step's first launch; `exposed_wait_ms` = how long the compute stream sat in that bucket's
+        wait() inside finish() -- the part of its all-reduce the backward did not hide (the row-count all-reduce is handle 0 when
+        present and is folded into the first bucket's wait)."""
+        if not self.timeline:
+            return None
+        torch.cuda.synchronize()
+        nb = len(self.buckets)
+        launch, wait, n = [0.0] * nb, [0.0] * nb, 0
+        for marks, waits, nh in self.timeline:
+            if len(marks) != nb:
+                continue
+            n += 1
+            t0 = marks[0][1]
+            for i, ev in marks:
+                launch[i] += t0.elapsed_time(ev)
+            extra = nh - nb                      # leading non-bucket handles (the row count)
+            for i in range(nb):
+                a = waits[0] if i == 0 else waits[extra + i]
+                wait[i] += a.elapsed_time(waits[extra + i + 1])
+        self.timeline = []
+        if not n:
+            return None
+        return {"steps": n, "exchange_dtype": str(self.xdtype).replace("torch.", ""),
+                "bucket_mb": [round((e - s) * (4 if self.xdtype == torch.float32 else 2) / 2 ** 20, 1) for s, e in self.buckets],
+                "launch_ms_after_first": [round(x / n, 3) for x in launch], "exposed_wait_ms": [round(x / n, 3) for x in wait]}
 
 
 def shard_rows(n_rows, rank, world):

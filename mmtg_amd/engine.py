@@ -308,6 +308,10 @@ class Engine:
         if not master.is_cuda:
             raise RuntimeError("the MMTG engine runs on an MI355X (cuda) device only -- there is no CPU path")
         self.sh = Shapes(model_cfgs, data_cfg, gpt2_cfg)
+        if x3 and self.sh.D % 128:
+            # the split-precision products walk whole 128-wide K tiles of n_embd; an x3 engine has no mixed fallback for its training
+            # step (its weight copies are plane pairs, its saved activations too), so a width it cannot serve is refused up front
+            raise ValueError("compute_dtype='bf16x3' needs n_embd to be a multiple of 128 (got %d): use compute_dtype='f32'" % self.sh.D)
         self.layout = ParamLayout(model_cfgs, gpt2_cfg)
         assert master.numel() == self.layout.total and master.dtype == torch.float32
         self.dev = master.device
@@ -476,6 +480,8 @@ class Engine:
         self.wte_desc = torch.tensor([(woff, self.layout.Vpad, self.sh.D, 0)], dtype=torch.int64, device=self.dev)
 
     def Wt(self, key):   # [out, in] copy of a Conv1D weight (bf16 mode)
+        if self.x3:
+            raise RuntimeError("Engine.Wt: an x3 engine's transposed copies are (hi | lo) plane pairs -- use Wtx()")
         off, shape, n = self.wt_entries[key]
         return self.wt[off:off + n].view(shape)
 
@@ -568,7 +574,9 @@ class Engine:
             if not kw and self._gemm_few_rows(x, w, out, M, N, K, True, K, bias=bias, lda=lda):
                 return
             hip.gemm(x, w, out, M, N, K, transB=True, lda=lda, ldb=K, bias=bias, **kw)
-        elif wkey in self.wt_entries:   # bf16: the [out,in] copy -> NT layout
+        elif wkey in self.wt_entries and not self.x3:   # bf16: the [out,in] copy -> NT layout
+            # (an x3 engine's `wt` holds (hi | lo) PLANE PAIRS, read by _fwd_x3 only; its plain products -- the decoder's
+            #  MMTG_DECODE_X3=0 / n_embd > 1024 fallback -- take the fp32 weight as stored through the exact-fp32 kernel below)
             K, N = w.shape
             hip.gemm(x, self.Wt(wkey), out, M, N, K, transB=True, lda=lda, ldb=K, bias=bias, **kw)
         else:
@@ -1029,7 +1037,7 @@ class Engine:
             hip.wgrad_group([(dlp, a["hf"], self.Gp("wte"), Vp, D, Vp, D, D)], M, hs, hws, hcnt, accumulate=not self.wgrad_overwrite, config=_X3_WG_CFG)
             if self.wgrad_overwrite and self._ow_rec is not None:
                 self._ow_rec[1].append((self.layout.pack_range["wte"][0], Vp * D))
-        elif getattr(self, "wte_t", None) is not None and Vp % 128 == 0:
+        elif getattr(self, "wte_t", None) is not None and Vp % 128 == 0 and not self.x3:      # (x3: wte_t is a plane pair)
             hip.gemm(dlogits, self.wte_t, dhf, M, D, Vp, transB=True, ldb=Vp)
         else:
             hip.gemm(dlogits, self.Wp("wte"), dhf, M, D, Vp, transB=False, ldb=D)

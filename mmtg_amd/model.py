@@ -179,6 +179,9 @@ class MMTG(nn.Module):
         self.gpt2_cfg = self.decoder.config
         self.layout = ParamLayout(model_cfgs, self.gpt2_cfg)
         self.shapes = Shapes(model_cfgs, data_config, self.gpt2_cfg)
+        if self.x3 and self.shapes.D % 128:
+            raise ValueError("compute_dtype='bf16x3' needs n_embd to be a multiple of 128 (got %d): the split-precision products walk "
+                             "whole 128-wide K tiles and the mode has no mixed fallback; use compute_dtype='f32'" % self.shapes.D)
         self._flat = torch.zeros(self.layout.total, dtype=torch.float32)
         self._engine = None
         self._anchor = None

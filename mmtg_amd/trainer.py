@@ -84,6 +84,9 @@ class MMTGTrainer:
                 "exp_avg": None if eng.opt_m is None else eng.opt_m.detach().cpu().clone(),
                 "exp_avg_sq": None if eng.opt_v is None else eng.opt_v.detach().cpu().clone(),
                 "step_count": eng.step_count, "sched_step": self.sched_step, "drop_seed": eng.drop_seed,
+                # the CU reservation the ranks agreed on (None: not tuned): a resumed run keeps it instead of spending nine steps
+                # re-tuning under wall-clock timings (MMTG_DDP_GEMM_CUS pins it from the environment)
+                "cu_budget": None if self.budget_report is None else self.budget_report.get("budget_chosen"),
                 "hparams": {"lr": self.lr, "alpha": self.alpha, "max_norm": self.max_norm, "betas": tuple(self.betas),
                             "eps": self.eps, "weight_decay": self.wd, "warmup_steps": self.warmup,
                             "total_steps": self.total, "lm_weight": self.lm_weight}}
@@ -97,6 +100,11 @@ class MMTGTrainer:
             v = sd[key]
             setattr(eng, name, None if v is None else v.to(eng.dev, torch.float32).clone())
         eng.step_count, self.sched_step, eng.drop_seed = int(sd["step_count"]), int(sd["sched_step"]), int(sd["drop_seed"])
+        if sd.get("cu_budget") is not None and self._tune is not None:
+            from . import ddp as _ddp
+            _ddp.set_chosen_budget(int(sd["cu_budget"]))
+            self.budget_report = {"budget_chosen": int(sd["cu_budget"]), "source": "checkpoint"}
+            self._tune = None
 
     def step(self, batch, stage=3, filter_rows=True):
         """One optimisation step; returns device scalars (no host sync) {'loss','lm_loss','kl'} of the LOCAL rows.
@@ -119,11 +127,12 @@ class MMTGTrainer:
         if self._tune is not None:
             tune_ev = torch.cuda.Event(enable_timing=True)
             tune_ev.record()
-        try:
-            return self._step(batch, stage, filter_rows)
-        finally:
-            if tune_ev is not None:
-                self._tune_after_step(tune_ev)
+        out = self._step(batch, stage, filter_rows)
+        # (only after a step that RETURNED: the book-keeping ends in a blocking all-reduce, which after an exception on one rank
+        #  would turn that rank's error into a hang of the group)
+        if tune_ev is not None:
+            self._tune_after_step(tune_ev)
+        return out
 
     TUNE_STEPS = 3
 
@@ -200,6 +209,51 @@ class MMTGTrainer:
         eng.adamw_step(self.current_lr(), self.max_norm, self.betas, self.eps, self.wd, count=self._count)
         self.sched_step += 1
         return out
+
+    # ---- evaluation (train.py:241-268)
+    @torch.no_grad()
+    def evaluate_batch(self, batch, stage=3, filter_rows=True):
+        """Forward + MyLoss (+ KL) of one validation batch, no update: the stage's row filter, the engine's forward in eval mode (no
+        dropout) with compute-dtype logits -- no fp32 [B, T, V] tensor, no autograd boundary -- and the loss kernels.  Returns the
+        DEVICE scalars {'loss': MyLoss mean, 'kl': kl, 'total': loss + alpha * kl} (no host sync), or None when the filter leaves
+        no rows (train.py:252-253 `continue`s)."""
+        eng = self.eng
+        if filter_rows and stage in (1, 2):
+            idx = curriculum_filter(batch["rating_host"] if "rating_host" in batch else batch["rating"], stage)
+            batch = {k: v[idx.to(v.device, non_blocking=True)] for k, v in batch.items() if k != "rating_host"}
+        elif "rating_host" in batch:
+            batch = {k: v for k, v in batch.items() if k != "rating_host"}
+        if int(batch["rating"].shape[0]) == 0:
+            return None
+        eng.forward(batch, train_flag=True, training=False, logits_f32=_LOGITS_F32)
+        sc = eng.loss(batch["rating"], stage)
+        loss, kl = sc[0], eng.act["kl"][0]
+        return {"loss": loss, "kl": kl, "total": loss + self.alpha * kl}
+
+    @torch.no_grad()
+    def evaluate(self, valid_batches, stage=3):
+        """The reference's evaluate() (train.py:241-268) over an iterable of validation batches: per batch
+        total = MyLoss.mean() + alpha * kl.mean(), summed -- on the device, one host read at the end -- and divided by the NUMBER OF
+        BATCHES (filtered-out ones included, as `valid_loss /= len(valid_dataset)` does).  Returns (valid_loss, kldiv_loss) floats;
+        the model is in eval mode during the pass (train.py:242) and gets its previous mode back afterwards."""
+        was_training = self.model.training
+        self.model.eval()
+        acc = torch.zeros(2, device=self.eng.dev, dtype=torch.float32)
+        n = 0
+        try:
+            for batch in valid_batches:
+                n += 1
+                out = self.evaluate_batch(batch, stage)
+                if out is None:
+                    continue
+                acc[0] += out["total"]
+                acc[1] += self.alpha * out["kl"]
+        finally:
+            self.model.train(was_training)
+        if n == 0:
+            return 0.0, 0.0
+        v = (acc / n).tolist()
+        return v[0], v[1]
 
     def finish_wait_ms(self):
         """Mean time per step the compute stream waited in the reducer's finish() -- the part of the gradient exchange the

@@ -54,6 +54,25 @@ def test_kv_cache_decode_matches_reference_ids(use_graph, mode, monkeypatch):
     assert GreedyDecoder.reference_return(ids[2].tolist(), 220) == ref
 
 
+def test_x3_engine_decoder_falls_back_to_the_exact_fp32_kernels(monkeypatch):
+    """MMTG_DECODE_X3=0 on a bf16x3 model: the decoder leaves the split-precision token step and runs the f32 mode's step on the
+    x3 engine's fp32 weights (Engine._fwd must not hand the plane-pair copies to the plain products: round-5 advice).  Held to the
+    reference's greedy ids like the f32 mode."""
+    monkeypatch.setenv("MMTG_DECODE_X3", "0")
+    fx, batch, model = build("bf16x3")
+    dp = json.loads(str(fx["decode_params"]))
+    tb = {k: v for k, v in batch_to_torch(batch, DEV).items() if k not in ("rating", "targets")}
+    dec = GreedyDecoder(model, max_batch=3, use_graph=False)
+    assert model.engine().x3 and not dec.x3
+    ids = dec.generate(tb, 30, temperature=dp["temperature"], repitition_penalty=dp["repitition_penalty"]).cpu().numpy()
+    for row in (0, 1):
+        key = f"greedy_len30_row{row}"
+        if key in fx.files:
+            assert GreedyDecoder.reference_return(ids[row].tolist(), 30) == fx[key].tolist(), row
+    with pytest.raises(RuntimeError, match="plane pairs"):
+        model.engine().Wt("decoder.gpt2.transformer.h.0.attn.c_proj.weight")
+
+
 @pytest.mark.parametrize("mode", ["f32", "bf16x3", "bf16"])
 def test_prompt_prefill_fills_the_caches_the_token_steps_would(mode, monkeypatch):
     """The prompt's batched prefill (one inference-branch forward over [prompt, [#START#]], decode.py::_prefill) against the P prompt

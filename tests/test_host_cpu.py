@@ -269,7 +269,19 @@ def _ddp_worker(rank, world, port, outdir):
         assert agreed == [16.0, 12.5, 15.0] and choice == -16
         tie, _ = agree_on_budget([5.0, 5.0, 5.0], (0, -16, -32))
         assert tie == 0                 # ties go to the first candidate on every rank
-        torch.save((rank, mine, grad, len(red.buckets), n, launched), os.path.join(outdir, 'r%d.pt' % rank))
+        # opt-in narrow exchange (MMTG_DDP_GRAD_DTYPE=bf16, round 6): cast -> SUM all-reduce in bf16 -> cast back into the fp32 buffer
+        os.environ["MMTG_DDP_GRAD_DTYPE"] = "bf16"
+        try:
+            red16 = GradReducer(lay, bucket_mb=4.0)
+        finally:
+            del os.environ["MMTG_DDP_GRAD_DTYPE"]
+        assert red16.xdtype == torch.bfloat16 and red.xdtype == torch.float32
+        g16 = mine.clone()
+        for pk in fire:
+            red16.on_pack_ready(g16, pk)
+        red16.finish(g16)
+        assert g16.dtype == torch.float32 and not red16._pending and not red16.handles
+        torch.save((rank, mine, grad, len(red.buckets), n, launched, g16), os.path.join(outdir, 'r%d.pt' % rank))
     finally:
         dist.destroy_process_group()
 
@@ -285,10 +297,14 @@ def test_bucketed_allreduce_world2_gloo(tmp_path):
         assert p.exitcode == 0
     res = [torch.load(tmp_path / ("r%d.pt" % r)) for r in range(world)]
     total = res[0][1] + res[1][1]
-    for rank, mine, reduced, nb, n, launched in res:
+    # the bf16 exchange: each rank's share rounded to bf16, summed, the sum rounded to bf16 (what a bf16 all-reduce of two ranks does)
+    total16 = (res[0][1].bfloat16().float() + res[1][1].bfloat16().float()).bfloat16().float()
+    for rank, mine, reduced, nb, n, launched, g16 in res:
         assert nb > 3            # really bucketed
         assert n == 7            # 3 + 4 rows across ranks
         assert torch.equal(reduced, total)
+        assert torch.equal(g16, total16)
+        assert (g16 - total).abs().max() <= 2.0 ** -7 * total.abs().max()          # within bf16 rounding of the fp32 exchange
 
 
 def test_postprocess_cut_rules_vs_reference_goldens():
@@ -394,6 +410,12 @@ def test_split_precision_mode_host_contract():
         MMTG(mcfg, dcfg, 160, gpt2_config=gcfg, token_table=synth.make_token_table(160, seed=1), compute_dtype="bf16x2")
     with pytest.raises(RuntimeError):
         m.engine()                       # the hot path is HIP-only: no CPU engine in any mode
+    # a width the split-precision products cannot tile (n_embd % 128 != 0) is refused when the model is built -- the mode has no
+    # mixed fallback (round-5 advice: it used to reach the bf16 copies' code with plane pairs) -- while f32 / bf16 take it
+    narrow = gpt2_config(n_layer=1, vocab_size=160, n_positions=128, n_embd=192, n_head=3)
+    with pytest.raises(ValueError, match="multiple of 128"):
+        MMTG(mcfg, dcfg, 160, gpt2_config=narrow, token_table=synth.make_token_table(160, seed=1), compute_dtype="bf16x3")
+    assert MMTG(mcfg, dcfg, 160, gpt2_config=narrow, token_table=synth.make_token_table(160, seed=1), compute_dtype="f32").shapes.D == 192
     t = torch.arange(2 * 3 * 8, dtype=torch.float32).bfloat16().view(2, 3, 8)
     p = hip.Planes(t, 3, 8)
     assert (p.ld, p.plane) == (8, 24)

@@ -118,6 +118,53 @@ def test_dropin_backward_f32_vs_golden(case, mode):
     assert sd["ln_layer1.weight"].grad is None
 
 
+@pytest.mark.parametrize("mode", PARITY_MODES + ["bf16"])
+@pytest.mark.parametrize("case", ["tiny_s5", "full_12l"])
+def test_trainer_evaluate_vs_golden_and_oracle(case, mode):
+    """MMTGTrainer.evaluate (train.py:241-268): forward + MyLoss, no update, no fp32 [B, T, V] logits.  Per stage, the unfiltered batch
+    against the reference-executed goldens (tiny_s5: MyLoss of stages 1-3 and KL) and the stage-filtered pass over [batch, batch,
+    an all-filtered batch] against the oracle's my_loss on the rows train.py:246-251 keeps, divided by the number of batches."""
+    fx, meta, mcfg, gcfg, dcfg, weights, table, batch, model = build(case, mode)
+    alpha = 0.2
+    tr = MMTGTrainer(model, lr=1e-5, alpha=alpha)
+    tb = batch_to_torch(batch, DEV)
+    p0 = model._flat.detach().clone()
+    rel = 1e-4 if mode != "bf16" else 3e-2
+    if "myloss_stage1" in fx.files:
+        for stage in (1, 2, 3):
+            out = tr.evaluate_batch(tb, stage, filter_rows=False)
+            ref = float(fx[f"myloss_stage{stage}"])
+            assert abs(out["loss"].item() - ref) < rel * max(1.0, abs(ref)), (stage, out["loss"].item(), ref)
+            assert abs(out["kl"].item() - float(fx["kl"])) < rel * abs(float(fx["kl"]))
+            assert abs(out["total"].item() - (out["loss"].item() + alpha * out["kl"].item())) < 1e-5
+    # the filtered pass against the oracle
+    sh = O.Shapes(mcfg, dcfg, gcfg)
+    w = O.weights_to_torch(weights)
+    cb = batch_to_torch(batch)
+    none_left = {k: v[cb["rating"] == 3] for k, v in cb.items()}          # stage 2 drops every row of it
+    for stage in (1, 2, 3):
+        r = cb["rating"]
+        idx = (torch.cat([torch.where(r < 2)[0], torch.where(r > 4)[0]]) if stage == 1 else
+               torch.cat([torch.where(r < 3)[0], torch.where(r > 3)[0]]) if stage == 2 else torch.arange(len(r)))
+        batches = [tb, tb] + ([{k: v.to(DEV) for k, v in none_left.items()}] if stage == 2 and len(none_left["rating"]) else [])
+        got_loss, got_kl = tr.evaluate(batches, stage)
+        if len(idx) == 0:
+            assert got_loss == 0.0 and got_kl == 0.0
+            continue
+        sub = {k: v[idx] for k, v in cb.items()}
+        with torch.no_grad():
+            _, okl, ologits = O.mmtg_forward(w, sh, torch.from_numpy(table), sub, True)
+            oloss = O.my_loss(ologits, sub["targets"], sub["rating"], stage, sh.P)
+        ref_total = 2.0 * (oloss.item() + alpha * okl.item()) / len(batches)
+        ref_kl = 2.0 * alpha * okl.item() / len(batches)
+        assert abs(got_loss - ref_total) < rel * max(1.0, abs(ref_total)), (stage, got_loss, ref_total)
+        assert abs(got_kl - ref_kl) < rel * max(1e-3, abs(ref_kl)), (stage, got_kl, ref_kl)
+    assert torch.equal(model._flat.detach(), p0) and tr.sched_step == 0 and tr.eng.step_count == 0      # nothing moved
+    assert not model.training
+    a = model.engine().act
+    assert mode != "bf16" or a["logits"].dtype == torch.bfloat16          # compute-dtype logits: no fp32 [B, T, V] tensor in the bf16 mode
+
+
 @pytest.mark.parametrize("mode", PARITY_MODES)
 @pytest.mark.parametrize("case", CASES)
 def test_fused_train_step_f32_vs_golden(case, mode):
