@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MMTG_ABI_VERSION 9
+#define MMTG_ABI_VERSION 10
 
 /* The library is built with -fvisibility=hidden: only the entry points below are exported. */
 #define MMTG_API __attribute__((visibility("default")))
@@ -507,6 +507,31 @@ MMTG_API int mmtg_decode_sample(const float* logits, long ldl, int V, long long*
                        int P, int sent, float temperature, float rep_penalty, int top_k, float top_p,
                        const float* uniforms, long ldu, int B, int* pos_next, void* stream);
 MMTG_API int mmtg_decode_advance(int* pos_ptr, void* stream);
+
+/* ---- Round 6: the MLP of a GPT-2 block of the decode token step as ONE launch (bf16, n_embd = 768, M <= 256 rows) -- the
+ * c_fc -> gelu_new -> mlp.c_proj -> + residual half of the transformers GPT-2 block the reference runs per token through
+ * model.py:320-326 / generate.py:124; replaces the mode-0 + mode-2 mmtg_decode_gemm pair of the fused step.
+ *   C = X + gelu( rstd (X W1f^T - mu colsum1) + bias1f ) W2t^T + bias2,   stats_out[m][p] = (sum, sum of squares) of C[m, 48 p .. 48 p + 48)
+ * X [M, ldx] bf16: the un-normalised residual rows (also the residual added back); stats_in [M][32][2] their statistics partials
+ * (np_in of them); W1f [3072, ldw1] / colsum1 / bias1f: the gamma-folded c_fc copy of mmtg_ln_fold_weights; W2t [768, ldw2]: the
+ * [out,in] copy of mlp.c_proj; G [M, ldg] bf16: scratch for the hidden activations (written and read inside the launch); C [M, ldc] bf16
+ * (may not alias X); stats_out: 16 partials per row.  ws: mmtg_decode_mlp_ws_floats(M) floats of fp32 partial products; sync:
+ * mmtg_decode_mlp_sync_words() 64-bit words, ZERO before the first launch (the launch re-arms them; word [65] is the error report:
+ * 2 = a wait ran into its 4 ms bound, 4 = a hand-off group was found on two XCDs in the plain mode -- results are then undefined,
+ * the host must check and clear it).  The launch is 256 workgroups that must be co-resident, one per CU (mmtg_decode_mlp_census).
+ * plain_handoff: 0 = the hidden activations cross workgroups through write-through stores + agent-scope loads (valid under any
+ * workgroup placement); 1 = through the XCD's L2 (valid when workgroups b and b + 8 k share an XCD: checked per launch, error bit 4).
+ * trace (nullable): 12 x 256 real-time-counter stamps (diagnostic).
+ * mmtg_decode_mlp_census: out64[8 v + x] += workgroups b with b % 8 == v found on physical XCD x, for a launch of the same shape
+ * (256 workgroups, one per CU): the placement the plain hand-off relies on holds when every row v has one entry of 32.          */
+MMTG_API long mmtg_decode_mlp_ws_floats(int M);
+MMTG_API int mmtg_decode_mlp_sync_words(void);
+MMTG_API int mmtg_decode_mlp_census(unsigned* out64, void* stream);
+MMTG_API int mmtg_decode_mlp(int M, int D, const void* X, long ldx, const float* stats_in, int np_in, float eps,
+                    const void* W1f, long ldw1, const float* colsum1, const float* bias1f,
+                    const void* W2t, long ldw2, const float* bias2, void* G, long ldg, void* C, long ldc,
+                    float* stats_out, float* ws, long ws_floats, unsigned long long* sync, int plain_handoff,
+                    unsigned long long* trace, void* stream);
 
 #ifdef __cplusplus
 }

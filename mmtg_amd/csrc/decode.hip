@@ -389,7 +389,7 @@ __global__ __launch_bounds__(256) void decode_embed_kernel(const T* __restrict__
 //     W'_kn, b' = b + beta W; mu / rstd come from the statistics partials.  Decode has no backward: nothing else needs LN(x).
 // Tile = 64 x 64 per 256-thread workgroup (2 x 2 waves of 32 x 32), K-contiguous operands, 4-deep LDS-DMA ring, counted vmcnt
 // (the main loop of gemm_dma_kernel<false, false, 64, 64, 2, 2, 4>, gemm.hip).
-constexpr int DG_NP = 32;     // statistics partials per row the buffers are sized for (n_embd <= 1024: one per 32 columns)
+// (DG_NP = 32 statistics partials per row: gemm_common.h)
 
 // Partial tiles cross XCDs: their stores and loads carry the agent-scope bit (sc1: write through / always miss; cache-policy
 // operand 16 of the raw buffer builtins) instead of an L2-wide write-back + invalidate per wave (csrc/wgrad.hip).  Compiler-visible

@@ -13,6 +13,7 @@
 namespace {
 
 enum { BM = 128, BN = 128, TILE_BYTES = 16384, NTHR = 256 };
+constexpr int DG_NP = 32;     // decode step: LayerNorm statistics partials per row the buffers are sized for (decode.hip, decode_mlp.hip)
 
 struct GemmArgs {
     const void* A; const void* B; void* C;

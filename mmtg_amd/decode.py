@@ -21,6 +21,19 @@ import torch
 from . import hip
 
 
+_PLACEMENT = {}
+
+
+def _placement_ok(dev):
+    """True when a 256-workgroup, one-per-CU launch puts workgroups b and b + 8 k on one XCD, 32 per XCD (census kernel, once per
+    device and process): what the plain hand-off of mmtg_decode_mlp relies on (the launch itself re-checks every group)."""
+    key = str(dev)
+    if key not in _PLACEMENT:
+        c = hip.decode_mlp_census(dev)
+        _PLACEMENT[key] = bool(((c == 32).sum(1) == 1).all() and ((c == 32).sum(0) == 1).all() and int(c.sum()) == 256)
+    return _PLACEMENT[key]
+
+
 class GreedyDecoder:
     def __init__(self, model, max_batch, max_len=None, use_graph=True, lanes=None, _parent=None, _lane=0):
         self.model = model
@@ -141,6 +154,22 @@ class GreedyDecoder:
                 self.folds_for = None
                 # (MMTG_DECODE_EMBED_IN_PROJ=0: projector_layer2 and the embedding add as two launches, the round-3 v8 step)
                 self.embed_in_proj = os.environ.get("MMTG_DECODE_EMBED_IN_PROJ", "1") != "0" and H % 8 == 0
+                # Round 6: c_fc -> GELU -> mlp.c_proj of a block as ONE launch (mmtg_decode_mlp): the hidden dimension is split over the
+                # XCDs, so the GEMM -> GEMM hand-off stays on one L2 and every weight crosses the fabric once; 4 graph nodes per
+                # block instead of 5.  Built for n_embd = 768 and up to 256 rows; MMTG_DECODE_MLP=0 keeps the two launches, =1
+                # forces the fused one at small batches too (tests).  MMTG_DECODE_MLP_HANDOFF=plain: through the L2 (checked per
+                # launch); default sc1 (write-through + agent-scope loads: valid under any workgroup placement).
+                # Not for the row blocks of a multi-lane decoder: its 256 workgroups must be co-resident, which side-by-side launches
+                # on several streams cannot promise.
+                mlp_env = os.environ.get("MMTG_DECODE_MLP")
+                self.mlp = _parent is None and D == 768 and B <= 256 and (mlp_env == "1" or (mlp_env is None and B >= 128))
+                if self.mlp:
+                    self.mlp_ws = f32(hip.decode_mlp_ws_floats(B))
+                    self.mlp_sync = torch.zeros(hip.decode_mlp_sync_words(), dtype=torch.int64, device=dev)
+                    self.mlp_plain = os.environ.get("MMTG_DECODE_MLP_HANDOFF", "sc1") == "plain"
+                    self.mlp_trace = None
+                    if self.mlp_plain and not _placement_ok(dev):
+                        self.mlp_plain = False          # workgroups b and b + 8 k do not share an XCD here: write-through hand-off
         self.pos, self.pos_next = self.pos_pair
         # the prompt in one batched pass (round 5; MMTG_DECODE_PREFILL=0: P token steps, as rounds 1-4 ran it)
         self.prefill = _parent is None and os.environ.get("MMTG_DECODE_PREFILL", "1") != "0"
@@ -377,21 +406,29 @@ class GreedyDecoder:
         nslab = -(-D // kper)
         x, xo = hcur, hnext
         st, sto = self.st
+        mlp = getattr(self, "mlp", False)
+        npx = NP            # statistics partials of the block's input rows (the projector's / a mode-2 product's: one per 32 columns)
         for l in range(sh.L):
             p = f"{pre}h.{l}."
             wf, c, bq = self.fq[l]
-            hip.decode_gemm(1, x, wf, self.part, B, 3 * D, D, colsum=c, stats_in=st, np_in=NP, eps=sh.eps, out_f32=True, splits=sq)
+            hip.decode_gemm(1, x, wf, self.part, B, 3 * D, D, colsum=c, stats_in=st, np_in=npx, eps=sh.eps, out_f32=True, splits=sq)
             hip.decode_attn_split(self.part, nslab, bq, self.kc[l], self.vc[l], self.keep, self.pos,
                                   self.ctx, B, sh.nH, 64, self.Tmax)
             hip.decode_gemm(2, self.ctx, eng.Wt(p + "attn.c_proj.weight"), xo, B, D, D, bias=eng.P(p + "attn.c_proj.bias"), resid=x,
                             stats_out=sto, splits=sp, ws=self.rws, counters=self.rcnt)
             wf, c, bfc = self.ffc[l]
+            if mlp:
+                # c_fc (LN-fold + GELU) -> mlp.c_proj (+ bias + residual + statistics, 16 partials of 48 columns) in one launch
+                hip.decode_mlp(xo, sto, NP, sh.eps, wf, c, bfc, eng.Wt(p + "mlp.c_proj.weight"), eng.P(p + "mlp.c_proj.bias"), self.g, x, st,
+                               self.mlp_ws, self.mlp_sync, B, D, plain=self.mlp_plain, trace=self.mlp_trace)
+                npx = 16
+                continue
             hip.decode_gemm(0, xo, wf, self.g, B, 4 * D, D, bias=bfc, colsum=c, stats_in=sto, np_in=NP, eps=sh.eps, act=hip.EPI_GELU)
             hip.decode_gemm(2, self.g, eng.Wt(p + "mlp.c_proj.weight"), x, B, D, 4 * D, bias=eng.P(p + "mlp.c_proj.bias"), resid=xo,
                             stats_out=st, splits=s2, ws=self.rws, counters=self.rcnt)
         if with_head:
             wf, c, bh = self.fh
-            hip.decode_gemm(0, x, wf, self.logits, B, eng.layout.Vpad, D, bias=bh, colsum=c, stats_in=st, np_in=NP, eps=sh.eps,
+            hip.decode_gemm(0, x, wf, self.logits, B, eng.layout.Vpad, D, bias=bh, colsum=c, stats_in=st, np_in=npx, eps=sh.eps,
                             out_f32=True)
 
     def _run_step(self, with_head, parity):
@@ -423,6 +460,10 @@ class GreedyDecoder:
             return ("decode token step (bf16x3): decode_gemm_x3_kernel<64x64> weight streaming over (hi | lo) plane pairs, three bf16 matrix-core "
                     "passes per product (split-K reduced in the kernel, LayerNorm applied algebraically, fp32 residual stream) + decode_attn "
                     "streaming an fp32 KV cache, 5 graph nodes per block")
+        if getattr(self, "fused", False) and getattr(self, "mlp", False):
+            return ("decode token step: decode_gemm_kernel<64x64> weight streaming (c_attn LN-fold slabs, attn.c_proj split-K reduced in the "
+                    "kernel) + decode_attn KV-cache streaming + decode_mlp_kernel (c_fc -> GELU -> mlp.c_proj in one launch, hidden dimension "
+                    "split over the XCDs, %s hand-off), 4 graph nodes per block" % ("L2" if self.mlp_plain else "write-through"))
         if getattr(self, "fused", False):
             return ("decode token step: decode_gemm_kernel<64x64> weight streaming (split-K reduced in the kernel, LayerNorm applied "
                     "algebraically) + decode_attn KV-cache streaming, 5 graph nodes per block")
@@ -452,6 +493,8 @@ class GreedyDecoder:
                 if ch.uniforms is None:
                     ch.uniforms = torch.empty_like(blk, memory_format=torch.contiguous_format)
                 ch.uniforms.copy_(blk)
+        if getattr(self, "mlp", False):
+            self.mlp_sync.zero_()           # counters armed, error report cleared (check_mlp_error reads it after the generation)
         eng.invalidate_copies()
         self.eng.refresh_copies()
         for d in ([self] + self.children):          # (a lane has its own folded copies: they are part of its scratch)
@@ -540,7 +583,17 @@ class GreedyDecoder:
                     self.seq[:, pos + 1] = torch.where(col >= 0, col, self.seq[:, pos + 1])
         finally:
             self.use_graph = saved_mode
+        self.check_mlp_error()
         return self.seq[:, sh.P:sh.P + 1 + length].clone()
+
+    def check_mlp_error(self):
+        """Raise if a mmtg_decode_mlp launch of this generation reported a bounded wait that ran out or a hand-off group split over
+        two XCDs (include/mmtg_hip.h): its results are undefined then.  One device read (the ids are read right after anyway)."""
+        if getattr(self, "mlp", False):
+            code = int(self.mlp_sync[65].item())
+            if code:
+                raise RuntimeError("mmtg_decode_mlp reported error %d (2: a wait ran into its 4 ms bound -- the 256 workgroups were not "
+                                   "co-resident; 4: a hand-off group sat on two XCDs in the plain mode); set MMTG_DECODE_MLP=0" % code)
 
     @staticmethod
     def reference_return(ids_row, length, sent=22):

@@ -13,7 +13,7 @@ import os
 import torch
 
 F32, BF16 = 0, 1
-ABI_VERSION = 9
+ABI_VERSION = 10
 EPI_NONE, EPI_GELU, EPI_TANH, EPI_RESID, EPI_DGELU, EPI_DTANH, EPI_ATOMIC, EPI_ROWDOT = range(8)
 GEMM_NO_TR, GEMM_REGSTAGE, GEMM_SKINNY, GEMM_NO_SKINNY, GEMM_WIDE, GEMM_NO_WIDE = 1, 2, 4, 8, 16, 32
 GEMM_PERSIST, GEMM_NO_PERSIST, GEMM_ROW_ORDER, GEMM_OCC4, GEMM_NO_OCC4, GEMM_COL_BLOCK, GEMM_P256, GEMM_NO_P8, GEMM_P8 = 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384
@@ -101,6 +101,10 @@ _SIGS = {
     "mmtg_decode_sample": ([_vp, _l, _i, _vp, _l, _vp, _i, _i, _f, _f, _i, _f, _vp, _l, _i, _vp, _vp], _i),
     "mmtg_decode_select": ([_vp, _l, _i, _vp, _l, _vp, _i, _i, _f, _f, _i, _vp, _vp], _i),
     "mmtg_decode_advance": ([_vp, _vp], _i),
+    "mmtg_decode_mlp_ws_floats": ([_i], _l),
+    "mmtg_decode_mlp_sync_words": ([], _i),
+    "mmtg_decode_mlp_census": ([_vp, _vp], _i),
+    "mmtg_decode_mlp": ([_i, _i, _vp, _l, _vp, _i, _f, _vp, _l, _vp, _vp, _vp, _l, _vp, _vp, _l, _vp, _l, _vp, _vp, _l, _vp, _i, _vp, _vp], _i),
 }
 
 
@@ -699,3 +703,27 @@ def decode_sample(logits, ldl, V, seq, pos, P, sent, temperature, rep_penalty, t
 
 def decode_advance(pos):
     _check(lib().mmtg_decode_advance(_p(pos), _stream()), "decode_advance")
+
+
+def decode_mlp_ws_floats(M):
+    return int(lib().mmtg_decode_mlp_ws_floats(int(M)))
+
+
+def decode_mlp_sync_words():
+    return int(lib().mmtg_decode_mlp_sync_words())
+
+
+def decode_mlp_census(device):
+    """Workgroup placement of a 256-workgroup, one-per-CU launch: an [8, 8] int tensor, [v, x] = workgroups with id % 8 == v found on
+    physical XCD x (include/mmtg_hip.h, mmtg_decode_mlp_census).  Synchronises."""
+    import torch
+    out = torch.zeros(64, dtype=torch.int32, device=device)
+    _check(lib().mmtg_decode_mlp_census(_p(out), _stream()), "decode_mlp_census")
+    return out.view(8, 8).cpu()
+
+
+def decode_mlp(X, stats_in, np_in, eps, W1f, colsum1, bias1f, W2t, bias2, G, C_, stats_out, ws, sync, M, D, plain=False, trace=None):
+    """c_fc (LN-fold + GELU) -> mlp.c_proj (+ bias + residual + statistics) of a GPT-2 block in one launch (include/mmtg_hip.h, mmtg_decode_mlp)."""
+    _check(lib().mmtg_decode_mlp(int(M), int(D), _p(X), X.stride(0), _p(stats_in), int(np_in), float(eps), _p(W1f), W1f.stride(0), _p(colsum1),
+                                 _p(bias1f), _p(W2t), W2t.stride(0), _p(bias2), _p(G), G.stride(0), _p(C_), C_.stride(0), _p(stats_out),
+                                 _p(ws), ws.numel(), _p(sync), int(bool(plain)), _p(trace), _stream()), "decode_mlp")

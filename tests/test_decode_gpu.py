@@ -311,10 +311,15 @@ def test_trainer_stage_filter_from_host_ratings_is_the_same_step():
     assert float((masters[0] - masters[1]).norm()) <= 1e-6 * float(masters[0].norm())
 
 
-def test_full_size_batched_decode_rules():
+@pytest.mark.parametrize("mlp", ["1", "0"])
+def test_full_size_batched_decode_rules(mlp, monkeypatch):
     """BASELINE configs[3] shape: full 12-layer model, batch 256, 128 positions, bf16 fast path with the hipGraph --
     greedy and top-k/top-p sampling both obey the generation rules on every row (forced cadence, banned ids, sticky
-    PAD, ids inside the vocabulary); greedy is reproducible run to run (deterministic split-K)."""
+    PAD, ids inside the vocabulary); greedy is reproducible run to run (deterministic split-K).
+    mlp = "1": the round-6 step (c_fc -> GELU -> mlp.c_proj as one launch per block, mmtg_decode_mlp; the default at this batch);
+    "0": the two-launch pair, which is also what the row blocks of a multi-lane decoder run -- so the lane-count invariance is
+    asserted there."""
+    monkeypatch.setenv("MMTG_DECODE_MLP", mlp)
     import numpy as np
     from mmtg_amd import synth
     from mmtg_amd.configs import data_config, gpt2_config, make_model_cfgs
@@ -327,6 +332,7 @@ def test_full_size_batched_decode_rules():
     nb = synth.make_batch(B, mcfg, dcfg, V, seed=7)
     batch = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in nb.items() if k not in ("rating", "targets")}
     dec = GreedyDecoder(model, max_batch=B, max_len=Ln)
+    assert dec.mlp == (mlp == "1")
     g1 = dec.generate(batch, Ln, temperature=1.1, repitition_penalty=1.5)
     g2 = dec.generate(batch, Ln, temperature=1.1, repitition_penalty=1.5)
     assert torch.equal(g1, g2)
@@ -336,7 +342,7 @@ def test_full_size_batched_decode_rules():
     assert not torch.equal(smp, g1)
     # the lane count (row blocks decoded side by side on their own streams) never changes a row's ids
     assert dec.lanes == 1
-    for lanes in (2, 4):
+    for lanes in ((2, 4) if mlp == "0" else ()):
         other = GreedyDecoder(model, max_batch=B, max_len=Ln, lanes=lanes)
         assert torch.equal(other.generate(batch, Ln, temperature=1.1, repitition_penalty=1.5), g1), lanes
         gen.manual_seed(3)
@@ -401,10 +407,11 @@ def test_fused_decode_step_matches_the_unfused_one(monkeypatch):
     fx, batch, model = build("bf16")
     tb = {k: v for k, v in batch_to_torch(batch, DEV).items() if k not in ("rating", "targets")}
     outs = {}
-    for fused in ("1", "0"):
-        monkeypatch.setenv("MMTG_DECODE_FUSED", fused)
+    for fused in ("1", "0", "mlp"):
+        monkeypatch.setenv("MMTG_DECODE_FUSED", "0" if fused == "0" else "1")
+        monkeypatch.setenv("MMTG_DECODE_MLP", "1" if fused == "mlp" else "0")
         dec = GreedyDecoder(model, max_batch=3, use_graph=False)
-        assert getattr(dec, "fused", False) == (fused == "1")
+        assert getattr(dec, "fused", False) == (fused != "0") and getattr(dec, "mlp", False) == (fused == "mlp")
         first = []
 
         def tap(j, with_head, picked, logits, first=first, V=dec.eng.sh.V):
@@ -416,19 +423,20 @@ def test_fused_decode_step_matches_the_unfused_one(monkeypatch):
         assert torch.equal(ids, ids2)
         # logits of the first and of the LAST model call (the decoder's buffer still holds the latter)
         outs[fused] = (ids.cpu().numpy(), dec.logits[:, :dec.eng.sh.V].float().cpu().clone(), first[0])
-    ids_f, ids_u = outs["1"][0], outs["0"][0]
-    for ids in (ids_f, ids_u):
-        free = [j for j in range(1, 41) if (j + 1) % 22 not in (0, 1)]
-        assert not np.isin(ids[:, free], [1, 2, 100, 102]).any()
-    # the FIRST model call always shares its prefix (prompt + [#START#]): its logits are compared unconditionally, for every row
-    lf, lu = outs["1"][2], outs["0"][2]
-    assert lf.shape == lu.shape and lf.shape[0] == 3
-    assert float((lf - lu).abs().max()) < 0.12 * max(1.0, float(lu.abs().max()) / 8.0)
-    # and the last call's wherever the two decoders still agree on the whole prefix
-    same_prefix = (ids_f == ids_u).all(axis=1)
-    if same_prefix.any():
-        lf, lu = outs["1"][1][same_prefix], outs["0"][1][same_prefix]
-        assert float((lf - lu).abs().max()) < 0.12 * max(1.0, float(lu.abs().max()) / 8.0)
+    for key in ("1", "mlp"):          # the fused step, and (round 6) the fused step with the one-launch MLP, each against the unfused one
+        ids_f, ids_u = outs[key][0], outs["0"][0]
+        for ids in (ids_f, ids_u):
+            free = [j for j in range(1, 41) if (j + 1) % 22 not in (0, 1)]
+            assert not np.isin(ids[:, free], [1, 2, 100, 102]).any()
+        # the FIRST model call always shares its prefix (prompt + [#START#]): its logits are compared unconditionally, for every row
+        lf, lu = outs[key][2], outs["0"][2]
+        assert lf.shape == lu.shape and lf.shape[0] == 3
+        assert float((lf - lu).abs().max()) < 0.12 * max(1.0, float(lu.abs().max()) / 8.0), key
+        # and the last call's wherever the two decoders still agree on the whole prefix
+        same_prefix = (ids_f == ids_u).all(axis=1)
+        if same_prefix.any():
+            lf, lu = outs[key][1][same_prefix], outs["0"][1][same_prefix]
+            assert float((lf - lu).abs().max()) < 0.12 * max(1.0, float(lu.abs().max()) / 8.0), key
 
 
 def _report(name, **kv):
@@ -440,9 +448,10 @@ def _report(name, **kv):
 
 
 @pytest.mark.parametrize("case,bound,mode", [("tiny_s5", 0.12, "bf16"), ("full_12l", 0.15, "bf16"),
+                                             ("tiny_s5", 0.12, "bf16+mlp"), ("full_12l", 0.15, "bf16+mlp"),
                                              ("tiny_s5", 1e-3, "bf16x3"), ("full_12l", 1e-3, "bf16x3")])
 @pytest.mark.parametrize("use_graph", [True, False])
-def test_bf16_fused_decoder_teacher_forced_on_the_reference_ids(case, bound, mode, use_graph):
+def test_bf16_fused_decoder_teacher_forced_on_the_reference_ids(case, bound, mode, use_graph, monkeypatch):
     """The BENCHMARKED decode path -- the bf16 fused, KV-cached, graph-replayed GreedyDecoder -- against the reference's own
     sample_sequence run (generate.py:117-142): row 0 is teacher-forced on the reference's 220-position greedy id list, and at
     every model call (a) the decoder's raw fp32 logits are compared with the logits the reference's model produced at that call
@@ -451,7 +460,12 @@ def test_bf16_fused_decoder_teacher_forced_on_the_reference_ids(case, bound, mod
     twice that bound over the temperature.  The decoder-side twin of test_greedy_ids_vs_golden_at_reduced_precision, which goes
     through model.forward and never touches the decode kernels.
     Round 5: the same harness on the split-precision decoder (compute_dtype="bf16x3": fp32 stream / KV cache, three bf16 passes per
-    product) under north_star's OWN gates: raw logits within 1e-3 of the reference's at every call and EVERY pick the reference's."""
+    product) under north_star's OWN gates: raw logits within 1e-3 of the reference's at every call and EVERY pick the reference's.
+    Round 6, "bf16+mlp": the bf16 step with c_fc -> GELU -> mlp.c_proj as ONE launch per block (mmtg_decode_mlp, the default at the
+    benchmarked batch of 256; forced on here at the fixtures' few rows) under the bf16 mode's bounds."""
+    want_mlp = mode.endswith("+mlp")
+    monkeypatch.setenv("MMTG_DECODE_MLP", "1" if want_mlp else "0")
+    mode = mode.split("+")[0]
     fx, meta, mcfg, gcfg, dcfg, weights, table, batch = load_case(case)
     model = MMTG(mcfg, dcfg, meta["V"], train_flag=False, gpt2_config=gcfg, token_table=table, compute_dtype=mode)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})
@@ -464,6 +478,7 @@ def test_bf16_fused_decoder_teacher_forced_on_the_reference_ids(case, bound, mod
     dec = GreedyDecoder(model, max_batch=B, use_graph=use_graph)
     if mode == "bf16":
         assert dec.fused, "the bf16 decoder must take the fused token step (the benchmarked path)"
+        assert dec.mlp == want_mlp
     else:
         assert dec.x3, "the bf16x3 decoder must take the split-precision token step (the benchmarked path)"
     teacher = torch.full((B, 1 + length), -1, dtype=torch.long)
@@ -511,7 +526,7 @@ def test_bf16_fused_decoder_teacher_forced_on_the_reference_ids(case, bound, mod
             worst_missed = max(worst_missed, margin)
             if first_div is None:
                 first_div = (c, margin)
-    _report("decoder_teacher_forced_%s_%s_fused_%s" % (case, mode, "graph" if use_graph else "eager"), calls=n, agree=ok,
+    _report("decoder_teacher_forced_%s_%s%s_fused_%s" % (case, mode, "_mlp" if want_mlp else "", "graph" if use_graph else "eager"), calls=n, agree=ok,
             logit_err_max=err_max, worst_missed_margin=worst_missed,
             first_divergence_call=None if first_div is None else first_div[0],
             first_divergence_margin=None if first_div is None else first_div[1])

@@ -1168,6 +1168,83 @@ def test_decode_gemm_ln_fold_and_in_kernel_reduce(M):
 
 
 
+@pytest.mark.parametrize("plain", [False, True])
+@pytest.mark.parametrize("M", [256, 200, 64, 3])
+def test_decode_mlp_one_launch_vs_the_two_launch_pair(M, plain):
+    """mmtg_decode_mlp (round 6): c_fc (LN-fold + GELU) -> mlp.c_proj (+ bias + residual + statistics) as ONE launch whose hidden
+    dimension is split over the XCDs, against (a) the explicit fp32 arithmetic on the same bf16 operands and (b) the mode-0 + mode-2
+    mmtg_decode_gemm pair it replaces (same rounding points: bf16 hidden activations, bf16 output; only the order of the fp32
+    partial sums differs).  Both hand-off modes; ragged row counts; repeated launches bit-equal (slice-ordered reduction), counters
+    re-armed, no error reported, statistics partials = sums over the STORED bf16 rows (16 partials of 48 columns)."""
+    D, HID, NP = 768, 3072, hip.DG_NP
+    g = torch.Generator().manual_seed(21 + M)
+    x = (torch.randn(M, D, generator=g) * 2.0 + torch.randn(M, 1, generator=g)).to(torch.bfloat16)
+    x[:, 5] *= 20.0
+    W1 = (torch.randn(HID, D, generator=g) * 0.03).to(torch.bfloat16)
+    W2 = (torch.randn(D, HID, generator=g) * 0.03).to(torch.bfloat16)
+    gamma, beta = 1.0 + 0.1 * torch.randn(D, generator=g), 0.1 * torch.randn(D, generator=g)
+    b1, b2 = 0.1 * torch.randn(HID, generator=g), 0.1 * torch.randn(D, generator=g)
+    xd, W2d, b2d = x.to(DEV), W2.to(DEV), b2.to(DEV)
+    W1f = torch.empty(HID, D, dtype=torch.bfloat16, device=DEV)
+    c1, b1f = torch.empty(HID, device=DEV), torch.empty(HID, device=DEV)
+    hip.ln_fold_weights(W1.to(DEV), gamma.to(DEV), beta.to(DEV), b1.to(DEV), W1f, c1, b1f, HID, D)
+    xf = x.float()
+    st = torch.zeros(M, NP, 2)
+    st[:, :D // 32, 0] = xf.view(M, D // 32, 32).sum(2)
+    st[:, :D // 32, 1] = (xf * xf).view(M, D // 32, 32).sum(2)
+    std = st.to(DEV)
+    # (b) the two launches
+    G0 = torch.empty(M, HID, dtype=torch.bfloat16, device=DEV)
+    hip.decode_gemm(0, xd, W1f, G0, M, HID, D, bias=b1f, colsum=c1, stats_in=std, np_in=D // 32, act=hip.EPI_GELU)
+    tiles = -(-M // 64) * (D // 64)
+    ws0 = torch.empty(tiles * 4 * 4096, device=DEV)
+    cnt0 = torch.zeros(tiles * 4, dtype=torch.int32, device=DEV)
+    C0 = torch.empty(M, D, dtype=torch.bfloat16, device=DEV)
+    so0 = torch.zeros(M, NP, 2, device=DEV)
+    hip.decode_gemm(2, G0, W2d, C0, M, D, HID, bias=b2d, resid=xd, stats_out=so0, splits=4, ws=ws0, counters=cnt0)
+    # the fused launch
+    ws = torch.full((hip.decode_mlp_ws_floats(M),), float("nan"), device=DEV)
+    sync = torch.zeros(hip.decode_mlp_sync_words(), dtype=torch.int64, device=DEV)
+    outs = []
+    for rep in range(3):
+        G = torch.full((M, HID), 3.0, dtype=torch.bfloat16, device=DEV)
+        C1 = torch.full((M, D), 7.0, dtype=torch.bfloat16, device=DEV)
+        so = torch.full((M, NP, 2), float("nan"), device=DEV)
+        hip.decode_mlp(xd, std, D // 32, 1e-5, W1f, c1, b1f, W2d, b2d, G, C1, so, ws, sync, M, D, plain=plain)
+        torch.cuda.synchronize()
+        assert int(sync.abs().sum()) == 0, sync.tolist()             # counters re-armed, no error word
+        outs.append((G, C1, so))
+    G, C1, so = outs[0]
+    for G_, C_, so_ in outs[1:]:
+        assert torch.equal(G_, G) and torch.equal(C_, C1) and torch.equal(so_[:, :16], so[:, :16])
+    # the hidden activations go through the same arithmetic in both forms
+    assert (G.float() - G0.float()).abs().max().item() <= 2e-2 * G0.float().abs().max().item()
+    assert (G == G0).float().mean().item() > 0.99
+    # (a) fp32 arithmetic on the stored bf16 hidden activations
+    ref = G.float().cpu() @ W2.float().t() + b2 + xf
+    close(C1, ref, torch.bfloat16, HID, "fused MLP output")
+    assert bool(((C1.float() - C0.float()).abs() <= 2.0 ** -6 * C0.float().abs() + 1e-2).all())          # within ~2 bf16 ulps of the pair
+    mu, var = xf.mean(1, keepdim=True), xf.var(1, unbiased=False, keepdim=True)
+    full = O.gelu_new(((xf - mu) / torch.sqrt(var + 1e-5) * gamma + beta) @ W1.float().t() + b1)
+    close(G, full, torch.bfloat16, D, "fused MLP hidden activations")
+    xs = C1.float()
+    assert (so[:, :16, 0] - xs.view(M, 16, 48).sum(2)).abs().max().item() <= 1e-3 * max(1.0, xs.abs().max().item())
+    sq = (xs * xs).view(M, 16, 48).sum(2)
+    assert (so[:, :16, 1] - sq).abs().max().item() <= 1e-3 * sq.abs().max().item()
+    assert torch.isnan(so[:, 16:]).all()                             # partials past 16 are not touched
+
+
+def test_decode_mlp_census_reports_the_placement_the_plain_handoff_needs():
+    """256 workgroups, one per CU: the census the plain hand-off relies on (workgroups b and b + 8 k on one XCD, 32 per XCD).  The
+    test records what the box does; the decoder only takes the plain mode when it holds."""
+    c = hip.decode_mlp_census(DEV)
+    assert c.shape == (8, 8) and int(c.sum()) == 256
+    from mmtg_amd.decode import _placement_ok
+    ok = bool(((c == 32).sum(1) == 1).all() and ((c == 32).sum(0) == 1).all())
+    assert _placement_ok(torch.device(DEV, torch.cuda.current_device())) == ok
+    print("XCD census (rows: workgroup id % 8, columns: XCC_ID):", c.tolist())
+
+
 # ------------------------------------------------------------------ generation
 def test_logits_process_argmax():
     B, V, G = 6, 500, 40
