@@ -12,10 +12,12 @@
 //     workgroups (rb, *) of ITS OWN XCD: the hand-off is an 8-workgroup barrier on one L2 (one 64-bit arrival word), not a device
 //     barrier and not a kernel boundary.  Its W2 panel (96 x 384, 72 KB) is requested DURING phase 1 and is resident in LDS when
 //     the hand-off completes: phase 2 starts with every weight byte already on the CU.
-//   * The 8 partial products of an output tile (one per XCD) are reduced reduce-scatter style: every workgroup publishes its
-//     64 x 96 fp32 partial with write-through stores, the 8 owners of a tile meet on one arrival counter, and each then sums 3 of the
-//     tile's 24 MFMA tiles over the 8 slices IN SLICE ORDER (bit-reproducible), adds bias + residual, rounds, stores bf16 rows and the
-//     (sum, sum of squares) of what it stored: the LayerNorm statistics of the new residual stream as 48-column partials.
+//   * The 8 partial products of an output tile (one per XCD) are reduced by the LAST ARRIVER, without waiting: every wave publishes its
+//     16 x 96 fp32 partial with write-through stores and bumps the arrival counters of its two 48-column strips; the wave whose add
+//     comes last sums the strip over the 8 slices IN SLICE ORDER (bit-reproducible whoever is last), adds bias + residual, rounds,
+//     stores bf16 rows and the (sum, sum of squares) of what it stored: the LayerNorm statistics of the new residual stream as
+//     48-column partials.  (The first version met on a per-tile counter and reduce-scattered 3 MFMA tiles per slice: the wait cost
+//     3.4-3.8 us per launch, profiles/r06_v1_decode_mlp_one_launch_timeline_reduce_scatter.txt.)
 // Weights cross the fabric once (9.4 MB per block instead of ~38), no split-K slab of the hidden activations exists, and the
 // launch count of a block drops from 5 to 4.
 //
@@ -46,9 +48,9 @@ constexpr int DM_LDS = DM_STAT + 2 * DM_RB * 4;                    // 161280 byt
 constexpr int DM_GST = DM_RB * 128;                                // phase 2: 8 KB of G rows per K tile (overlays the ring)
 constexpr int DM_PART = DM_RB * DM_TN2 * 4;                        // 24 KB: one workgroup's fp32 partial
 static_assert(DM_LDS <= 160 * 1024 && DM_NK2 * DM_GST <= DM_W2OFF, "LDS plan");
-static_assert(DM_NT2 * 4 == 24 && DM_NX * 3 == 24, "reduce-scatter: 3 of a tile's 24 MFMA tiles per slice");
-// sync words (unsigned long long): [0, 32) hand-off groups (v * 4 + rb), [32, 64) reduce tiles (rb * 8 + ct), [64] finished, [65] error
-constexpr int DM_SY_GROUP = 0, DM_SY_TILE = 32, DM_SY_DONE = 64, DM_SY_ERR = 65, DM_SY_WORDS = 66;
+// sync words (unsigned long long): [0, 32) hand-off groups (v * 4 + rb), [64] finished, [65] error report, then 256 32-bit arrival
+// counters of the reduction ((tile * 4 + wave row) * 2 + 48-column strip), each re-armed by its last arriver
+constexpr int DM_SY_GROUP = 0, DM_SY_DONE = 64, DM_SY_ERR = 65, DM_SY_WORDS = 66, DM_SY_TOTAL = DM_SY_WORDS + 128;
 constexpr unsigned long long DM_TIMEOUT_TICKS = 400000ull;        // 4 ms of the 100 MHz real-time counter
 
 struct DmArgs {
@@ -286,36 +288,39 @@ __global__ __launch_bounds__(256) void decode_mlp_kernel(DmArgs p) {
 #pragma unroll
             for (int j = 0; j < DM_NT2; ++j)
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc2[j]), rws, tbase + v * DM_PART + (wave * DM_NT2 + j) * 1024 + lane * 16, 0, 16);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every write-through store of THIS wave acknowledged
             DM_STAMP(7);
-            if (tid == 0) {
-                unsigned long long* word = p.sync + DM_SY_TILE + t2;
-                __hip_atomic_fetch_add(word, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                s_ok = dm_wait(word, DM_NX, err) != 0ull;
-            }
-            __syncthreads();
-            live = s_ok != 0;
+            // ---- reduce by the last arriver, no waiting: an arrival counter per (tile, wave row, 48-column strip); the wave of the 8
+            // slices whose add comes last sums the strip over the slices IN SLICE ORDER (its own from registers: bit-reproducible
+            // whoever arrives last), adds bias + residual, rounds, stores the bf16 rows and their (sum, sum of squares) -- and re-arms
+            // the counter.  A wave signals only for its own stores (behind its own wait above).
+            unsigned* const cnt = reinterpret_cast<unsigned*>(p.sync + DM_SY_WORDS) + (t2 * 4 + wave) * 2;
+            unsigned old = 0;
+            if (lane < 2) old = __hip_atomic_fetch_add(cnt + lane, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned old0 = __builtin_amdgcn_readlane(old, 0), old1 = __builtin_amdgcn_readlane(old, 1);
             DM_STAMP(8);
-            if (live) {
-                // ---- reduce-scatter: slice v owns MFMA tiles {3 (v & 1) + w} of wave row (v >> 1); wave w < 3 sums one over the 8 slices
-                const int wq = v >> 1, jb = 3 * (v & 1);
-                float* const red = reinterpret_cast<float*>(smem + DM_PAD);          // [3][16][2]
-                if (wave < 3) {
-                    const int j = jb + wave;
-                    f32x4 prt[DM_NX];
 #pragma unroll
-                    for (int s = 0; s < DM_NX; ++s)
-                        prt[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rws, tbase + s * DM_PART + (wq * DM_NT2 + j) * 1024 + lane * 16, 0, 16));
-                    const int m = m0 + wq * 16 + l15, n = n2 + j * 16 + 4 * g;
+            for (int h = 0; h < 2; ++h) {
+                if ((h ? old1 : old0) != (unsigned)(DM_NX - 1)) continue;
+                if (lane == 0) __hip_atomic_store(cnt + h, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                f32x4 prt[DM_NX][3];
+#pragma unroll
+                for (int s = 0; s < DM_NX; ++s)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q)
+                        prt[s][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rws, tbase + s * DM_PART + (wave * DM_NT2 + 3 * h + q) * 1024 + lane * 16, 0, 16));
+                const int m = m0 + wave * 16 + l15;
+                const bool ok = m < p.M;
+                float r1 = 0.f, r2 = 0.f;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const int j = 3 * h + q, n = n2 + j * 16 + 4 * g;
                     const f32x4 bb = *reinterpret_cast<const f32x4*>(p.b2 + n);
-                    const bool ok = m < p.M;
                     bf16x4 x4 = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
                     if (ok) x4 = *reinterpret_cast<const bf16x4*>(p.X + (long)m * p.ldx + n);
-                    f32x4 sum = prt[0];
+                    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int s = 1; s < DM_NX; ++s) sum += prt[s];                 // slice order: bit-reproducible
-                    float r1 = 0.f, r2 = 0.f;
+                    for (int s = 0; s < DM_NX; ++s) sum += s == v ? acc2[j] : prt[s][q];        // slice order; mine from registers
                     bf16x4 o;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -325,18 +330,13 @@ __global__ __launch_bounds__(256) void decode_mlp_kernel(DmArgs p) {
                         r2 += f * f;
                     }
                     if (ok) *reinterpret_cast<bf16x4*>(p.C + (long)m * p.ldc + n) = o;
-                    r1 += __shfl_xor(r1, 16, 64); r2 += __shfl_xor(r2, 16, 64);
-                    r1 += __shfl_xor(r1, 32, 64); r2 += __shfl_xor(r2, 32, 64);
-                    if (g == 0) { red[(wave * 16 + l15) * 2] = r1; red[(wave * 16 + l15) * 2 + 1] = r2; }
                 }
-                __syncthreads();
-                if (tid < 16) {
-                    const int m = m0 + wq * 16 + tid;
-                    if (m < p.M) {
-                        float* dst = p.stats_out + ((long)m * DG_NP + ct * 2 + (v & 1)) * 2;
-                        dst[0] = red[tid * 2] + red[(16 + tid) * 2] + red[(32 + tid) * 2];
-                        dst[1] = red[tid * 2 + 1] + red[(16 + tid) * 2 + 1] + red[(32 + tid) * 2 + 1];
-                    }
+                r1 += __shfl_xor(r1, 16, 64); r2 += __shfl_xor(r2, 16, 64);
+                r1 += __shfl_xor(r1, 32, 64); r2 += __shfl_xor(r2, 32, 64);
+                if (g == 0 && ok) {
+                    float* dst = p.stats_out + ((long)m * DG_NP + ct * 2 + h) * 2;
+                    dst[0] = r1;
+                    dst[1] = r2;
                 }
             }
         }
@@ -348,7 +348,8 @@ __global__ __launch_bounds__(256) void decode_mlp_kernel(DmArgs p) {
     if (tid == 0) {
         const unsigned long long old = __hip_atomic_fetch_add(p.sync + DM_SY_DONE, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (old == (unsigned long long)(p.nwg - 1)) {
-            for (int i = 0; i <= DM_SY_DONE; ++i) __hip_atomic_store(p.sync + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int i = 0; i < 32; ++i) __hip_atomic_store(p.sync + DM_SY_GROUP + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(p.sync + DM_SY_DONE, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -371,7 +372,7 @@ __global__ __launch_bounds__(256) void decode_mlp_census_kernel(unsigned* out) {
 extern "C" long mmtg_decode_mlp_ws_floats(int M) {
     return (long)cdiv(M, DM_RB) * DM_NCT * DM_NX * (DM_PART / 4);
 }
-extern "C" int mmtg_decode_mlp_sync_words(void) { return DM_SY_WORDS; }
+extern "C" int mmtg_decode_mlp_sync_words(void) { return DM_SY_TOTAL; }
 
 extern "C" int mmtg_decode_mlp_census(unsigned* out64, void* stream) {
     MMTG_REQUIRE(out64, "decode_mlp_census: null pointer");

@@ -20,7 +20,8 @@ from mmtg_amd import hip  # noqa: E402
 DEV = "cuda"
 STAGES = ["start -> first K tile landed", "phase 1 K loop (c_fc, K = 768)", "GELU epilogue + G stores acknowledged",
           "hand-off wait (8 workgroups, one XCD)", "G rows -> LDS", "phase 2 (mlp.c_proj K slice, from LDS)",
-          "partial published (write-through, acknowledged)", "reduce wait (8 slices, 8 XCDs)", "reduce + bias + residual + statistics"]
+          "partial published (write-through, acknowledged)", "arrival counters bumped (2 returning atomics)",
+          "last arrivers: strips summed over the 8 slices, stored"]
 
 
 def main():
@@ -89,7 +90,7 @@ def main():
                 fused(l, plain, tr if (rep == 2 and l == L - 1) else None)
         torch.cuda.synchronize()
         t = tr.view(256, 12).double().cpu() / 100.0                  # us
-        live = t[:, 9] > 0
+        live = t[:, 8] > 0                                          # (workgroups past row M never reach the later stamps)
         t = t[live]
         t0 = t[:, 0].min()
         print("timeline, %s hand-off (%d workgroups; us, median / p90 / max over workgroups):" % ("L2" if plain else "write-through", int(live.sum())))

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 6, call A: the one-launch decode MLP -- op tests, stand-alone timeline, token-step A/B -- plus the new host-side tests.
-mkdir -p gpurun_out/r6a
-E=gpurun_out/r6a
+mkdir -p gpurun_out/r6b
+E=gpurun_out/r6b
 timeout 900 python -m pytest tests/test_ops_gpu.py -m gpu -q --no-header -p no:cacheprovider -x -k "decode_mlp or decode_gemm_ln_fold" 2>&1 | tail -15 | tee $E/pytest_mlp_ops.txt
 timeout 300 python tools/decode_mlp_timeline.py 256 2>&1 | tee $E/decode_mlp_timeline_m256.txt
 timeout 200 python tools/decode_mlp_timeline.py 128 2>&1 | tail -30 > $E/decode_mlp_timeline_m128.txt
@@ -16,4 +16,4 @@ for ln in sys.stdin:
 " | tee -a $E/decode_ab.txt
 done
 timeout 1500 python -m pytest tests/test_decode_gpu.py -m gpu -q --no-header -p no:cacheprovider -x -k "teacher_forced or fused_decode_step or x3_engine or full_size_batched" 2>&1 | tail -15 | tee $E/pytest_decode.txt
-timeout 900 python -m pytest tests/test_model_gpu.py -m gpu -q --no-header -p no:cacheprovider -x -k "evaluate" 2>&1 | tail -8 | tee $E/pytest_evaluate.txt
+
