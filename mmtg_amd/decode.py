@@ -156,13 +156,17 @@ class GreedyDecoder:
                 self.embed_in_proj = os.environ.get("MMTG_DECODE_EMBED_IN_PROJ", "1") != "0" and H % 8 == 0
                 # Round 6: c_fc -> GELU -> mlp.c_proj of a block as ONE launch (mmtg_decode_mlp): the hidden dimension is split over the
                 # XCDs, so the GEMM -> GEMM hand-off stays on one L2 and every weight crosses the fabric once; 4 graph nodes per
-                # block instead of 5.  Built for n_embd = 768 and up to 256 rows; MMTG_DECODE_MLP=0 keeps the two launches, =1
-                # forces the fused one at small batches too (tests).  MMTG_DECODE_MLP_HANDOFF=plain: through the L2 (checked per
-                # launch); default sc1 (write-through + agent-scope loads: valid under any workgroup placement).
-                # Not for the row blocks of a multi-lane decoder: its 256 workgroups must be co-resident, which side-by-side launches
-                # on several streams cannot promise.
-                mlp_env = os.environ.get("MMTG_DECODE_MLP")
-                self.mlp = _parent is None and D == 768 and B <= 256 and (mlp_env == "1" or (mlp_env is None and B >= 128))
+                # block instead of 5.  Built for n_embd = 768 and up to 256 rows, parity-tested, and OPT-IN (MMTG_DECODE_MLP=1):
+                # measured at batch 256 it ties the two launches stand-alone (20.2 against 20.8 us; 17.6 against 19.2 at 128 rows)
+                # and loses inside the token step (713-720 against 682-695 us): the boundary it removes costs 1.1-1.7 us
+                # (profiles/r06_v2_graph_node_floor_by_launch_shape.txt) + a ~2 us first-tile ramp, the hand-off that replaces it
+                # 0.96 us of store acknowledgement + 2.75 us of wait (arrival skew of the 8 producers) + 0.69 us of reload
+                # (profiles/r06_v2_decode_mlp_in_step_timeline.txt), and the 8-way cross-XCD reduction has a longer tail than the
+                # 4-way one.  MMTG_DECODE_MLP_HANDOFF=plain: through the L2 (checked per launch; slower in the step: its partial-line
+                # stores fetch lines); default sc1 (write-through + agent-scope loads: valid under any workgroup placement).
+                # Never for the row blocks of a multi-lane decoder: its 256 workgroups must be co-resident, which side-by-side
+                # launches on several streams cannot promise.
+                self.mlp = _parent is None and D == 768 and B <= 256 and os.environ.get("MMTG_DECODE_MLP") == "1"
                 if self.mlp:
                     self.mlp_ws = f32(hip.decode_mlp_ws_floats(B))
                     self.mlp_sync = torch.zeros(hip.decode_mlp_sync_words(), dtype=torch.int64, device=dev)
