@@ -33,6 +33,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# (before the HIP runtime can initialise: kernel arguments in device memory, as `import mmtg_amd` sets it for any user of the
+#  package -- mmtg_amd/__init__.py has the measurement)
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -542,11 +545,21 @@ def f32_object(args, dev, mcfg, dcfg, gcfg, V, steps=5, warmup=2, mode="f32"):
                 "bf16 plane pairs with fp32 accumulation -- held to the SAME parity tests as 'f32' (tests/test_model_gpu.py PARITY_MODES, "
                 "tests/test_decode_gpu.py): logits <= 1e-3, greedy ids bit-exact against the reference's goldens")
     roof["per_category_ms_per_step"] = {k: round(v["ms"] / steps, 3) for k, v in prof.items() if v["launches"]}
+    if mode == "bf16x3f":
+        roof.pop("achieved_mfma_work", None)
+        roof["frac"] = None
+        roof["note"] = ("mixed: the forward's products issue three bf16 MFMA passes, the backward's one -- `achieved` = algorithmic product "
+                        "FLOPs (2 M N K) / kernel time of both")
+        note = ("compute_dtype='bf16x3f' (round 6): the bf16x3 forward -- logits / loss / KL / greedy ids at the fp32 mode's parity "
+                "(tests/test_model_gpu.py FORWARD_PARITY_MODES) -- with the backward as ONE bf16 matrix-core pass per product over the hi "
+                "planes the forward stored: gradients at the bf16 mode's accuracy (test_bf16_vs_oracle, test_full_12l_gradients_vs_golden)")
     out = {"train": {"value": round(B * T * steps / el, 1), "unit": "tokens/s", "ms_per_step": round(1e3 * el / steps, 3),
                      "steps": steps, "warmup": warmup, "rows": B, "seq_len": T, "roofline": roof},
            "note": note}
     del trainer, model
     torch.cuda.empty_cache()
+    if mode == "bf16x3f":       # (its decode step is the bf16x3 one: see that object)
+        return out
     a2 = copy.copy(args)
     a2.dtype, a2.no_roofline, a2.no_cpu_baseline = mode, True, True
     d = bench_decode(a2, 1, 0, dev, steps=1 if mode == "f32" else 3, warmup=1, with_cpu=False)
@@ -703,7 +716,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="rows per GPU")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "bf16x3"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "bf16x3", "bf16x3f"])
     ap.add_argument("--layers", type=int, default=12)
     ap.add_argument("--config", default="base", choices=["base", "medium"],
                     help="medium: BASELINE configs[4] (GPT-2-medium 24L/1024/16H, S=8, T=512, rating skew K=32)")
@@ -936,12 +949,14 @@ def main():
             torch.cuda.empty_cache()
             return {"error": "%s: %s" % (type(e).__name__, str(e)[:400])}
 
-    f32 = x3 = None
+    f32 = x3 = x3f = None
     extras = rank == 0 and world == 1 and not ddp and args.config == "base" and args.layers == 12 and args.dtype == "bf16"
     if extras and not args.no_x3:
         trainer = model = None
         torch.cuda.empty_cache()
         x3 = guarded(f32_object, args, dev, mcfg, dcfg, gcfg, V, mode="bf16x3")
+        torch.cuda.empty_cache()
+        x3f = guarded(f32_object, args, dev, mcfg, dcfg, gcfg, V, mode="bf16x3f")
     if extras and not args.no_f32:
         trainer = model = None
         torch.cuda.empty_cache()
@@ -980,6 +995,8 @@ def main():
             out["decode"] = decode
         if x3 is not None:
             out["bf16x3"] = x3
+        if x3f is not None:
+            out["bf16x3f"] = x3f
         if f32 is not None:
             out["f32"] = f32
         if x3 is not None or f32 is not None:
@@ -1001,6 +1018,9 @@ def main():
                         decode_frac=dr.get("frac"),
                         decode_traffic_ratio=(round(dr["traffic"] / dr["algorithmic_bytes_per_token_step"], 3)
                                               if dr.get("traffic") and dr.get("algorithmic_bytes_per_token_step") else None))
+        if isinstance(x3f, dict) and "train" in x3f:
+            summ.update(forward_parity_dtype="bf16x3f", forward_parity_train_tokens_per_s=x3f["train"]["value"],
+                        forward_parity_train_ms_per_step=x3f["train"]["ms_per_step"])
         if isinstance(x3, dict) and "train" in x3:
             summ.update(parity_dtype="bf16x3", parity_train_tokens_per_s=x3["train"]["value"], parity_train_ms_per_step=x3["train"]["ms_per_step"],
                         parity_decode_tokens_per_s=x3.get("decode", {}).get("value"),

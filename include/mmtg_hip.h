@@ -76,6 +76,8 @@ enum {
                                     MMTG_EPI_DGELU multiplies by aux as it is (C = acc * aux): the backward then needs no transcendental --
                                     the only consumer of the saved pre-activation was gelu' (both products of a pair must carry the flag) */
 #define MMTG_GEMM_P8 16384       /* flags: eight-phase kernel also for the dGELU product (otherwise on the single-stage kernel by measurement) */
+#define MMTG_GEMM_AUX2_BF16 131072 /* flags (round 6, mmtg_gemm_x3 only): MMTG_EPI_GELU stores aux2 (the pre-activation) as bf16 rows [M, ldc] instead of
+                                     fp32 -- the hybrid mode (compute_dtype "bf16x3f") runs its backward on the bf16 kernels */
 #define MMTG_GEMM_P8_288 65536   /* flags (round 4): force the eight-phase kernel's 288-row tiles where it applies (the tile rule picks them by cost; tests / A-B) */
 #define MMTG_GEMM_P256 4096      /* flags: persistent pipelined kernel with 256x128 tiles, 8 waves, one workgroup per CU (bf16, transA = 0) */
 #define MMTG_GEMM_COL_BLOCK 2048 /* flags: force the column-blocked item order with blocks of two tile columns (test hook;
@@ -131,9 +133,11 @@ MMTG_API int mmtg_gemm_x3(int M, int N, int K, const void* A, long lda, long pla
 /* fp32 [rows, cols] (ld = lds) -> its (hi | lo) bf16 plane pair (ld = ldp, lo plane `plane` elements behind the hi plane). */
 MMTG_API int mmtg_split_planes(const float* src, long lds, int rows, int cols, void* planes, long ldp, long plane, void* stream);
 /* LayerNorm forward (fp32 rows in, statistics out as mmtg_layernorm_fwd) whose output goes straight to a plane pair: the
- * GPT-2 LayerNorms feed products only (ln_1 -> c_attn, ln_2 -> c_fc, ln_f -> lm_head), so the fp32 rows are never stored. */
+ * GPT-2 LayerNorms feed products only (ln_1 -> c_attn, ln_2 -> c_fc, ln_f -> lm_head), so the fp32 rows are never stored.
+ * x_bf16 (nullable, round 6): also receives bf16(x) [rows, cols] -- the input rows as the bf16 LayerNorm backward reads them
+ * (compute_dtype "bf16x3f": split-precision forward, bf16 backward). */
 MMTG_API int mmtg_layernorm_fwd_x3(const float* x, void* planes, long ldp, long plane, const float* gamma, const float* beta,
-                          float* mean, float* rstd, int rows, int cols, float eps, void* stream);
+                          float* mean, float* rstd, int rows, int cols, float eps, void* x_bf16, void* stream);
 
 /* Products whose operand rows are GATHERED from a table by index -- the multi-modal conditioning front end of
  * GPT2_Decoder.forward (model.py:254-281) without materialising X[m] = E[id_m] + c[b, seg_m] (62 MB at B = 64):

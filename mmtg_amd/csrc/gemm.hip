@@ -1547,6 +1547,7 @@ extern "C" int mmtg_gemm_x3(int M, int N, int K, const void* A, long lda, long p
     a.bytesA = (int)bytesA; a.bytesB = (int)bytesB;
     a.planeA = (int)(planeA * 2); a.planeB = (int)(planeB * 2);
     a.planes = planes; a.ldp = ldp; a.plane_out = plane_out;
+    a.aux2_bf16 = (flags & MMTG_GEMM_AUX2_BF16) ? 1 : 0;
     a.x3 = 1;
     a.kper = K;
     a.drop_thresh = drop_thresh; a.drop_seed = drop_seed;

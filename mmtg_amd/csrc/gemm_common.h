@@ -46,6 +46,7 @@ struct GemmArgs {
     int planeA, planeB;    // bytes from an operand's hi plane to its lo plane (x3 kernels only)
     void* planes;          // optional second output of the x3 epilogues: the result as a (hi | lo) plane pair, ld = ldp
     long ldp, plane_out;   // plane_out: ELEMENTS from the hi plane to the lo plane of `planes`
+    int aux2_bf16;         // MMTG_GEMM_AUX2_BF16: the x3 GELU epilogue stores its second output (pre-activation) as bf16 rows
 };
 
 template <typename T> struct GT {
@@ -396,7 +397,10 @@ __device__ __forceinline__ void epi_tiles(const GemmArgs& p, f32x4 (&acc)[TM][TN
                     float gd[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) gd[e] = gelu_new_grad_t<TF>(v[e]);
-                    store8<T>(reinterpret_cast<T*>(p.aux2) + (long)m * p.ldc + n, gd);
+                    if (X3 && p.aux2_bf16) store8<bf16>(reinterpret_cast<bf16*>(p.aux2) + (long)m * p.ldc + n, gd);
+                    else store8<T>(reinterpret_cast<T*>(p.aux2) + (long)m * p.ldc + n, gd);
+                } else if (X3 && p.aux2_bf16) {      // (bf16x3f: the bf16 backward's dGELU epilogue reads bf16 rows)
+                    store8<bf16>(reinterpret_cast<bf16*>(p.aux2) + (long)m * p.ldc + n, v);
                 } else {
                     store8<T>(reinterpret_cast<T*>(p.aux2) + (long)m * p.ldc + n, v);
                 }

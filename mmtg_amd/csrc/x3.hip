@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
 __global__ __launch_bounds__(256) void ln_fwd_planes_kernel(const float* __restrict__ x, bf16* __restrict__ y, long ldp, long plane,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             float* __restrict__ mean, float* __restrict__ rstd,
-                                                            int rows, int cols, float eps) {
+                                                            int rows, int cols, float eps, bf16* __restrict__ xb) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -57,6 +57,12 @@ __global__ __launch_bounds__(256) void ln_fwd_planes_kernel(const float* __restr
             const f32x4 a = *reinterpret_cast<const f32x4*>(xr + c), b = *reinterpret_cast<const f32x4*>(xr + c + 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[it][e] = a[e]; v[it][4 + e] = b[e]; }
+            if (xb) {       // (bf16x3f: the rows as the bf16 backward's LayerNorm kernels read them)
+                bf16x8 xo;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xo[e] = (bf16)v[it][e];
+                *reinterpret_cast<bf16x8*>(xb + (long)row * cols + c) = xo;
+            }
 #pragma unroll
             for (int e = 0; e < 8; ++e) s += v[it][e];
         }
@@ -114,14 +120,14 @@ extern "C" int mmtg_split_planes(const float* src, long lds_, int rows, int cols
 }
 
 extern "C" int mmtg_layernorm_fwd_x3(const float* x, void* planes, long ldp, long plane, const float* gamma, const float* beta,
-                                     float* mean, float* rstd, int rows, int cols, float eps, void* stream) {
+                                     float* mean, float* rstd, int rows, int cols, float eps, void* x_bf16, void* stream) {
     MMTG_REQUIRE(rows > 0 && cols > 0 && cols % 8 == 0 && cols <= 1024, "layernorm_fwd_x3: cols=%d must be a multiple of 8 and <= 1024", cols);
     MMTG_REQUIRE(x && planes && gamma && beta && mean && rstd, "layernorm_fwd_x3: null pointer");
     MMTG_REQUIRE(ldp % 8 == 0 && plane % 8 == 0 && ldp >= cols && plane >= (long)(rows - 1) * ldp + cols && MMTG_ALIGNED16(x) && MMTG_ALIGNED16(planes) &&
-                 MMTG_ALIGNED16(gamma) && MMTG_ALIGNED16(beta), "layernorm_fwd_x3: alignment / plane layout");
+                 MMTG_ALIGNED16(gamma) && MMTG_ALIGNED16(beta) && MMTG_ALIGNED16(x_bf16), "layernorm_fwd_x3: alignment / plane layout");
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(MMTG_PROF_LAYERNORM, s, 8.0 * rows * cols, 8.0 * rows * cols);
-    hipLaunchKernelGGL(ln_fwd_planes_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, (bf16*)planes, ldp, plane, gamma, beta, mean, rstd, rows, cols, eps);
+    hipLaunchKernelGGL(ln_fwd_planes_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, (bf16*)planes, ldp, plane, gamma, beta, mean, rstd, rows, cols, eps, (bf16*)x_bf16);
     MMTG_LAUNCH_CHECK("layernorm_fwd_x3");
     return MMTG_OK;
 }

@@ -17,6 +17,7 @@ Reference semantics (file:line into /root/reference/src):
 """
 from __future__ import annotations
 
+import contextlib
 import math
 
 import numpy as np
@@ -301,10 +302,12 @@ def initial_drop_seed(rank=0):
 class Engine:
     """Owns the flat buffers and runs forward / loss / backward / optimizer."""
 
-    def __init__(self, model_cfgs, data_cfg, gpt2_cfg, master, table, dtype=hip.BF16, x3=False):
+    def __init__(self, model_cfgs, data_cfg, gpt2_cfg, master, table, dtype=hip.BF16, x3=False, hybrid=False):
         hip.lib()  # fail loudly if the extension is not built
         if x3 and dtype != hip.F32:
             raise ValueError("the split-precision (bf16x3) products belong to fp32 storage")
+        if hybrid and not x3:
+            raise ValueError("the hybrid mode (bf16x3f) is the split-precision forward with a bf16 backward: it needs x3")
         if not master.is_cuda:
             raise RuntimeError("the MMTG engine runs on an MI355X (cuda) device only -- there is no CPU path")
         self.sh = Shapes(model_cfgs, data_cfg, gpt2_cfg)
@@ -323,6 +326,10 @@ class Engine:
         # x3 (round 5): fp32 storage everywhere, the GPT-2 / LM-head products on the bf16 matrix cores as three passes over
         # (hi | lo) bf16 plane pairs (hip.gemm_x3).  wc2 = the plane pair of the whole flat parameter buffer.
         self.x3 = bool(x3)
+        # hybrid ("bf16x3f", round 6): the forward of the x3 mode -- logits / loss / KL at the fp32 mode's parity -- and the backward of
+        # the bf16 mode, ONE matrix-core pass per product, over the hi planes the forward stored (hi = bf16(x): exactly the tensor the
+        # bf16 kernels take, same leading dimension) and the hi planes of the weights; the encoder / fuser stay exact fp32 both ways
+        self.hybrid = bool(hybrid)
         self.wc2 = torch.zeros(2, self.layout.total, device=self.dev, dtype=torch.bfloat16) if self.x3 else None
         self.copies_fresh = dtype == hip.F32 and not self.x3
         self._init_transposed()
@@ -836,7 +843,11 @@ class Engine:
                 # split-precision attention read them -- the attention context is needed in fp32 by its backward's delta AND as
                 # planes by c_proj
                 a1 = self.pbuf(f"l{l}_a", M, D)
-                hip.layernorm_fwd_x3(hcur, a1, self.P(p + "ln_1.weight"), self.P(p + "ln_1.bias"), mu1, rs1, M, D, sh.eps)
+                hyb = self.hybrid
+                # (hybrid: the LayerNorm kernels also store their input rows as bf16 -- what the bf16 LayerNorm backward reads)
+                xb1 = self.buf(f"l{l}_xin_b", (M, D), torch.bfloat16) if hyb else None
+                xb2 = self.buf(f"l{l}_xmid_b", (M, D), torch.bfloat16) if hyb else None
+                hip.layernorm_fwd_x3(hcur, a1, self.P(p + "ln_1.weight"), self.P(p + "ln_1.bias"), mu1, rs1, M, D, sh.eps, xb=xb1)
                 qkv = self.pbuf(f"l{l}_qkvp", M, 3 * D)
                 self._fwd_x3(a1, p + "attn.c_attn.weight", None, M, bias=self.P(p + "attn.c_attn.bias"), planes=qkv, ldc=3 * D)
                 if not need_logits and l == sh.L - 1:      # (the prefill wants K / V only: nothing of the last block beyond c_attn)
@@ -850,15 +861,18 @@ class Engine:
                 self._fwd_x3(ctxp, p + "attn.c_proj.weight", xmid, M, bias=self.P(p + "attn.c_proj.bias"),
                              epi=hip.EPI_RESID, aux=hcur, ldaux=D, drop_p=pr, drop_seed=s[1])
                 m2 = self.pbuf(f"l{l}_m", M, D)
-                hip.layernorm_fwd_x3(xmid, m2, self.P(p + "ln_2.weight"), self.P(p + "ln_2.bias"), mu2, rs2, M, D, sh.eps)
-                u = self.buf(f"l{l}_u", (M, 4 * D))
+                hip.layernorm_fwd_x3(xmid, m2, self.P(p + "ln_2.weight"), self.P(p + "ln_2.bias"), mu2, rs2, M, D, sh.eps, xb=xb2)
+                # (hybrid: the saved pre-activation as bf16 rows, the bf16 dGELU epilogue's operand -- half the bytes, too)
+                u = self.buf(f"l{l}_u_b" if hyb else f"l{l}_u", (M, 4 * D), torch.bfloat16 if hyb else None)
                 gact = self.pbuf(f"l{l}_g", M, 4 * D)
                 self._fwd_x3(m2, p + "mlp.c_fc.weight", None, M, bias=self.P(p + "mlp.c_fc.bias"), planes=gact, ldc=4 * D,
-                             epi=hip.EPI_GELU, aux2=u)
+                             epi=hip.EPI_GELU, aux2=u, flags=hip.GEMM_AUX2_BF16 if hyb else 0)
                 xout = self.buf(f"resid_{l + 1}", (M, D))
                 self._fwd_x3(gact, p + "mlp.c_proj.weight", xout, M, bias=self.P(p + "mlp.c_proj.bias"),
                              epi=hip.EPI_RESID, aux=xmid, ldaux=D, drop_p=pr, drop_seed=s[2])
                 layers.append((hcur, mu1, rs1, a1, qkv, ctx, lse, xmid, mu2, rs2, m2, u, gact, s, ctxp))
+                if hyb:
+                    a.setdefault("hyb_rows", []).append((xb1, xb2))
                 hcur = xout
                 continue
             a1 = self.buf(f"l{l}_a", (M, D))
@@ -900,7 +914,9 @@ class Engine:
         logits = self.buf("logits" if l32 else "logits_c", (M, Vp), torch.float32 if l32 else self.tdt)
         if x3:
             hf = self.pbuf("hf", M, D)
-            hip.layernorm_fwd_x3(hcur, hf, self.P(pre + "ln_f.weight"), self.P(pre + "ln_f.bias"), muf, rsf, M, D, sh.eps)
+            if self.hybrid:
+                a["x_last_b"] = self.buf("x_last_b", (M, D), torch.bfloat16)
+            hip.layernorm_fwd_x3(hcur, hf, self.P(pre + "ln_f.weight"), self.P(pre + "ln_f.bias"), muf, rsf, M, D, sh.eps, xb=a.get("x_last_b"))
             hip.gemm_x3(hf, self.Wpx("wte", Vp, D), logits, M, Vp, D)
         else:
             hf = self.buf("hf", (M, D))
@@ -951,6 +967,12 @@ class Engine:
     def loss_backward(self, gscale=1.0, lm_coef=0.0):
         """d(gscale * MyLoss + lm_scale * LM loss)/d logits into the engine's dlogits buffer."""
         a, sh = self.act, self.sh
+        if a.get("x3") and self.hybrid:
+            # hybrid: fp32 logits in, the gradient as bf16 rows (the bf16 backward's LM-head operand)
+            dl = self.buf("dlogits_b", (a["M"], self.layout.Vpad), torch.bfloat16)
+            hip.loss_bwd(a["logits"], self.layout.Vpad, sh.V, a["topic_ids"], a["targets"], a["lse_rows"], a["coef"],
+                         gscale, a["B"], sh.P, a["L"], dl, self.layout.Vpad, self.layout.Vpad, lm_coef=lm_coef)
+            return dl
         if a.get("x3"):
             # x3: the gradient goes straight into the plane pair the LM head's split-precision products read
             dlp = self.pbuf("dlogits_p", a["M"], self.layout.Vpad)
@@ -966,7 +988,7 @@ class Engine:
     def dlogits_from(self, g32):
         """External d(logits) [B,T,V] fp32 (drop-in autograd path) -> padded compute-dtype buffer."""
         a = self.act
-        dl = self.buf("dlogits", (a["M"], self.layout.Vpad))
+        dl = self.buf("dlogits_b", (a["M"], self.layout.Vpad), torch.bfloat16) if (self.hybrid and a.get("x3")) else self.buf("dlogits", (a["M"], self.layout.Vpad))
         g32 = g32.contiguous().view(a["M"], self.sh.V)
         hip.cast_pad_rows(g32, self.sh.V, dl, self.layout.Vpad, a["M"], self.sh.V)
         return dl
@@ -1005,15 +1027,77 @@ class Engine:
         if self.bucket_hook is not None:
             self.bucket_hook(pack)
 
+    @contextlib.contextmanager
+    def _as_bf16(self):
+        """The decoder part of the hybrid mode's backward runs the bf16 mode's code path on an fp32-storage engine: for its
+        duration the engine presents bf16 storage -- buffers default to bf16, W() / Wt() / the [D, Vpad] copy are the HI planes of
+        the weight plane pairs (hi = bf16(w): the bf16 mode's own weight copy, bit for bit)."""
+        saved = (self.dtype, self.tdt, self.x3, self.wc, self.wt, self.wte_t)
+        self.dtype, self.tdt, self.x3 = hip.BF16, torch.bfloat16, False
+        self.wc = self.wc2[0]
+        self.wt = None if saved[4] is None else saved[4][0]
+        self.wte_t = None if saved[5] is None else saved[5][0]
+        try:
+            yield
+        finally:
+            self.dtype, self.tdt, self.x3, self.wc, self.wt, self.wte_t = saved
+
+    def _backward_hybrid(self, dlogits, dkl):
+        """compute_dtype "bf16x3f": d(logits) through the decoder as ONE bf16 pass per product -- the bf16 mode's kernels over the hi
+        planes the split-precision forward stored (LayerNorm outputs, qkv, attention context, GELU output, projector activations),
+        the bf16 copies of the LayerNorm inputs and of the c_fc pre-activation it wrote beside them, and the hi planes of the
+        weights -- then the encoder / fuser backward in exact fp32 as in the x3 mode.  Gradients land in the same flat fp32 buffer."""
+        a, sh = self.act, self.sh
+        M, Vp = a["M"], self.layout.Vpad
+        if isinstance(dlogits, hip.Planes):
+            dlogits = dlogits.t[0]
+        if dlogits.dtype != torch.bfloat16:
+            dlb = self.buf("dlogits_b", (M, Vp), torch.bfloat16)
+            hip.cast_f32_to(dlogits, dlb, M * Vp)
+            dlogits = dlb
+        hi = lambda pl: pl.t[0]
+        layers = []
+        for rec, (xb1, xb2) in zip(a["layers"], a["hyb_rows"]):
+            (xin, mu1, rs1, a1, qkv, ctx, lse, xmid, mu2, rs2, m2, u, gact, s_, ctxp) = rec
+            layers.append((xb1, mu1, rs1, hi(a1), hi(qkv), hi(ctxp), lse, xb2, mu2, rs2, hi(m2), u, hi(gact), s_, None))
+        ab = dict(a)
+        if a.get("px3"):
+            h1b, xb = hi(a["h1p"]), hi(a["xp"])
+        else:       # (projector widths the split-precision products do not tile: fp32 rows, cast once)
+            h1b = self.buf("h1_b", tuple(a["h1"].shape), torch.bfloat16)
+            hip.cast_f32_to(a["h1"], h1b, a["h1"].numel())
+            xb = self.buf("x_cond_b", tuple(a["x"].shape), torch.bfloat16)
+            hip.cast_f32_to(a["x"], xb, a["x"].numel())
+        ab.update(x3=False, px3=False, gelu_grad=False, layers=layers, x_last=a["x_last_b"], hf=hi(a["hf"]), h1=h1b, x=xb, ids32=None)
+        try:
+            with self._as_bf16():
+                self.act = ab
+                seg = self._backward_decoder(ab, dlogits)
+        finally:
+            self.act = a
+        seg32 = self.buf("d_seg32", tuple(seg.shape), torch.float32)
+        hip.cast_to_f32(seg, seg32, seg.numel())
+        self._backward_encoder(a, seg32, dkl)
+
     def backward(self, dlogits, dkl=0.0):
         """Back-propagate d(logits) [M,Vpad] (compute dtype) and d(kl) through the whole
         model; parameter gradients are ACCUMULATED into the flat fp32 buffer."""
-        a, sh = self.act, self.sh
+        a = self.act
         self.ensure_grad()
         if self._lazy is not None and not self.wgrad_overwrite:
             # (a backward that accumulates after a zero_grad(shape_key) that relied on overwrites: zero what it skipped)
             self.grad.zero_()
             self._lazy = None
+        if self.hybrid and a.get("x3"):
+            self._backward_hybrid(dlogits, dkl)
+        else:
+            self._backward_encoder(a, self._backward_decoder(a, dlogits), dkl)
+        self._lazy = None
+
+    def _backward_decoder(self, a, dlogits):
+        """LM head -> GPT-2 blocks -> input embedding -> projector; returns the per-segment sums of d(h1_pre) [B*S, H] that the
+        experience vectors' gradient is made of."""
+        sh = self.sh
         B, T, M, L = a["B"], a["T"], a["M"], a["L"]
         S, E, H, D, P = sh.S, sh.E, sh.H, sh.D, sh.P
         pe, pa, pr = a["pdrop"]
@@ -1296,6 +1380,14 @@ class Engine:
             hip.colsum(dh1, M, H, self.G("decoder.projector_layer1.bias"))      # (the weight gradient went with W2's above)
         else:
             self._wgrad(a["x"], dh1, "decoder.projector_layer1.weight", "decoder.projector_layer1.bias", M, "linear")
+        return seg
+
+    def _backward_encoder(self, a, seg, dkl):
+        """d c = seg W1 -> beta fuser -> alpha attention + LayerNorm + recurrent channels -> topic channel."""
+        sh = self.sh
+        B, M = a["B"], a["M"]
+        S, E, H, D = sh.S, sh.E, sh.H, sh.D
+        lnws = self.buf("ln_bwd_ws", (hip.lib().mmtg_layernorm_bwd_ws(M, max(D, H)),), torch.float32)
         dc = self.buf("d_c", (B * S, E))
         self._dgrad(seg, "decoder.projector_layer1.weight", dc, B * S, "linear")
         # ---- beta fuser
@@ -1335,7 +1427,6 @@ class Engine:
                           self.G("ln_layer1.weight"), self.G("ln_layer1.bias"), B, H, ws=lnws)
         self._wgrad(a["xt"], dt_raw, "encoder.topic_fc.weight", "encoder.topic_fc.bias", B, "linear")
         self._ready("encoder.topic_fc.bias")
-        self._lazy = None
 
     def _rnn_bwd(self, ch, layers, dh_all, B, dhp32, tmp32):
         """BPTT of one encoder channel (rows b*S+t), top layer first.  dh_all [B*S, H]: gradient of the top layer's outputs."""

@@ -19,6 +19,7 @@ GEMM_NO_TR, GEMM_REGSTAGE, GEMM_SKINNY, GEMM_NO_SKINNY, GEMM_WIDE, GEMM_NO_WIDE 
 GEMM_PERSIST, GEMM_NO_PERSIST, GEMM_ROW_ORDER, GEMM_OCC4, GEMM_NO_OCC4, GEMM_COL_BLOCK, GEMM_P256, GEMM_NO_P8, GEMM_P8 = 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384
 GEMM_GELU_GRAD = 32768
 GEMM_P8_288 = 65536
+GEMM_AUX2_BF16 = 131072     # mmtg_gemm_x3: the GELU epilogue stores the pre-activation as bf16 rows (bf16x3f)
 PROF_CATS = ["gemm_bf16", "gemm_f32", "attn_fwd", "attn_bwd", "layernorm", "embed", "loss",
              "optim", "encoder", "decode", "misc"]
 
@@ -76,7 +77,7 @@ _SIGS = {
     "mmtg_adamw": ([_vp, _vp, _vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _i, _vp, _f, _f, _vp, _vp], _i),
     "mmtg_gemm_x3": ([_i, _i, _i, _vp, _l, _l, _vp, _l, _l, _vp, _l, _vp, _l, _l, _vp, _i, _vp, _l, _vp, _u, _u, _i, _vp], _i),
     "mmtg_split_planes": ([_vp, _l, _i, _i, _vp, _l, _l, _vp], _i),
-    "mmtg_layernorm_fwd_x3": ([_vp, _vp, _l, _l, _vp, _vp, _vp, _vp, _i, _i, _f, _vp], _i),
+    "mmtg_layernorm_fwd_x3": ([_vp, _vp, _l, _l, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp], _i),
     "mmtg_cast_f32_to": ([_i, _vp, _vp, _l, _vp], _i),
     "mmtg_cast_pad_rows": ([_i, _vp, _l, _vp, _l, _i, _i, _vp], _i),
     "mmtg_cast_to_f32": ([_i, _vp, _vp, _l, _vp], _i),
@@ -272,9 +273,9 @@ def split_planes(src, rows, cols, out, lds=None):
     return out
 
 
-def layernorm_fwd_x3(x, out, gamma, beta, mean, rstd, rows, cols, eps=1e-5):
+def layernorm_fwd_x3(x, out, gamma, beta, mean, rstd, rows, cols, eps=1e-5, xb=None):
     _check(lib().mmtg_layernorm_fwd_x3(_p(x), _p(out.t), out.ld, out.plane, _p(gamma), _p(beta), _p(mean), _p(rstd), rows, cols,
-                                       float(eps), _stream()), "layernorm_fwd_x3")
+                                       float(eps), _p(xb), _stream()), "layernorm_fwd_x3")
 
 
 def gemm_x3(A, B, C_, M, N, K, planes=None, ldc=None, bias=None, epi=EPI_NONE, aux=None, ldaux=0, aux2=None,

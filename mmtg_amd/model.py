@@ -147,9 +147,11 @@ class MMTG(nn.Module):
     Extra keyword arguments (all optional, the positional contract is unchanged):
       gpt2_config   dict overriding config/model_config.json
       token_table   WenLan table (dict or [V,2048]); default ./vocab/token_id2emb_dict.pkl
-      compute_dtype 'bf16' (default; bf16 storage, fp32 accumulate), 'f32' (exact fp32 MFMA) or 'bf16x3' (fp32 storage,
+      compute_dtype 'bf16' (default; bf16 storage, fp32 accumulate), 'f32' (exact fp32 MFMA), 'bf16x3' (fp32 storage,
                     the GPT-2 / lm_head products as three bf16 matrix-core passes over (hi | lo) split operands: the
-                    fp32 mode's parity at a multiple of its speed)
+                    fp32 mode's parity at a multiple of its speed) or 'bf16x3f' (round 6: bf16x3's forward -- logits, loss,
+                    KL and greedy ids at the fp32 mode's parity -- with the backward as ONE bf16 pass over the hi planes the
+                    forward stored: gradients at the bf16 mode's accuracy)
     """
 
     def __init__(self, model_cfgs, data_config, vocab_size, train_flag=False, gpt2_config=None,
@@ -164,8 +166,9 @@ class MMTG(nn.Module):
         assert model_cfgs["topic"]["hidden_dim"] == model_cfgs["image"]["hidden_dim"] == model_cfgs["text"]["hidden_dim"], \
             "The hidden dim of topic, image and text must be equal."
         compute_dtype = compute_dtype or os.environ.get("MMTG_DTYPE", "bf16")
-        self.compute_dtype = {"bf16": hip.BF16, "f32": hip.F32, "fp32": hip.F32, "bf16x3": hip.F32}[compute_dtype]
-        self.x3 = compute_dtype == "bf16x3"
+        self.compute_dtype = {"bf16": hip.BF16, "f32": hip.F32, "fp32": hip.F32, "bf16x3": hip.F32, "bf16x3f": hip.F32}[compute_dtype]
+        self.x3 = compute_dtype in ("bf16x3", "bf16x3f")
+        self.hybrid = compute_dtype == "bf16x3f"      # split-precision forward (the reference's outputs to 1e-3), ONE bf16 pass backward
 
         self.encoder = MultiModalEncoder()
         self.ln_layer1 = _Holder()
@@ -306,7 +309,7 @@ class MMTG(nn.Module):
                 raise RuntimeError("MMTG.forward needs the model on an MI355X: call model.to('cuda'). "
                                    "The hot path is HIP-only (no CPU fallback).")
             self._engine = Engine(self.model_cfgs, self.data_config, self.gpt2_cfg, self._flat,
-                                  self.decoder._table, self.compute_dtype, x3=self.x3)
+                                  self.decoder._table, self.compute_dtype, x3=self.x3, hybrid=self.hybrid)
             self._anchor = torch.zeros((), device=self._flat.device, requires_grad=True)
         return self._engine
 

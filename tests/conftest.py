@@ -1,6 +1,8 @@
 import os
 import sys
 
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")      # as `import mmtg_amd` sets it (before the HIP runtime initialises)
+
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
