@@ -41,6 +41,12 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+from bench_parts import common as _common  # noqa: E402
+from bench_parts.common import _host_threads, _timed, gpu_rewarm  # noqa: E402
+from bench_parts.decode import bench_decode  # noqa: E402
+from bench_parts.launch import _claim_stdout, _dry_launch, _emit, _self_launch  # noqa: E402
+from bench_parts.objects import _pmc_traffic, allreduce_probe, conditioning_probe, f32_object, medium_object  # noqa: E402
+
 
 def algorithmic_flops_per_token(S, T, D, L, V, H=512, E=2048):
     """forward FLOPs per decoder token (causal-half attention), x3 for training."""
@@ -51,23 +57,6 @@ def algorithmic_flops_per_token(S, T, D, L, V, H=512, E=2048):
     fwd = L * (layer + attn) + head + proj
     enc_per_sample = 2 * (E * H) + 2 * S * 2 * (E * 3 * H + H * 3 * H) + 2 * S * 2 * (H * 3 * H) + 2 * S * H * E
     return fwd, enc_per_sample
-
-
-def _host_threads():
-    """Cores this process may actually run on (the box advertises more logical CPUs than the job's
-    affinity / cgroup grants; oversubscribing them stalls OpenMP)."""
-    try:
-        ncpu = len(os.sched_getaffinity(0))
-    except AttributeError:
-        ncpu = os.cpu_count() or 1
-    quota = ncpu
-    try:
-        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
-        if q != "max":
-            quota = max(1, int(float(q) / float(per)))
-    except Exception:
-        pass
-    return max(1, min(ncpu, quota, 64))
 
 
 def cpu_baseline(mcfg, dcfg, gcfg, V, T, seconds_budget=100.0):
@@ -150,563 +139,12 @@ def cpu_decode_baseline(mcfg, dcfg, gcfg, V, positions=220, seconds_budget=45.0)
             "ids_agree": bool(same),
             "sample": "oracle (CPU PyTorch fp32 restatement) greedy decoding, batch 1, full 12L/768/V=%d after the 15-token prompt: value = as "
                       "the reference runs it (no KV cache, prefix re-run per token) over %d of the %d positions asked (cut by a %d s budget); "
-                      "kv_cached = the same loop with per-layer K / V kept, all %d positions" % (V, done, positions, int(seconds_budget), positions)}
+                      "kv_cached = the same loop with per-layer K / V kept, all %d positions" % (V, done, positions, int(seconds_budget),
+                          positions)}
 
 
-_PROFILING_RUN = False          # set by main(): --no-check marks a profiling / counter pass (no re-warm launches in its statistics)
 
 
-def gpu_rewarm(dev, seconds=0.4, max_launches=400):
-    """Keep the matrix cores busy for a moment before an optional object's warm-up: the CPU baselines leave the GPU idle for up to
-    two minutes, and the first launches after that run at ramping clocks (one default run measured its first decode generation at
-    ~400 ms instead of 90 with only the object's own one-generation warm-up in front of it).  Outside every timed region.
-    NOT in profiling passes (--no-check, or MMTG_BENCH_NO_REWARM=1): its 4096^3 products dispatch as gemm_p8_kernel and would be
-    averaged into the GEMM family's per-launch counters; and bounded by a launch count as well as by time (under --pmc every
-    dispatch is serialised, a wall-clock bound alone would instrument an unbounded number of them)."""
-    if _PROFILING_RUN or os.environ.get("MMTG_BENCH_NO_REWARM"):
-        return
-    from mmtg_amd import hip
-    a = torch.randn(4096, 4096, device=dev).bfloat16()
-    c = torch.empty(4096, 4096, device=dev, dtype=torch.bfloat16)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    done = 0
-    while time.perf_counter() - t0 < seconds and done < max_launches:
-        for _ in range(20):
-            hip.gemm(a, a, c, 4096, 4096, 4096, transB=True)
-        done += 20
-        torch.cuda.synchronize()
-
-
-def _timed(fn, world, dev):
-    """barrier + synchronize on both sides of fn(); max over ranks."""
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    fn()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    el = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([el], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
-    return el
-
-
-def bench_decode(args, world, rank, dev, steps, warmup, with_cpu=True):
-    """Greedy decode tokens/s: every rank decodes its own batch (replicas only, no exchange).  Returns the result
-    object (rank 0) or None."""
-    from mmtg_amd import MMTG, hip, synth
-    from mmtg_amd.configs import data_config, gpt2_config, make_model_cfgs
-    from mmtg_amd.decode import GreedyDecoder
-    S, V = 5, 13317
-    mcfg, dcfg = make_model_cfgs(seq_len=S), data_config(seq_len=S)
-    gcfg = gpt2_config(n_layer=args.layers, vocab_size=V)
-    model = MMTG(mcfg, dcfg, V, gpt2_config=gcfg, compute_dtype=args.dtype, token_table=synth.make_token_table(V, seed=2))
-    model.reset_parameters(seed=0)
-    model.to(dev).eval()
-    B, Ln = args.decode_batch, args.decode_len
-    nb = synth.make_batch(B, mcfg, dcfg, V, seed=7 + rank)
-    batch = {k: torch.from_numpy(np.asarray(v)).to(dev) for k, v in nb.items() if k not in ("rating", "targets")}
-    if os.environ.get("MMTG_DECODE_PROF"):
-        dec = GreedyDecoder(model, max_batch=B, max_len=Ln, use_graph=False)
-        dec.generate(batch, Ln, temperature=1.1, repitition_penalty=1.5)
-        hip.prof_enable(True)
-        dec.generate(batch, Ln, temperature=1.1, repitition_penalty=1.5)
-        hip.prof_enable(False)
-        pr = hip.prof_read()
-        print({k: (v["launches"], round(v["ms"], 2)) for k, v in pr.items() if v["launches"]})
-        return None
-    dec = GreedyDecoder(model, max_batch=B, max_len=Ln, use_graph=not getattr(args, "decode_eager", False))
-    if not (args.no_roofline and getattr(args, "decode_eager", False)):      # (not in the counter passes: every dispatch is instrumented)
-        gpu_rewarm(dev)
-    # (counter-collection passes -- eager launches under rocprofv3 --pmc -- may ask for NO warm-up generation: every dispatch is
-    #  counted, and the profiler's counter pass has died on runs of much more than 10 k dispatches, DESIGN.md section 7)
-    for _ in range(warmup if (warmup == 0 and getattr(args, "decode_eager", False)) else max(1, warmup)):
-        ids = dec.generate(batch, Ln, temperature=1.1, repitition_penalty=1.5)
-    out_ids = [None]
-
-    def run():
-        for _ in range(steps):
-            out_ids[0] = dec.generate(batch, Ln, temperature=1.1, repitition_penalty=1.5)
-
-    el = _timed(run, world, dev)
-    ids = out_ids[0]
-    free = [j for j in range(1, Ln + 1) if (j + 1) % 22 not in (0, 1)]
-    check = {"ids_shape": list(ids.shape), "all_rows_start_with_START": bool((ids[:, 0] == 1).all().item()),
-             "banned_ids_sampled": int(torch.isin(ids[:, free], torch.tensor([1, 2, 100, 102], device=ids.device)).sum().item()),
-             "distinct_ids": int(torch.unique(ids).numel())}
-    roof = cpu = None
-    step_us = n_token_steps = None
-    once_ms = None
-    counter_pass = args.no_roofline and getattr(args, "decode_eager", False)
-    if rank == 0 and not counter_pass:
-        # HIP events on the launch stream around the token steps of one more generation (after its once-per-generation part: weight
-        # copies, encoder, the prompt's batched prefill): the token step's duration
-        step_us, n_token_steps = token_step_us(dec, batch, Ln)
-        once_ms = round(1e3 * el / steps - 1e-3 * step_us * n_token_steps, 3)
-    elif rank == 0:
-        # (--no-roofline --decode-eager, the counter-collection passes: no extra generation -- every dispatch is instrumented and the
-        #  profiler dies on long runs; the figure below then includes the generation's once-only part)
-        n_token_steps = dcfg.topic_prompt_length + Ln - dec.first_pos
-        step_us = 1e6 * el / steps / n_token_steps
-    if rank == 0 and not args.no_roofline:
-        roof = decode_roofline(args, model, batch, B, Ln, dec, step_us)
-    if rank == 0 and world == 1 and with_cpu and not args.no_cpu_baseline:
-        cpu = cpu_decode_baseline(mcfg, dcfg, gcfg, V)
-    if rank != 0:
-        return None
-    out = {"metric": "greedy-decode tokens/sec, full MMTG config", "value": round(B * world * Ln * steps / el, 1),
-           "unit": "tokens/s", "n_gpus": world, "steps": steps, "warmup": warmup,
-           "ms_per_step": round(1e3 * el / steps, 3), "higher_is_better": True, "scaling": "weak",
-           "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-           "config": {"workload": "batched greedy generation, KV cache, %s: batch %d, "
-                                  "%d generated positions after a 15-token prompt (%s), GPT-2 %dL/768/12H V=%d"
-                                  % (dec.describe(), B, Ln, "prefilled in one batched pass" if dec.first_pos else "fed as token steps",
-                                     args.layers, V),
-                      "us_per_token_step": round(step_us, 2), "token_steps_per_generation": n_token_steps,
-                      # what a generation spends outside its token steps: fresh weight copies / LayerNorm folds, the encoder, the prompt
-                      "once_per_generation_ms": once_ms,
-                      "parallelism": "replicas x%d (no exchange)" % world},
-           "check": check}
-    if roof is not None:
-        out["roofline"] = roof
-    if cpu is not None:
-        out["cpu_baseline"] = cpu
-    return out
-
-
-def decode_mean_kv_rows(first_pos, n_steps):
-    """K / V rows a token step touches per layer and batch row, averaged over positions first_pos .. first_pos + n_steps - 1: `pos`
-    cached rows read + the step's own row written."""
-    return first_pos + (n_steps - 1) / 2.0 + 1.0
-
-
-def token_step_us(dec, batch, Ln, eager=False):
-    """(us per token step, token steps) of one generation: HIP events around the step loop only -- begin() (weight copies, LayerNorm
-    folds, encoder, the prompt's prefill) runs before the first event."""
-    saved = dec.use_graph
-    if eager:
-        dec.use_graph = False
-    try:
-        n = dec.begin(batch, Ln, temperature=1.1, repitition_penalty=1.5)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for pos in range(dec.first_pos, n):
-            dec.step_at(pos)
-        e1.record()
-        torch.cuda.synchronize()
-    finally:
-        dec.use_graph = saved
-    return 1e3 * e0.elapsed_time(e1) / (n - dec.first_pos), n - dec.first_pos
-
-
-def decode_roofline(args, model, batch, B, Ln, dec, step_us_events):
-    """A decode token step (one hipGraph replay = the launch) against the HBM roofline.  Algorithmic bytes per token step
-    (SURVEY 8(d)): every weight once (bf16) + the KV cache of the prefix read once + one new K/V row written per layer;
-    duration = HIP events around a graph-replayed generation / its token steps."""
-    from mmtg_amd import hip
-    sh = model.shapes
-    esz = 2 if args.dtype == "bf16" else 4
-    D, L, V, H, E = sh.D, sh.L, sh.V, sh.H, sh.E
-    w_bytes = esz * (L * 12 * D * D + V * D + E * H + H * D)
-    kv_row = 2 * L * D * esz                                # K and V of one position, all layers
-    # live per-launch timing of one generation's token steps through the library's profiling hooks (HIP events on the launch stream)
-    saved = dec.use_graph
-    dec.use_graph = False
-    try:
-        n_end = dec.begin(batch, Ln, temperature=1.1, repitition_penalty=1.5)
-        first = dec.first_pos
-        hip.prof_enable(True)
-        for pos in range(first, n_end):
-            dec.step_at(pos)
-        hip.prof_enable(False)
-    finally:
-        dec.use_graph = saved
-    steps_per_seq = n_end - first
-    # the token step at position pos reads the pos cached rows of every layer and writes one: mean over the steps that run
-    kv_bytes = B * kv_row * decode_mean_kv_rows(first, steps_per_seq)
-    alg = w_bytes + kv_bytes
-    pr = hip.prof_read()
-    tot_ms = sum(v["ms"] for v in pr.values())
-    step_us = step_us_events
-    ach = alg / max(step_us, 1e-9) / 1e3            # GB/s
-    traffic, tsrc = None, None
-    import glob
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_decode_pmc_traffic.json")), reverse=True):
-        try:
-            with open(f) as fh:
-                m = json.load(fh)
-        except Exception:
-            continue
-        if m.get("kernel_source_sha") == hip.source_sha() and B == 256 and m.get("dtype", "bf16") == args.dtype:
-            if m.get("step") in ("fused", "bf16x3") and (getattr(dec, "fused", False) or getattr(dec, "x3", False)):
-                # counter pass of the fused step, taken at the generation length the file names (the KV-cache share scales with it)
-                traffic = m["hbm_bytes_per_token_step"]
-                tsrc = os.path.relpath(f, ROOT) + (" [FUSED step at --decode-len %d: %d bytes per token step against %d algorithmic at that length]"
-                                                   % (m["decode_len"], m["hbm_bytes_per_token_step"], m["algorithmic_bytes_per_token_step_at_this_length"]))
-                break
-            if m.get("step") == "fused":
-                continue
-            if m.get("step") == "unfused" and getattr(dec, "fused", False):
-                # the counter passes only ran on the round-2 step (round 3): not this step's traffic
-                traffic, tsrc = None, os.path.relpath(f, ROOT) + " holds the UNFUSED step's %d bytes per token step; the fused step's counter pass crashes in the profiler" % m["hbm_bytes_per_token_step"]
-            else:
-                traffic, tsrc = m["hbm_bytes_per_token_step"], os.path.relpath(f, ROOT)
-            break
-    return {"bound": "hbm", "kernel": dec.kernel_name(), "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s",
-            "frac": round(ach / 8000.0, 4), "traffic": traffic,
-            "traffic_source": (tsrc + (" (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE over every kernel of the token step)" if traffic else "")) if tsrc else
-                              "none: no profiles/r*_decode_pmc_traffic.json was taken on kernel sources sha %s" % hip.source_sha()[:12],
-            "algorithmic_bytes_per_token_step": int(alg), "weights_bytes": int(w_bytes), "kv_bytes_mean": int(kv_bytes),
-            "us_per_token_step_hip_events": round(step_us, 2),
-            "eager_kernel_us_per_token_step": round(1e3 * tot_ms / steps_per_seq, 2),
-            "launches_per_token_step": round(sum(v["launches"] for v in pr.values()) / steps_per_seq, 1),
-            "per_category_ms_per_generation": {k: round(v["ms"], 3) for k, v in pr.items() if v["launches"]},
-            "token_steps_per_generation": steps_per_seq, "first_token_step_position": first,
-            "note": "achieved = algorithmic bytes of a token step (every weight once + the mean KV prefix of the positions the token steps run at) "
-                    "/ HIP-event duration of a graph-replayed token step; the per-category times are an eager (un-captured, host-bound) replay of "
-                    "the same token steps through the library's profiling hooks"}
-
-
-def _pmc_traffic(kernel_sha):
-    """HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 --pmc measurement of THIS
-    program (tools/gpu_pmc_bench.sh) -- only when it was taken on the kernel sources the running library was built
-    from; a stale file is refused."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_pmc_gemm_traffic.json")), reverse=True)
-    for f in files:
-        try:
-            with open(f) as fh:
-                m = json.load(fh)
-        except Exception:
-            continue
-        if m.get("kernel_source_sha") == kernel_sha:
-            return m, os.path.relpath(f, ROOT)
-    return None, None
-
-
-def _event_us(call, iters=20, warm=3):
-    """Mean duration of call() in us: HIP events on the launch stream around `iters` back-to-back launches."""
-    for _ in range(warm):
-        call()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        call()
-    e1.record()
-    torch.cuda.synchronize()
-    return 1e3 * e0.elapsed_time(e1) / iters
-
-
-def conditioning_unfused(dev, storage, B, P, L, S, E=2048, V=13317, iters=20):
-    """The LITERAL conditioning kernel of model.py:254-268 -- embed_condition_kernel: gather E[id] for every decoder position, add
-    the experience vector c[b, seg], store X [B*T, E] -- timed alone.  It is what the fp32-storage modes (f32, bf16x3) run in the step;
-    the bf16 mode fuses the gather into the projector product instead (conditioning_probe's `fused` entry).  Bytes per launch
-    (unfused form): B*T*E*e gathered + B*T*E*e written (+ B*S*E*e of c)."""
-    from mmtg_amd import hip, synth
-    tdt = torch.float32 if storage == "f32" else torch.bfloat16
-    esz = 4 if storage == "f32" else 2
-    g = torch.Generator(device="cpu").manual_seed(5)
-    table = torch.from_numpy(synth.make_token_table(V, seed=2)).to(dev).to(tdt).contiguous()
-    T, M = P + L, B * (P + L)
-    topic = torch.randint(1, V, (B, P), generator=g).to(dev)
-    targets = torch.randint(1, V, (B, L), generator=g).to(dev)
-    c = torch.randn(B * S, E, generator=g).to(dev).to(tdt).contiguous()
-    x = torch.empty(M, E, device=dev, dtype=tdt)
-    two_sents = max(2, (L - 1) // S)                               # L = S * two_sents + 1 (MyDataset.py:81-118)
-
-    def call():
-        hip.embed_condition(table, topic, targets, c, x, B, P, L, S, E, two_sents, V)
-
-    us = _event_us(call, iters)
-    nbytes = 2 * M * E * esz + B * S * E * esz
-    gbs = nbytes / us / 1e3
-    return {"kernel": "embed_condition_kernel<%s> (gather + experience add, X stored)" % ("float" if storage == "f32" else "bf16"),
-            "shape": "B=%d T=%d S=%d E=%d V=%d" % (B, T, S, E, V), "bytes": int(nbytes), "us": round(us, 2), "GB/s": round(gbs, 1),
-            "frac_hbm": round(gbs / 8000.0, 4), "bound": "hbm", "meets_40pct_of_hbm": bool(gbs / 8000.0 >= 0.40)}
-
-
-def conditioning_probe(model, batch, iters=20):
-    """north_star's "multi-modal cross-attention over the 2048-d WenLan embeddings >= 40 % of the HBM roofline", reported per form:
-    `fused` = what the bf16 step runs -- mmtg_gemm_gather, the projector product gathering the table rows through its LDS-DMA
-    (SURVEY 8(d): B*T*2048*2 bytes of gathered rows per launch; MFMA-bound, the gate does not apply to it as an HBM kernel);
-    `unfused_*` = the literal gather + experience-add kernel (what the fp32-storage parity modes run), at the released shape
-    (configs[1]) and at configs[4]'s shape, in both storage types -- the HBM-bound form the gate is about."""
-    from mmtg_amd import hip
-    eng = model.engine()
-    eng.forward(batch, train_flag=True, training=False, logits_f32=False)
-    a, sh = eng.act, eng.sh
-    if a.get("ids32") is None:
-        return None
-    B, T, M = a["B"], a["T"], a["M"]
-    rowmap = eng._rowmaps[(B, T)]
-    cW = eng.buf("c_w1", (B * sh.S + 1, sh.H))
-    W1, b1 = eng.W("decoder.projector_layer1.weight"), eng.P("decoder.projector_layer1.bias")
-
-    def call():
-        hip.gemm_gather(0, eng.table, W1, a["h1"], M, sh.H, sh.E, a["ids32"], eng.table.shape[0], lda=sh.E, ldb=sh.E, bias=b1,
-                        epi=hip.EPI_TANH_ADD, aux=cW, ldaux=sh.H, aux_rows=rowmap)
-
-    us = _event_us(call, iters)
-    nbytes = M * sh.E * 2
-    flops = 2.0 * M * sh.H * sh.E
-    gbs = nbytes / us / 1e3
-    fused = {"kernel": "mmtg_gemm_gather mode 0 (gemm_dma_kernel<128x128, GATHER>: E[id] rows gathered by the LDS-DMA, "
-                       "+ (c W1^T)[b, seg] and tanh in the epilogue)",
-             "bytes": nbytes, "us": round(us, 2), "GB/s": round(gbs, 1), "frac_hbm": round(gbs / 8000.0, 4), "bound": "mfma",
-             "tflops": round(flops / us / 1e6, 1), "frac_mfma": round(flops / us / 1e6 / 2500.0, 4),
-             "note": "fused into the projector product the conditioning is MFMA-bound (2*M*512*2048 FLOP over the gathered rows): the "
-                     "gathered bytes move at frac_hbm, the HBM gate is not this form's bound; timed warm (the 54.5 MB table sits in the "
-                     "Infinity Cache, as it does inside the step)"}
-    out = {"fused_bf16": fused}
-    dev = eng.dev
-    L = T - sh.P
-    for name, storage, shape in (("unfused_f32_configs1", "f32", (B, sh.P, L, sh.S)), ("unfused_bf16_configs1", "bf16", (B, sh.P, L, sh.S)),
-                                 ("unfused_f32_configs4", "f32", (32, 15, 497, 8)), ("unfused_bf16_configs4", "bf16", (32, 15, 497, 8))):
-        try:
-            out[name] = conditioning_unfused(dev, storage, *shape, E=sh.E, V=eng.table.shape[0], iters=iters)
-        except Exception as e:      # noqa: BLE001 -- an optional probe never costs the line
-            out[name] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
-    met = [k for k, v in out.items() if isinstance(v, dict) and v.get("meets_40pct_of_hbm")]
-    out["verdict"] = {"gate": "north_star: conditioning (cross-attention over the WenLan embeddings) >= 40 % of the 8 TB/s HBM roofline",
-                      "met_by": met, "not_applicable_to": ["fused_bf16 (MFMA-bound: frac_mfma is its roofline fraction)"],
-                      "note": "the unfused kernel is the literal gather + add of model.py:254-268; with the table partly Infinity-Cache resident "
-                              "its rate can exceed what HBM alone would deliver"}
-    # (kept for readers of earlier rounds' lines: the fused form's figures at the top level)
-    out.update({k: fused[k] for k in ("kernel", "bytes", "us", "GB/s", "frac_hbm", "bound", "tflops", "frac_mfma")})
-    return out
-
-
-def allreduce_probe(trainer, steps, world, dev):
-    """Per-step cost of the gradient exchange alone (no compute beside it): the same bucketed all-reduces + row count
-    the trainer issues, on a scratch buffer, `steps` times between barriers."""
-    eng, red = trainer.eng, trainer.reducer
-    scratch = torch.zeros_like(eng.grad)
-    cnt = torch.ones(1, device=dev)
-
-    def run():
-        for _ in range(steps):
-            red.start_count(cnt)
-            red.finish(scratch)
-
-    run()
-    el = _timed(run, world, dev)
-    return 1e3 * el / steps
-
-
-def f32_object(args, dev, mcfg, dcfg, gcfg, V, steps=5, warmup=2, mode="f32"):
-    """The modes north_star's numeric gates hold in (logits within 1e-3, greedy ids bit-exact), timed by the same driver run: a
-    bounded number of train steps of the same workload + one greedy generation at the decode object's batch.
-    mode "f32": exact fp32 storage and MFMA (v_mfma_f32_16x16x4_f32) end to end.
-    mode "bf16x3" (round 5): fp32 storage, the GPT-2 / lm_head products as three bf16 matrix-core passes over (hi | lo) split
-    operands (mmtg_gemm_x3 / mmtg_wgrad_group config 2 / mmtg_decode_gemm_x3) -- the same parity tests, green, at 2-3x the speed."""
-    from mmtg_amd import MMTG, hip, synth
-    from mmtg_amd.trainer import MMTGTrainer
-    import copy
-    model = MMTG(mcfg, dcfg, V, train_flag=True, gpt2_config=gcfg, compute_dtype=mode, token_table=synth.make_token_table(V, seed=2))
-    model.reset_parameters(seed=0)
-    model.to(dev).train()
-    gpu_rewarm(dev)
-    trainer = MMTGTrainer(model, lr=1e-5, alpha=0.2, warmup_steps=10, total_steps=100000)
-    B = args.batch
-    batches = [{k: torch.from_numpy(np.asarray(v)).to(dev) for k, v in synth.make_batch(B, mcfg, dcfg, V, seed=i).items()} for i in range(2)]
-    T = dcfg.topic_prompt_length + batches[0]["targets"].shape[1]
-
-    def run(n):
-        for i in range(n):
-            trainer.step(batches[i % 2], stage=3)
-
-    run(warmup)
-    el = _timed(lambda: run(steps), 1, dev)
-    hip.prof_enable(True)
-    _timed(lambda: run(steps), 1, dev)
-    hip.prof_enable(False)
-    prof = hip.prof_read()
-    if mode == "f32":
-        g = prof["gemm_f32"]
-        ach = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
-        roof = {"bound": "mfma", "kernel": "gemm_kernel<f32> (v_mfma_f32_16x16x4_f32)", "achieved": round(ach, 2),
-                "peak": 157.3, "unit": "TFLOP/s", "frac": round(ach / 157.3, 4)}
-        note = ("compute_dtype='f32': exact fp32 storage and MFMA end to end -- the mode tests/test_model_gpu.py holds to "
-                "logits <= 1e-3 and bit-exact greedy ids against the reference's goldens")
-    else:
-        g = prof["gemm_bf16"]
-        ach = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
-        roof = {"bound": "mfma", "kernel": "gemm_p8_kernel<X3> / wgrad_group_kernel<X3> (v_mfma_f32_16x16x32_bf16, three passes per product)",
-                "achieved": round(ach, 2), "achieved_mfma_work": round(3 * ach, 2), "peak": 2500.0, "unit": "TFLOP/s",
-                "frac": round(3 * ach / 2500.0, 4),
-                "note": "achieved = algorithmic product FLOPs (2 M N K) / kernel time; every product issues three bf16 MFMA passes, so the "
-                        "matrix cores do achieved_mfma_work = 3 x achieved, which frac prices against the dense bf16 peak"}
-        note = ("compute_dtype='bf16x3' (round 5): fp32 storage, GPT-2 / lm_head products as X_hi W_hi + X_lo W_hi + X_hi W_lo over (hi | lo) "
-                "bf16 plane pairs with fp32 accumulation -- held to the SAME parity tests as 'f32' (tests/test_model_gpu.py PARITY_MODES, "
-                "tests/test_decode_gpu.py): logits <= 1e-3, greedy ids bit-exact against the reference's goldens")
-    roof["per_category_ms_per_step"] = {k: round(v["ms"] / steps, 3) for k, v in prof.items() if v["launches"]}
-    if mode == "bf16x3f":
-        roof.pop("achieved_mfma_work", None)
-        roof["frac"] = None
-        roof["note"] = ("mixed: the forward's products issue three bf16 MFMA passes, the backward's one -- `achieved` = algorithmic product "
-                        "FLOPs (2 M N K) / kernel time of both")
-        note = ("compute_dtype='bf16x3f' (round 6): the bf16x3 forward -- logits / loss / KL / greedy ids at the fp32 mode's parity "
-                "(tests/test_model_gpu.py FORWARD_PARITY_MODES) -- with the backward as ONE bf16 matrix-core pass per product over the hi "
-                "planes the forward stored: gradients at the bf16 mode's accuracy (test_bf16_vs_oracle, test_full_12l_gradients_vs_golden)")
-    out = {"train": {"value": round(B * T * steps / el, 1), "unit": "tokens/s", "ms_per_step": round(1e3 * el / steps, 3),
-                     "steps": steps, "warmup": warmup, "rows": B, "seq_len": T, "roofline": roof},
-           "note": note}
-    del trainer, model
-    torch.cuda.empty_cache()
-    if mode == "bf16x3f":       # (its decode step is the bf16x3 one: see that object)
-        return out
-    a2 = copy.copy(args)
-    a2.dtype, a2.no_roofline, a2.no_cpu_baseline = mode, True, True
-    d = bench_decode(a2, 1, 0, dev, steps=1 if mode == "f32" else 3, warmup=1, with_cpu=False)
-    out["decode"] = {"value": d["value"], "unit": "tokens/s", "ms_per_step": d["ms_per_step"], "batch": a2.decode_batch,
-                     "positions": args.decode_len, "us_per_token_step": d["config"]["us_per_token_step"],
-                     "once_per_generation_ms": d["config"]["once_per_generation_ms"], "check": d["check"],
-                     "parity_asserted_by": "tests/test_decode_gpu.py (-m gpu; NOT re-measured by this run): teacher-forced on the "
-                                           "reference's own 220-position id lists, this decoder's pick == the reference's token at every call "
-                                           "and raw logits within 1e-3; see profiles/*_pytest_gpu.txt / the driver's GPUTEST record"}
-    return out
-
-
-def medium_object(args, dev, steps=5, warmup=3):
-    """BASELINE configs[4]'s single-GPU body under the driver's clock: GPT-2-medium 24L/1024/16H, S = 8, T = 512, 32 rows, rating
-    skew K = 32 with the stage-2 filter inside the step (ratings handed over on the host as well: no device read-back).  A bounded
-    run (3 warm-up + 5 timed steps, then 5 instrumented ones for the GEMM family's rate), outside the bf16 line's timed region."""
-    from mmtg_amd import MMTG, hip, synth
-    from mmtg_amd.configs import data_config, gpt2_config, make_model_cfgs
-    from mmtg_amd.trainer import MMTGTrainer
-    V, S, msl, skew, B = 13317, 8, 29, 32.0, 32
-    mcfg = make_model_cfgs(seq_len=S)
-    dcfg = data_config(seq_len=S, max_sent_length=msl)
-    gcfg = gpt2_config(n_layer=24, n_embd=1024, n_head=16, n_positions=512, n_ctx=512, vocab_size=V)
-    model = MMTG(mcfg, dcfg, V, train_flag=True, gpt2_config=gcfg, compute_dtype="bf16", token_table=synth.make_token_table(V, seed=2))
-    model.reset_parameters(seed=0)
-    model.to(dev).train()
-    gpu_rewarm(dev)
-    trainer = MMTGTrainer(model, lr=1e-5, alpha=0.2, warmup_steps=10, total_steps=100000)
-    batches = []
-    for i in range(2):
-        nb = synth.make_batch(B, mcfg, dcfg, V, seed=i, low_to_high=skew)
-        nb["rating"] = np.where(np.asarray(nb["rating"]) == 3, 2, nb["rating"])
-        b = {k: torch.from_numpy(np.asarray(v)).to(dev) for k, v in nb.items()}
-        b["rating_host"] = torch.from_numpy(np.asarray(nb["rating"]))
-        batches.append(b)
-    T = dcfg.topic_prompt_length + batches[0]["targets"].shape[1]
-
-    def run(n):
-        for i in range(n):
-            trainer.step(batches[i % 2], stage=2)
-
-    run(warmup)
-    el = _timed(lambda: run(steps), 1, dev)
-    hip.prof_enable(True)
-    _timed(lambda: run(steps), 1, dev)
-    hip.prof_enable(False)
-    prof = hip.prof_read()
-    g = prof["gemm_bf16"]
-    ach = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
-    out = {"metric": "train tokens/sec, scaled stress config (GPT-2-medium decoder, 8 experience steps), one GPU of the 8",
-           "value": round(B * T * steps / el, 1), "unit": "tokens/s", "ms_per_step": round(1e3 * el / steps, 3), "steps": steps,
-           "warmup": warmup, "rows": B, "seq_len": T, "dtype": "bf16",
-           "roofline": {"bound": "mfma", "kernel": "bf16 GEMM family", "achieved": round(ach, 2), "peak": 2500.0, "unit": "TFLOP/s",
-                        "frac": round(ach / 2500.0, 4),
-                        "per_category_ms_per_step": {k: round(v["ms"] / steps, 3) for k, v in prof.items() if v["launches"]}},
-           "params_finite": bool(torch.isfinite(model._flat).all().item())}
-    del trainer, model
-    torch.cuda.empty_cache()
-    return out
-
-
-_JSON_FD = None
-
-
-def _claim_stdout():
-    """Keep file descriptor 1 for the ONE JSON line: everything else that writes to stdout (RCCL prints its library
-    path there from C, after Python's own buffers are gone) is sent to stderr."""
-    global _JSON_FD
-    if _JSON_FD is None:
-        sys.stdout.flush()
-        _JSON_FD = os.dup(1)
-        os.dup2(2, 1)
-
-
-def _emit(obj):
-    os.write(_JSON_FD if _JSON_FD is not None else 1, (json.dumps(obj) + "\n").encode())
-
-
-def _free_port():
-    import socket
-    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
-        so.bind(("127.0.0.1", 0))
-        return so.getsockname()[1]
-
-
-def _self_launch(argv, n):
-    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): this process -- which has made NO GPU call and
-    makes none -- starts N fresh children, one rank per GPU, with the same environment contract torch.distributed.run
-    would give them (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT), forwards rank 0's stdout
-    (the ONE JSON line) to its own stdout, sends every other rank's stdout to stderr and exits with the worst child
-    return code.  Children are new processes (subprocess, not exec): nothing that has initialised the GPU is replaced."""
-    import subprocess
-    port = os.environ.get("MASTER_PORT") or str(_free_port())
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port, MMTG_BENCH_CHILD="1")
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
-                                      stdout=subprocess.PIPE if r == 0 else 2))
-    import threading
-    lines = []
-    reader = threading.Thread(target=lambda: lines.extend(procs[0].stdout), daemon=True)   # rank 0's stdout: the JSON line
-    reader.start()
-    worst, deadline = 0, None
-    pending = list(procs)
-    while pending:
-        for p in list(pending):
-            rc = p.poll()
-            if rc is None:
-                continue
-            pending.remove(p)
-            if rc != 0:
-                worst = worst or rc
-                if deadline is None:                # a rank died: the others would wait in a collective for ever
-                    deadline = time.time() + float(os.environ.get("MMTG_BENCH_KILL_GRACE", "30"))
-        if deadline is not None and time.time() > deadline:
-            for p in pending:
-                p.kill()                            # exactly the PIDs this process started
-        time.sleep(0.05)
-    reader.join(timeout=5.0)
-    if worst == 0:
-        for raw in lines:
-            os.write(_JSON_FD if _JSON_FD is not None else 1, raw)
-    return worst
-
-
-def _dry_launch(args):
-    """--dry-launch: prove the launch contract without a GPU -- every rank joins a gloo group over the rendezvous the
-    launcher handed it, ranks are all-gathered, rank 0 prints the ONE JSON line."""
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    seen = [rank]
-    if os.environ.get("MMTG_DRY_FAIL_RANK") == str(rank):      # test hook: a rank that dies before the rendezvous
-        raise SystemExit(7)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-        got = [None] * world
-        dist.all_gather_object(got, (rank, int(os.environ.get("LOCAL_RANK", "0")), os.getpid()))
-        seen = got
-        dist.barrier()
-        dist.destroy_process_group()
-    print("[bench dry-launch] rank %d of %d pid %d" % (rank, world, os.getpid()), file=sys.stderr)
-    if rank == 0:
-        _emit({"dry_launch": True, "n_gpus": args.gpus, "world": world, "ranks": seen,
-               "self_launched": bool(os.environ.get("MMTG_BENCH_CHILD"))})
 
 
 def main():
@@ -730,18 +168,19 @@ def main():
                     help="decode: batched greedy generation (BASELINE configs[3]: batch 256, max_len 128)")
     ap.add_argument("--decode-batch", type=int, default=256)
     ap.add_argument("--decode-len", type=int, default=128)
-    ap.add_argument("--decode-eager", action="store_true", help="decode without graph capture (counter-collection passes: every dispatch visible)")
+    ap.add_argument("--decode-eager", action="store_true",
+        help="decode without graph capture (counter-collection passes: every dispatch visible)")
     ap.add_argument("--dry-launch", action="store_true",
                     help="launch contract only (no GPU): ranks rendezvous over gloo, rank 0 prints one JSON line")
     ap.add_argument("--no-f32", action="store_true", help="skip the f32 (parity-gate mode) object of the default line")
     ap.add_argument("--no-x3", action="store_true", help="skip the bf16x3 (split-precision parity mode) object of the default line")
     ap.add_argument("--no-medium", action="store_true", help="skip the configs[4] (GPT-2-medium, T = 512) object of the default line")
-    ap.add_argument("--primary-only", action="store_true", help="the primary train measurement only: no decode / bf16x3 / f32 / medium objects (profiling passes)")
+    ap.add_argument("--primary-only", action="store_true",
+        help="the primary train measurement only: no decode / bf16x3 / f32 / medium objects (profiling passes)")
     args = ap.parse_args()
     if args.primary_only:
         args.no_decode = args.no_x3 = args.no_f32 = args.no_medium = True
-    global _PROFILING_RUN
-    _PROFILING_RUN = bool(args.no_check)
+    _common._PROFILING_RUN = bool(args.no_check)
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # no launcher: become one (before anything touches the GPU)
@@ -775,7 +214,7 @@ def main():
     from mmtg_amd.trainer import MMTGTrainer
 
     if args.mode == "decode":
-        out = bench_decode(args, world, rank, dev, args.steps, args.warmup)
+        out = bench_decode(args, world, rank, dev, args.steps, args.warmup, cpu_fn=cpu_decode_baseline)
         if rank == 0 and out is not None:
             _emit(out)
         if dist.is_initialized():
@@ -860,7 +299,10 @@ def main():
         # (bf16x3: three bf16 passes per product -- algorithmic FLOPs priced against a third of the dense bf16 peak)
         peak = 2500.0 if args.dtype == "bf16" else 157.3 if args.dtype == "f32" else 2500.0 / 3.0
         ach = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
-        roof = {"bound": "mfma", "kernel": ("gemm_p8_kernel / gemm_occ4_kernel / gemm_dma_kernel <bf16> (all instantiations)" if args.dtype == "bf16" else "gemm_kernel<f32>" if args.dtype == "f32" else "gemm_p8_kernel<X3> / wgrad_group_kernel<X3>"), "achieved": round(ach, 2), "peak": round(peak, 1),
+        roof = {"bound": "mfma",
+            "kernel": ("gemm_p8_kernel / gemm_occ4_kernel / gemm_dma_kernel <bf16> (all instantiations)" if args.dtype == "bf16"
+                       else "gemm_kernel<f32>" if args.dtype == "f32" else "gemm_p8_kernel<X3> / wgrad_group_kernel<X3>"),
+            "achieved": round(ach, 2), "peak": round(peak, 1),
                 "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
                 "launches_per_step": g["launches"] // args.steps,
                 "avg_launch_us": round(1e3 * g["ms"] / max(1, g["launches"]), 2),
@@ -940,7 +382,7 @@ def main():
         del trainer
         model = None
         torch.cuda.empty_cache()
-        decode = bench_decode(args, world, rank, dev, steps=5, warmup=2)
+        decode = bench_decode(args, world, rank, dev, steps=5, warmup=2, cpu_fn=cpu_decode_baseline)
     # the optional objects below run AFTER the primary measurement and must never cost it: a failure becomes {"error": ...}
     def guarded(fn, *a, **kw):
         try:
@@ -1022,7 +464,8 @@ def main():
             summ.update(forward_parity_dtype="bf16x3f", forward_parity_train_tokens_per_s=x3f["train"]["value"],
                         forward_parity_train_ms_per_step=x3f["train"]["ms_per_step"])
         if isinstance(x3, dict) and "train" in x3:
-            summ.update(parity_dtype="bf16x3", parity_train_tokens_per_s=x3["train"]["value"], parity_train_ms_per_step=x3["train"]["ms_per_step"],
+            summ.update(parity_dtype="bf16x3", parity_train_tokens_per_s=x3["train"]["value"],
+                parity_train_ms_per_step=x3["train"]["ms_per_step"],
                         parity_decode_tokens_per_s=x3.get("decode", {}).get("value"),
                         parity_decode_us_per_token_step=x3.get("decode", {}).get("us_per_token_step"))
         if isinstance(conditioning, dict) and isinstance(conditioning.get("unfused_f32_configs1"), dict):
