@@ -238,9 +238,13 @@ MMTG_API int mmtg_attn_bwd_x3(const void* qkv_planes, long qplane, const int* ke
 /* diagnostic: per-wave timeline of the whole-head forward kernel (bf16, T <= 256): buf = u64 [B*nH*8][8]
  * (s_memrealtime at entry / loads issued / first chunk landed / long tile done / stored / exit, XCC id, valid) or NULL */
 MMTG_API int mmtg_attn_trace(void* buf);
+/* flags (round 6): MMTG_ATTN_ELEM_MASK -- the bf16 whole-head kernels (T <= 512) regenerate the attention-dropout mask of the tiled /
+ * split-precision kernels (keep (q, k) iff hash(seed, ((b nH + h) T + q) T + k) >= drop_thresh, scale 1 / (1 - p) exactly) instead of
+ * their own 12-bit word masks: the bf16x3f mode's backward then differentiates the mask its split-precision forward applied.        */
+#define MMTG_ATTN_ELEM_MASK 1
 MMTG_API int mmtg_attn_bwd(int dtype, const void* qkv, const int* keep, const void* out, const void* dout,
                   const float* lse, float* delta, int delta_ready, float* dq32, void* dqkv, float* dbias, float* dbias_ws,
-                  int B, int T, int nH, int dh, unsigned drop_thresh, unsigned drop_seed, void* stream);
+                  int B, int T, int nH, int dh, unsigned drop_thresh, unsigned drop_seed, int flags, void* stream);
 
 /* ---------------------------------------------------------------- conditioning front end
  * WenLan lookup + experience add (model.py:254-268):

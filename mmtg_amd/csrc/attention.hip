@@ -568,6 +568,17 @@ __device__ __forceinline__ void gen_keep_mask(uint32_t* sMask, uint32_t bh, int 
         int k = 0;
         while (16 * (k + 1) * (k + 2) <= i) ++k;             // at most MT / 32 steps
         const int j = i - 16 * k * (k + 1), row = 32 * k + j / (k + 1), w = j % (k + 1);
+        if (keepq > 4096u) {
+            // ELEMENT mask (MMTG_ATTN_ELEM_MASK, round 6): keepq is the 32-bit drop threshold and bit j of the word is the keep
+            // decision of the tiled / split-precision kernels for (query row, key 32 w + j) -- hash(seed, (bh T + row) T + key) >=
+            // threshold (dropout_scale) -- so that this backward differentiates the mask the bf16x3f mode's forward applied
+            const uint32_t base = (bh * (uint32_t)Tn + (uint32_t)row) * (uint32_t)Tn + 32u * (uint32_t)w;
+            uint32_t bits = 0;
+#pragma unroll 8
+            for (int bit = 0; bit < 32; ++bit) bits |= (hash_u32(seed, base + (uint32_t)bit) >= keepq ? 1u : 0u) << bit;
+            sMask[mask_row_base<MT>(row) + w] = bits;
+            continue;
+        }
         uint32_t x = hash_u32(seed, (bh * (uint32_t)Tn + (uint32_t)row) * (uint32_t)(MT / 32) + (uint32_t)w) | 1u;
         uint32_t acc = 0;
 #pragma unroll
@@ -1597,7 +1608,7 @@ extern "C" int mmtg_colsum(int dtype, const void* X, long ldx, int M, int N, flo
 
 extern "C" int mmtg_attn_bwd(int dtype, const void* qkv, const int* keep, const void* out, const void* dout,
                              const float* lse, float* delta, int delta_ready, float* dq32, void* dqkv, float* dbias, float* dbias_ws,
-                             int B, int T, int nH, int dh, unsigned drop_thresh, unsigned drop_seed, void* stream) {
+                             int B, int T, int nH, int dh, unsigned drop_thresh, unsigned drop_seed, int flags, void* stream) {
     MMTG_REQUIRE(dh == DH, "attn_bwd: head dim %d unsupported (built for 64)", dh);
     MMTG_REQUIRE(B > 0 && T > 0 && nH > 0, "attn_bwd: bad sizes");
     MMTG_REQUIRE(qkv && keep && out && dout && lse && delta && dq32 && dqkv, "attn_bwd: null pointer");
@@ -1647,9 +1658,12 @@ extern "C" int mmtg_attn_bwd(int dtype, const void* qkv, const int* keep, const 
         }
         if (!delta_ready) hipLaunchKernelGGL(attn_delta_kernel<bf16>, dim3(cdiv(rows * nH, 4)), dim3(256), 0, s, (const bf16*)out, (const bf16*)dout, delta, T, nH, rows);
         const unsigned th16 = small_keep16(drop_thresh);
-        const bool drop = th16 < 4096u;
-        const unsigned kq = drop ? th16 : 0u;
-        const float ik16 = drop ? small_inv_keep(th16) : 1.0f;
+        // MMTG_ATTN_ELEM_MASK: the per-element mask of the tiled / split-precision kernels (the 32-bit threshold travels in the
+        // keep argument, the exact 1 / keep scale beside it) instead of the whole-head kernels' own 12-bit word masks
+        const bool elem = (flags & MMTG_ATTN_ELEM_MASK) && drop_thresh > 4096u;
+        const bool drop = elem || th16 < 4096u;
+        const unsigned kq = elem ? drop_thresh : drop ? th16 : 0u;
+        const float ik16 = elem ? ik : drop ? small_inv_keep(th16) : 1.0f;
         // dK/dV kernel: with dropout the half-wave build (every wave two tile pairs, up to 256 VGPRs, no spills) wins at T <= 256
         // (117 vs 135 us for backward + delta in isolation); without, the full-wave build does (106 vs 111).
         // MMTG_ATTN_KV_NW=4|8 (T <= 256) / 8|16 (T <= 512) forces one.

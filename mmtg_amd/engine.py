@@ -228,6 +228,9 @@ _LMHEAD_GROUP_SPLITS = int(_os.environ.get("MMTG_LMHEAD_GROUP_SPLITS", "0"))
 _WGRAD_STREAM = _os.environ.get("MMTG_WGRAD_STREAM", "0") != "0"
 # x3 grouped weight gradients: config 6 = combined stages (all four planes of a K tile per 64 KB stage, two workgroups per CU: 512
 # slots), MMTG_WGRAD_X3_COMBINED=0 = config 2, three passes over 32 KB stages at four workgroups per CU (A/B switch)
+# Round 6 (opt-in until measured, MMTG_ENC_STREAMS=1): the two encoder channels (image / text: independent chains of ~20 tiny dependent
+# launches each way) run side by side -- the text channel on a second stream with its own workspaces -- forward and backward
+_ENC_STREAMS = _os.environ.get("MMTG_ENC_STREAMS", "0") != "0"
 _X3_WG_CFG = 6 if _os.environ.get("MMTG_WGRAD_X3_COMBINED", "1") != "0" else 2
 _WGRAD_GROUP_CFG = int(_os.environ.get("MMTG_WGRAD_GROUP_CFG", "0"))          # 0: 128x128 tiles, four workgroups per CU; 1: 256x256 eight-phase
 
@@ -336,6 +339,7 @@ class Engine:
         self.set_table(table)
         self.prior = torch.from_numpy(gaussian_prior(self.sh.S)).to(self.dev)
         self.ws = {}
+        self._ws_tag = ""
         self.act = None
         self.training = False
         self.drop_seed = initial_drop_seed(_dist_rank())
@@ -374,7 +378,7 @@ class Engine:
         n = 1
         for d in shape:
             n *= int(d)
-        key = (name, dtype)
+        key = (name + self._ws_tag, dtype)          # (_ws_tag: "" / "~s" while a second stream's chain is being enqueued: its own workspaces)
         t = self.ws.get(key)
         if t is None or t.numel() < n:
             cap = _round_capacity(n)
@@ -738,12 +742,14 @@ class Engine:
         hip.layernorm_fwd(t_raw, t_ln, self.P("ln_layer1.weight"), self.P("ln_layer1.bias"), *st["ln1"], B, H)
         enc = {}
         for ch, x, lnk, site in (("image", xi, "ln_layer2", 0), ("text", xr, "ln_layer3", 1)):
-            layers = self._rnn_fwd(ch, x, B, training, seed, site)
-            h_all = layers[-1]["h"]
-            h_ln = self.buf("hln_" + ch, (B * S, H))
-            st[lnk] = (self.buf(lnk + "_mu", (B * S,), torch.float32), self.buf(lnk + "_rs", (B * S,), torch.float32))
-            hip.layernorm_fwd(h_all, h_ln, self.P(lnk + ".weight"), self.P(lnk + ".bias"), *st[lnk], B * S, H)
+            with self._beside(ch == "text"):
+                layers = self._rnn_fwd(ch, x, B, training, seed, site)
+                h_all = layers[-1]["h"]
+                h_ln = self.buf("hln_" + ch, (B * S, H))
+                st[lnk] = (self.buf(lnk + "_mu", (B * S,), torch.float32), self.buf(lnk + "_rs", (B * S,), torch.float32))
+                hip.layernorm_fwd(h_all, h_ln, self.P(lnk + ".weight"), self.P(lnk + ".bias"), *st[lnk], B * S, H)
             enc[ch] = (layers, h_ln)
+        self._join_beside()
 
         # ---------------- alpha attention (model.py:133-161) on batch-first rows b*S+i
         kl = self.buf("kl", (1,), torch.float32, zero=True)
@@ -1011,6 +1017,28 @@ class Engine:
         for t in tensors:
             hip.prefetch(t, self._pf_sink, _PREFETCH, stream=self._pf_stream)
 
+    @contextlib.contextmanager
+    def _beside(self, on):
+        """MMTG_ENC_STREAMS=1: enqueue the body on the second stream (forked from the current one) with workspaces of its own --
+        every buffer it names through buf() carries a tag -- so that it runs beside what the current stream enqueues next;
+        `_join_beside` makes the current stream wait for it.  Off (default) / on=False: a no-op."""
+        if not (on and _ENC_STREAMS):
+            yield
+            return
+        side = self._side_stream()
+        side.wait_stream(torch.cuda.current_stream())
+        self._ws_tag, self._beside_live = "~s", True
+        try:
+            with torch.cuda.stream(side):
+                yield
+        finally:
+            self._ws_tag = ""
+
+    def _join_beside(self):
+        if getattr(self, "_beside_live", False):
+            torch.cuda.current_stream().wait_stream(self._side)
+            self._beside_live = False
+
     def _side_stream(self):
         if getattr(self, "_side", None) is None:
             self._side = torch.cuda.Stream(device=self.dev)
@@ -1068,7 +1096,7 @@ class Engine:
             hip.cast_f32_to(a["h1"], h1b, a["h1"].numel())
             xb = self.buf("x_cond_b", tuple(a["x"].shape), torch.bfloat16)
             hip.cast_f32_to(a["x"], xb, a["x"].numel())
-        ab.update(x3=False, px3=False, gelu_grad=False, layers=layers, x_last=a["x_last_b"], hf=hi(a["hf"]), h1=h1b, x=xb, ids32=None)
+        ab.update(x3=False, px3=False, gelu_grad=False, elem_mask=True, layers=layers, x_last=a["x_last_b"], hf=hi(a["hf"]), h1=h1b, x=xb, ids32=None)
         try:
             with self._as_bf16():
                 self.act = ab
@@ -1281,8 +1309,11 @@ class Engine:
             self._prefetch(qkv)                 # while the c_proj weight gradient runs: the attention backward's rows
             if not group:
                 self._wgrad(ctx, dy, p + "attn.c_proj.weight", None, M, "conv1d")
+            # (hybrid: the split-precision forward drew the attention-dropout mask element by element; the whole-head backward
+            #  kernels regenerate THAT mask instead of their own word masks)
             hip.attn_bwd(qkv, a["keep"], ctx, dctx, lse, delta, dq32, dqkv, B, T, sh.nH, D // sh.nH,
                          drop_p=pa, drop_seed=s[0], delta_ready=fuse_delta, dbias=self.G(p + "attn.c_attn.bias"),
+                         flags=hip.ATTN_ELEM_MASK if a.get("elem_mask") else 0,
                          dbias_ws=self.buf("attn_dbias_rows", (hip.attn_bwd_bias_rows(B, T, self.dtype), 3 * D), torch.float32))
             self._prefetch(a1, xin)             # while the c_attn dgrad runs: its weight gradient's operand, LayerNorm input
             self._dgrad(dqkv, p + "attn.c_attn.weight", da, M, "conv1d")
@@ -1400,25 +1431,27 @@ class Engine:
         hip.beta_fuse_bwd(a["t_ln"], a["alpha"]["img"][1], a["alpha"]["text"][1], self.Pp("att_w"), a["ba"], do,
                           dtopic, dci, dct, self.Gp("att_w"), self.Gp("att_b"), B, S, H)
         self._ready("att_b")
-        # ---- alpha attention + LayerNorm + GRU per modality
-        dhp32 = self.buf("d_hp32", (B, H), torch.float32)
-        tmp32 = self.buf("d_tmp32", (B, H), torch.float32)
+        # ---- alpha attention + LayerNorm + GRU per modality (MMTG_ENC_STREAMS=1: the text channel's chain on the second stream)
         for mod, ch, lnk, dctx_a in (("text", "text", "ln_layer3", dct), ("img", "image", "ln_layer2", dci)):
-            qkv_a, _, probs = a["alpha"][mod]
-            layers, h_ln = a["enc"][ch]
-            h_all = layers[-1]["h"]
-            dqkv_a = self.buf("d_aqkv", (B * S, 3 * H))
-            hip.alpha_attn_bwd(qkv_a, self.prior, probs, dctx_a, dkl, dqkv_a, B, S, H, sh.heads)
-            dhln = self.buf("d_hln", (B * S, H))
-            if not self._gemm_few_rows(dqkv_a, self.Wp(mod + "_qkv_w"), dhln, B * S, H, 3 * H, False, H):
-                hip.gemm(dqkv_a, self.Wp(mod + "_qkv_w"), dhln, B * S, H, 3 * H, transB=False, ldb=H)
-            hip.gemm(dqkv_a, h_ln, self.Gp(mod + "_qkv_w"), 3 * H, H, B * S, transA=True, transB=False, lda=3 * H,
-                     ldb=H, ldc=H, epi=hip.EPI_ATOMIC, splits=1)
-            hip.colsum(dqkv_a, B * S, 3 * H, self.Gp(mod + "_qkv_b"))
-            dh_all = self.buf("d_hall", (B * S, H))
-            hip.layernorm_bwd(dhln, h_all, self.P(lnk + ".weight"), *a["st"][lnk], None, dh_all,
-                              self.G(lnk + ".weight"), self.G(lnk + ".bias"), B * S, H, ws=lnws)
-            self._rnn_bwd(ch, layers, dh_all, B, dhp32, tmp32)
+            with self._beside(mod == "text"):
+                dhp32 = self.buf("d_hp32", (B, H), torch.float32)
+                tmp32 = self.buf("d_tmp32", (B, H), torch.float32)
+                lnws_m = self.buf("ln_bwd_ws", (hip.lib().mmtg_layernorm_bwd_ws(M, max(D, H)),), torch.float32)
+                qkv_a, _, probs = a["alpha"][mod]
+                layers, h_ln = a["enc"][ch]
+                h_all = layers[-1]["h"]
+                dqkv_a = self.buf("d_aqkv", (B * S, 3 * H))
+                hip.alpha_attn_bwd(qkv_a, self.prior, probs, dctx_a, dkl, dqkv_a, B, S, H, sh.heads)
+                dhln = self.buf("d_hln", (B * S, H))
+                if not self._gemm_few_rows(dqkv_a, self.Wp(mod + "_qkv_w"), dhln, B * S, H, 3 * H, False, H):
+                    hip.gemm(dqkv_a, self.Wp(mod + "_qkv_w"), dhln, B * S, H, 3 * H, transB=False, ldb=H)
+                hip.gemm(dqkv_a, h_ln, self.Gp(mod + "_qkv_w"), 3 * H, H, B * S, transA=True, transB=False, lda=3 * H,
+                         ldb=H, ldc=H, epi=hip.EPI_ATOMIC, splits=1)
+                hip.colsum(dqkv_a, B * S, 3 * H, self.Gp(mod + "_qkv_b"))
+                dh_all = self.buf("d_hall", (B * S, H))
+                hip.layernorm_bwd(dhln, h_all, self.P(lnk + ".weight"), *a["st"][lnk], None, dh_all,
+                                  self.G(lnk + ".weight"), self.G(lnk + ".bias"), B * S, H, ws=lnws_m)
+                self._rnn_bwd(ch, layers, dh_all, B, dhp32, tmp32)
         # ---- topic channel
         dt_ln = self.buf("d_tln", (B, H))
         hip.cast_f32_to(dtopic, dt_ln, B * H)
@@ -1426,6 +1459,7 @@ class Engine:
         hip.layernorm_bwd(dt_ln, a["t_raw"], self.P("ln_layer1.weight"), *a["st"]["ln1"], None, dt_raw,
                           self.G("ln_layer1.weight"), self.G("ln_layer1.bias"), B, H, ws=lnws)
         self._wgrad(a["xt"], dt_raw, "encoder.topic_fc.weight", "encoder.topic_fc.bias", B, "linear")
+        self._join_beside()
         self._ready("encoder.topic_fc.bias")
 
     def _rnn_bwd(self, ch, layers, dh_all, B, dhp32, tmp32):

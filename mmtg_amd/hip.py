@@ -50,7 +50,7 @@ _SIGS = {
     "mmtg_attn_fwd_x3": ([_vp, _l, _vp, _vp, _vp, _l, _vp, _i, _i, _i, _i, _u, _u, _vp], _i),
     "mmtg_attn_bwd_x3": ([_vp, _l, _vp, _vp, _vp, _l, _vp, _vp, _i, _vp, _l, _vp, _l, _vp, _vp, _l, _i, _i, _i, _i, _u, _u, _vp], _i),
     "mmtg_attn_trace": ([_vp], _i),
-    "mmtg_attn_bwd": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _u, _u, _vp], _i),
+    "mmtg_attn_bwd": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _u, _u, _i, _vp], _i),
     "mmtg_embed_condition": ([_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
     "mmtg_segment_sum": ([_i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp], _i),
     "mmtg_embed_add": ([_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _u, _u, _vp], _i),
@@ -387,11 +387,14 @@ def attn_bwd_x3(qkv_planes, keep, out, dout_planes, lse, delta, dq32, dqkv_plane
                                   drop_thresh(drop_p), drop_seed & 0xFFFFFFFF, _stream()), "attn_bwd_x3")
 
 
+ATTN_ELEM_MASK = 1      # attn_bwd flags: the tiled / split-precision kernels' per-element dropout mask in the whole-head kernels
+
+
 def attn_bwd(qkv, keep, out, dout, lse, delta, dq32, dqkv, B, T, nH, dh, drop_p=0.0, drop_seed=0, delta_ready=False,
-             dbias=None, dbias_ws=None):
+             dbias=None, dbias_ws=None, flags=0):
     _check(lib().mmtg_attn_bwd(dt(qkv), _p(qkv), _p(keep), _p(out), _p(dout), _p(lse), _p(delta), int(delta_ready), _p(dq32),
                                _p(dqkv), _p(dbias), _p(dbias_ws), B, T, nH, dh, drop_thresh(drop_p), drop_seed & 0xFFFFFFFF,
-                               _stream()), "attn_bwd")
+                               int(flags), _stream()), "attn_bwd")
 
 
 def attn_trace(buf):

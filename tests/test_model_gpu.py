@@ -1078,3 +1078,47 @@ def test_bf16x3_training_step_with_dropout_matches_the_f32_mode():
     assert cos > 0.999999, cos
     assert float((g3 - g32).abs().max()) < 2e-3 * float(g32.abs().max())
     assert float((p3 - p32).abs().max()) <= 0.21 * 1e-4              # Adam's first step moves a weight by ~lr
+
+
+@pytest.mark.parametrize("pdrop", [0.1, 0.4])
+def test_bf16x3f_backward_differentiates_the_forward_s_dropout_masks(pdrop):
+    """compute_dtype "bf16x3f" in training mode (dropout at GPT-2's three sites): its forward is the split-precision one -- same loss
+    and KL as bf16x3 from the same seeds, bit for bit the same kernels -- and its bf16 backward must differentiate THAT forward: the
+    residual-site masks are the same counter hashes in both kernel families, the attention mask is regenerated element by element
+    inside the whole-head bf16 backward kernels (MMTG_ATTN_ELEM_MASK; their own masks are 12-bit word masks drawn differently).
+    A backward through different masks is uncorrelated noise on the attention path; here the gradient agrees with bf16x3's to bf16
+    accuracy (cosine over the whole flat buffer and per GPT-2 attention tensor), and a longer run stays finite
+    (tools/train_curve.py MODE=bf16x3f is the 3000-step version)."""
+    fx, meta, mcfg, gcfg, dcfg, weights, table, batch = load_case("tiny_s5")
+    gc = dict(gcfg, embd_pdrop=pdrop, attn_pdrop=pdrop, resid_pdrop=pdrop)
+    tb = batch_to_torch(batch, DEV)
+    res = {}
+    for mode in ("bf16x3", "bf16x3f"):
+        torch.manual_seed(1234)
+        model = MMTG(mcfg, dcfg, meta["V"], train_flag=True, gpt2_config=gc, token_table=table, compute_dtype=mode)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})
+        model.to(DEV).train()
+        tr = MMTGTrainer(model, lr=1e-4, alpha=0.2)
+        out = tr.step(tb, stage=3, filter_rows=False)
+        res[mode] = (out["loss"].item(), out["kl"].item(), model.engine().grad.clone(), model)
+    l3, k3, g3, m3 = res["bf16x3"]
+    lf, kf, gf, mf = res["bf16x3f"]
+    assert lf == l3 and kf == k3, (lf, l3, kf, k3)                  # the same forward
+    assert bool(torch.isfinite(gf).all())
+    cos = float((gf.double() @ g3.double()) / (gf.double().norm() * g3.double().norm()))
+    assert cos > 0.995, cos
+    lay = m3.layout
+    for l in range(gcfg["n_layer"]):
+        for nm in ("attn.c_attn.weight", "attn.c_proj.weight", "mlp.c_fc.weight"):
+            off, shape, n = lay.entries[f"decoder.gpt2.transformer.h.{l}.{nm}"]
+            a, b = gf[off:off + n].double(), g3[off:off + n].double()
+            c = float((a @ b) / (a.norm() * b.norm() + 1e-300))
+            assert c > 0.98, (l, nm, c)
+    # a few more steps stay finite and keep tracking the split-precision mode's loss
+    tr3, trf = MMTGTrainer(m3, lr=1e-3, alpha=0.2), MMTGTrainer(mf, lr=1e-3, alpha=0.2)
+    for m in (m3, mf):
+        m.engine().drop_seed = 777
+    for i in range(8):
+        a3, af = tr3.step(tb, stage=3, filter_rows=False), trf.step(tb, stage=3, filter_rows=False)
+        assert np.isfinite(af["loss"].item()) and bool(torch.isfinite(mf._flat).all()), i
+        assert abs(af["loss"].item() - a3["loss"].item()) < 0.15 * max(1.0, abs(a3["loss"].item())), (i, af["loss"].item(), a3["loss"].item())
