@@ -492,6 +492,7 @@ inline float inv_keep_x3(unsigned thresh) { return thresh ? (float)(4294967296.0
 }  // namespace
 
 extern "C" int mmtg_colsum(int dtype, const void* X, long ldx, int M, int N, float* out, float* ws, long ws_floats, void* stream);
+extern "C" long mmtg_colsum_ws(int M, int N);
 
 extern "C" int mmtg_attn_fwd_x3(const void* qkv_planes, long qplane, const int* keep, float* out, void* out_planes, long plane, float* lse,
                                 int B, int T, int nH, int dh, unsigned drop_thresh, unsigned drop_seed, void* stream) {
@@ -513,7 +514,8 @@ extern "C" int mmtg_attn_fwd_x3(const void* qkv_planes, long qplane, const int* 
  * gradient are split-precision products and nothing else reads it.  dq32: fp32 scratch of ceil(T / 128) x [B*T, D] floats (every block
  * of 128 keys stores its dQ contribution into its own buffer, the finish kernel adds them in block order: no atomics, bit-reproducible);
  * delta: [B*T, nH] scratch; dbias (nullable):
- * [3D] += column sums of d(qkv); dbias_ws: >= (B * ceil(T / 128) + ceil(B*T / 16)) * 3D floats;
+ * [3D] += column sums of d(qkv); dbias_ws: >= (B * ceil(T / 128) + ceil(B*T / 16)) * 3D floats + mmtg_colsum_ws of the two partial-row
+ * reductions (more than 2048 partial rows: batch 256 at T = 236 -- the ordered two-stage sum, never the fp32-atomic fallback);
  * delta_ready != 0: delta was filled by the caller (the c_proj dgrad's MMTG_EPI_ROWDOT epilogue). */
 extern "C" int mmtg_attn_bwd_x3(const void* qkv_planes, long qplane, const int* keep, const float* out, const void* dout_planes, long doplane,
                                 const float* lse, float* delta,
@@ -529,8 +531,9 @@ extern "C" int mmtg_attn_bwd_x3(const void* qkv_planes, long qplane, const int* 
                  "attn_bwd_x3: alignment / plane layout");
     const int nkb = cdiv(T, XKB), nband = cdiv(rows, XFB);
     MMTG_REQUIRE(dq32_floats >= (long)nkb * rows * D, "attn_bwd_x3: dq32 needs %ld floats (one [B*T, D] buffer per block of 128 keys)", (long)nkb * rows * D);
-    MMTG_REQUIRE(!dbias || (dbias_ws && dbias_ws_floats >= ((long)B * nkb + nband) * 3 * D), "attn_bwd_x3: the bias gradient needs %ld workspace floats",
-                 ((long)B * nkb + nband) * 3 * D);
+    const long ws_rows = ((long)B * nkb + nband) * 3 * D, ws_kv = mmtg_colsum_ws(B * nkb, 3 * D), ws_q = mmtg_colsum_ws(nband, D);
+    MMTG_REQUIRE(!dbias || (dbias_ws && dbias_ws_floats >= ws_rows + ws_kv + ws_q), "attn_bwd_x3: the bias gradient needs %ld workspace floats",
+                 ws_rows + ws_kv + ws_q);
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(MMTG_PROF_ATTN_BWD, s, 5.0 * B * nH * (double)T * T * dh, 4.0 * 8.0 * B * T * nH * dh);
     static bool attr_set = false;
@@ -548,9 +551,10 @@ extern "C" int mmtg_attn_bwd_x3(const void* qkv_planes, long qplane, const int* 
     hipLaunchKernelGGL(attn_dq_finish_x3_kernel, dim3(nband), dim3(256), 0, s, dq32, rows * D, T, (bf16*)dqkv_planes, dplane, q_rows, rows, D);
     MMTG_LAUNCH_CHECK("attn_bwd_x3");
     if (dbias) {
-        int rc = mmtg_colsum(MMTG_F32, kv_rows, 3 * D, B * nkb, 3 * D, dbias, nullptr, 0, stream);
+        // (tall partial-row matrices take mmtg_colsum's ordered two-stage sum through the tail of the workspace: bit-reproducible at any batch)
+        int rc = mmtg_colsum(MMTG_F32, kv_rows, 3 * D, B * nkb, 3 * D, dbias, ws_kv ? dbias_ws + ws_rows : nullptr, ws_kv, stream);
         if (rc) return rc;
-        rc = mmtg_colsum(MMTG_F32, q_rows, D, nband, D, dbias, nullptr, 0, stream);
+        rc = mmtg_colsum(MMTG_F32, q_rows, D, nband, D, dbias, ws_q ? dbias_ws + ws_rows + ws_kv : nullptr, ws_q, stream);
         if (rc) return rc;
     }
     return MMTG_OK;

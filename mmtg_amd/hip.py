@@ -371,8 +371,10 @@ def attn_bwd_x3_dq_floats(B, T, D):
 
 
 def attn_bwd_x3_ws(B, T, D):
-    """Floats of the dbias workspace of attn_bwd_x3."""
-    return (B * (-(-T // 128)) + -(-(B * T) // 16)) * 3 * D
+    """Floats of the dbias workspace of attn_bwd_x3: the partial rows + the workspaces of their ordered column sums (mmtg_colsum_ws:
+    128 x N floats once a reduction has more than 2048 rows)."""
+    nkv, nq = B * (-(-T // 128)), -(-(B * T) // 16)
+    return (nkv + nq) * 3 * D + (128 * 3 * D if nkv > 2048 else 0) + (128 * D if nq > 2048 else 0)
 
 
 def attn_bwd_x3(qkv_planes, keep, out, dout_planes, lse, delta, dq32, dqkv_planes, B, T, nH, dh, drop_p=0.0, drop_seed=0, dbias=None,

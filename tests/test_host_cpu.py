@@ -185,7 +185,7 @@ def test_c_abi_exports_every_declared_symbol():
     lib = ctypes.CDLL(hip.lib_path())
     for name in declared:
         assert hasattr(lib, name), name
-    assert hip.lib().mmtg_abi_version() == hip.ABI_VERSION == 9
+    assert hip.lib().mmtg_abi_version() == hip.ABI_VERSION == 10
     # ... and nothing else: the library is built with -fvisibility=hidden + a linker version script, so no internal C++
     # helper (mmtg_set_error, ProfScope, template instantiations, hipcc's __hip_cuid_*) leaks into the dynamic symbol table
     import subprocess
