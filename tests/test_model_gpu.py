@@ -1103,7 +1103,9 @@ def test_bf16x3f_backward_differentiates_the_forward_s_dropout_masks(pdrop):
         res[mode] = (out["loss"].item(), out["kl"].item(), model.engine().grad.clone(), model)
     l3, k3, g3, m3 = res["bf16x3"]
     lf, kf, gf, mf = res["bf16x3f"]
-    assert lf == l3 and kf == k3, (lf, l3, kf, k3)                  # the same forward
+    # the same forward: MyLoss bit for bit; the KL scalar is accumulated with fp32 atomics over (row, head) workgroups of the two alpha
+    # attention launches (its sum order varies run to run in the last bits, in every mode)
+    assert lf == l3 and abs(kf - k3) <= 1e-5 * abs(k3), (lf, l3, kf, k3)
     assert bool(torch.isfinite(gf).all())
     cos = float((gf.double() @ g3.double()) / (gf.double().norm() * g3.double().norm()))
     assert cos > 0.995, cos
