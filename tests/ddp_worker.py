@@ -93,6 +93,28 @@ def main():
                 res["layout_total"] = models[0][0].layout.total
                 res["%s_layout" % dtype] = {k: models[0][0].layout.entries[k][:1] + (models[0][0].layout.entries[k][2],)
                                             for k in models[0][0].layout.entries}
+        elif mode == "world1_bf16":
+            # MMTG_DDP_GRAD_DTYPE=bf16 over RCCL at world 1 (forced): every bucket is cast to bf16, all-reduced by RCCL in bf16 and cast
+            # back; the per-bucket timeline is collected (HIP events on the compute stream)
+            assert world == 1 and os.environ.get("MMTG_FORCE_DDP") and os.environ.get("MMTG_DDP_GRAD_DTYPE") == "bf16"
+            model, mcfg, dcfg, V = build("bf16", 0.0, dev)
+            model.eval()
+            nb = synth.make_batch(8, mcfg, dcfg, V, seed=11)
+            batch = {k: torch.from_numpy(np.asarray(v)).to(dev) for k, v in nb.items()}
+            tr = MMTGTrainer(model, lr=0.0, alpha=0.2, distributed=True, bucket_mb=8.0)
+            assert tr.reducer.xdtype == torch.bfloat16 and tr.reducer.active
+            tr.reducer.measure = True
+            tr.step(batch, stage=3)
+            tr.step(batch, stage=3)
+            torch.cuda.synchronize()
+            res["grad"] = tr.eng.grad.detach().cpu().clone()
+            res["timeline"] = tr.reducer.timeline_report()
+            plain, _, _, _ = build("bf16", 0.0, dev)
+            plain.eval()
+            tp = MMTGTrainer(plain, lr=0.0, alpha=0.2, distributed=False)
+            tp.step(batch, stage=3)
+            torch.cuda.synchronize()
+            res["grad_plain"] = tp.eng.grad.detach().cpu().clone()
         elif mode == "shards":
             from mmtg_amd.ddp import shard_rows
             model, mcfg, dcfg, V = build("f32", 0.0, dev)

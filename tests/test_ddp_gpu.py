@@ -80,6 +80,24 @@ def test_forced_ddp_world1_equals_the_plain_trainer(tmp_path):
         assert float((ddp[0][0] - ddp[1][0]).abs().max()) > 1e-4
 
 
+def test_bf16_gradient_exchange_over_rccl_world1_and_bucket_timeline(tmp_path):
+    """MMTG_DDP_GRAD_DTYPE=bf16 (round 6, opt-in) executed over RCCL (world 1, forced): every bucket crosses as bf16 -- cast, SUM
+    all-reduce, cast back -- so the exchanged gradient equals the plain trainer's rounded to bf16 once (a SUM over one rank is the
+    identity), element for element; the per-bucket timeline of the exchange (when the backward handed each bucket over, how long the
+    compute stream waited for it) is reported for every bucket."""
+    res = _launch("world1_bf16", 1, str(tmp_path / "w1b"), {"MMTG_FORCE_DDP": "1", "MMTG_DDP_GRAD_DTYPE": "bf16"})[0]
+    assert res.get("ok") and res["backend"] == "nccl"
+    g, ref = res["grad"], res["grad_plain"]
+    assert torch.equal(g, ref.bfloat16().float())
+    assert float((g - ref).abs().max()) <= 2.0 ** -8 * float(ref.abs().max())
+    tl = res["timeline"]
+    assert tl and tl["exchange_dtype"] == "bfloat16" and tl["steps"] == 2
+    nb = len(tl["bucket_mb"])
+    assert nb > 3 and len(tl["launch_ms_after_first"]) == nb and len(tl["exposed_wait_ms"]) == nb
+    assert tl["launch_ms_after_first"][0] == 0.0 and all(x >= 0.0 for x in tl["launch_ms_after_first"] + tl["exposed_wait_ms"])
+    assert tl["launch_ms_after_first"] == sorted(tl["launch_ms_after_first"])          # buckets leave in gradient-ready order
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
 def test_two_rank_gradient_equals_single_rank_on_the_concatenated_batch(tmp_path):
     """2 ranks, contiguous row shards of one 16-row batch, stage-1 filter per shard (unequal shards): the all-reduced
