@@ -229,3 +229,33 @@ def test_attention_x3_matches_the_exact_fp32_kernels(B, T, drop):
     dqp2, db2 = hip.Planes.empty(B * T, 3 * D, DEV), torch.zeros(3 * D, device=DEV)
     hip.attn_bwd_x3(qkvp, keep, out, doutp, lse, torch.empty_like(delta), dqs, dqp2, B, T, nH, dh, drop_p=drop, drop_seed=seed, dbias=db2, dbias_ws=ws3)
     assert torch.equal(dqp2.t, dqp.t) and torch.equal(db2, db)
+
+
+@pytest.mark.parametrize("B,T", [(2, 129), (1, 236), (1, 400)])
+def test_whole_head_bf16_backward_regenerates_the_element_dropout_mask(B, T):
+    """MMTG_ATTN_ELEM_MASK (round 6, the bf16x3f mode's backward): the bf16 whole-head attention backward kernels, given the fp32 /
+    split-precision kernels' forward (context, LSE, dropout seed), differentiate THAT forward -- their d(qkv) agrees with the exact-fp32
+    backward to bf16 accuracy -- whereas with their own 12-bit word masks (no flag) the same call differentiates a different dropout
+    realisation and is far off.  p = 0.3 so that the difference is unmistakable."""
+    nH, dh, drop, seed = 12, 64, 0.3, 991
+    D = nH * dh
+    g = torch.Generator(device=DEV).manual_seed(B * 1000 + T)
+    qkv = (torch.randn(B * T, 3 * D, device=DEV, generator=g) * 0.8).bfloat16()
+    keep = torch.ones(B, T, dtype=torch.int32, device=DEV)
+    keep[0, T - 7:] = 0
+    dout = (torch.randn(B * T, D, device=DEV, generator=g) * 0.1).bfloat16()
+    q32, d32 = qkv.float(), dout.float()
+    out32, lse32 = torch.empty(B * T, D, device=DEV), torch.empty(B, nH, T, device=DEV)
+    hip.attn_fwd(q32, keep, out32, lse32, B, T, nH, dh, drop_p=drop, drop_seed=seed)
+    delta, dq32 = torch.empty(B * T, nH, device=DEV), torch.empty(B * T, D, device=DEV)
+    ref = torch.zeros(B * T, 3 * D, device=DEV)
+    hip.attn_bwd(q32, keep, out32, d32, lse32, delta, dq32, ref, B, T, nH, dh, drop_p=drop, drop_seed=seed)
+    outb = out32.bfloat16()
+    got = {}
+    for flags in (hip.ATTN_ELEM_MASK, 0):
+        dqkv = torch.zeros(B * T, 3 * D, device=DEV, dtype=torch.bfloat16)
+        hip.attn_bwd(qkv, keep, outb, dout, lse32, torch.empty_like(delta), torch.empty_like(dq32), dqkv, B, T, nH, dh, drop_p=drop, drop_seed=seed,
+                     flags=flags)
+        got[flags] = float((dqkv.float() - ref).norm() / ref.norm())
+    assert got[hip.ATTN_ELEM_MASK] < 0.03, got
+    assert got[0] > 0.25, got          # (guards against a vacuous pass: the kernels' own masks are a different realisation)
