@@ -232,6 +232,8 @@ _WGRAD_STREAM = _os.environ.get("MMTG_WGRAD_STREAM", "0") != "0"
 # reproducibility tests green under it): the two encoder channels (image / text: independent chains of ~20 tiny dependent launches each
 # way) side by side -- the text channel on a second stream with its own workspaces -- forward and backward
 _ENC_STREAMS = _os.environ.get("MMTG_ENC_STREAMS", "0") != "0"
+# bf16x3f: the encoder / fuser backward on the bf16 kernels as well (MMTG_HYBRID_ENC_BF16=0: exact fp32, the round's first version)
+_HYBRID_ENC_BF16 = _os.environ.get("MMTG_HYBRID_ENC_BF16", "1") != "0"
 _X3_WG_CFG = 6 if _os.environ.get("MMTG_WGRAD_X3_COMBINED", "1") != "0" else 2
 _WGRAD_GROUP_CFG = int(_os.environ.get("MMTG_WGRAD_GROUP_CFG", "0"))          # 0: 128x128 tiles, four workgroups per CU; 1: 256x256 eight-phase
 
@@ -1104,9 +1106,40 @@ class Engine:
                 seg = self._backward_decoder(ab, dlogits)
         finally:
             self.act = a
+        if _HYBRID_ENC_BF16:
+            # the encoder / fuser backward on the bf16 kernels too (the mode's gradients are bf16-accurate by contract): bf16 copies of
+            # the ~14 small activations it reads (320 x 512 ... 320 x 2048), then the same code path under the bf16 presentation --
+            # 0.8 ms of exact-fp32 products (14 TFLOP/s on 34 few-row launches) become ~0.2
+            ae = self._encoder_record_bf16(a)
+            with self._as_bf16():
+                self._backward_encoder(ae, seg, dkl)
+            return
         seg32 = self.buf("d_seg32", tuple(seg.shape), torch.float32)
         hip.cast_to_f32(seg, seg32, seg.numel())
         self._backward_encoder(a, seg32, dkl)
+
+    def _encoder_record_bf16(self, a):
+        """The activation record `_backward_encoder` reads, with every fp32 tensor it takes as a kernel operand replaced by a bf16
+        copy (statistics, attention probabilities, cell saves and fuser weights stay fp32: the bf16 kernels read them as fp32 too)."""
+        def cast(t, name):
+            b = self.buf("hyb_" + name, tuple(t.shape), torch.bfloat16)
+            hip.cast_f32_to(t, b, t.numel())
+            return b
+        ae = dict(a)
+        for k in ("o", "t_ln", "t_raw", "xt"):
+            ae[k] = cast(a[k], k)
+        ae["alpha"] = {mod: (cast(q, "aqkv_" + mod), cast(c, "actx_" + mod), p) for mod, (q, c, p) in a["alpha"].items()}
+        enc = {}
+        for ch, (layers, h_ln) in a["enc"].items():
+            recs = []
+            for l, rec in enumerate(layers):
+                r = dict(rec)
+                r["h"] = cast(rec["h"], "h_%s%d" % (ch, l))
+                r["inp"] = recs[l - 1]["h"] if (l > 0 and rec["inp"] is layers[l - 1]["h"]) else cast(rec["inp"], "inp_%s%d" % (ch, l))
+                recs.append(r)
+            enc[ch] = (recs, cast(h_ln, "hln_" + ch))
+        ae["enc"] = enc
+        return ae
 
     def backward(self, dlogits, dkl=0.0):
         """Back-propagate d(logits) [M,Vpad] (compute dtype) and d(kl) through the whole
