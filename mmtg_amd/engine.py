@@ -1077,7 +1077,8 @@ class Engine:
         """compute_dtype "bf16x3f": d(logits) through the decoder as ONE bf16 pass per product -- the bf16 mode's kernels over the hi
         planes the split-precision forward stored (LayerNorm outputs, qkv, attention context, GELU output, projector activations),
         the bf16 copies of the LayerNorm inputs and of the c_fc pre-activation it wrote beside them, and the hi planes of the
-        weights -- then the encoder / fuser backward in exact fp32 as in the x3 mode.  Gradients land in the same flat fp32 buffer."""
+        weights -- then the encoder / fuser backward, on the bf16 kernels as well (MMTG_HYBRID_ENC_BF16=0: in exact fp32 as in the x3
+        mode).  Gradients land in the same flat fp32 buffer."""
         a, sh = self.act, self.sh
         M, Vp = a["M"], self.layout.Vpad
         if isinstance(dlogits, hip.Planes):
