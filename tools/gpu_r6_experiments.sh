@@ -171,5 +171,22 @@ timeout 600 python __graft_entry__.py smoke 2>&1 | tail -6 | tee gpurun_out/r6m/
 timeout 1500 python bench.py > gpurun_out/r6m/bench_default.json 2> gpurun_out/r6m/bench_default.err; tail -c 300 gpurun_out/r6m/bench_default.json
 
   ;;
-*) echo "usage: $0 {a|c|d|e|f|g|h|i|j|k|l|m}"; exit 2 ;;
+n)
+# existing opt-in overlap switches re-measured with kernel arguments in device memory: grouped weight gradients on a side stream,
+# the attention backward's dQ kernel beside its dK / dV kernel
+mkdir -p gpurun_out/r6n
+for rep in 1 2; do
+for cfg in "0 0" "1 0" "0 1"; do
+  set -- $cfg
+  MMTG_WGRAD_STREAM=$1 MMTG_ATTN_BWD_FORK=$2 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --primary-only --no-roofline 2>/dev/null | python -c "
+import sys, json
+for ln in sys.stdin:
+    try: d = json.loads(ln)
+    except Exception: continue
+    print('WGRAD_STREAM=$1 ATTN_BWD_FORK=$2', d['value'], 'tok/s', d['ms_per_step'], 'ms/step')
+" | tee -a gpurun_out/r6n/overlap_switches_ab.txt
+done
+done
+;;
+*) echo "usage: $0 {a|c|d|e|f|g|h|i|j|k|l|m|n}"; exit 2 ;;
 esac
