@@ -358,6 +358,8 @@ def main():
                     "tail_bucket_mb": round(trainer.reducer.tail_bytes() / 2 ** 20, 1),
                     "gradient_bytes": int(trainer.eng.layout.total * 4),
                     "exchange_dtype": str(trainer.reducer.xdtype).replace("torch.", ""),
+                    # "abi" (MMTG_DDP_COMM=abi): buckets through libmmtg_hip's own RCCL communicator (mmtg_allreduce_bucket_async)
+                    "comm": "abi" if trainer.reducer.abi else "torch", "comm_info": trainer.reducer.comm_info,
                     # first-contact instrumentation: per bucket, when the backward handed it to RCCL (ms after the first launch) and
                     # how long the compute stream sat in its wait inside finish() -- the part of that all-reduce nothing hid
                     "bucket_timeline": bucket_timeline,

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MMTG_ABI_VERSION 10
+#define MMTG_ABI_VERSION 11
 
 /* The library is built with -fvisibility=hidden: only the entry points below are exported. */
 #define MMTG_API __attribute__((visibility("default")))
@@ -540,6 +540,32 @@ MMTG_API int mmtg_decode_mlp(int M, int D, const void* X, long ldx, const float*
                     const void* W2t, long ldw2, const float* bias2, void* G, long ldg, void* C, long ldc,
                     float* stats_out, float* ws, long ws_floats, unsigned long long* sync, int plain_handoff,
                     unsigned long long* trace, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------------------
+ * The data-parallel exchange ("a second small ABI").  One process per GPU holds ONE RCCL communicator;
+ * gradient buckets -- contiguous slices of the flat fp32 gradient, in the order the backward finishes them -- are SUM all-reduced
+ * in place over xGMI.  Replaces torch.nn.DataParallel's per-step reduce_add_coalesced of every gradient to GPU 0 and its
+ * parameter broadcast (reference src/train.py:112-114; generate.py:191, predict.py:195 wrap the model the same way).
+ * Conventions that differ from the kernels above: the library owns the communicator, one side stream and two events (created by
+ * mmtg_comm_init, released by mmtg_comm_destroy); RCCL is bound at first use (dlopen: the host process's copy when it has one,
+ * else MMTG_RCCL_LIB, else librccl.so.1) -- without it these calls return MMTG_ERR_UNSUPPORTED, nothing falls back to the host.
+ * Collectives must be issued in the same order on every rank, from one thread.
+ *   mmtg_comm_unique_id   rank 0 draws the 128-byte id (ncclGetUniqueId); the host ships it to the other ranks (any side channel)
+ *   mmtg_comm_init        collective: every rank calls it with the same id, on the device it has made current
+ *   mmtg_comm_info        rank / world / device of the live communicator (world 0: none) and the bound RCCL's version code
+ *   mmtg_allreduce_bucket in-place SUM of `count` elements (MMTG_F32 | MMTG_BF16) enqueued on `stream`
+ *   mmtg_allreduce_bucket_async  the same on the library's side stream, ordered after everything already on `after_stream`
+ *                         (the compute stream): the exchange runs beside the rest of the backward
+ *   mmtg_comm_join        `stream` waits for every bucket enqueued with _async so far (no host wait)
+ *   mmtg_comm_destroy     drains the side stream and releases the communicator (no-op without one)                            */
+#define MMTG_COMM_ID_BYTES 128
+MMTG_API int mmtg_comm_unique_id(void* id /* host, MMTG_COMM_ID_BYTES */);
+MMTG_API int mmtg_comm_init(int rank, int world, const void* id /* host, MMTG_COMM_ID_BYTES */);
+MMTG_API int mmtg_comm_info(int* rank, int* world, int* device, int* rccl_version);
+MMTG_API int mmtg_allreduce_bucket(void* ptr, long count, int dtype, void* stream);
+MMTG_API int mmtg_allreduce_bucket_async(void* ptr, long count, int dtype, void* after_stream);
+MMTG_API int mmtg_comm_join(void* stream);
+MMTG_API int mmtg_comm_destroy(void);
 
 #ifdef __cplusplus
 }

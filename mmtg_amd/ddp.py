@@ -14,6 +14,11 @@ xGMI is point-to-point (7 links x ~153 GB/s per GPU): buckets are large (default
 The global row count (curriculum filtering leaves the ranks with unequal shards) is all-reduced the same way as a
 one-element device tensor and consumed on the device by the clip + AdamW kernel: no host synchronisation.
 
+MMTG_DDP_COMM=abi (opt-in, round 6): the buckets go through libmmtg_hip's own RCCL communicator (SURVEY.md section 8b's second
+small ABI, csrc/comm.hip: mmtg_comm_init / mmtg_allreduce_bucket_async / mmtg_comm_join) -- one C call per bucket from the
+backward, the fork from and the join with the compute stream done with HIP events inside the library -- and torch.distributed
+stays the control plane only (rendezvous: it ships rank 0's unique id; the self-tuning's MAX all-reduce).
+
 Works unchanged on CPU tensors with the gloo backend (tests/test_host_cpu.py::test_bucketed_allreduce_world2_gloo);
 executed on the GPU over RCCL by tests/test_ddp_gpu.py (world size 1 with MMTG_FORCE_DDP=1, and 2 ranks where two
 GPUs are visible).
@@ -48,6 +53,51 @@ def grad_exchange_dtype():
     if v in ("bf16", "bfloat16"):
         return torch.bfloat16
     raise ValueError("MMTG_DDP_GRAD_DTYPE must be f32 or bf16, got %r" % v)
+
+
+def comm_backend():
+    """MMTG_DDP_COMM: "torch" (default: torch.distributed.all_reduce per bucket) or "abi" (libmmtg_hip's RCCL communicator)."""
+    v = os.environ.get("MMTG_DDP_COMM", "torch").lower()
+    if v not in ("torch", "abi"):
+        raise ValueError("MMTG_DDP_COMM must be torch or abi, got %r" % v)
+    return v
+
+
+def abi_comm_acquire(group=None):
+    """The process's RCCL communicator behind the C ABI, created on first use (collective: every rank of `group` calls it): rank 0
+    draws the unique id, torch.distributed -- whatever its backend -- carries the 128 bytes to the others, every rank joins on its
+    current device.  It lives until the process ends (abi_comm_release() for an orderly shutdown); a second acquire checks that
+    the live communicator is this group's."""
+    from . import hip
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    info = hip.comm_info()
+    if info["world"]:
+        if (info["rank"], info["world"]) != (rank, world):
+            raise RuntimeError("the live communicator is rank %d of %d, this group wants rank %d of %d"
+                               % (info["rank"], info["world"], rank, world))
+        return info
+    box = [hip.comm_unique_id() if rank == 0 else None]
+    if world > 1:
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    hip.comm_init(rank, world, box[0])
+    import atexit
+    atexit.register(abi_comm_release)
+    return hip.comm_info()
+
+
+def abi_comm_release():
+    from . import hip
+    hip.comm_destroy()
+
+
+class _EventHandle:
+    """What finish() waits on for a bucket launched through the C ABI on a host-owned side stream (the measured form)."""
+
+    def __init__(self, done):
+        self.done = done
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.done)
 
 
 def cu_budget_fixed():
@@ -120,6 +170,10 @@ class GradReducer:
             self._budget_set = True
         self.pack_end = {name: o + n for name, (o, n) in layout.pack_range.items()}
         self.xdtype = grad_exchange_dtype()
+        # MMTG_DDP_COMM=abi: GPU runs only (the communicator is RCCL's); CPU tensors (gloo tests) keep torch.distributed
+        self.abi = comm_backend() == "abi" and torch.cuda.is_available() and (self.world > 1 or self.force)
+        self.comm_info = abi_comm_acquire(group) if self.abi else None
+        self._side = None           # host-owned side stream of the measured form
         self._stage = {}            # bucket index -> bf16 staging tensor (MMTG_DDP_GRAD_DTYPE=bf16), reused step after step
         # first-contact instrumentation (bench.py --gpus N): per bucket, when the backward handed it to RCCL and how long the
         # compute stream then sat in its wait -- events on the compute stream, collected only while `measure` is on
@@ -149,6 +203,7 @@ class GradReducer:
         self.handles = []
         self._pending = []          # (bucket index, staging tensor) of the buckets in flight in a narrower dtype
         self._marks = []            # measure: (bucket index, launch event)
+        self._abi_pending = False   # buckets on the library's side stream since the last join
 
     def _event(self):
         ev = torch.cuda.Event(enable_timing=True)
@@ -158,7 +213,7 @@ class GradReducer:
     def start_count(self, count):
         """Asynchronous SUM all-reduce (in place) of the one-element device tensor holding this rank's row count."""
         if self.active:
-            self.handles.append(dist.all_reduce(count, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self.handles.append(self._launch(count))
 
     def on_pack_ready(self, grad_flat, pack_name):
         self.on_ready(grad_flat, self.pack_end[pack_name])
@@ -180,8 +235,26 @@ class GradReducer:
                 buf = st
             if self.measure and grad_flat.is_cuda:
                 self._marks.append((i, self._event()))
-            self.handles.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self.handles.append(self._launch(buf))
             self.next_bucket += 1
+
+    def _launch(self, buf):
+        """One asynchronous in-place SUM all-reduce; returns what finish() waits on (None: the library's join covers it)."""
+        if not (self.abi and buf.is_cuda):
+            return dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        from . import hip
+        if not self.measure:
+            hip.allreduce_bucket_async(buf)         # fork by event inside the library; finish() joins once
+            self._abi_pending = True
+            return None
+        # measured form: the same collective on a side stream the host owns, so that every bucket has its own end event
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=buf.device)
+        self._side.wait_stream(torch.cuda.current_stream())
+        hip.allreduce_bucket(buf, stream=self._side)
+        done = torch.cuda.Event()
+        done.record(self._side)
+        return _EventHandle(done)
 
     def tail_bytes(self):
         """Bytes of the last bucket: what can only leave after the backward's last kernel (the exposed part's upper bound)."""
@@ -195,9 +268,13 @@ class GradReducer:
             timed = self.measure and grad_flat.is_cuda
             waits = [self._event()] if timed else None
             for h in self.handles:
-                h.wait()
+                if h is not None:
+                    h.wait()
                 if timed:
                     waits.append(self._event())
+            if self._abi_pending:
+                from . import hip
+                hip.comm_join()                 # the compute stream waits for the library's side stream (no host wait)
             for i, st in self._pending:         # narrow exchange: the reduced sums back into the flat fp32 buffer
                 s, e = self.buckets[i]
                 grad_flat[s:e].copy_(st)

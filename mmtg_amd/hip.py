@@ -13,7 +13,7 @@ import os
 import torch
 
 F32, BF16 = 0, 1
-ABI_VERSION = 10
+ABI_VERSION = 11
 EPI_NONE, EPI_GELU, EPI_TANH, EPI_RESID, EPI_DGELU, EPI_DTANH, EPI_ATOMIC, EPI_ROWDOT = range(8)
 GEMM_NO_TR, GEMM_REGSTAGE, GEMM_SKINNY, GEMM_NO_SKINNY, GEMM_WIDE, GEMM_NO_WIDE = 1, 2, 4, 8, 16, 32
 GEMM_PERSIST, GEMM_NO_PERSIST, GEMM_ROW_ORDER, GEMM_OCC4, GEMM_NO_OCC4, GEMM_COL_BLOCK, GEMM_P256, GEMM_NO_P8, GEMM_P8 = 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384
@@ -106,6 +106,13 @@ _SIGS = {
     "mmtg_decode_mlp_sync_words": ([], _i),
     "mmtg_decode_mlp_census": ([_vp, _vp], _i),
     "mmtg_decode_mlp": ([_i, _i, _vp, _l, _vp, _i, _f, _vp, _l, _vp, _vp, _vp, _l, _vp, _vp, _l, _vp, _l, _vp, _vp, _l, _vp, _i, _vp, _vp], _i),
+    "mmtg_comm_unique_id": ([_vp], _i),
+    "mmtg_comm_init": ([_i, _i, _vp], _i),
+    "mmtg_comm_info": ([_vp, _vp, _vp, _vp], _i),
+    "mmtg_allreduce_bucket": ([_vp, _l, _i, _vp], _i),
+    "mmtg_allreduce_bucket_async": ([_vp, _l, _i, _vp], _i),
+    "mmtg_comm_join": ([_vp], _i),
+    "mmtg_comm_destroy": ([], _i),
 }
 
 
@@ -209,6 +216,55 @@ def zero_ranges(base, desc, n):
 def gemm_cu_budget(cus):
     """CUs the eight-phase kernel's tile rule may count on (0 = all, > 0 = that many, < 0 = all but that many)."""
     _check(lib().mmtg_gemm_cu_budget(int(cus)), "gemm_cu_budget")
+
+
+# ------------------------------------------------------------------ the data-parallel exchange (csrc/comm.hip)
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """Rank 0: the 128-byte id every rank passes to comm_init (ship it over any side channel)."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    _check(lib().mmtg_comm_unique_id(C.addressof(buf)), "comm_unique_id")
+    return buf.raw
+
+
+def comm_init(rank, world, unique_id):
+    """Collective: the process's RCCL communicator on the current device (one process per GPU)."""
+    if len(unique_id) != COMM_ID_BYTES:
+        raise ValueError("comm_init: the id is %d bytes, not %d" % (len(unique_id), COMM_ID_BYTES))
+    buf = C.create_string_buffer(bytes(unique_id), COMM_ID_BYTES)
+    _check(lib().mmtg_comm_init(int(rank), int(world), C.addressof(buf)), "comm_init")
+
+
+def comm_info():
+    """{"rank", "world", "device", "rccl_version"} of the live communicator (world 0: none)."""
+    v = (C.c_int * 4)()
+    base = C.addressof(v)
+    _check(lib().mmtg_comm_info(base, base + 4, base + 8, base + 12), "comm_info")
+    return {"rank": v[0], "world": v[1], "device": v[2], "rccl_version": v[3]}
+
+
+def allreduce_bucket(t, stream=None):
+    """In-place SUM all-reduce of the contiguous fp32 / bf16 tensor `t`, enqueued on `stream` (default: the current one)."""
+    assert t.is_contiguous()
+    st = _stream() if stream is None else stream.cuda_stream
+    _check(lib().mmtg_allreduce_bucket(t.data_ptr(), t.numel(), dt(t), st), "allreduce_bucket")
+
+
+def allreduce_bucket_async(t):
+    """The same on the library's side stream, ordered after what the current stream holds now; comm_join() ends the overlap."""
+    assert t.is_contiguous()
+    _check(lib().mmtg_allreduce_bucket_async(t.data_ptr(), t.numel(), dt(t), _stream()), "allreduce_bucket_async")
+
+
+def comm_join():
+    """The current stream waits for every bucket enqueued with allreduce_bucket_async so far."""
+    _check(lib().mmtg_comm_join(_stream()), "comm_join")
+
+
+def comm_destroy():
+    _check(lib().mmtg_comm_destroy(), "comm_destroy")
 
 
 def debug_occupy(workgroups, usec, lds_bytes=163840, stream=None):

@@ -6,6 +6,7 @@ way, then runs the fused trainer over the bucketed all-reduce path and writes wh
 modes
   world1   one rank, MMTG_FORCE_DDP=1: every bucket and the row count go through RCCL; the same two steps (stage-1
            filter, dropout on) are then run by a non-distributed trainer from the same state.
+  world1_abi  one rank, MMTG_FORCE_DDP=1 MMTG_DDP_COMM=abi: the exchange through libmmtg_hip's own RCCL communicator.
   shards   WORLD_SIZE ranks, each a contiguous shard of one global batch (stage-1 filter applied per shard, so the
            shards are unequal); rank 0 also runs the whole batch alone.  Compares the reduced gradient.
 """
@@ -115,6 +116,67 @@ def main():
             tp.step(batch, stage=3)
             torch.cuda.synchronize()
             res["grad_plain"] = tp.eng.grad.detach().cpu().clone()
+        elif mode == "world1_abi":
+            # MMTG_DDP_COMM=abi at world 1 (forced): the buckets and the row count go through libmmtg_hip's own RCCL communicator
+            # (csrc/comm.hip); torch.distributed -- gloo here -- is the control plane only and must see no all-reduce
+            from mmtg_amd import hip
+            assert world == 1 and os.environ.get("MMTG_FORCE_DDP") and os.environ.get("MMTG_DDP_COMM") == "abi"
+            model, mcfg, dcfg, V = build("bf16", 0.0, dev)
+            model.eval()
+            nb = synth.make_batch(8, mcfg, dcfg, V, seed=11)
+            batch = {k: torch.from_numpy(np.asarray(v)).to(dev) for k, v in nb.items()}
+            tr = MMTGTrainer(model, lr=0.0, alpha=0.2, distributed=True, bucket_mb=8.0)
+            assert tr.reducer.abi and tr.reducer.active and len(tr.reducer.buckets) > 3
+            res["info"] = hip.comm_info()
+            # the raw entry points: a SUM over one rank is the identity, in both storage types and both launch forms
+            t = torch.randn(1 << 20, device=dev)
+            t0 = t.clone()
+            hip.allreduce_bucket(t)
+            tb = torch.randn(1 << 20, device=dev).bfloat16()
+            tb0 = tb.clone()
+            hip.allreduce_bucket_async(tb)
+            hip.comm_join()
+            torch.cuda.synchronize()
+            res["raw_identity"] = bool(torch.equal(t, t0) and torch.equal(tb, tb0))
+            try:
+                hip.comm_init(0, 1, hip.comm_unique_id())
+                res["second_init_refused"] = False
+            except RuntimeError as e:
+                res["second_init_refused"] = "already holds a communicator" in str(e)
+            try:
+                hip.allreduce_bucket(torch.zeros(4, device=dev, dtype=torch.float16).view(torch.int16))
+                res["bad_dtype_refused"] = False
+            except (TypeError, RuntimeError):
+                res["bad_dtype_refused"] = True
+            n_torch = []
+            orig = dist.all_reduce
+
+            def counting(tt, *a, **k):
+                n_torch.append(tt.numel())
+                return orig(tt, *a, **k)
+
+            dist.all_reduce = counting
+            try:
+                tr.step(batch, stage=3)                     # the product form: mmtg_allreduce_bucket_async + one join
+                torch.cuda.synchronize()
+                res["grad_async"] = tr.eng.grad.detach().cpu().clone()
+                res["count"] = float(tr._count.item())
+                tr.reducer.measure = True                   # the measured form: a host-owned side stream, one end event per bucket
+                tr.step(batch, stage=3)
+                tr.step(batch, stage=3)
+                torch.cuda.synchronize()
+            finally:
+                dist.all_reduce = orig
+            res["torch_allreduces"] = len(n_torch)
+            res["grad_measured"] = tr.eng.grad.detach().cpu().clone()
+            res["timeline"] = tr.reducer.timeline_report()
+            plain, _, _, _ = build("bf16", 0.0, dev)
+            plain.eval()
+            tp = MMTGTrainer(plain, lr=0.0, alpha=0.2, distributed=False)
+            tp.step(batch, stage=3)
+            torch.cuda.synchronize()
+            res["grad_plain"] = tp.eng.grad.detach().cpu().clone()
+            res["count_plain"] = float(tp._count.item())
         elif mode == "shards":
             from mmtg_amd.ddp import shard_rows
             model, mcfg, dcfg, V = build("f32", 0.0, dev)

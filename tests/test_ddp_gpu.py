@@ -98,6 +98,29 @@ def test_bf16_gradient_exchange_over_rccl_world1_and_bucket_timeline(tmp_path):
     assert tl["launch_ms_after_first"] == sorted(tl["launch_ms_after_first"])          # buckets leave in gradient-ready order
 
 
+def test_exchange_through_the_library_s_own_rccl_communicator_world1(tmp_path):
+    """MMTG_DDP_COMM=abi (SURVEY.md section 8b's second small ABI, csrc/comm.hip) executed on the GPU at world 1 (forced), with
+    torch.distributed on gloo as the control plane only: the raw entry points are the identity over one rank (fp32 and bf16, the
+    explicit-stream and the fork / join forms), a second communicator in the process is refused, torch.distributed sees no
+    all-reduce, and the trainer's gradient -- buckets launched from the backward with one C call each, joined once before the
+    optimizer -- equals the plain trainer's bit for bit, in the product form and in the measured one (per-bucket end events)."""
+    res = _launch("world1_abi", 1, str(tmp_path / "w1a"),
+                  {"MMTG_FORCE_DDP": "1", "MMTG_DDP_COMM": "abi", "MMTG_DDP_TEST_BACKEND": "gloo"})[0]
+    assert res.get("ok") and res["backend"] == "gloo"
+    info = res["info"]
+    assert info["rank"] == 0 and info["world"] == 1 and info["device"] == 0 and info["rccl_version"] > 20000
+    assert res["raw_identity"] and res["second_init_refused"] and res["bad_dtype_refused"]
+    assert res["torch_allreduces"] == 0
+    assert res["count"] == res["count_plain"] > 0
+    assert float(res["grad_plain"].abs().max()) > 0
+    assert torch.equal(res["grad_async"], res["grad_plain"])
+    assert torch.equal(res["grad_measured"], res["grad_plain"])
+    tl = res["timeline"]
+    nb = len(tl["bucket_mb"])
+    assert tl["steps"] == 2 and nb > 3 and len(tl["exposed_wait_ms"]) == nb
+    assert tl["launch_ms_after_first"] == sorted(tl["launch_ms_after_first"])
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
 def test_two_rank_gradient_equals_single_rank_on_the_concatenated_batch(tmp_path):
     """2 ranks, contiguous row shards of one 16-row batch, stage-1 filter per shard (unequal shards): the all-reduced

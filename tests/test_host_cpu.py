@@ -185,7 +185,7 @@ def test_c_abi_exports_every_declared_symbol():
     lib = ctypes.CDLL(hip.lib_path())
     for name in declared:
         assert hasattr(lib, name), name
-    assert hip.lib().mmtg_abi_version() == hip.ABI_VERSION == 10
+    assert hip.lib().mmtg_abi_version() == hip.ABI_VERSION == 11
     # ... and nothing else: the library is built with -fvisibility=hidden + a linker version script, so no internal C++
     # helper (mmtg_set_error, ProfScope, template instantiations, hipcc's __hip_cuid_*) leaks into the dynamic symbol table
     import subprocess
@@ -206,6 +206,39 @@ def test_host_side_of_the_round4_abi_without_a_gpu():
     assert L.mmtg_build_flags() == b""                                    # the product build carries no diagnostic defines
     bad = L.mmtg_split_planes(0x7000000000, 8, 4, 12, 0x7100000000, 16, 64, None)
     assert bad != 0 and b"split_planes" in L.mmtg_last_error()           # cols % 8 != 0
+
+
+def test_comm_abi_without_a_communicator_fails_loudly(monkeypatch):
+    """The data-parallel exchange's second small ABI (csrc/comm.hip) on a box without a GPU: the library loads
+    without RCCL as a link-time dependency, reports "no communicator", and every collective entry point refuses with a message --
+    nothing falls back to a host reduction.  MMTG_DDP_COMM is validated; on CPU tensors the reducer keeps torch.distributed."""
+    import subprocess
+    from mmtg_amd import ddp
+    needed = subprocess.run(["readelf", "-d", hip.lib_path()], capture_output=True, text=True, check=True).stdout
+    assert "rccl" not in needed.lower()
+    assert hip.comm_info()["world"] == 0 and hip.comm_info()["rank"] == -1
+    t = torch.zeros(8)
+    with pytest.raises(RuntimeError, match="no communicator"):
+        hip._check(hip.lib().mmtg_allreduce_bucket(t.data_ptr(), 8, hip.F32, None), "allreduce_bucket")
+    with pytest.raises(RuntimeError, match="no communicator"):
+        hip._check(hip.lib().mmtg_allreduce_bucket_async(t.data_ptr(), 8, hip.F32, None), "allreduce_bucket_async")
+    with pytest.raises(RuntimeError, match="no communicator"):
+        hip._check(hip.lib().mmtg_comm_join(None), "comm_join")
+    with pytest.raises(RuntimeError, match="rank 3 of 2"):
+        hip.comm_init(3, 2, bytes(hip.COMM_ID_BYTES))
+    with pytest.raises(ValueError):
+        hip.comm_init(0, 1, b"short")
+    hip.comm_destroy()                                   # a no-op without a communicator
+    assert float(t.abs().max()) == 0.0
+    monkeypatch.setenv("MMTG_DDP_COMM", "mpi")
+    with pytest.raises(ValueError, match="MMTG_DDP_COMM"):
+        ddp.comm_backend()
+    monkeypatch.setenv("MMTG_DDP_COMM", "abi")
+    assert ddp.comm_backend() == "abi"
+    if not torch.cuda.is_available():
+        model, _, _ = tiny_model()
+        red = ddp.GradReducer(model.layout, bucket_mb=1.0)
+        assert red.abi is False and red.comm_info is None
 
 
 def test_product_never_imports_the_oracle():

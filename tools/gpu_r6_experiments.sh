@@ -188,5 +188,25 @@ for ln in sys.stdin:
 done
 done
 ;;
-*) echo "usage: $0 {a|c|d|e|f|g|h|i|j|k|l|m|n}"; exit 2 ;;
+o)
+# the exchange through the library's own RCCL communicator (MMTG_DDP_COMM=abi, csrc/comm.hip): the data-parallel tests, then the
+# full-size step at world 1 with the exchange forced (MMTG_FORCE_DDP=1), torch.distributed per bucket against one C call per bucket
+mkdir -p gpurun_out/r6o
+E=gpurun_out/r6o
+timeout 1500 python -m pytest tests/test_ddp_gpu.py -m gpu -q --no-header -p no:cacheprovider -x 2>&1 | tail -8 | tee $E/pytest_ddp.txt
+for rep in 1 2; do
+for comm in torch abi; do
+  MMTG_FORCE_DDP=1 MMTG_DDP_COMM=$comm timeout 400 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --primary-only --no-roofline 2>$E/err_$comm.log | python -c "
+import sys, json
+for ln in sys.stdin:
+    try: d = json.loads(ln)
+    except Exception: continue
+    dd = d.get('ddp') or {}
+    print('forced world-1 exchange, comm=$comm', d['value'], 'tok/s', d['ms_per_step'], 'ms/step; finish wait', dd.get('finish_wait_ms_per_step'), 'ms; exchange alone', dd.get('allreduce_ms_per_step_isolated'), 'ms;', dd.get('comm'), dd.get('comm_info'))
+" | tee -a $E/forced_world1_comm_ab.txt
+done
+done
+tail -3 $E/err_abi.log
+;;
+*) echo "usage: $0 {a|c|d|e|f|g|h|i|j|k|l|m|n|o}"; exit 2 ;;
 esac
