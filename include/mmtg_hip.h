@@ -380,6 +380,7 @@ MMTG_API int mmtg_axpy_f32(float* y, const float* x, float a, long n, void* stre
  * MMTG_EPI_SPLIT: slab s = fp32 [M, ldc] at C + s * M * ldc): dst[i] (+)= sum_s part[s * stride + i],
  * slabs added in order -- the deterministic replacement of the fp32-atomic epilogue for the autograd
  * weight gradients of nn.Linear / Conv1D (model.py:77-79,134-136,199,279-281 and the GPT-2 products).
+ * Slab producers: the bf16 single-stage LDS-DMA kernel and (round 6) the exact-fp32 kernel.
  * n and stride in floats, multiples of 4; accumulate = 0 overwrites dst.                              */
 MMTG_API int mmtg_slab_sum(const float* part, int splits, long stride, float* dst, int accumulate, long n, void* stream);
 /* Grouped weight-gradient products with an in-kernel deterministic split-K reduction (csrc/wgrad.hip): ONE launch for

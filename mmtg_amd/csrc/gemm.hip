@@ -77,7 +77,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_kernel(GemmArgs p) {
         __syncthreads();
     }
     // (the loop's final __syncthreads() already separates the last tile reads from this overlay)
-    if constexpr (!std_orient) p.C = reinterpret_cast<char*>(p.C) + (long)split * p.split_stride;     // MMTG_EPI_SPLIT slab (0 otherwise)
+    p.C = reinterpret_cast<char*>(p.C) + (long)split * p.split_stride;     // MMTG_EPI_SPLIT slab (0 otherwise), every layout
     gemm_epilogue<T, std_orient, 4, 4>(p, acc, m0 + wm * 64, n0 + wn * 64, g, l15,
                                        smem + wave * epi_scratch_bytes<4, 4>(), lane);
 }
@@ -1345,9 +1345,9 @@ extern "C" int mmtg_gemm(int dtype, int transA, int transB, int M, int N, int K,
         MMTG_REQUIRE(!bias || MMTG_ALIGNED16(bias), "gemm: bias must be 16-byte aligned");
         MMTG_REQUIRE(splits <= 1 || epi == MMTG_EPI_SPLIT, "gemm: split-K needs the atomic or the split epilogue");
         if (epi == MMTG_EPI_SPLIT)
-            MMTG_REQUIRE(out_f32 && !bias && (dtype == MMTG_BF16 ? !(flags & (MMTG_GEMM_REGSTAGE | MMTG_GEMM_NO_TR | MMTG_GEMM_PERSIST)) : !wgrad),
+            MMTG_REQUIRE(out_f32 && !bias && (dtype == MMTG_BF16 ? !(flags & (MMTG_GEMM_REGSTAGE | MMTG_GEMM_NO_TR | MMTG_GEMM_PERSIST)) : true),
                          "gemm: the split epilogue stores raw fp32 partial products (out_f32, no bias) from the bf16 LDS-DMA kernels "
-                         "or, forward layouts only, the fp32 kernel");
+                         "or the fp32 kernel");
     } else {
         MMTG_REQUIRE(!bias, "gemm: atomic epilogue takes no bias");
     }

@@ -495,6 +495,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
                                               char* lds, int lane) {
     if constexpr (std_orient) {
         float* C = reinterpret_cast<float*>(p.C);
+        // MMTG_EPI_SPLIT (the register-staged kernel, exact-fp32 weight gradients): the caller has moved C to this K split's slab --
+        // the raw partial product with plain stores, mmtg_slab_sum adds the slabs in index order (no fp32 atomics: reproducible)
+        const bool slab = p.epi == MMTG_EPI_SPLIT;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -503,7 +506,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int m = mw0 + i * 16 + 4 * g + r;
-                    if (m < p.M && n < p.N) atomicAdd(C + (long)m * p.ldc + n, acc[i][j][r] * p.alpha);
+                    if (m < p.M && n < p.N) {
+                        if (slab) C[(long)m * p.ldc + n] = acc[i][j][r];
+                        else atomicAdd(C + (long)m * p.ldc + n, acc[i][j][r] * p.alpha);
+                    }
                 }
             }
     } else {

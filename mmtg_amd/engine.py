@@ -621,7 +621,10 @@ class Engine:
         tiles = ((Mg + 127) // 128) * ((Ng + 127) // 128)
         if bf and _WGRAD_SLAB and Ng % 8 == 0:
             splits = _wgrad_splits_p8(Mg, Ng, Mtok) or splits
-        use_slab = bf and _WGRAD_SLAB and 1 < splits and tiles < 512 and Ng % 8 == 0
+        # (the exact-fp32 cross-check mode, round 6: its split weight gradients as slabs too -- any tile count, speed is not its
+        #  point -- so that the mode's gradient is bit-reproducible like the others'; MMTG_WGRAD_ATOMIC=1 restores the atomics)
+        exact = self.dtype == hip.F32 and not self.x3
+        use_slab = _WGRAD_SLAB and 1 < splits and Ng % 8 == 0 and ((bf and tiles < 512) or exact)
         if self._lazy is not None and (self.layout.entries[wkey][0], Mg * Ng) in self._lazy and not (use_slab and self.wgrad_overwrite):
             gw.zero_()          # the lazy zero_grad skipped this tensor expecting an overwrite that is not happening now
         if use_slab:
@@ -1213,8 +1216,16 @@ class Engine:
             if self.wgrad_overwrite and self._ow_rec is not None:
                 self._ow_rec[1].append((self.layout.pack_range["wte"][0], Vp * D))
         else:
-            hip.gemm(dlogits, a["hf"], self.Gp("wte"), Vp, D, M, transA=True, transB=False, lda=Vp, ldb=D, ldc=D,
-                     epi=hip.EPI_ATOMIC, splits=_wgrad_splits(Vp, D, M, self.dtype == hip.BF16))
+            splits = _wgrad_splits(Vp, D, M, self.dtype == hip.BF16)
+            if self.dtype == hip.F32 and not self.x3 and _WGRAD_SLAB and splits > 1:
+                # exact-fp32 mode: K-split slabs summed in order ON TOP of what the gradient already holds (no fp32 atomics)
+                part = self.buf("wgrad_slabs", (splits * Vp * D,), torch.float32)
+                hip.gemm(dlogits, a["hf"], part, Vp, D, M, transA=True, transB=False, lda=Vp, ldb=D, ldc=D,
+                         epi=hip.EPI_SPLIT, out_f32=True, splits=splits)
+                hip.slab_sum(part, splits, Vp * D, self.Gp("wte"), Vp * D, accumulate=True)
+            else:
+                hip.gemm(dlogits, a["hf"], self.Gp("wte"), Vp, D, M, transA=True, transB=False, lda=Vp, ldb=D, ldc=D,
+                         epi=hip.EPI_ATOMIC, splits=splits)
         # Every LayerNorm backward on the residual stream also emits, in the same pass, the
         # dropout-masked gradient entering the previous residual branch and that branch's bias
         # gradient (column sum) -- see mmtg_layernorm_bwd.
@@ -1346,10 +1357,15 @@ class Engine:
                 self._wgrad(ctx, dy, p + "attn.c_proj.weight", None, M, "conv1d")
             # (hybrid: the split-precision forward drew the attention-dropout mask element by element; the whole-head backward
             #  kernels regenerate THAT mask instead of their own word masks)
+            # (exact-fp32 mode: the tiled kernel combines its waves' bias sums with LDS atomics -- arrival order -- so the c_attn bias
+            #  gradient is an ordered column sum over d(qkv) there instead: one more pass in the cross-check mode, reproducible bits)
+            exact = self.dtype == hip.F32 and not self.x3 and _WGRAD_SLAB
             hip.attn_bwd(qkv, a["keep"], ctx, dctx, lse, delta, dq32, dqkv, B, T, sh.nH, D // sh.nH,
-                         drop_p=pa, drop_seed=s[0], delta_ready=fuse_delta, dbias=self.G(p + "attn.c_attn.bias"),
+                         drop_p=pa, drop_seed=s[0], delta_ready=fuse_delta, dbias=None if exact else self.G(p + "attn.c_attn.bias"),
                          flags=hip.ATTN_ELEM_MASK if a.get("elem_mask") else 0,
-                         dbias_ws=self.buf("attn_dbias_rows", (hip.attn_bwd_bias_rows(B, T, self.dtype), 3 * D), torch.float32))
+                         dbias_ws=None if exact else self.buf("attn_dbias_rows", (hip.attn_bwd_bias_rows(B, T, self.dtype), 3 * D), torch.float32))
+            if exact:
+                hip.colsum(dqkv, M, 3 * D, self.G(p + "attn.c_attn.bias"))
             self._prefetch(a1, xin)             # while the c_attn dgrad runs: its weight gradient's operand, LayerNorm input
             self._dgrad(dqkv, p + "attn.c_attn.weight", da, M, "conv1d")
             if l > 0:

@@ -1022,7 +1022,7 @@ def test_single_experience_step_vs_oracle(enc):
             assert float(p.grad.abs().max()) == 0.0 and float(r.abs().max()) == 0.0, k
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "bf16x3", "bf16x3f"])       # (the exact-fp32 parity mode still splits its weight gradients over fp32 atomics and runs the tiled attention kernels)
+@pytest.mark.parametrize("dtype", ["bf16", "bf16x3", "bf16x3f", "f32"])
 def test_training_step_is_bit_reproducible(dtype):
     """Round 4: no reduction of the backward ends in floating-point atomics any more -- LayerNorm gains / biases, every bias
     gradient (LayerNorm-fused column sums, dGELU bands, the attention kernels' rows), the token-type embedding rows, the fuser's
@@ -1031,7 +1031,10 @@ def test_training_step_is_bit_reproducible(dtype):
     AdamW steps, bit for bit (stage-1 filter and dropout on; allocator history perturbed between the runs).  The full-size run
     of the same check: tools/determinism_probe.py (profiles/r04_*determinism*).
     Round 5: the split-precision mode too -- its attention backward stores every key block's dQ share into the block's own buffer
-    (summed in block order) instead of fp32 atomics, its weight gradients run through the grouped kernel."""
+    (summed in block order) instead of fp32 atomics, its weight gradients run through the grouped kernel.
+    Round 6: the exact-fp32 cross-check mode too -- its split weight gradients are K-split slabs summed in order (the register-staged
+    kernel's MMTG_EPI_SPLIT stores) and its c_attn bias gradient an ordered column sum over d(qkv); what is left to arrival order in
+    that mode is the tiled attention backward's dQ at more than two key blocks (T > 256), outside this test and the benchmark."""
     from ddp_worker import build as build_small
     from mmtg_amd import synth
     grads, params = [], []

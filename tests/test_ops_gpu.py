@@ -964,14 +964,16 @@ def test_transpose_batch(dtype):
         assert torch.equal(dst[o:o + r * c].view(c, r), src[o:o + r * c].view(r, c).t())
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("M,N,K,splits", [(768, 2304, 4744, 7), (200, 136, 1000, 3), (3072, 768, 2048, 5), (128, 128, 64, 4)])
-def test_weight_gradient_slabs(M, N, K, splits):
+def test_weight_gradient_slabs(M, N, K, splits, dtype):
     """Weight gradients as K-split slabs (plain stores) + mmtg_slab_sum: same product as the fp32-atomic
     epilogue (tolerance: fp32 summation order only, 2e-5 relative to the largest entry), bit-identical
-    between runs, accumulate / overwrite semantics, slabs past the end of K hold zeros."""
-    A = rnd(K, M, dtype=torch.bfloat16, seed=31).to(DEV)
-    B = rnd(K, N, dtype=torch.bfloat16, seed=32).to(DEV)
-    ref = A.float().t() @ B.float()
+    between runs, accumulate / overwrite semantics, slabs past the end of K hold zeros.  bf16: the single-stage LDS-DMA kernel;
+    fp32 (round 6): the exact-fp32 register-staged kernel -- the cross-check mode's weight gradients without atomics."""
+    A = rnd(K, M, dtype=dtype, seed=31).to(DEV)
+    B = rnd(K, N, dtype=dtype, seed=32).to(DEV)
+    ref = (A.double().t() @ B.double()).float()
     scale = ref.abs().max().item()
     atom = torch.zeros(M, N, device=DEV)
     hip.gemm(A, B, atom, M, N, K, transA=True, epi=hip.EPI_ATOMIC, splits=splits)
