@@ -36,6 +36,9 @@ if ROOT not in sys.path:
 # (before the HIP runtime can initialise: kernel arguments in device memory, as `import mmtg_amd` sets it for any user of the
 #  package -- mmtg_amd/__init__.py has the measurement)
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+# (multi-process GPU work on this pool: the host driver only supports dmabuf IPC -- without it RCCL fails with
+#  `hipIpcGetMemHandle: invalid argument`; already exported by the harness, kept here for a bare launcher)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
