@@ -208,5 +208,18 @@ done
 done
 tail -3 $E/err_abi.log
 ;;
-*) echo "usage: $0 {a|c|d|e|f|g|h|i|j|k|l|m|n|o}"; exit 2 ;;
+p)
+# kernel arguments in device memory again, on whatever box this call gets (the round's boxes differ by 3 % in the bf16 step)
+mkdir -p gpurun_out/r6p2
+for ka in 1 0 1 0; do
+  HIP_FORCE_DEV_KERNARG=$ka timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --primary-only --no-roofline 2>/dev/null | python -c "
+import sys, json
+for ln in sys.stdin:
+    try: d = json.loads(ln)
+    except Exception: continue
+    print('HIP_FORCE_DEV_KERNARG=$ka', d['value'], 'tok/s', d['ms_per_step'], 'ms/step')
+" | tee -a gpurun_out/r6p2/train_dev_kernarg_ab.txt
+done
+;;
+*) echo "usage: $0 {a|c|d|e|f|g|h|i|j|k|l|m|n|o|p}"; exit 2 ;;
 esac
