@@ -221,5 +221,44 @@ for ln in sys.stdin:
 " | tee -a gpurun_out/r6p2/train_dev_kernarg_ab.txt
 done
 ;;
-*) echo "usage: $0 {a|c|d|e|f|g|h|i|j|k|l|m|n|o|p}"; exit 2 ;;
+q)
+# the attention backward's dQ kernel launched without the queue barrier (hipExtAnyOrderLaunch) behind its dK / dV kernel:
+# parity tests with the switch on, the step A/B, and whether the two kernels really overlap (rocprofv3 kernel trace).
+# (needs tools/experiments/attn_bwd_anyorder_launch.patch applied: the runtime keeps the barrier on gfx950, the switch was removed)
+mkdir -p gpurun_out/r6q2
+E=gpurun_out/r6q2
+MMTG_ATTN_BWD_ANYORDER=1 timeout 900 python -m pytest tests/test_ops_gpu.py tests/test_model_gpu.py -m gpu -q --no-header -p no:cacheprovider -x -k "attn or attention or bf16_vs_oracle or reproducible" 2>&1 | tail -4 | tee $E/pytest_anyorder.txt
+for rep in 1 2 3; do
+for ao in 0 1; do
+  MMTG_ATTN_BWD_ANYORDER=$ao timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --primary-only --no-roofline 2>/dev/null | python -c "
+import sys, json
+for ln in sys.stdin:
+    try: d = json.loads(ln)
+    except Exception: continue
+    print('ATTN_BWD_ANYORDER=$ao', d['value'], 'tok/s', d['ms_per_step'], 'ms/step')
+" | tee -a $E/anyorder_ab.txt
+done
+done
+export TMPDIR=/tmp
+R=$(pwd)
+( cd /tmp && MMTG_ATTN_BWD_ANYORDER=1 timeout 600 rocprofv3 --kernel-trace --output-format csv -d $R/$E/trace -o t -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --primary-only --no-roofline --no-check > $R/$E/trace.log 2>&1 )
+f=$(find $E/trace -name "*kernel_trace.csv" | head -1)
+python3 - "$f" <<'PY' | tee $E/overlap_from_kernel_trace.txt
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+n = ov = 0
+for a, b in zip(rows, rows[1:]):
+    if "attn_bwd_small_kv2" in a["Kernel_Name"] and "attn_bwd_small_q" in b["Kernel_Name"]:
+        n += 1
+        d = int(a["End_Timestamp"]) - int(b["Start_Timestamp"])
+        ov += d > 0
+        if n <= 6:
+            print("kv2 %.1f us, q starts %.1f us %s kv2's end, q %.1f us" % ((int(a["End_Timestamp"]) - int(a["Start_Timestamp"])) / 1e3,
+                  abs(d) / 1e3, "BEFORE" if d > 0 else "after", (int(b["End_Timestamp"]) - int(b["Start_Timestamp"])) / 1e3))
+print("pairs", n, "overlapping", ov)
+PY
+rm -rf $E/trace
+;;
+*) echo "usage: $0 {a|c|d|e|f|g|h|i|j|k|l|m|n|o|p|q}"; exit 2 ;;
 esac
