@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MMTG_ABI_VERSION 11
+#define MMTG_ABI_VERSION 12
 
 /* The library is built with -fvisibility=hidden: only the entry points below are exported. */
 #define MMTG_API __attribute__((visibility("default")))
@@ -180,6 +180,13 @@ MMTG_API int mmtg_splitk_finish(int dtype, const float* part, int splits, int M,
  * run to run (the round-1 kernel finished with fp32 atomics from ~1000 workgroups). */
 MMTG_API long mmtg_colsum_ws(int M, int N);      /* workspace floats mmtg_colsum needs for M rows (0: none) */
 MMTG_API int mmtg_colsum(int dtype, const void* X, long ldx, int M, int N, float* out, float* ws, long ws_floats, void* stream);
+/* Round 6: many small ordered column sums in ONE launch -- out_i[c] += sum_{r < M_i} X_i[r * ldx_i + c], c < N_i, every item summed in
+ * the order mmtg_colsum uses for the same rows (the same bits); fp32 rows, M_i <= 2048.  `items` is a HOST array (the items travel in
+ * the kernel arguments, 64 per launch).  The backward of a GPT-2 block ends four such reductions (two LayerNorm second stages, the
+ * dGELU bands, the attention kernels' bias rows: the bias / LayerNorm gradients autograd produces behind model.py:282-288) that nothing
+ * reads before the optimizer: mmtg_layernorm_bwd_partial / MMTG_ATTN_DBIAS_ROWS leave them as partial rows, this call sums them.      */
+typedef struct { const float* X; float* out; long ldx; int M; int N; } mmtg_colsum_item;
+MMTG_API int mmtg_colsum_batch(const mmtg_colsum_item* items, int n, void* stream);
 
 /* ---------------------------------------------------------------- LayerNorm
  * torch.nn.LayerNorm (model.py:380-382) and GPT-2's ln_1/ln_2/ln_f.          */
@@ -196,6 +203,13 @@ MMTG_API int mmtg_layernorm_bwd(int dtype, const void* dy, const void* x, const 
                        float* dgamma, float* dbeta, int rows, int cols,
                        void* dx_masked, unsigned drop_thresh, unsigned drop_seed, float* dcolsum,
                        float* ws, long ws_floats, void* stream);
+/* The first stage of mmtg_layernorm_bwd alone (round 6): dx (+ dx_masked) as above, and the partial rows ws[k][q][cols], k < *partial_rows
+ * (host, out), q = 0: d gamma, 1: d beta, 2: column sums of dx_masked / dx when want_colsum -- to be summed by mmtg_colsum_batch
+ * (X = ws + q * cols, ldx = 3 * cols, M = *partial_rows, N = cols): the same bits as the one-call form.  ws must stay untouched until then. */
+MMTG_API int mmtg_layernorm_bwd_partial(int dtype, const void* dy, const void* x, const float* gamma,
+                       const float* mean, const float* rstd, const void* dres, void* dx, int rows, int cols,
+                       void* dx_masked, unsigned drop_thresh, unsigned drop_seed, int want_colsum,
+                       float* ws, long ws_floats, int* partial_rows, void* stream);
 /* x3 mode: mmtg_layernorm_bwd on fp32 rows whose dropout-masked input gradient (dx itself without dropout) goes to a (hi | lo) bf16
  * plane pair [rows, cols] (lo plane `plane` elements behind) instead of an fp32 tensor: only split-precision products read it. */
 MMTG_API int mmtg_layernorm_bwd_x3(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
@@ -242,6 +256,11 @@ MMTG_API int mmtg_attn_trace(void* buf);
  * split-precision kernels (keep (q, k) iff hash(seed, ((b nH + h) T + q) T + k) >= drop_thresh, scale 1 / (1 - p) exactly) instead of
  * their own 12-bit word masks: the bf16x3f mode's backward then differentiates the mask its split-precision forward applied.        */
 #define MMTG_ATTN_ELEM_MASK 1
+/* MMTG_ATTN_DBIAS_ROWS (round 6) -- where mmtg_attn_bwd_dbias_rows(dtype, B, T) > 0 (the bf16 whole-head kernels) the c_attn bias
+ * gradient is left as that many partial rows [rows, 3D] at the head of dbias_ws for the caller's mmtg_colsum_batch (dbias is then only
+ * the request for them); other shapes ignore the flag and sum inside the call.                                                        */
+#define MMTG_ATTN_DBIAS_ROWS 2
+MMTG_API int mmtg_attn_bwd_dbias_rows(int dtype, int B, int T);
 MMTG_API int mmtg_attn_bwd(int dtype, const void* qkv, const int* keep, const void* out, const void* dout,
                   const float* lse, float* delta, int delta_ready, float* dq32, void* dqkv, float* dbias, float* dbias_ws,
                   int B, int T, int nH, int dh, unsigned drop_thresh, unsigned drop_seed, int flags, void* stream);

@@ -1606,6 +1606,12 @@ extern "C" int mmtg_attn_fwd(int dtype, const void* qkv, const int* keep, void* 
 
 extern "C" int mmtg_colsum(int dtype, const void* X, long ldx, int M, int N, float* out, float* ws, long ws_floats, void* stream);
 
+/* rows of dbias_ws ([rows, 3D] fp32 partial sums of the c_attn bias gradient) that mmtg_attn_bwd leaves UNSUMMED under MMTG_ATTN_DBIAS_ROWS
+ * for this shape; 0: the shape runs on kernels that reduce inside the call whatever the flag says */
+extern "C" int mmtg_attn_bwd_dbias_rows(int dtype, int B, int T) {
+    return (dtype == MMTG_BF16 && T <= (attn_route_no512() ? 256 : SM_MAXT) && !attn_route_tiled()) ? B : 0;
+}
+
 extern "C" int mmtg_attn_bwd(int dtype, const void* qkv, const int* keep, const void* out, const void* dout,
                              const float* lse, float* delta, int delta_ready, float* dq32, void* dqkv, float* dbias, float* dbias_ws,
                              int B, int T, int nH, int dh, unsigned drop_thresh, unsigned drop_seed, int flags, void* stream) {
@@ -1728,7 +1734,9 @@ extern "C" int mmtg_attn_bwd(int dtype, const void* qkv, const int* keep, const 
     // several key blocks per head: dQ went through the fp32 atomics + finish pass; sum its columns here
     // (the whole-head kernels write ONE partial bias row per batch row and leave nothing to the dQ column pass)
     const int nkb_ = small_path ? 1 : cdiv(T, dtype == MMTG_F32 ? 4 * AT<float>::KPW : 4 * AT<bf16>::KPW);
-    if (bias_rows) {
+    // MMTG_ATTN_DBIAS_ROWS (whole-head kernels only, mmtg_attn_bwd_dbias_rows() > 0): the B partial rows stay in dbias_ws for the caller's
+    // batched sum (mmtg_colsum_batch) instead of a launch of their own here
+    if (bias_rows && !((flags & MMTG_ATTN_DBIAS_ROWS) && small_path)) {
         int rc = mmtg_colsum(MMTG_F32, dbias_ws, 3L * D, B * nkb_, 3 * D, dbias, nullptr, 0, stream);      // (few rows: one ordered pass)
         if (rc) return rc;
     }

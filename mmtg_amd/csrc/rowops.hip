@@ -803,13 +803,15 @@ static inline int ln_bwd_blocks(int rows) { return min(cdiv(rows, 4), 1024); }
 
 extern "C" long mmtg_layernorm_bwd_ws(int rows, int cols) { return (long)ln_bwd_blocks(rows) * 3 * cols; }
 
-extern "C" int mmtg_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma,
-                                  const float* mean, const float* rstd, const void* dres, void* dx,
-                                  float* dgamma, float* dbeta, int rows, int cols,
-                                  void* dx_masked, unsigned drop_thresh, unsigned drop_seed, float* dcolsum,
-                                  float* ws, long ws_floats, void* stream) {
+// finalize: the second stage in the same call (dgamma / dbeta / dcolsum += the ordered sums of the partial rows); otherwise the partial
+// rows stay in ws ([*partial_rows][3][cols]) for the caller's mmtg_colsum_batch and `want` alone says whether quantity 2 is produced
+static int ln_bwd_impl(int dtype, const void* dy, const void* x, const float* gamma,
+                       const float* mean, const float* rstd, const void* dres, void* dx,
+                       float* dgamma, float* dbeta, int rows, int cols,
+                       void* dx_masked, unsigned drop_thresh, unsigned drop_seed, float* dcolsum, int want_colsum,
+                       float* ws, long ws_floats, bool finalize, int* partial_rows, void* stream) {
     MMTG_REQUIRE(rows > 0 && cols > 0 && cols % 4 == 0 && cols <= 1024, "layernorm_bwd: cols=%d must be a multiple of 4 and <= 1024", cols);
-    MMTG_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta, "layernorm_bwd: null pointer");
+    MMTG_REQUIRE(dy && x && gamma && mean && rstd && dx && (!finalize || (dgamma && dbeta)), "layernorm_bwd: null pointer");
     MMTG_REQUIRE(ws && ws_floats >= mmtg_layernorm_bwd_ws(rows, cols), "layernorm_bwd: workspace of %ld floats required",
                  mmtg_layernorm_bwd_ws(rows, cols));
     MMTG_REQUIRE(!drop_thresh || dx_masked, "layernorm_bwd: dropout mask requested without dx_masked");
@@ -818,7 +820,7 @@ extern "C" int mmtg_layernorm_bwd(int dtype, const void* dy, const void* x, cons
     ProfScope prof(MMTG_PROF_LAYERNORM, s, 16.0 * rows * cols, ((dres ? 4.0 : 3.0) + (dx_masked ? 1.0 : 0.0)) * esz * rows * cols);
     int nb = ln_bwd_blocks(rows);
     const float ik = drop_thresh ? (float)(4294967296.0 / (4294967296.0 - (double)drop_thresh)) : 1.0f;
-    const int want = dcolsum != nullptr;
+    const int want = finalize ? dcolsum != nullptr : want_colsum != 0;
     MMTG_REQUIRE(dtype == MMTG_F32 || dtype == MMTG_BF16, "layernorm_bwd: bad dtype");
     static const bool v1 = getenv("MMTG_LN_V1") != nullptr;      // A/B switch for measurements
     const int epc = dtype == MMTG_F32 ? 4 : 8;
@@ -872,11 +874,35 @@ extern "C" int mmtg_layernorm_bwd(int dtype, const void* dy, const void* x, cons
         else
             hipLaunchKernelGGL(ln_bwd_kernel<bf16>, grid, block, 0, s, (const bf16*)dy, (const bf16*)x, gamma, mean, rstd, (const bf16*)dres, (bf16*)dx, (bf16*)dx_masked, ws, rows, cols, want, drop_thresh, drop_seed, ik);
     }
-    static const bool fin_atomic = getenv("MMTG_LN_FINALIZE_ATOMIC") != nullptr;      // A/B: the round-1 z-sliced finalize (fp32 atomics)
-    if (fin_atomic) hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3(cdiv(cols, 64), 3, 16), dim3(256), 0, s, ws, nb, cols, dgamma, dbeta, dcolsum);
-    else hipLaunchKernelGGL(ln_bwd_finalize_det_kernel, dim3(cdiv(cols, 64), 3), dim3(1024), 0, s, ws, nb, cols, dgamma, dbeta, dcolsum);
+    if (partial_rows) *partial_rows = nb;
+    if (finalize) {
+        static const bool fin_atomic = getenv("MMTG_LN_FINALIZE_ATOMIC") != nullptr;      // A/B: the round-1 z-sliced finalize (fp32 atomics)
+        if (fin_atomic) hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3(cdiv(cols, 64), 3, 16), dim3(256), 0, s, ws, nb, cols, dgamma, dbeta, dcolsum);
+        else hipLaunchKernelGGL(ln_bwd_finalize_det_kernel, dim3(cdiv(cols, 64), 3), dim3(1024), 0, s, ws, nb, cols, dgamma, dbeta, dcolsum);
+    }
     MMTG_LAUNCH_CHECK("layernorm_bwd");
     return MMTG_OK;
+}
+
+extern "C" int mmtg_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma,
+                                  const float* mean, const float* rstd, const void* dres, void* dx,
+                                  float* dgamma, float* dbeta, int rows, int cols,
+                                  void* dx_masked, unsigned drop_thresh, unsigned drop_seed, float* dcolsum,
+                                  float* ws, long ws_floats, void* stream) {
+    return ln_bwd_impl(dtype, dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, cols, dx_masked, drop_thresh, drop_seed, dcolsum, 0,
+                       ws, ws_floats, true, nullptr, stream);
+}
+
+/* First stage only (round 6): d(x) (+ the masked copy) and the partial rows ws[k][q][cols] (q = 0: d gamma, 1: d beta, 2: the column sums
+ * of the masked d(x) when want_colsum) of k < *partial_rows workgroups; the caller sums them later, many LayerNorms' in one
+ * mmtg_colsum_batch launch, in the order the one-call form's second stage uses (the same bits). */
+extern "C" int mmtg_layernorm_bwd_partial(int dtype, const void* dy, const void* x, const float* gamma,
+                                          const float* mean, const float* rstd, const void* dres, void* dx, int rows, int cols,
+                                          void* dx_masked, unsigned drop_thresh, unsigned drop_seed, int want_colsum,
+                                          float* ws, long ws_floats, int* partial_rows, void* stream) {
+    MMTG_REQUIRE(partial_rows, "layernorm_bwd_partial: null pointer");
+    return ln_bwd_impl(dtype, dy, x, gamma, mean, rstd, dres, dx, nullptr, nullptr, rows, cols, dx_masked, drop_thresh, drop_seed, nullptr,
+                       want_colsum, ws, ws_floats, false, partial_rows, stream);
 }
 
 /* x3 mode (fp32 rows): mmtg_layernorm_bwd whose (dropout-masked) input gradient ALSO / INSTEAD goes to a (hi | lo) bf16 plane pair
@@ -917,6 +943,46 @@ extern "C" int mmtg_layernorm_bwd_x3(const float* dy, const float* x, const floa
 
 // rows above which the sum runs in two stages (slices -> workspace -> ordered sum of the slices)
 constexpr int COLSUM_TALL = 2048, COLSUM_SLICES = 128;
+
+// Many small ordered column sums in ONE launch (round 6): the backward of a GPT-2 block ends four reductions of a few hundred fp32
+// rows each (two LayerNorm second stages, the dGELU bands, the attention kernels' bias rows) -- 57 launches of 4-6 us per step that
+// nothing depends on before the optimizer.  Item i is workgroup row i of the grid; the items travel in the kernel arguments.
+namespace {
+constexpr int COLSUM_BATCH = 64;
+struct ColsumBatch { mmtg_colsum_item it[COLSUM_BATCH]; };
+__global__ __launch_bounds__(1024) void colsum_batch_kernel(const ColsumBatch b) {
+    __shared__ float red[16][64];
+    const mmtg_colsum_item& e = b.it[blockIdx.y];
+    if ((int)blockIdx.x * 64 >= e.N) return;          // (uniform per workgroup)
+    colsum_rows_block<float>(e.X, e.ldx, e.M, e.N, e.out, 1, blockIdx.x, red);
+}
+}  // namespace
+
+extern "C" int mmtg_colsum_batch(const mmtg_colsum_item* items, int n, void* stream) {
+    MMTG_REQUIRE(items && n >= 0, "colsum_batch: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    double elems = 0;
+    for (int i = 0; i < n; ++i) {
+        const mmtg_colsum_item& e = items[i];
+        MMTG_REQUIRE(e.X && e.out && e.M > 0 && e.M <= COLSUM_TALL && e.N > 0 && e.ldx >= e.N,
+                     "colsum_batch: item %d: fp32 rows [M <= %d, N], ldx >= N", i, COLSUM_TALL);
+        elems += (double)e.M * e.N;
+    }
+    if (!n) return MMTG_OK;
+    ProfScope prof(MMTG_PROF_MISC, s, elems, 4.0 * elems);
+    for (int i0 = 0; i0 < n; i0 += COLSUM_BATCH) {
+        ColsumBatch b;
+        const int m = min(COLSUM_BATCH, n - i0);
+        int maxn = 0;
+        for (int i = 0; i < COLSUM_BATCH; ++i) {
+            b.it[i] = items[i0 + (i < m ? i : 0)];
+            if (i < m) maxn = max(maxn, b.it[i].N);
+        }
+        hipLaunchKernelGGL(colsum_batch_kernel, dim3(cdiv(maxn, 64), m), dim3(1024), 0, s, b);
+    }
+    MMTG_LAUNCH_CHECK("colsum_batch");
+    return MMTG_OK;
+}
 extern "C" long mmtg_colsum_ws(int M, int N) { return M > COLSUM_TALL ? (long)COLSUM_SLICES * N : 0; }
 
 extern "C" int mmtg_colsum(int dtype, const void* X, long ldx, int M, int N, float* out, float* ws, long ws_floats, void* stream) {

@@ -222,6 +222,9 @@ _WGRAD_GROUP_SPLITS = int(_os.environ.get("MMTG_WGRAD_GROUP_SPLITS", "0"))    # 
 # per step, but the tiny, cancellation-dominated gradient of mm_atten_layer.att_matrices.3.weight moves from 1.05x to 1.18x of the
 # oracle's norm on the 2-layer golden model (every other tensor within 1 %): outside the parity suite's 10 % bound, so not the default
 _GELU_GRAD = _os.environ.get("MMTG_GELU_GRAD", "0") != "0"
+# the bf16 decoder backward's small ordered column sums (LayerNorm second stages, dGELU bands, attention bias rows: 4 per block) summed
+# by ONE batched launch per data-parallel hand-over point -- one per step without a bucket hook -- instead of a launch each (A/B switch)
+_DEFER_SUMS = _os.environ.get("MMTG_DEFER_SUMS", "1") != "0"
 _LMHEAD_GROUP = _os.environ.get("MMTG_LMHEAD_GROUP", "1") != "0"      # the tied embedding's weight gradient through the grouped kernel (A/B switch)
 _LMHEAD_GROUP_SPLITS = int(_os.environ.get("MMTG_LMHEAD_GROUP_SPLITS", "0"))
 # the grouped weight-gradient launches on a SIDE stream, one block behind the dgrad chain (MMTG_WGRAD_STREAM; see Engine.backward)
@@ -354,6 +357,7 @@ class Engine:
         self.opt_v = None
         self.normsq = torch.zeros(1, device=self.dev)
         self.bucket_hook = None   # callable(pack_index) fired as packs of gradients become final
+        self._sums, self._defer = [], False     # deferred column sums of the backward (see _defer_sum)
         self._pf_stream = None
         self._rowmaps = {}
 
@@ -1059,7 +1063,36 @@ class Engine:
 
     def _ready(self, pack):
         if self.bucket_hook is not None:
+            self._flush_sums()          # the gradients the hook may hand to the exchange must be final: pending column sums first
             self.bucket_hook(pack)
+
+    # ---- deferred column sums (mmtg_colsum_batch): the sources are per-site workspaces that nothing rewrites before the flush
+    def _defer_sum(self, X, ldx, M, N, out, offset=0):
+        """out[c] += sum_{r < M} X[offset + r * ldx + c], c < N, at the next flush (fp32 X, M <= 2048)."""
+        self._sums.append((X.data_ptr() + 4 * offset, out.data_ptr(), int(ldx), int(M), int(N)))
+
+    def _flush_sums(self):
+        if self._sums:
+            hip.colsum_batch(self._sums)
+            self._sums = []
+
+    def _ln_bwd(self, site, dy, x, gamma_key, mean, rstd, dres, dx, rows, cols, dx_masked=None, drop_p=0.0, drop_seed=0, colsum_key=None):
+        """LayerNorm backward of the bf16 decoder path: with deferred sums the first stage only, into this site's own partial-row
+        workspace, the three gradients it ends in queued for the batched sum; otherwise the one-call form on the shared workspace."""
+        g = gamma_key[:-len("weight")]
+        if self._defer:
+            ws = self.buf("ln_bwd_ws_" + site, (hip.lib().mmtg_layernorm_bwd_ws(rows, cols),), torch.float32)
+            nb = hip.layernorm_bwd_partial(dy, x, self.P(gamma_key), mean, rstd, dres, dx, rows, cols, ws, dx_masked=dx_masked,
+                                           drop_p=drop_p, drop_seed=drop_seed, want_colsum=colsum_key is not None)
+            self._defer_sum(ws, 3 * cols, nb, cols, self.G(gamma_key))
+            self._defer_sum(ws, 3 * cols, nb, cols, self.G(g + "bias"), offset=cols)
+            if colsum_key is not None:
+                self._defer_sum(ws, 3 * cols, nb, cols, self.G(colsum_key), offset=2 * cols)
+        else:
+            lnws = self.buf("ln_bwd_ws", (hip.lib().mmtg_layernorm_bwd_ws(rows, max(self.sh.D, self.sh.H)),), torch.float32)
+            hip.layernorm_bwd(dy, x, self.P(gamma_key), mean, rstd, dres, dx, self.G(gamma_key), self.G(g + "bias"), rows, cols,
+                              dx_masked=dx_masked, drop_p=drop_p, drop_seed=drop_seed,
+                              dcolsum=None if colsum_key is None else self.G(colsum_key), ws=lnws)
 
     @contextlib.contextmanager
     def _as_bf16(self):
@@ -1230,6 +1263,7 @@ class Engine:
         # dropout-masked gradient entering the previous residual branch and that branch's bias
         # gradient (column sum) -- see mmtg_layernorm_bwd.
         lnws = self.buf("ln_bwd_ws", (hip.lib().mmtg_layernorm_bwd_ws(M, max(D, H)),), torch.float32)
+        self._defer = _DEFER_SUMS and self.dtype == hip.BF16 and not x3
         dx = self.buf("d_resid_a", (M, D))
         dx2 = self.buf("d_resid_b", (M, D))
         # One grouped launch per block for its four weight gradients (mmtg_wgrad_group): the mlp.c_proj product's dy must then
@@ -1259,10 +1293,8 @@ class Engine:
                                  self.G(pre + "ln_f.weight"), self.G(pre + "ln_f.bias"), M, D, dyp,
                                  drop_p=pr, drop_seed=a["layers"][sh.L - 1][13][2], dcolsum=self.G(lastp + "mlp.c_proj.bias"), ws=lnws)
         else:
-            hip.layernorm_bwd(dhf, a["x_last"], self.P(pre + "ln_f.weight"), a["muf"], a["rsf"], None, dx,
-                              self.G(pre + "ln_f.weight"), self.G(pre + "ln_f.bias"), M, D,
-                              dx_masked=dmask_top, drop_p=pr, drop_seed=a["layers"][sh.L - 1][13][2],
-                              dcolsum=self.G(lastp + "mlp.c_proj.bias"), ws=lnws)
+            self._ln_bwd("f", dhf, a["x_last"], pre + "ln_f.weight", a["muf"], a["rsf"], None, dx, M, D,
+                         dx_masked=dmask_top, drop_p=pr, drop_seed=a["layers"][sh.L - 1][13][2], colsum_key=lastp + "mlp.c_proj.bias")
         self._ready("ln_f.b")
         du = None if x3 else self.buf("d_u", (M, 4 * D))
         dm = self.buf("d_m", (M, D))
@@ -1327,11 +1359,14 @@ class Engine:
             dy = dmask if pr > 0 else dx
             # (the dGELU epilogue also emits the column sums of du per 64-row band: a [M/64, 4D] reduction
             #  gives the c_fc bias gradient instead of a pass over du)
-            bands = self.buf("d_u_bands", ((M + 63) // 64, 4 * D), torch.float32)
+            bands = self.buf("d_u_bands_%d" % l if self._defer else "d_u_bands", ((M + 63) // 64, 4 * D), torch.float32)
             self._prefetch(m2, gact)            # while dGELU runs: the operands of the two weight gradients after it
             self._dgrad(dy, p + "mlp.c_proj.weight", du, M, "conv1d", epi=hip.EPI_DGELU, aux=u, ldaux=4 * D, aux2=bands,
                         flags=hip.GEMM_GELU_GRAD if a["gelu_grad"] else 0)
-            hip.colsum(bands, bands.shape[0], 4 * D, self.G(p + "mlp.c_fc.bias"))
+            if self._defer and bands.shape[0] <= 2048:
+                self._defer_sum(bands, 4 * D, bands.shape[0], 4 * D, self.G(p + "mlp.c_fc.bias"))
+            else:
+                hip.colsum(bands, bands.shape[0], 4 * D, self.G(p + "mlp.c_fc.bias"))
             # (both consumers of du run while it is still in the Infinity Cache; the c_proj weight gradient, whose
             #  operands come from HBM either way, goes last -- it must precede the LayerNorm backward, which reuses dmask)
             self._dgrad(du, p + "mlp.c_fc.weight", dm, M, "conv1d")
@@ -1340,10 +1375,8 @@ class Engine:
                 self._wgrad(m2, du, p + "mlp.c_fc.weight", None, M, "conv1d")
                 self._prefetch(xmid, ctx)           # while the c_proj weight gradient runs: LayerNorm input, attention context
                 self._wgrad(gact, dy, p + "mlp.c_proj.weight", None, M, "conv1d")
-            hip.layernorm_bwd(dm, xmid, self.P(p + "ln_2.weight"), mu2, rs2, dx, dx2,
-                              self.G(p + "ln_2.weight"), self.G(p + "ln_2.bias"), M, D,
-                              dx_masked=dmask_b, drop_p=pr, drop_seed=s[1],
-                              dcolsum=self.G(p + "attn.c_proj.bias"), ws=lnws)
+            self._ln_bwd("%d_2" % l, dm, xmid, p + "ln_2.weight", mu2, rs2, dx, dx2, M, D,
+                         dx_masked=dmask_b, drop_p=pr, drop_seed=s[1], colsum_key=p + "attn.c_proj.bias")
             # x_mid = x_in + drop(ctx Wp + bp)
             dy = dmask_b if pr > 0 else dx2
             # bf16: the dgrad GEMM's epilogue also emits delta = rowsum(d ctx * ctx) per head
@@ -1360,10 +1393,16 @@ class Engine:
             # (exact-fp32 mode: the tiled kernel combines its waves' bias sums with LDS atomics -- arrival order -- so the c_attn bias
             #  gradient is an ordered column sum over d(qkv) there instead: one more pass in the cross-check mode, reproducible bits)
             exact = self.dtype == hip.F32 and not self.x3 and _WGRAD_SLAB
+            # (deferred sums: the whole-head kernels leave their B partial bias rows in this block's own scratch for the batched sum)
+            brows = hip.attn_bwd_dbias_rows(self.dtype, B, T) if self._defer else 0
+            brows = brows if 0 < brows <= 2048 else 0
+            bws = None if exact else self.buf("attn_dbias_rows_%d" % l if brows else "attn_dbias_rows",
+                                               (hip.attn_bwd_bias_rows(B, T, self.dtype), 3 * D), torch.float32)
             hip.attn_bwd(qkv, a["keep"], ctx, dctx, lse, delta, dq32, dqkv, B, T, sh.nH, D // sh.nH,
                          drop_p=pa, drop_seed=s[0], delta_ready=fuse_delta, dbias=None if exact else self.G(p + "attn.c_attn.bias"),
-                         flags=hip.ATTN_ELEM_MASK if a.get("elem_mask") else 0,
-                         dbias_ws=None if exact else self.buf("attn_dbias_rows", (hip.attn_bwd_bias_rows(B, T, self.dtype), 3 * D), torch.float32))
+                         flags=(hip.ATTN_ELEM_MASK if a.get("elem_mask") else 0) | (hip.ATTN_DBIAS_ROWS if brows else 0), dbias_ws=bws)
+            if brows:
+                self._defer_sum(bws, 3 * D, brows, 3 * D, self.G(p + "attn.c_attn.bias"))
             if exact:
                 hip.colsum(dqkv, M, 3 * D, self.G(p + "attn.c_attn.bias"))
             self._prefetch(a1, xin)             # while the c_attn dgrad runs: its weight gradient's operand, LayerNorm input
@@ -1394,13 +1433,11 @@ class Engine:
                 torch.cuda.current_stream().wait_event(wdone.pop(l + 1))
                 self._ready(f"{pre}h.{l + 1}.ln_1.bias")
             if l > 0:
-                hip.layernorm_bwd(da, xin, self.P(p + "ln_1.weight"), mu1, rs1, dx2, dx,
-                                  self.G(p + "ln_1.weight"), self.G(p + "ln_1.bias"), M, D,
-                                  dx_masked=(sets[(l - 1) & 1][1] if stream_mode else dmask), drop_p=pr, drop_seed=a["layers"][l - 1][13][2],
-                                  dcolsum=self.G(f"{pre}h.{l - 1}.mlp.c_proj.bias"), ws=lnws)
+                self._ln_bwd("%d_1" % l, da, xin, p + "ln_1.weight", mu1, rs1, dx2, dx, M, D,
+                             dx_masked=(sets[(l - 1) & 1][1] if stream_mode else dmask), drop_p=pr, drop_seed=a["layers"][l - 1][13][2],
+                             colsum_key=f"{pre}h.{l - 1}.mlp.c_proj.bias")
             else:
-                hip.layernorm_bwd(da, xin, self.P(p + "ln_1.weight"), mu1, rs1, dx2, dx,
-                                  self.G(p + "ln_1.weight"), self.G(p + "ln_1.bias"), M, D, ws=lnws)
+                self._ln_bwd("0_1", da, xin, p + "ln_1.weight", mu1, rs1, dx2, dx, M, D)
             if not stream_mode:
                 self._ready(p + "ln_1.bias")
         if stream_mode:
@@ -1409,6 +1446,10 @@ class Engine:
                 self._ready(f"{pre}h.{l_}.ln_1.bias")
         elif _WGRAD_STREAM and pr > 0 and getattr(self, "_side", None) is not None:
             torch.cuda.current_stream().wait_stream(self._side)  # (only the tied embedding's gradient ran on the side stream)
+        # (deferred column sums: everything the blocks queued since the last hand-over point -- the whole decoder's without a bucket hook --
+        #  in one launch, here, with the embedding / projector / encoder backward still to come behind it)
+        self._flush_sums()
+        self._defer = False
         # ---- GPT-2 input embedding: h0 = drop(g + wpe + wte[type])
         nty = min(32, sh.V)
         hip.embed_add_bwd(dx, a["type_ids"], self.G(pre + "wpe.weight"), self.G(pre + "wte.weight"), M, T, D,

@@ -13,7 +13,7 @@ import os
 import torch
 
 F32, BF16 = 0, 1
-ABI_VERSION = 11
+ABI_VERSION = 12
 EPI_NONE, EPI_GELU, EPI_TANH, EPI_RESID, EPI_DGELU, EPI_DTANH, EPI_ATOMIC, EPI_ROWDOT = range(8)
 GEMM_NO_TR, GEMM_REGSTAGE, GEMM_SKINNY, GEMM_NO_SKINNY, GEMM_WIDE, GEMM_NO_WIDE = 1, 2, 4, 8, 16, 32
 GEMM_PERSIST, GEMM_NO_PERSIST, GEMM_ROW_ORDER, GEMM_OCC4, GEMM_NO_OCC4, GEMM_COL_BLOCK, GEMM_P256, GEMM_NO_P8, GEMM_P8 = 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384
@@ -106,6 +106,9 @@ _SIGS = {
     "mmtg_decode_mlp_sync_words": ([], _i),
     "mmtg_decode_mlp_census": ([_vp, _vp], _i),
     "mmtg_decode_mlp": ([_i, _i, _vp, _l, _vp, _i, _f, _vp, _l, _vp, _vp, _vp, _l, _vp, _vp, _l, _vp, _l, _vp, _vp, _l, _vp, _i, _vp, _vp], _i),
+    "mmtg_colsum_batch": ([_vp, _i, _vp], _i),
+    "mmtg_layernorm_bwd_partial": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _u, _u, _i, _vp, _l, _vp, _vp], _i),
+    "mmtg_attn_bwd_dbias_rows": ([_i, _i, _i], _i),
     "mmtg_comm_unique_id": ([_vp], _i),
     "mmtg_comm_init": ([_i, _i, _vp], _i),
     "mmtg_comm_info": ([_vp, _vp, _vp, _vp], _i),
@@ -376,6 +379,28 @@ def colsum(X, M, N, out, ldx=None, ws=None):
     _check(lib().mmtg_colsum(dt(X), _p(X), N if ldx is None else ldx, M, N, _p(out), _p(ws) if need else 0, need, _stream()), "colsum")
 
 
+class ColsumItem(C.Structure):
+    """mmtg_colsum_item of include/mmtg_hip.h."""
+    _fields_ = [("X", C.c_void_p), ("out", C.c_void_p), ("ldx", C.c_long), ("M", C.c_int), ("N", C.c_int)]
+
+
+_colsum_batch_cache = {}
+
+
+def colsum_batch(items):
+    """items: list of (X data_ptr, out data_ptr, ldx, M, N) -- fp32 rows, M <= 2048: out[c] += sum_r X[r * ldx + c] for every item in ONE
+    launch (64 items per launch), each in mmtg_colsum's order.  The ctypes array is cached per item list (a step repeats its list)."""
+    if not items:
+        return
+    key = tuple(items)
+    arr = _colsum_batch_cache.get(key)
+    if arr is None:
+        if len(_colsum_batch_cache) > 64:
+            _colsum_batch_cache.clear()
+        arr = _colsum_batch_cache[key] = (ColsumItem * len(items))(*[ColsumItem(*it) for it in items])
+    _check(lib().mmtg_colsum_batch(C.addressof(arr), len(items), _stream()), "colsum_batch")
+
+
 # ------------------------------------------------------------------ LayerNorm
 def layernorm_fwd(x, y, gamma, beta, mean, rstd, rows, cols, eps=1e-5):
     _check(lib().mmtg_layernorm_fwd(dt(x), _p(x), _p(y), _p(gamma), _p(beta), _p(mean), _p(rstd), rows, cols,
@@ -396,6 +421,15 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, cols,
     _check(lib().mmtg_layernorm_bwd(dt(x), _p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx),
                                     _p(dgamma), _p(dbeta), rows, cols, _p(dx_masked), drop_thresh(drop_p),
                                     drop_seed & 0xFFFFFFFF, _p(dcolsum), _p(ws), ws.numel(), _stream()), "layernorm_bwd")
+
+
+def layernorm_bwd_partial(dy, x, gamma, mean, rstd, dres, dx, rows, cols, ws, dx_masked=None, drop_p=0.0, drop_seed=0, want_colsum=False):
+    """First stage of layernorm_bwd only; returns the number of partial rows left in ws ([rows][3][cols]) for colsum_batch."""
+    n = C.c_int(0)
+    _check(lib().mmtg_layernorm_bwd_partial(dt(x), _p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx), rows, cols,
+                                            _p(dx_masked), drop_thresh(drop_p), drop_seed & 0xFFFFFFFF, int(want_colsum),
+                                            _p(ws), ws.numel(), C.addressof(n), _stream()), "layernorm_bwd_partial")
+    return n.value
 
 
 def layernorm_bwd_x3(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, cols, dx_planes, drop_p=0.0, drop_seed=0, dcolsum=None, ws=None):
@@ -457,6 +491,14 @@ def attn_bwd(qkv, keep, out, dout, lse, delta, dq32, dqkv, B, T, nH, dh, drop_p=
 
 def attn_trace(buf):
     _check(lib().mmtg_attn_trace(_p(buf)), "attn_trace")
+
+
+ATTN_DBIAS_ROWS = 2
+
+
+def attn_bwd_dbias_rows(dtype_code, B, T):
+    """Partial bias rows attn_bwd(flags=ATTN_DBIAS_ROWS) leaves unsummed at the head of dbias_ws for this shape (0: it sums inside the call)."""
+    return int(lib().mmtg_attn_bwd_dbias_rows(dtype_code, B, T))
 
 
 def attn_bwd_bias_rows(B, T, dtype_code):

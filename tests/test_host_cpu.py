@@ -185,7 +185,7 @@ def test_c_abi_exports_every_declared_symbol():
     lib = ctypes.CDLL(hip.lib_path())
     for name in declared:
         assert hasattr(lib, name), name
-    assert hip.lib().mmtg_abi_version() == hip.ABI_VERSION == 11
+    assert hip.lib().mmtg_abi_version() == hip.ABI_VERSION == 12
     # ... and nothing else: the library is built with -fvisibility=hidden + a linker version script, so no internal C++
     # helper (mmtg_set_error, ProfScope, template instantiations, hipcc's __hip_cuid_*) leaks into the dynamic symbol table
     import subprocess
@@ -204,6 +204,11 @@ def test_host_side_of_the_round4_abi_without_a_gpu():
     assert 0 < L.mmtg_sumsq_ws(109064709) <= 4096
     # the error contract without a GPU: argument checks run on the host before any launch
     assert L.mmtg_build_flags() == b""                                    # the product build carries no diagnostic defines
+    # the batched column sums validate their host-side item list before any launch (round 6)
+    it = (hip.ColsumItem * 1)(hip.ColsumItem(0x7000000000, 0x7100000000, 64, 4096, 64))
+    assert L.mmtg_colsum_batch(ctypes.addressof(it), 1, None) != 0 and b"colsum_batch: item 0" in L.mmtg_last_error()      # > 2048 rows
+    assert L.mmtg_colsum_batch(ctypes.addressof(it), 0, None) == 0                                                        # nothing to do
+    assert L.mmtg_attn_bwd_dbias_rows(hip.BF16, 64, 236) == 64 and L.mmtg_attn_bwd_dbias_rows(hip.F32, 64, 236) == 0
     bad = L.mmtg_split_planes(0x7000000000, 8, 4, 12, 0x7100000000, 16, 64, None)
     assert bad != 0 and b"split_planes" in L.mmtg_last_error()           # cols % 8 != 0
 

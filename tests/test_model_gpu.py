@@ -1055,6 +1055,43 @@ def test_training_step_is_bit_reproducible(dtype):
     assert torch.equal(params[0], params[1]), int((params[0] != params[1]).sum())
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "bf16x3f"])
+def test_batched_column_sums_leave_the_gradient_bits_unchanged(dtype, monkeypatch):
+    """Round 6: the bf16 decoder backward queues its small ordered column sums (two LayerNorm second stages, the dGELU bands and the
+    attention bias rows of every block) and sums them in ONE mmtg_colsum_batch launch -- or one per data-parallel hand-over point
+    when a bucket hook is installed (the gradients the hook sees must be final).  Same sums, same order: the gradient buffer and the
+    parameters after two steps equal the launch-per-sum form's bit for bit, in all three forms; the batched forms launch fewer kernels."""
+    from ddp_worker import build as build_small
+    from mmtg_amd import engine as E, hip as H, synth
+    results = {}
+    for form in ("each", "batched", "hooked"):
+        monkeypatch.setattr(E, "_DEFER_SUMS", form != "each")
+        model, mcfg, dcfg, V = build_small(dtype, 0.1, torch.device("cuda", 0))
+        tr = MMTGTrainer(model, lr=1e-3, alpha=0.2)
+        tr.eng.drop_seed = 4242
+        seen = []
+        if form == "hooked":
+            tr.eng.bucket_hook = lambda pack: seen.append((pack, len(tr.eng._sums)))
+        nb = synth.make_batch(12, mcfg, dcfg, V, seed=7)
+        batch = {k: torch.from_numpy(np.asarray(v)).to(DEV) for k, v in nb.items()}
+        tr.step(batch, stage=1)
+        g = tr.eng.grad.detach().clone()
+        H.prof_enable(True)
+        H.prof_read()
+        tr.step(batch, stage=3)
+        torch.cuda.synchronize()
+        launches = sum(v["launches"] for v in H.prof_read().values())
+        H.prof_enable(False)
+        results[form] = (g, model.engine().master.detach().clone(), launches)
+        assert tr.eng._sums == [] and tr.eng._defer is False
+        if form == "hooked":
+            assert len(seen) > 3 and all(n == 0 for _, n in seen)        # nothing pending whenever the hook runs
+    for form in ("batched", "hooked"):
+        assert torch.equal(results["each"][0], results[form][0]), form
+        assert torch.equal(results["each"][1], results[form][1]), form
+    assert results["batched"][2] < results["hooked"][2] < results["each"][2], [r[2] for r in results.values()]
+
+
 def test_bf16x3_training_step_with_dropout_matches_the_f32_mode():
     """Training mode (dropout 0.1 at GPT-2's three sites) in the split-precision mode against the exact-fp32 mode: both modes draw the
     SAME counter-hash masks from the same seeds (the x3 products' residual epilogues, the x3 attention kernels and the plane-writing

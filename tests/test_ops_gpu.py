@@ -541,6 +541,80 @@ def test_layernorm(dtype, cols, rows):
     close(dcs, dx.float().sum(0), torch.float32, rows, "ln colsum without mask")
 
 
+def test_batched_column_sums_equal_the_one_call_forms_bit_for_bit():
+    """Round 6: mmtg_colsum_batch sums many small fp32 row sets in ONE launch, each in mmtg_colsum's order -- so (a) a batch of plain
+    items equals mmtg_colsum per item, (b) mmtg_layernorm_bwd_partial + the batch equals mmtg_layernorm_bwd (d gamma, d beta, the fused
+    column sum of the masked d(x); same d(x) and masked copy), (c) mmtg_attn_bwd with MMTG_ATTN_DBIAS_ROWS + the batch equals the call
+    that sums its bias rows itself -- bit for bit, the accumulate (+=) semantics included; more than 64 items take several launches."""
+    # (a) 70 items of mixed shapes, one of them a strided view
+    items, want = [], []
+    keep_alive = []
+    for i in range(70):
+        M, N = [(236, 3072), (64, 2304), (756, 768), (5, 8), (2048, 64), (33, 100)][i % 6]
+        ldx = N + (8 if i % 3 == 0 else 0)
+        X = rnd(M, ldx, seed=100 + i).to(DEV)
+        out = torch.full((N,), float(i), device=DEV)
+        ref = torch.full((N,), float(i), device=DEV)
+        hip.colsum(X, M, N, ref, ldx=ldx)
+        items.append((X.data_ptr(), out.data_ptr(), ldx, M, N))
+        keep_alive.append((X, out))
+        want.append(ref)
+    hip.colsum_batch(items)
+    for (X, out), ref in zip(keep_alive, want):
+        assert torch.equal(out, ref)
+    with pytest.raises(RuntimeError, match="colsum_batch"):
+        hip.colsum_batch([(keep_alive[0][0].data_ptr(), keep_alive[0][1].data_ptr(), 3072, 4096, 3072)])     # > 2048 rows
+    # (b) LayerNorm backward, bf16 rows at the training shape's width, dropout tail on
+    rows, cols = 5001, 768
+    x = rnd(rows, cols, dtype=torch.bfloat16, seed=1, scale=2.0).to(DEV)
+    dy = rnd(rows, cols, dtype=torch.bfloat16, seed=4).to(DEV)
+    dres = rnd(rows, cols, dtype=torch.bfloat16, seed=5).to(DEV)
+    g = (1 + 0.1 * rnd(cols, seed=2)).to(DEV)
+    b = (0.1 * rnd(cols, seed=3)).to(DEV)
+    y, mean, rstd = torch.empty_like(x), torch.empty(rows, device=DEV), torch.empty(rows, device=DEV)
+    hip.layernorm_fwd(x, y, g, b, mean, rstd, rows, cols)
+    res = []
+    for partial in (False, True):
+        dx, dxm = torch.empty_like(x), torch.empty_like(x)
+        dg, db, dcs = (torch.full((cols,), v, device=DEV) for v in (1.0, -1.0, 2.0))
+        if partial:
+            ws = torch.full((int(hip.lib().mmtg_layernorm_bwd_ws(rows, cols)),), float("nan"), device=DEV)
+            nb = hip.layernorm_bwd_partial(dy, x, g, mean, rstd, dres, dx, rows, cols, ws, dx_masked=dxm, drop_p=0.2, drop_seed=99,
+                                           want_colsum=True)
+            assert 0 < nb <= 1024
+            hip.colsum_batch([(ws.data_ptr() + 4 * q * cols, t.data_ptr(), 3 * cols, nb, cols) for q, t in enumerate((dg, db, dcs))])
+        else:
+            hip.layernorm_bwd(dy, x, g, mean, rstd, dres, dx, dg, db, rows, cols, dx_masked=dxm, drop_p=0.2, drop_seed=99, dcolsum=dcs)
+        res.append((dx, dxm, dg, db, dcs))
+    for u, v in zip(*res):
+        assert torch.equal(u, v)
+    assert float((res[0][2] - 1.0).abs().max()) > 0
+    # (c) whole-head attention backward
+    B, T, nH, dh = 4, 236, 3, 64
+    D = nH * dh
+    qkv = rnd(B, T, 3 * D, dtype=torch.bfloat16, seed=7).to(DEV)
+    keep = torch.ones(B, T, dtype=torch.int32, device=DEV)
+    dout = rnd(B, T, D, dtype=torch.bfloat16, seed=8).to(DEV)
+    out, lse = torch.empty(B, T, D, device=DEV, dtype=torch.bfloat16), torch.empty(B, nH, T, device=DEV)
+    hip.attn_fwd(qkv, keep, out, lse, B, T, nH, dh)
+    assert hip.attn_bwd_dbias_rows(hip.BF16, B, T) == B and hip.attn_bwd_dbias_rows(hip.F32, B, T) == 0
+    assert hip.attn_bwd_dbias_rows(hip.BF16, B, 1024) == 0           # the tiled kernels reduce inside the call
+    got = []
+    for defer in (False, True):
+        delta, dq32 = torch.empty(B * T, nH, device=DEV), torch.empty(B * T, D, device=DEV)
+        dqkv = torch.empty(B, T, 3 * D, device=DEV, dtype=torch.bfloat16)
+        dbias = torch.full((3 * D,), 0.5, device=DEV)
+        rws = torch.full((hip.attn_bwd_bias_rows(B, T, hip.BF16), 3 * D), float("nan"), device=DEV)
+        hip.attn_bwd(qkv, keep, out, dout, lse, delta, dq32, dqkv, B, T, nH, dh, dbias=dbias, dbias_ws=rws,
+                     flags=hip.ATTN_DBIAS_ROWS if defer else 0)
+        if defer:
+            assert torch.equal(dbias, torch.full_like(dbias, 0.5))       # nothing summed yet
+            hip.colsum_batch([(rws.data_ptr(), dbias.data_ptr(), 3 * D, B, 3 * D)])
+        got.append((dqkv, dbias))
+    assert torch.equal(got[0][0], got[1][0]) and torch.equal(got[0][1], got[1][1])
+    assert float((got[0][1] - 0.5).abs().max()) > 0
+
+
 # ------------------------------------------------------------------ attention
 def ref_attention(qkv, keep, nH):
     B, T, D3 = qkv.shape

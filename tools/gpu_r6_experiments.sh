@@ -260,5 +260,23 @@ print("pairs", n, "overlapping", ov)
 PY
 rm -rf $E/trace
 ;;
-*) echo "usage: $0 {a|c|d|e|f|g|h|i|j|k|l|m|n|o|p|q}"; exit 2 ;;
+r)
+# the decoder backward's small column sums batched into one launch (MMTG_DEFER_SUMS): op + model tests, then the step A/B
+mkdir -p gpurun_out/r6r2
+E=gpurun_out/r6r2
+timeout 900 python -m pytest tests/test_ops_gpu.py tests/test_model_gpu.py -m gpu -q --no-header -p no:cacheprovider -x -k "batched_column or layernorm or attention or reproducible or bf16_vs_oracle or full_12l" 2>&1 | tail -4 | tee $E/pytest_defer.txt
+for rep in 1 2 3; do
+for ds in 0 1; do
+  MMTG_DEFER_SUMS=$ds timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --primary-only --no-roofline 2>/dev/null | python -c "
+import sys, json
+for ln in sys.stdin:
+    try: d = json.loads(ln)
+    except Exception: continue
+    print('DEFER_SUMS=$ds', d['value'], 'tok/s', d['ms_per_step'], 'ms/step', d['check'].get('launches_per_step'), 'launches/step')
+" | tee -a $E/defer_sums_ab.txt
+done
+done
+for ds in 0 1; do MMTG_DEFER_SUMS=$ds timeout 300 python tools/bench_x3.py bf16x3f 64 10 2>&1 | grep -v amdgpu.ids | head -2 | sed "s/^/DEFER_SUMS=$ds /" | tee -a $E/defer_sums_ab.txt; done
+;;
+*) echo "usage: $0 {a|c|d|e|f|g|h|i|j|k|l|m|n|o|p|q|r}"; exit 2 ;;
 esac
