@@ -216,6 +216,11 @@ MMTG_API int mmtg_layernorm_bwd_x3(const float* dy, const float* x, const float*
                           const float* dres, float* dx, float* dgamma, float* dbeta, int rows, int cols,
                           void* dx_planes, long plane, unsigned drop_thresh, unsigned drop_seed, float* dcolsum,
                           float* ws, long ws_floats, void* stream);
+/* ... and its first stage alone (as mmtg_layernorm_bwd_partial): the partial rows stay in ws for mmtg_colsum_batch */
+MMTG_API int mmtg_layernorm_bwd_x3_partial(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                          const float* dres, float* dx, int rows, int cols, void* dx_planes, long plane,
+                          unsigned drop_thresh, unsigned drop_seed, int want_colsum,
+                          float* ws, long ws_floats, int* partial_rows, void* stream);
 
 /* ---------------------------------------------------------------- causal self-attention
  * GPT2Attention._attn: softmax(QK^T/sqrt(dh) + causal + key padding) V with
@@ -234,7 +239,9 @@ MMTG_API int mmtg_attn_fwd(int dtype, const void* qkv, const int* keep, void* ou
  * scratch of dq32_floats >= ceil(T/128) * B*T * D floats (one [B*T, D] buffer per block of 128 keys: plain stores, summed in block
  * order by the finish kernel -- no atomics, bit-reproducible); delta: [B*T, nH] scratch; dbias
  * (nullable): [3D] += column sums of d(qkv), through dbias_ws (>= (B * ceil(T/128) + ceil(B*T/16)) * 3D floats); delta_ready != 0:
- * delta[m, h] = sum_d dout * out was filled by the caller (mmtg_gemm_x3's MMTG_EPI_ROWDOT epilogue does it for free).           */
+ * delta[m, h] = sum_d dout * out was filled by the caller (mmtg_gemm_x3's MMTG_EPI_ROWDOT epilogue does it for free).
+ * Round 6: dbias == NULL with dbias_ws non-null leaves the partial bias rows UNSUMMED at the head of dbias_ws -- [B * ceil(T/128)][3D]
+ * (k and v parts; the q part zero), then [ceil(B*T/16)][D] (the q part) -- for the caller's mmtg_colsum_batch.                     */
 MMTG_API int mmtg_attn_fwd_x3(const void* qkv_planes, long qplane, const int* keep, float* out, void* out_planes, long plane, float* lse,
                      int B, int T, int nH, int dh, unsigned drop_thresh, unsigned drop_seed, void* stream);
 MMTG_API int mmtg_attn_bwd_x3(const void* qkv_planes, long qplane, const int* keep, const float* out, const void* dout_planes, long doplane,

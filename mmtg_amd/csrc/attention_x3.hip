@@ -534,6 +534,10 @@ extern "C" int mmtg_attn_bwd_x3(const void* qkv_planes, long qplane, const int* 
     const long ws_rows = ((long)B * nkb + nband) * 3 * D, ws_kv = mmtg_colsum_ws(B * nkb, 3 * D), ws_q = mmtg_colsum_ws(nband, D);
     MMTG_REQUIRE(!dbias || (dbias_ws && dbias_ws_floats >= ws_rows + ws_kv + ws_q), "attn_bwd_x3: the bias gradient needs %ld workspace floats",
                  ws_rows + ws_kv + ws_q);
+    // dbias == NULL with a workspace (round 6): the partial bias rows only -- kv rows [B * nkb][3D] then q rows [nband][D] at the head of
+    // dbias_ws -- for the caller's mmtg_colsum_batch (both <= 2048 rows there) instead of the two ordered sums of this call
+    const bool rows_only = !dbias && dbias_ws;
+    MMTG_REQUIRE(!rows_only || dbias_ws_floats >= ws_rows, "attn_bwd_x3: the partial bias rows need %ld workspace floats", ws_rows);
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(MMTG_PROF_ATTN_BWD, s, 5.0 * B * nH * (double)T * T * dh, 4.0 * 8.0 * B * T * nH * dh);
     static bool attr_set = false;
@@ -544,8 +548,8 @@ extern "C" int mmtg_attn_bwd_x3(const void* qkv_planes, long qplane, const int* 
     }
     if (!delta_ready)
         hipLaunchKernelGGL(attn_delta_x3_kernel, dim3(cdiv(rows * nH, 4)), dim3(256), 0, s, out, (const bf16*)dout_planes, doplane, delta, nH, rows);
-    float* const kv_rows = dbias ? dbias_ws : nullptr;                       // [B * nkb][3D]: k and v parts (q part zero)
-    float* const q_rows = dbias ? dbias_ws + (long)B * nkb * 3 * D : nullptr; // [nband][D]
+    float* const kv_rows = (dbias || rows_only) ? dbias_ws : nullptr;                       // [B * nkb][3D]: k and v parts (q part zero)
+    float* const q_rows = (dbias || rows_only) ? dbias_ws + (long)B * nkb * 3 * D : nullptr; // [nband][D]
     hipLaunchKernelGGL(attn_bwd_x3_kernel, dim3(nkb, nH, B), dim3(64 * XNW), BwdLds::END, s, (const bf16*)qkv_planes, qplane, keep, (const bf16*)dout_planes, doplane, lse, delta, dq32, rows * D, (bf16*)dqkv_planes, dplane,
                        kv_rows, T, nH, drop_thresh, drop_seed, inv_keep_x3(drop_thresh));
     hipLaunchKernelGGL(attn_dq_finish_x3_kernel, dim3(nband), dim3(256), 0, s, dq32, rows * D, T, (bf16*)dqkv_planes, dplane, q_rows, rows, D);

@@ -907,12 +907,12 @@ extern "C" int mmtg_layernorm_bwd_partial(int dtype, const void* dy, const void*
 
 /* x3 mode (fp32 rows): mmtg_layernorm_bwd whose (dropout-masked) input gradient ALSO / INSTEAD goes to a (hi | lo) bf16 plane pair
  * [rows, cols] (lo plane `plane` elements behind) -- the operand of the block's split-precision dgrad / weight-gradient products. */
-extern "C" int mmtg_layernorm_bwd_x3(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
-                                     const float* dres, float* dx, float* dgamma, float* dbeta, int rows, int cols,
-                                     void* dx_planes, long plane, unsigned drop_thresh, unsigned drop_seed, float* dcolsum,
-                                     float* ws, long ws_floats, void* stream) {
+static int ln_bwd_x3_impl(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                          const float* dres, float* dx, float* dgamma, float* dbeta, int rows, int cols,
+                          void* dx_planes, long plane, unsigned drop_thresh, unsigned drop_seed, float* dcolsum, int want_colsum,
+                          float* ws, long ws_floats, bool finalize, int* partial_rows, void* stream) {
     MMTG_REQUIRE(rows > 0 && cols > 0 && cols % 8 == 0 && cols <= 1024, "layernorm_bwd_x3: cols=%d must be a multiple of 8 and <= 1024", cols);
-    MMTG_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && dx_planes, "layernorm_bwd_x3: null pointer");
+    MMTG_REQUIRE(dy && x && gamma && mean && rstd && dx && (!finalize || (dgamma && dbeta)) && dx_planes, "layernorm_bwd_x3: null pointer");
     MMTG_REQUIRE(ws && ws_floats >= mmtg_layernorm_bwd_ws(rows, cols), "layernorm_bwd_x3: workspace of %ld floats required", mmtg_layernorm_bwd_ws(rows, cols));
     MMTG_REQUIRE(MMTG_ALIGNED16(dy) && MMTG_ALIGNED16(x) && MMTG_ALIGNED16(dx) && (!dres || MMTG_ALIGNED16(dres)) && MMTG_ALIGNED16(gamma) &&
                  MMTG_ALIGNED16(dx_planes) && plane % 8 == 0 && plane >= (long)rows * cols, "layernorm_bwd_x3: alignment / plane layout");
@@ -920,7 +920,7 @@ extern "C" int mmtg_layernorm_bwd_x3(const float* dy, const float* x, const floa
     ProfScope prof(MMTG_PROF_LAYERNORM, s, 16.0 * rows * cols, ((dres ? 4.0 : 3.0) + 1.0) * 4.0 * rows * cols);
     int nb = ln_bwd_blocks(rows);
     const float ik = drop_thresh ? (float)(4294967296.0 / (4294967296.0 - (double)drop_thresh)) : 1.0f;
-    const int want = dcolsum != nullptr;
+    const int want = finalize ? dcolsum != nullptr : want_colsum != 0;
     static int cap = 0;
     if (!cap) {
         int dev = 0, cus = 0;
@@ -936,9 +936,28 @@ extern "C" int mmtg_layernorm_bwd_x3(const float* dy, const float* x, const floa
                                     want, drop_thresh, drop_seed, ik, (bf16*)dx_planes, plane)
     if (nc <= 4) LN2X(4); else if (nc <= 6) LN2X(6); else LN2X(8);
 #undef LN2X
-    hipLaunchKernelGGL(ln_bwd_finalize_det_kernel, dim3(cdiv(cols, 64), 3), dim3(1024), 0, s, ws, nb, cols, dgamma, dbeta, dcolsum);
+    if (partial_rows) *partial_rows = nb;
+    if (finalize) hipLaunchKernelGGL(ln_bwd_finalize_det_kernel, dim3(cdiv(cols, 64), 3), dim3(1024), 0, s, ws, nb, cols, dgamma, dbeta, dcolsum);
     MMTG_LAUNCH_CHECK("layernorm_bwd_x3");
     return MMTG_OK;
+}
+
+extern "C" int mmtg_layernorm_bwd_x3(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                                     const float* dres, float* dx, float* dgamma, float* dbeta, int rows, int cols,
+                                     void* dx_planes, long plane, unsigned drop_thresh, unsigned drop_seed, float* dcolsum,
+                                     float* ws, long ws_floats, void* stream) {
+    return ln_bwd_x3_impl(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, cols, dx_planes, plane, drop_thresh, drop_seed, dcolsum, 0,
+                          ws, ws_floats, true, nullptr, stream);
+}
+
+/* mmtg_layernorm_bwd_partial for the x3 form: the first stage only, the partial rows ws[k][q][cols] left for mmtg_colsum_batch */
+extern "C" int mmtg_layernorm_bwd_x3_partial(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                                             const float* dres, float* dx, int rows, int cols, void* dx_planes, long plane,
+                                             unsigned drop_thresh, unsigned drop_seed, int want_colsum,
+                                             float* ws, long ws_floats, int* partial_rows, void* stream) {
+    MMTG_REQUIRE(partial_rows, "layernorm_bwd_x3_partial: null pointer");
+    return ln_bwd_x3_impl(dy, x, gamma, mean, rstd, dres, dx, nullptr, nullptr, rows, cols, dx_planes, plane, drop_thresh, drop_seed, nullptr,
+                          want_colsum, ws, ws_floats, false, partial_rows, stream);
 }
 
 // rows above which the sum runs in two stages (slices -> workspace -> ordered sum of the slices)

@@ -1076,6 +1076,22 @@ class Engine:
             hip.colsum_batch(self._sums)
             self._sums = []
 
+    def _ln_bwd_x3(self, site, dy, x, gamma_key, mean, rstd, dres, dx, rows, cols, dx_planes, drop_p=0.0, drop_seed=0, colsum_key=None):
+        """_ln_bwd for the split-precision path (fp32 rows, the masked gradient written as a plane pair)."""
+        g = gamma_key[:-len("weight")]
+        if self._defer:
+            ws = self.buf("ln_bwd_ws_" + site, (hip.lib().mmtg_layernorm_bwd_ws(rows, cols),), torch.float32)
+            nb = hip.layernorm_bwd_x3_partial(dy, x, self.P(gamma_key), mean, rstd, dres, dx, rows, cols, dx_planes, ws,
+                                              drop_p=drop_p, drop_seed=drop_seed, want_colsum=colsum_key is not None)
+            self._defer_sum(ws, 3 * cols, nb, cols, self.G(gamma_key))
+            self._defer_sum(ws, 3 * cols, nb, cols, self.G(g + "bias"), offset=cols)
+            if colsum_key is not None:
+                self._defer_sum(ws, 3 * cols, nb, cols, self.G(colsum_key), offset=2 * cols)
+        else:
+            lnws = self.buf("ln_bwd_ws", (hip.lib().mmtg_layernorm_bwd_ws(rows, max(self.sh.D, self.sh.H)),), torch.float32)
+            hip.layernorm_bwd_x3(dy, x, self.P(gamma_key), mean, rstd, dres, dx, self.G(gamma_key), self.G(g + "bias"), rows, cols, dx_planes,
+                                 drop_p=drop_p, drop_seed=drop_seed, dcolsum=None if colsum_key is None else self.G(colsum_key), ws=lnws)
+
     def _ln_bwd(self, site, dy, x, gamma_key, mean, rstd, dres, dx, rows, cols, dx_masked=None, drop_p=0.0, drop_seed=0, colsum_key=None):
         """LayerNorm backward of the bf16 decoder path: with deferred sums the first stage only, into this site's own partial-row
         workspace, the three gradients it ends in queued for the batched sum; otherwise the one-call form on the shared workspace."""
@@ -1263,7 +1279,7 @@ class Engine:
         # dropout-masked gradient entering the previous residual branch and that branch's bias
         # gradient (column sum) -- see mmtg_layernorm_bwd.
         lnws = self.buf("ln_bwd_ws", (hip.lib().mmtg_layernorm_bwd_ws(M, max(D, H)),), torch.float32)
-        self._defer = _DEFER_SUMS and self.dtype == hip.BF16 and not x3
+        self._defer = _DEFER_SUMS and (self.dtype == hip.BF16 or x3)
         dx = self.buf("d_resid_a", (M, D))
         dx2 = self.buf("d_resid_b", (M, D))
         # One grouped launch per block for its four weight gradients (mmtg_wgrad_group): the mlp.c_proj product's dy must then
@@ -1289,9 +1305,8 @@ class Engine:
             # (x3: every LayerNorm backward writes the masked gradient entering the previous residual branch as the plane pair
             #  that branch's split-precision products read -- no fp32 copy, no separate split pass)
             dyp = self.pbuf("d_masked_p", M, D)
-            hip.layernorm_bwd_x3(dhf, a["x_last"], self.P(pre + "ln_f.weight"), a["muf"], a["rsf"], None, dx,
-                                 self.G(pre + "ln_f.weight"), self.G(pre + "ln_f.bias"), M, D, dyp,
-                                 drop_p=pr, drop_seed=a["layers"][sh.L - 1][13][2], dcolsum=self.G(lastp + "mlp.c_proj.bias"), ws=lnws)
+            self._ln_bwd_x3("f", dhf, a["x_last"], pre + "ln_f.weight", a["muf"], a["rsf"], None, dx, M, D, dyp,
+                            drop_p=pr, drop_seed=a["layers"][sh.L - 1][13][2], colsum_key=lastp + "mlp.c_proj.bias")
         else:
             self._ln_bwd("f", dhf, a["x_last"], pre + "ln_f.weight", a["muf"], a["rsf"], None, dx, M, D,
                          dx_masked=dmask_top, drop_p=pr, drop_seed=a["layers"][sh.L - 1][13][2], colsum_key=lastp + "mlp.c_proj.bias")
@@ -1321,23 +1336,31 @@ class Engine:
                 du, dmask, dmask_b, dqkv = sets[l & 1]
             if x3:
                 # ---- split-precision block backward: every gradient that feeds a product travels as a plane pair
-                bands = self.buf("d_u_bands", ((M + 63) // 64, 4 * D), torch.float32)
+                bands = self.buf("d_u_bands_%d" % l if self._defer else "d_u_bands", ((M + 63) // 64, 4 * D), torch.float32)
                 dup = self.pbuf("d_u_p", M, 4 * D)
                 self._dgrad_x3(dyp, p + "mlp.c_proj.weight", None, M, planes=dup, ldc=4 * D, epi=hip.EPI_DGELU, aux=u, ldaux=4 * D, aux2=bands)
-                hip.colsum(bands, bands.shape[0], 4 * D, self.G(p + "mlp.c_fc.bias"))
+                if self._defer and bands.shape[0] <= 2048:
+                    self._defer_sum(bands, 4 * D, bands.shape[0], 4 * D, self.G(p + "mlp.c_fc.bias"))
+                else:
+                    hip.colsum(bands, bands.shape[0], 4 * D, self.G(p + "mlp.c_fc.bias"))
                 self._dgrad_x3(dup, p + "mlp.c_fc.weight", dm, M)
                 dy2p = self.pbuf("d_masked_b_p", M, D)
-                hip.layernorm_bwd_x3(dm, xmid, self.P(p + "ln_2.weight"), mu2, rs2, dx, dx2,
-                                     self.G(p + "ln_2.weight"), self.G(p + "ln_2.bias"), M, D, dy2p,
-                                     drop_p=pr, drop_seed=s[1], dcolsum=self.G(p + "attn.c_proj.bias"), ws=lnws)
+                self._ln_bwd_x3("%d_2" % l, dm, xmid, p + "ln_2.weight", mu2, rs2, dx, dx2, M, D, dy2p,
+                                drop_p=pr, drop_seed=s[1], colsum_key=p + "attn.c_proj.bias")
                 dqkvp = self.pbuf("d_qkv_p", M, 3 * D)
                 # d(ctx) as a plane pair only (the attention backward is its one reader); the dgrad's epilogue also emits delta =
                 # rowsum(d ctx * ctx) per head: no separate pass over ctx / d ctx
                 dctxp = self.pbuf("d_ctx_p", M, D)
                 self._dgrad_x3(dy2p, p + "attn.c_proj.weight", None, M, planes=dctxp, ldc=D, epi=hip.EPI_ROWDOT, aux=ctx, ldaux=D, aux2=delta)
+                # (deferred sums: the partial bias rows -- k / v parts per key block, q part per 16-row band -- stay in this block's own scratch)
+                nkv, nq = B * (-(-T // 128)), -(-M // 16)
+                brows = self._defer and nkv <= 2048 and nq <= 2048
+                bws = self.buf("attn_dbias_x3_%d" % l if brows else "attn_dbias_x3", (hip.attn_bwd_x3_ws(B, T, D),), torch.float32)
                 hip.attn_bwd_x3(qkv, a["keep"], ctx, dctxp, lse, delta, dq32, dqkvp, B, T, sh.nH, D // sh.nH, drop_p=pa, drop_seed=s[0],
-                                dbias=self.G(p + "attn.c_attn.bias"), delta_ready=True,
-                                dbias_ws=self.buf("attn_dbias_x3", (hip.attn_bwd_x3_ws(B, T, D),), torch.float32))
+                                dbias=None if brows else self.G(p + "attn.c_attn.bias"), delta_ready=True, dbias_ws=bws)
+                if brows:
+                    self._defer_sum(bws, 3 * D, nkv, 3 * D, self.G(p + "attn.c_attn.bias"))
+                    self._defer_sum(bws, D, nq, D, self.G(p + "attn.c_attn.bias"), offset=nkv * 3 * D)
                 self._dgrad_x3(dqkvp, p + "attn.c_attn.weight", da, M)
                 keys = (p + "mlp.c_fc.weight", p + "mlp.c_proj.weight", p + "attn.c_proj.weight", p + "attn.c_attn.weight")
                 probs = [(m2, dup, self.G(keys[0]), D, 4 * D), (gact, dyp, self.G(keys[1]), 4 * D, D),
@@ -1346,13 +1369,10 @@ class Engine:
                 if self.wgrad_overwrite and self._ow_rec is not None:
                     self._ow_rec[1].extend((self.layout.entries[k][0], self.layout.entries[k][2]) for k in keys)
                 if l > 0:
-                    hip.layernorm_bwd_x3(da, xin, self.P(p + "ln_1.weight"), mu1, rs1, dx2, dx,
-                                         self.G(p + "ln_1.weight"), self.G(p + "ln_1.bias"), M, D, dyp,
-                                         drop_p=pr, drop_seed=a["layers"][l - 1][13][2],
-                                         dcolsum=self.G(f"{pre}h.{l - 1}.mlp.c_proj.bias"), ws=lnws)
+                    self._ln_bwd_x3("%d_1" % l, da, xin, p + "ln_1.weight", mu1, rs1, dx2, dx, M, D, dyp,
+                                    drop_p=pr, drop_seed=a["layers"][l - 1][13][2], colsum_key=f"{pre}h.{l - 1}.mlp.c_proj.bias")
                 else:
-                    hip.layernorm_bwd(da, xin, self.P(p + "ln_1.weight"), mu1, rs1, dx2, dx,
-                                      self.G(p + "ln_1.weight"), self.G(p + "ln_1.bias"), M, D, ws=lnws)
+                    self._ln_bwd("0_1", da, xin, p + "ln_1.weight", mu1, rs1, dx2, dx, M, D)
                 self._ready(p + "ln_1.bias")
                 continue
             # x_out = x_mid + drop(gact W2 + b2): dy = dx * mask (already produced, with its bias gradient)

@@ -109,6 +109,7 @@ _SIGS = {
     "mmtg_colsum_batch": ([_vp, _i, _vp], _i),
     "mmtg_layernorm_bwd_partial": ([_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _u, _u, _i, _vp, _l, _vp, _vp], _i),
     "mmtg_attn_bwd_dbias_rows": ([_i, _i, _i], _i),
+    "mmtg_layernorm_bwd_x3_partial": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _l, _u, _u, _i, _vp, _l, _vp, _vp], _i),
     "mmtg_comm_unique_id": ([_vp], _i),
     "mmtg_comm_init": ([_i, _i, _vp], _i),
     "mmtg_comm_info": ([_vp, _vp, _vp, _vp], _i),
@@ -437,6 +438,15 @@ def layernorm_bwd_x3(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, co
     _check(lib().mmtg_layernorm_bwd_x3(_p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx), _p(dgamma), _p(dbeta), rows, cols,
                                        _p(dx_planes.t), dx_planes.plane, drop_thresh(drop_p), drop_seed & 0xFFFFFFFF, _p(dcolsum),
                                        _p(ws), ws.numel(), _stream()), "layernorm_bwd_x3")
+
+
+def layernorm_bwd_x3_partial(dy, x, gamma, mean, rstd, dres, dx, rows, cols, dx_planes, ws, drop_p=0.0, drop_seed=0, want_colsum=False):
+    """First stage of layernorm_bwd_x3 only; returns the number of partial rows left in ws ([rows][3][cols]) for colsum_batch."""
+    n = C.c_int(0)
+    _check(lib().mmtg_layernorm_bwd_x3_partial(_p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx), rows, cols,
+                                               _p(dx_planes.t), dx_planes.plane, drop_thresh(drop_p), drop_seed & 0xFFFFFFFF,
+                                               int(want_colsum), _p(ws), ws.numel(), C.addressof(n), _stream()), "layernorm_bwd_x3_partial")
+    return n.value
 
 
 # ------------------------------------------------------------------ attention

@@ -1055,12 +1055,13 @@ def test_training_step_is_bit_reproducible(dtype):
     assert torch.equal(params[0], params[1]), int((params[0] != params[1]).sum())
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "bf16x3f"])
+@pytest.mark.parametrize("dtype", ["bf16", "bf16x3f", "bf16x3"])
 def test_batched_column_sums_leave_the_gradient_bits_unchanged(dtype, monkeypatch):
     """Round 6: the bf16 decoder backward queues its small ordered column sums (two LayerNorm second stages, the dGELU bands and the
     attention bias rows of every block) and sums them in ONE mmtg_colsum_batch launch -- or one per data-parallel hand-over point
     when a bucket hook is installed (the gradients the hook sees must be final).  Same sums, same order: the gradient buffer and the
-    parameters after two steps equal the launch-per-sum form's bit for bit, in all three forms; the batched forms launch fewer kernels."""
+    parameters after two steps equal the launch-per-sum form's bit for bit, in all three forms; the batched forms launch fewer kernels.
+    bf16x3: the split-precision backward's sums the same way (mmtg_layernorm_bwd_x3_partial, mmtg_attn_bwd_x3's rows-only form)."""
     from ddp_worker import build as build_small
     from mmtg_amd import engine as E, hip as H, synth
     results = {}

@@ -229,6 +229,40 @@ def test_attention_x3_matches_the_exact_fp32_kernels(B, T, drop):
     dqp2, db2 = hip.Planes.empty(B * T, 3 * D, DEV), torch.zeros(3 * D, device=DEV)
     hip.attn_bwd_x3(qkvp, keep, out, doutp, lse, torch.empty_like(delta), dqs, dqp2, B, T, nH, dh, drop_p=drop, drop_seed=seed, dbias=db2, dbias_ws=ws3)
     assert torch.equal(dqp2.t, dqp.t) and torch.equal(db2, db)
+    # round 6: the partial bias rows left for the batched column sums (dbias = None + a workspace) give the same bits
+    dqp3, db3 = hip.Planes.empty(B * T, 3 * D, DEV), torch.zeros(3 * D, device=DEV)
+    ws4 = torch.full((hip.attn_bwd_x3_ws(B, T, D),), float("nan"), device=DEV)
+    hip.attn_bwd_x3(qkvp, keep, out, doutp, lse, torch.empty_like(delta), dqs, dqp3, B, T, nH, dh, drop_p=drop, drop_seed=seed, dbias=None, dbias_ws=ws4)
+    nkv, nq = B * (-(-T // 128)), -(-(B * T) // 16)
+    hip.colsum_batch([(ws4.data_ptr(), db3.data_ptr(), 3 * D, nkv, 3 * D), (ws4.data_ptr() + 4 * nkv * 3 * D, db3.data_ptr(), D, nq, D)])
+    assert torch.equal(dqp3.t, dqp.t) and torch.equal(db3, db)
+
+
+def test_layernorm_bwd_x3_partial_rows_plus_the_batched_sum_equal_the_one_call_form():
+    """mmtg_layernorm_bwd_x3_partial (first stage only) + mmtg_colsum_batch over its partial rows = mmtg_layernorm_bwd_x3, bit for bit:
+    d(x), the masked plane pair, d gamma, d beta and the fused column sum."""
+    rows, cols = 3001, 768
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.randn(rows, cols, device=DEV, generator=g) * 2
+    dy, dres = torch.randn(rows, cols, device=DEV, generator=g), torch.randn(rows, cols, device=DEV, generator=g)
+    gam = 1 + 0.1 * torch.randn(cols, device=DEV, generator=g)
+    mean, var = x.mean(-1), x.var(-1, unbiased=False)
+    rstd = (var + 1e-5).rsqrt()
+    res = []
+    for partial in (False, True):
+        dx, pl = torch.empty_like(x), hip.Planes.empty(rows, cols, DEV)
+        dg, db, dcs = (torch.full((cols,), v, device=DEV) for v in (1.0, -1.0, 2.0))
+        ws = torch.full((int(hip.lib().mmtg_layernorm_bwd_ws(rows, cols)),), float("nan"), device=DEV)
+        if partial:
+            nb = hip.layernorm_bwd_x3_partial(dy, x, gam, mean, rstd, dres, dx, rows, cols, pl, ws, drop_p=0.1, drop_seed=77, want_colsum=True)
+            assert 0 < nb <= 1024
+            hip.colsum_batch([(ws.data_ptr() + 4 * q * cols, t.data_ptr(), 3 * cols, nb, cols) for q, t in enumerate((dg, db, dcs))])
+        else:
+            hip.layernorm_bwd_x3(dy, x, gam, mean, rstd, dres, dx, dg, db, rows, cols, pl, drop_p=0.1, drop_seed=77, dcolsum=dcs, ws=ws)
+        res.append((dx, pl.t.clone(), dg, db, dcs))
+    for u, v in zip(*res):
+        assert torch.equal(u, v)
+    assert float((res[0][4] - 2.0).abs().max()) > 0
 
 
 @pytest.mark.parametrize("B,T", [(2, 129), (1, 236), (1, 400)])
