@@ -182,7 +182,7 @@ MMTG_API long mmtg_colsum_ws(int M, int N);      /* workspace floats mmtg_colsum
 MMTG_API int mmtg_colsum(int dtype, const void* X, long ldx, int M, int N, float* out, float* ws, long ws_floats, void* stream);
 /* Round 6: many small ordered column sums in ONE launch -- out_i[c] += sum_{r < M_i} X_i[r * ldx_i + c], c < N_i, every item summed in
  * the order mmtg_colsum uses for the same rows (the same bits); fp32 rows, M_i <= 2048.  `items` is a HOST array (the items travel in
- * the kernel arguments, 64 per launch).  The backward of a GPT-2 block ends four such reductions (two LayerNorm second stages, the
+ * the kernel arguments, 64 per launch); the items of a call run concurrently, so no two may share output elements.  The backward of a GPT-2 block ends four such reductions (two LayerNorm second stages, the
  * dGELU bands, the attention kernels' bias rows: the bias / LayerNorm gradients autograd produces behind model.py:282-288) that nothing
  * reads before the optimizer: mmtg_layernorm_bwd_partial / MMTG_ATTN_DBIAS_ROWS leave them as partial rows, this call sums them.      */
 typedef struct { const float* X; float* out; long ldx; int M; int N; } mmtg_colsum_item;
@@ -241,7 +241,8 @@ MMTG_API int mmtg_attn_fwd(int dtype, const void* qkv, const int* keep, void* ou
  * (nullable): [3D] += column sums of d(qkv), through dbias_ws (>= (B * ceil(T/128) + ceil(B*T/16)) * 3D floats); delta_ready != 0:
  * delta[m, h] = sum_d dout * out was filled by the caller (mmtg_gemm_x3's MMTG_EPI_ROWDOT epilogue does it for free).
  * Round 6: dbias == NULL with dbias_ws non-null leaves the partial bias rows UNSUMMED at the head of dbias_ws -- [B * ceil(T/128)][3D]
- * (k and v parts; the q part zero), then [ceil(B*T/16)][D] (the q part) -- for the caller's mmtg_colsum_batch.                     */
+ * (k and v parts; the q part zero), then [ceil(B*T/16)][D] (the q part) -- for the caller's mmtg_colsum_batch (as two items with
+ * disjoint output columns: [D, 3D) from the first rows, [0, D) from the second).                                                    */
 MMTG_API int mmtg_attn_fwd_x3(const void* qkv_planes, long qplane, const int* keep, float* out, void* out_planes, long plane, float* lse,
                      int B, int T, int nH, int dh, unsigned drop_thresh, unsigned drop_seed, void* stream);
 MMTG_API int mmtg_attn_bwd_x3(const void* qkv_planes, long qplane, const int* keep, const float* out, const void* dout_planes, long doplane,

@@ -1073,6 +1073,11 @@ class Engine:
 
     def _flush_sums(self):
         if self._sums:
+            # the items of a flush run concurrently: no two may add into the same output elements
+            spans = sorted((it[1], it[1] + 4 * it[4]) for it in self._sums)
+            for (a0, a1), (b0, b1) in zip(spans, spans[1:]):
+                if b0 < a1:
+                    raise RuntimeError("deferred column sums with overlapping outputs in one batch")
             hip.colsum_batch(self._sums)
             self._sums = []
 
@@ -1359,7 +1364,9 @@ class Engine:
                 hip.attn_bwd_x3(qkv, a["keep"], ctx, dctxp, lse, delta, dq32, dqkvp, B, T, sh.nH, D // sh.nH, drop_p=pa, drop_seed=s[0],
                                 dbias=None if brows else self.G(p + "attn.c_attn.bias"), delta_ready=True, dbias_ws=bws)
                 if brows:
-                    self._defer_sum(bws, 3 * D, nkv, 3 * D, self.G(p + "attn.c_attn.bias"))
+                    # (two items must not share output columns -- they run in one launch: the key-block rows carry the k and v parts,
+                    #  their q columns are zero; the band rows carry the q part)
+                    self._defer_sum(bws, 3 * D, nkv, 2 * D, self.G(p + "attn.c_attn.bias")[D:], offset=D)
                     self._defer_sum(bws, D, nq, D, self.G(p + "attn.c_attn.bias"), offset=nkv * 3 * D)
                 self._dgrad_x3(dqkvp, p + "attn.c_attn.weight", da, M)
                 keys = (p + "mlp.c_fc.weight", p + "mlp.c_proj.weight", p + "attn.c_proj.weight", p + "attn.c_attn.weight")

@@ -234,7 +234,10 @@ def test_attention_x3_matches_the_exact_fp32_kernels(B, T, drop):
     ws4 = torch.full((hip.attn_bwd_x3_ws(B, T, D),), float("nan"), device=DEV)
     hip.attn_bwd_x3(qkvp, keep, out, doutp, lse, torch.empty_like(delta), dqs, dqp3, B, T, nH, dh, drop_p=drop, drop_seed=seed, dbias=None, dbias_ws=ws4)
     nkv, nq = B * (-(-T // 128)), -(-(B * T) // 16)
-    hip.colsum_batch([(ws4.data_ptr(), db3.data_ptr(), 3 * D, nkv, 3 * D), (ws4.data_ptr() + 4 * nkv * 3 * D, db3.data_ptr(), D, nq, D)])
+    # (the items of a batch run concurrently and must not share output columns: k / v parts from the key-block rows -- whose q columns
+    #  are zero -- and the q part from the band rows)
+    assert float(ws4[:nkv * 3 * D].view(nkv, 3 * D)[:, :D].abs().max()) == 0.0
+    hip.colsum_batch([(ws4.data_ptr() + 4 * D, db3.data_ptr() + 4 * D, 3 * D, nkv, 2 * D), (ws4.data_ptr() + 4 * nkv * 3 * D, db3.data_ptr(), D, nq, D)])
     assert torch.equal(dqp3.t, dqp.t) and torch.equal(db3, db)
 
 

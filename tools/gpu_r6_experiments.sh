@@ -278,5 +278,14 @@ done
 done
 for ds in 0 1; do MMTG_DEFER_SUMS=$ds timeout 300 python tools/bench_x3.py bf16x3f 64 10 2>&1 | grep -v amdgpu.ids | head -2 | sed "s/^/DEFER_SUMS=$ds /" | tee -a $E/defer_sums_ab.txt; done
 ;;
-*) echo "usage: $0 {a|c|d|e|f|g|h|i|j|k|l|m|n|o|p|q|r}"; exit 2 ;;
+s)
+# the split-precision backward's column sums batched too: op + model tests, then the bf16x3 step A/B
+mkdir -p gpurun_out/r6s2
+E=gpurun_out/r6s2
+timeout 1500 python -m pytest tests/test_x3_gpu.py tests/test_model_gpu.py tests/test_ddp_gpu.py -m gpu -q --no-header -p no:cacheprovider -x -k "x3 or batched_column or reproducible or world1 or one_gpu" 2>&1 | tail -4 | tee $E/pytest_defer_x3.txt
+for rep in 1 2; do
+for ds in 0 1; do MMTG_DEFER_SUMS=$ds timeout 300 python tools/bench_x3.py bf16x3 64 10 2>&1 | grep -v amdgpu.ids | head -1 | sed "s/^/DEFER_SUMS=$ds /" | tee -a $E/defer_sums_x3_ab.txt; done
+done
+;;
+*) echo "usage: $0 {a|c|d|e|f|g|h|i|j|k|l|m|n|o|p|q|r|s}"; exit 2 ;;
 esac
