@@ -1283,7 +1283,6 @@ class Engine:
         # Every LayerNorm backward on the residual stream also emits, in the same pass, the
         # dropout-masked gradient entering the previous residual branch and that branch's bias
         # gradient (column sum) -- see mmtg_layernorm_bwd.
-        lnws = self.buf("ln_bwd_ws", (hip.lib().mmtg_layernorm_bwd_ws(M, max(D, H)),), torch.float32)
         self._defer = _DEFER_SUMS and (self.dtype == hip.BF16 or x3)
         dx = self.buf("d_resid_a", (M, D))
         dx2 = self.buf("d_resid_b", (M, D))
