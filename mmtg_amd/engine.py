@@ -225,6 +225,13 @@ _GELU_GRAD = _os.environ.get("MMTG_GELU_GRAD", "0") != "0"
 # the bf16 decoder backward's small ordered column sums (LayerNorm second stages, dGELU bands, attention bias rows: 4 per block) summed
 # by ONE batched launch per data-parallel hand-over point -- one per step without a bucket hook -- instead of a launch each (A/B switch)
 _DEFER_SUMS = _os.environ.get("MMTG_DEFER_SUMS", "1") != "0"
+# the grouped weight gradients of the LAST blocks the backward walks (blocks MMTG_WGRAD_TAIL - 1 .. 0) on a side stream beside the
+# backward's tail -- the fuser / encoder backward: ~60 small dependent launches during which the GPU is mostly idle -- instead of inside
+# the block loop; joined before the gradient norm.  Single-GPU steps with dropout on (their operands are the masked copies, which get
+# buffers of their own: 209 MB per block at GPT-2 base); 0 = off.  Measured (same box, ms per step): 0: 14.91, 1-2: 14.9-15.0 (the
+# co-running launches slow the tail as much as they hide), 4: 14.72, 6: 14.66, 8: 14.64, 12: 14.67; the same launches at the same
+# place on the MAIN stream (MMTG_WGRAD_TAIL_MAIN=1): 14.98 -- the gain is the overlap, not the order
+_WGRAD_TAIL = int(_os.environ.get("MMTG_WGRAD_TAIL", "8"))
 _LMHEAD_GROUP = _os.environ.get("MMTG_LMHEAD_GROUP", "1") != "0"      # the tied embedding's weight gradient through the grouped kernel (A/B switch)
 _LMHEAD_GROUP_SPLITS = int(_os.environ.get("MMTG_LMHEAD_GROUP_SPLITS", "0"))
 # the grouped weight-gradient launches on a SIDE stream, one block behind the dgrad chain (MMTG_WGRAD_STREAM; see Engine.backward)
@@ -358,6 +365,7 @@ class Engine:
         self.normsq = torch.zeros(1, device=self.dev)
         self.bucket_hook = None   # callable(pack_index) fired as packs of gradients become final
         self._sums, self._defer = [], False     # deferred column sums of the backward (see _defer_sum)
+        self._tail_jobs, self._tail_side = [], None      # grouped weight gradients deferred to the backward's tail (_WGRAD_TAIL)
         self._pf_stream = None
         self._rowmaps = {}
 
@@ -1212,6 +1220,9 @@ class Engine:
             self._backward_hybrid(dlogits, dkl)
         else:
             self._backward_encoder(a, self._backward_decoder(a, dlogits), dkl)
+        if self._tail_side is not None:         # the weight gradients that ran beside the tail: final before anything reads the gradient
+            torch.cuda.current_stream().wait_stream(self._tail_side)
+            self._tail_side = None
         self._lazy = None
 
     def _backward_decoder(self, a, dlogits):
@@ -1305,6 +1316,13 @@ class Engine:
         lastp = f"{pre}h.{sh.L - 1}."
         # (MMTG_WGRAD_STREAM: the top block's masked gradient goes into the buffer set of that block's parity, see below)
         dmask_top = self.buf("d_masked_1", (M, D)) if (group and not x3 and _WGRAD_STREAM and pr > 0 and (sh.L - 1) & 1) else dmask
+        # MMTG_WGRAD_TAIL: the last blocks' operand buffers are their own (nothing rewrites them before their launch at the tail)
+        ntail = min(_WGRAD_TAIL, sh.L) if (group and not x3 and not _WGRAD_STREAM and pr > 0 and self.bucket_hook is None) else 0
+        tsets = {t: (self.buf("d_u_t%d" % t, (M, 4 * D)), self.buf("d_masked_t%d" % t, (M, D)), self.buf("d_masked_b_t%d" % t, (M, D)),
+                     self.buf("d_qkv_t%d" % t, (M, 3 * D))) for t in range(ntail)}
+        if ntail == sh.L:
+            dmask_top = tsets[sh.L - 1][1]
+        self._tail_jobs = []
         if x3:
             # (x3: every LayerNorm backward writes the masked gradient entering the previous residual branch as the plane pair
             #  that branch's split-precision products read -- no fp32 copy, no separate split pass)
@@ -1338,6 +1356,8 @@ class Engine:
             (xin, mu1, rs1, a1, qkv, ctx, lse, xmid, mu2, rs2, m2, u, gact, s, ctxp) = a["layers"][l]
             if stream_mode:
                 du, dmask, dmask_b, dqkv = sets[l & 1]
+            if l in tsets:
+                du, dmask, dmask_b, dqkv = tsets[l]
             if x3:
                 # ---- split-precision block backward: every gradient that feeds a product travels as a plane pair
                 bands = self.buf("d_u_bands_%d" % l if self._defer else "d_u_bands", ((M + 63) // 64, 4 * D), torch.float32)
@@ -1447,6 +1467,8 @@ class Engine:
                         hip.wgrad_group(probs, M, gsplits, gws, gcnt, accumulate=not self.wgrad_overwrite, config=gcfg)
                         wdone[l] = self._event(l)
                         wdone[l].record(side)
+                elif l in tsets:
+                    self._tail_jobs.append((probs, M, gsplits, gws, gcnt, not self.wgrad_overwrite, gcfg))       # launched at the tail
                 else:
                     hip.wgrad_group(probs, M, gsplits, gws, gcnt, accumulate=not self.wgrad_overwrite, config=gcfg)
                 if self.wgrad_overwrite and self._ow_rec is not None:
@@ -1460,7 +1482,8 @@ class Engine:
                 self._ready(f"{pre}h.{l + 1}.ln_1.bias")
             if l > 0:
                 self._ln_bwd("%d_1" % l, da, xin, p + "ln_1.weight", mu1, rs1, dx2, dx, M, D,
-                             dx_masked=(sets[(l - 1) & 1][1] if stream_mode else dmask), drop_p=pr, drop_seed=a["layers"][l - 1][13][2],
+                             dx_masked=(sets[(l - 1) & 1][1] if stream_mode else tsets[l - 1][1] if (l - 1) in tsets else dmask),
+                             drop_p=pr, drop_seed=a["layers"][l - 1][13][2],
                              colsum_key=f"{pre}h.{l - 1}.mlp.c_proj.bias")
             else:
                 self._ln_bwd("0_1", da, xin, p + "ln_1.weight", mu1, rs1, dx2, dx, M, D)
@@ -1529,6 +1552,21 @@ class Engine:
             hip.colsum(dh1, M, H, self.G("decoder.projector_layer1.bias"))      # (the weight gradient went with W2's above)
         else:
             self._wgrad(a["x"], dh1, "decoder.projector_layer1.weight", "decoder.projector_layer1.bias", M, "linear")
+        if self._tail_jobs:
+            # the deferred blocks' grouped weight gradients, in block order on ONE side stream (they share a workspace and counters; the
+            # inline launches are complete by now): behind everything enqueued so far, beside the fuser / encoder backward that follows
+            if _os.environ.get("MMTG_WGRAD_TAIL_MAIN"):          # (A/B: the same launches on the main stream, no overlap with the tail)
+                for probs, m_, gs_, gws_, gcnt_, acc_, cfg_ in self._tail_jobs:
+                    hip.wgrad_group(probs, m_, gs_, gws_, gcnt_, accumulate=acc_, config=cfg_)
+                self._tail_jobs = []
+                return seg
+            side = self._side_stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for probs, m_, gs_, gws_, gcnt_, acc_, cfg_ in self._tail_jobs:
+                    hip.wgrad_group(probs, m_, gs_, gws_, gcnt_, accumulate=acc_, config=cfg_)
+            self._tail_jobs = []
+            self._tail_side = side
         return seg
 
     def _backward_encoder(self, a, seg, dkl):

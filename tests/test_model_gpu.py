@@ -1093,6 +1093,54 @@ def test_batched_column_sums_leave_the_gradient_bits_unchanged(dtype, monkeypatc
     assert results["batched"][2] < results["hooked"][2] < results["each"][2], [r[2] for r in results.values()]
 
 
+@pytest.mark.parametrize("dtype,layers", [("bf16", 2), ("bf16", 3), ("bf16x3f", 3)])
+def test_weight_gradients_beside_the_backward_s_tail_leave_the_bits_unchanged(dtype, layers, monkeypatch):
+    """Round 6: the grouped weight gradients of the last blocks the backward walks (MMTG_WGRAD_TAIL = 2: blocks 1 and 0) are launched
+    on a side stream beside the fuser / encoder backward -- from operand buffers of their own -- and joined before the gradient norm.
+    Same kernels on the same operands: gradient buffer and parameters after two steps equal the in-loop form's bit for bit (a 2-layer
+    model: every block deferred, the top block's masked gradient comes from ln_f; 3 layers: the hand-over between an in-loop block and
+    a deferred one).  With a data-parallel bucket hook installed nothing is deferred (the hook must see final gradients)."""
+    from mmtg_amd import engine as E, synth
+    from mmtg_amd.configs import data_config, gpt2_config, make_model_cfgs
+    S, V = 5, 160
+    mcfg, dcfg = make_model_cfgs(seq_len=S), data_config(seq_len=S)
+    gcfg = gpt2_config(n_layer=layers, vocab_size=V, n_positions=256, embd_pdrop=0.1, attn_pdrop=0.1, resid_pdrop=0.1)
+    weights = synth.make_weights(mcfg, gcfg, seed=100)
+    nb = synth.make_batch(12, mcfg, dcfg, V, seed=7)
+    batch = {k: torch.from_numpy(np.asarray(v)).to(DEV) for k, v in nb.items()}
+    results = {}
+    for form in ("loop", "tail", "hooked"):
+        monkeypatch.setattr(E, "_WGRAD_TAIL", 0 if form == "loop" else 2)
+        model = MMTG(mcfg, dcfg, V, train_flag=True, gpt2_config=gcfg, token_table=synth.make_token_table(V, seed=101), compute_dtype=dtype)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})
+        model.to(DEV).train()
+        tr = MMTGTrainer(model, lr=1e-3, alpha=0.2)
+        tr.eng.drop_seed = 4242
+        if form == "hooked":
+            tr.eng.bucket_hook = lambda pack: None
+        launched = []
+        orig = E.hip.wgrad_group
+
+        def spy(probs, *a, **k):
+            launched.append(torch.cuda.current_stream() != torch.cuda.default_stream())
+            return orig(probs, *a, **k)
+
+        monkeypatch.setattr(E.hip, "wgrad_group", spy)
+        tr.step(batch, stage=1)
+        g = tr.eng.grad.detach().clone()
+        tr.step(batch, stage=3)
+        torch.cuda.synchronize()
+        monkeypatch.setattr(E.hip, "wgrad_group", orig)
+        results[form] = (g, model.engine().master.detach().clone())
+        assert tr.eng._tail_side is None and tr.eng._tail_jobs == []
+        on_side = sum(launched)
+        assert on_side == (2 * min(2, layers) if form == "tail" else 0), (form, launched)
+    for form in ("tail", "hooked"):
+        assert torch.equal(results["loop"][0], results[form][0]), form
+        assert torch.equal(results["loop"][1], results[form][1]), form
+    assert float(results["loop"][0].abs().max()) > 0
+
+
 def test_bf16x3_training_step_with_dropout_matches_the_f32_mode():
     """Training mode (dropout 0.1 at GPT-2's three sites) in the split-precision mode against the exact-fp32 mode: both modes draw the
     SAME counter-hash masks from the same seeds (the x3 products' residual epilogues, the x3 attention kernels and the plane-writing

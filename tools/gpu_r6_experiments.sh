@@ -287,5 +287,23 @@ for rep in 1 2; do
 for ds in 0 1; do MMTG_DEFER_SUMS=$ds timeout 300 python tools/bench_x3.py bf16x3 64 10 2>&1 | grep -v amdgpu.ids | head -1 | sed "s/^/DEFER_SUMS=$ds /" | tee -a $E/defer_sums_x3_ab.txt; done
 done
 ;;
-*) echo "usage: $0 {a|c|d|e|f|g|h|i|j|k|l|m|n|o|p|q|r|s}"; exit 2 ;;
+t)
+# the last blocks' grouped weight gradients beside the backward's tail (MMTG_WGRAD_TAIL): tests, then the step A/B by number of blocks
+mkdir -p gpurun_out/r6t2
+E=gpurun_out/r6t2
+timeout 1500 python -m pytest tests/test_model_gpu.py -m gpu -q --no-header -p no:cacheprovider -x -k "tail or reproducible or batched_column or fused_step or full_12l" 2>&1 | tail -4 | tee $E/pytest_tail.txt
+for rep in 1 2; do
+for nt in 0 1 2 3 4; do
+  MMTG_WGRAD_TAIL=$nt timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --primary-only --no-roofline 2>/dev/null | python -c "
+import sys, json
+for ln in sys.stdin:
+    try: d = json.loads(ln)
+    except Exception: continue
+    print('WGRAD_TAIL=$nt', d['value'], 'tok/s', d['ms_per_step'], 'ms/step', d['check']['probe_myloss_after'])
+" | tee -a $E/wgrad_tail_ab.txt
+done
+done
+for nt in 0 2; do MMTG_WGRAD_TAIL=$nt timeout 300 python tools/bench_x3.py bf16x3f 64 10 2>&1 | grep -v amdgpu.ids | head -1 | sed "s/^/WGRAD_TAIL=$nt /" | tee -a $E/wgrad_tail_ab.txt; done
+;;
+*) echo "usage: $0 {a|c|d|e|f|g|h|i|j|k|l|m|n|o|p|q|r|s|t}"; exit 2 ;;
 esac
