@@ -230,7 +230,8 @@ _DEFER_SUMS = _os.environ.get("MMTG_DEFER_SUMS", "1") != "0"
 # the block loop; joined before the gradient norm.  Single-GPU steps with dropout on (their operands are the masked copies, which get
 # buffers of their own: 209 MB per block at GPT-2 base); 0 = off.  Measured (same box, ms per step): 0: 14.91, 1-2: 14.9-15.0 (the
 # co-running launches slow the tail as much as they hide), 4: 14.72, 6: 14.66, 8: 14.64, 12: 14.67; the same launches at the same
-# place on the MAIN stream (MMTG_WGRAD_TAIL_MAIN=1): 14.98 -- the gain is the overlap, not the order
+# place on the MAIN stream (MMTG_WGRAD_TAIL_MAIN=1): 14.98 -- the gain is the overlap, not the order.  bf16x3 (plane-pair operands,
+# with or without dropout): 33.57 -> 33.07 at 8 (33.03 at 4, 33.29 at 12)
 _WGRAD_TAIL = int(_os.environ.get("MMTG_WGRAD_TAIL", "8"))
 _LMHEAD_GROUP = _os.environ.get("MMTG_LMHEAD_GROUP", "1") != "0"      # the tied embedding's weight gradient through the grouped kernel (A/B switch)
 _LMHEAD_GROUP_SPLITS = int(_os.environ.get("MMTG_LMHEAD_GROUP_SPLITS", "0"))
@@ -1317,16 +1318,18 @@ class Engine:
         # (MMTG_WGRAD_STREAM: the top block's masked gradient goes into the buffer set of that block's parity, see below)
         dmask_top = self.buf("d_masked_1", (M, D)) if (group and not x3 and _WGRAD_STREAM and pr > 0 and (sh.L - 1) & 1) else dmask
         # MMTG_WGRAD_TAIL: the last blocks' operand buffers are their own (nothing rewrites them before their launch at the tail)
-        ntail = min(_WGRAD_TAIL, sh.L) if (group and not x3 and not _WGRAD_STREAM and pr > 0 and self.bucket_hook is None) else 0
-        tsets = {t: (self.buf("d_u_t%d" % t, (M, 4 * D)), self.buf("d_masked_t%d" % t, (M, D)), self.buf("d_masked_b_t%d" % t, (M, D)),
-                     self.buf("d_qkv_t%d" % t, (M, 3 * D))) for t in range(ntail)}
-        if ntail == sh.L:
+        # (the split-precision blocks' operands are plane pairs the LayerNorm backward writes with or without dropout: name suffix per block)
+        ntail = min(_WGRAD_TAIL, sh.L) if (group and not _WGRAD_STREAM and (pr > 0 or x3) and self.bucket_hook is None) else 0
+        tsets = {} if x3 else {t: (self.buf("d_u_t%d" % t, (M, 4 * D)), self.buf("d_masked_t%d" % t, (M, D)),
+                                   self.buf("d_masked_b_t%d" % t, (M, D)), self.buf("d_qkv_t%d" % t, (M, 3 * D))) for t in range(ntail)}
+        xsfx = (lambda t: "_t%d" % t if t < ntail else "") if x3 else (lambda t: "")
+        if ntail == sh.L and not x3:
             dmask_top = tsets[sh.L - 1][1]
         self._tail_jobs = []
         if x3:
             # (x3: every LayerNorm backward writes the masked gradient entering the previous residual branch as the plane pair
             #  that branch's split-precision products read -- no fp32 copy, no separate split pass)
-            dyp = self.pbuf("d_masked_p", M, D)
+            dyp = self.pbuf("d_masked_p" + xsfx(sh.L - 1), M, D)
             self._ln_bwd_x3("f", dhf, a["x_last"], pre + "ln_f.weight", a["muf"], a["rsf"], None, dx, M, D, dyp,
                             drop_p=pr, drop_seed=a["layers"][sh.L - 1][13][2], colsum_key=lastp + "mlp.c_proj.bias")
         else:
@@ -1361,17 +1364,17 @@ class Engine:
             if x3:
                 # ---- split-precision block backward: every gradient that feeds a product travels as a plane pair
                 bands = self.buf("d_u_bands_%d" % l if self._defer else "d_u_bands", ((M + 63) // 64, 4 * D), torch.float32)
-                dup = self.pbuf("d_u_p", M, 4 * D)
+                dup = self.pbuf("d_u_p" + xsfx(l), M, 4 * D)
                 self._dgrad_x3(dyp, p + "mlp.c_proj.weight", None, M, planes=dup, ldc=4 * D, epi=hip.EPI_DGELU, aux=u, ldaux=4 * D, aux2=bands)
                 if self._defer and bands.shape[0] <= 2048:
                     self._defer_sum(bands, 4 * D, bands.shape[0], 4 * D, self.G(p + "mlp.c_fc.bias"))
                 else:
                     hip.colsum(bands, bands.shape[0], 4 * D, self.G(p + "mlp.c_fc.bias"))
                 self._dgrad_x3(dup, p + "mlp.c_fc.weight", dm, M)
-                dy2p = self.pbuf("d_masked_b_p", M, D)
+                dy2p = self.pbuf("d_masked_b_p" + xsfx(l), M, D)
                 self._ln_bwd_x3("%d_2" % l, dm, xmid, p + "ln_2.weight", mu2, rs2, dx, dx2, M, D, dy2p,
                                 drop_p=pr, drop_seed=s[1], colsum_key=p + "attn.c_proj.bias")
-                dqkvp = self.pbuf("d_qkv_p", M, 3 * D)
+                dqkvp = self.pbuf("d_qkv_p" + xsfx(l), M, 3 * D)
                 # d(ctx) as a plane pair only (the attention backward is its one reader); the dgrad's epilogue also emits delta =
                 # rowsum(d ctx * ctx) per head: no separate pass over ctx / d ctx
                 dctxp = self.pbuf("d_ctx_p", M, D)
@@ -1391,10 +1394,14 @@ class Engine:
                 keys = (p + "mlp.c_fc.weight", p + "mlp.c_proj.weight", p + "attn.c_proj.weight", p + "attn.c_attn.weight")
                 probs = [(m2, dup, self.G(keys[0]), D, 4 * D), (gact, dyp, self.G(keys[1]), 4 * D, D),
                          (ctxp, dy2p, self.G(keys[2]), D, D), (a1, dqkvp, self.G(keys[3]), D, 3 * D)]
-                hip.wgrad_group(probs, M, gsplits, gws, gcnt, accumulate=not self.wgrad_overwrite, config=_X3_WG_CFG)
+                if l < ntail:
+                    self._tail_jobs.append((probs, M, gsplits, gws, gcnt, not self.wgrad_overwrite, _X3_WG_CFG))       # launched at the tail
+                else:
+                    hip.wgrad_group(probs, M, gsplits, gws, gcnt, accumulate=not self.wgrad_overwrite, config=_X3_WG_CFG)
                 if self.wgrad_overwrite and self._ow_rec is not None:
                     self._ow_rec[1].extend((self.layout.entries[k][0], self.layout.entries[k][2]) for k in keys)
                 if l > 0:
+                    dyp = self.pbuf("d_masked_p" + xsfx(l - 1), M, D)          # the planes block l - 1 reads (its own when it is deferred)
                     self._ln_bwd_x3("%d_1" % l, da, xin, p + "ln_1.weight", mu1, rs1, dx2, dx, M, D, dyp,
                                     drop_p=pr, drop_seed=a["layers"][l - 1][13][2], colsum_key=f"{pre}h.{l - 1}.mlp.c_proj.bias")
                 else:

@@ -915,6 +915,7 @@ def test_weight_gradients_on_a_side_stream_match_the_default_order(monkeypatch):
     nb = synth.make_batch(6, mcfg, dcfg, V, seed=7)
     tb = {k: torch.from_numpy(np.asarray(v)).to(DEV) for k, v in nb.items()}
     grads = []
+    monkeypatch.setattr(E, "_WGRAD_TAIL", 0)       # (the default schedule's own side-stream use -- the last blocks beside the tail -- off: in-loop order)
     for stream in (False, True):
         monkeypatch.setattr(E, "_WGRAD_STREAM", stream)
         model = MMTG(mcfg, dcfg, V, train_flag=True, gpt2_config=gcfg, token_table=synth.make_token_table(V, seed=101), compute_dtype="bf16")
@@ -1093,7 +1094,7 @@ def test_batched_column_sums_leave_the_gradient_bits_unchanged(dtype, monkeypatc
     assert results["batched"][2] < results["hooked"][2] < results["each"][2], [r[2] for r in results.values()]
 
 
-@pytest.mark.parametrize("dtype,layers", [("bf16", 2), ("bf16", 3), ("bf16x3f", 3)])
+@pytest.mark.parametrize("dtype,layers", [("bf16", 2), ("bf16", 3), ("bf16x3f", 3), ("bf16x3", 2), ("bf16x3", 3)])
 def test_weight_gradients_beside_the_backward_s_tail_leave_the_bits_unchanged(dtype, layers, monkeypatch):
     """Round 6: the grouped weight gradients of the last blocks the backward walks (MMTG_WGRAD_TAIL = 2: blocks 1 and 0) are launched
     on a side stream beside the fuser / encoder backward -- from operand buffers of their own -- and joined before the gradient norm.
