@@ -82,3 +82,27 @@ def _event_us(call, iters=20, warm=3):
     e1.record()
     torch.cuda.synchronize()
     return 1e3 * e0.elapsed_time(e1) / iters
+
+
+import contextlib as _contextlib
+
+
+@_contextlib.contextmanager
+def launches_unshared():
+    """For an instrumented pass (HIP events around every launch): every kernel alone on the GPU.  The product schedule runs the last 8
+    blocks' grouped weight-gradient launches on a side stream beside the backward's small-kernel tail (engine._WGRAD_TAIL); there a
+    launch's event-to-event time includes the time it shares the CUs, which says nothing about the kernel.  `value` / `ms_per_step`
+    are always measured in the product schedule."""
+    import mmtg_amd.engine as E
+    saved = E._WGRAD_TAIL
+    E._WGRAD_TAIL = 0
+    try:
+        yield
+    finally:
+        E._WGRAD_TAIL = saved
+
+
+UNSHARED_NOTE = ("achieved / frac: HIP events around every launch of an instrumented pass in which every kernel runs alone "
+                 "(MMTG_WGRAD_TAIL=0 for that pass); the product schedule -- what `value` is measured in -- runs 8 of the grouped "
+                 "weight-gradient launches beside the backward's small-kernel tail, where event-to-event time includes the sharing "
+                 "(frac_in_product_schedule)")

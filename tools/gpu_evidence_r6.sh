@@ -28,6 +28,11 @@ prof() {   # name, program args...
   rm -rf $E/prof_$name
 }
 prof bf16_train $R/bench.py --steps 10 --warmup 4 --no-cpu-baseline --primary-only --no-check
+# (the same program with every launch alone on the GPU: the schedule the bench line's instrumented roofline pass uses -- the product
+#  schedule above runs 8 grouped weight-gradient launches beside the backward's tail, where their durations include the sharing)
+export MMTG_WGRAD_TAIL=0
+prof bf16_train_unshared $R/bench.py --steps 10 --warmup 4 --no-cpu-baseline --primary-only --no-check
+unset MMTG_WGRAD_TAIL
 prof bf16x3f_train $R/tools/bench_x3.py bf16x3f 64 10
 prof bf16x3_train $R/tools/bench_x3.py bf16x3 64 10
 prof bf16_decode $R/bench.py --mode decode --steps 2 --warmup 1 --no-cpu-baseline --no-roofline
