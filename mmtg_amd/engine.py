@@ -233,6 +233,9 @@ _DEFER_SUMS = _os.environ.get("MMTG_DEFER_SUMS", "1") != "0"
 # place on the MAIN stream (MMTG_WGRAD_TAIL_MAIN=1): 14.98 -- the gain is the overlap, not the order.  bf16x3 (plane-pair operands,
 # with or without dropout): 33.57 -> 33.07 at 8 (33.03 at 4, 33.29 at 12)
 _WGRAD_TAIL = int(_os.environ.get("MMTG_WGRAD_TAIL", "8"))
+# where the side stream forks: "loop" = right after the block loop (beside the embedding / projector backward too: 14.28 -> 14.10 ms on
+# top of the above), "proj" = after the projector backward (A/B)
+_TAIL_FORK_EARLY = _os.environ.get("MMTG_WGRAD_TAIL_FORK", "loop") == "loop"
 _LMHEAD_GROUP = _os.environ.get("MMTG_LMHEAD_GROUP", "1") != "0"      # the tied embedding's weight gradient through the grouped kernel (A/B switch)
 _LMHEAD_GROUP_SPLITS = int(_os.environ.get("MMTG_LMHEAD_GROUP_SPLITS", "0"))
 # the grouped weight-gradient launches on a SIDE stream, one block behind the dgrad chain (MMTG_WGRAD_STREAM; see Engine.backward)
@@ -1506,6 +1509,8 @@ class Engine:
         #  in one launch, here, with the embedding / projector / encoder backward still to come behind it)
         self._flush_sums()
         self._defer = False
+        if _TAIL_FORK_EARLY:            # (fork here: beside the embedding / projector backward too; MMTG_WGRAD_TAIL_FORK=proj: after the projector)
+            self._launch_tail_jobs()
         # ---- GPT-2 input embedding: h0 = drop(g + wpe + wte[type])
         nty = min(32, sh.V)
         hip.embed_add_bwd(dx, a["type_ids"], self.G(pre + "wpe.weight"), self.G(pre + "wte.weight"), M, T, D,
@@ -1526,9 +1531,10 @@ class Engine:
             psplits = _group_splits_x3(ptiles, M)
             _, pnws, pncnt = hip.wgrad_group_sizes(pshapes, psplits, 0)
             pws = self.buf("wgrad_group_ws_proj", (pnws,), torch.float32) if psplits > 1 else None
-            pcnt = self.ws.get(("wgrad_group_cnt", torch.int32))
+            # (counters of its own: the blocks' deferred launches may be running on the side stream by now -- _WGRAD_TAIL)
+            pcnt = self.ws.get(("wgrad_group_cnt_proj", torch.int32))
             if pcnt is None or pcnt.numel() < pncnt:
-                pcnt = self.ws[("wgrad_group_cnt", torch.int32)] = torch.zeros(pncnt, device=self.dev, dtype=torch.int32)
+                pcnt = self.ws[("wgrad_group_cnt_proj", torch.int32)] = torch.zeros(pncnt, device=self.dev, dtype=torch.int32)
             pkeys = ("decoder.projector_layer2.weight", "decoder.projector_layer1.weight")
             for k in pkeys:      # (tensors the lazy zero_grad skipped are overwritten below; otherwise accumulate as ever)
                 if self._lazy is not None and (self.layout.entries[k][0], self.layout.entries[k][2]) in self._lazy and not self.wgrad_overwrite:
@@ -1559,22 +1565,27 @@ class Engine:
             hip.colsum(dh1, M, H, self.G("decoder.projector_layer1.bias"))      # (the weight gradient went with W2's above)
         else:
             self._wgrad(a["x"], dh1, "decoder.projector_layer1.weight", "decoder.projector_layer1.bias", M, "linear")
-        if self._tail_jobs:
-            # the deferred blocks' grouped weight gradients, in block order on ONE side stream (they share a workspace and counters; the
-            # inline launches are complete by now): behind everything enqueued so far, beside the fuser / encoder backward that follows
-            if _os.environ.get("MMTG_WGRAD_TAIL_MAIN"):          # (A/B: the same launches on the main stream, no overlap with the tail)
-                for probs, m_, gs_, gws_, gcnt_, acc_, cfg_ in self._tail_jobs:
-                    hip.wgrad_group(probs, m_, gs_, gws_, gcnt_, accumulate=acc_, config=cfg_)
-                self._tail_jobs = []
-                return seg
-            side = self._side_stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for probs, m_, gs_, gws_, gcnt_, acc_, cfg_ in self._tail_jobs:
-                    hip.wgrad_group(probs, m_, gs_, gws_, gcnt_, accumulate=acc_, config=cfg_)
-            self._tail_jobs = []
-            self._tail_side = side
+        if not _TAIL_FORK_EARLY:
+            self._launch_tail_jobs()
         return seg
+
+    def _launch_tail_jobs(self):
+        """The deferred blocks' grouped weight gradients, in block order on ONE side stream (they share a workspace and counters; the
+        in-loop launches are complete by now): behind everything enqueued so far, beside what the main stream enqueues next."""
+        if not self._tail_jobs:
+            return
+        if _os.environ.get("MMTG_WGRAD_TAIL_MAIN"):          # (A/B: the same launches on the main stream, no overlap with the tail)
+            for probs, m_, gs_, gws_, gcnt_, acc_, cfg_ in self._tail_jobs:
+                hip.wgrad_group(probs, m_, gs_, gws_, gcnt_, accumulate=acc_, config=cfg_)
+            self._tail_jobs = []
+            return
+        side = self._side_stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for probs, m_, gs_, gws_, gcnt_, acc_, cfg_ in self._tail_jobs:
+                hip.wgrad_group(probs, m_, gs_, gws_, gcnt_, accumulate=acc_, config=cfg_)
+        self._tail_jobs = []
+        self._tail_side = side
 
     def _backward_encoder(self, a, seg, dkl):
         """d c = seg W1 -> beta fuser -> alpha attention + LayerNorm + recurrent channels -> topic channel."""
